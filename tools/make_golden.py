@@ -1,0 +1,145 @@
+"""Generate tests/golden/*.npz by running the reference's own functions (build container only).
+
+    python tools/make_golden.py            # (re)writes every fixture
+    python tools/make_golden.py --time     # also times the reference's Python path
+
+Each fixture holds the *inputs* (reference contigs + SoA batch columns + parameters) and the
+*expected outputs* produced by /root/reference/mapdamage (dense tables in the canonical layout
+of mapdamage_amd/layout.py, the sparse length histogram, and the three text files byte for
+byte).  Fixtures are data; no reference source is stored.
+"""
+
+import argparse
+import json
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from mapdamage_amd import synth  # noqa: E402
+from mapdamage_amd.batch import Reference, batch_from_records  # noqa: E402
+from tools import ref_harness  # noqa: E402
+
+GOLDEN = ROOT / "tests" / "golden"
+
+LIBS2 = [("Zed", "libB"), ("Alpha", "libA")]   # sorted order differs from header order
+LIBS1 = [("Sample1", "Lib1")]
+MERGED = [("*", "*")]
+
+
+def save_case(name, ref, batch, libraries, length, around, minqual, per_read=False, note=""):
+    t0 = time.perf_counter()
+    res = ref_harness.run_reference(ref, batch, libraries, length, around, minqual,
+                                    per_read=per_read)
+    dt = time.perf_counter() - t0
+    libs, mis, comp, lgd = ref_harness.dense_tables(res, libraries, length, around)
+    meta = dict(name=name, length=length, around=around, minqual=minqual,
+                libraries=[list(x) for x in libraries], sorted_libraries=[list(x) for x in libs],
+                contig_names=ref.names, n_reads=batch.n, n_kept=res["n_kept"], note=note,
+                generator="tools/make_golden.py", reference="ginolhac/mapDamage 2.3.0a0 @2024_10_08")
+    arrays = dict(
+        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+        ref_bases=np.frombuffer(b"".join(ref.seqs), dtype=np.uint8),
+        ref_lengths=np.asarray(ref.lengths, dtype=np.int64),
+        flag=batch.flag, lib=batch.lib, tid=batch.tid, pos=batch.pos, tlen=batch.tlen,
+        cigar_off=batch.cigar_off, cigar=batch.cigar, seq_off=batch.seq_off, seq=batch.seq,
+        mis=mis, comp=comp, lgd=lgd,
+        txt_mis=np.frombuffer(res["texts"]["misincorporation.txt"].encode(), dtype=np.uint8),
+        txt_comp=np.frombuffer(res["texts"]["dnacomp.txt"].encode(), dtype=np.uint8),
+        txt_lgd=np.frombuffer(res["texts"]["lgdistribution.txt"].encode(), dtype=np.uint8),
+    )
+    if batch.qual is not None:
+        arrays["qual"] = batch.qual
+    if per_read:
+        arrays["per_read"] = np.frombuffer(json.dumps(res["per_read"]).encode(), dtype=np.uint8)
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(GOLDEN / (name + ".npz"), **arrays)
+    print("%-28s reads=%6d kept=%6d  mis_sum=%d  %.2fs" % (name, batch.n, res["n_kept"],
+                                                           int(mis.sum()), dt))
+    return res
+
+
+def appendix_d_case():
+    """The ten hand vectors of SURVEY.md Appendix D on the 60-base genome ``c``."""
+    c = b"ACGTACGTTGCAAGGCTTAACCGGTTACGATCGATCGGGATATCCGCGATATAGCTAGCT"
+    ref = Reference(["c"], [c])
+    M, I, D, N, S, H = 0, 1, 2, 3, 4, 5
+    R = 0x10
+    recs = [
+        dict(flag=0, tid=0, pos=1, cigar=[(M, 10)], seq="TGTACGTTGC"),
+        dict(flag=R, tid=0, pos=1, cigar=[(M, 10)], seq="CGTACGTTGC"),
+        dict(flag=0, tid=0, pos=4, cigar=[(S, 2), (M, 8), (S, 3)], seq="GGACGTTGCATTT"),
+        dict(flag=0, tid=0, pos=0, cigar=[(M, 4), (N, 5), (M, 4)], seq="ACGTGCAA"),
+        dict(flag=0, tid=0, pos=0, cigar=[(M, 3), (I, 2), (M, 3), (D, 1), (M, 2)], seq="ACGGGTACTT"),
+        dict(flag=0, tid=0, pos=0, cigar=[(M, 6)], seq="ACGTAC"),
+        dict(flag=0, tid=0, pos=54, cigar=[(M, 6)], seq="CTAGCT"),
+        dict(flag=0, tid=0, pos=0, cigar=[(M, 3), (I, 1), (M, 3)], seq="ACGTTAC",
+             qual=[40, 40, 2, 40, 2, 40, 40]),
+        dict(flag=0, tid=0, pos=0, cigar=[(M, 6)], seq="ANGTRC"),
+        dict(flag=0, tid=0, pos=0, cigar=[(H, 2), (M, 6)], seq="ACGTAC"),
+        dict(flag=0, tid=0, pos=0, cigar=[(I, 2), (M, 6)], seq="TTACGTAC"),
+        dict(flag=R, tid=0, pos=10, cigar=[(S, 1), (M, 5), (I, 1), (M, 4), (D, 2), (M, 3), (S, 2)],
+             seq="GCAAGGTCTTAACGTT"),
+    ]
+    for r in recs:
+        r.setdefault("qual", None)
+        r.setdefault("lib", 0)
+        r.setdefault("tlen", 0)
+    return ref, batch_from_records(recs, with_qual=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--time", action="store_true")
+    args = ap.parse_args()
+
+    # Appendix D hand vectors, tiny windows, with per-read gapped strings
+    ref, batch = appendix_d_case()
+    save_case("appendixD_L8_A3_Q0", ref, batch, LIBS1, 8, 3, 0, per_read=True)
+    save_case("appendixD_L8_A3_Q20", ref, batch, LIBS1, 8, 3, 20, per_read=True)
+
+    # edge set on the small genome, small and default windows, with/without -Q
+    sref = synth.small_genome()
+    edge = synth.make_edge_reads(sref, with_qual=True, nlib=2)
+    save_case("edge_L8_A3_Q0", sref, edge, LIBS2, 8, 3, 0, per_read=True)
+    save_case("edge_L8_A3_Q25", sref, edge, LIBS2, 8, 3, 25, per_read=True)
+    save_case("edge_L70_A10_Q0", sref, edge, LIBS2, 70, 10, 0)
+    save_case("edge_L1_A0_Q0", sref, edge, LIBS2, 1, 0, 0)
+    save_case("edge_L200_A25_Q10", sref, edge, LIBS2, 200, 25, 10)
+
+    # config 1 (BASELINE configs[0]): ~1k mixed reads + edge set, two libraries
+    sref, c1 = synth.config1_batch()
+    save_case("config1_L70_A10_Q0", sref, c1, LIBS2, 70, 10, 0)
+    save_case("config1_L70_A10_Q20", sref, c1, LIBS2, 70, 10, 20)
+    merged = c1.slice(0, c1.n)
+    merged.lib[:] = 0
+    save_case("config1_merged_L70_A10_Q0", sref, merged, MERGED, 70, 10, 0,
+              note="--merge-libraries: every read maps to ('*','*') (reader.py:44-46)")
+    same = c1.slice(0, c1.n)
+    save_case("config1_samelib_L25_A5_Q0", sref, same, [("S", "L"), ("S", "L")], 25, 5, 0,
+              note="two read groups naming the same (SM, LB): one library (reader.py:47-50)")
+
+    # config 2/3/4-style samples on a mid-size genome
+    mref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)),
+                             n_run=500, lower_run=3000)
+    save_case("config2s_L70_A10", mref, synth.config2_batch(mref, 4000, seed=2), LIBS1, 70, 10, 0)
+    save_case("config3s_L70_A10", mref, synth.config3_batch(mref, 4000, seed=3), LIBS1, 70, 10, 0)
+    save_case("config3s_L70_A10_Q15", mref, synth.config3_batch(mref, 3000, seed=33, with_qual=True),
+              LIBS1, 70, 10, 15)
+    save_case("config4s_L70_A10", mref, synth.config4_batch(mref, 4000, seed=4), LIBS1, 70, 10, 0)
+
+    if args.time:
+        big = synth.config2_batch(mref, 100_000, seed=2)
+        t0 = time.perf_counter()
+        res = ref_harness.run_reference(mref, big, LIBS1, 70, 10, 0)
+        dt = time.perf_counter() - t0
+        print("reference python path: %d reads in %.2fs = %.0f reads/s (1 core)" %
+              (res["n_kept"], dt, res["n_kept"] / dt))
+
+
+if __name__ == "__main__":
+    main()
