@@ -1,0 +1,136 @@
+/*
+ * mdx.h — C ABI of libmdx.so, the MI355X-native damage-tabulation engine.
+ *
+ * The reference (ginolhac/mapDamage) has no FFI/plugin interface for this path; its seam is
+ * the set of accumulator objects created in mapdamage/main.py:147-155 and the loop body
+ * main.py:165-217 that feeds them.  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Threading: one host thread drives one context; contexts are independent (one per GPU).
+ * All work is enqueued on the context's HIP stream (mdx_set_stream lets the caller share a
+ * stream with e.g. PyTorch); calls return after enqueueing unless stated otherwise.
+ * Ownership: the caller owns every buffer it passes in; device memory allocated by the
+ * library is released by mdx_destroy / mdx_batch_free.
+ * Errors: functions return 0 (MDX_OK) or a negative code; mdx_last_error() gives text.
+ */
+#ifndef MDX_H
+#define MDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_ABI_VERSION 1
+
+#define MDX_OK 0
+#define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
+#define MDX_ERR_HIP (-2)          /* HIP runtime failure */
+#define MDX_ERR_STATE (-3)        /* call order violated (e.g. tabulate before set_reference) */
+#define MDX_ERR_MASK_INDEX (-4)   /* align.py:69-71 IndexError (kept for ABI completeness) */
+#define MDX_ERR_LGD_OVERFLOW (-5) /* more out-of-range fragment lengths than lgd_over_cap */
+#define MDX_ERR_BAD_READ (-6)     /* record the reference cannot process: alignment past the
+                                     contig end (pysam ValueError from align.py:33 / main.py:180),
+                                     tid/library out of range, CIGAR/SEQ length mismatch */
+
+#define MDX_N_MIS_COLS 25         /* mapdamage/seq.py:6-30 without the derived "Total" */
+
+typedef struct mdx_ctx mdx_ctx;
+
+/* Per-run options: --length/--around/--min-basequal (mapdamage/config.py:143-166) and the
+ * number of libraries (mapdamage/reader.py:47-50; 1 with --merge-libraries, reader.py:44-46). */
+typedef struct {
+    int32_t length;        /* L >= 1 */
+    int32_t around;        /* A >= 0 */
+    int32_t minqual;       /* 0..93; 0 disables masking */
+    int32_t nlib;          /* >= 1 */
+    int32_t lgd_max;       /* dense fragment-length histogram covers [0, lgd_max) */
+    int32_t device;        /* HIP device ordinal */
+    int64_t lgd_over_cap;  /* capacity (records) of the out-of-range length list */
+} mdx_config;
+
+/* One batch of alignment records as SoA columns: exactly what main.py:165-217 reads from each
+ * pysam.AlignedSegment.  `seq` is the full SEQ (soft clips included); `qual`
+ * raw Phred (BAM convention, first byte 0xFF = absent) or NULL; `cigar` BAM-encoded len<<4|op. */
+typedef struct {
+    int64_t n_reads;
+    int64_t n_cigar;       /* == cigar_off[n_reads] */
+    int64_t n_bases;       /* == seq_off[n_reads]   */
+    const uint16_t *flag;
+    const uint16_t *lib;
+    const int32_t *tid;
+    const int32_t *pos;
+    const int32_t *tlen;
+    const uint32_t *cigar_off; /* n_reads + 1 */
+    const uint32_t *cigar;
+    const uint32_t *seq_off;   /* n_reads + 1 */
+    const uint8_t *seq;
+    const uint8_t *qual;       /* may be NULL */
+} mdx_batch;
+
+int mdx_abi_version(void);
+const char *mdx_strerror(int code);
+
+/* Replaces the construction of MisincorporationRates / DNAComposition / FragmentLengths
+ * (mapdamage/main.py:147-155, statistics.py:10-20,59-73,107-115): zeroed device accumulators. */
+int mdx_create(const mdx_config *cfg, mdx_ctx **out);
+void mdx_destroy(mdx_ctx *ctx);
+const char *mdx_last_error(const mdx_ctx *ctx);
+
+/* Use `hip_stream` (a hipStream_t) for all subsequent work; NULL = the context's own stream. */
+int mdx_set_stream(mdx_ctx *ctx, void *hip_stream);
+
+/* Replaces pysam.FastaFile(options.ref) + the per-read ref.fetch(...).upper() calls
+ * (main.py:115,180; align.py:32-33): uploads the contigs (original FASTA bytes, BAM tid order,
+ * contig i = bases[contig_off[i] .. contig_off[i+1])) once and keeps them resident in HBM,
+ * case-folded and symbol-classified by a device kernel.  Host pointers. */
+int mdx_set_reference(mdx_ctx *ctx, const uint8_t *bases, const int64_t *contig_off, int32_t n_contig);
+
+/* Copies a host batch into device memory owned by the library (for resident/benchmark use).
+ * `dev` receives device pointers; release with mdx_batch_free. */
+int mdx_batch_upload(mdx_ctx *ctx, const mdx_batch *host, mdx_batch *dev);
+int mdx_batch_free(mdx_ctx *ctx, mdx_batch *dev);
+
+/* Replaces the loop body main.py:165-217 for every record of the batch: flag filter
+ * (reader.py:121-132), coordinates/flanks (align.py:14-35), CIGAR gapping with optional
+ * quality masking (align.py:38-88), strand step (main.py:200-205), and the accumulator
+ * updates (statistics.py:22-51,75-93,117-126).  Accumulates; may be called repeatedly.
+ * _host: columns in host memory (staged H2D on the stream); _device: columns already in HBM. */
+int mdx_tabulate_host(mdx_ctx *ctx, const mdx_batch *batch);
+int mdx_tabulate_device(mdx_ctx *ctx, const mdx_batch *batch);
+
+/* Waits for the stream and reports deferred per-read errors (MDX_ERR_BAD_READ ...);
+ * *bad_read (may be NULL) receives the index of the first offending record of its batch. */
+int mdx_sync(mdx_ctx *ctx, int64_t *bad_read);
+
+/* Number of uint64 words of the packed canonical table block written by mdx_finish_device:
+ * [ mis nlib*2*2*L*25 | comp nlib*2*2*(L+A)*4 | lgd nlib*2*2*lgd_max | n_kept | n_lgd_over ]. */
+int64_t mdx_table_words(const mdx_ctx *ctx);
+
+/* Writes the canonical tables (layout: mapdamage_amd/layout.py) into a *device* buffer of
+ * mdx_table_words() uint64 — the buffer a caller all-reduces (RCCL, sum) across GPUs. */
+int mdx_finish_device(mdx_ctx *ctx, uint64_t *d_tables);
+
+/* Replaces reading the `.data` dicts before `.write()` (main.py:229-231): synchronises and
+ * copies the canonical tables to host memory.  lgd_over receives (lib, kind, strand, length)
+ * quadruples for lengths >= lgd_max (at most lgd_over_cap); any pointer may be NULL. */
+int mdx_finish(mdx_ctx *ctx, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t *lgd_over,
+               int64_t lgd_over_cap, int64_t *n_lgd_over, int64_t *n_kept);
+
+/* Zero all accumulators (new run with the same options and reference). */
+int mdx_reset(mdx_ctx *ctx);
+
+/* Kernel timing with HIP events recorded on the launch stream around the tabulation kernel.
+ * mdx_timing_read synchronises, returns the number of timed launches and their summed
+ * duration since the last call, and clears the record. */
+int mdx_timing_enable(mdx_ctx *ctx, int enable);
+int mdx_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
+
+/* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
+int mdx_table_mode(const mdx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H */

@@ -1,0 +1,47 @@
+"""Builds libmdx.so (HIP kernels + C-ABI) for gfx950 in-tree with hipcc."""
+
+import os
+import pathlib
+import shutil
+import subprocess
+
+HERE = pathlib.Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "libmdx.so"
+SOURCES = ["mdx_kernels.hip", "mdx_capi.cpp"]
+HEADERS = [CSRC / "mdx_internal.h", HERE.parent / "include" / "mdx.h"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP extension cannot be built")
+    return exe
+
+
+def needs_build():
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + HEADERS
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build_lib(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-x", "hip", "-Wall", "-Wno-unused-function"]
+    cmd += list(extra_flags)
+    cmd += [str(CSRC / s) for s in SOURCES]
+    cmd += ["-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    build_lib(force=True, verbose=True, extra_flags=sys.argv[1:])
+    print("built", LIB)

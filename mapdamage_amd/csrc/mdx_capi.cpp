@@ -1,0 +1,432 @@
+// C-ABI layer of libmdx.so (declared in include/mdx.h): context, device memory, launches.
+// No torch, no C++ types across the boundary, no exceptions escape.
+#include "../../include/mdx.h"
+#include "mdx_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU
+constexpr int kLgdLds = 512;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct mdx_ctx {
+    mdx_config cfg{};
+    MdxDims dims{};
+    int mode = MDX_MODE_LDS;
+    int n_cu = 256;
+    int max_grid = 0;
+    size_t lds_bytes = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // reference
+    uint8_t *d_ref = nullptr;
+    int64_t *d_contig_off = nullptr;
+    int n_contig = 0;
+    int64_t ref_len = 0;
+    // accumulators
+    unsigned long long *d_raw = nullptr;
+    unsigned long long *d_lgd_dense = nullptr;
+    long long *d_lgd_over = nullptr;
+    unsigned long long *d_n_lgd_over = nullptr;
+    unsigned long long *d_err = nullptr;
+    uint32_t *d_partials = nullptr;
+    // staging for mdx_tabulate_host
+    DevBuf st[10];
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::string err;
+};
+
+namespace {
+
+int fail(mdx_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((ctx), MDX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int64_t lgd_words(const mdx_ctx *c) { return (int64_t)c->cfg.nlib * 4 * c->cfg.lgd_max; }
+int64_t mis_words(const mdx_ctx *c) { return (int64_t)c->cfg.nlib * 4 * c->cfg.length * MDX_N_MIS_COLS; }
+int64_t comp_words(const mdx_ctx *c) { return (int64_t)c->cfg.nlib * 4 * (c->cfg.length + c->cfg.around) * 4; }
+
+int zero_accumulators(mdx_ctx *c) {
+    HIP_TRY(c, hipMemsetAsync(c->d_raw, 0, (size_t)c->dims.w_total * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_lgd_dense, 0, (size_t)lgd_words(c) * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_n_lgd_over, 0, 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, 8, c->stream));
+    return MDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_abi_version(void) { return MDX_ABI_VERSION; }
+
+const char *mdx_strerror(int code) {
+    switch (code) {
+        case MDX_OK: return "ok";
+        case MDX_ERR_ARG: return "invalid argument";
+        case MDX_ERR_HIP: return "HIP runtime error";
+        case MDX_ERR_STATE: return "invalid call order";
+        case MDX_ERR_MASK_INDEX: return "masked column beyond gapped reference";
+        case MDX_ERR_LGD_OVERFLOW: return "fragment-length overflow list full";
+        case MDX_ERR_BAD_READ: return "record cannot be processed (alignment past contig end, bad tid/library, CIGAR/SEQ mismatch)";
+    }
+    return "unknown error";
+}
+
+int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
+    if (!cfg || !out) return MDX_ERR_ARG;
+    *out = nullptr;
+    if (cfg->length < 1 || cfg->around < 0 || cfg->minqual < 0 || cfg->minqual > 93 || cfg->nlib < 1 ||
+        cfg->nlib > 65535 || cfg->lgd_max < 1 || cfg->lgd_over_cap < 0)
+        return MDX_ERR_ARG;
+    mdx_ctx *c = new (std::nothrow) mdx_ctx();
+    if (!c) return MDX_ERR_ARG;
+    c->cfg = *cfg;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        delete c;
+        return MDX_ERR_HIP;
+    }
+    *out = c;  // from here on the caller destroys it, also on error (mdx_last_error stays readable)
+    HIP_TRY(c, hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, cfg->device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+
+    const int lgd_lds = cfg->lgd_max < kLgdLds ? cfg->lgd_max : kLgdLds;
+    if ((int64_t)cfg->nlib * (4LL * cfg->length * 25 + 4LL * (cfg->length + cfg->around) * 4 + 16LL * cfg->length +
+                              4LL * lgd_lds) > 0x7FFFFFF0LL)
+        return fail(c, MDX_ERR_ARG, "table too large (nlib * length)");
+    c->dims = mdx_make_dims(cfg->length, cfg->around, cfg->nlib, cfg->lgd_max, lgd_lds);
+    c->lds_bytes = mdx_k_lds_bytes(c->dims);
+    if (c->lds_bytes <= kLdsLimit) {
+        c->mode = MDX_MODE_LDS;
+        int per_cu = (int)(kLdsLimit / c->lds_bytes);
+        const int by_threads = 2048 / mdx_k_block_threads();
+        if (per_cu > by_threads) per_cu = by_threads;
+        c->max_grid = c->n_cu * per_cu;
+        HIP_TRY(c, mdx_k_prepare(c->lds_bytes));
+        HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * c->dims.w_total * 4));
+    } else {
+        c->mode = MDX_MODE_GLOBAL;  // tables do not fit the LDS: global-atomic fallback
+        c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
+    }
+    HIP_TRY(c, hipMalloc((void **)&c->d_raw, (size_t)c->dims.w_total * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_lgd_dense, (size_t)lgd_words(c) * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_lgd_over, (size_t)(cfg->lgd_over_cap > 0 ? cfg->lgd_over_cap : 1) * 32));
+    HIP_TRY(c, hipMalloc((void **)&c->d_n_lgd_over, 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_err, 8));
+    int rc = zero_accumulators(c);
+    if (rc != MDX_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MDX_OK;
+}
+
+void mdx_destroy(mdx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &b : c->st) b.release();
+    void *ptrs[] = {c->d_ref, c->d_contig_off, c->d_raw, c->d_lgd_dense, c->d_lgd_over,
+                    c->d_n_lgd_over, c->d_err, c->d_partials};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *mdx_last_error(const mdx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int mdx_set_stream(mdx_ctx *c, void *hip_stream) {
+    if (!c) return MDX_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return MDX_OK;
+}
+
+int mdx_set_reference(mdx_ctx *c, const uint8_t *bases, const int64_t *contig_off, int32_t n_contig) {
+    if (!c || !contig_off || n_contig < 1) return fail(c, MDX_ERR_ARG, "set_reference: bad arguments");
+    for (int i = 0; i < n_contig; i++)
+        if (contig_off[i + 1] < contig_off[i]) return fail(c, MDX_ERR_ARG, "contig_off not monotone");
+    const int64_t n = contig_off[n_contig];
+    if (contig_off[0] != 0 || (n > 0 && !bases)) return fail(c, MDX_ERR_ARG, "set_reference: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_ref) { (void)hipFree(c->d_ref); c->d_ref = nullptr; }
+    if (c->d_contig_off) { (void)hipFree(c->d_contig_off); c->d_contig_off = nullptr; }
+    // a guard band on both sides keeps speculative flank addresses inside the allocation
+    const size_t pad = 256;
+    uint8_t *tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&tmp, (size_t)n + 1));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ref, (size_t)n + 2 * pad));
+    HIP_TRY(c, hipMalloc((void **)&c->d_contig_off, (size_t)(n_contig + 1) * 8));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref, 5, (size_t)n + 2 * pad, c->stream));
+    if (n > 0) HIP_TRY(c, hipMemcpyAsync(tmp, bases, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_contig_off, contig_off, (size_t)(n_contig + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    mdx_k_encode_ref(tmp, c->d_ref + pad, n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+    c->n_contig = n_contig;
+    c->ref_len = n;
+    return MDX_OK;
+}
+
+static int check_batch(mdx_ctx *c, const mdx_batch *b) {
+    if (!c || !b) return MDX_ERR_ARG;
+    if (b->n_reads < 0 || b->n_cigar < 0 || b->n_bases < 0) return fail(c, MDX_ERR_ARG, "negative batch size");
+    if (b->n_bases > 0xFFFFFFFFLL || b->n_cigar > 0xFFFFFFFFLL)
+        return fail(c, MDX_ERR_ARG, "batch exceeds 32-bit offsets; split it");
+    if (b->n_reads > 0 && (!b->flag || !b->lib || !b->tid || !b->pos || !b->tlen || !b->cigar_off || !b->seq_off))
+        return fail(c, MDX_ERR_ARG, "null column");
+    if ((b->n_cigar > 0 && !b->cigar) || (b->n_bases > 0 && !b->seq)) return fail(c, MDX_ERR_ARG, "null column");
+    return MDX_OK;
+}
+
+int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
+    int rc = check_batch(c, h);
+    if (rc != MDX_OK) return rc;
+    if (!dv) return MDX_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    std::memset(dv, 0, sizeof(*dv));
+    dv->n_reads = h->n_reads; dv->n_cigar = h->n_cigar; dv->n_bases = h->n_bases;
+    const int64_t n = h->n_reads;
+    struct Col { const void *src; const void **dst; size_t bytes; } cols[] = {
+        {h->flag, (const void **)&dv->flag, (size_t)n * 2},
+        {h->lib, (const void **)&dv->lib, (size_t)n * 2},
+        {h->tid, (const void **)&dv->tid, (size_t)n * 4},
+        {h->pos, (const void **)&dv->pos, (size_t)n * 4},
+        {h->tlen, (const void **)&dv->tlen, (size_t)n * 4},
+        {h->cigar_off, (const void **)&dv->cigar_off, (size_t)(n + 1) * 4},
+        {h->cigar, (const void **)&dv->cigar, (size_t)h->n_cigar * 4},
+        {h->seq_off, (const void **)&dv->seq_off, (size_t)(n + 1) * 4},
+        {h->seq, (const void **)&dv->seq, (size_t)h->n_bases},
+        {h->qual, (const void **)&dv->qual, h->qual ? (size_t)h->n_bases : 0},
+    };
+    for (auto &col : cols) {
+        if (!col.src || n == 0) continue;
+        void *p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, col.bytes + 64));
+        *col.dst = p;
+        HIP_TRY(c, hipMemcpyAsync(p, col.src, col.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MDX_OK;
+}
+
+int mdx_batch_free(mdx_ctx *c, mdx_batch *dv) {
+    if (!c || !dv) return MDX_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const void *ptrs[] = {dv->flag, dv->lib, dv->tid, dv->pos, dv->tlen, dv->cigar_off,
+                          dv->cigar, dv->seq_off, dv->seq, dv->qual};
+    for (const void *p : ptrs) if (p) (void)hipFree(const_cast<void *>(p));
+    std::memset(dv, 0, sizeof(*dv));
+    return MDX_OK;
+}
+
+int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
+    int rc = check_batch(c, b);
+    if (rc != MDX_OK) return rc;
+    if (!c->d_ref) return fail(c, MDX_ERR_STATE, "mdx_set_reference has not been called");
+    if (b->n_reads == 0) return MDX_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    MdxTabArgs a{};
+    a.n_reads = b->n_reads;
+    a.flag = b->flag; a.lib = b->lib; a.tid = b->tid; a.pos = b->pos; a.tlen = b->tlen;
+    a.cigar_off = b->cigar_off; a.cigar = b->cigar; a.seq_off = b->seq_off; a.seq = b->seq; a.qual = b->qual;
+    a.ref = c->d_ref + 256;
+    a.contig_off = c->d_contig_off;
+    a.n_contig = c->n_contig;
+    a.minqual = c->cfg.minqual;
+    a.dims = c->dims;
+    a.partials = c->d_partials;
+    a.raw = c->d_raw;
+    a.lgd_dense = c->d_lgd_dense;
+    a.lgd_over = c->d_lgd_over;
+    a.lgd_over_cap = c->cfg.lgd_over_cap;
+    a.n_lgd_over = c->d_n_lgd_over;
+    a.err = c->d_err;
+    const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
+    const int wpb = mdx_k_block_threads() / 64;
+    const int64_t ntiles = (b->n_reads + 63) / 64;
+    int64_t want = (ntiles + wpb - 1) / wpb;
+    const int grid = (int)(want < c->max_grid ? want : c->max_grid);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        HIP_TRY(c, hipEventCreate(&e0));
+        HIP_TRY(c, hipEventCreate(&e1));
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
+    mdx_k_tabulate(a, c->mode, mask, grid, c->mode == MDX_MODE_LDS ? c->lds_bytes : 0, c->stream);
+    if (c->timing) {
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        c->events.emplace_back(e0, e1);
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (c->mode == MDX_MODE_LDS) {
+        mdx_k_reduce_partials(c->d_partials, c->d_raw, c->dims.w_total, grid, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return MDX_OK;
+}
+
+int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
+    int rc = check_batch(c, h);
+    if (rc != MDX_OK) return rc;
+    if (h->n_reads == 0) return MDX_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int64_t n = h->n_reads;
+    const void *src[10] = {h->flag, h->lib, h->tid, h->pos, h->tlen, h->cigar_off, h->cigar, h->seq_off, h->seq, h->qual};
+    const size_t bytes[10] = {(size_t)n * 2, (size_t)n * 2, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4,
+                              (size_t)(n + 1) * 4, (size_t)h->n_cigar * 4, (size_t)(n + 1) * 4,
+                              (size_t)h->n_bases, h->qual ? (size_t)h->n_bases : 0};
+    // the staging buffers may still be read by the previous batch's kernel
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 10; i++) {
+        if (!src[i] || bytes[i] == 0) continue;
+        HIP_TRY(c, c->st[i].reserve(bytes[i] + 64));
+        HIP_TRY(c, hipMemcpyAsync(c->st[i].p, src[i], bytes[i], hipMemcpyHostToDevice, c->stream));
+    }
+    mdx_batch dv = *h;
+    dv.flag = (const uint16_t *)c->st[0].p; dv.lib = (const uint16_t *)c->st[1].p;
+    dv.tid = (const int32_t *)c->st[2].p; dv.pos = (const int32_t *)c->st[3].p;
+    dv.tlen = (const int32_t *)c->st[4].p; dv.cigar_off = (const uint32_t *)c->st[5].p;
+    dv.cigar = (const uint32_t *)c->st[6].p; dv.seq_off = (const uint32_t *)c->st[7].p;
+    dv.seq = (const uint8_t *)c->st[8].p; dv.qual = h->qual ? (const uint8_t *)c->st[9].p : nullptr;
+    return mdx_tabulate_device(c, &dv);
+}
+
+int mdx_sync(mdx_ctx *c, int64_t *bad_read) {
+    if (!c) return MDX_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long err = 0, nover = 0;
+    HIP_TRY(c, hipMemcpy(&err, c->d_err, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&nover, c->d_n_lgd_over, 8, hipMemcpyDeviceToHost));
+    if (err != ~0ull) {
+        if (bad_read) *bad_read = (int64_t)(err >> 8);
+        const int code = -(int)(err & 0xFF);
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "record %lld of its batch: %s", (long long)(err >> 8), mdx_strerror(code));
+        return fail(c, code, msg);
+    }
+    if ((int64_t)nover > c->cfg.lgd_over_cap) return fail(c, MDX_ERR_LGD_OVERFLOW, mdx_strerror(MDX_ERR_LGD_OVERFLOW));
+    return MDX_OK;
+}
+
+int64_t mdx_table_words(const mdx_ctx *c) {
+    if (!c) return 0;
+    return mis_words(c) + comp_words(c) + lgd_words(c) + 2;
+}
+
+int mdx_finish_device(mdx_ctx *c, uint64_t *d_tables) {
+    if (!c || !d_tables) return MDX_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    mdx_k_finalize(c->d_raw, c->d_lgd_dense, c->d_n_lgd_over, c->dims, (unsigned long long *)d_tables, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_finish(mdx_ctx *c, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t *lgd_over,
+               int64_t lgd_over_cap, int64_t *n_lgd_over, int64_t *n_kept) {
+    if (!c) return MDX_ERR_ARG;
+    int rc = mdx_sync(c, nullptr);
+    if (rc != MDX_OK) return rc;
+    const int64_t words = mdx_table_words(c);
+    uint64_t *d = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d, (size_t)words * 8));
+    rc = mdx_finish_device(c, d);
+    if (rc == MDX_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        const int64_t nm = mis_words(c), nc = comp_words(c), nl = lgd_words(c);
+        if (e == hipSuccess && mis) e = hipMemcpy(mis, d, (size_t)nm * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && comp) e = hipMemcpy(comp, d + nm, (size_t)nc * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && lgd) e = hipMemcpy(lgd, d + nm + nc, (size_t)nl * 8, hipMemcpyDeviceToHost);
+        uint64_t tail[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(tail, d + nm + nc + nl, 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            if (n_kept) *n_kept = (int64_t)tail[0];
+            int64_t nov = (int64_t)tail[1];
+            if (n_lgd_over) *n_lgd_over = nov;
+            if (lgd_over && nov > 0) {
+                if (nov > lgd_over_cap) nov = lgd_over_cap;
+                e = hipMemcpy(lgd_over, c->d_lgd_over, (size_t)nov * 32, hipMemcpyDeviceToHost);
+            }
+        }
+        if (e != hipSuccess) rc = fail(c, MDX_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int mdx_reset(mdx_ctx *c) {
+    if (!c) return MDX_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = zero_accumulators(c);
+    if (rc != MDX_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->err.clear();
+    return MDX_OK;
+}
+
+int mdx_timing_enable(mdx_ctx *c, int enable) {
+    if (!c) return MDX_ERR_ARG;
+    c->timing = enable != 0;
+    return MDX_OK;
+}
+
+int mdx_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
+    if (!c) return MDX_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    int64_t n = 0;
+    for (auto &ev : c->events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; n++; }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    c->events.clear();
+    if (n_launches) *n_launches = n;
+    if (total_ms) *total_ms = tot;
+    return MDX_OK;
+}
+
+int mdx_table_mode(const mdx_ctx *c) { return c ? c->mode : -1; }
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Internal interface between the C-ABI layer (mdx_capi.cpp) and the gfx950 kernels
+// (mdx_kernels.hip).  Not installed; the public boundary is include/mdx.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Raw (reference-orientation) accumulator layout, in words, per library:
+//   MIS [strand 2][side 2][L][25]      substitution / indel / soft-clip events + rare ref-base counts
+//   COMP[strand 2][side 2][L + A][4]   read-base (slots 0..L-1) and flank-base (slots L..L+A-1) counts
+//   M   [strand 2][side 2][L][4]       "read base == reference base == b" matches (the common case;
+//                                       contributes to both MIS[b] and COMP[b] at finalisation)
+//   LGD [kind 2][strand 2][lgd_lds]    short fragment lengths
+// followed, after the last library, by one word: number of kept reads.
+// side 0 = left-anchored (columns counted from the leftmost reference coordinate),
+// side 1 = right-anchored.  The canonical 5p/3p tables are a permutation of these
+// (strand '+': 5p = left, 3p = right; strand '-': swapped and complemented).
+struct MdxDims {
+    int L, A, nlib, lgd_max, lgd_lds;
+    int w_mis, w_comp, w_m, w_lgd, w_lib;
+    int64_t w_total;  // nlib * w_lib + 1
+    __host__ __device__ int off_comp() const { return w_mis; }
+    __host__ __device__ int off_m() const { return w_mis + w_comp; }
+    __host__ __device__ int off_lgd() const { return w_mis + w_comp + w_m; }
+};
+
+static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd_lds) {
+    MdxDims d;
+    d.L = L; d.A = A; d.nlib = nlib; d.lgd_max = lgd_max; d.lgd_lds = lgd_lds;
+    d.w_mis = 2 * 2 * L * 25;
+    d.w_comp = 2 * 2 * (L + A) * 4;
+    d.w_m = 2 * 2 * L * 4;
+    d.w_lgd = 2 * 2 * lgd_lds;
+    d.w_lib = d.w_mis + d.w_comp + d.w_m + d.w_lgd;
+    d.w_total = (int64_t)nlib * d.w_lib + 1;
+    return d;
+}
+
+struct MdxTabArgs {
+    // batch (device pointers)
+    int64_t n_reads;
+    const uint16_t *flag;
+    const uint16_t *lib;
+    const int32_t *tid;
+    const int32_t *pos;
+    const int32_t *tlen;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const uint32_t *seq_off;
+    const uint8_t *seq;
+    const uint8_t *qual;
+    // resident reference: one symbol class per base (0..3 ACGT, 4 '-', 5 other)
+    const uint8_t *ref;
+    const int64_t *contig_off;
+    int n_contig;
+    int minqual;
+    MdxDims dims;
+    // accumulators
+    uint32_t *partials;              // [grid][w_total] (LDS mode)
+    unsigned long long *raw;         // [w_total] u64 (global-atomic mode writes here directly)
+    unsigned long long *lgd_dense;   // [nlib][2][2][lgd_max]
+    long long *lgd_over;             // [cap][4]
+    long long lgd_over_cap;
+    unsigned long long *n_lgd_over;
+    unsigned long long *err;         // min over (read_index << 8 | -code); ~0 = no error
+};
+
+enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };
+
+int mdx_k_block_threads();
+size_t mdx_k_lds_bytes(const MdxDims &d);
+hipError_t mdx_k_prepare(size_t lds_bytes);
+void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
+void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
+void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, int64_t w_total, int grid,
+                           hipStream_t s);
+void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
+                    const unsigned long long *n_lgd_over, MdxDims d, unsigned long long *out,
+                    hipStream_t s);

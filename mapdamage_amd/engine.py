@@ -1,0 +1,273 @@
+"""ctypes binding of libmdx.so (include/mdx.h) — the product path.
+
+There is no CPU fallback here: if the HIP library is missing or no GPU is visible the
+constructor raises.  ``DamageEngine`` replaces the three accumulator objects the reference
+creates in mapdamage/main.py:147-155 and the loop body main.py:165-217 that feeds them.
+"""
+
+import ctypes
+import pathlib
+
+import numpy as np
+
+from . import layout as L
+from .batch import ReadBatch, Reference
+from .tables import TableSet
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_LIBPATH = _HERE / "libmdx.so"
+_lib = None
+
+EXPORTS = (
+    "mdx_abi_version", "mdx_strerror", "mdx_create", "mdx_destroy", "mdx_last_error",
+    "mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
+    "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_table_words",
+    "mdx_finish_device", "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
+    "mdx_table_mode",
+)
+
+
+class MdxConfig(ctypes.Structure):
+    _fields_ = [("length", ctypes.c_int32), ("around", ctypes.c_int32),
+                ("minqual", ctypes.c_int32), ("nlib", ctypes.c_int32),
+                ("lgd_max", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("lgd_over_cap", ctypes.c_int64)]
+
+
+class MdxBatch(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_int64), ("n_cigar", ctypes.c_int64),
+                ("n_bases", ctypes.c_int64),
+                ("flag", ctypes.c_void_p), ("lib", ctypes.c_void_p), ("tid", ctypes.c_void_p),
+                ("pos", ctypes.c_void_p), ("tlen", ctypes.c_void_p),
+                ("cigar_off", ctypes.c_void_p), ("cigar", ctypes.c_void_p),
+                ("seq_off", ctypes.c_void_p), ("seq", ctypes.c_void_p),
+                ("qual", ctypes.c_void_p)]
+
+
+class MdxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libmdx error %d: %s" % (code, message))
+        self.code = code
+
+
+class BadReadError(ValueError):
+    """A record the reference itself cannot process, e.g. an alignment running past the end
+    of its contig, where pysam's ``FastaFile.fetch`` raises ``ValueError`` (align.py:33)."""
+
+    def __init__(self, read_index, message):
+        super().__init__("invalid coordinates or record at batch index %d: %s"
+                         % (read_index, message))
+        self.read_index = read_index
+
+
+def load_library(path=None):
+    """Load libmdx.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = pathlib.Path(path) if path else _LIBPATH
+    if not p.exists():
+        raise RuntimeError("%s is missing: build it with `python -m mapdamage_amd.build` "
+                           "(hipcc, gfx950); there is no CPU fallback" % p)
+    lib = ctypes.CDLL(str(p))
+    lib.mdx_strerror.restype = ctypes.c_char_p
+    lib.mdx_last_error.restype = ctypes.c_char_p
+    lib.mdx_last_error.argtypes = [ctypes.c_void_p]
+    lib.mdx_table_words.restype = ctypes.c_int64
+    lib.mdx_table_words.argtypes = [ctypes.c_void_p]
+    lib.mdx_destroy.restype = None
+    lib.mdx_destroy.argtypes = [ctypes.c_void_p]
+    for name in ("mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
+                 "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_finish_device",
+                 "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
+                 "mdx_table_mode"):
+        getattr(lib, name).restype = ctypes.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _host_batch(batch: ReadBatch):
+    b = MdxBatch()
+    b.n_reads = batch.n
+    b.n_cigar = int(batch.cigar.shape[0])
+    b.n_bases = int(batch.seq.shape[0])
+    keep = []
+    for name in ("flag", "lib", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq"):
+        arr = np.ascontiguousarray(getattr(batch, name))
+        setattr(b, name, arr.ctypes.data)
+        keep.append(arr)
+    if batch.qual is not None:
+        q = np.ascontiguousarray(batch.qual)
+        b.qual = q.ctypes.data
+        keep.append(q)
+    b._keep = keep  # the columns must outlive the call
+    return b
+
+
+class DeviceBatch:
+    """A batch resident in HBM (allocated by the library)."""
+
+    def __init__(self, engine, dev, n_reads, n_bases, n_cigar):
+        self._engine = engine
+        self.dev = dev
+        self.n = n_reads
+        self.n_bases = n_bases
+        self.n_cigar = n_cigar
+
+    def free(self):
+        if self.dev is not None and self._engine._ctx:
+            self._engine._lib.mdx_batch_free(self._engine._ctx, ctypes.byref(self.dev))
+        self.dev = None
+
+
+class DamageEngine:
+    """Device-side counterpart of MisincorporationRates + DNAComposition + FragmentLengths.
+
+    ``libraries``: list of (sample, library) tuples indexed by the ``lib`` column (unique
+    libraries in header order, or ``[("*", "*")]`` for --merge-libraries)."""
+
+    def __init__(self, libraries, length=70, around=10, minqual=0, lgd_max=65536, device=0,
+                 lgd_over_cap=1 << 20):
+        self._lib = load_library()
+        self.libraries = [tuple(x) for x in libraries]
+        self.length, self.around, self.minqual, self.lgd_max = length, around, minqual, lgd_max
+        self.lgd_over_cap = lgd_over_cap
+        cfg = MdxConfig(length, around, minqual, len(self.libraries), lgd_max, device, lgd_over_cap)
+        ctx = ctypes.c_void_p()
+        rc = self._lib.mdx_create(ctypes.byref(cfg), ctypes.byref(ctx))
+        self._ctx = ctx if ctx.value else None
+        if rc != 0:
+            msg = self._lib.mdx_strerror(rc).decode()
+            if self._ctx:
+                msg += ": " + self._lib.mdx_last_error(self._ctx).decode()
+                self._lib.mdx_destroy(self._ctx)
+                self._ctx = None
+            raise MdxError(rc, msg + " (a HIP device is required; there is no CPU fallback)")
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise MdxError(rc, self._lib.mdx_last_error(self._ctx).decode()
+                           or self._lib.mdx_strerror(rc).decode())
+
+    def close(self):
+        if self._ctx:
+            self._lib.mdx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def table_mode(self):
+        return "lds" if self._lib.mdx_table_mode(self._ctx) == 0 else "global"
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.mdx_set_stream(self._ctx, ctypes.c_void_p(hip_stream or 0)))
+
+    # ------------------------------------------------------------------ inputs
+    def set_reference(self, ref: Reference):
+        bases, offs = ref.concat()
+        self._check(self._lib.mdx_set_reference(self._ctx, _ptr(bases), _ptr(offs),
+                                                ctypes.c_int32(len(ref.names))))
+
+    def upload(self, batch: ReadBatch) -> DeviceBatch:
+        hb = _host_batch(batch)
+        dev = MdxBatch()
+        self._check(self._lib.mdx_batch_upload(self._ctx, ctypes.byref(hb), ctypes.byref(dev)))
+        return DeviceBatch(self, dev, batch.n, int(batch.seq.shape[0]), int(batch.cigar.shape[0]))
+
+    def tabulate(self, batch):
+        """Accumulate one batch (host ``ReadBatch`` or resident ``DeviceBatch``)."""
+        if isinstance(batch, DeviceBatch):
+            self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(batch.dev)))
+        else:
+            hb = _host_batch(batch)
+            self._check(self._lib.mdx_tabulate_host(self._ctx, ctypes.byref(hb)))
+            # host columns may be released once the staged copies are enqueued and done
+            self._lib.mdx_sync(self._ctx, None)
+
+    def tabulate_pointers(self, n_reads, n_cigar, n_bases, **ptrs):
+        """Device pointers owned by the caller (e.g. torch tensors): zero-copy entry."""
+        b = MdxBatch()
+        b.n_reads, b.n_cigar, b.n_bases = n_reads, n_cigar, n_bases
+        for k, v in ptrs.items():
+            setattr(b, k, v)
+        self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(b)))
+
+    def sync(self):
+        bad = ctypes.c_int64(-1)
+        rc = self._lib.mdx_sync(self._ctx, ctypes.byref(bad))
+        if rc == L.MDX_ERR_BAD_READ:
+            raise BadReadError(bad.value, self._lib.mdx_last_error(self._ctx).decode())
+        self._check(rc)
+
+    # ------------------------------------------------------------------ outputs
+    def table_words(self):
+        return int(self._lib.mdx_table_words(self._ctx))
+
+    def finish_device(self, device_ptr):
+        """Write the packed canonical tables to a device buffer (for RCCL all-reduce)."""
+        self._check(self._lib.mdx_finish_device(self._ctx, ctypes.c_void_p(device_ptr)))
+
+    def unpack_tables(self, words: np.ndarray, lgd_over=None) -> TableSet:
+        """Split a packed table block (host copy of ``finish_device`` output)."""
+        nlib, Ln, A = len(self.libraries), self.length, self.around
+        nm = nlib * 4 * Ln * L.N_MIS_COLS
+        nc = nlib * 4 * (Ln + A) * 4
+        nl = nlib * 4 * self.lgd_max
+        words = np.ascontiguousarray(words).view(np.uint64)
+        assert words.shape[0] == nm + nc + nl + 2
+        mis = words[:nm].reshape(nlib, 2, 2, Ln, L.N_MIS_COLS).copy()
+        comp = words[nm:nm + nc].reshape(nlib, 2, 2, Ln + A, 4).copy()
+        lgd = words[nm + nc:nm + nc + nl].reshape(nlib, 2, 2, self.lgd_max).copy()
+        over = np.zeros((0, 4), np.int64) if lgd_over is None else lgd_over
+        return TableSet(self.libraries, Ln, A, mis, comp, lgd, over, int(words[-2]))
+
+    def finish(self) -> TableSet:
+        """Synchronise and fetch the canonical tables (main.py:229-231 reads them next)."""
+        self.sync()
+        nlib, Ln, A = len(self.libraries), self.length, self.around
+        mis = np.zeros((nlib, 2, 2, Ln, L.N_MIS_COLS), np.uint64)
+        comp = np.zeros((nlib, 2, 2, Ln + A, 4), np.uint64)
+        lgd = np.zeros((nlib, 2, 2, self.lgd_max), np.uint64)
+        cap = max(1, self.lgd_over_cap)
+        over = np.zeros((cap, 4), np.int64)
+        n_over = ctypes.c_int64(0)
+        n_kept = ctypes.c_int64(0)
+        self._check(self._lib.mdx_finish(self._ctx, _ptr(mis), _ptr(comp), _ptr(lgd), _ptr(over),
+                                         ctypes.c_int64(cap), ctypes.byref(n_over),
+                                         ctypes.byref(n_kept)))
+        return TableSet(self.libraries, Ln, A, mis, comp, lgd, over[:n_over.value].copy(),
+                        n_kept.value)
+
+    def lgd_overflow(self):
+        """Out-of-range fragment lengths only (cheap; used after an all-reduce)."""
+        return self.finish().lgd_over
+
+    def reset(self):
+        self._check(self._lib.mdx_reset(self._ctx))
+
+    # ------------------------------------------------------------------ timing
+    def timing(self, enable=True):
+        self._check(self._lib.mdx_timing_enable(self._ctx, 1 if enable else 0))
+
+    def timing_read(self):
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0)
+        self._check(self._lib.mdx_timing_read(self._ctx, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value

@@ -65,7 +65,7 @@ def make_reads(ref, n, seed, read_len=100, len_range=None, nlib=1, paired=False,
     """
     rng = np.random.default_rng(seed)
     bases, offs = ref.concat()
-    upper = bases & np.uint8(0xDF)
+    upper = np.concatenate([bases & np.uint8(0xDF), np.full(1024, ord("N"), np.uint8)])
     lens = np.asarray(ref.lengths, dtype=np.int64)
     if contigs is None:
         contigs = [i for i, ln in enumerate(lens) if ln >= 2000]
@@ -108,6 +108,7 @@ def _permute_fixed(batch, order):
 def _make_chunk(rng, n, upper, offs, lens, contigs, weights, read_len, len_range, nlib, paired,
                 frac_reverse, frac_softclip, frac_ins, frac_del, frac_skip, frac_hardclip,
                 frac_filtered, frac_n_base, with_qual, damage):
+    from numpy.lib.stride_tricks import sliding_window_view
     if len_range is None:
         qlen = np.full(n, read_len, dtype=np.int64)
         maxlen = read_len
@@ -121,8 +122,7 @@ def _make_chunk(rng, n, upper, offs, lens, contigs, weights, read_len, len_range
     side = rng.integers(0, 3, size=n)  # 0 left, 1 right, 2 both
     a = np.where(has_clip & (side != 1), rng.integers(1, 11, size=n), 0).astype(np.int64)
     b = np.where(has_clip & (side != 0), rng.integers(1, 11, size=n), 0).astype(np.int64)
-    # keep at least 20 aligned bases
-    over = (a + b) > (qlen - 20)
+    over = (a + b) > (qlen - 20)  # keep at least 20 aligned bases
     a[over] = 0
     b[over] = 0
     hard = rng.random(n) < frac_hardclip
@@ -139,7 +139,6 @@ def _make_chunk(rng, n, upper, offs, lens, contigs, weights, read_len, len_range
     aligned = qlen - a - b                      # query bases in M/I ops
     ins_k = np.where(t == 1, k, 0)
     mlen = aligned - ins_k                      # bases in M ops
-    # split point: at least 5 M bases either side of the mid op
     split = (5 + (rng.random(n) * np.maximum(mlen - 10, 1)).astype(np.int64))
     m1 = np.where(t == 0, mlen, np.minimum(split, mlen - 5))
     m2 = mlen - m1
@@ -152,55 +151,70 @@ def _make_chunk(rng, n, upper, offs, lens, contigs, weights, read_len, len_range
     clen = lens[tid]
     margin = 12
     pos = margin + (rng.random(n) * (clen - span - 2 * margin)).astype(np.int64)
+    gstart = offs[tid] + pos
 
-    # reference coordinate of every SEQ column (-1 = random base)
-    c = np.arange(maxlen, dtype=np.int64)[None, :]
-    a_, m1_, ins_, skip_, q_, b_ = (x[:, None] for x in (a, m1, ins_k, skip, qlen, b))
-    in_m1 = (c >= a_) & (c < a_ + m1_)
-    in_m2 = (c >= a_ + m1_ + ins_) & (c < q_ - b_)
-    valid = c < q_
-    gpos = (offs[tid] + pos)[:, None]
-    coord = np.where(in_m1, gpos + (c - a_), 0)
-    coord = np.where(in_m2, gpos + m1_ + skip_ + (c - a_ - m1_ - ins_), coord)
-    seqm = upper[coord]
-    rnd = _ACGT[rng.integers(0, 4, size=(n, maxlen))]
-    from_ref = in_m1 | in_m2
-    seqm = np.where(from_ref & (seqm != ord("N")), seqm, rnd)
+    # SEQ matrix: column c of a plain read is reference base gstart - a + c
+    win = sliding_window_view(upper, maxlen)
+    seqm = win[gstart - a].copy()
+    cplx = np.nonzero((a > 0) | (b > 0) | (t > 0))[0]
+    if cplx.size:
+        c = np.arange(maxlen, dtype=np.int64)[None, :]
+        a_, m1_, ins_, q_, b_ = (x[cplx, None] for x in (a, m1, ins_k, qlen, b))
+        sub = seqm[cplx]
+        # bases after the mid operation come from a window shifted by (skip - inserted)
+        sub2 = win[gstart[cplx] - a[cplx] + skip[cplx] - ins_k[cplx]]
+        sub = np.where(c >= a_ + m1_ + ins_, sub2, sub)
+        rnd_cols = (c < a_) | ((c >= a_ + m1_) & (c < a_ + m1_ + ins_)) | (c >= q_ - b_)
+        rnd = _ACGT[rng.integers(0, 4, size=sub.shape, dtype=np.uint8)]
+        seqm[cplx] = np.where(rnd_cols, rnd, sub)
+    isn = np.nonzero(seqm == ord("N"))
+    if isn[0].size:
+        seqm[isn] = _ACGT[rng.integers(0, 4, size=isn[0].size, dtype=np.uint8)]
 
     if damage:
-        p = _damage_probs(maxlen)
-        d5 = np.broadcast_to(c, (n, maxlen))
-        d3 = np.clip(q_ - 1 - c, 0, maxlen - 1)
+        p = _damage_probs(maxlen + 1)
         r = rng.random((n, maxlen), dtype=np.float32)
-        ct = (seqm == ord("C")) & (r < p[d5])
+        ct = (r < p[None, :maxlen]) & (seqm == ord("C"))      # distance from the left end
         r = rng.random((n, maxlen), dtype=np.float32)
-        ga = (seqm == ord("G")) & (r < p[d3])
-        seqm = np.where(ct, np.uint8(ord("T")), seqm)
-        seqm = np.where(ga, np.uint8(ord("A")), seqm)
+        if len_range is None:
+            ga = r < p[None, maxlen - 1::-1][:, :maxlen]       # distance from the right end
+        else:
+            d3 = np.clip(qlen[:, None] - 1 - np.arange(maxlen)[None, :], 0, maxlen)
+            ga = r < p[d3]
+        ga &= seqm == ord("G")
+        seqm[ct] = ord("T")
+        seqm[ga] = ord("A")
         r = rng.random((n, maxlen), dtype=np.float32)
-        bg = r < 0.001
-        seqm = np.where(bg, _ACGT[rng.integers(0, 4, size=(n, maxlen))], seqm)
+        bg = np.nonzero(r < 0.001)
+        seqm[bg] = _ACGT[rng.integers(0, 4, size=bg[0].size, dtype=np.uint8)]
     if frac_n_base > 0:
         rows = rng.random(n) < frac_n_base
         r = rng.random((n, maxlen), dtype=np.float32)
-        seqm = np.where(rows[:, None] & (r < 0.05), np.uint8(ord("N")), seqm)
+        seqm[rows[:, None] & (r < 0.05)] = ord("N")
 
-    seq = seqm[valid]
+    if len_range is None:
+        seq = seqm.reshape(-1)
+    else:
+        seq = seqm[np.arange(maxlen)[None, :] < qlen[:, None]]
     seq_off = np.zeros(n + 1, np.int64)
     np.cumsum(qlen, out=seq_off[1:])
     qual = None
     if with_qual:
-        qual = rng.integers(2, 42, size=seq.shape[0]).astype(np.uint8)
+        qual = rng.integers(2, 42, size=seq.shape[0], dtype=np.uint8)
 
     # CIGAR: [H] [S] M1 [X] [M2] [S] [H]
-    mid_op = np.array([0, L.OP_I, L.OP_D, L.OP_N], dtype=np.int64)[t]
-    ops = np.stack([
-        (hl << 4) | L.OP_H, (a << 4) | L.OP_S, (m1 << 4) | L.OP_M, (k << 4) | mid_op,
-        (m2 << 4) | L.OP_M, (b << 4) | L.OP_S, np.zeros(n, np.int64)], axis=1)
-    present = np.stack([hl > 0, a > 0, m1 > 0, k > 0, m2 > 0, b > 0, np.zeros(n, bool)], axis=1)
-    cigar = ops[present].astype(np.uint32)
-    cigar_off = np.zeros(n + 1, np.int64)
-    np.cumsum(present.sum(axis=1), out=cigar_off[1:])
+    if cplx.size or hard.any():
+        mid_op = np.array([0, L.OP_I, L.OP_D, L.OP_N], dtype=np.int64)[t]
+        ops = np.stack([
+            (hl << 4) | L.OP_H, (a << 4) | L.OP_S, (m1 << 4) | L.OP_M, (k << 4) | mid_op,
+            (m2 << 4) | L.OP_M, (b << 4) | L.OP_S], axis=1)
+        present = np.stack([hl > 0, a > 0, m1 > 0, k > 0, m2 > 0, b > 0], axis=1)
+        cigar = ops[present].astype(np.uint32)
+        cigar_off = np.zeros(n + 1, np.int64)
+        np.cumsum(present.sum(axis=1), out=cigar_off[1:])
+    else:
+        cigar = ((m1 << 4) | L.OP_M).astype(np.uint32)
+        cigar_off = np.arange(n + 1, dtype=np.int64)
 
     flag = np.zeros(n, dtype=np.int64)
     rev = rng.random(n) < frac_reverse

@@ -1,0 +1,140 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden vectors produced by the
+reference and against the C oracle on seeded inputs.  Integer tables: bit-exact."""
+
+import numpy as np
+import pytest
+
+from mapdamage_amd import synth
+from mapdamage_amd.batch import batch_from_records
+from tests.util import Golden, assert_tables_equal, golden_names, oracle_tableset
+
+pytestmark = pytest.mark.gpu
+
+
+def run_engine(ref, batch, libraries, length, around, minqual=0, lgd_max=65536, resident=False,
+               splits=1):
+    from mapdamage_amd.engine import DamageEngine
+    with DamageEngine(libraries, length, around, minqual, lgd_max=lgd_max) as eng:
+        eng.set_reference(ref)
+        for k in range(splits):
+            part = batch.shard(k, splits) if splits > 1 else batch
+            if resident:
+                dev = eng.upload(part)
+                eng.tabulate(dev)
+                eng.sync()
+                dev.free()
+            else:
+                eng.tabulate(part)
+        return eng.finish()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_reference_golden(name):
+    g = Golden(name)
+    ts = run_engine(g.ref, g.batch, g.libraries, g.length, g.around, g.minqual, lgd_max=4096)
+    g.check(ts)
+
+
+@pytest.mark.parametrize("name", ["config1_L70_A10_Q20", "edge_L8_A3_Q25"])
+def test_hip_resident_and_split_batches(name):
+    g = Golden(name)
+    ts = run_engine(g.ref, g.batch, g.libraries, g.length, g.around, g.minqual, lgd_max=4096,
+                    resident=True, splits=3)
+    g.check(ts)
+
+
+CASES = [
+    dict(n=200_000, seed=2, kw=dict(read_len=100), L=70, A=10, Q=0),
+    dict(n=100_000, seed=3, kw=dict(read_len=100, paired=True, frac_softclip=0.10, frac_ins=0.04,
+                                    frac_del=0.04, frac_skip=0.002, frac_hardclip=0.001), L=70, A=10, Q=0),
+    dict(n=100_000, seed=4, kw=dict(len_range=(35, 150), paired=True, frac_softclip=0.10,
+                                    frac_ins=0.04, frac_del=0.04, frac_skip=0.002,
+                                    frac_hardclip=0.001, nlib=3, frac_filtered=0.05,
+                                    frac_n_base=0.02), L=70, A=10, Q=0),
+    dict(n=60_000, seed=5, kw=dict(len_range=(20, 90), frac_softclip=0.2, frac_ins=0.1, frac_del=0.1,
+                                   frac_skip=0.02, with_qual=True, nlib=2), L=25, A=4, Q=20),
+    dict(n=30_000, seed=6, kw=dict(len_range=(30, 300), frac_softclip=0.2, frac_ins=0.1, frac_del=0.1,
+                                   with_qual=True), L=150, A=30, Q=12),
+    dict(n=20_000, seed=7, kw=dict(read_len=50, nlib=1), L=1, A=0, Q=0),
+]
+
+
+@pytest.fixture(scope="module")
+def mid_genome():
+    return synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)),
+                             n_run=500, lower_run=3000)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d_L%d_Q%d" % (c["seed"], c["L"], c["Q"]))
+def test_hip_matches_oracle_seeded(case, mid_genome):
+    batch = synth.make_reads(mid_genome, case["n"], case["seed"], **case["kw"])
+    nlib = case["kw"].get("nlib", 1)
+    libs = [("S%d" % i, "L%d" % i) for i in range(nlib)]
+    want = oracle_tableset(mid_genome, batch, libs, case["L"], case["A"], case["Q"])
+    got = run_engine(mid_genome, batch, libs, case["L"], case["A"], case["Q"])
+    assert_tables_equal(got, want)
+    assert got.misincorporation_text() == want.misincorporation_text()
+
+
+def test_hip_global_atomic_fallback_matches_oracle(mid_genome):
+    """Tables too large for the LDS (many libraries) take the global-atomic path."""
+    from mapdamage_amd.engine import DamageEngine
+    nlib = 7
+    batch = synth.make_reads(mid_genome, 40_000, 8, len_range=(30, 120), nlib=nlib, frac_softclip=0.1,
+                             frac_ins=0.05, frac_del=0.05, with_qual=True)
+    libs = [("S%d" % i, "L%d" % i) for i in range(nlib)]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 15)
+    with DamageEngine(libs, 70, 10, 15) as eng:
+        assert eng.table_mode == "global"
+        eng.set_reference(mid_genome)
+        eng.tabulate(batch)
+        got = eng.finish()
+    assert_tables_equal(got, want)
+
+
+def test_hip_rejects_alignment_past_contig_end():
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    ref = synth.small_genome()
+    n_last = ref.lengths[-1]
+    recs = [dict(flag=0, tid=0, pos=10, cigar=[(0, 20)], seq="A" * 20, qual=None, lib=0, tlen=0),
+            dict(flag=0, tid=2, pos=n_last - 10, cigar=[(0, 25)], seq="A" * 25, qual=None, lib=0, tlen=0)]
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.tabulate(batch_from_records(recs))
+        with pytest.raises(BadReadError) as e:
+            eng.finish()
+        assert e.value.read_index == 1
+
+
+def test_hip_empty_and_all_filtered_batches():
+    from mapdamage_amd.engine import DamageEngine
+    ref = synth.small_genome()
+    recs = [dict(flag=0x4, tid=0, pos=10, cigar=[(0, 20)], seq="A" * 20, qual=None, lib=0, tlen=0),
+            dict(flag=0x400, tid=0, pos=10, cigar=[(0, 20)], seq="A" * 20, qual=None, lib=0, tlen=0)]
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.tabulate(batch_from_records([]))
+        eng.tabulate(batch_from_records(recs))
+        ts = eng.finish()
+    assert ts.n_kept == 0 and int(ts.mis.sum()) == 0 and int(ts.comp.sum()) == 0
+
+
+def test_hip_accumulate_is_linear(mid_genome):
+    """Size-independent property: tabulating a batch twice doubles every counter."""
+    from mapdamage_amd.engine import DamageEngine
+    batch = synth.make_reads(mid_genome, 50_000, 12, read_len=100, frac_softclip=0.1, frac_ins=0.03)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(mid_genome)
+        dev = eng.upload(batch)
+        eng.tabulate(dev)
+        one = eng.finish()
+        eng.tabulate(dev)
+        two = eng.finish()
+        eng.reset()
+        eng.tabulate(dev)
+        again = eng.finish()
+        dev.free()
+    np.testing.assert_array_equal(two.mis, 2 * one.mis)
+    np.testing.assert_array_equal(two.comp, 2 * one.comp)
+    np.testing.assert_array_equal(two.lgd, 2 * one.lgd)
+    assert_tables_equal(again, one)
