@@ -129,8 +129,8 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
     c->stream = c->own_stream;
 
     const int lgd_lds = cfg->lgd_max < kLgdLds ? cfg->lgd_max : kLgdLds;
-    if ((int64_t)cfg->nlib * (4LL * cfg->length * 25 + 4LL * (cfg->length + cfg->around) * 4 + 16LL * cfg->length +
-                              4LL * lgd_lds) > 0x7FFFFFF0LL)
+    if ((int64_t)cfg->nlib * (4LL * cfg->length * 29 + 8LL * (2LL * cfg->length + 2LL * cfg->around + 64) +
+                              4LL * lgd_lds) > 0x7FFFFFF0LL || cfg->length > (1 << 24) || cfg->around > (1 << 24))
         return fail(c, MDX_ERR_ARG, "table too large (nlib * length)");
     c->dims = mdx_make_dims(cfg->length, cfg->around, cfg->nlib, cfg->lgd_max, lgd_lds);
     c->lds_bytes = mdx_k_lds_bytes(c->dims);
@@ -195,7 +195,7 @@ int mdx_set_reference(mdx_ctx *c, const uint8_t *bases, const int64_t *contig_of
     HIP_TRY(c, hipMalloc((void **)&tmp, (size_t)n + 1));
     HIP_TRY(c, hipMalloc((void **)&c->d_ref, (size_t)n + 2 * pad));
     HIP_TRY(c, hipMalloc((void **)&c->d_contig_off, (size_t)(n_contig + 1) * 8));
-    HIP_TRY(c, hipMemsetAsync(c->d_ref, 5, (size_t)n + 2 * pad, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref, 0x85, (size_t)n + 2 * pad, c->stream));
     if (n > 0) HIP_TRY(c, hipMemcpyAsync(tmp, bases, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_contig_off, contig_off, (size_t)(n_contig + 1) * 8, hipMemcpyHostToDevice, c->stream));
     mdx_k_encode_ref(tmp, c->d_ref + pad, n, c->stream);

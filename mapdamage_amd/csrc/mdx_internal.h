@@ -6,32 +6,43 @@
 #include <stdint.h>
 
 // Raw (reference-orientation) accumulator layout, in words, per library:
-//   MIS [strand 2][side 2][L][25]      substitution / indel / soft-clip events + rare ref-base counts
-//   COMP[strand 2][side 2][L + A][4]   read-base (slots 0..L-1) and flank-base (slots L..L+A-1) counts
-//   M   [strand 2][side 2][L][4]       "read base == reference base == b" matches (the common case;
-//                                       contributes to both MIS[b] and COMP[b] at finalisation)
-//   LGD [kind 2][strand 2][lgd_lds]    short fragment lengths
+//   MIS [strand 2][side 2][L][25]   rare events: substitutions, indels, soft clips, and the
+//                                    reference-base count of columns that are not plain matches
+//                                    (base columns 0..3 in A,C,T,G order = (ascii >> 1) & 3)
+//   CMP [strand 2][side 2][L][4]    read-base counts of columns that are not plain matches
+//   TC  [strand 2][base 4][T_pad]   task-indexed counts, the common case.  Task t of a read:
+//                                      t in [0, L)          left-anchored column t, read == ref == base
+//                                      t in [L, 2L)         right-anchored column t - L, same
+//                                      t in [2L, 2L+A)      left flank base at distance t - 2L + 1
+//                                      t in [2L+A, 2L+2A)   right flank base at distance t - 2L - A + 1
+//                                    one lane owns one task, so a wavefront's 64 increments land in 64
+//                                    consecutive words (T_pad is a multiple of 64): no bank conflicts
+//   LGD [kind 2][strand 2][lgd_lds] short fragment lengths
 // followed, after the last library, by one word: number of kept reads.
 // side 0 = left-anchored (columns counted from the leftmost reference coordinate),
-// side 1 = right-anchored.  The canonical 5p/3p tables are a permutation of these
-// (strand '+': 5p = left, 3p = right; strand '-': swapped and complemented).
+// side 1 = right-anchored.  The canonical 5p/3p tables are a fixed permutation of these
+// (strand '+': 5p = left, 3p = right; strand '-': swapped and complemented), applied once by
+// finalize_kernel.
 struct MdxDims {
     int L, A, nlib, lgd_max, lgd_lds;
-    int w_mis, w_comp, w_m, w_lgd, w_lib;
+    int n_task, t_pad;
+    int w_mis, w_cmp, w_tc, w_lgd, w_lib;
     int64_t w_total;  // nlib * w_lib + 1
-    __host__ __device__ int off_comp() const { return w_mis; }
-    __host__ __device__ int off_m() const { return w_mis + w_comp; }
-    __host__ __device__ int off_lgd() const { return w_mis + w_comp + w_m; }
+    __host__ __device__ int off_cmp() const { return w_mis; }
+    __host__ __device__ int off_tc() const { return w_mis + w_cmp; }
+    __host__ __device__ int off_lgd() const { return w_mis + w_cmp + w_tc; }
 };
 
 static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd_lds) {
     MdxDims d;
     d.L = L; d.A = A; d.nlib = nlib; d.lgd_max = lgd_max; d.lgd_lds = lgd_lds;
+    d.n_task = 2 * L + 2 * A;
+    d.t_pad = (d.n_task + 63) / 64 * 64;
     d.w_mis = 2 * 2 * L * 25;
-    d.w_comp = 2 * 2 * (L + A) * 4;
-    d.w_m = 2 * 2 * L * 4;
+    d.w_cmp = 2 * 2 * L * 4;
+    d.w_tc = 2 * 4 * d.t_pad;
     d.w_lgd = 2 * 2 * lgd_lds;
-    d.w_lib = d.w_mis + d.w_comp + d.w_m + d.w_lgd;
+    d.w_lib = d.w_mis + d.w_cmp + d.w_tc + d.w_lgd;
     d.w_total = (int64_t)nlib * d.w_lib + 1;
     return d;
 }

@@ -6,11 +6,15 @@
 //     (reader.py:121-132), CIGAR scan (clips, reference span, column count), fragment-length
 //     update (statistics.py:117-126), soft-clip update (statistics.py:37-51), error checks;
 //   * phase 2, wavefront-per-record: the record's scalars are broadcast with v_readlane and
-//     the 64 lanes walk its alignment columns (bases and reference classes are read with
-//     consecutive addresses across lanes) and bump counters;
-//   * counters live in a block-private LDS image of the raw tables (ds_add_u32); at block end
-//     the image is stored to a per-block slot and a second kernel column-sums the slots into
-//     the u64 accumulators (no global atomics on the hot path).
+//     the 64 lanes each own one *task* of the record (one left- or right-anchored alignment
+//     column, or one flank base); bases and reference symbols are read with consecutive
+//     addresses across lanes.  The loads of record j+1 are issued before record j is counted
+//     (register double-buffering) so that the gather latency of the resident genome is hidden;
+//   * the common outcome (read base == reference base, or an A/C/G/T flank base) is one
+//     conflict-free ds_add_u32 into a task-indexed LDS table; everything else (substitutions,
+//     indels, N, masked columns) takes a rare, divergent path into the MIS/CMP tables;
+//   * at block end the LDS image is stored to a per-block slot and a second kernel sums the
+//     slots into the u64 accumulators (no global atomics on the hot path).
 // Counting is done in *reference orientation* (left-/right-anchored, no complementing); the
 // strand step of main.py:200-205 (reverse-complement + flank swap) becomes a fixed permutation
 // applied once by finalize_kernel.  The oracle (oracle/mdx_oracle.c) builds and reverses the
@@ -18,53 +22,65 @@
 #include "mdx_internal.h"
 
 typedef uint8_t u8;
+typedef int8_t i8;
 typedef uint16_t u16;
 typedef uint32_t u32;
 typedef unsigned long long u64;
 typedef long long i64;
 
 #define MDX_BLOCK 512
-#define SYM_GAP 4
-#define SYM_OTHER 5
+#define MAX_NSLOT 4
 #define COL_S 24
 #define ERR_BAD_READ 6
+// symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
+#define SYM_GAP 4
+#define SYM_OTHER 5
+// resident reference bytes: upper-case ASCII for A,C,G,T; negative (as int8) for the rest, so
+// that a zero-extended read byte can never compare equal to a sign-extended invalid one
+#define REF_GAP 0x84
+#define REF_OTHER 0x85
 
-// column of substitution ref>read (mapdamage/seq.py:6-30 order, "Total" removed); 31 = none
+// final column (mapdamage/seq.py:6-30 order, "Total" removed) of substitution ref>read,
+// indexed [ref class][read class] with classes A,C,T,G,-; 31 = none
 __constant__ u8 c_col[25] = {
-    31, 8, 6, 9, 16,
-    11, 31, 10, 5, 18,
-    4, 14, 31, 15, 19,
-    13, 7, 12, 31, 17,
-    20, 22, 23, 21, 31};
-// column seen from the reverse strand (complement both symbols)
+    /* A> */ 31, 8, 9, 6, 16,
+    /* C> */ 11, 31, 5, 10, 18,
+    /* T> */ 13, 7, 31, 12, 17,
+    /* G> */ 4, 14, 15, 31, 19,
+    /* -> */ 20, 22, 21, 23, 31};
+// final column seen from the reverse strand (complement both symbols), for columns >= 4
 __constant__ u8 c_comp_col[25] = {3, 2, 1, 0, 5, 4, 7, 6, 12, 13, 14, 15, 8,
                                   9, 10, 11, 17, 16, 19, 18, 21, 20, 23, 22, 24};
 
 int mdx_k_block_threads() { return MDX_BLOCK; }
 size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)d.w_total * 4; }
 
-// ASCII -> symbol class.  (ch >> 1) & 3 maps A,C,T,G to 0,1,2,3; the byte is accepted only if
-// it is exactly that upper-case letter ("nt in 'ACGT-'", statistics.py:27).
-__device__ __forceinline__ int classify_ascii(u32 ch) {
-    u32 k = (ch >> 1) & 3u;
-    u32 recon = (0x47544341u >> (k * 8)) & 0xFFu;  // 'A','C','T','G'
-    int code = (int)(k ^ (k >> 1));                // A0 C1 G2 T3
-    return ch == recon ? code : (ch == (u32)'-' ? SYM_GAP : SYM_OTHER);
+// read byte -> class; accepted only if it is exactly the upper-case letter
+// ("nt in 'ACGT-'", statistics.py:27)
+__device__ __forceinline__ int classify_read(u32 ch) {
+    const u32 k = (ch >> 1) & 3u;
+    const u32 recon = (0x47544341u >> (k * 8)) & 0xFFu;  // 'A','C','T','G'
+    return ch == recon ? (int)k : (ch == (u32)'-' ? SYM_GAP : SYM_OTHER);
+}
+// resident reference byte (sign-extended) -> class
+__device__ __forceinline__ int classify_ref(int rch) {
+    return rch < 0 ? (rch & 0xF) : ((rch >> 1) & 3);
 }
 
 __global__ void encode_ref_kernel(const u8 *__restrict__ in, u8 *__restrict__ out, i64 n) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         u32 ch = in[i];
         if (ch >= 'a' && ch <= 'z') ch -= 32;  // .upper() of main.py:180 / align.py:32-33
-        out[i] = (u8)classify_ascii(ch);
+        const int c = classify_read(ch);
+        out[i] = c < 4 ? (u8)ch : (c == SYM_GAP ? (u8)REF_GAP : (u8)REF_OTHER);
     }
 }
 
 void mdx_k_encode_ref(const u8 *d_ascii, u8 *d_codes, int64_t n, hipStream_t s) {
     if (n <= 0) return;
-    int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(encode_ref_kernel, dim3(grid), dim3(256), 0, s, d_ascii, d_codes, (i64)n);
 }
 
@@ -73,24 +89,42 @@ __device__ __forceinline__ void bump(u32 *lds, u64 *raw, int idx) {
     if (USE_LDS) atomicAdd(&lds[idx], 1u);
     else atomicAdd(&raw[idx], 1ull);
 }
+template <bool USE_LDS>
+__device__ __forceinline__ void bump_n(u32 *lds, u64 *raw, int idx, u32 n) {
+    if (USE_LDS) atomicAdd(&lds[idx], n);
+    else atomicAdd(&raw[idx], (u64)n);
+}
 
 __device__ __forceinline__ void flag_error(u64 *err, i64 read, int code) {
     atomicMin(err, ((u64)read << 8) | (u64)code);
 }
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ i64 rl64(i64 v, int lane) {
-    int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), lane);
-    int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
-    return ((i64)hi << 32) | (u32)lo;
-}
 
-// record descriptor bits
+// record descriptor bits (one int per record, broadcast in phase 2)
 #define D_REV 1
 #define D_SIMPLE 2
 #define D_HASQ 4
+#define D_NB_SHIFT 8    // nbefore, 8 bits
+#define D_NA_SHIFT 16   // nafter, 8 bits
 
-template <bool USE_LDS, bool MASK>
+// Rare path of a plain-match record column: (ch, rch) is not a plain match.
+template <bool USE_LDS>
+__device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b_cmp, int L, int side,
+                                            int p, u32 ch, int rch, bool masked) {
+    const int s = classify_read(ch);
+    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + p) * 4 + s);  // statistics.py:75-83
+    if (!masked) {
+        const int r = classify_ref(rch);
+        if (s <= SYM_GAP && r <= SYM_GAP && r != s) {  // statistics.py:26-35
+            const int row = b_mis + (side * L + p) * 25;
+            if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
+            bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
+        }
+    }
+}
+
+template <bool USE_LDS, bool MASK, int NSLOT>
 __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -106,6 +140,21 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         __syncthreads();
     }
 
+    // per-lane task constants (NSLOT > 0): task t = lane + 64 k
+    //   column offset from (rbase - A):  cp = coef * nq + c0
+    //   validity:                         thr <= (read task ? nq : left flank ? nbefore : nafter)
+    int t_c0[MAX_NSLOT], t_coef[MAX_NSLOT], t_thr[MAX_NSLOT], t_kind[MAX_NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+        const int t = lane + 64 * k;
+        int c0 = 0, coef = 0, thr = 0x7FFFFFFF, kind = 4;  // kind: 0/1 read column, 2/3 flank, 4 none
+        if (t < L) { c0 = t + A; thr = t + 1; kind = 0; }
+        else if (t < 2 * L) { const int p = t - L; coef = 1; c0 = A - 1 - p; thr = p + 1; kind = 1; }
+        else if (t < 2 * L + A) { const int dist = t - 2 * L + 1; c0 = A - dist; thr = dist; kind = 2; }
+        else if (t < d.n_task) { const int dist = t - 2 * L - A + 1; coef = 1; c0 = A - 1 + dist; thr = dist; kind = 3; }
+        t_c0[k] = c0; t_coef[k] = coef; t_thr[k] = thr; t_kind[k] = kind;
+    }
+
     const i64 ntiles = (a.n_reads + 63) >> 6;
     for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
         // ------------------------------------------------------------ phase 1: lane per record
@@ -113,18 +162,19 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         const bool valid = ri < a.n_reads;
         const u32 fl = valid ? (u32)a.flag[ri] : 0x4u;
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
-        int desc = 0, libid = 0, nq = 0, n0 = 0, ncols = 0, nI = 0, nbefore = 0, nafter = 0;
-        int cig_n = 0;
-        i64 rbase = 0, sq = 0, cig_o = 0;
+        int desc = 0, libid = 0, nq = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
+        u32 sq = 0, cig_o = 0;
+        i64 rbase = 0;
+        int lkey = -1;  // fragment-length key for the LDS histogram
         if (kept) {
             const int rev = (fl >> 4) & 1;
             libid = a.lib[ri];
             const int tid = a.tid[ri];
             const i64 pos = a.pos[ri];
             cig_o = a.cigar_off[ri];
-            cig_n = (int)(a.cigar_off[ri + 1] - (u32)cig_o);
-            const i64 so = a.seq_off[ri];
-            const i64 lseq = (i64)a.seq_off[ri + 1] - so;
+            cig_n = (int)(a.cigar_off[ri + 1] - cig_o);
+            const u32 so = a.seq_off[ri];
+            const i64 lseq = (i64)a.seq_off[ri + 1] - (i64)so;
             bool bad = tid < 0 || tid >= a.n_contig || libid >= d.nlib || lseq <= 0 || pos < 0;
             const int lbase = bad ? 0 : libid * d.w_lib;
 
@@ -177,10 +227,12 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 kept = false;
             } else {
                 nq = (int)nq64; n0 = (int)n064; ncols = (int)tl; nI = (int)sI;
-                sq = so + qs;
-                nbefore = pos < A ? (int)pos : A;
-                nafter = clen - aend < A ? (int)(clen - aend) : A;
-                desc = rev | ((sI == 0 && sDN == 0 && rlen > 0) ? D_SIMPLE : 0);
+                sq = so + (u32)qs;
+                const int nbefore = pos < A ? (int)pos : A;
+                const int nafter = clen - aend < A ? (int)(clen - aend) : A;
+                desc = rev | ((sI == 0 && sDN == 0 && rlen > 0) ? D_SIMPLE : 0) |
+                       ((nbefore > 255 ? 255 : nbefore) << D_NB_SHIFT) | ((nafter > 255 ? 255 : nafter) << D_NA_SHIFT);
+                if (A > 255) desc &= ~D_SIMPLE;  // flank lengths do not fit the packed descriptor
                 if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) desc |= D_HASQ;
                 // statistics.py:117-126
                 int kind = -1;
@@ -197,7 +249,7 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 }
                 if (kind >= 0) {
                     if (flen < d.lgd_lds) {
-                        bump<USE_LDS>(lds, raw, lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen);
+                        lkey = lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen;
                     } else if (flen < d.lgd_max) {
                         atomicAdd(&a.lgd_dense[(((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
                     } else {
@@ -212,151 +264,207 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 }
             }
         }
-        u64 todo = __ballot(kept);
-        if (lane == 0 && todo) {
-            const int cnt = __popcll(todo);
-            if (USE_LDS) atomicAdd(&lds[d.w_total - 1], (u32)cnt);
-            else atomicAdd(&raw[d.w_total - 1], (u64)cnt);
+        // fragment lengths: two rounds of wave-level aggregation (uniform read lengths give one
+        // or two distinct keys per tile), the remainder as individual adds
+        {
+            u64 pend = __ballot(lkey >= 0);
+#pragma unroll 1
+            for (int round = 0; round < 2 && pend; round++) {
+                const int leader = __ffsll((long long)pend) - 1;
+                const int key = rl(lkey, leader);
+                const u64 same = __ballot(lkey == key);
+                if (lane == leader) bump_n<USE_LDS>(lds, raw, key, (u32)__popcll(same));
+                if (lkey == key) lkey = -1;
+                pend &= ~same;
+            }
+            if (lkey >= 0) bump<USE_LDS>(lds, raw, lkey);
+        }
+        const u64 todo_all = __ballot(kept);
+        if (lane == 0 && todo_all) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), (u32)__popcll(todo_all));
+
+        // ------------------------------------------------------------ phase 2a: plain records
+        const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
+        u64 todo_g = todo_all;
+        if (NSLOT > 0) {
+            u64 todo = __ballot(kept && (desc & D_SIMPLE));
+            todo_g = todo_all & ~todo;
+            // software pipeline: *_n = record whose loads are in flight, *_c = record being counted
+            u32 ch_n[MAX_NSLOT], ch_c[MAX_NSLOT], q_n[MAX_NSLOT], q_c[MAX_NSLOT];
+            int rch_n[MAX_NSLOT], rch_c[MAX_NSLOT];
+            int desc_n = 0, nq_n = 0, lib_n = 0;
+
+            auto issue = [&](int j) {
+                desc_n = rl(desc, j);
+                nq_n = rl(nq, j);
+                lib_n = rl(libid, j);
+                const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
+                const u32 s_sq = (u32)rl((int)sq, j);
+                const i8 *__restrict__ refA = (const i8 *)a.ref + (s_rbase - A);
+                const u8 *__restrict__ seqA = a.seq + ((i64)s_sq - A);
+                const u8 *__restrict__ qualA = MASK ? a.qual + ((i64)s_sq - A) : nullptr;
+                const int nb = (desc_n >> D_NB_SHIFT) & 0xFF, na = (desc_n >> D_NA_SHIFT) & 0xFF;
+                const bool full = nq_n >= L && nb == A && na == A;  // every task of the record exists
+#pragma unroll
+                for (int k = 0; k < NSLOT; k++) {
+                    const u32 cp = (u32)(t_coef[k] * nq_n + t_c0[k]);
+                    int r = -1;
+                    u32 c = 0x200u, q = 0xFFu;  // 0x200: task does not exist for this record
+                    bool ok = t_kind[k] < 4;
+                    if (!full) ok = t_thr[k] <= (t_kind[k] < 2 ? nq_n : (t_kind[k] == 2 ? nb : na));
+                    if (ok) {
+                        r = refA[cp];
+                        if (t_kind[k] < 2) {
+                            c = seqA[cp];
+                            if (MASK && (desc_n & D_HASQ)) q = qualA[cp];
+                        } else {
+                            c = (u32)r & 0xFFu;  // flank base "matches itself" iff it is A/C/G/T
+                        }
+                    }
+                    rch_n[k] = r; ch_n[k] = c; q_n[k] = q;
+                }
+            };
+
+            if (todo) issue(__ffsll((long long)todo) - 1);
+            while (todo) {
+                todo &= todo - 1;
+                const int s_desc = desc_n, s_lib = lib_n;
+#pragma unroll
+                for (int k = 0; k < NSLOT; k++) { ch_c[k] = ch_n[k]; rch_c[k] = rch_n[k]; q_c[k] = q_n[k]; }
+                if (todo) issue(__ffsll((long long)todo) - 1);
+
+                const int rev = s_desc & D_REV;
+                const int lb = s_lib * d.w_lib;
+                const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad + lane;
+#pragma unroll
+                for (int k = 0; k < NSLOT; k++) {
+                    const bool masked = MASK && (int)q_c[k] < a.minqual;  // align.py:65-71
+                    const bool hit = (int)ch_c[k] == rch_c[k] && !masked;
+                    if (hit) bump<USE_LDS>(lds, raw, b_tc + 64 * k + (int)((ch_c[k] >> 1) & 3u) * d.t_pad);
+                    const bool miss = !hit && t_kind[k] < 2 && ch_c[k] < 0x100u;
+                    if (__ballot(miss)) {
+                        if (miss) {
+                            const int t = lane + 64 * k;
+                            const int side = t >= L;
+                            rare_column<USE_LDS>(lds, raw, lb + rev * 2 * L * 25, lb + d.off_cmp() + rev * 2 * L * 4,
+                                                 L, side, side ? t - L : t, ch_c[k], rch_c[k], masked);
+                        }
+                    }
+                }
+            }
         }
 
-        // ------------------------------------------------------------ phase 2: wave per record
-        while (todo) {
-            const int j = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
+        // ------------------------------------------------------------ phase 2b: gapped records
+        while (todo_g) {
+            const int j = __ffsll((long long)todo_g) - 1;
+            todo_g &= todo_g - 1;
             const int s_desc = rl(desc, j);
             const int s_nq = rl(nq, j);
             const int s_n0 = rl(n0, j);
-            const int s_nbefore = rl(nbefore, j);
-            const int s_nafter = rl(nafter, j);
-            const i64 s_rbase = rl64(rbase, j);
-            const i64 s_sq = rl64(sq, j);
+            const int s_ncols = rl(ncols, j);
+            const int s_nrg = s_n0 + rl(nI, j);
+            const u32 s_co = (u32)rl((int)cig_o, j);
+            const int s_cn = rl(cig_n, j);
+            const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
+            const u32 s_sq = (u32)rl((int)sq, j);
             const int rev = s_desc & D_REV;
             const bool hasq = MASK && (s_desc & D_HASQ);
             const int lb = rl(libid, j) * d.w_lib;
-            const int b_mis = lb + (rev * 2) * L * 25;
-            const int b_comp = lb + d.off_comp() + (rev * 2) * (L + A) * 4;
-            const int b_m = lb + d.off_m() + (rev * 2) * L * 4;
-            const u8 *__restrict__ rp = a.ref + s_rbase;
+            const int b_mis = lb + rev * 2 * L * 25;
+            const int b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+            const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad;
+            const i8 *__restrict__ rp = (const i8 *)a.ref + s_rbase;
             const u8 *__restrict__ sp = a.seq + s_sq;
             const u8 *__restrict__ qp = MASK ? a.qual + s_sq : nullptr;
+            // flank lengths (not from the packed descriptor: A may exceed 255 here)
+            int s_nb, s_na;
+            {
+                const i64 pos = a.pos[tile * 64 + j];
+                const int tid = a.tid[tile * 64 + j];
+                const i64 clen = a.contig_off[tid + 1] - a.contig_off[tid];
+                s_nb = pos < A ? (int)pos : A;
+                s_na = clen - (pos + s_n0) < A ? (int)(clen - (pos + s_n0)) : A;
+            }
 
-            if (s_desc & D_SIMPLE) {
-                // gapped read == query, gapped reference == reference slice (align.py:38-50 is
-                // the identity): column c pairs sp[c] with rp[c]; flanks are rp[-d], rp[nq-1+d]
-                const int Lp = s_nq < L ? s_nq : L;
-                const int span = Lp + A;
-                for (int t = lane; t < 2 * span; t += 64) {
-                    const int side = t >= span;
-                    const int p = (side ? t - span : t) - A;  // [-A, Lp)
-                    const int c = side ? s_nq - 1 - p : p;
-                    if (p < 0) {
-                        // statistics.py:85-93 (flank bases, already clamped to the contig)
-                        const int dist = -p;
-                        if (dist <= (side ? s_nafter : s_nbefore)) {
-                            const int r = rp[c];
-                            if (r < 4) bump<USE_LDS>(lds, raw, b_comp + (side * (L + A) + L + dist - 1) * 4 + r);
+            // misincorporation pairs, each string indexed from its own end (main.py:210-212)
+            int Lm = s_ncols < s_nrg ? s_ncols : s_nrg;
+            if (Lm > L) Lm = L;
+            for (int t = lane; t < 2 * Lm; t += 64) {
+                const int side = t >= Lm;
+                const int i = side ? t - Lm : t;
+                const int js = side ? s_ncols - 1 - i : i;
+                const int jr = side ? s_nrg - 1 - i : i;
+                // walk the CIGAR: query index under gapped-read column js (-1 = deletion gap),
+                // reference index under gapped-reference column jr (-1 = insertion gap)
+                int col = 0, qoff = 0, shift = 0, qi = -2, rix = -2;
+                for (int k = 0; k < s_cn; k++) {
+                    const u32 cg = a.cigar[s_co + k];
+                    const int op = cg & 0xF;
+                    const int len = (int)(cg >> 4);
+                    if (op == 0 || op == 7 || op == 8) {
+                        if (qi == -2 && js < col + len) qi = qoff + (js - col);
+                        col += len; qoff += len;
+                    } else if (op == 1) {
+                        if (qi == -2 && js < col + len) qi = qoff + (js - col);
+                        if (rix == -2) {
+                            if (jr < col) rix = jr - shift;
+                            else if (jr < col + len) rix = -1;
                         }
-                    } else {
-                        const int r = rp[c];
-                        const int s = classify_ascii(sp[c]);
-                        const bool m = hasq && (int)qp[c] < a.minqual;  // align.py:65-71
-                        if (s < 4) {
-                            if (!m && r == s) bump<USE_LDS>(lds, raw, b_m + (side * L + p) * 4 + s);
-                            else bump<USE_LDS>(lds, raw, b_comp + (side * (L + A) + p) * 4 + s);  // statistics.py:75-83
-                        }
-                        if (!m && s <= SYM_GAP && r <= SYM_GAP && r != s) {  // statistics.py:26-35
-                            const int row = b_mis + (side * L + p) * 25;
-                            if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
-                            bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
-                        }
+                        shift += len; col += len; qoff += len;
+                    } else if (op == 2) {
+                        if (qi == -2 && js < col + len) qi = -1;
+                        col += len;
                     }
                 }
-            } else {
-                const int s_ncols = rl(ncols, j);
-                const int s_nrg = s_n0 + rl(nI, j);
-                const i64 s_co = rl64(cig_o, j);
-                const int s_cn = rl(cig_n, j);
-                // misincorporation pairs, each string indexed from its own end (main.py:210-212)
-                int Lm = s_ncols < s_nrg ? s_ncols : s_nrg;
-                if (Lm > L) Lm = L;
-                for (int t = lane; t < 2 * Lm; t += 64) {
-                    const int side = t >= Lm;
-                    const int i = side ? t - Lm : t;
-                    const int js = side ? s_ncols - 1 - i : i;
-                    const int jr = side ? s_nrg - 1 - i : i;
-                    // walk the CIGAR: query index under gapped-read column js (-1 = deletion gap),
-                    // reference index under gapped-reference column jr (-1 = insertion gap)
-                    int col = 0, qoff = 0, shift = 0, qi = -2, rix = -2;
-                    for (int k = 0; k < s_cn; k++) {
-                        const u32 cg = a.cigar[s_co + k];
-                        const int op = cg & 0xF;
-                        const int len = (int)(cg >> 4);
-                        if (op == 0 || op == 7 || op == 8) {
-                            if (qi == -2 && js < col + len) qi = qoff + (js - col);
-                            col += len; qoff += len;
-                        } else if (op == 1) {
-                            if (qi == -2 && js < col + len) qi = qoff + (js - col);
-                            if (rix == -2) {
-                                if (jr < col) rix = jr - shift;
-                                else if (jr < col + len) rix = -1;
-                            }
-                            shift += len; col += len; qoff += len;
-                        } else if (op == 2) {
-                            if (qi == -2 && js < col + len) qi = -1;
-                            col += len;
-                        }
-                    }
-                    if (rix == -2) rix = jr - shift;
-                    int s = qi < 0 ? SYM_GAP : classify_ascii(sp[qi]);
-                    int r = rix < 0 ? SYM_GAP : (int)rp[rix];
-                    if (hasq) {
-                        const bool ms = qi >= 0 && (int)qp[qi] < a.minqual;
-                        bool mr = ms;
-                        if (jr != js) {
-                            // mask of the *reference* column jr follows the read column jr
-                            mr = false;
-                            if (jr < s_ncols) {
-                                int c2 = 0, q2 = 0, qj = -2;
-                                for (int k = 0; k < s_cn && qj == -2; k++) {
-                                    const u32 cg = a.cigar[s_co + k];
-                                    const int op = cg & 0xF;
-                                    const int len = (int)(cg >> 4);
-                                    if (op == 0 || op == 7 || op == 8 || op == 1) {
-                                        if (jr < c2 + len) qj = q2 + (jr - c2);
-                                        c2 += len; q2 += len;
-                                    } else if (op == 2) {
-                                        if (jr < c2 + len) qj = -1;
-                                        c2 += len;
-                                    }
+                if (rix == -2) rix = jr - shift;
+                int s = qi < 0 ? SYM_GAP : classify_read(sp[qi]);
+                int r = rix < 0 ? SYM_GAP : classify_ref(rp[rix]);
+                if (hasq) {
+                    const bool ms = qi >= 0 && (int)qp[qi] < a.minqual;
+                    bool mr = ms;
+                    if (jr != js) {
+                        // mask of the *reference* column jr follows the read column jr
+                        mr = false;
+                        if (jr < s_ncols) {
+                            int c2 = 0, q2 = 0, qj = -2;
+                            for (int k = 0; k < s_cn && qj == -2; k++) {
+                                const u32 cg = a.cigar[s_co + k];
+                                const int op = cg & 0xF;
+                                const int len = (int)(cg >> 4);
+                                if (op == 0 || op == 7 || op == 8 || op == 1) {
+                                    if (jr < c2 + len) qj = q2 + (jr - c2);
+                                    c2 += len; q2 += len;
+                                } else if (op == 2) {
+                                    if (jr < c2 + len) qj = -1;
+                                    c2 += len;
                                 }
-                                mr = qj >= 0 && (int)qp[qj] < a.minqual;
                             }
+                            mr = qj >= 0 && (int)qp[qj] < a.minqual;
                         }
-                        if (ms) s = SYM_OTHER;
-                        if (mr) r = SYM_OTHER;
                     }
-                    if (s <= SYM_GAP && r <= SYM_GAP) {
-                        const int row = b_mis + (side * L + i) * 25;
-                        if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
-                        if (r != s) bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
-                    }
+                    if (ms) s = SYM_OTHER;
+                    if (mr) r = SYM_OTHER;
                 }
-                // read composition on the ungapped, unmasked query (statistics.py:75-83)
-                const int Lq = s_nq < L ? s_nq : L;
-                for (int t = lane; t < 2 * Lq; t += 64) {
-                    const int side = t >= Lq;
-                    const int k0 = side ? t - Lq : t;
-                    const int s = classify_ascii(sp[side ? s_nq - 1 - k0 : k0]);
-                    if (s < 4) bump<USE_LDS>(lds, raw, b_comp + (side * (L + A) + k0) * 4 + s);
+                if (s <= SYM_GAP && r <= SYM_GAP) {
+                    const int row = b_mis + (side * L + i) * 25;
+                    if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
+                    if (r != s) bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
                 }
-                // flanks (statistics.py:85-93)
-                for (int t = lane; t < 2 * A; t += 64) {
-                    const int side = t >= A;
-                    const int dist = (side ? t - A : t) + 1;
-                    if (dist <= (side ? s_nafter : s_nbefore)) {
-                        const int r = side ? rp[s_n0 - 1 + dist] : rp[-dist];
-                        if (r < 4) bump<USE_LDS>(lds, raw, b_comp + (side * (L + A) + L + dist - 1) * 4 + r);
-                    }
+            }
+            // read composition on the ungapped, unmasked query (statistics.py:75-83)
+            const int Lq = s_nq < L ? s_nq : L;
+            for (int t = lane; t < 2 * Lq; t += 64) {
+                const int side = t >= Lq;
+                const int k0 = side ? t - Lq : t;
+                const int s = classify_read(sp[side ? s_nq - 1 - k0 : k0]);
+                if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + k0) * 4 + s);
+            }
+            // flanks (statistics.py:85-93) go to their task slots
+            for (int t = lane; t < 2 * A; t += 64) {
+                const int side = t >= A;
+                const int dist = (side ? t - A : t) + 1;
+                if (dist <= (side ? s_na : s_nb)) {
+                    const int r = side ? rp[s_n0 - 1 + dist] : rp[-dist];
+                    if (r >= 0) bump<USE_LDS>(lds, raw, b_tc + ((r >> 1) & 3) * d.t_pad + 2 * L + t);
                 }
             }
         }
@@ -369,41 +477,67 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     }
 }
 
-hipError_t mdx_k_prepare(size_t lds_bytes) {
-    hipError_t e;
-    e = hipFuncSetAttribute((const void *)tabulate_kernel<true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)tabulate_kernel<true, true>,
+template <bool MASK, int NSLOT>
+static hipError_t prep_one(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, MASK, NSLOT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+hipError_t mdx_k_prepare(size_t lds_bytes) {
+    hipError_t e = hipSuccess;
+#define PREP(N)                                                       \
+    if (e == hipSuccess) e = prep_one<false, N>(lds_bytes);           \
+    if (e == hipSuccess) e = prep_one<true, N>(lds_bytes);
+    PREP(0) PREP(1) PREP(2) PREP(3) PREP(4)
+#undef PREP
+    return e;
+}
+
+template <bool USE_LDS, bool MASK, int NSLOT>
+static void launch_one(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL((tabulate_kernel<USE_LDS, MASK, NSLOT>), dim3(grid), dim3(MDX_BLOCK),
+                       USE_LDS ? lds_bytes : 0, s, a);
 }
 
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    if (mode == MDX_MODE_LDS) {
-        if (mask) hipLaunchKernelGGL((tabulate_kernel<true, true>), dim3(grid), dim3(MDX_BLOCK), lds_bytes, s, a);
-        else hipLaunchKernelGGL((tabulate_kernel<true, false>), dim3(grid), dim3(MDX_BLOCK), lds_bytes, s, a);
-    } else {
-        if (mask) hipLaunchKernelGGL((tabulate_kernel<false, true>), dim3(grid), dim3(MDX_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((tabulate_kernel<false, false>), dim3(grid), dim3(MDX_BLOCK), 0, s, a);
+    int nslot = a.dims.t_pad / 64;
+    if (nslot > MAX_NSLOT || a.dims.A > 255) nslot = 0;  // every record takes the generic walk
+    if (mode != MDX_MODE_LDS) {
+        // tables do not fit the LDS: global u64 atomics, generic code only
+        if (mask) launch_one<false, true, 0>(a, grid, 0, s);
+        else launch_one<false, false, 0>(a, grid, 0, s);
+        return;
     }
+#define CASE(N)                                                  \
+    case N:                                                      \
+        if (mask) launch_one<true, true, N>(a, grid, lds_bytes, s); \
+        else launch_one<true, false, N>(a, grid, lds_bytes, s);  \
+        break;
+    switch (nslot) { CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) }
+#undef CASE
 }
 
-// raw[w] += sum over block slots (coalesced across w)
+// raw[w] += sum over block slots; blocks are split into `parts` groups to expose parallelism
 __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__restrict__ raw, i64 w_total,
-                                       int grid) {
+                                       int grid, int parts) {
     const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= w_total) return;
+    const int part = blockIdx.y;
+    const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
     u64 acc = 0;
-    for (int b = 0; b < grid; b++) acc += partials[(i64)b * w_total + w];
-    if (acc) raw[w] += acc;
+    for (int b = b0; b < b1; b++) acc += partials[(i64)b * w_total + w];
+    if (acc) atomicAdd(&raw[w], acc);
 }
 
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, int64_t w_total, int grid,
                            hipStream_t s) {
     const int threads = 256;
     const int blocks = (int)((w_total + threads - 1) / threads);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(threads), 0, s, partials, raw, (i64)w_total, grid);
+    int parts = grid < 32 ? grid : 32;
+    if (parts < 1) parts = 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts), dim3(threads), 0, s, partials, raw,
+                       (i64)w_total, grid, parts);
 }
 
 // raw (reference orientation) -> canonical tables (mapdamage_amd/layout.py):
@@ -426,25 +560,33 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             const i64 lb = x * d.w_lib;
             // '+': 5p = left(0), 3p = right(1);  '-': 5p = right, 3p = left
             const int side = strand ? end : 1 - end;
-            const int rc = strand ? c_comp_col[col] : col;
-            v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
-            if (col < 4) v += raw[lb + d.off_m() + ((strand * 2 + side) * L + p) * 4 + rc];
+            if (col < 4) {
+                const int b = strand ? 3 - col : col;        // complement on the reverse strand
+                const int k = b ^ (b >> 1);                  // A,C,G,T -> device class A,C,T,G
+                v = raw[lb + ((strand * 2 + side) * L + p) * 25 + k] +
+                    raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + side * L + p];
+            } else {
+                const int rc = strand ? c_comp_col[col] : col;
+                v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
+            }
         } else if (i < n_mis + n_comp) {
             i64 x = i - n_mis;
-            const int b = x % 4; x /= 4;
+            const int b0 = x % 4; x /= 4;
             const int row = x % (L + A); x /= (L + A);
             const int strand = x % 2; x /= 2;
             const int end = x % 2; x /= 2;
             const i64 lb = x * d.w_lib;
             const int side = strand ? end : 1 - end;
-            const int rb = strand ? 3 - b : b;
+            const int b = strand ? 3 - b0 : b0;
+            const int k = b ^ (b >> 1);
             // 5p rows: -A..-1 (flank, distance A-row) then 1..L (read slot row-A)
             // 3p rows: -L..-1 (read slot L-1-row) then 1..A (flank, distance row-L+1)
-            int slot;
-            if (end == 1) slot = row < A ? L + (A - row) - 1 : row - A;
-            else slot = row < L ? L - 1 - row : L + (row - L + 1) - 1;
-            v = raw[lb + d.off_comp() + ((strand * 2 + side) * (L + A) + slot) * 4 + rb];
-            if (slot < L) v += raw[lb + d.off_m() + ((strand * 2 + side) * L + slot) * 4 + rb];
+            int slot = -1, dist = 0;
+            if (end == 1) { if (row < A) dist = A - row; else slot = row - A; }
+            else { if (row < L) slot = L - 1 - row; else dist = row - L + 1; }
+            const i64 tc = lb + d.off_tc() + (strand * 4 + k) * d.t_pad;
+            if (slot >= 0) v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k] + raw[tc + side * L + slot];
+            else v = raw[tc + 2 * L + side * A + dist - 1];
         } else if (i < n_mis + n_comp + n_lgd) {
             i64 x = i - n_mis - n_comp;
             const int len = x % d.lgd_max; x /= d.lgd_max;
