@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--reads", type=int, default=5_000_000, help="reads per GPU per step")
     ap.add_argument("--cpu-reads", type=int, default=5_000_000, help="bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sorted", action="store_true", help="coordinate-sort the batch (like a sorted BAM)")
     args = ap.parse_args()
 
     import torch
@@ -62,6 +63,9 @@ def main():
     L, A = 70, 10
     ref = synth.make_genome()
     batch = synth.config2_batch(ref, args.reads, seed=2 + rank)
+    if args.sorted:
+        import numpy as _np
+        batch = synth._permute_fixed(batch, _np.lexsort((batch.pos, batch.tid)))
     libs = [("synthetic", "lib1")]
     eng = DamageEngine(libs, L, A, 0, lgd_max=4096, device=dev.index)
     eng.set_reference(ref)

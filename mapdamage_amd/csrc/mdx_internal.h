@@ -10,13 +10,16 @@
 //                                    reference-base count of columns that are not plain matches
 //                                    (base columns 0..3 in A,C,T,G order = (ascii >> 1) & 3)
 //   CMP [strand 2][side 2][L][4]    read-base counts of columns that are not plain matches
-//   TC  [strand 2][base 4][T_pad]   task-indexed counts, the common case.  Task t of a read:
-//                                      t in [0, L)          left-anchored column t, read == ref == base
-//                                      t in [L, 2L)         right-anchored column t - L, same
-//                                      t in [2L, 2L+A)      left flank base at distance t - 2L + 1
-//                                      t in [2L+A, 2L+2A)   right flank base at distance t - 2L - A + 1
-//                                    one lane owns one task, so a wavefront's 64 increments land in 64
-//                                    consecutive words (T_pad is a multiple of 64): no bank conflicts
+//   TC  [strand 2][base 4][T_pad]   task-indexed counts, the common case (read base == reference
+//                                    base, or an A/C/G/T flank base).  A record has 2L + 2A tasks;
+//                                    task index tau (see the tau_* functions):
+//                                      left-anchored columns p < 64*np   -> np "pure left" slots
+//                                      right-anchored columns p < 64*np  -> np "pure right" slots
+//                                      tail: remaining left columns, remaining right columns,
+//                                            left flank (A), right flank (A)
+//                                    A wavefront handles one 64-task slot per step with lane = tau % 64,
+//                                    so its 64 increments land in 64 consecutive words (no bank
+//                                    conflicts), and the pure slots need no per-lane task decoding.
 //   LGD [kind 2][strand 2][lgd_lds] short fragment lengths
 // followed, after the last library, by one word: number of kept reads.
 // side 0 = left-anchored (columns counted from the leftmost reference coordinate),
@@ -25,19 +28,28 @@
 // finalize_kernel.
 struct MdxDims {
     int L, A, nlib, lgd_max, lgd_lds;
+    int np, rl, nt;   // pure slots per side, leftover columns per side, tail slots
     int n_task, t_pad;
     int w_mis, w_cmp, w_tc, w_lgd, w_lib;
     int64_t w_total;  // nlib * w_lib + 1
     __host__ __device__ int off_cmp() const { return w_mis; }
     __host__ __device__ int off_tc() const { return w_mis + w_cmp; }
     __host__ __device__ int off_lgd() const { return w_mis + w_cmp + w_tc; }
+    __host__ __device__ int tau_left(int p) const { return p < 64 * np ? p : p + 64 * np; }
+    __host__ __device__ int tau_right(int p) const { return p < 64 * np ? 64 * np + p : 64 * np + rl + p; }
+    __host__ __device__ int tau_lflank(int dist) const { return 128 * np + 2 * rl + dist - 1; }
+    __host__ __device__ int tau_rflank(int dist) const { return 128 * np + 2 * rl + A + dist - 1; }
 };
 
 static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd_lds) {
     MdxDims d;
     d.L = L; d.A = A; d.nlib = nlib; d.lgd_max = lgd_max; d.lgd_lds = lgd_lds;
+    d.np = L / 64;
+    if (d.np > 2) d.np = 2;
+    d.rl = L - 64 * d.np;
     d.n_task = 2 * L + 2 * A;
-    d.t_pad = (d.n_task + 63) / 64 * 64;
+    d.nt = (2 * d.rl + 2 * A + 63) / 64;
+    d.t_pad = 128 * d.np + 64 * d.nt;
     d.w_mis = 2 * 2 * L * 25;
     d.w_cmp = 2 * 2 * L * 4;
     d.w_tc = 2 * 4 * d.t_pad;

@@ -29,7 +29,6 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 #define MDX_BLOCK 512
-#define MAX_NSLOT 4
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -101,17 +100,18 @@ __device__ __forceinline__ void flag_error(u64 *err, i64 read, int code) {
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// record descriptor bits (one int per record, broadcast in phase 2)
+// record descriptor word w1 (one int per record, broadcast in phase 2)
 #define D_REV 1
 #define D_SIMPLE 2
 #define D_HASQ 4
+#define D_FULL 8        // plain-match record with every task present (nq >= L, both flanks complete)
 #define D_NB_SHIFT 8    // nbefore, 8 bits
 #define D_NA_SHIFT 16   // nafter, 8 bits
 
 // Rare path of a plain-match record column: (ch, rch) is not a plain match.
 template <bool USE_LDS>
 __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b_cmp, int L, int side,
-                                            int p, u32 ch, int rch, bool masked) {
+                                         int p, u32 ch, int rch, bool masked) {
     const int s = classify_read(ch);
     if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + p) * 4 + s);  // statistics.py:75-83
     if (!masked) {
@@ -124,7 +124,12 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
     }
 }
 
-template <bool USE_LDS, bool MASK, int NSLOT>
+#define NPX (NP > 0 ? NP : 1)
+#define NTX (NT > 0 ? NT : 1)
+
+// NT == 0: no fast path (every record takes the generic CIGAR walk); otherwise NP pure slots per
+// side and NT tail slots, matching MdxDims::np / nt.
+template <bool USE_LDS, bool MASK, int NP, int NT>
 __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -140,19 +145,28 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         __syncthreads();
     }
 
-    // per-lane task constants (NSLOT > 0): task t = lane + 64 k
-    //   column offset from (rbase - A):  cp = coef * nq + c0
-    //   validity:                         thr <= (read task ? nq : left flank ? nbefore : nafter)
-    int t_c0[MAX_NSLOT], t_coef[MAX_NSLOT], t_thr[MAX_NSLOT], t_kind[MAX_NSLOT];
+    // per-lane constants of the tail slots: tail index i = lane + 64 k covers, in order, the left
+    // columns p >= 64 NP, the right columns p >= 64 NP, the left flank and the right flank.
+    //   reference offset from (rbase - A): cp = coef * nq + c0;  SEQ offset: cq = coefq * nq + cq0
+    //   hit test: ((ch & m1) | o1) == (rch & m2)   (flank lanes: "reference byte is A/C/G/T")
+    //   validity (records with missing tasks): thr <= (read column ? nq : left flank ? nb : na)
+    int t_c0[NTX], t_cq0[NTX], t_coef[NTX], t_coefq[NTX], t_thr[NTX], t_kind[NTX], t_p[NTX];
+    u32 t_m1[NTX], t_o1[NTX], t_m2[NTX];
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-        const int t = lane + 64 * k;
-        int c0 = 0, coef = 0, thr = 0x7FFFFFFF, kind = 4;  // kind: 0/1 read column, 2/3 flank, 4 none
-        if (t < L) { c0 = t + A; thr = t + 1; kind = 0; }
-        else if (t < 2 * L) { const int p = t - L; coef = 1; c0 = A - 1 - p; thr = p + 1; kind = 1; }
-        else if (t < 2 * L + A) { const int dist = t - 2 * L + 1; c0 = A - dist; thr = dist; kind = 2; }
-        else if (t < d.n_task) { const int dist = t - 2 * L - A + 1; coef = 1; c0 = A - 1 + dist; thr = dist; kind = 3; }
-        t_c0[k] = c0; t_coef[k] = coef; t_thr[k] = thr; t_kind[k] = kind;
+    for (int k = 0; k < NT; k++) {
+        const int i = lane + 64 * k;
+        int c0 = A, cq0 = 0, coef = 0, coefq = 0, thr = 0x7FFFFFFF, kind = 4, p = 0;
+        u32 m1 = 0, o1 = 1, m2 = 0;
+        if (i < d.rl) { p = 64 * NP + i; c0 = p + A; cq0 = p; thr = p + 1; kind = 0; m1 = 0xFF; o1 = 0; m2 = ~0u; }
+        else if (i < 2 * d.rl) {
+            p = 64 * NP + i - d.rl; coef = 1; coefq = 1; c0 = A - 1 - p; cq0 = -1 - p; thr = p + 1; kind = 1;
+            m1 = 0xFF; o1 = 0; m2 = ~0u;
+        } else if (i < 2 * d.rl + A) { const int dist = i - 2 * d.rl + 1; c0 = A - dist; thr = dist; kind = 2; o1 = 0; m2 = 0x80000000u; }
+        else if (i < 2 * d.rl + 2 * A) {
+            const int dist = i - 2 * d.rl - A + 1; coef = 1; c0 = A - 1 + dist; thr = dist; kind = 3; o1 = 0; m2 = 0x80000000u;
+        }
+        t_c0[k] = c0; t_cq0[k] = cq0; t_coef[k] = coef; t_coefq[k] = coefq; t_thr[k] = thr; t_kind[k] = kind;
+        t_p[k] = p; t_m1[k] = m1; t_o1[k] = o1; t_m2[k] = m2;
     }
 
     const i64 ntiles = (a.n_reads + 63) >> 6;
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         const bool valid = ri < a.n_reads;
         const u32 fl = valid ? (u32)a.flag[ri] : 0x4u;
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
-        int desc = 0, libid = 0, nq = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
+        int w0 = 0, w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         u32 sq = 0, cig_o = 0;
         i64 rbase = 0;
         int lkey = -1;  // fragment-length key for the LDS histogram
@@ -230,10 +244,11 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 sq = so + (u32)qs;
                 const int nbefore = pos < A ? (int)pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
-                desc = rev | ((sI == 0 && sDN == 0 && rlen > 0) ? D_SIMPLE : 0) |
-                       ((nbefore > 255 ? 255 : nbefore) << D_NB_SHIFT) | ((nafter > 255 ? 255 : nafter) << D_NA_SHIFT);
-                if (A > 255) desc &= ~D_SIMPLE;  // flank lengths do not fit the packed descriptor
-                if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) desc |= D_HASQ;
+                const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 65536;
+                w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
+                if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
+                if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
+                w0 = (nq & 0xFFFF) | (libid << 16);
                 // statistics.py:117-126
                 int kind = -1;
                 i64 flen = 0;
@@ -285,70 +300,124 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         // ------------------------------------------------------------ phase 2a: plain records
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
-        if (NSLOT > 0) {
-            u64 todo = __ballot(kept && (desc & D_SIMPLE));
+        if (NT > 0) {
+            u64 todo = __ballot(kept && (w1 & D_SIMPLE));
             todo_g = todo_all & ~todo;
             // software pipeline: *_n = record whose loads are in flight, *_c = record being counted
-            u32 ch_n[MAX_NSLOT], ch_c[MAX_NSLOT], q_n[MAX_NSLOT], q_c[MAX_NSLOT];
-            int rch_n[MAX_NSLOT], rch_c[MAX_NSLOT];
-            int desc_n = 0, nq_n = 0, lib_n = 0;
+            u32 chL_n[NPX], chR_n[NPX], chT_n[NTX], chL_c[NPX], chR_c[NPX], chT_c[NTX];
+            int rL_n[NPX], rR_n[NPX], rT_n[NTX], rL_c[NPX], rR_c[NPX], rT_c[NTX];
+            u32 qL_n[NPX], qR_n[NPX], qT_n[NTX], qL_c[NPX], qR_c[NPX], qT_c[NTX];
+            int w0_n = 0, w1_n = 0;
 
             auto issue = [&](int j) {
-                desc_n = rl(desc, j);
-                nq_n = rl(nq, j);
-                lib_n = rl(libid, j);
+                w0_n = rl(w0, j);
+                w1_n = rl(w1, j);
                 const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
                 const u32 s_sq = (u32)rl((int)sq, j);
                 const i8 *__restrict__ refA = (const i8 *)a.ref + (s_rbase - A);
-                const u8 *__restrict__ seqA = a.seq + ((i64)s_sq - A);
-                const u8 *__restrict__ qualA = MASK ? a.qual + ((i64)s_sq - A) : nullptr;
-                const int nb = (desc_n >> D_NB_SHIFT) & 0xFF, na = (desc_n >> D_NA_SHIFT) & 0xFF;
-                const bool full = nq_n >= L && nb == A && na == A;  // every task of the record exists
+                const u8 *__restrict__ seqP = a.seq + s_sq;
+                const u8 *__restrict__ qualP = MASK ? a.qual + s_sq : nullptr;
+                const int s_nq = w0_n & 0xFFFF;
+                if (w1_n & D_FULL) {
 #pragma unroll
-                for (int k = 0; k < NSLOT; k++) {
-                    const u32 cp = (u32)(t_coef[k] * nq_n + t_c0[k]);
-                    int r = -1;
-                    u32 c = 0x200u, q = 0xFFu;  // 0x200: task does not exist for this record
-                    bool ok = t_kind[k] < 4;
-                    if (!full) ok = t_thr[k] <= (t_kind[k] < 2 ? nq_n : (t_kind[k] == 2 ? nb : na));
-                    if (ok) {
-                        r = refA[cp];
-                        if (t_kind[k] < 2) {
-                            c = seqA[cp];
-                            if (MASK && (desc_n & D_HASQ)) q = qualA[cp];
-                        } else {
-                            c = (u32)r & 0xFFu;  // flank base "matches itself" iff it is A/C/G/T
-                        }
+                    for (int k = 0; k < NP; k++) {
+                        const u32 p = (u32)(lane + 64 * k);
+                        rL_n[k] = refA[p + (u32)A];
+                        chL_n[k] = seqP[p];
+                        const u32 cqr = (u32)(s_nq - 1 - 64 * k) - (u32)lane;
+                        rR_n[k] = refA[cqr + (u32)A];
+                        chR_n[k] = seqP[cqr];
+                        if (MASK) { qL_n[k] = qualP[p]; qR_n[k] = qualP[cqr]; }
                     }
-                    rch_n[k] = r; ch_n[k] = c; q_n[k] = q;
+#pragma unroll
+                    for (int k = 0; k < NT; k++) {
+                        const u32 cp = (u32)(t_coef[k] * s_nq + t_c0[k]);
+                        const u32 cq = (u32)(t_coefq[k] * s_nq + t_cq0[k]);
+                        rT_n[k] = refA[cp];
+                        chT_n[k] = seqP[cq];
+                        if (MASK) qT_n[k] = qualP[cq];
+                    }
+                } else {
+                    // some tasks do not exist (short read or contig edge): clamp their addresses
+                    const int nb = (w1_n >> D_NB_SHIFT) & 0xFF, na = (w1_n >> D_NA_SHIFT) & 0xFF;
+#pragma unroll
+                    for (int k = 0; k < NP; k++) {
+                        const int p = lane + 64 * k;
+                        const u32 cql = (u32)min(p, s_nq - 1);
+                        rL_n[k] = refA[(u32)(p + A)];
+                        chL_n[k] = seqP[cql];
+                        const u32 cqr = (u32)max(s_nq - 1 - p, 0);
+                        rR_n[k] = refA[cqr + (u32)A];
+                        chR_n[k] = seqP[cqr];
+                        if (MASK) { qL_n[k] = qualP[cql]; qR_n[k] = qualP[cqr]; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; k++) {
+                        const bool ok = t_thr[k] <= (t_kind[k] < 2 ? s_nq : (t_kind[k] == 2 ? nb : na));
+                        const u32 cp = ok ? (u32)(t_coef[k] * s_nq + t_c0[k]) : (u32)A;
+                        const u32 cq = ok ? (u32)(t_coefq[k] * s_nq + t_cq0[k]) : 0u;
+                        rT_n[k] = refA[cp];
+                        chT_n[k] = seqP[cq];
+                        if (MASK) qT_n[k] = qualP[cq];
+                    }
                 }
             };
 
             if (todo) issue(__ffsll((long long)todo) - 1);
             while (todo) {
                 todo &= todo - 1;
-                const int s_desc = desc_n, s_lib = lib_n;
+                const int s_w0 = w0_n, s_w1 = w1_n;
 #pragma unroll
-                for (int k = 0; k < NSLOT; k++) { ch_c[k] = ch_n[k]; rch_c[k] = rch_n[k]; q_c[k] = q_n[k]; }
+                for (int k = 0; k < NP; k++) {
+                    chL_c[k] = chL_n[k]; chR_c[k] = chR_n[k]; rL_c[k] = rL_n[k]; rR_c[k] = rR_n[k];
+                    if (MASK) { qL_c[k] = qL_n[k]; qR_c[k] = qR_n[k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    chT_c[k] = chT_n[k]; rT_c[k] = rT_n[k];
+                    if (MASK) qT_c[k] = qT_n[k];
+                }
                 if (todo) issue(__ffsll((long long)todo) - 1);
 
-                const int rev = s_desc & D_REV;
-                const int lb = s_lib * d.w_lib;
-                const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad + lane;
+                const int rev = s_w1 & D_REV;
+                const int s_nq = s_w0 & 0xFFFF;
+                const int lb = (int)((u32)s_w0 >> 16) * d.w_lib;
+                const int tcw = d.t_pad;
+                const int base_v = lb + d.off_tc() + rev * 4 * tcw + lane;  // word index of (code 0, tau = lane)
+                const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+                const int minq = (MASK && (s_w1 & D_HASQ)) ? a.minqual : 0;  // align.py:65-71
+                const bool full = s_w1 & D_FULL;
+                const int nb = (s_w1 >> D_NB_SHIFT) & 0xFF, na = (s_w1 >> D_NA_SHIFT) & 0xFF;
 #pragma unroll
-                for (int k = 0; k < NSLOT; k++) {
-                    const bool masked = MASK && (int)q_c[k] < a.minqual;  // align.py:65-71
-                    const bool hit = (int)ch_c[k] == rch_c[k] && !masked;
-                    if (hit) bump<USE_LDS>(lds, raw, b_tc + 64 * k + (int)((ch_c[k] >> 1) & 3u) * d.t_pad);
-                    const bool miss = !hit && t_kind[k] < 2 && ch_c[k] < 0x100u;
-                    if (__ballot(miss)) {
-                        if (miss) {
-                            const int t = lane + 64 * k;
-                            const int side = t >= L;
-                            rare_column<USE_LDS>(lds, raw, lb + rev * 2 * L * 25, lb + d.off_cmp() + rev * 2 * L * 4,
-                                                 L, side, side ? t - L : t, ch_c[k], rch_c[k], masked);
-                        }
+                for (int k = 0; k < NP; k++) {
+                    const int p = lane + 64 * k;
+                    const bool ok = full || p < s_nq;
+                    {
+                        const bool masked = MASK && (int)qL_c[k] < minq;
+                        const bool hit = ok && (int)chL_c[k] == rL_c[k] && !masked;
+                        if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * k + (int)__umul24((u32)(rL_c[k] >> 1) & 3u, (u32)tcw));
+                        const bool miss = ok && !hit;
+                        if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 0, p, chL_c[k], rL_c[k], masked);
                     }
+                    {
+                        const bool masked = MASK && (int)qR_c[k] < minq;
+                        const bool hit = ok && (int)chR_c[k] == rR_c[k] && !masked;
+                        if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (NP + k) + (int)__umul24((u32)(rR_c[k] >> 1) & 3u, (u32)tcw));
+                        const bool miss = ok && !hit;
+                        if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 1, p, chR_c[k], rR_c[k], masked);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    bool ok = true;
+                    if (!full) ok = t_thr[k] <= (t_kind[k] < 2 ? s_nq : (t_kind[k] == 2 ? nb : na));
+                    const bool masked = MASK && t_kind[k] < 2 && (int)qT_c[k] < minq;
+                    const u32 t1 = (chT_c[k] & t_m1[k]) | t_o1[k];
+                    const u32 t2 = (u32)rT_c[k] & t_m2[k];
+                    const bool hit = ok && t1 == t2 && !masked;
+                    if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (2 * NP + k) + (int)__umul24((u32)(rT_c[k] >> 1) & 3u, (u32)tcw));
+                    const bool miss = ok && !hit && t_kind[k] < 2;
+                    if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, t_kind[k], t_p[k], chT_c[k], rT_c[k], masked);
                 }
             }
         }
@@ -357,7 +426,7 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         while (todo_g) {
             const int j = __ffsll((long long)todo_g) - 1;
             todo_g &= todo_g - 1;
-            const int s_desc = rl(desc, j);
+            const int s_w1 = rl(w1, j);
             const int s_nq = rl(nq, j);
             const int s_n0 = rl(n0, j);
             const int s_ncols = rl(ncols, j);
@@ -366,8 +435,8 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
             const int s_cn = rl(cig_n, j);
             const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
             const u32 s_sq = (u32)rl((int)sq, j);
-            const int rev = s_desc & D_REV;
-            const bool hasq = MASK && (s_desc & D_HASQ);
+            const int rev = s_w1 & D_REV;
+            const bool hasq = MASK && (s_w1 & D_HASQ);
             const int lb = rl(libid, j) * d.w_lib;
             const int b_mis = lb + rev * 2 * L * 25;
             const int b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
@@ -464,7 +533,7 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 const int dist = (side ? t - A : t) + 1;
                 if (dist <= (side ? s_na : s_nb)) {
                     const int r = side ? rp[s_n0 - 1 + dist] : rp[-dist];
-                    if (r >= 0) bump<USE_LDS>(lds, raw, b_tc + ((r >> 1) & 3) * d.t_pad + 2 * L + t);
+                    if (r >= 0) bump<USE_LDS>(lds, raw, b_tc + ((r >> 1) & 3) * d.t_pad + (side ? d.tau_rflank(dist) : d.tau_lflank(dist)));
                 }
             }
         }
@@ -477,45 +546,55 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     }
 }
 
-template <bool MASK, int NSLOT>
+template <bool MASK, int NP, int NT>
 static hipError_t prep_one(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void *)tabulate_kernel<true, MASK, NSLOT>,
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, MASK, NP, NT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
+#define FOR_EACH_FAST_VARIANT(X) X(0, 1) X(0, 2) X(1, 1) X(1, 2) X(2, 1) X(2, 2)
+
 hipError_t mdx_k_prepare(size_t lds_bytes) {
-    hipError_t e = hipSuccess;
-#define PREP(N)                                                       \
-    if (e == hipSuccess) e = prep_one<false, N>(lds_bytes);           \
-    if (e == hipSuccess) e = prep_one<true, N>(lds_bytes);
-    PREP(0) PREP(1) PREP(2) PREP(3) PREP(4)
+    hipError_t e = prep_one<false, 0, 0>(lds_bytes);
+    if (e == hipSuccess) e = prep_one<true, 0, 0>(lds_bytes);
+#define PREP(P, T)                                                   \
+    if (e == hipSuccess) e = prep_one<false, P, T>(lds_bytes);       \
+    if (e == hipSuccess) e = prep_one<true, P, T>(lds_bytes);
+    FOR_EACH_FAST_VARIANT(PREP)
 #undef PREP
     return e;
 }
 
-template <bool USE_LDS, bool MASK, int NSLOT>
+template <bool USE_LDS, bool MASK, int NP, int NT>
 static void launch_one(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL((tabulate_kernel<USE_LDS, MASK, NSLOT>), dim3(grid), dim3(MDX_BLOCK),
+    hipLaunchKernelGGL((tabulate_kernel<USE_LDS, MASK, NP, NT>), dim3(grid), dim3(MDX_BLOCK),
                        USE_LDS ? lds_bytes : 0, s, a);
 }
 
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    int nslot = a.dims.t_pad / 64;
-    if (nslot > MAX_NSLOT || a.dims.A > 255) nslot = 0;  // every record takes the generic walk
+    const MdxDims &d = a.dims;
     if (mode != MDX_MODE_LDS) {
         // tables do not fit the LDS: global u64 atomics, generic code only
-        if (mask) launch_one<false, true, 0>(a, grid, 0, s);
-        else launch_one<false, false, 0>(a, grid, 0, s);
+        if (mask) launch_one<false, true, 0, 0>(a, grid, 0, s);
+        else launch_one<false, false, 0, 0>(a, grid, 0, s);
         return;
     }
-#define CASE(N)                                                  \
-    case N:                                                      \
-        if (mask) launch_one<true, true, N>(a, grid, lds_bytes, s); \
-        else launch_one<true, false, N>(a, grid, lds_bytes, s);  \
-        break;
-    switch (nslot) { CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) }
+    // the fast path keeps speculative addresses within the 256-byte guard band of the reference
+    const bool fast = d.nt >= 1 && d.nt <= 2 && d.np <= 2 && d.L + d.A <= 255 && d.L < 64 * (d.np + 1);
+    bool done = false;
+#define CASE(P, T)                                                        \
+    if (fast && !done && d.np == P && d.nt == T) {                        \
+        if (mask) launch_one<true, true, P, T>(a, grid, lds_bytes, s);    \
+        else launch_one<true, false, P, T>(a, grid, lds_bytes, s);        \
+        done = true;                                                      \
+    }
+    FOR_EACH_FAST_VARIANT(CASE)
 #undef CASE
+    if (!done) {
+        if (mask) launch_one<true, true, 0, 0>(a, grid, lds_bytes, s);
+        else launch_one<true, false, 0, 0>(a, grid, lds_bytes, s);
+    }
 }
 
 // raw[w] += sum over block slots; blocks are split into `parts` groups to expose parallelism
@@ -564,7 +643,7 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
                 const int b = strand ? 3 - col : col;        // complement on the reverse strand
                 const int k = b ^ (b >> 1);                  // A,C,G,T -> device class A,C,T,G
                 v = raw[lb + ((strand * 2 + side) * L + p) * 25 + k] +
-                    raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + side * L + p];
+                    raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p))];
             } else {
                 const int rc = strand ? c_comp_col[col] : col;
                 v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
@@ -585,8 +664,8 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             if (end == 1) { if (row < A) dist = A - row; else slot = row - A; }
             else { if (row < L) slot = L - 1 - row; else dist = row - L + 1; }
             const i64 tc = lb + d.off_tc() + (strand * 4 + k) * d.t_pad;
-            if (slot >= 0) v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k] + raw[tc + side * L + slot];
-            else v = raw[tc + 2 * L + side * A + dist - 1];
+            if (slot >= 0) v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k] + raw[tc + (side ? d.tau_right(slot) : d.tau_left(slot))];
+            else v = raw[tc + (side ? d.tau_rflank(dist) : d.tau_lflank(dist))];
         } else if (i < n_mis + n_comp + n_lgd) {
             i64 x = i - n_mis - n_comp;
             const int len = x % d.lgd_max; x /= d.lgd_max;
