@@ -21,6 +21,8 @@
 // strings literally instead, so the two share no derivation.
 #include "mdx_internal.h"
 
+#include <type_traits>
+
 typedef uint8_t u8;
 typedef int8_t i8;
 typedef uint16_t u16;
@@ -47,6 +49,8 @@ __constant__ u8 c_col[25] = {
     /* T> */ 13, 7, 31, 12, 17,
     /* G> */ 4, 14, 15, 31, 19,
     /* -> */ 20, 22, 21, 23, 31};
+// raw MIS columns whose reference symbol is class k (three substitutions and the deletion)
+__constant__ u8 c_refcols[16] = {8, 9, 6, 16, 11, 5, 10, 18, 13, 7, 12, 17, 4, 14, 15, 19};
 // final column seen from the reverse strand (complement both symbols), for columns >= 4
 __constant__ u8 c_comp_col[25] = {3, 2, 1, 0, 5, 4, 7, 6, 12, 13, 14, 15, 8,
                                   9, 10, 11, 17, 16, 19, 18, 21, 20, 23, 22, 24};
@@ -108,18 +112,27 @@ __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_rea
 #define D_NB_SHIFT 8    // nbefore, 8 bits
 #define D_NA_SHIFT 16   // nafter, 8 bits
 
-// Rare path of a plain-match record column: (ch, rch) is not a plain match.
+// (final column - 4) of substitution ref>read for classes A,C,T,G, 4 bits per [ref][read] entry
+#define SUB_LUT 0x0ba0803961072540ull
+//   A>: -,4,5,2   C>: 7,-,1,6   T>: 9,3,-,8   G>: 0,10,11,-   (entry index = ref * 4 + read)
+
+// Rare path of a plain-match record column: (ch, rch) is not a plain match.  The read base goes to
+// CMP (statistics.py:75-83); a substitution/indel goes to its MIS column only — the accompanying
+// reference-base count of statistics.py:30 is derived by finalize_kernel (mis[r] = matches +
+// sum of the r>x columns).
 template <bool USE_LDS>
 __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b_cmp, int L, int side,
-                                         int p, u32 ch, int rch, bool masked) {
+                                            int p, u32 ch, int rch, bool masked) {
     const int s = classify_read(ch);
-    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + p) * 4 + s);  // statistics.py:75-83
-    if (!masked) {
+    const int sp = side * L + p;
+    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + sp * 4 + s);
+    if (!masked && s <= SYM_GAP) {
         const int r = classify_ref(rch);
-        if (s <= SYM_GAP && r <= SYM_GAP && r != s) {  // statistics.py:26-35
-            const int row = b_mis + (side * L + p) * 25;
-            if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
-            bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
+        if (r <= SYM_GAP && r != s) {  // statistics.py:26-35
+            int col;
+            if (r < 4 && s < 4) col = 4 + (int)((SUB_LUT >> (4 * (r * 4 + s))) & 15ull);
+            else col = c_col[r * 5 + s];
+            bump<USE_LDS>(lds, raw, b_mis + sp * 25 + col);
         }
     }
 }
@@ -386,38 +399,41 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 const int base_v = lb + d.off_tc() + rev * 4 * tcw + lane;  // word index of (code 0, tau = lane)
                 const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
                 const int minq = (MASK && (s_w1 & D_HASQ)) ? a.minqual : 0;  // align.py:65-71
-                const bool full = s_w1 & D_FULL;
                 const int nb = (s_w1 >> D_NB_SHIFT) & 0xFF, na = (s_w1 >> D_NA_SHIFT) & 0xFF;
+                // FULL: every task of the record exists (the common case: no validity tests)
+                const bool FULL = s_w1 & D_FULL;
+                {
 #pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const int p = lane + 64 * k;
-                    const bool ok = full || p < s_nq;
-                    {
-                        const bool masked = MASK && (int)qL_c[k] < minq;
-                        const bool hit = ok && (int)chL_c[k] == rL_c[k] && !masked;
-                        if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * k + (int)__umul24((u32)(rL_c[k] >> 1) & 3u, (u32)tcw));
-                        const bool miss = ok && !hit;
-                        if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 0, p, chL_c[k], rL_c[k], masked);
+                    for (int k = 0; k < NP; k++) {
+                        const int p = lane + 64 * k;
+                        const bool ok = FULL || p < s_nq;
+                        {
+                            const bool masked = MASK && (int)qL_c[k] < minq;
+                            const bool hit = ok && (int)chL_c[k] == rL_c[k] && !masked;
+                            if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * k + (int)__umul24((u32)(rL_c[k] >> 1) & 3u, (u32)tcw));
+                            const bool miss = ok && !hit;
+                            if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 0, p, chL_c[k], rL_c[k], masked);
+                        }
+                        {
+                            const bool masked = MASK && (int)qR_c[k] < minq;
+                            const bool hit = ok && (int)chR_c[k] == rR_c[k] && !masked;
+                            if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (NP + k) + (int)__umul24((u32)(rR_c[k] >> 1) & 3u, (u32)tcw));
+                            const bool miss = ok && !hit;
+                            if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 1, p, chR_c[k], rR_c[k], masked);
+                        }
                     }
-                    {
-                        const bool masked = MASK && (int)qR_c[k] < minq;
-                        const bool hit = ok && (int)chR_c[k] == rR_c[k] && !masked;
-                        if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (NP + k) + (int)__umul24((u32)(rR_c[k] >> 1) & 3u, (u32)tcw));
-                        const bool miss = ok && !hit;
-                        if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 1, p, chR_c[k], rR_c[k], masked);
-                    }
-                }
 #pragma unroll
-                for (int k = 0; k < NT; k++) {
-                    bool ok = true;
-                    if (!full) ok = t_thr[k] <= (t_kind[k] < 2 ? s_nq : (t_kind[k] == 2 ? nb : na));
-                    const bool masked = MASK && t_kind[k] < 2 && (int)qT_c[k] < minq;
-                    const u32 t1 = (chT_c[k] & t_m1[k]) | t_o1[k];
-                    const u32 t2 = (u32)rT_c[k] & t_m2[k];
-                    const bool hit = ok && t1 == t2 && !masked;
-                    if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (2 * NP + k) + (int)__umul24((u32)(rT_c[k] >> 1) & 3u, (u32)tcw));
-                    const bool miss = ok && !hit && t_kind[k] < 2;
-                    if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, t_kind[k], t_p[k], chT_c[k], rT_c[k], masked);
+                    for (int k = 0; k < NT; k++) {
+                        bool ok = true;
+                        if (!FULL) ok = t_thr[k] <= (t_kind[k] < 2 ? s_nq : (t_kind[k] == 2 ? nb : na));
+                        const bool masked = MASK && t_kind[k] < 2 && (int)qT_c[k] < minq;
+                        const u32 t1 = (chT_c[k] & t_m1[k]) | t_o1[k];
+                        const u32 t2 = (u32)rT_c[k] & t_m2[k];
+                        const bool hit = ok && t1 == t2 && !masked;
+                        if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (2 * NP + k) + (int)__umul24((u32)(rT_c[k] >> 1) & 3u, (u32)tcw));
+                        const bool miss = ok && !hit && t_kind[k] < 2;
+                        if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, t_kind[k], t_p[k], chT_c[k], rT_c[k], masked);
+                    }
                 }
             }
         }
@@ -514,9 +530,10 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                     if (mr) r = SYM_OTHER;
                 }
                 if (s <= SYM_GAP && r <= SYM_GAP) {
+                    // the reference-base count of a mismatching column is derived at finalisation
                     const int row = b_mis + (side * L + i) * 25;
-                    if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
                     if (r != s) bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
+                    else if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
                 }
             }
             // read composition on the ungapped, unmasked query (statistics.py:75-83)
@@ -642,8 +659,11 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             if (col < 4) {
                 const int b = strand ? 3 - col : col;        // complement on the reverse strand
                 const int k = b ^ (b >> 1);                  // A,C,G,T -> device class A,C,T,G
-                v = raw[lb + ((strand * 2 + side) * L + p) * 25 + k] +
+                const i64 row = lb + ((strand * 2 + side) * L + p) * 25;
+                // matches (gapped records / plain records) + every column whose reference symbol is k
+                v = raw[row + k] +
                     raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p))];
+                for (int x = 0; x < 4; x++) v += raw[row + c_refcols[k * 4 + x]];
             } else {
                 const int rc = strand ? c_comp_col[col] : col;
                 v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
