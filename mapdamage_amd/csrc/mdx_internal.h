@@ -6,20 +6,19 @@
 #include <stdint.h>
 
 // Raw (reference-orientation) accumulator layout, in words, per library:
-//   MIS [strand 2][side 2][L][25]   rare events: substitutions, indels, soft clips, and the
-//                                    reference-base count of columns that are not plain matches
-//                                    (base columns 0..3 in A,C,T,G order = (ascii >> 1) & 3)
+//   MIS [strand 2][side 2][L][25]   rare events: substitutions, indels, soft clips; base columns
+//                                    0..3 (A,C,T,G order = (ascii >> 1) & 3) count the matching
+//                                    columns of gapped records
 //   CMP [strand 2][side 2][L][4]    read-base counts of columns that are not plain matches
-//   TC  [strand 2][base 4][T_pad]   task-indexed counts, the common case (read base == reference
-//                                    base, or an A/C/G/T flank base).  A record has 2L + 2A tasks;
-//                                    task index tau (see the tau_* functions):
-//                                      left-anchored columns p < 64*np   -> np "pure left" slots
-//                                      right-anchored columns p < 64*np  -> np "pure right" slots
-//                                      tail: remaining left columns, remaining right columns,
-//                                            left flank (A), right flank (A)
-//                                    A wavefront handles one 64-task slot per step with lane = tau % 64,
-//                                    so its 64 increments land in 64 consecutive words (no bank
-//                                    conflicts), and the pure slots need no per-lane task decoding.
+//   TC  [strand 2][base 4][256]     the common case of plain (ungapped, complete) records: read base ==
+//                                    reference base, or an A/C/G/T flank base.  One lane of the
+//                                    wavefront owns four consecutive bytes (one dword) of a record:
+//                                      lanes [0, nl4)            left-anchored columns 4m .. 4m+3
+//                                      lanes [nl4, 2 nl4)        right-anchored columns 4m+3 .. 4m (byte order)
+//                                      lanes [2 nl4, +nf4)       left flank, distances 4(m+1) .. 4m+1
+//                                      lanes [2 nl4 + nf4, +nf4) right flank, distances 4m+1 .. 4m+4
+//                                    and the table index of (lane, byte j) is tau = 64 j + lane, so the
+//                                    64 increments of one ds_add_u32 fall in 64 consecutive words.
 //   LGD [kind 2][strand 2][lgd_lds] short fragment lengths
 // followed, after the last library, by one word: number of kept reads.
 // side 0 = left-anchored (columns counted from the leftmost reference coordinate),
@@ -28,28 +27,41 @@
 // finalize_kernel.
 struct MdxDims {
     int L, A, nlib, lgd_max, lgd_lds;
-    int np, rl, nt;   // pure slots per side, leftover columns per side, tail slots
-    int n_task, t_pad;
+    int nl4, nf4, apad;   // dword lanes per side, per flank; 4 * nf4
+    int t_pad;            // 256
     int w_mis, w_cmp, w_tc, w_lgd, w_lib;
-    int64_t w_total;  // nlib * w_lib + 1
+    int64_t w_total;      // nlib * w_lib + 1
     __host__ __device__ int off_cmp() const { return w_mis; }
     __host__ __device__ int off_tc() const { return w_mis + w_cmp; }
     __host__ __device__ int off_lgd() const { return w_mis + w_cmp + w_tc; }
-    __host__ __device__ int tau_left(int p) const { return p < 64 * np ? p : p + 64 * np; }
-    __host__ __device__ int tau_right(int p) const { return p < 64 * np ? 64 * np + p : 64 * np + rl + p; }
-    __host__ __device__ int tau_lflank(int dist) const { return 128 * np + 2 * rl + dist - 1; }
-    __host__ __device__ int tau_rflank(int dist) const { return 128 * np + 2 * rl + A + dist - 1; }
+    __host__ __device__ int tau_left(int p) const { return 64 * (p & 3) + (p >> 2); }
+    __host__ __device__ int tau_right(int p) const { return 64 * (3 - (p & 3)) + nl4 + (p >> 2); }
+    __host__ __device__ int tau_lflank(int dist) const {
+        if (nl4 == 0) return dist - 1;  // no fast path: flank tasks numbered densely
+        const int m = (dist - 1) >> 2;
+        return 64 * (4 * (m + 1) - dist) + 2 * nl4 + m;
+    }
+    __host__ __device__ int tau_rflank(int dist) const {
+        if (nl4 == 0) return A + dist - 1;
+        const int m = (dist - 1) >> 2;
+        return 64 * (dist - 1 - 4 * m) + 2 * nl4 + nf4 + m;
+    }
+    // the dword fast path needs all its lanes in one wavefront and its flank window in the guard band
+    __host__ __device__ bool fast_ok() const { return nl4 > 0 && apad <= 248 && L + A <= 248; }
 };
 
 static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd_lds) {
     MdxDims d;
     d.L = L; d.A = A; d.nlib = nlib; d.lgd_max = lgd_max; d.lgd_lds = lgd_lds;
-    d.np = L / 64;
-    if (d.np > 2) d.np = 2;
-    d.rl = L - 64 * d.np;
-    d.n_task = 2 * L + 2 * A;
-    d.nt = (2 * d.rl + 2 * A + 63) / 64;
-    d.t_pad = 128 * d.np + 64 * d.nt;
+    d.nl4 = (L + 3) / 4;
+    d.nf4 = (A + 3) / 4;
+    d.apad = 4 * d.nf4;
+    d.t_pad = 256;
+    if (2 * d.nl4 + 2 * d.nf4 > 64 || d.apad > 248 || L + A > 248) {  // no fast path
+        d.nl4 = 0; d.nf4 = 0;
+        d.t_pad = ((2 * A + 63) / 64) * 64;
+        if (d.t_pad == 0) d.t_pad = 64;
+    }
     d.w_mis = 2 * 2 * L * 25;
     d.w_cmp = 2 * 2 * L * 4;
     d.w_tc = 2 * 4 * d.t_pad;

@@ -27,6 +27,7 @@ typedef uint8_t u8;
 typedef int8_t i8;
 typedef uint16_t u16;
 typedef uint32_t u32;
+typedef u32 __attribute__((aligned(1))) u32_u;
 typedef unsigned long long u64;
 typedef long long i64;
 
@@ -137,12 +138,9 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
     }
 }
 
-#define NPX (NP > 0 ? NP : 1)
-#define NTX (NT > 0 ? NT : 1)
-
-// NT == 0: no fast path (every record takes the generic CIGAR walk); otherwise NP pure slots per
-// side and NT tail slots, matching MdxDims::np / nt.
-template <bool USE_LDS, bool MASK, int NP, int NT>
+// FAST: the dword-lane path for plain, complete records (MdxDims::fast_ok()); otherwise every
+// record takes the generic CIGAR walk.
+template <bool USE_LDS, bool MASK, bool FAST>
 __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -158,29 +156,31 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         __syncthreads();
     }
 
-    // per-lane constants of the tail slots: tail index i = lane + 64 k covers, in order, the left
-    // columns p >= 64 NP, the right columns p >= 64 NP, the left flank and the right flank.
-    //   reference offset from (rbase - A): cp = coef * nq + c0;  SEQ offset: cq = coefq * nq + cq0
-    //   hit test: ((ch & m1) | o1) == (rch & m2)   (flank lanes: "reference byte is A/C/G/T")
-    //   validity (records with missing tasks): thr <= (read column ? nq : left flank ? nb : na)
-    int t_c0[NTX], t_cq0[NTX], t_coef[NTX], t_coefq[NTX], t_thr[NTX], t_kind[NTX], t_p[NTX];
-    u32 t_m1[NTX], t_o1[NTX], t_m2[NTX];
-#pragma unroll
-    for (int k = 0; k < NT; k++) {
-        const int i = lane + 64 * k;
-        int c0 = A, cq0 = 0, coef = 0, coefq = 0, thr = 0x7FFFFFFF, kind = 4, p = 0;
-        u32 m1 = 0, o1 = 1, m2 = 0;
-        if (i < d.rl) { p = 64 * NP + i; c0 = p + A; cq0 = p; thr = p + 1; kind = 0; m1 = 0xFF; o1 = 0; m2 = ~0u; }
-        else if (i < 2 * d.rl) {
-            p = 64 * NP + i - d.rl; coef = 1; coefq = 1; c0 = A - 1 - p; cq0 = -1 - p; thr = p + 1; kind = 1;
-            m1 = 0xFF; o1 = 0; m2 = ~0u;
-        } else if (i < 2 * d.rl + A) { const int dist = i - 2 * d.rl + 1; c0 = A - dist; thr = dist; kind = 2; o1 = 0; m2 = 0x80000000u; }
-        else if (i < 2 * d.rl + 2 * A) {
-            const int dist = i - 2 * d.rl - A + 1; coef = 1; c0 = A - 1 + dist; thr = dist; kind = 3; o1 = 0; m2 = 0x80000000u;
+    // per-lane constants of the dword fast path (see MdxDims): the lane's four bytes are
+    //   reference: refB[rcoef * nq + r0]  with refB = ref + rbase - apad
+    //   SEQ:       seq[scoef * nq + s0]   (flank lanes: a dummy, disabled by em = 0)
+    // byte j is a task iff bit 8j of vm is set; (side, p) of byte j: p = pbase + pstep * j.
+    int c_r0 = d.apad, c_rcoef = 0, c_s0 = 0, c_scoef = 0, c_side = 0, c_pbase = 0, c_pstep = 1;
+    u32 c_em = 0, c_vm = 0;
+    bool c_read = false;
+    if (FAST) {
+        const int m0 = lane, m1 = lane - d.nl4, m2 = lane - 2 * d.nl4, m3 = lane - 2 * d.nl4 - d.nf4;
+        if (m0 < d.nl4) {
+            c_r0 = d.apad + 4 * m0; c_s0 = 4 * m0; c_em = ~0u; c_read = true; c_side = 0; c_pbase = 4 * m0; c_pstep = 1;
+            for (int j = 0; j < 4; j++) if (4 * m0 + j < L) c_vm |= 0xFFu << (8 * j);
+        } else if (m1 < d.nl4) {
+            c_rcoef = 1; c_r0 = d.apad - 4 - 4 * m1; c_scoef = 1; c_s0 = -4 - 4 * m1; c_em = ~0u; c_read = true;
+            c_side = 1; c_pbase = 4 * m1 + 3; c_pstep = -1;
+            for (int j = 0; j < 4; j++) if (4 * m1 + 3 - j < L) c_vm |= 0xFFu << (8 * j);
+        } else if (m2 < d.nf4) {
+            c_r0 = d.apad - 4 * (m2 + 1);
+            for (int j = 0; j < 4; j++) if (4 * (m2 + 1) - j <= A) c_vm |= 0xFFu << (8 * j);
+        } else if (m3 < d.nf4) {
+            c_rcoef = 1; c_r0 = d.apad + 4 * m3;
+            for (int j = 0; j < 4; j++) if (4 * m3 + j + 1 <= A) c_vm |= 0xFFu << (8 * j);
         }
-        t_c0[k] = c0; t_cq0[k] = cq0; t_coef[k] = coef; t_coefq[k] = coefq; t_thr[k] = thr; t_kind[k] = kind;
-        t_p[k] = p; t_m1[k] = m1; t_o1[k] = o1; t_m2[k] = m2;
     }
+    const u32 c_d0 = c_vm & 1u, c_d1 = (c_vm >> 8) & 1u, c_d2 = (c_vm >> 16) & 1u, c_d3 = (c_vm >> 24) & 1u;
 
     const i64 ntiles = (a.n_reads + 63) >> 6;
     for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
                 const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 65536;
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
-                if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
+                if (simple && nq >= 4 * d.nl4 && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
                 if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
                 w0 = (nq & 0xFFFF) | (libid << 16);
                 // statistics.py:117-126
@@ -311,15 +311,14 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         if (lane == 0 && todo_all) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), (u32)__popcll(todo_all));
 
         // ------------------------------------------------------------ phase 2a: plain records
+        // One lane = one dword (four consecutive bytes) of the record; one wavefront step = one record.
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
-        if (NT > 0) {
-            u64 todo = __ballot(kept && (w1 & D_SIMPLE));
+        if (FAST) {
+            u64 todo = __ballot(kept && (w1 & D_FULL));
             todo_g = todo_all & ~todo;
             // software pipeline: *_n = record whose loads are in flight, *_c = record being counted
-            u32 chL_n[NPX], chR_n[NPX], chT_n[NTX], chL_c[NPX], chR_c[NPX], chT_c[NTX];
-            int rL_n[NPX], rR_n[NPX], rT_n[NTX], rL_c[NPX], rR_c[NPX], rT_c[NTX];
-            u32 qL_n[NPX], qR_n[NPX], qT_n[NTX], qL_c[NPX], qR_c[NPX], qT_c[NTX];
+            u32 s4_n = 0, r4_n = 0, q4_n = 0, s4_c, r4_c, q4_c;
             int w0_n = 0, w1_n = 0;
 
             auto issue = [&](int j) {
@@ -327,112 +326,62 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 w1_n = rl(w1, j);
                 const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
                 const u32 s_sq = (u32)rl((int)sq, j);
-                const i8 *__restrict__ refA = (const i8 *)a.ref + (s_rbase - A);
+                const u8 *__restrict__ refB = a.ref + (s_rbase - d.apad);
                 const u8 *__restrict__ seqP = a.seq + s_sq;
-                const u8 *__restrict__ qualP = MASK ? a.qual + s_sq : nullptr;
                 const int s_nq = w0_n & 0xFFFF;
-                if (w1_n & D_FULL) {
-#pragma unroll
-                    for (int k = 0; k < NP; k++) {
-                        const u32 p = (u32)(lane + 64 * k);
-                        rL_n[k] = refA[p + (u32)A];
-                        chL_n[k] = seqP[p];
-                        const u32 cqr = (u32)(s_nq - 1 - 64 * k) - (u32)lane;
-                        rR_n[k] = refA[cqr + (u32)A];
-                        chR_n[k] = seqP[cqr];
-                        if (MASK) { qL_n[k] = qualP[p]; qR_n[k] = qualP[cqr]; }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NT; k++) {
-                        const u32 cp = (u32)(t_coef[k] * s_nq + t_c0[k]);
-                        const u32 cq = (u32)(t_coefq[k] * s_nq + t_cq0[k]);
-                        rT_n[k] = refA[cp];
-                        chT_n[k] = seqP[cq];
-                        if (MASK) qT_n[k] = qualP[cq];
-                    }
-                } else {
-                    // some tasks do not exist (short read or contig edge): clamp their addresses
-                    const int nb = (w1_n >> D_NB_SHIFT) & 0xFF, na = (w1_n >> D_NA_SHIFT) & 0xFF;
-#pragma unroll
-                    for (int k = 0; k < NP; k++) {
-                        const int p = lane + 64 * k;
-                        const u32 cql = (u32)min(p, s_nq - 1);
-                        rL_n[k] = refA[(u32)(p + A)];
-                        chL_n[k] = seqP[cql];
-                        const u32 cqr = (u32)max(s_nq - 1 - p, 0);
-                        rR_n[k] = refA[cqr + (u32)A];
-                        chR_n[k] = seqP[cqr];
-                        if (MASK) { qL_n[k] = qualP[cql]; qR_n[k] = qualP[cqr]; }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NT; k++) {
-                        const bool ok = t_thr[k] <= (t_kind[k] < 2 ? s_nq : (t_kind[k] == 2 ? nb : na));
-                        const u32 cp = ok ? (u32)(t_coef[k] * s_nq + t_c0[k]) : (u32)A;
-                        const u32 cq = ok ? (u32)(t_coefq[k] * s_nq + t_cq0[k]) : 0u;
-                        rT_n[k] = refA[cp];
-                        chT_n[k] = seqP[cq];
-                        if (MASK) qT_n[k] = qualP[cq];
-                    }
-                }
+                const u32 ro = (u32)(c_rcoef * s_nq + c_r0);
+                const u32 so = (u32)(c_scoef * s_nq + c_s0);
+                r4_n = *(const u32_u *)(refB + ro);
+                s4_n = *(const u32_u *)(seqP + so);
+                if (MASK) q4_n = *(const u32_u *)(a.qual + s_sq + so);
             };
 
             if (todo) issue(__ffsll((long long)todo) - 1);
             while (todo) {
                 todo &= todo - 1;
                 const int s_w0 = w0_n, s_w1 = w1_n;
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    chL_c[k] = chL_n[k]; chR_c[k] = chR_n[k]; rL_c[k] = rL_n[k]; rR_c[k] = rR_n[k];
-                    if (MASK) { qL_c[k] = qL_n[k]; qR_c[k] = qR_n[k]; }
-                }
-#pragma unroll
-                for (int k = 0; k < NT; k++) {
-                    chT_c[k] = chT_n[k]; rT_c[k] = rT_n[k];
-                    if (MASK) qT_c[k] = qT_n[k];
-                }
+                s4_c = s4_n; r4_c = r4_n;
+                if (MASK) q4_c = q4_n;
                 if (todo) issue(__ffsll((long long)todo) - 1);
 
                 const int rev = s_w1 & D_REV;
-                const int s_nq = s_w0 & 0xFFFF;
                 const int lb = (int)((u32)s_w0 >> 16) * d.w_lib;
-                const int tcw = d.t_pad;
-                const int base_v = lb + d.off_tc() + rev * 4 * tcw + lane;  // word index of (code 0, tau = lane)
-                const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
-                const int minq = (MASK && (s_w1 & D_HASQ)) ? a.minqual : 0;  // align.py:65-71
-                const int nb = (s_w1 >> D_NB_SHIFT) & 0xFF, na = (s_w1 >> D_NA_SHIFT) & 0xFF;
-                // FULL: every task of the record exists (the common case: no validity tests)
-                const bool FULL = s_w1 & D_FULL;
-                {
+                const int base_v = lb + d.off_tc() + rev * 4 * 256 + lane;  // word index of (code 0, byte 0)
+                // x: per byte, zero iff the byte is a plain match (read == reference, reference is A/C/G/T);
+                // flank lanes only test the reference byte; bytes that are not tasks are forced to zero
+                u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
+                u32 mq = 0;
+                if (MASK) {
+                    // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
+                    const u32 minq4 = (s_w1 & D_HASQ) ? (u32)a.minqual * 0x01010101u : 0u;
+                    mq = ~((q4_c | 0x80808080u) - minq4) & 0x80808080u & c_em;
+                    x |= mq;
+                }
+                x &= c_vm;
+                const u32 k0 = (r4_c >> 1) & 3u, k1 = (r4_c >> 9) & 3u, k2 = (r4_c >> 17) & 3u, k3 = (r4_c >> 25) & 3u;
+                if (__ballot(x != 0) == 0) {
+                    // every task of the record is a plain match
+                    bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0);
+                    bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1);
+                    bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2);
+                    bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3);
+                } else {
+                    const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+                    const u32 h0 = (x & 0xFFu) == 0, h1 = (x & 0xFF00u) == 0, h2 = (x & 0xFF0000u) == 0, h3 = (x & 0xFF000000u) == 0;
+                    bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0 & h0);
+                    bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1 & h1);
+                    bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2 & h2);
+                    bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3 & h3);
+                    if (c_read && x != 0) {
 #pragma unroll
-                    for (int k = 0; k < NP; k++) {
-                        const int p = lane + 64 * k;
-                        const bool ok = FULL || p < s_nq;
-                        {
-                            const bool masked = MASK && (int)qL_c[k] < minq;
-                            const bool hit = ok && (int)chL_c[k] == rL_c[k] && !masked;
-                            if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * k + (int)__umul24((u32)(rL_c[k] >> 1) & 3u, (u32)tcw));
-                            const bool miss = ok && !hit;
-                            if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 0, p, chL_c[k], rL_c[k], masked);
+                        for (int jb = 0; jb < 4; jb++) {
+                            if ((x >> (8 * jb)) & 0xFFu) {
+                                const u32 ch = (s4_c >> (8 * jb)) & 0xFFu;
+                                const int rch = (int)(i8)((r4_c >> (8 * jb)) & 0xFFu);
+                                rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, c_side, c_pbase + c_pstep * jb, ch, rch,
+                                                     MASK && ((mq >> (8 * jb)) & 0x80u));
+                            }
                         }
-                        {
-                            const bool masked = MASK && (int)qR_c[k] < minq;
-                            const bool hit = ok && (int)chR_c[k] == rR_c[k] && !masked;
-                            if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (NP + k) + (int)__umul24((u32)(rR_c[k] >> 1) & 3u, (u32)tcw));
-                            const bool miss = ok && !hit;
-                            if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, 1, p, chR_c[k], rR_c[k], masked);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NT; k++) {
-                        bool ok = true;
-                        if (!FULL) ok = t_thr[k] <= (t_kind[k] < 2 ? s_nq : (t_kind[k] == 2 ? nb : na));
-                        const bool masked = MASK && t_kind[k] < 2 && (int)qT_c[k] < minq;
-                        const u32 t1 = (chT_c[k] & t_m1[k]) | t_o1[k];
-                        const u32 t2 = (u32)rT_c[k] & t_m2[k];
-                        const bool hit = ok && t1 == t2 && !masked;
-                        if (hit) bump<USE_LDS>(lds, raw, base_v + 64 * (2 * NP + k) + (int)__umul24((u32)(rT_c[k] >> 1) & 3u, (u32)tcw));
-                        const bool miss = ok && !hit && t_kind[k] < 2;
-                        if (miss) rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, t_kind[k], t_p[k], chT_c[k], rT_c[k], masked);
                     }
                 }
             }
@@ -563,54 +512,40 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     }
 }
 
-template <bool MASK, int NP, int NT>
+template <bool MASK, bool FAST>
 static hipError_t prep_one(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void *)tabulate_kernel<true, MASK, NP, NT>,
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, MASK, FAST>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
-#define FOR_EACH_FAST_VARIANT(X) X(0, 1) X(0, 2) X(1, 1) X(1, 2) X(2, 1) X(2, 2)
-
 hipError_t mdx_k_prepare(size_t lds_bytes) {
-    hipError_t e = prep_one<false, 0, 0>(lds_bytes);
-    if (e == hipSuccess) e = prep_one<true, 0, 0>(lds_bytes);
-#define PREP(P, T)                                                   \
-    if (e == hipSuccess) e = prep_one<false, P, T>(lds_bytes);       \
-    if (e == hipSuccess) e = prep_one<true, P, T>(lds_bytes);
-    FOR_EACH_FAST_VARIANT(PREP)
-#undef PREP
+    hipError_t e = prep_one<false, false>(lds_bytes);
+    if (e == hipSuccess) e = prep_one<true, false>(lds_bytes);
+    if (e == hipSuccess) e = prep_one<false, true>(lds_bytes);
+    if (e == hipSuccess) e = prep_one<true, true>(lds_bytes);
     return e;
 }
 
-template <bool USE_LDS, bool MASK, int NP, int NT>
+template <bool USE_LDS, bool MASK, bool FAST>
 static void launch_one(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL((tabulate_kernel<USE_LDS, MASK, NP, NT>), dim3(grid), dim3(MDX_BLOCK),
+    hipLaunchKernelGGL((tabulate_kernel<USE_LDS, MASK, FAST>), dim3(grid), dim3(MDX_BLOCK),
                        USE_LDS ? lds_bytes : 0, s, a);
 }
 
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    const MdxDims &d = a.dims;
     if (mode != MDX_MODE_LDS) {
         // tables do not fit the LDS: global u64 atomics, generic code only
-        if (mask) launch_one<false, true, 0, 0>(a, grid, 0, s);
-        else launch_one<false, false, 0, 0>(a, grid, 0, s);
+        if (mask) launch_one<false, true, false>(a, grid, 0, s);
+        else launch_one<false, false, false>(a, grid, 0, s);
         return;
     }
-    // the fast path keeps speculative addresses within the 256-byte guard band of the reference
-    const bool fast = d.nt >= 1 && d.nt <= 2 && d.np <= 2 && d.L + d.A <= 255 && d.L < 64 * (d.np + 1);
-    bool done = false;
-#define CASE(P, T)                                                        \
-    if (fast && !done && d.np == P && d.nt == T) {                        \
-        if (mask) launch_one<true, true, P, T>(a, grid, lds_bytes, s);    \
-        else launch_one<true, false, P, T>(a, grid, lds_bytes, s);        \
-        done = true;                                                      \
-    }
-    FOR_EACH_FAST_VARIANT(CASE)
-#undef CASE
-    if (!done) {
-        if (mask) launch_one<true, true, 0, 0>(a, grid, lds_bytes, s);
-        else launch_one<true, false, 0, 0>(a, grid, lds_bytes, s);
+    if (a.dims.fast_ok()) {
+        if (mask) launch_one<true, true, true>(a, grid, lds_bytes, s);
+        else launch_one<true, false, true>(a, grid, lds_bytes, s);
+    } else {
+        if (mask) launch_one<true, true, false>(a, grid, lds_bytes, s);
+        else launch_one<true, false, false>(a, grid, lds_bytes, s);
     }
 }
 
@@ -661,8 +596,8 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
                 const int k = b ^ (b >> 1);                  // A,C,G,T -> device class A,C,T,G
                 const i64 row = lb + ((strand * 2 + side) * L + p) * 25;
                 // matches (gapped records / plain records) + every column whose reference symbol is k
-                v = raw[row + k] +
-                    raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p))];
+                v = raw[row + k];
+                if (d.nl4 > 0) v += raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p))];
                 for (int x = 0; x < 4; x++) v += raw[row + c_refcols[k * 4 + x]];
             } else {
                 const int rc = strand ? c_comp_col[col] : col;
@@ -684,7 +619,10 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             if (end == 1) { if (row < A) dist = A - row; else slot = row - A; }
             else { if (row < L) slot = L - 1 - row; else dist = row - L + 1; }
             const i64 tc = lb + d.off_tc() + (strand * 4 + k) * d.t_pad;
-            if (slot >= 0) v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k] + raw[tc + (side ? d.tau_right(slot) : d.tau_left(slot))];
+            if (slot >= 0) {
+                v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k];
+                if (d.nl4 > 0) v += raw[tc + (side ? d.tau_right(slot) : d.tau_left(slot))];
+            }
             else v = raw[tc + (side ? d.tau_rflank(dist) : d.tau_lflank(dist))];
         } else if (i < n_mis + n_comp + n_lgd) {
             i64 x = i - n_mis - n_comp;
