@@ -281,6 +281,7 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     a.lgd_over_cap = c->cfg.lgd_over_cap;
     a.n_lgd_over = c->d_n_lgd_over;
     a.err = c->d_err;
+    a.queue_off = mdx_k_queue_off(c->dims);
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
     const int wpb = mdx_k_block_threads() / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;

@@ -98,12 +98,14 @@ struct MdxTabArgs {
     long long lgd_over_cap;
     unsigned long long *n_lgd_over;
     unsigned long long *err;         // min over (read_index << 8 | -code); ~0 = no error
+    int queue_off;                   // word offset of the per-wave rare-event queues in the LDS
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };
 
 int mdx_k_block_threads();
 size_t mdx_k_lds_bytes(const MdxDims &d);
+int mdx_k_queue_off(const MdxDims &d);
 hipError_t mdx_k_prepare(size_t lds_bytes);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);

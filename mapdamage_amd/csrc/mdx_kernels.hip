@@ -32,6 +32,7 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 #define MDX_BLOCK 512
+#define EVQ_CAP 128                     // rare-event queue capacity per wavefront (words)
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -57,7 +58,8 @@ __constant__ u8 c_comp_col[25] = {3, 2, 1, 0, 5, 4, 7, 6, 12, 13, 14, 15, 8,
                                   9, 10, 11, 17, 16, 19, 18, 21, 20, 23, 22, 24};
 
 int mdx_k_block_threads() { return MDX_BLOCK; }
-size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)d.w_total * 4; }
+size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)(d.w_total + 3) / 4 * 16 + (size_t)(MDX_BLOCK / 64) * EVQ_CAP * 4; }
+int mdx_k_queue_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
 
 // read byte -> class; accepted only if it is exactly the upper-case letter
 // ("nt in 'ACGT-'", statistics.py:27)
@@ -312,25 +314,56 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
 
         // ------------------------------------------------------------ phase 2a: plain records
         // One lane = one dword (four consecutive bytes) of the record; one wavefront step = one record.
+        // Bytes that are not plain matches are not handled here: they are appended as events to a
+        // wave-private LDS queue and counted later 64 at a time (drain_events), so the divergent
+        // classification code runs once per 64 events instead of once per record.
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
         if (FAST) {
             u64 todo = __ballot(kept && (w1 & D_FULL));
             todo_g = todo_all & ~todo;
+            // absolute address of the record's reference window and its TC base, per lane (phase-1 layout)
+            const i64 refw = (i64)(size_t)a.ref + rbase - d.apad;
+            const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
+            const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
+            u32 *const queue = lds + a.queue_off + (threadIdx.x >> 6) * EVQ_CAP;
+            int qcount = 0;
+
+            auto drain_events = [&]() {
+                for (int base = 0; base < qcount; base += 64) {
+                    const int e = base + lane;
+                    const bool ev_ok = e < qcount;
+                    const u32 ev = ev_ok ? queue[e] : 0u;
+                    const int jr = (int)(ev >> 24) & 63;
+                    const int e_w0 = __shfl(w0, jr), e_w1 = __shfl(w1, jr);  // all lanes execute the shuffles
+                    if (ev_ok) {
+                        const int ln = (int)(ev >> 18) & 63, jb = (int)(ev >> 16) & 3;
+                        const int side = ln >= d.nl4;
+                        const int m = ln - (side ? d.nl4 : 0);
+                        const int p = side ? 4 * m + 3 - jb : 4 * m + jb;
+                        const int rev = e_w1 & D_REV;
+                        const int lb = (int)((u32)e_w0 >> 16) * d.w_lib;
+                        rare_column<USE_LDS>(lds, raw, lb + rev * 2 * L * 25, lb + d.off_cmp() + rev * 2 * L * 4, L, side, p,
+                                             ev & 0xFFu, (int)(i8)((ev >> 8) & 0xFFu), MASK && (ev >> 30) & 1u);
+                    }
+                }
+                qcount = 0;
+            };
+
             // software pipeline: *_n = record whose loads are in flight, *_c = record being counted
             u32 s4_n = 0, r4_n = 0, q4_n = 0, s4_c, r4_c, q4_c;
-            int w0_n = 0, w1_n = 0;
+            int nq_n = 0, tcb_n = 0, w1_n = 0, j_n = 0;
 
             auto issue = [&](int j) {
-                w0_n = rl(w0, j);
-                w1_n = rl(w1, j);
-                const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
+                j_n = j;
+                nq_n = rl(w0, j) & 0xFFFF;
+                tcb_n = rl(tcb, j);
+                if (MASK) w1_n = rl(w1, j);
+                const u8 *__restrict__ refB = (const u8 *)(size_t)(((i64)rl(rf_hi, j) << 32) | (u32)rl(rf_lo, j));
                 const u32 s_sq = (u32)rl((int)sq, j);
-                const u8 *__restrict__ refB = a.ref + (s_rbase - d.apad);
                 const u8 *__restrict__ seqP = a.seq + s_sq;
-                const int s_nq = w0_n & 0xFFFF;
-                const u32 ro = (u32)(c_rcoef * s_nq + c_r0);
-                const u32 so = (u32)(c_scoef * s_nq + c_s0);
+                const u32 ro = (u32)(c_rcoef * nq_n + c_r0);
+                const u32 so = (u32)(c_scoef * nq_n + c_s0);
                 r4_n = *(const u32_u *)(refB + ro);
                 s4_n = *(const u32_u *)(seqP + so);
                 if (MASK) q4_n = *(const u32_u *)(a.qual + s_sq + so);
@@ -339,14 +372,12 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
             if (todo) issue(__ffsll((long long)todo) - 1);
             while (todo) {
                 todo &= todo - 1;
-                const int s_w0 = w0_n, s_w1 = w1_n;
+                const int s_tcb = tcb_n, s_w1 = w1_n, s_j = j_n;
                 s4_c = s4_n; r4_c = r4_n;
                 if (MASK) q4_c = q4_n;
                 if (todo) issue(__ffsll((long long)todo) - 1);
 
-                const int rev = s_w1 & D_REV;
-                const int lb = (int)((u32)s_w0 >> 16) * d.w_lib;
-                const int base_v = lb + d.off_tc() + rev * 4 * 256 + lane;  // word index of (code 0, byte 0)
+                const int base_v = s_tcb + lane;  // word index of (code 0, byte 0)
                 // x: per byte, zero iff the byte is a plain match (read == reference, reference is A/C/G/T);
                 // flank lanes only test the reference byte; bytes that are not tasks are forced to zero
                 u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
@@ -366,25 +397,32 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                     bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2);
                     bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3);
                 } else {
-                    const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
                     const u32 h0 = (x & 0xFFu) == 0, h1 = (x & 0xFF00u) == 0, h2 = (x & 0xFF0000u) == 0, h3 = (x & 0xFF000000u) == 0;
                     bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0 & h0);
                     bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1 & h1);
                     bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2 & h2);
                     bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3 & h3);
-                    if (c_read && x != 0) {
+                    // queue the non-matching read bytes: [30] masked, [29:24] record, [23:18] lane, [17:16] byte,
+                    // [15:8] reference byte, [7:0] read byte
+                    const u32 ev_hi = ((u32)s_j << 24) | ((u32)lane << 18);
 #pragma unroll
-                        for (int jb = 0; jb < 4; jb++) {
-                            if ((x >> (8 * jb)) & 0xFFu) {
-                                const u32 ch = (s4_c >> (8 * jb)) & 0xFFu;
-                                const int rch = (int)(i8)((r4_c >> (8 * jb)) & 0xFFu);
-                                rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, c_side, c_pbase + c_pstep * jb, ch, rch,
-                                                     MASK && ((mq >> (8 * jb)) & 0x80u));
+                    for (int jb = 0; jb < 4; jb++) {
+                        const bool mis = c_read && ((x >> (8 * jb)) & 0xFFu);
+                        const u64 mm = __ballot(mis);
+                        if (mm) {
+                            if (mis) {
+                                const int slot = qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+                                u32 ev = ev_hi | ((u32)jb << 16) | (((r4_c >> (8 * jb)) & 0xFFu) << 8) | ((s4_c >> (8 * jb)) & 0xFFu);
+                                if (MASK) ev |= ((mq >> (8 * jb + 7)) & 1u) << 30;
+                                queue[slot] = ev;
                             }
+                            qcount += __popcll(mm);
+                            if (qcount > EVQ_CAP - 64) drain_events();
                         }
                     }
                 }
             }
+            if (qcount) drain_events();
         }
 
         // ------------------------------------------------------------ phase 2b: gapped records
