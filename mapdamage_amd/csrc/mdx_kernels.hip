@@ -322,8 +322,8 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
         if (FAST) {
             u64 todo = __ballot(kept && (w1 & D_FULL));
             todo_g = todo_all & ~todo;
-            // absolute address of the record's reference window and its TC base, per lane (phase-1 layout)
-            const i64 refw = (i64)(size_t)a.ref + rbase - d.apad;
+            // offset of the record's reference window and its TC base, per lane (phase-1 layout)
+            const i64 refw = rbase - d.apad;  // offset (not an absolute address: keeps the loads in the global space)
             const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
             const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
             u32 *const queue = lds + a.queue_off + (threadIdx.x >> 6) * EVQ_CAP;
@@ -348,44 +348,50 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                     }
                 }
                 qcount = 0;
+                // nothing LDS-returning may be pending when control rejoins the hot loop: otherwise the
+                // compiler guards the loop's first instructions with s_waitcnt lgkmcnt(0), which also
+                // waits for the previous record's ds_add_u32s on every iteration
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             };
 
-            // software pipeline: *_n = record whose loads are in flight, *_c = record being counted
-            u32 s4_n = 0, r4_n = 0, q4_n = 0, s4_c, r4_c, q4_c;
-            int nq_n = 0, tcb_n = 0, w1_n = 0, j_n = 0;
+            // software pipeline: four records in flight, each in its own register set (no register
+            // rotation: a copy of an in-flight destination would wait for its load)
+            struct Stage { u32 s4, r4, q4; int tcb, w1, j; bool valid; };
+            u64 pending = todo;
 
-            auto issue = [&](int j) {
-                j_n = j;
-                nq_n = rl(w0, j) & 0xFFFF;
-                tcb_n = rl(tcb, j);
-                if (MASK) w1_n = rl(w1, j);
-                const u8 *__restrict__ refB = (const u8 *)(size_t)(((i64)rl(rf_hi, j) << 32) | (u32)rl(rf_lo, j));
+            // fill() always issues its two loads (past the last record it re-reads the previous one), so
+            // the number of loads in flight is static and the waits before count() are counted ones
+            int last_j = todo ? __ffsll((long long)todo) - 1 : 0;
+            auto fill = [&](Stage &st) {
+                st.valid = pending != 0;
+                const int j = st.valid ? __ffsll((long long)pending) - 1 : last_j;
+                pending &= pending - 1;
+                last_j = j;
+                st.j = j;
+                const int s_nq = rl(w0, j) & 0xFFFF;
+                st.tcb = rl(tcb, j);
+                if (MASK) st.w1 = rl(w1, j);
+                const u8 *__restrict__ refB = a.ref + (((i64)rl(rf_hi, j) << 32) | (u32)rl(rf_lo, j));
                 const u32 s_sq = (u32)rl((int)sq, j);
                 const u8 *__restrict__ seqP = a.seq + s_sq;
-                const u32 ro = (u32)(c_rcoef * nq_n + c_r0);
-                const u32 so = (u32)(c_scoef * nq_n + c_s0);
-                r4_n = *(const u32_u *)(refB + ro);
-                s4_n = *(const u32_u *)(seqP + so);
-                if (MASK) q4_n = *(const u32_u *)(a.qual + s_sq + so);
+                const u32 ro = (u32)(c_rcoef * s_nq + c_r0);
+                const u32 so = (u32)(c_scoef * s_nq + c_s0);
+                st.r4 = *(const u32_u *)(refB + ro);
+                st.s4 = *(const u32_u *)(seqP + so);
+                if (MASK) st.q4 = *(const u32_u *)(a.qual + s_sq + so);
             };
 
-            if (todo) issue(__ffsll((long long)todo) - 1);
-            while (todo) {
-                todo &= todo - 1;
-                const int s_tcb = tcb_n, s_w1 = w1_n, s_j = j_n;
-                s4_c = s4_n; r4_c = r4_n;
-                if (MASK) q4_c = q4_n;
-                if (todo) issue(__ffsll((long long)todo) - 1);
-
-                const int base_v = s_tcb + lane;  // word index of (code 0, byte 0)
+            auto count = [&](const Stage &st) {
+                const u32 s4_c = st.s4, r4_c = st.r4;
+                const int base_v = st.tcb + lane;  // word index of (code 0, byte 0)
                 // x: per byte, zero iff the byte is a plain match (read == reference, reference is A/C/G/T);
                 // flank lanes only test the reference byte; bytes that are not tasks are forced to zero
                 u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
                 u32 mq = 0;
                 if (MASK) {
                     // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
-                    const u32 minq4 = (s_w1 & D_HASQ) ? (u32)a.minqual * 0x01010101u : 0u;
-                    mq = ~((q4_c | 0x80808080u) - minq4) & 0x80808080u & c_em;
+                    const u32 minq4 = (st.w1 & D_HASQ) ? (u32)a.minqual * 0x01010101u : 0u;
+                    mq = ~((st.q4 | 0x80808080u) - minq4) & 0x80808080u & c_em;
                     x |= mq;
                 }
                 x &= c_vm;
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                     bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3 & h3);
                     // queue the non-matching read bytes: [30] masked, [29:24] record, [23:18] lane, [17:16] byte,
                     // [15:8] reference byte, [7:0] read byte
-                    const u32 ev_hi = ((u32)s_j << 24) | ((u32)lane << 18);
+                    const u32 ev_hi = ((u32)st.j << 24) | ((u32)lane << 18);
 #pragma unroll
                     for (int jb = 0; jb < 4; jb++) {
                         const bool mis = c_read && ((x >> (8 * jb)) & 0xFFu);
@@ -421,6 +427,18 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                         }
                     }
                 }
+            };
+
+            Stage st0{}, st1{}, st2{}, st3{};
+            if (todo) { fill(st0); fill(st1); fill(st2); fill(st3); }
+            while (st0.valid) {
+                count(st0); fill(st0);
+                if (!st1.valid) break;
+                count(st1); fill(st1);
+                if (!st2.valid) break;
+                count(st2); fill(st2);
+                if (!st3.valid) break;
+                count(st3); fill(st3);
             }
             if (qcount) drain_events();
         }
