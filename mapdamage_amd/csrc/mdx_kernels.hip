@@ -31,8 +31,8 @@ typedef u32 __attribute__((aligned(1))) u32_u;
 typedef unsigned long long u64;
 typedef long long i64;
 
-#define MDX_BLOCK 512
-#define EVQ_CAP 128                     // rare-event queue capacity per wavefront (words)
+#define MDX_BLOCK 768                   // 12 wavefronts; two blocks per CU share the 160 KiB LDS
+#define EVQ_CAP 128                     // rare-event queue capacity per wavefront (16-byte events)
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -58,7 +58,7 @@ __constant__ u8 c_comp_col[25] = {3, 2, 1, 0, 5, 4, 7, 6, 12, 13, 14, 15, 8,
                                   9, 10, 11, 17, 16, 19, 18, 21, 20, 23, 22, 24};
 
 int mdx_k_block_threads() { return MDX_BLOCK; }
-size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)(d.w_total + 3) / 4 * 16 + (size_t)(MDX_BLOCK / 64) * EVQ_CAP * 4; }
+size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)(d.w_total + 3) / 4 * 16 + (size_t)(MDX_BLOCK / 64) * EVQ_CAP * 16; }
 int mdx_k_queue_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
 
 // read byte -> class; accepted only if it is exactly the upper-case letter
@@ -143,7 +143,7 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
 // FAST: the dword-lane path for plain, complete records (MdxDims::fast_ok()); otherwise every
 // record takes the generic CIGAR walk.
 template <bool USE_LDS, bool MASK, bool FAST>
-__global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
+__global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
@@ -184,11 +184,12 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
     }
     const u32 c_d0 = c_vm & 1u, c_d1 = (c_vm >> 8) & 1u, c_d2 = (c_vm >> 16) & 1u, c_d3 = (c_vm >> 24) & 1u;
 
-    const i64 ntiles = (a.n_reads + 63) >> 6;
-    for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
+    // each wavefront owns one contiguous range of records (balanced to +-1 record), walked in tiles of 64
+    const i64 r_lo = a.n_reads * gwave / nwaves, r_hi = a.n_reads * (gwave + 1) / nwaves;
+    for (i64 tbase = r_lo; tbase < r_hi; tbase += 64) {
         // ------------------------------------------------------------ phase 1: lane per record
-        const i64 ri = tile * 64 + lane;
-        const bool valid = ri < a.n_reads;
+        const i64 ri = tbase + lane;
+        const bool valid = ri < r_hi;
         const u32 fl = valid ? (u32)a.flag[ri] : 0x4u;
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
         int w0 = 0, w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
@@ -326,25 +327,41 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
             const i64 refw = rbase - d.apad;  // offset (not an absolute address: keeps the loads in the global space)
             const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
             const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
-            u32 *const queue = lds + a.queue_off + (threadIdx.x >> 6) * EVQ_CAP;
+            // event = {read dword, reference dword, x (nonzero bytes = not a plain match),
+            //          masked-quality bits | record << 8 | lane}
+            uint4 *const queue = (uint4 *)(lds + a.queue_off) + (threadIdx.x >> 6) * EVQ_CAP;
             int qcount = 0;
 
+            // Events undo the optimistic TC increment of each byte that was not a plain match and, for
+            // read bytes, count what the byte really is (rare_column).  64 events per pass.
             auto drain_events = [&]() {
                 for (int base = 0; base < qcount; base += 64) {
                     const int e = base + lane;
                     const bool ev_ok = e < qcount;
-                    const u32 ev = ev_ok ? queue[e] : 0u;
-                    const int jr = (int)(ev >> 24) & 63;
-                    const int e_w0 = __shfl(w0, jr), e_w1 = __shfl(w1, jr);  // all lanes execute the shuffles
+                    uint4 ev = make_uint4(0, 0, 0, 0);
+                    if (ev_ok) ev = queue[e];
+                    const int jr = (int)(ev.w >> 8) & 63;
+                    // all lanes execute the shuffles (a disabled source lane would return 0)
+                    const int e_w0 = __shfl(w0, jr), e_w1 = __shfl(w1, jr), e_tcb = __shfl(tcb, jr);
                     if (ev_ok) {
-                        const int ln = (int)(ev >> 18) & 63, jb = (int)(ev >> 16) & 3;
+                        const int ln = (int)ev.w & 63;
+                        const bool is_read = ln < 2 * d.nl4;
                         const int side = ln >= d.nl4;
                         const int m = ln - (side ? d.nl4 : 0);
-                        const int p = side ? 4 * m + 3 - jb : 4 * m + jb;
                         const int rev = e_w1 & D_REV;
                         const int lb = (int)((u32)e_w0 >> 16) * d.w_lib;
-                        rare_column<USE_LDS>(lds, raw, lb + rev * 2 * L * 25, lb + d.off_cmp() + rev * 2 * L * 4, L, side, p,
-                                             ev & 0xFFu, (int)(i8)((ev >> 8) & 0xFFu), MASK && (ev >> 30) & 1u);
+                        const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+#pragma unroll
+                        for (int jb = 0; jb < 4; jb++) {
+                            if ((ev.z >> (8 * jb)) & 0xFFu) {
+                                const u32 rb = (ev.y >> (8 * jb)) & 0xFFu;
+                                bump_n<USE_LDS>(lds, raw, e_tcb + 64 * jb + ln + (int)(((rb >> 1) & 3u) << 8), 0xFFFFFFFFu);  // -1
+                                if (is_read)
+                                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, side ? 4 * m + 3 - jb : 4 * m + jb,
+                                                         (ev.x >> (8 * jb)) & 0xFFu, (int)(i8)rb,
+                                                         MASK && ((ev.w >> (8 * jb + 7)) & 1u));
+                            }
+                        }
                     }
                 }
                 qcount = 0;
@@ -396,36 +413,20 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
                 }
                 x &= c_vm;
                 const u32 k0 = (r4_c >> 1) & 3u, k1 = (r4_c >> 9) & 3u, k2 = (r4_c >> 17) & 3u, k3 = (r4_c >> 25) & 3u;
-                if (__ballot(x != 0) == 0) {
-                    // every task of the record is a plain match
-                    bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0);
-                    bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1);
-                    bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2);
-                    bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3);
-                } else {
-                    const u32 h0 = (x & 0xFFu) == 0, h1 = (x & 0xFF00u) == 0, h2 = (x & 0xFF0000u) == 0, h3 = (x & 0xFF000000u) == 0;
-                    bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0 & h0);
-                    bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1 & h1);
-                    bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2 & h2);
-                    bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3 & h3);
-                    // queue the non-matching read bytes: [30] masked, [29:24] record, [23:18] lane, [17:16] byte,
-                    // [15:8] reference byte, [7:0] read byte
-                    const u32 ev_hi = ((u32)st.j << 24) | ((u32)lane << 18);
-#pragma unroll
-                    for (int jb = 0; jb < 4; jb++) {
-                        const bool mis = c_read && ((x >> (8 * jb)) & 0xFFu);
-                        const u64 mm = __ballot(mis);
-                        if (mm) {
-                            if (mis) {
-                                const int slot = qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                                u32 ev = ev_hi | ((u32)jb << 16) | (((r4_c >> (8 * jb)) & 0xFFu) << 8) | ((s4_c >> (8 * jb)) & 0xFFu);
-                                if (MASK) ev |= ((mq >> (8 * jb + 7)) & 1u) << 30;
-                                queue[slot] = ev;
-                            }
-                            qcount += __popcll(mm);
-                            if (qcount > EVQ_CAP - 64) drain_events();
-                        }
+                // optimistic: count every task byte as a plain match ...
+                bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0);
+                bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1);
+                bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2);
+                bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3);
+                // ... and queue the lanes holding a byte that is not one (drain_events corrects them)
+                const u64 mm = __ballot(x != 0);
+                if (mm) {
+                    if (x != 0) {
+                        const int slot = qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+                        queue[slot] = make_uint4(s4_c, r4_c, x, (mq & 0x80808080u) | ((u32)st.j << 8) | (u32)lane);
                     }
+                    qcount += __popcll(mm);
+                    if (qcount > EVQ_CAP - 64) drain_events();
                 }
             };
 
@@ -468,8 +469,8 @@ __global__ __launch_bounds__(MDX_BLOCK) void tabulate_kernel(MdxTabArgs a) {
             // flank lengths (not from the packed descriptor: A may exceed 255 here)
             int s_nb, s_na;
             {
-                const i64 pos = a.pos[tile * 64 + j];
-                const int tid = a.tid[tile * 64 + j];
+                const i64 pos = a.pos[tbase + j];
+                const int tid = a.tid[tbase + j];
                 const i64 clen = a.contig_off[tid + 1] - a.contig_off[tid];
                 s_nb = pos < A ? (int)pos : A;
                 s_na = clen - (pos + s_n0) < A ? (int)(clen - (pos + s_n0)) : A;
