@@ -59,6 +59,7 @@ def main():
     if world > 1:
         dist.barrier()
     from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.distributed import allreduce_words
 
     L, A = 70, 10
     ref = synth.make_genome()
@@ -89,8 +90,7 @@ def main():
         eng.tabulate(dbatch)
     eng.finish_device(tables.data_ptr())
     eng.sync()
-    if world > 1:
-        dist.all_reduce(tables)
+    allreduce_words(tables)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -98,6 +98,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_launch, kernel_ms = eng.timing_read()
+
+    # HBM traffic per launch from the committed PMC summary of this same command (tools/prof.sh)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("reads_per_launch") == args.reads:
+            traffic = (tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
+    except (OSError, ValueError, KeyError):
+        pass
 
     total_reads = args.reads * args.steps * world
     value = total_reads / dt
@@ -115,7 +125,7 @@ def main():
                    "parallelism": "shard-by-read x%d + RCCL all-reduce of tables" % world,
                    "table_mode": eng.table_mode},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "tabulate_kernel", "kernel_ms": per_launch_ms,
                      "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ},
     }

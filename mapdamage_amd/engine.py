@@ -226,17 +226,8 @@ class DamageEngine:
 
     def unpack_tables(self, words: np.ndarray, lgd_over=None) -> TableSet:
         """Split a packed table block (host copy of ``finish_device`` output)."""
-        nlib, Ln, A = len(self.libraries), self.length, self.around
-        nm = nlib * 4 * Ln * L.N_MIS_COLS
-        nc = nlib * 4 * (Ln + A) * 4
-        nl = nlib * 4 * self.lgd_max
-        words = np.ascontiguousarray(words).view(np.uint64)
-        assert words.shape[0] == nm + nc + nl + 2
-        mis = words[:nm].reshape(nlib, 2, 2, Ln, L.N_MIS_COLS).copy()
-        comp = words[nm:nm + nc].reshape(nlib, 2, 2, Ln + A, 4).copy()
-        lgd = words[nm + nc:nm + nc + nl].reshape(nlib, 2, 2, self.lgd_max).copy()
-        over = np.zeros((0, 4), np.int64) if lgd_over is None else lgd_over
-        return TableSet(self.libraries, Ln, A, mis, comp, lgd, over, int(words[-2]))
+        from .tables import unpack_words
+        return unpack_words(words, self.libraries, self.length, self.around, self.lgd_max, lgd_over)
 
     def finish(self) -> TableSet:
         """Synchronise and fetch the canonical tables (main.py:229-231 reads them next)."""
@@ -255,9 +246,15 @@ class DamageEngine:
         return TableSet(self.libraries, Ln, A, mis, comp, lgd, over[:n_over.value].copy(),
                         n_kept.value)
 
-    def lgd_overflow(self):
-        """Out-of-range fragment lengths only (cheap; used after an all-reduce)."""
-        return self.finish().lgd_over
+    def lgd_overflow_only(self):
+        """Out-of-range fragment-length records of this context (used after an all-reduce)."""
+        self.sync()
+        cap = max(1, self.lgd_over_cap)
+        over = np.zeros((cap, 4), np.int64)
+        n_over = ctypes.c_int64(0)
+        self._check(self._lib.mdx_finish(self._ctx, None, None, None, _ptr(over), ctypes.c_int64(cap),
+                                         ctypes.byref(n_over), None))
+        return over[:min(cap, n_over.value)].copy()
 
     def reset(self):
         self._check(self._lib.mdx_reset(self._ctx))

@@ -1,0 +1,176 @@
+"""Mirror of the reference's command line for the tabulation pass (mapdamage/main.py:49-266,
+mapdamage/config.py:80-494): same flags, same defaults, same output files
+(``misincorporation.txt``, ``dnacomp.txt``, ``lgdistribution.txt``, ``Runtime_log.txt``), with the
+per-read loop replaced by ``DamageEngine`` (HIP).  R plotting, the Bayesian stage and rescaling
+are out of scope: their flags are parsed, and asking for them is an error."""
+
+import argparse
+import logging
+import sys
+import time
+from pathlib import Path
+
+from . import __version__
+from .engine import BadReadError, DamageEngine
+from .fasta import compare_sequence_dicts, read_fasta_index, reference_for_bam
+from .reader import BAMReader
+from .sam import BAMError
+from .statistics import check_table_and_warn_if_dmg_freq_is_low
+
+_LOG_FORMAT = "%(asctime)s %(name)s %(levelname)s %(message)s"
+
+
+def _ranged(cls, lo=float("-inf"), hi=float("inf")):
+    def parse(value):
+        value = cls(value)
+        if value < lo:
+            raise argparse.ArgumentTypeError("must be greater than or equal to %s" % (lo,))
+        if value > hi:
+            raise argparse.ArgumentTypeError("must be less than or equal to %s" % (hi,))
+        return value
+    return parse
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="mapDamage", usage="%(prog)s [options] -i alignment.bam -r reference.fasta")
+    p.add_argument("--version", action="version", version="%(prog)s (mapdamage_amd " + __version__ + ")")
+    g = p.add_argument_group("Input and output")
+    g.add_argument("-i", "--input", dest="filename", type=Path, metavar="SAM/BAM")
+    g.add_argument("-r", "--reference", dest="ref", type=Path, metavar="FASTA")
+    g.add_argument("-d", "--folder", type=Path)
+    g.add_argument("-n", "--downsample", type=float, metavar="X")
+    g.add_argument("--downsample-seed", type=int, metavar="X")
+    g = p.add_argument_group("General options")
+    g.add_argument("--merge-libraries", action="store_true")
+    g.add_argument("--merge-reference-sequences", action="store_true", help=argparse.SUPPRESS)
+    g.add_argument("-l", "--length", type=_ranged(int, 1), default=70)
+    g.add_argument("-a", "--around", type=_ranged(int, 0), default=10)
+    g.add_argument("-Q", "--min-basequal", dest="minqual", type=_ranged(int, 0, 93), default=0)
+    g.add_argument("--plot-only", action="store_true")
+    g.add_argument("--log-level", default="INFO", type=str.upper, choices=("DEBUG", "INFO", "WARNING", "ERROR"))
+    g.add_argument("--no-plot", dest="no_r", action="store_true", help=argparse.SUPPRESS)
+    g = p.add_argument_group("Options for graphics")
+    g.add_argument("-y", "--ymax", type=float, default=0.3)
+    g.add_argument("-m", "--readplot", type=_ranged(int, 1), default=25)
+    g.add_argument("-b", "--refplot", type=_ranged(int, 1), default=10)
+    g.add_argument("-t", "--title")
+    g = p.add_argument_group("Options for the statistical estimation")
+    for flag, typ, default in (("--rand", int, 30), ("--burn", int, 10000), ("--adjust", int, 10),
+                               ("--iter", int, 50000), ("--seq-length", int, 12)):
+        g.add_argument(flag, type=typ, default=default)
+    g.add_argument("--termini", choices=("5p", "3p", "both"), default="both")
+    for flag in ("--forward", "--reverse", "--var-disp", "--jukes-cantor", "--diff-hangs", "--fix-nicks",
+                 "--use-raw-nick-freq", "--single-stranded", "--theme-bw", "--stats-only", "--no-stats",
+                 "--check-R-packages"):
+        g.add_argument(flag, action="store_true")
+    g = p.add_argument_group("Options for rescaling of BAM files")
+    g.add_argument("--rescale", action="store_true")
+    g.add_argument("--rescale-only", action="store_true")
+    g.add_argument("--rescale-out", type=Path)
+    g.add_argument("--rescale-length-5p", type=int)
+    g.add_argument("--rescale-length-3p", type=int)
+    g = p.add_argument_group("MI355X engine")
+    g.add_argument("--device", type=int, default=0, help="HIP device ordinal")
+    g.add_argument("--batch-reads", type=int, default=4_000_000, help="records per device batch")
+    return p
+
+
+def parse_args(argv):
+    parser = build_parser()
+    o = parser.parse_args(argv)
+    if o.plot_only or o.stats_only or o.rescale or o.rescale_only or o.check_R_packages:
+        parser.error("plotting, the Bayesian estimation and rescaling are not part of this engine "
+                     "(tabulation pass only); run them with the reference on the emitted tables")
+    if not o.filename:
+        parser.error("--input SAM/BAM file not specified")
+    if not o.ref:
+        parser.error("--reference FASTA file not specified")
+    if o.downsample is not None:
+        if o.downsample <= 0:
+            parser.error("-n/--downsample must be a positive value")
+        elif o.downsample >= 1:
+            o.downsample = int(o.downsample)
+    if o.ymax <= 0 or o.ymax > 1:
+        parser.error("--ymax (-b) must be an real number beetween 0 and 1")
+    if o.refplot > o.around:
+        parser.error("--refplot (-b) must be less than --around (-a)")
+    if o.readplot > o.length:
+        parser.error("--readplot (-m) must be less than --length (-l)")
+    if not o.folder:
+        o.folder = Path(o.filename.stem + ".mapDamage")
+    o.folder.mkdir(parents=True, exist_ok=True, mode=0o750)
+    o.no_stats = True
+    return o
+
+
+def main(argv):
+    start_time = time.time()
+    logging.basicConfig(format=_LOG_FORMAT, datefmt="%H:%M:%S")
+    logger = logging.getLogger(__name__)
+    try:
+        options = parse_args(argv)
+    except SystemExit as error:
+        return int(error.code or 0) and 1
+    logging.getLogger().setLevel(options.log_level)
+    handler = logging.FileHandler(options.folder / "Runtime_log.txt")
+    handler.setFormatter(logging.Formatter(_LOG_FORMAT))
+    handler.setLevel(options.log_level)
+    logging.getLogger().addHandler(handler)
+    try:
+        logger.info("Started with the command: " + " ".join(sys.argv))
+        reader = BAMReader(options.filename, merge_libraries=options.merge_libraries,
+                           downsample_to=options.downsample, downsample_seed=options.downsample_seed)
+        reflengths = reader.get_references()
+        fai_lengths = read_fasta_index(str(options.ref) + ".fai")
+        if not fai_lengths:
+            return 1
+        if not compare_sequence_dicts(fai_lengths, reflengths):
+            return 1
+        ref = reference_for_bam(options.ref, reader.handle.header.references)
+        libraries = reader.get_libraries()
+
+        logger.info("Reading from '%s'", options.filename)
+        if options.minqual != 0:
+            logger.info("Filtering out bases with a Phred score < %d", options.minqual)
+        logger.info("Writing results to '%s/'", options.folder)
+
+        indices = reader.kept_indices()
+        batch = reader.handle.batch
+        if len(indices) != batch.n:
+            batch = batch.take(indices)
+        batch.lib = reader.library_column(indices)
+        if options.minqual and batch.n and not (batch.qual != 0xFF).any():
+            logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+
+        with DamageEngine(libraries, options.length, options.around, options.minqual,
+                          device=options.device) as engine:
+            engine.set_reference(ref)
+            for lo in range(0, batch.n, options.batch_reads):
+                engine.tabulate(batch.slice(lo, lo + options.batch_reads))
+            tables = engine.finish()
+        logger.debug("Done. %d filtered alignments processed", tables.n_kept)
+        logger.debug("BAM read in %f seconds", time.time() - start_time)
+
+        tables.write(options.folder)
+        check_table_and_warn_if_dmg_freq_is_low(options.folder)
+        logger.info("Successful run")
+        logger.debug("Run completed in %f seconds", time.time() - start_time)
+        return 0
+    except BadReadError as error:
+        # the reference dies with pysam's ValueError here (align.py:33)
+        logger.error("%s", error)
+        raise
+    except BAMError as error:
+        logger.error("%s", error)
+        raise
+    finally:
+        logging.getLogger().removeHandler(handler)
+        handler.close()
+
+
+def entry_point():
+    return main(sys.argv[1:])
+
+
+if __name__ == "__main__":
+    sys.exit(entry_point())

@@ -1,0 +1,261 @@
+"""SAM / BAM decoding and encoding without pysam (pysam is absent from this image).
+
+Produces the SoA ``ReadBatch`` columns of the boundary directly.  Text SAM and BGZF-compressed
+BAM (through the standard library's zlib) are supported for reading and writing; this is the
+host-side "N1" row of SURVEY §8f in its first, pure-Python form.
+"""
+
+import gzip
+import io
+import struct
+import zlib
+
+import numpy as np
+
+from . import layout as L
+from .batch import ReadBatch
+
+_SEQ_DECODE = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+_SEQ_ENCODE = np.full(256, 15, np.uint8)
+for _i, _c in enumerate(b"=ACMGRSVTWYHKDBN"):
+    _SEQ_ENCODE[_c] = _i
+    _SEQ_ENCODE[ord(chr(_c).lower())] = _i
+
+
+class BAMError(RuntimeError):
+    """Read-group problems (mapdamage/reader.py:16-17)."""
+
+
+class Header:
+    def __init__(self, text=""):
+        self.text = text
+        self.references, self.lengths, self.read_groups = [], [], []
+        for line in text.splitlines():
+            fields = line.split("\t")
+            tags = dict(f.split(":", 1) for f in fields[1:] if ":" in f)
+            if fields[0] == "@SQ":
+                self.references.append(tags["SN"])
+                self.lengths.append(int(tags["LN"]))
+            elif fields[0] == "@RG":
+                self.read_groups.append(tags)
+
+    def get(self, key, default=()):
+        return self.read_groups if key == "RG" else default
+
+
+class Alignments:
+    """All records of a SAM/BAM file: header + SoA batch + per-record RG id and query name."""
+
+    def __init__(self, header, batch, rg, qname):
+        self.header, self.batch, self.rg, self.qname = header, batch, rg, qname
+
+
+def _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames):
+    n = len(flags)
+    cigar_off = np.zeros(n + 1, np.uint32)
+    np.cumsum(np.asarray(cig_counts, dtype=np.int64), out=cigar_off[1:])
+    seq_off = np.zeros(n + 1, np.uint32)
+    np.cumsum(np.asarray([len(s) for s in seqs], dtype=np.int64), out=seq_off[1:])
+    seq = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    qual = np.frombuffer(b"".join(quals), dtype=np.uint8).copy()
+    batch = ReadBatch(np.asarray(flags, np.uint16), np.zeros(n, np.uint16), np.asarray(tids, np.int32),
+                      np.asarray(poss, np.int32), np.asarray(tlens, np.int32), cigar_off,
+                      np.asarray(cigs, np.uint32), seq_off, seq, qual).validate()
+    return Alignments(header, batch, rgs, qnames)
+
+
+def read_sam(path_or_handle):
+    handle = open(path_or_handle, "rt") if isinstance(path_or_handle, (str, bytes)) or hasattr(path_or_handle, "__fspath__") else path_or_handle
+    head, lines = [], []
+    for line in handle:
+        (head if line.startswith("@") else lines).append(line)
+    header = Header("".join(head))
+    tid_of = {name: i for i, name in enumerate(header.references)}
+    flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames = [], [], [], [], [], [], [], [], [], []
+    for line in lines:
+        f = line.rstrip("\n").split("\t")
+        if len(f) < 11:
+            continue
+        qnames.append(f[0])
+        flags.append(int(f[1]))
+        tids.append(tid_of.get(f[2], -1))
+        poss.append(int(f[3]) - 1)
+        tlens.append(int(f[8]))
+        n_ops, num = 0, 0
+        if f[5] != "*":
+            for ch in f[5]:
+                if ch.isdigit():
+                    num = num * 10 + ord(ch) - 48
+                else:
+                    cigs.append((num << 4) | L.CIGAR_CHARS.index(ch))
+                    n_ops += 1
+                    num = 0
+        cig_counts.append(n_ops)
+        s = b"" if f[9] == "*" else f[9].upper().encode()
+        # htslib stores SEQ through the 4-bit alphabet: anything else becomes N
+        s = bytes(_SEQ_DECODE[_SEQ_ENCODE[np.frombuffer(s, dtype=np.uint8)]])
+        seqs.append(s)
+        if f[10] == "*":
+            quals.append(b"\xff" * len(s))
+        else:
+            quals.append(bytes((np.frombuffer(f[10].encode(), dtype=np.uint8) - 33).astype(np.uint8)))
+        rg = None
+        for tag in f[11:]:
+            if tag.startswith("RG:Z:"):
+                rg = tag[5:]
+        rgs.append(rg)
+    return _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames)
+
+
+def read_bam(path):
+    with gzip.open(path, "rb") as handle:   # BGZF is a series of gzip members
+        data = handle.read()
+    if data[:4] != b"BAM\x01":
+        raise ValueError("%r is not a BAM file" % (path,))
+    l_text, = struct.unpack_from("<i", data, 4)
+    text = data[8:8 + l_text].split(b"\x00")[0].decode()
+    off = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, off)
+    off += 4
+    names, lengths = [], []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", data, off)
+        names.append(data[off + 4:off + 4 + l_name - 1].decode())
+        l_ref, = struct.unpack_from("<i", data, off + 4 + l_name)
+        lengths.append(l_ref)
+        off += 8 + l_name
+    header = Header(text)
+    if not header.references:
+        header.references, header.lengths = names, lengths
+    flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames = [], [], [], [], [], [], [], [], [], []
+    n = len(data)
+    while off + 4 <= n:
+        block_size, = struct.unpack_from("<i", data, off)
+        rec = memoryview(data)[off + 4:off + 4 + block_size]
+        off += 4 + block_size
+        tid, pos, l_read_name, _mapq, _bin, n_cigar, flag, l_seq, _ntid, _npos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+        p = 32
+        qnames.append(bytes(rec[p:p + l_read_name - 1]).decode())
+        p += l_read_name
+        cig = np.frombuffer(rec[p:p + 4 * n_cigar], dtype="<u4")
+        p += 4 * n_cigar
+        packed = np.frombuffer(rec[p:p + (l_seq + 1) // 2], dtype=np.uint8)
+        p += (l_seq + 1) // 2
+        nib = np.empty(packed.shape[0] * 2, np.uint8)
+        nib[0::2] = packed >> 4
+        nib[1::2] = packed & 15
+        seqs.append(bytes(_SEQ_DECODE[nib[:l_seq]]))
+        quals.append(bytes(rec[p:p + l_seq]))
+        p += l_seq
+        rg = None
+        aux = bytes(rec[p:])
+        q = 0
+        while q + 3 <= len(aux):
+            tag, typ = aux[q:q + 2], aux[q + 2:q + 3]
+            q += 3
+            if typ == b"Z" or typ == b"H":
+                end = aux.index(b"\x00", q)
+                if tag == b"RG":
+                    rg = aux[q:end].decode()
+                q = end + 1
+            elif typ in b"AcC":
+                q += 1
+            elif typ in b"sS":
+                q += 2
+            elif typ in b"iIf":
+                q += 4
+            elif typ == b"B":
+                sub = aux[q:q + 1]
+                cnt, = struct.unpack_from("<i", aux, q + 1)
+                q += 5 + cnt * {b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}[sub]
+            else:
+                break
+        flags.append(flag); tids.append(tid); poss.append(pos); tlens.append(tlen)
+        cigs.extend(int(c) for c in cig)
+        cig_counts.append(n_cigar)
+        rgs.append(rg)
+    return _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames)
+
+
+def read_alignments(path):
+    """SAM or BAM by content (mapdamage/reader.py:38 lets htslib sniff the format)."""
+    if str(path) == "-":
+        import sys
+        return read_sam(sys.stdin)
+    with open(path, "rb") as handle:
+        magic = handle.read(2)
+    return read_bam(path) if magic == b"\x1f\x8b" else read_sam(str(path))
+
+
+# ---------------------------------------------------------------------------- writers (tests, synthetic inputs)
+def header_text(ref_names, ref_lengths, read_groups):
+    lines = ["@HD\tVN:1.6\tSO:unsorted"]
+    lines += ["@SQ\tSN:%s\tLN:%d" % (n, ln) for n, ln in zip(ref_names, ref_lengths)]
+    for rg in read_groups:
+        lines.append("@RG\t" + "\t".join("%s:%s" % kv for kv in rg.items()))
+    return "\n".join(lines) + "\n"
+
+
+def _cigar_string(ops):
+    return "".join("%d%s" % (int(c) >> 4, L.CIGAR_CHARS[int(c) & 15]) for c in ops) or "*"
+
+
+def write_sam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None):
+    """``read_groups``: list of dicts (ID, SM, LB ...); ``rg_of_record``: RG id per record or None."""
+    with open(path, "wt") as out:
+        out.write(header_text(ref_names, ref_lengths, read_groups))
+        for i in range(batch.n):
+            c0, c1 = int(batch.cigar_off[i]), int(batch.cigar_off[i + 1])
+            s0, s1 = int(batch.seq_off[i]), int(batch.seq_off[i + 1])
+            seq = batch.seq[s0:s1].tobytes().decode() or "*"
+            qual = "*"
+            if batch.qual is not None and s1 > s0 and int(batch.qual[s0]) != 0xFF:
+                qual = (batch.qual[s0:s1] + 33).astype(np.uint8).tobytes().decode()
+            tid = int(batch.tid[i])
+            fields = ["r%d" % i, str(int(batch.flag[i])), ref_names[tid] if tid >= 0 else "*",
+                      str(int(batch.pos[i]) + 1), "30", _cigar_string(batch.cigar[c0:c1]), "*", "0",
+                      str(int(batch.tlen[i])), seq, qual]
+            rg = None if rg_of_record is None else rg_of_record[i]
+            if rg is not None:
+                fields.append("RG:Z:%s" % rg)
+            out.write("\t".join(fields) + "\n")
+
+
+def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None):
+    text = header_text(ref_names, ref_lengths, read_groups).encode()
+    raw = io.BytesIO()
+    raw.write(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names)))
+    for name, ln in zip(ref_names, ref_lengths):
+        nb = name.encode() + b"\x00"
+        raw.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln))
+    for i in range(batch.n):
+        c0, c1 = int(batch.cigar_off[i]), int(batch.cigar_off[i + 1])
+        s0, s1 = int(batch.seq_off[i]), int(batch.seq_off[i + 1])
+        name = ("r%d" % i).encode() + b"\x00"
+        l_seq = s1 - s0
+        codes = _SEQ_ENCODE[batch.seq[s0:s1]]
+        if l_seq % 2:
+            codes = np.concatenate([codes, np.zeros(1, np.uint8)])
+        packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
+        qual = batch.qual[s0:s1].tobytes() if batch.qual is not None else b"\xff" * l_seq
+        aux = b""
+        rg = None if rg_of_record is None else rg_of_record[i]
+        if rg is not None:
+            aux = b"RGZ" + rg.encode() + b"\x00"
+        body = struct.pack("<iiBBHHHiiii", int(batch.tid[i]), int(batch.pos[i]), len(name), 30, 4680,
+                           c1 - c0, int(batch.flag[i]), l_seq, -1, -1, int(batch.tlen[i]))
+        body += name + batch.cigar[c0:c1].astype("<u4").tobytes() + packed + qual + aux
+        raw.write(struct.pack("<i", len(body)) + body)
+    data = raw.getvalue()
+    with open(path, "wb") as out:
+        for lo in range(0, len(data), 0xFF00):
+            out.write(_bgzf_block(data[lo:lo + 0xFF00]))
+        out.write(_bgzf_block(b""))
+
+
+def _bgzf_block(chunk):
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    deflated = comp.compress(chunk) + comp.flush()
+    bsize = len(deflated) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+            + deflated + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))

@@ -106,6 +106,32 @@ class TableSet:
         (folder / "lgdistribution.txt").write_text(self.lgdistribution_text())
 
 
+def table_words(nlib, length, around, lgd_max):
+    """uint64 words of the packed table block (include/mdx.h: mdx_table_words)."""
+    return nlib * 4 * length * L.N_MIS_COLS + nlib * 4 * (length + around) * 4 + nlib * 4 * lgd_max + 2
+
+
+def pack_words(ts: "TableSet") -> np.ndarray:
+    """TableSet -> packed block [mis | comp | lgd | n_kept | n_lgd_over] (the all-reduce message)."""
+    tail = np.asarray([ts.n_kept, ts.lgd_over.shape[0]], dtype=np.uint64)
+    return np.concatenate([ts.mis.reshape(-1), ts.comp.reshape(-1), ts.lgd.reshape(-1), tail]).astype(np.uint64)
+
+
+def unpack_words(words, libraries, length, around, lgd_max, lgd_over=None) -> "TableSet":
+    """Packed block (host copy of mdx_finish_device output, possibly all-reduced) -> TableSet."""
+    nlib = len(libraries)
+    nm = nlib * 4 * length * L.N_MIS_COLS
+    nc = nlib * 4 * (length + around) * 4
+    nl = nlib * 4 * lgd_max
+    words = np.ascontiguousarray(words).view(np.uint64)
+    assert words.shape[0] == nm + nc + nl + 2, (words.shape, nm + nc + nl + 2)
+    mis = words[:nm].reshape(nlib, 2, 2, length, L.N_MIS_COLS).copy()
+    comp = words[nm:nm + nc].reshape(nlib, 2, 2, length + around, 4).copy()
+    lgd = words[nm + nc:nm + nc + nl].reshape(nlib, 2, 2, lgd_max).copy()
+    over = np.zeros((0, 4), np.int64) if lgd_over is None else np.asarray(lgd_over, np.int64).reshape(-1, 4)
+    return TableSet([tuple(x) for x in libraries], length, around, mis, comp, lgd, over, int(words[-2]))
+
+
 def merge_library_ids(libraries):
     """Map read-group order to unique library ids (reader.py:47-50: several read groups may
     name the same (SM, LB)).  Returns (unique list, remap array old id -> new id)."""

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI) against the golden vectors produced by the
 reference and against the C oracle on seeded inputs.  Integer tables: bit-exact."""
 
+import pathlib
+
 import numpy as np
 import pytest
 
@@ -138,3 +140,22 @@ def test_hip_accumulate_is_linear(mid_genome):
     np.testing.assert_array_equal(two.comp, 2 * one.comp)
     np.testing.assert_array_equal(two.lgd, 2 * one.lgd)
     assert_tables_equal(again, one)
+
+
+@pytest.mark.parametrize("fmt", ["sam", "bam"])
+def test_cli_end_to_end_byte_identical_outputs(tmp_path, fmt):
+    """`python -m mapdamage_amd -i x.bam -r ref.fa -Q 20` writes the reference's three tables."""
+    from mapdamage_amd import fasta, sam
+    from mapdamage_amd.main import main
+    g = Golden("config1_L70_A10_Q20")
+    rgs = [{"ID": "rg%d" % i, "SM": s, "LB": l} for i, (s, l) in enumerate(g.meta["libraries"])]
+    raw_lib = np.load(str(pathlib.Path(__file__).parent / "golden" / "config1_L70_A10_Q20.npz"))["lib"]
+    rg_of = ["rg%d" % int(l) for l in raw_lib]
+    path = tmp_path / ("in." + fmt)
+    (sam.write_sam if fmt == "sam" else sam.write_bam)(path, g.batch, g.ref.names, g.ref.lengths, rgs, rg_of)
+    fasta.write_fasta(tmp_path / "ref.fa", g.ref)
+    out = tmp_path / "res"
+    assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "-Q", "20", "--no-stats"]) == 0
+    for name in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
+        assert (out / name).read_text() == g.txt[name], name
+    assert (out / "Runtime_log.txt").exists()

@@ -1,0 +1,118 @@
+"""Host side of the boundary (CPU only): SAM/BAM/FASTA codecs, read-group / downsampling logic
+(mirror of mapdamage/reader.py), the accumulator-class mirror and the emitters."""
+
+import random
+
+import numpy as np
+import pytest
+
+from mapdamage_amd import fasta, sam, synth
+from mapdamage_amd.reader import BAMReader
+from mapdamage_amd.sam import BAMError
+from mapdamage_amd.statistics import (DNAComposition, FragmentLengths, MisincorporationRates,
+                                      check_table_and_warn_if_dmg_freq_is_low)
+from tests.util import Golden, oracle_tableset
+
+RGS = [{"ID": "rgA", "SM": "Zed", "LB": "libB"}, {"ID": "rgB", "SM": "Alpha", "LB": "libA"},
+       {"ID": "rgC", "SM": "Zed", "LB": "libB"}]
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("io")
+    ref, batch = synth.config1_batch()
+    rg_of = [("rgA", "rgB", "rgC")[int(l) * 2 % 3] if False else ("rgA" if int(l) == 0 else "rgB") for l in batch.lib]
+    # a few reads of library 0 use the second read group that names the same (SM, LB)
+    rg_of = ["rgC" if (r == "rgA" and i % 7 == 0) else r for i, r in enumerate(rg_of)]
+    sam.write_sam(d / "x.sam", batch, ref.names, ref.lengths, RGS, rg_of)
+    sam.write_bam(d / "x.bam", batch, ref.names, ref.lengths, RGS, rg_of)
+    fasta.write_fasta(d / "ref.fa", ref)
+    return d, ref, batch, rg_of
+
+
+@pytest.mark.parametrize("name", ["x.sam", "x.bam"])
+def test_alignment_codecs_roundtrip(files, name):
+    d, ref, batch, rg_of = files
+    al = sam.read_alignments(d / name)
+    for k in ("flag", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual"):
+        np.testing.assert_array_equal(getattr(al.batch, k), getattr(batch, k), err_msg=k)
+    assert al.rg == rg_of
+    assert al.header.references == ref.names and al.header.lengths == ref.lengths
+
+
+def test_fasta_roundtrip_and_index(files):
+    d, ref, _, _ = files
+    names, seqs = fasta.read_fasta(d / "ref.fa")
+    assert names == ref.names and seqs == ref.seqs
+    fai = fasta.read_fasta_index(str(d / "ref.fa.fai"))
+    assert fai == dict(zip(ref.names, ref.lengths))
+    assert fasta.compare_sequence_dicts(fai, dict(zip(ref.names, ref.lengths)))
+    assert not fasta.compare_sequence_dicts(fai, {"c1": 3999})
+    assert not fasta.compare_sequence_dicts(fai, {"other": 10})
+    reordered = fasta.reference_for_bam(d / "ref.fa", ref.names[::-1])
+    assert reordered.seqs == ref.seqs[::-1]
+
+
+def test_reader_libraries_filter_and_errors(files):
+    d, ref, batch, rg_of = files
+    r = BAMReader(d / "x.bam")
+    assert r.get_libraries() == [("Zed", "libB"), ("Alpha", "libA")]   # rgC merges into the first
+    idx = r.kept_indices()
+    assert len(idx) == int(((batch.flag & 0xF04) == 0).sum())
+    lib = r.library_column(idx)
+    np.testing.assert_array_equal(lib, batch.lib[idx])
+    merged = BAMReader(d / "x.bam", merge_libraries=True)
+    assert merged.get_libraries() == [("*", "*")] and not merged.library_column(idx).any()
+    r.handle.rg[int(idx[3])] = None
+    with pytest.raises(BAMError, match="has no read-group"):
+        r.library_column(idx)
+    r.handle.rg[int(idx[3])] = "nope"
+    with pytest.raises(BAMError, match="not listed in BAM header"):
+        r.library_column(idx)
+
+
+def test_reader_downsampling_follows_python_rng(files):
+    d, ref, batch, _ = files
+    kept = np.nonzero((batch.flag & 0xF04) == 0)[0]
+    r = BAMReader(d / "x.sam", downsample_to=0.25, downsample_seed=7)
+    rand = random.Random(7)
+    want = [int(i) for i in kept if rand.random() < 0.25]
+    assert list(r.kept_indices()) == want
+    r = BAMReader(d / "x.sam", downsample_to=100, downsample_seed=3)
+    got = r.kept_indices()
+    assert len(got) == 100 and len(set(got.tolist())) == 100
+    keys = [(int(batch.tid[i]), int(batch.pos[i])) for i in got]
+    assert keys == sorted(keys)
+
+
+def test_statistics_mirror_writes_reference_format(tmp_path):
+    g = Golden("config1_L70_A10_Q20")
+    ts = oracle_tableset(g.ref, g.batch, g.libraries, g.length, g.around, g.minqual, lgd_max=4096)
+    mis = MisincorporationRates.from_tables(ts)
+    comp = DNAComposition.from_tables(ts)
+    lgd = FragmentLengths.from_tables(ts)
+    mis.write(tmp_path / "misincorporation.txt")
+    comp.write(tmp_path / "dnacomp.txt")
+    lgd.write(tmp_path / "lgdistribution.txt")
+    for name in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
+        assert (tmp_path / name).read_text() == g.txt[name], name
+    lib = ("Zed", "libB")
+    li = ts.libraries.index(lib)
+    assert mis.data[lib]["5p"]["+"]["C>T"][0] == int(ts.mis[li, 1, 0, 0, 5])
+    assert comp.data[lib]["3p"]["-"]["G"][-1] == int(ts.comp[li, 0, 1, g.length - 1, 2])
+    assert check_table_and_warn_if_dmg_freq_is_low(tmp_path) is True
+    assert check_table_and_warn_if_dmg_freq_is_low(tmp_path / "missing") is False
+
+
+def test_cli_parser_mirrors_reference_flags():
+    from mapdamage_amd.main import build_parser
+    p = build_parser()
+    o = p.parse_args(["-i", "a.bam", "-r", "r.fa"])
+    assert (o.length, o.around, o.minqual, o.readplot, o.refplot, o.ymax) == (70, 10, 0, 25, 10, 0.3)
+    o = p.parse_args(["-i", "a.bam", "-r", "r.fa", "-l", "50", "-a", "5", "-Q", "20", "--merge-libraries",
+                      "-n", "0.5", "--downsample-seed", "1", "--no-stats"])
+    assert (o.length, o.around, o.minqual, o.merge_libraries, o.downsample) == (50, 5, 20, True, 0.5)
+    with pytest.raises(SystemExit):
+        p.parse_args(["-Q", "94"])
+    with pytest.raises(SystemExit):
+        p.parse_args(["-l", "0"])
