@@ -431,15 +431,20 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             };
 
             Stage st0{}, st1{}, st2{}, st3{};
-            if (todo) { fill(st0); fill(st1); fill(st2); fill(st3); }
-            while (st0.valid) {
-                count(st0); fill(st0);
-                if (!st1.valid) break;
-                count(st1); fill(st1);
-                if (!st2.valid) break;
-                count(st2); fill(st2);
-                if (!st3.valid) break;
-                count(st3); fill(st3);
+            if (todo) {
+                fill(st0); fill(st1); fill(st2); fill(st3);
+                // single-exit loop, eight loads in flight at every point of it (stages past the last record
+                // re-read it and are skipped by their valid flag): lets the compiler count its vmcnt waits
+                do {
+                    if (st0.valid) count(st0);
+                    fill(st0);
+                    if (st1.valid) count(st1);
+                    fill(st1);
+                    if (st2.valid) count(st2);
+                    fill(st2);
+                    if (st3.valid) count(st3);
+                    fill(st3);
+                } while (st0.valid);
             }
             if (qcount) drain_events();
         }
