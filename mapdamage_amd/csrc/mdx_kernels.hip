@@ -95,6 +95,17 @@ __device__ __forceinline__ void bump(u32 *lds, u64 *raw, int idx) {
     if (USE_LDS) atomicAdd(&lds[idx], 1u);
     else atomicAdd(&raw[idx], 1ull);
 }
+// TC increment of the fast path: LDS byte address = base + ((r4 >> bit) & 3) * 1024 + imm.
+// Hand-written (v_bfe_u32, v_lshl_add_u32, ds_add_u32): the compiler's own sequence is shift + and +
+// add3 per byte.  The hidden ds_add only makes the compiler's lgkmcnt waits more conservative (LDS
+// operations complete in order).
+__device__ __forceinline__ void tc_bump(u32 r4, int bit, u32 base_bytes, int imm, u32 data) {
+    u32 k, addr;
+    asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(k) : "v"(r4), "n"(bit));
+    asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(addr) : "v"(k), "v"(base_bytes));
+    asm volatile("ds_add_u32 %0, %1 offset:%2" : : "v"(addr), "v"(data), "n"(imm) : "memory");
+}
+
 template <bool USE_LDS>
 __device__ __forceinline__ void bump_n(u32 *lds, u64 *raw, int idx, u32 n) {
     if (USE_LDS) atomicAdd(&lds[idx], n);
@@ -412,12 +423,13 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                     x |= mq;
                 }
                 x &= c_vm;
-                const u32 k0 = (r4_c >> 1) & 3u, k1 = (r4_c >> 9) & 3u, k2 = (r4_c >> 17) & 3u, k3 = (r4_c >> 25) & 3u;
-                // optimistic: count every task byte as a plain match ...
-                bump_n<USE_LDS>(lds, raw, base_v + (int)(k0 << 8), c_d0);
-                bump_n<USE_LDS>(lds, raw, base_v + 64 + (int)(k1 << 8), c_d1);
-                bump_n<USE_LDS>(lds, raw, base_v + 128 + (int)(k2 << 8), c_d2);
-                bump_n<USE_LDS>(lds, raw, base_v + 192 + (int)(k3 << 8), c_d3);
+                // optimistic: count every task byte as a plain match (the base class of the reference
+                // byte, (ascii >> 1) & 3, selects the 1 KiB plane of TC) ...
+                const u32 base_b = ((u32)base_v << 2) + __builtin_amdgcn_groupstaticsize();  // + dynamic LDS base
+                tc_bump(r4_c, 1, base_b, 0, c_d0);
+                tc_bump(r4_c, 9, base_b, 256, c_d1);
+                tc_bump(r4_c, 17, base_b, 512, c_d2);
+                tc_bump(r4_c, 25, base_b, 768, c_d3);
                 // ... and queue the lanes holding a byte that is not one (drain_events corrects them)
                 const u64 mm = __ballot(x != 0);
                 if (mm) {
