@@ -282,6 +282,7 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     a.n_lgd_over = c->d_n_lgd_over;
     a.err = c->d_err;
     a.queue_off = mdx_k_queue_off(c->dims);
+    a.ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL ? 1 : 0;
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
     const int wpb = mdx_k_block_threads() / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;

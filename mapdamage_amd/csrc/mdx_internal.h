@@ -99,6 +99,7 @@ struct MdxTabArgs {
     unsigned long long *n_lgd_over;
     unsigned long long *err;         // min over (read_index << 8 | -code); ~0 = no error
     int queue_off;                   // word offset of the per-wave rare-event queues in the LDS
+    int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };

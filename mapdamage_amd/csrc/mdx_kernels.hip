@@ -335,9 +335,11 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             u64 todo = __ballot(kept && (w1 & D_FULL));
             todo_g = todo_all & ~todo;
             // offset of the record's reference window and its TC base, per lane (phase-1 layout)
-            const i64 refw = rbase - d.apad;  // offset (not an absolute address: keeps the loads in the global space)
+            // offset from the start of the guard band (>= 0; not an absolute address: keeps the loads global)
+            const i64 refw = rbase - d.apad + 256;
             const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
             const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
+            const int wq = (nq & 0xFFFF) | (tcb << 16);  // tcb < 40960 words (160 KiB of LDS)
             // event = {read dword, reference dword, x (nonzero bytes = not a plain match),
             //          masked-quality bits | record << 8 | lane}
             uint4 *const queue = (uint4 *)(lds + a.queue_off) + (threadIdx.x >> 6) * EVQ_CAP;
@@ -362,16 +364,18 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                         const int rev = e_w1 & D_REV;
                         const int lb = (int)((u32)e_w0 >> 16) * d.w_lib;
                         const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
-#pragma unroll
-                        for (int jb = 0; jb < 4; jb++) {
-                            if ((ev.z >> (8 * jb)) & 0xFFu) {
-                                const u32 rb = (ev.y >> (8 * jb)) & 0xFFu;
-                                bump_n<USE_LDS>(lds, raw, e_tcb + 64 * jb + ln + (int)(((rb >> 1) & 3u) << 8), 0xFFFFFFFFu);  // -1
-                                if (is_read)
-                                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, side ? 4 * m + 3 - jb : 4 * m + jb,
-                                                         (ev.x >> (8 * jb)) & 0xFFu, (int)(i8)rb,
-                                                         MASK && ((ev.w >> (8 * jb + 7)) & 1u));
-                            }
+                        // usually exactly one byte of the dword differs: handle the lowest non-matching byte
+                        // with per-lane shifts (all lanes busy), repeat only while some lane has another
+                        u32 xr = ev.z;
+                        while (xr) {
+                            const int jb = (__ffs((int)xr) - 1) >> 3;
+                            const int sh = 8 * jb;
+                            xr &= ~(0xFFu << sh);
+                            const u32 rb = (ev.y >> sh) & 0xFFu;
+                            bump_n<USE_LDS>(lds, raw, e_tcb + 64 * jb + ln + (int)(((rb >> 1) & 3u) << 8), 0xFFFFFFFFu);  // -1
+                            if (is_read)
+                                rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, side ? 4 * m + 3 - jb : 4 * m + jb,
+                                                     (ev.x >> sh) & 0xFFu, (int)(i8)rb, MASK && ((ev.w >> (sh + 7)) & 1u));
                         }
                     }
                 }
@@ -396,10 +400,13 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 pending &= pending - 1;
                 last_j = j;
                 st.j = j;
-                const int s_nq = rl(w0, j) & 0xFFFF;
-                st.tcb = rl(tcb, j);
+                const int s_wq = rl(wq, j);
+                const int s_nq = s_wq & 0xFFFF;
+                st.tcb = (int)((u32)s_wq >> 16);
                 if (MASK) st.w1 = rl(w1, j);
-                const u8 *__restrict__ refB = a.ref + (((i64)rl(rf_hi, j) << 32) | (u32)rl(rf_lo, j));
+                u64 roff = (u32)rl(rf_lo, j);
+                if (!a.ref32) roff |= (u64)(u32)rl(rf_hi, j) << 32;  // genomes of 4 Gbases and more
+                const u8 *__restrict__ refB = (a.ref - 256) + roff;
                 const u32 s_sq = (u32)rl((int)sq, j);
                 const u8 *__restrict__ seqP = a.seq + s_sq;
                 const u32 ro = (u32)(c_rcoef * s_nq + c_r0);
