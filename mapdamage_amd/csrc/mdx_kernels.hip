@@ -195,6 +195,51 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
     }
     const u32 c_d0 = c_vm & 1u, c_d1 = (c_vm >> 8) & 1u, c_d2 = (c_vm >> 16) & 1u, c_d3 = (c_vm >> 24) & 1u;
 
+    // Rare-event queue of the fast path (wave-private ring in the LDS, EVQ_CAP 16-byte events):
+    // event = {read dword, reference dword, x (nonzero bytes = not a plain match),
+    //          masked-quality flags [3:0] | lane [9:4] | reverse strand [10] | library [26:11]}
+    // Events are self-contained, so they survive tile changes and are drained in full passes of 64.
+    uint4 *const queue = (uint4 *)(lds + a.queue_off) + (threadIdx.x >> 6) * EVQ_CAP;
+    int qhead = 0, qcount = 0;
+
+    // One pass: undo the optimistic TC increment of each byte that was not a plain match and, for read
+    // bytes, count what the byte really is (rare_column) — lane-parallel over up to 64 events.
+    auto drain_pass = [&]() {
+        const bool ev_ok = lane < qcount;
+        uint4 ev = make_uint4(0, 0, 0, 0);
+        if (ev_ok) ev = queue[(qhead + lane) & (EVQ_CAP - 1)];
+        const int n = qcount < 64 ? qcount : 64;
+        qhead = (qhead + n) & (EVQ_CAP - 1);
+        qcount -= n;
+        if (ev_ok) {
+            const int ln = (int)(ev.w >> 4) & 63;
+            const int rev = (int)(ev.w >> 10) & 1;
+            const int lb = (int)(ev.w >> 11) * d.w_lib;
+            const bool is_read = ln < 2 * d.nl4;
+            const int side = ln >= d.nl4;
+            const int m = ln - (side ? d.nl4 : 0);
+            const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+            const int e_tcb = lb + d.off_tc() + rev * 1024;
+            // usually exactly one byte of the dword differs: handle the lowest non-matching byte
+            // with per-lane shifts (all lanes busy), repeat only while some lane has another
+            u32 xr = ev.z;
+            while (xr) {
+                const int jb = (__ffs((int)xr) - 1) >> 3;
+                const int sh = 8 * jb;
+                xr &= ~(0xFFu << sh);
+                const u32 rb = (ev.y >> sh) & 0xFFu;
+                bump_n<USE_LDS>(lds, raw, e_tcb + 64 * jb + ln + (int)(((rb >> 1) & 3u) << 8), 0xFFFFFFFFu);  // -1
+                if (is_read)
+                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, side ? 4 * m + 3 - jb : 4 * m + jb,
+                                         (ev.x >> sh) & 0xFFu, (int)(i8)rb, MASK && ((ev.w >> jb) & 1u));
+            }
+        }
+        // nothing LDS-returning may be pending when control rejoins the hot loop: otherwise the
+        // compiler guards the loop's first instructions with s_waitcnt lgkmcnt(0), which also
+        // waits for the previous record's ds_add_u32s on every iteration
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    };
+
     // each wavefront owns one contiguous range of records (balanced to +-1 record), walked in tiles of 64
     const i64 r_lo = a.n_reads * gwave / nwaves, r_hi = a.n_reads * (gwave + 1) / nwaves;
     for (i64 tbase = r_lo; tbase < r_hi; tbase += 64) {
@@ -327,7 +372,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
         // ------------------------------------------------------------ phase 2a: plain records
         // One lane = one dword (four consecutive bytes) of the record; one wavefront step = one record.
         // Bytes that are not plain matches are not handled here: they are appended as events to a
-        // wave-private LDS queue and counted later 64 at a time (drain_events), so the divergent
+        // wave-private LDS queue and counted later 64 at a time (drain_pass), so the divergent
         // classification code runs once per 64 events instead of once per record.
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
@@ -340,52 +385,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
             const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
             const int wq = (nq & 0xFFFF) | (tcb << 16);  // tcb < 40960 words (160 KiB of LDS)
-            // event = {read dword, reference dword, x (nonzero bytes = not a plain match),
-            //          masked-quality bits | record << 8 | lane}
-            uint4 *const queue = (uint4 *)(lds + a.queue_off) + (threadIdx.x >> 6) * EVQ_CAP;
-            int qcount = 0;
-
-            // Events undo the optimistic TC increment of each byte that was not a plain match and, for
-            // read bytes, count what the byte really is (rare_column).  64 events per pass.
-            auto drain_events = [&]() {
-                for (int base = 0; base < qcount; base += 64) {
-                    const int e = base + lane;
-                    const bool ev_ok = e < qcount;
-                    uint4 ev = make_uint4(0, 0, 0, 0);
-                    if (ev_ok) ev = queue[e];
-                    const int jr = (int)(ev.w >> 8) & 63;
-                    // all lanes execute the shuffles (a disabled source lane would return 0)
-                    const int e_w0 = __shfl(w0, jr), e_w1 = __shfl(w1, jr), e_tcb = __shfl(tcb, jr);
-                    if (ev_ok) {
-                        const int ln = (int)ev.w & 63;
-                        const bool is_read = ln < 2 * d.nl4;
-                        const int side = ln >= d.nl4;
-                        const int m = ln - (side ? d.nl4 : 0);
-                        const int rev = e_w1 & D_REV;
-                        const int lb = (int)((u32)e_w0 >> 16) * d.w_lib;
-                        const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
-                        // usually exactly one byte of the dword differs: handle the lowest non-matching byte
-                        // with per-lane shifts (all lanes busy), repeat only while some lane has another
-                        u32 xr = ev.z;
-                        while (xr) {
-                            const int jb = (__ffs((int)xr) - 1) >> 3;
-                            const int sh = 8 * jb;
-                            xr &= ~(0xFFu << sh);
-                            const u32 rb = (ev.y >> sh) & 0xFFu;
-                            bump_n<USE_LDS>(lds, raw, e_tcb + 64 * jb + ln + (int)(((rb >> 1) & 3u) << 8), 0xFFFFFFFFu);  // -1
-                            if (is_read)
-                                rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, side ? 4 * m + 3 - jb : 4 * m + jb,
-                                                     (ev.x >> sh) & 0xFFu, (int)(i8)rb, MASK && ((ev.w >> (sh + 7)) & 1u));
-                        }
-                    }
-                }
-                qcount = 0;
-                // nothing LDS-returning may be pending when control rejoins the hot loop: otherwise the
-                // compiler guards the loop's first instructions with s_waitcnt lgkmcnt(0), which also
-                // waits for the previous record's ds_add_u32s on every iteration
-                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            };
-
+            const int evw = ((w1 & D_REV) << 10) | (libid << 11);  // record part of an event's 4th word
             // software pipeline: four records in flight, each in its own register set (no register
             // rotation: a copy of an in-flight destination would wait for its load)
             struct Stage { u32 s4, r4, q4; int tcb, w1, j; bool valid; };
@@ -437,15 +437,17 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 tc_bump(r4_c, 9, base_b, 256, c_d1);
                 tc_bump(r4_c, 17, base_b, 512, c_d2);
                 tc_bump(r4_c, 25, base_b, 768, c_d3);
-                // ... and queue the lanes holding a byte that is not one (drain_events corrects them)
+                // ... and queue the lanes holding a byte that is not one (drain_pass corrects them)
                 const u64 mm = __ballot(x != 0);
                 if (mm) {
                     if (x != 0) {
-                        const int slot = qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                        queue[slot] = make_uint4(s4_c, r4_c, x, (mq & 0x80808080u) | ((u32)st.j << 8) | (u32)lane);
+                        const int slot = qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+                        u32 w = (u32)rl(evw, st.j) | ((u32)lane << 4);
+                        if (MASK) w |= ((mq >> 7) & 1u) | ((mq >> 14) & 2u) | ((mq >> 21) & 4u) | ((mq >> 28) & 8u);
+                        queue[slot & (EVQ_CAP - 1)] = make_uint4(s4_c, r4_c, x, w);
                     }
                     qcount += __popcll(mm);
-                    if (qcount > EVQ_CAP - 64) drain_events();
+                    if (qcount >= 64) drain_pass();  // at most 63 + 64 events are ever queued
                 }
             };
 
@@ -465,7 +467,6 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                     fill(st3);
                 } while (st0.valid);
             }
-            if (qcount) drain_events();
         }
 
         // ------------------------------------------------------------ phase 2b: gapped records
@@ -586,6 +587,9 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
         }
     }
 
+    if (FAST) {
+        while (qcount > 0) drain_pass();
+    }
     if (USE_LDS) {
         __syncthreads();
         u32 *out = a.partials + (i64)blockIdx.x * d.w_total;
