@@ -174,22 +174,24 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
     //   SEQ:       seq[scoef * nq + s0]   (flank lanes: a dummy, disabled by em = 0)
     // byte j is a task iff bit 8j of vm is set; (side, p) of byte j: p = pbase + pstep * j.
     int c_r0 = d.apad, c_rcoef = 0, c_s0 = 0, c_scoef = 0, c_side = 0, c_pbase = 0, c_pstep = 1;
+    int c_kind = 4, c_m4 = 0;  // lane kind: 0 left columns, 1 right columns, 2 left flank, 3 right flank, 4 none
     u32 c_em = 0, c_vm = 0;
     bool c_read = false;
     if (FAST) {
         const int m0 = lane, m1 = lane - d.nl4, m2 = lane - 2 * d.nl4, m3 = lane - 2 * d.nl4 - d.nf4;
         if (m0 < d.nl4) {
             c_r0 = d.apad + 4 * m0; c_s0 = 4 * m0; c_em = ~0u; c_read = true; c_side = 0; c_pbase = 4 * m0; c_pstep = 1;
+            c_kind = 0; c_m4 = 4 * m0;
             for (int j = 0; j < 4; j++) if (4 * m0 + j < L) c_vm |= 0xFFu << (8 * j);
         } else if (m1 < d.nl4) {
             c_rcoef = 1; c_r0 = d.apad - 4 - 4 * m1; c_scoef = 1; c_s0 = -4 - 4 * m1; c_em = ~0u; c_read = true;
-            c_side = 1; c_pbase = 4 * m1 + 3; c_pstep = -1;
+            c_side = 1; c_pbase = 4 * m1 + 3; c_pstep = -1; c_kind = 1; c_m4 = 4 * m1;
             for (int j = 0; j < 4; j++) if (4 * m1 + 3 - j < L) c_vm |= 0xFFu << (8 * j);
         } else if (m2 < d.nf4) {
-            c_r0 = d.apad - 4 * (m2 + 1);
+            c_r0 = d.apad - 4 * (m2 + 1); c_kind = 2; c_m4 = 4 * m2;
             for (int j = 0; j < 4; j++) if (4 * (m2 + 1) - j <= A) c_vm |= 0xFFu << (8 * j);
         } else if (m3 < d.nf4) {
-            c_rcoef = 1; c_r0 = d.apad + 4 * m3;
+            c_rcoef = 1; c_r0 = d.apad + 4 * m3; c_kind = 3; c_m4 = 4 * m3;
             for (int j = 0; j < 4; j++) if (4 * m3 + j + 1 <= A) c_vm |= 0xFFu << (8 * j);
         }
     }
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 sq = so + (u32)qs;
                 const int nbefore = pos < A ? (int)pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
-                const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 65536;
+                const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 32768;
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= 4 * d.nl4 && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
                 if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
@@ -466,6 +468,89 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                     if (st3.valid) count(st3);
                     fill(st3);
                 } while (st0.valid);
+            }
+
+            // -------- plain records with missing tasks (shorter than the window, or at a contig edge):
+            // same dword layout, the byte-validity mask is computed per record instead of per lane
+            u64 todo_p = __ballot(kept && (w1 & D_SIMPLE) && !(w1 & D_FULL));
+            todo_g &= ~todo_p;
+            if (todo_p) {
+                struct PStage { u32 s4, r4, q4; int nq, tcb, w1, j; bool valid; };
+                u64 pend_p = todo_p;
+                int last_p = __ffsll((long long)todo_p) - 1;
+                auto fill_p = [&](PStage &st) {
+                    st.valid = pend_p != 0;
+                    const int j = st.valid ? __ffsll((long long)pend_p) - 1 : last_p;
+                    pend_p &= pend_p - 1;
+                    last_p = j;
+                    st.j = j;
+                    const int s_wq = rl(wq, j);
+                    const int s_nq = s_wq & 0xFFFF;
+                    st.nq = s_nq;
+                    st.tcb = (int)((u32)s_wq >> 16);
+                    st.w1 = rl(w1, j);
+                    u64 roff = (u32)rl(rf_lo, j);
+                    if (!a.ref32) roff |= (u64)(u32)rl(rf_hi, j) << 32;
+                    // a right-column dword of a short record may start before the record: its window offset
+                    // is negative (down to -(4 nl4 - 1), still inside the 256-byte guard band), so bias it
+                    const u8 *__restrict__ refB = (a.ref - 512) + roff;
+                    const u32 s_sq = (u32)rl((int)sq, j);
+                    const u8 *__restrict__ seqP = a.seq + s_sq;
+                    const u32 ro = (u32)(c_rcoef * s_nq + c_r0 + 256);
+                    int so = c_scoef * s_nq + c_s0;                     // may leave the record: clamp to 0
+                    if (so < 0 || so >= s_nq) so = 0;
+                    st.r4 = *(const u32_u *)(refB + ro);
+                    st.s4 = *(const u32_u *)(seqP + (u32)so);
+                    if (MASK) st.q4 = *(const u32_u *)(a.qual + s_sq + (u32)so);
+                };
+                auto count_p = [&](const PStage &st) {
+                    const int nb = (st.w1 >> D_NB_SHIFT) & 0xFF, na = (st.w1 >> D_NA_SHIFT) & 0xFF;
+                    // valid bytes of this lane: nv of them, at the low end (left columns, right flank:
+                    // increasing position) or at the high end (right columns, left flank)
+                    const int avail = (c_kind < 2 ? st.nq : (c_kind == 2 ? nb : na)) - c_m4;
+                    const int nv = avail < 0 ? 0 : (avail > 4 ? 4 : avail);
+                    const bool top = c_kind == 1 || c_kind == 2;
+                    const u32 ones = 0xFFFFFFFFu;
+                    const u32 dyn = nv == 0 ? 0u : (top ? ones << (32 - 8 * nv) : ones >> (32 - 8 * nv));
+                    const u32 vm = c_vm & dyn;
+                    // a right-column dword that starts before the record was loaded at offset 0: shift it
+                    u32 s4_c = st.s4, q4_c = st.q4;
+                    const int before = c_m4 + 4 - st.nq;  // bytes of the dword in front of the record
+                    if (c_kind == 1 && before > 0 && before < 4) { s4_c <<= 8 * before; q4_c <<= 8 * before; }
+                    const u32 r4_c = st.r4;
+                    u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
+                    u32 mq = 0;
+                    if (MASK) {
+                        const u32 minq4 = (st.w1 & D_HASQ) ? (u32)a.minqual * 0x01010101u : 0u;
+                        mq = ~((q4_c | 0x80808080u) - minq4) & 0x80808080u & c_em;
+                        x |= mq;
+                    }
+                    x &= vm;
+                    const u32 base_b = ((u32)(st.tcb + lane) << 2) + __builtin_amdgcn_groupstaticsize();
+                    tc_bump(r4_c, 1, base_b, 0, vm & 1u);
+                    tc_bump(r4_c, 9, base_b, 256, (vm >> 8) & 1u);
+                    tc_bump(r4_c, 17, base_b, 512, (vm >> 16) & 1u);
+                    tc_bump(r4_c, 25, base_b, 768, (vm >> 24) & 1u);
+                    const u64 mm = __ballot(x != 0);
+                    if (mm) {
+                        if (x != 0) {
+                            const int slot = qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+                            u32 w = (u32)rl(evw, st.j) | ((u32)lane << 4);
+                            if (MASK) w |= ((mq >> 7) & 1u) | ((mq >> 14) & 2u) | ((mq >> 21) & 4u) | ((mq >> 28) & 8u);
+                            queue[slot & (EVQ_CAP - 1)] = make_uint4(s4_c, r4_c, x, w);
+                        }
+                        qcount += __popcll(mm);
+                        if (qcount >= 64) drain_pass();
+                    }
+                };
+                PStage p0{}, p1{};
+                fill_p(p0); fill_p(p1);
+                do {
+                    if (p0.valid) count_p(p0);
+                    fill_p(p0);
+                    if (p1.valid) count_p(p1);
+                    fill_p(p1);
+                } while (p0.valid);
             }
         }
 
