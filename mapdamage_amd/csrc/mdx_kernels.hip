@@ -565,6 +565,10 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             const int s_nrg = s_n0 + rl(nI, j);
             const u32 s_co = (u32)rl((int)cig_o, j);
             const int s_cn = rl(cig_n, j);
+            // the record's CIGAR, one op per lane (a single coalesced load); the walks below read it with
+            // v_readlane instead of a dependent memory load per op (records with > 64 ops re-read memory)
+            const u32 op_lane = lane < s_cn ? a.cigar[s_co + lane] : 0u;
+            auto op_at = [&](int k) -> u32 { return s_cn <= 64 ? (u32)rl((int)op_lane, k) : a.cigar[s_co + k]; };
             const i64 s_rbase = ((i64)rl(rb_hi, j) << 32) | (u32)rl(rb_lo, j);
             const u32 s_sq = (u32)rl((int)sq, j);
             const int rev = s_w1 & D_REV;
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 // reference index under gapped-reference column jr (-1 = insertion gap)
                 int col = 0, qoff = 0, shift = 0, qi = -2, rix = -2;
                 for (int k = 0; k < s_cn; k++) {
-                    const u32 cg = a.cigar[s_co + k];
+                    const u32 cg = op_at(k);
                     const int op = cg & 0xF;
                     const int len = (int)(cg >> 4);
                     if (op == 0 || op == 7 || op == 8) {
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                         if (jr < s_ncols) {
                             int c2 = 0, q2 = 0, qj = -2;
                             for (int k = 0; k < s_cn && qj == -2; k++) {
-                                const u32 cg = a.cigar[s_co + k];
+                                const u32 cg = op_at(k);
                                 const int op = cg & 0xF;
                                 const int len = (int)(cg >> 4);
                                 if (op == 0 || op == 7 || op == 8 || op == 1) {
