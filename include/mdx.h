@@ -127,6 +127,12 @@ int mdx_reset(mdx_ctx *ctx);
 int mdx_timing_enable(mdx_ctx *ctx, int enable);
 int mdx_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
 
+/* Replaces seqtk.comp() of the reference's native extension (mapdamage/seqtk/seqtk.c:55-143) as
+ * used by composition.write_base_comp (mapdamage/composition.py:6-25): per-contig counts of
+ * A, C, G, T (upper and lower case folded) of the resident reference.
+ * counts: host buffer of n_contig * 4 uint64, order A, C, G, T.  Synchronous. */
+int mdx_genome_composition(mdx_ctx *ctx, uint64_t *counts);
+
 /* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
 int mdx_table_mode(const mdx_ctx *ctx);
 

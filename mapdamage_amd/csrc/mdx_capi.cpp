@@ -432,4 +432,23 @@ int mdx_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
 
 int mdx_table_mode(const mdx_ctx *c) { return c ? c->mode : -1; }
 
+int mdx_genome_composition(mdx_ctx *c, uint64_t *counts) {
+    if (!c || !counts) return MDX_ERR_ARG;
+    if (!c->d_ref) return fail(c, MDX_ERR_STATE, "mdx_set_reference has not been called");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    unsigned long long *d_out = nullptr;
+    const size_t bytes = (size_t)c->n_contig * 4 * 8;
+    HIP_TRY(c, hipMalloc((void **)&d_out, bytes));
+    hipError_t e = hipMemsetAsync(d_out, 0, bytes, c->stream);
+    if (e == hipSuccess) {
+        mdx_k_genome_comp(c->d_ref + 256, c->d_contig_off, c->n_contig, d_out, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(counts, d_out, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, MDX_ERR_HIP, hipGetErrorString(e));
+    return MDX_OK;
+}
+
 }  // extern "C"

@@ -115,3 +115,5 @@ void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, in
 void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
                     const unsigned long long *n_lgd_over, MdxDims d, unsigned long long *out,
                     hipStream_t s);
+void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_contig, unsigned long long *out,
+                       hipStream_t s);

@@ -819,3 +819,43 @@ void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd
                     hipStream_t s) {
     hipLaunchKernelGGL(finalize_kernel, dim3(512), dim3(256), 0, s, raw, lgd_dense, n_lgd_over, d, out);
 }
+
+// Genome base composition (mapdamage/composition.py:6-25 over seqtk.c:79-104): per-contig counts of
+// A, C, G, T with upper and lower case folded — here read from the resident, already case-folded
+// reference.  HBM-streaming reduction: 16 bytes per lane, per-lane counts, wavefront reduction,
+// one atomic per (wavefront, contig, base).
+__global__ void genome_comp_kernel(const u8 *__restrict__ ref, const i64 *__restrict__ contig_off, int n_contig,
+                                   u64 *__restrict__ out) {
+    const i64 total = contig_off[n_contig];
+    const i64 nchunk = (total + 15) >> 4;
+    for (i64 chunk = (i64)blockIdx.x * blockDim.x + threadIdx.x; chunk < nchunk; chunk += (i64)gridDim.x * blockDim.x) {
+        const i64 b0 = chunk << 4;
+        // contig of the chunk's first base (binary search on the offsets)
+        int lo = 0, hi = n_contig - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (contig_off[mid] <= b0) lo = mid; else hi = mid - 1;
+        }
+        int cur = lo;
+        u32 cnt[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; k++) {
+            const i64 b = b0 + k;
+            if (b >= total) break;
+            while (b >= contig_off[cur + 1]) {
+                for (int c = 0; c < 4; c++) if (cnt[c]) { atomicAdd(&out[(i64)cur * 4 + c], (u64)cnt[c]); cnt[c] = 0; }
+                cur++;
+            }
+            const int r = (i8)ref[b];
+            if (r >= 0) {  // A,C,T,G classes 0,1,2,3 -> output order A,C,G,T
+                const int k2 = (r >> 1) & 3;
+                cnt[k2 ^ (k2 >> 1)]++;
+            }
+        }
+        for (int c = 0; c < 4; c++) if (cnt[c]) atomicAdd(&out[(i64)cur * 4 + c], (u64)cnt[c]);
+    }
+}
+
+void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_contig, unsigned long long *out,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(genome_comp_kernel, dim3(2048), dim3(256), 0, s, ref, (const i64 *)contig_off, n_contig, out);
+}

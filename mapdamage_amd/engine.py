@@ -23,7 +23,7 @@ EXPORTS = (
     "mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
     "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_table_words",
     "mdx_finish_device", "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
-    "mdx_table_mode",
+    "mdx_table_mode", "mdx_genome_composition",
 )
 
 
@@ -80,7 +80,7 @@ def load_library(path=None):
     for name in ("mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
                  "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_finish_device",
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
-                 "mdx_table_mode"):
+                 "mdx_table_mode", "mdx_genome_composition"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -255,6 +255,12 @@ class DamageEngine:
         self._check(self._lib.mdx_finish(self._ctx, None, None, None, _ptr(over), ctypes.c_int64(cap),
                                          ctypes.byref(n_over), None))
         return over[:min(cap, n_over.value)].copy()
+
+    def genome_composition(self, n_contig):
+        """Per-contig A, C, G, T counts of the resident reference (seqtk.comp of the reference)."""
+        counts = np.zeros((n_contig, 4), np.uint64)
+        self._check(self._lib.mdx_genome_composition(self._ctx, _ptr(counts)))
+        return counts
 
     def reset(self):
         self._check(self._lib.mdx_reset(self._ctx))

@@ -36,7 +36,7 @@ def test_oracle_rejects_alignment_past_contig_end():
 
 def test_golden_fixture_inventory():
     names = golden_names()
-    assert len(names) >= 15
+    assert len(names) >= 15 and not any(n.startswith("genome_") for n in names)
     for n in names:
         g = Golden(n)
         assert g.batch.n == g.meta["n_reads"]

@@ -12,7 +12,7 @@ GOLDEN = pathlib.Path(__file__).resolve().parent / "golden"
 
 
 def golden_names():
-    return sorted(p.stem for p in GOLDEN.glob("*.npz"))
+    return sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("genome_"))
 
 
 class Golden:

@@ -132,6 +132,31 @@ def main():
               LIBS1, 70, 10, 15)
     save_case("config4s_L70_A10", mref, synth.config4_batch(mref, 4000, seed=4), LIBS1, 70, 10, 0)
 
+    # dnacomp_genome.csv through the reference's composition.write_base_comp, with its own native
+    # seqtk extension compiled into oracle/_ref (never copied): SURVEY §8f N4
+    import tempfile
+    from mapdamage_amd import fasta
+    from oracle import ref_seqtk
+    seqtk = ref_seqtk.load()
+    md = ref_harness.import_reference()
+    sys.modules["mapdamage.seqtk"] = seqtk
+    import importlib
+    import mapdamage.composition as refcomp
+    refcomp.seqtk = seqtk
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = pathlib.Path(tmp) / "g.fa"
+        fasta.write_fasta(fa, mref)
+        refcomp.write_base_comp(fa, pathlib.Path(tmp) / "dnacomp_genome.csv")
+        text = (pathlib.Path(tmp) / "dnacomp_genome.csv").read_bytes()
+        per_contig = [[c["A"], c["C"], c["G"], c["T"]] for c in seqtk.comp(str(fa))]
+    np.savez_compressed(GOLDEN / "genome_composition.npz",
+                        ref_bases=np.frombuffer(b"".join(mref.seqs), dtype=np.uint8),
+                        ref_lengths=np.asarray(mref.lengths, dtype=np.int64),
+                        names=np.frombuffer(json.dumps(mref.names).encode(), dtype=np.uint8),
+                        counts=np.asarray(per_contig, dtype=np.uint64),
+                        csv=np.frombuffer(text, dtype=np.uint8))
+    print("genome_composition         ", per_contig, text)
+
     if args.time:
         big = synth.config2_batch(mref, 100_000, seed=2)
         t0 = time.perf_counter()
