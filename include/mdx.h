@@ -133,6 +133,22 @@ int mdx_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
  * counts: host buffer of n_contig * 4 uint64, order A, C, G, T.  Synchronous. */
 int mdx_genome_composition(mdx_ctx *ctx, uint64_t *counts);
 
+/* Quality rescaling, mapdamage/rescale.py (BASELINE configs[4]).
+ * mdx_rescale_set_model replaces _get_corr_prob + the per-column floating-point work of
+ * _rescale_qual_read (rescale.py:23-46, 228-246): `lut` [2][1+len5p+len3p][94] maps (substitution
+ * 0 = C>T / 1 = G>A, position key, old Phred) to the new Phred; `term` [2][1+len5p+len3p] is the
+ * per-column contribution to the MR tag.  Position key 0 = no correction, 1..len5p = position from
+ * the 5' end, len5p+k = position -k from the 3' end (mapdamage_amd/rescale.py builds both with the
+ * reference's own expressions).
+ * mdx_rescale_host replaces _rescale_qual_core's loop (rescale.py:300-344) for a batch: record
+ * routing, _rescale_qual_read, soft-clip re-attachment.  Host pointers; synchronous.  qual_out has
+ * the layout of batch->qual; mr_raw[i] is the MR sum before its "%.5f" truncation (NaN when record i
+ * is written unchanged); status[i]: 0 unmapped, 1 no qualities, 2 rescaled from both ends,
+ * 3 rescaled from the 5' end only (inward-facing pair), 4 improperly paired (unchanged). */
+int mdx_rescale_set_model(mdx_ctx *ctx, const uint8_t *lut, const double *term, int32_t len5p, int32_t len3p);
+int mdx_rescale_host(mdx_ctx *ctx, const mdx_batch *batch, const int32_t *mtid, const int32_t *mpos,
+                     uint8_t *qual_out, double *mr_raw, uint8_t *status);
+
 /* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
 int mdx_table_mode(const mdx_ctx *ctx);
 

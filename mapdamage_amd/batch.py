@@ -28,6 +28,8 @@ class ReadBatch:
     seq_off: np.ndarray     # u32[n+1]
     seq: np.ndarray         # u8[n_bases] ASCII
     qual: Optional[np.ndarray] = None  # u8[n_bases] raw phred, or None
+    mtid: Optional[np.ndarray] = None  # i32[n] mate reference id (only the rescale routing reads it)
+    mpos: Optional[np.ndarray] = None  # i32[n] mate position
 
     @property
     def n(self):
@@ -66,6 +68,8 @@ class ReadBatch:
             seq_off=(self.seq_off[lo:hi + 1] - np.uint32(s0)).astype(np.uint32),
             seq=self.seq[s0:s1].copy(),
             qual=None if self.qual is None else self.qual[s0:s1].copy(),
+            mtid=None if self.mtid is None else self.mtid[lo:hi].copy(),
+            mpos=None if self.mpos is None else self.mpos[lo:hi].copy(),
         )
 
     def take(self, index):

@@ -55,6 +55,10 @@ struct mdx_ctx {
     uint32_t *d_partials = nullptr;
     // staging for mdx_tabulate_host
     DevBuf st[10];
+    // rescale model (mdx_rescale_set_model)
+    uint8_t *d_lut = nullptr;
+    double *d_term = nullptr;
+    int len5p = 0, len3p = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -164,7 +168,7 @@ void mdx_destroy(mdx_ctx *c) {
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &b : c->st) b.release();
     void *ptrs[] = {c->d_ref, c->d_contig_off, c->d_raw, c->d_lgd_dense, c->d_lgd_over,
-                    c->d_n_lgd_over, c->d_err, c->d_partials};
+                    c->d_n_lgd_over, c->d_err, c->d_partials, c->d_lut, c->d_term};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -431,6 +435,66 @@ int mdx_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
 }
 
 int mdx_table_mode(const mdx_ctx *c) { return c ? c->mode : -1; }
+
+int mdx_rescale_set_model(mdx_ctx *c, const uint8_t *lut, const double *term, int32_t len5p, int32_t len3p) {
+    if (!c || !lut || !term || len5p < 0 || len3p < 0 || len5p + len3p > 100000) return fail(c, MDX_ERR_ARG, "rescale model");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_lut) { (void)hipFree(c->d_lut); c->d_lut = nullptr; }
+    if (c->d_term) { (void)hipFree(c->d_term); c->d_term = nullptr; }
+    const size_t npos = (size_t)1 + len5p + len3p;
+    HIP_TRY(c, hipMalloc((void **)&c->d_lut, 2 * npos * 94));
+    HIP_TRY(c, hipMalloc((void **)&c->d_term, 2 * npos * 8));
+    HIP_TRY(c, hipMemcpy(c->d_lut, lut, 2 * npos * 94, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_term, term, 2 * npos * 8, hipMemcpyHostToDevice));
+    c->len5p = len5p; c->len3p = len3p;
+    return MDX_OK;
+}
+
+int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const int32_t *mpos, uint8_t *qual_out,
+                     double *mr_raw, uint8_t *status) {
+    int rc = check_batch(c, h);
+    if (rc != MDX_OK) return rc;
+    if (!c->d_ref || !c->d_lut) return fail(c, MDX_ERR_STATE, "set_reference and rescale_set_model first");
+    if (!h->qual || !mtid || !mpos || !qual_out || !mr_raw || !status) return fail(c, MDX_ERR_ARG, "null column");
+    if (h->n_reads == 0) return MDX_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    mdx_batch dv;
+    rc = mdx_batch_upload(c, h, &dv);
+    if (rc != MDX_OK) return rc;
+    const int64_t n = h->n_reads;
+    int32_t *d_mtid = nullptr, *d_mpos = nullptr;
+    uint8_t *d_qout = nullptr, *d_status = nullptr;
+    double *d_mr = nullptr;
+    hipError_t e = hipMalloc((void **)&d_mtid, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_mpos, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_qout, (size_t)h->n_bases + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_status, (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_mr, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_mtid, mtid, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_mpos, mpos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        MdxRescaleArgs a{};
+        a.n_reads = n; a.flag = dv.flag; a.tid = dv.tid; a.pos = dv.pos; a.mtid = d_mtid; a.mpos = d_mpos;
+        a.cigar_off = dv.cigar_off; a.cigar = dv.cigar; a.seq_off = dv.seq_off; a.seq = dv.seq; a.qual = dv.qual;
+        a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
+        a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
+        a.qual_out = d_qout; a.mr_raw = d_mr; a.status = d_status; a.err = c->d_err;
+        int64_t want = (n + 3) / 4;
+        const int cap = c->n_cu * 8;
+        mdx_k_rescale(a, (int)(want < cap ? want : cap), c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(qual_out, d_qout, (size_t)h->n_bases, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(mr_raw, d_mr, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(status, d_status, (size_t)n, hipMemcpyDeviceToHost);
+    void *tmp[] = {d_mtid, d_mpos, d_qout, d_status, d_mr};
+    for (void *p : tmp) if (p) (void)hipFree(p);
+    (void)mdx_batch_free(c, &dv);
+    if (e != hipSuccess) return fail(c, MDX_ERR_HIP, hipGetErrorString(e));
+    return mdx_sync(c, nullptr);
+}
 
 int mdx_genome_composition(mdx_ctx *c, uint64_t *counts) {
     if (!c || !counts) return MDX_ERR_ARG;

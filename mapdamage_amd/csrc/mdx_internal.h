@@ -117,3 +117,22 @@ void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd
                     hipStream_t s);
 void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_contig, unsigned long long *out,
                        hipStream_t s);
+
+struct MdxRescaleArgs {
+    int64_t n_reads;
+    const uint16_t *flag;
+    const int32_t *tid, *pos, *mtid, *mpos;
+    const uint32_t *cigar_off, *cigar, *seq_off;
+    const uint8_t *seq, *qual;
+    const uint8_t *ref;
+    const int64_t *contig_off;
+    int n_contig;
+    const uint8_t *lut;      // [2][npos][94]
+    const double *term;      // [2][npos]
+    int len5p, len3p;
+    uint8_t *qual_out;
+    double *mr_raw;
+    uint8_t *status;
+    unsigned long long *err;
+};
+void mdx_k_rescale(const MdxRescaleArgs &a, int grid, hipStream_t s);

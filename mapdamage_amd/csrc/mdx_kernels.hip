@@ -859,3 +859,154 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
                        hipStream_t s) {
     hipLaunchKernelGGL(genome_comp_kernel, dim3(2048), dim3(256), 0, s, ref, (const i64 *)contig_off, n_contig, out);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Quality rescaling (mapdamage/rescale.py:195-365; BASELINE config[4]).  One wavefront per record;
+// one lane per query base, walked in the read's own 5'->3' order so that the MR sum is
+// accumulated in the reference's column order (fp64, bit-exact).  The new quality is a byte lookup
+// LUT[sub][position key][old quality] prepared on the host with the reference's floating-point
+// expressions (mapdamage_amd/rescale.py).
+__global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
+    const int lane = threadIdx.x & 63;
+    const i64 gwave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    const int npos = 1 + a.len5p + a.len3p;
+    for (i64 ri = gwave; ri < a.n_reads; ri += nwaves) {
+        const u32 fl = a.flag[ri];
+        const u32 so = a.seq_off[ri];
+        const int lseq = (int)(a.seq_off[ri + 1] - so);
+        const u32 co = a.cigar_off[ri];
+        const int cn = (int)(a.cigar_off[ri + 1] - co);
+        const u8 *__restrict__ qin = a.qual + so;
+        u8 *__restrict__ qout = a.qual_out + so;
+        const int rev = (fl >> 4) & 1, mate_rev = (fl >> 5) & 1;
+        // record routing, rescale.py:300-342
+        int st, forward_only = 0;
+        if (fl & 0x4) st = 0;
+        else if (lseq == 0 || qin[0] == 0xFF) st = 1;
+        else if (fl & 0x1) {
+            const int pos = a.pos[ri], mp = a.mpos[ri];
+            const bool same = a.tid[ri] == a.mtid[ri];
+            if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; forward_only = 1; }
+            else st = 4;
+        } else st = 2;
+        if (lane == 0) { a.status[ri] = (u8)st; a.mr_raw[ri] = __builtin_nan(""); }
+        if (st < 2 || st == 4) {
+            for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
+            continue;
+        }
+        // CIGAR: one op per lane; scan by lane 0's view via readlane
+        const u32 op_lane = lane < cn ? a.cigar[co + lane] : 0u;
+        auto op_at = [&](int k) -> u32 { return cn <= 64 ? (u32)rl((int)op_lane, k) : a.cigar[co + k]; };
+        int qs = 0, clipr = 0, rlen = 0, ncols = 0, nI = 0, qcons = 0;
+        bool leading = true;
+        for (int k = 0; k < cn; k++) {
+            const u32 c = op_at(k);
+            const int op = c & 0xF, len = (int)(c >> 4);
+            if (leading) { if (op == 4) qs += len; else if (op != 5) leading = false; }
+            if (op == 0 || op == 7 || op == 8) { ncols += len; rlen += len; qcons += len; }
+            else if (op == 1) { ncols += len; nI += len; qcons += len; }
+            else if (op == 2) { ncols += len; rlen += len; }
+            else if (op == 3) rlen += len;
+        }
+        for (int k = cn - 1; k >= 1; k--) {
+            const u32 c = op_at(k);
+            const int op = c & 0xF;
+            if (op == 5) continue;
+            if (op == 4) clipr += (int)(c >> 4); else break;
+        }
+        const int nq = lseq - qs - clipr > 0 ? lseq - qs - clipr : 0;
+        const int n0 = rlen ? rlen : 1;
+        const int nrg = n0 + nI;
+        const int tid = a.tid[ri];
+        const i64 pos = a.pos[ri];
+        bool bad = cn == 0 || tid < 0 || tid >= a.n_contig || pos < 0 || nq != qcons;
+        i64 rbase = 0;
+        if (!bad) {
+            const i64 c0 = a.contig_off[tid];
+            bad = pos + n0 > a.contig_off[tid + 1] - c0;
+            rbase = c0 + pos;
+        }
+        // rescale.py:266-271 re-attaches clips only when the first / last op is S: any other clip
+        // layout (H before S) leaves a quality string of the wrong length, which pysam rejects
+        if (!bad) {
+            const u32 f = op_at(0), l = op_at(cn - 1);
+            const int pre = (f & 0xF) == 4 ? (int)(f >> 4) : 0, suf = (l & 0xF) == 4 ? (int)(l >> 4) : 0;
+            bad = pre != qs || suf != clipr || (cn == 1 && (f & 0xF) == 4);
+        }
+        if (bad) {
+            if (lane == 0) flag_error(a.err, ri, ERR_BAD_READ);
+            for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
+            continue;
+        }
+        // soft-clipped qualities are kept
+        for (int b = lane; b < qs; b += 64) qout[b] = qin[b];
+        for (int b = qs + nq + lane; b < lseq; b += 64) qout[b] = qin[b];
+
+        const i8 *__restrict__ rp = (const i8 *)a.ref + rbase;
+        const u8 *__restrict__ sp = a.seq + so + qs;
+        double mr = 0.0;
+        for (int base = 0; base < nq; base += 64) {
+            const int oq = base + lane;                 // query base in read orientation (0 = 5' end)
+            double term = 0.0;
+            if (oq < nq) {
+                const int qi = rev ? nq - 1 - oq : oq;  // forward query index
+                // gapped-read column of query base qi, then the gapped-reference column facing it
+                // (each string is reversed from its own end on the reverse strand, rescale.py:221-224)
+                int col = 0, qoff = 0, js = -1;
+                for (int k = 0; k < cn && js < 0; k++) {
+                    const u32 c = op_at(k);
+                    const int op = c & 0xF, len = (int)(c >> 4);
+                    if (op == 0 || op == 7 || op == 8 || op == 1) {
+                        if (qi < qoff + len) js = col + (qi - qoff);
+                        col += len; qoff += len;
+                    } else if (op == 2) col += len;
+                }
+                const int jr = rev ? nrg - ncols + js : js;
+                int c2 = 0, shift = 0, rix = -2;
+                for (int k = 0; k < cn && rix == -2; k++) {
+                    const u32 c = op_at(k);
+                    const int op = c & 0xF, len = (int)(c >> 4);
+                    if (op == 1) {
+                        if (jr < c2) rix = jr - shift;
+                        else if (jr < c2 + len) rix = -1;
+                        shift += len; c2 += len;
+                    } else if (op == 0 || op == 7 || op == 8 || op == 2) c2 += len;
+                }
+                if (rix == -2) rix = jr - shift;
+                const int rch = rix < 0 ? -1 : (int)rp[rix];
+                const u32 ch = sp[qi];
+                const u32 q = qin[qs + qi];
+                // read-orientation pair (T,C) -> C>T ; (A,G) -> G>A; complemented on the reverse strand
+                int sub = -1;
+                if (!rev) { if (ch == 'T' && rch == 'C') sub = 0; else if (ch == 'A' && rch == 'G') sub = 1; }
+                else { if (ch == 'A' && rch == 'G') sub = 0; else if (ch == 'T' && rch == 'C') sub = 1; }
+                u32 newq = q;
+                if (sub >= 0) {
+                    // _corr_this_base, rescale.py:49-79
+                    int p = oq + 1;
+                    const int back = p - nq - 1;
+                    if (!forward_only && p >= -back) p = back;
+                    const int key = p > 0 ? (p <= a.len5p ? p : 0) : (-p <= a.len3p ? a.len5p - p : 0);
+                    term = a.term[sub * npos + key];
+                    if (q <= 93) newq = a.lut[(sub * npos + key) * 94 + q];
+                }
+                qout[qs + qi] = (u8)newq;
+            }
+            // ordered fp64 accumulation of the non-zero terms (x + 0.0 == x exactly)
+            u64 nz = __ballot(term != 0.0);
+            while (nz) {
+                const int l = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                const int lo = rl(__double2loint(term), l), hi = rl(__double2hiint(term), l);
+                mr += __hiloint2double(hi, lo);
+            }
+        }
+        if (lane == 0) a.mr_raw[ri] = mr;
+    }
+}
+
+void mdx_k_rescale(const MdxRescaleArgs &a, int grid, hipStream_t s) {
+    if (a.n_reads <= 0) return;
+    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(256), 0, s, a);
+}

@@ -23,7 +23,7 @@ EXPORTS = (
     "mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
     "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_table_words",
     "mdx_finish_device", "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
-    "mdx_table_mode", "mdx_genome_composition",
+    "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
 )
 
 
@@ -80,7 +80,7 @@ def load_library(path=None):
     for name in ("mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
                  "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_finish_device",
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
-                 "mdx_table_mode", "mdx_genome_composition"):
+                 "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host"):
         getattr(lib, name).restype = ctypes.c_int
     if path is None:
         _lib = lib
@@ -261,6 +261,31 @@ class DamageEngine:
         counts = np.zeros((n_contig, 4), np.uint64)
         self._check(self._lib.mdx_genome_composition(self._ctx, _ptr(counts)))
         return counts
+
+    def set_rescale_model(self, model):
+        """``model``: mapdamage_amd.rescale.RescaleModel."""
+        lut = np.ascontiguousarray(model.lut, dtype=np.uint8)
+        term = np.ascontiguousarray(model.term, dtype=np.float64)
+        self._check(self._lib.mdx_rescale_set_model(self._ctx, _ptr(lut), _ptr(term),
+                                                    ctypes.c_int32(model.len5p), ctypes.c_int32(model.len3p)))
+
+    def rescale(self, batch: ReadBatch):
+        """Rescaled qualities, raw MR sums (NaN = record unchanged) and routing status per record
+        (mapdamage/rescale.py:285-365).  ``batch`` needs ``qual``, ``mtid`` and ``mpos``."""
+        if batch.qual is None or batch.mtid is None or batch.mpos is None:
+            raise ValueError("rescaling needs the qual, mtid and mpos columns")
+        hb = _host_batch(batch)
+        mtid = np.ascontiguousarray(batch.mtid, dtype=np.int32)
+        mpos = np.ascontiguousarray(batch.mpos, dtype=np.int32)
+        qual_out = np.zeros_like(batch.qual)
+        mr = np.zeros(batch.n, np.float64)
+        status = np.zeros(batch.n, np.uint8)
+        rc = self._lib.mdx_rescale_host(self._ctx, ctypes.byref(hb), _ptr(mtid), _ptr(mpos), _ptr(qual_out),
+                                        _ptr(mr), _ptr(status))
+        if rc == L.MDX_ERR_BAD_READ:
+            raise BadReadError(-1, self._lib.mdx_last_error(self._ctx).decode())
+        self._check(rc)
+        return qual_out, mr, status
 
     def reset(self):
         self._check(self._lib.mdx_reset(self._ctx))

@@ -78,9 +78,12 @@ def build_parser():
 def parse_args(argv):
     parser = build_parser()
     o = parser.parse_args(argv)
-    if o.plot_only or o.stats_only or o.rescale or o.rescale_only or o.check_R_packages:
-        parser.error("plotting, the Bayesian estimation and rescaling are not part of this engine "
-                     "(tabulation pass only); run them with the reference on the emitted tables")
+    if o.plot_only or o.stats_only or o.rescale or o.check_R_packages:
+        parser.error("plotting and the Bayesian estimation are not part of this engine; run them with the "
+                     "reference on the emitted tables (--rescale-only works from an existing "
+                     "Stats_out_MCMC_correct_prob.csv)")
+    if o.rescale_only and not o.folder:
+        parser.error("--folder required when using --rescale-only")
     if not o.filename:
         parser.error("--input SAM/BAM file not specified")
     if not o.ref:
@@ -100,7 +103,44 @@ def parse_args(argv):
         o.folder = Path(o.filename.stem + ".mapDamage")
     o.folder.mkdir(parents=True, exist_ok=True, mode=0o750)
     o.no_stats = True
+    if not o.rescale_out and o.rescale_only:
+        o.rescale_out = o.folder / (o.filename.stem + ".rescaled.bam")
+    if o.rescale_length_3p is None:
+        o.rescale_length_3p = o.seq_length
+    elif not (0 <= o.rescale_length_3p <= o.seq_length):
+        parser.error("--rescale-length-3p must be less than or equal to --seq-length and greater than zero")
+    if o.rescale_length_5p is None:
+        o.rescale_length_5p = o.seq_length
+    elif not (0 <= o.rescale_length_5p <= o.seq_length):
+        parser.error("--rescale-length-5p must be less than or equal to --seq-length and greater than zero")
     return o
+
+
+def rescale_qual(options):
+    """Mirror of rescale.rescale_qual (mapdamage/rescale.py:368-383) for --rescale-only."""
+    from .rescale import RescaleError, RescaleModel, rescale_bam
+    from .sam import read_bam
+    logger = logging.getLogger(__name__)
+    logger.info("Rescaling BAM: '%s' -> '%s'", options.filename, options.rescale_out)
+    start = time.time()
+    try:
+        model = RescaleModel.from_csv(options.folder / "Stats_out_MCMC_correct_prob.csv",
+                                      options.rescale_length_5p, options.rescale_length_3p)
+        names = read_bam(options.filename).header.references
+        ref = reference_for_bam(options.ref, names)
+        with DamageEngine([("*", "*")], options.length, options.around, 0, device=options.device) as engine:
+            counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model)
+    except RescaleError as error:
+        logger.error("%s", error)
+        return 1
+    if counts["inward_pairs"] or counts["improper_pairs"]:
+        logger.warning("Processed %i paired reads, assumed to be non-overlapping, facing inwards and correctly "
+                       "paired; %i of these were excluded as improperly paired.",
+                       counts["inward_pairs"] + counts["improper_pairs"], counts["improper_pairs"])
+    if counts["without_qualities"]:
+        logger.warning("Skipped %i reads without quality scores", counts["without_qualities"])
+    logger.debug("Rescaling completed in %f seconds", time.time() - start)
+    return 0
 
 
 def main(argv):
@@ -118,6 +158,9 @@ def main(argv):
     logging.getLogger().addHandler(handler)
     try:
         logger.info("Started with the command: " + " ".join(sys.argv))
+        if options.rescale_only:
+            logger.info("Starting rescaling...")
+            return rescale_qual(options)
         reader = BAMReader(options.filename, merge_libraries=options.merge_libraries,
                            downsample_to=options.downsample, downsample_seed=options.downsample_seed)
         reflengths = reader.get_references()

@@ -1,0 +1,113 @@
+"""Quality rescaling (mapdamage/rescale.py; BASELINE config[4]).
+
+The reference lowers the base quality of every C>T (5' side) / G>A (3' side) column by the
+posterior damage probability of its position (``_rescale_qual_read``, rescale.py:195-282).  The
+new quality depends only on (substitution, position key, old quality), so the floating-point
+work — ``10 ** x``, ``math.log10``, Python's half-to-even ``round`` — is done **once on the host,
+with the reference's own expressions**, into an integer lookup table; the HIP kernel is a pure
+byte lookup and therefore bit-exact.  The ``MR`` tag (sum of the correction probabilities of a
+read, rescale.py:246,275) is summed on the device in fp64 in the reference's column order.
+"""
+
+import csv
+import math
+import pathlib
+
+import numpy as np
+
+STATUS_UNMAPPED, STATUS_NO_QUAL, STATUS_BOTH, STATUS_FORWARD, STATUS_IMPROPER = range(5)
+
+
+class RescaleError(RuntimeError):
+    pass
+
+
+def get_corr_prob(filepath, rescale_length_5p, rescale_length_3p):
+    """``{(ref, read, position): probability}`` from Stats_out_MCMC_correct_prob.csv
+    (rescale.py:23-46)."""
+    filepath = pathlib.Path(filepath)
+    try:
+        with filepath.open(newline="") as handle:
+            reader = csv.DictReader(handle, strict=True)
+            corr_prob = {}
+            for line in reader:
+                position = int(line["Position"])
+                if -rescale_length_3p <= position <= rescale_length_5p:
+                    corr_prob[("C", "T", position)] = float(line["C.T"])
+                    corr_prob[("G", "A", position)] = float(line["G.A"])
+            return corr_prob
+    except FileNotFoundError:
+        raise RescaleError("File does not exist; please re-run mapDamage")
+    except csv.Error as error:
+        raise RescaleError("Error while reading line %d: %s" % (reader.line_num, error))
+
+
+def _phred_pval_to_raw(pval):
+    return int(round(-10 * math.log10(abs(pval))))          # rescale.py:13-15 (without the +33)
+
+
+def _phred_raw_to_pval(q):
+    return 10 ** (-(float(q + 33) - float(33)) / 10)        # rescale.py:18-20
+
+
+class RescaleModel:
+    """Lookup tables indexed [substitution 0=C>T,1=G>A][position key index][old quality 0..93].
+
+    Position key index: 0 = no correction for that key; 1..len5p = positions from the 5' end;
+    len5p + k = position -k from the 3' end."""
+
+    def __init__(self, corr_prob, rescale_length_5p, rescale_length_3p):
+        self.len5p, self.len3p = int(rescale_length_5p), int(rescale_length_3p)
+        self.npos = 1 + self.len5p + self.len3p
+        self.lut = np.zeros((2, self.npos, 94), np.uint8)
+        self.term = np.zeros((2, self.npos), np.float64)
+        for si, (ref, read) in enumerate((("C", "T"), ("G", "A"))):
+            for kidx in range(self.npos):
+                position = kidx if kidx <= self.len5p else -(kidx - self.len5p)
+                corr = corr_prob.get((ref, read, position), 0) if kidx else 0
+                pdam = 1 - corr                                          # rescale.py:232-239
+                self.term[si, kidx] = 1 - pdam                           # rescale.py:246
+                for q in range(94):
+                    pseq = 1 - _phred_raw_to_pval(q)                     # rescale.py:240
+                    newp = pdam * pseq                                   # rescale.py:241
+                    self.lut[si, kidx, q] = _phred_pval_to_raw(1 - newp)  # rescale.py:242
+
+    @classmethod
+    def from_csv(cls, path, rescale_length_5p, rescale_length_3p):
+        return cls(get_corr_prob(path, rescale_length_5p, rescale_length_3p), rescale_length_5p,
+                   rescale_length_3p)
+
+
+def finalize_mr(raw_sum):
+    """``float("%.5f" % sum)`` (rescale.py:276)."""
+    return float("%.5f" % raw_sum)
+
+
+def rescale_bam(engine, ref, in_path, out_path, model):
+    """File-level mirror of ``_rescale_qual_core`` (rescale.py:285-365): every record of the BAM is
+    written back, rescaled records get their new qualities and an ``MR:f`` tag, everything else in
+    the record (name, MAPQ, mate fields, other tags) is preserved byte for byte.
+    Returns the per-status record counts."""
+    import struct
+
+    from .sam import read_bam, write_bam_raw
+    al = read_bam(in_path, keep_raw=True)
+    batch = al.batch
+    engine.set_reference(ref)
+    engine.set_rescale_model(model)
+    qual_out, mr_raw, status = engine.rescale(batch)
+    out = []
+    for i, body in enumerate(al.raw):
+        if status[i] in (STATUS_BOTH, STATUS_FORWARD):
+            if al.has_mr[i]:
+                raise SystemExit("Read: %s already has a MR tag, can't rescale" % al.qname[i])   # rescale.py:277-278
+            l_read_name, n_cigar, l_seq = body[8], struct.unpack_from("<H", body, 12)[0], struct.unpack_from("<i", body, 16)[0]
+            qoff = 32 + l_read_name + 4 * n_cigar + (l_seq + 1) // 2
+            s0 = int(batch.seq_off[i])
+            body = (body[:qoff] + qual_out[s0:s0 + l_seq].tobytes() + body[qoff + l_seq:]
+                    + b"MRf" + struct.pack("<f", finalize_mr(mr_raw[i])))
+        out.append(body)
+    write_bam_raw(out_path, al.raw_header, out)
+    return {name: int((status == code).sum()) for name, code in
+            (("unmapped", STATUS_UNMAPPED), ("without_qualities", STATUS_NO_QUAL), ("single_end", STATUS_BOTH),
+             ("inward_pairs", STATUS_FORWARD), ("improper_pairs", STATUS_IMPROPER))}

@@ -44,10 +44,13 @@ class Header:
 
 
 class Alignments:
-    """All records of a SAM/BAM file: header + SoA batch + per-record RG id and query name."""
+    """All records of a SAM/BAM file: header + SoA batch + per-record RG id and query name.
+    ``raw`` (BAM only, ``keep_raw=True``): the record bodies as stored, and ``raw_header`` the bytes
+    in front of the first record, so that a rewritten file keeps every field it does not touch."""
 
     def __init__(self, header, batch, rg, qname):
         self.header, self.batch, self.rg, self.qname = header, batch, rg, qname
+        self.raw, self.raw_header, self.has_mr = None, None, None
 
 
 def _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames):
@@ -107,7 +110,7 @@ def read_sam(path_or_handle):
     return _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames)
 
 
-def read_bam(path):
+def read_bam(path, keep_raw=False):
     with gzip.open(path, "rb") as handle:   # BGZF is a series of gzip members
         data = handle.read()
     if data[:4] != b"BAM\x01":
@@ -128,12 +131,18 @@ def read_bam(path):
     if not header.references:
         header.references, header.lengths = names, lengths
     flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames = [], [], [], [], [], [], [], [], [], []
+    mtids, mposs, raws, has_mr = [], [], [], []
+    raw_header = data[:off]
     n = len(data)
     while off + 4 <= n:
         block_size, = struct.unpack_from("<i", data, off)
         rec = memoryview(data)[off + 4:off + 4 + block_size]
         off += 4 + block_size
-        tid, pos, l_read_name, _mapq, _bin, n_cigar, flag, l_seq, _ntid, _npos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+        tid, pos, l_read_name, _mapq, _bin, n_cigar, flag, l_seq, ntid, npos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+        mtids.append(ntid)
+        mposs.append(npos)
+        if keep_raw:
+            raws.append(bytes(rec))
         p = 32
         qnames.append(bytes(rec[p:p + l_read_name - 1]).decode())
         p += l_read_name
@@ -149,10 +158,13 @@ def read_bam(path):
         p += l_seq
         rg = None
         aux = bytes(rec[p:])
+        has_mr.append(False)
         q = 0
         while q + 3 <= len(aux):
             tag, typ = aux[q:q + 2], aux[q + 2:q + 3]
             q += 3
+            if tag == b"MR":
+                has_mr[-1:] = [True]
             if typ == b"Z" or typ == b"H":
                 end = aux.index(b"\x00", q)
                 if tag == b"RG":
@@ -174,7 +186,25 @@ def read_bam(path):
         cigs.extend(int(c) for c in cig)
         cig_counts.append(n_cigar)
         rgs.append(rg)
-    return _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames)
+    al = _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames)
+    al.batch.mtid = np.asarray(mtids, np.int32)
+    al.batch.mpos = np.asarray(mposs, np.int32)
+    al.has_mr = has_mr
+    if keep_raw:
+        al.raw, al.raw_header = raws, raw_header
+    return al
+
+
+def write_bam_raw(path, raw_header, records):
+    """BGZF-compress an already encoded BAM stream (header bytes + record bodies)."""
+    data = bytearray(raw_header)
+    for body in records:
+        data += struct.pack("<i", len(body)) + body
+    data = bytes(data)
+    with open(path, "wb") as out:
+        for lo in range(0, len(data), 0xFF00):
+            out.write(_bgzf_block(data[lo:lo + 0xFF00]))
+        out.write(_bgzf_block(b""))
 
 
 def read_alignments(path):
@@ -242,8 +272,10 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
         rg = None if rg_of_record is None else rg_of_record[i]
         if rg is not None:
             aux = b"RGZ" + rg.encode() + b"\x00"
+        ntid = -1 if batch.mtid is None else int(batch.mtid[i])
+        npos = -1 if batch.mpos is None else int(batch.mpos[i])
         body = struct.pack("<iiBBHHHiiii", int(batch.tid[i]), int(batch.pos[i]), len(name), 30, 4680,
-                           c1 - c0, int(batch.flag[i]), l_seq, -1, -1, int(batch.tlen[i]))
+                           c1 - c0, int(batch.flag[i]), l_seq, ntid, npos, int(batch.tlen[i]))
         body += name + batch.cigar[c0:c1].astype("<u4").tobytes() + packed + qual + aux
         raw.write(struct.pack("<i", len(body)) + body)
     data = raw.getvalue()

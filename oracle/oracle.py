@@ -70,3 +70,25 @@ def tabulate(ref, batch, nlib, length, around, minqual=0, lgd_max=65536):
         raise OracleError(rc, bad.value)
     return dict(mis=mis, comp=comp, lgd=lgd, lgd_over=over[:n_over.value].copy(),
                 n_kept=n_kept.value)
+
+
+def rescale(ref, batch, corr, len5p, len3p):
+    """C oracle of mapdamage/rescale.py.  corr: float64 [2][1 + len5p + len3p] (see mdx_oracle.c).
+    Returns (qual_out u8[n_bases], mr_raw f64[n] (NaN = not rescaled), status u8[n])."""
+    bases, offs = ref.concat()
+    lib = _lib()
+    lib.mdx_oracle_rescale.restype = ctypes.c_int
+    corr = np.ascontiguousarray(corr, dtype=np.float64)
+    assert corr.shape == (2, 1 + len5p + len3p)
+    qual_out = np.zeros_like(batch.qual)
+    mr = np.zeros(batch.n, np.float64)
+    status = np.zeros(batch.n, np.uint8)
+    bad = ctypes.c_int64(-1)
+    rc = lib.mdx_oracle_rescale(
+        _p(bases), _p(offs), ctypes.c_int32(len(ref.names)), ctypes.c_int64(batch.n), _p(batch.flag),
+        _p(batch.tid), _p(batch.pos), _p(batch.cigar_off), _p(batch.cigar), _p(batch.seq_off),
+        _p(batch.seq), _p(batch.qual), _p(batch.mtid), _p(batch.mpos), _p(corr), ctypes.c_int32(len5p),
+        ctypes.c_int32(len3p), _p(qual_out), _p(mr), _p(status), ctypes.byref(bad))
+    if rc != 0:
+        raise OracleError(rc, bad.value)
+    return qual_out, mr, status

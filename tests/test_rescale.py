@@ -1,0 +1,129 @@
+"""Quality rescaling (mapdamage/rescale.py; BASELINE configs[4]).  The golden holds the output of the
+reference's own _rescale_qual_core over a stand-in AlignmentFile (tools/ref_harness.py)."""
+
+import json
+import pathlib
+
+import numpy as np
+import pytest
+
+from mapdamage_amd import synth
+from mapdamage_amd.batch import ReadBatch, Reference
+from mapdamage_amd.rescale import RescaleModel, finalize_mr, get_corr_prob
+
+GOLDEN = pathlib.Path(__file__).resolve().parent / "golden" / "genome_rescale.npz"
+
+
+def load(tmp_path):
+    z = np.load(GOLDEN)
+    names = json.loads(bytes(z["names"]).decode())
+    seqs, o = [], 0
+    bases = bytes(z["ref_bases"])
+    for ln in z["ref_lengths"]:
+        seqs.append(bases[o:o + int(ln)])
+        o += int(ln)
+    batch = ReadBatch(z["flag"], np.zeros(len(z["flag"]), np.uint16), z["tid"], z["pos"], z["tlen"], z["cigar_off"],
+                      z["cigar"], z["seq_off"], z["seq"], z["qual"], z["mtid"], z["mpos"]).validate()
+    path = tmp_path / "Stats_out_MCMC_correct_prob.csv"
+    path.write_bytes(bytes(z["csv"]))
+    len5p, len3p = int(z["len5p"]), int(z["len3p"])
+    model = RescaleModel.from_csv(path, len5p, len3p)
+    return Reference(names, seqs), batch, model, get_corr_prob(path, len5p, len3p), z["qual_out"], z["mr"]
+
+
+def corr_table(corr_prob, model):
+    corr = np.zeros((2, model.npos))
+    for (r, _s, p), v in corr_prob.items():
+        corr[0 if r == "C" else 1, p if p > 0 else model.len5p - p] = v
+    return corr
+
+
+def check(qual_out, mr_raw, want_qual, want_mr):
+    np.testing.assert_array_equal(qual_out, want_qual)
+    assert np.array_equal(np.isnan(mr_raw), np.isnan(want_mr))
+    got = np.asarray([np.nan if np.isnan(m) else finalize_mr(m) for m in mr_raw])
+    np.testing.assert_array_equal(got[~np.isnan(got)], want_mr[~np.isnan(want_mr)])
+
+
+def test_lookup_table_matches_survey_probe():
+    """SURVEY Appendix D rescale probe: q = 40, corr 0 / 0.01 / 0.1 / 0.25 / 0.5 / 0.9."""
+    cp = {("C", "T", 1): 0.5, ("C", "T", 2): 0.25, ("C", "T", 3): 0.1, ("C", "T", 4): 0.01, ("G", "A", -1): 0.9}
+    m = RescaleModel(cp, 12, 12)
+    assert [int(m.lut[0, k, 40]) for k in (0, 4, 3, 2, 1)] == [40, 20, 10, 6, 3]
+    assert int(m.lut[1, 13, 40]) == 0 and m.term[0, 1] == 0.5 and m.term[0, 0] == 0.0
+    assert all(int(m.lut[0, 0, q]) == q for q in range(94))   # no correction: quality unchanged
+
+
+def test_oracle_matches_reference_golden(tmp_path):
+    from oracle import oracle
+    ref, batch, model, corr_prob, want_qual, want_mr = load(tmp_path)
+    qual_out, mr_raw, status = oracle.rescale(ref, batch, corr_table(corr_prob, model), model.len5p, model.len3p)
+    check(qual_out, mr_raw, want_qual, want_mr)
+    assert set(np.unique(status)) == {0, 1, 2, 3, 4}
+    assert int((want_qual != batch.qual).sum()) > 100       # the fixture does rescale something
+
+
+@pytest.mark.gpu
+def test_hip_matches_reference_golden(tmp_path):
+    from mapdamage_amd.engine import DamageEngine
+    ref, batch, model, corr_prob, want_qual, want_mr = load(tmp_path)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        qual_out, mr_raw, status = eng.rescale(batch)
+    check(qual_out, mr_raw, want_qual, want_mr)
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_seeded(tmp_path):
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500,
+                            lower_run=3000)
+    b = synth.make_reads(ref, 60_000, 21, len_range=(25, 160), paired=True, frac_softclip=0.2, frac_ins=0.08,
+                         frac_del=0.08, frac_skip=0.01, with_qual=True, frac_filtered=0.03)
+    rng = np.random.default_rng(3)
+    b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
+    b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
+    b.flag = np.where(rng.random(b.n) < 0.5, b.flag & 0xF14, b.flag).astype(np.uint16)
+    want_q, want_mr, want_st = oracle.rescale(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        got_q, got_mr, got_st = eng.rescale(b)
+    np.testing.assert_array_equal(got_q, want_q)
+    np.testing.assert_array_equal(got_st, want_st)
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])   # bit-exact fp64 sums
+
+
+@pytest.mark.gpu
+def test_cli_rescale_only_rewrites_bam(tmp_path):
+    """`--rescale-only`: every record written back, new qualities + MR:f on the rescaled ones,
+    untouched fields preserved."""
+    import struct
+
+    from mapdamage_amd import fasta, sam
+    from mapdamage_amd.main import main
+    ref, batch, model, corr_prob, want_qual, want_mr = load(tmp_path)
+    sam.write_bam(tmp_path / "in.bam", batch, ref.names, ref.lengths, [], None)
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    folder = tmp_path / "res"
+    folder.mkdir()
+    (folder / "Stats_out_MCMC_correct_prob.csv").write_bytes((tmp_path / "Stats_out_MCMC_correct_prob.csv").read_bytes())
+    rc = main(["-i", str(tmp_path / "in.bam"), "-r", str(tmp_path / "ref.fa"), "-d", str(folder), "--rescale-only",
+               "--rescale-length-5p", "12", "--rescale-length-3p", "10"])
+    assert rc == 0
+    out = sam.read_bam(folder / "in.rescaled.bam", keep_raw=True)
+    assert out.batch.n == batch.n
+    np.testing.assert_array_equal(out.batch.qual, want_qual)
+    for k in ("flag", "tid", "pos", "tlen", "cigar", "seq", "mtid", "mpos"):
+        np.testing.assert_array_equal(getattr(out.batch, k), getattr(batch, k), err_msg=k)
+    assert out.qname == ["r%d" % i for i in range(batch.n)]
+    for i, body in enumerate(out.raw):
+        if np.isnan(want_mr[i]):
+            assert not out.has_mr[i]
+        else:
+            assert out.has_mr[i] and body[-7:-4] == b"MRf"
+            assert struct.unpack("<f", body[-4:])[0] == np.float32(want_mr[i])

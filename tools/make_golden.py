@@ -92,6 +92,30 @@ def appendix_d_case():
     return ref, batch_from_records(recs, with_qual=True)
 
 
+def rescale_csv():
+    """A Stats_out_MCMC_correct_prob.csv in the format of r/stats/main.r:225 (positions 1..12, -12..-1)."""
+    rows = ['"","Position","C.T","G.A"']
+    for i, p in enumerate(list(range(1, 13)) + list(range(-12, 0))):
+        ct = 0.5 * 0.6 ** (abs(p) - 1) if p > 0 else 0.0123
+        ga = 0.47 * 0.55 ** (abs(p) - 1) if p < 0 else 0.0217
+        rows.append('"%d",%d,%r,%r' % (i + 1, p, ct, ga))
+    return "\n".join(rows) + "\n"
+
+
+def rescale_batch(ref, n=1500, seed=5):
+    """Mixed single-end / paired records with qualities, mates, clips, indels, skips, filtered flags."""
+    b = synth.make_reads(ref, n, seed, len_range=(20, 120), paired=True, frac_softclip=0.15, frac_ins=0.1,
+                         frac_del=0.1, frac_skip=0.02, with_qual=True, frac_filtered=0.05)
+    rng = np.random.default_rng(seed + 100)
+    b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
+    b.mpos = (b.pos + rng.integers(-200, 200, size=b.n)).astype(np.int32)
+    single = rng.random(b.n) < 0.5
+    b.flag = np.where(single, b.flag & 0xF14, b.flag).astype(np.uint16)
+    for i in np.nonzero(rng.random(b.n) < 0.03)[0]:
+        b.qual[b.seq_off[i]:b.seq_off[i + 1]] = 0xFF
+    return b
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
@@ -156,6 +180,28 @@ def main():
                         counts=np.asarray(per_contig, dtype=np.uint64),
                         csv=np.frombuffer(text, dtype=np.uint8))
     print("genome_composition         ", per_contig, text)
+
+    # quality rescaling through the reference's own _rescale_qual_core (routing + per-read rescale)
+    rref = synth.small_genome()
+    rb = rescale_batch(rref)
+    csv_text = rescale_csv()
+    quals, mrs, log = ref_harness.run_reference_rescale(rref, rb, csv_text, 12, 10)
+    qflat = rb.qual.copy()
+    for i, q in enumerate(quals):
+        if q is not None:
+            s0, s1 = int(rb.seq_off[i]), int(rb.seq_off[i + 1])
+            assert len(q) == s1 - s0
+            qflat[s0:s1] = np.asarray(q, dtype=np.uint8)
+    np.savez_compressed(GOLDEN / "genome_rescale.npz",
+                        ref_bases=np.frombuffer(b"".join(rref.seqs), dtype=np.uint8),
+                        ref_lengths=np.asarray(rref.lengths, dtype=np.int64),
+                        names=np.frombuffer(json.dumps(rref.names).encode(), dtype=np.uint8),
+                        flag=rb.flag, tid=rb.tid, pos=rb.pos, tlen=rb.tlen, cigar_off=rb.cigar_off, cigar=rb.cigar,
+                        seq_off=rb.seq_off, seq=rb.seq, qual=rb.qual, mtid=rb.mtid, mpos=rb.mpos,
+                        csv=np.frombuffer(csv_text.encode(), dtype=np.uint8), len5p=12, len3p=10,
+                        qual_out=qflat, mr=np.asarray([np.nan if m is None else m for m in mrs], dtype=np.float64),
+                        log=np.frombuffer(json.dumps(log).encode(), dtype=np.uint8))
+    print("genome_rescale              reads=%d rescaled=%d" % (rb.n, sum(m is not None for m in mrs)))
 
     if args.time:
         big = synth.config2_batch(mref, 100_000, seed=2)

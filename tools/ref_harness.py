@@ -187,3 +187,81 @@ def dense_tables(result, libraries, length, around):
                     lgd.append((li, L.KINDS.index(kind), L.STRANDS.index(strand), ln, cnt))
     lgd = np.asarray(sorted(lgd), dtype=np.int64).reshape(-1, 5)
     return libs, mis, comp, lgd
+
+
+# ------------------------------------------------------------------------------------ rescale
+class _RescaleRead(_Read):
+    """Adds what mapdamage/rescale.py touches: mate fields, tags, a settable ``qual``."""
+    __slots__ = ("is_unmapped", "mate_is_reverse", "pnext", "mrnm", "qname", "tags", "index")
+
+    def __init__(self, rec, index, mtid, mpos):
+        super().__init__(rec)
+        self.is_unmapped = bool(self.flag & 0x4)
+        self.mate_is_reverse = bool(self.flag & 0x20)
+        self.pnext = mpos
+        self.mrnm = mtid
+        self.qname = "r%d" % index
+        self.tags = {}
+        self.index = index
+
+    def has_tag(self, key):
+        return key in self.tags
+
+    def set_tag(self, key, value, value_type=None):
+        self.tags[key] = (value, value_type)
+
+
+def run_reference_rescale(ref, batch, csv_text, len5p, len3p):
+    """Runs the reference's own _rescale_qual_core (routing + _rescale_qual_read) with a stand-in
+    pysam.AlignmentFile that iterates duck-typed reads and collects what is written.
+    Returns (list of new qual lists per record, MR values (None when absent), log lines)."""
+    import logging
+    import tempfile
+    md = import_reference()
+    import pysam as pysam_stub
+
+    reads = [_RescaleRead(batch.record(i), i, int(batch.mtid[i]), int(batch.mpos[i])) for i in range(batch.n)]
+    written = []
+
+    class FakeAlignmentFile:
+        def __init__(self, path, mode="r", template=None):
+            self.mode = mode
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def __iter__(self):
+            return iter(reads)
+
+        def getrname(self, tid):
+            return ref.names[tid]
+
+        def write(self, hit):
+            written.append(hit)
+
+    pysam_stub.AlignmentFile = FakeAlignmentFile
+    records = []
+
+    class Capture(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+
+    handler = Capture()
+    logging.getLogger("mapdamage.rescale").addHandler(handler)
+    logging.getLogger("mapdamage.rescale").setLevel(logging.INFO)
+    with tempfile.TemporaryDirectory() as tmp:
+        folder = pathlib.Path(tmp)
+        (folder / "Stats_out_MCMC_correct_prob.csv").write_text(csv_text)
+        options = types.SimpleNamespace(folder=folder, rescale_length_5p=len5p, rescale_length_3p=len3p,
+                                        filename="in.bam", rescale_out="out.bam")
+        md.rescale._rescale_qual_core(_Fasta(ref), options)
+    logging.getLogger("mapdamage.rescale").removeHandler(handler)
+    assert len(written) == batch.n
+    quals, mrs = [], []
+    for hit in written:
+        quals.append(None if hit.qual is None else [ord(c) - 33 for c in hit.qual])
+        mrs.append(hit.tags["MR"][0] if "MR" in hit.tags else None)
+    return quals, mrs, records
