@@ -149,6 +149,27 @@ int mdx_rescale_set_model(mdx_ctx *ctx, const uint8_t *lut, const double *term, 
 int mdx_rescale_host(mdx_ctx *ctx, const mdx_batch *batch, const int32_t *mtid, const int32_t *mpos,
                      uint8_t *qual_out, double *mr_raw, uint8_t *status);
 
+/* Native BAM decoding (host side, no GPU involved).  Replaces opening and iterating a
+ * pysam.AlignmentFile (mapdamage/reader.py:38, 83-96; pysam is not needed): the BGZF blocks are
+ * inflated on `threads` host threads and every record is unpacked into the SoA columns of mdx_batch.
+ * The handle owns all memory; mdx_bam_batch returns host views valid until mdx_bam_free.
+ * `lib` is zero-filled (the caller maps read groups to libraries, reader.py:63-81, from rg_index:
+ * per-record index into mdx_bam_rg_name(), -1 = no RG tag).  mtid/mpos are the mate fields used by
+ * the rescale routing; has_mr flags records that already carry an MR tag (rescale.py:277). */
+typedef struct mdx_bam mdx_bam;
+int mdx_bam_read(const char *path, int threads, mdx_bam **out);
+void mdx_bam_free(mdx_bam *bam);
+const char *mdx_bam_error(const mdx_bam *bam);
+const char *mdx_bam_header_text(const mdx_bam *bam);
+int32_t mdx_bam_n_ref(const mdx_bam *bam);
+const char *mdx_bam_ref_name(const mdx_bam *bam, int32_t i);
+int64_t mdx_bam_ref_length(const mdx_bam *bam, int32_t i);
+int mdx_bam_batch(const mdx_bam *bam, mdx_batch *view, const int32_t **mtid, const int32_t **mpos,
+                  const int32_t **rg_index, const uint8_t **has_mr);
+int32_t mdx_bam_n_rg(const mdx_bam *bam);
+const char *mdx_bam_rg_name(const mdx_bam *bam, int32_t i);
+const char *mdx_bam_qnames(const mdx_bam *bam, const uint32_t **offsets);
+
 /* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
 int mdx_table_mode(const mdx_ctx *ctx);
 

@@ -8,7 +8,7 @@ import subprocess
 HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmdx.so"
-SOURCES = ["mdx_kernels.hip", "mdx_capi.cpp"]
+SOURCES = ["mdx_kernels.hip", "mdx_capi.cpp", "mdx_bamio.cpp"]
 HEADERS = [CSRC / "mdx_internal.h", HERE.parent / "include" / "mdx.h"]
 
 
@@ -34,7 +34,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
            "-x", "hip", "-Wall", "-Wno-unused-function"]
     cmd += list(extra_flags)
     cmd += [str(CSRC / s) for s in SOURCES]
-    cmd += ["-o", str(LIB)]
+    cmd += ["-lz", "-lpthread", "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,285 @@
+// Native BAM decoder of libmdx.so (host side of the boundary): BGZF blocks are
+// inflated on several host threads and every record is unpacked straight into the SoA columns of
+// mdx_batch — the counterpart of iterating a pysam.AlignmentFile (mapdamage/reader.py:38,83-96,
+// 121-132) without pysam.  Pure host code (zlib); no HIP calls.
+#include "../../include/mdx.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+struct mdx_bam {
+    std::string error;
+    std::string header_text;
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lengths;
+    // SoA columns
+    std::vector<uint16_t> flag, lib;
+    std::vector<int32_t> tid, pos, tlen, mtid, mpos, rg_index;
+    std::vector<uint32_t> cigar_off, cigar, seq_off, qname_off;
+    std::vector<uint8_t> seq, qual;
+    std::string qnames;
+    std::vector<std::string> rg_names;
+    std::vector<uint8_t> has_mr;
+};
+
+namespace {
+
+struct Block { size_t in_off, in_size, out_off, out_size; };
+
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
+
+bool scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, size_t &total, std::string &err) {
+    size_t off = 0;
+    total = 0;
+    while (off < file.size()) {
+        if (off + 18 > file.size() || file[off] != 0x1f || file[off + 1] != 0x8b || !(file[off + 3] & 4)) {
+            err = "not a BGZF-compressed file";
+            return false;
+        }
+        const size_t xlen = rd16(&file[off + 10]);
+        size_t x = off + 12, xend = x + xlen;
+        size_t bsize = 0;
+        while (x + 4 <= xend && xend <= file.size()) {
+            const size_t slen = rd16(&file[x + 2]);
+            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&file[x + 4]) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || off + bsize > file.size() || bsize < xlen + 20) { err = "corrupt BGZF block"; return false; }
+        Block b;
+        b.in_off = off + 12 + xlen;
+        b.in_size = bsize - xlen - 20;
+        b.out_size = rd32(&file[off + bsize - 4]);
+        b.out_off = total;
+        total += b.out_size;
+        blocks.push_back(b);
+        off += bsize;
+    }
+    return true;
+}
+
+bool inflate_block(const uint8_t *src, size_t n, uint8_t *dst, size_t m) {
+    if (m == 0) return true;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)n;
+    zs.next_out = dst;
+    zs.avail_out = (uInt)m;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+template <class F>
+void parallel_for(size_t n, int threads, F body) {
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    std::vector<std::thread> pool;
+    std::atomic<size_t> next{0};
+    const size_t chunk = std::max<size_t>(1, n / ((size_t)threads * 8));
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&]() {
+            for (;;) {
+                const size_t lo = next.fetch_add(chunk);
+                if (lo >= n) break;
+                const size_t hi = std::min(n, lo + chunk);
+                for (size_t i = lo; i < hi; i++) body(i);
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
+    if (!path || !out) return MDX_ERR_ARG;
+    mdx_bam *b = new (std::nothrow) mdx_bam();
+    if (!b) return MDX_ERR_ARG;
+    *out = b;
+    std::vector<uint8_t> file;
+    {
+        FILE *fp = std::fopen(path, "rb");
+        if (!fp) { b->error = std::string("cannot open ") + path; return MDX_ERR_ARG; }
+        std::fseek(fp, 0, SEEK_END);
+        const long sz = std::ftell(fp);
+        std::fseek(fp, 0, SEEK_SET);
+        file.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), fp);
+        std::fclose(fp);
+        if (got != file.size()) { b->error = "short read"; return MDX_ERR_ARG; }
+    }
+    std::vector<Block> blocks;
+    size_t total = 0;
+    if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
+    std::vector<uint8_t> data(total + 8);
+    std::atomic<bool> ok{true};
+    parallel_for(blocks.size(), threads, [&](size_t i) {
+        const Block &k = blocks[i];
+        if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
+    });
+    if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
+    std::vector<uint8_t>().swap(file);
+
+    if (total < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) { b->error = "not a BAM file"; return MDX_ERR_ARG; }
+    size_t off = 4;
+    const int32_t l_text = rdi32(&data[off]);
+    off += 4;
+    if (l_text < 0 || off + (size_t)l_text + 4 > total) { b->error = "corrupt BAM header"; return MDX_ERR_ARG; }
+    b->header_text.assign((const char *)&data[off], std::strlen((const char *)&data[off]) < (size_t)l_text
+                                                         ? std::strlen((const char *)&data[off]) : (size_t)l_text);
+    off += l_text;
+    const int32_t n_ref = rdi32(&data[off]);
+    off += 4;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (off + 4 > total) { b->error = "corrupt BAM header"; return MDX_ERR_ARG; }
+        const int32_t l_name = rdi32(&data[off]);
+        if (l_name < 1 || off + 8 + (size_t)l_name > total) { b->error = "corrupt BAM header"; return MDX_ERR_ARG; }
+        b->ref_names.emplace_back((const char *)&data[off + 4], (size_t)l_name - 1);
+        b->ref_lengths.push_back(rdi32(&data[off + 4 + l_name]));
+        off += 8 + l_name;
+    }
+    // pass 1 (sequential): record starts and the prefix sums that size the ragged columns
+    std::vector<size_t> rec;
+    std::vector<uint32_t> coff{0}, soff{0}, noff{0};
+    while (off + 4 <= total) {
+        const int32_t bs = rdi32(&data[off]);
+        if (bs < 32 || off + 4 + (size_t)bs > total) { b->error = "corrupt BAM record"; return MDX_ERR_ARG; }
+        const uint8_t *r = &data[off + 4];
+        const uint32_t l_name = r[8], n_cig = rd16(r + 12);
+        const int32_t l_seq = rdi32(r + 16);
+        if (l_seq < 0 || 32 + l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) {
+            b->error = "corrupt BAM record";
+            return MDX_ERR_ARG;
+        }
+        const uint64_t ns = (uint64_t)soff.back() + (uint64_t)l_seq;
+        if (ns > 0xFFFFFFFFull) { b->error = "more than 4 Gbases in one file: split it"; return MDX_ERR_ARG; }
+        rec.push_back(off + 4);
+        coff.push_back(coff.back() + n_cig);
+        soff.push_back((uint32_t)ns);
+        noff.push_back(noff.back() + (l_name ? l_name - 1 : 0));
+        off += 4 + (size_t)bs;
+    }
+    const size_t n = rec.size();
+    b->flag.resize(n); b->lib.assign(n, 0); b->tid.resize(n); b->pos.resize(n); b->tlen.resize(n);
+    b->mtid.resize(n); b->mpos.resize(n); b->rg_index.assign(n, -1); b->has_mr.assign(n, 0);
+    b->cigar_off = coff; b->seq_off = soff; b->qname_off = noff;
+    b->cigar.resize(coff.back()); b->seq.resize((size_t)soff.back() + 64); b->qual.resize((size_t)soff.back() + 64);
+    b->qnames.resize(noff.back());
+    std::vector<std::pair<const char *, uint32_t>> rg(n, {nullptr, 0});
+    static const char DEC[17] = "=ACMGRSVTWYHKDBN";
+    // pass 2 (parallel): unpack every record into the columns
+    parallel_for(n, threads, [&](size_t i) {
+        const uint8_t *r = &data[rec[i]];
+        const size_t bs = (size_t)rdi32(r - 4);
+        const uint32_t l_name = r[8], n_cig = rd16(r + 12);
+        const int32_t l_seq = rdi32(r + 16);
+        b->tid[i] = rdi32(r); b->pos[i] = rdi32(r + 4); b->flag[i] = rd16(r + 14);
+        b->mtid[i] = rdi32(r + 20); b->mpos[i] = rdi32(r + 24); b->tlen[i] = rdi32(r + 28);
+        const uint8_t *p = r + 32;
+        if (l_name) std::memcpy(&b->qnames[noff[i]], p, l_name - 1);
+        p += l_name;
+        for (uint32_t k = 0; k < n_cig; k++) b->cigar[coff[i] + k] = rd32(p + 4 * k);
+        p += 4 * (size_t)n_cig;
+        uint8_t *s = &b->seq[soff[i]];
+        for (int32_t k = 0; k < l_seq; k++) {
+            const uint8_t byte = p[k >> 1];
+            s[k] = (uint8_t)DEC[(k & 1) ? (byte & 15) : (byte >> 4)];
+        }
+        p += ((size_t)l_seq + 1) / 2;
+        std::memcpy(&b->qual[soff[i]], p, (size_t)l_seq);
+        p += l_seq;
+        const uint8_t *end = r + bs;
+        while (p + 3 <= end) {
+            const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+            p += 3;
+            if (t0 == 'M' && t1 == 'R') b->has_mr[i] = 1;
+            if (ty == 'Z' || ty == 'H') {
+                const uint8_t *z = (const uint8_t *)std::memchr(p, 0, (size_t)(end - p));
+                if (!z) break;
+                if (t0 == 'R' && t1 == 'G' && ty == 'Z') rg[i] = {(const char *)p, (uint32_t)(z - p)};
+                p = z + 1;
+            } else if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
+            else if (ty == 's' || ty == 'S') p += 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
+            else if (ty == 'B') {
+                if (p + 5 > end) break;
+                const uint8_t sub = p[0];
+                const uint32_t cnt = rd32(p + 1);
+                const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                p += 5 + (size_t)cnt * w;
+            } else break;
+        }
+    });
+    // read-group ids -> small integers (header order is resolved by the caller)
+    std::unordered_map<std::string, int32_t> index;
+    for (size_t i = 0; i < n; i++) {
+        if (!rg[i].first) continue;
+        std::string key(rg[i].first, rg[i].second);
+        auto it = index.find(key);
+        if (it == index.end()) {
+            it = index.emplace(key, (int32_t)b->rg_names.size()).first;
+            b->rg_names.push_back(key);
+        }
+        b->rg_index[i] = it->second;
+    }
+    return MDX_OK;
+}
+
+void mdx_bam_free(mdx_bam *b) { delete b; }
+
+const char *mdx_bam_error(const mdx_bam *b) { return b ? b->error.c_str() : "null handle"; }
+
+const char *mdx_bam_header_text(const mdx_bam *b) { return b ? b->header_text.c_str() : ""; }
+
+int32_t mdx_bam_n_ref(const mdx_bam *b) { return b ? (int32_t)b->ref_names.size() : 0; }
+
+const char *mdx_bam_ref_name(const mdx_bam *b, int32_t i) {
+    return (b && i >= 0 && (size_t)i < b->ref_names.size()) ? b->ref_names[i].c_str() : "";
+}
+
+int64_t mdx_bam_ref_length(const mdx_bam *b, int32_t i) {
+    return (b && i >= 0 && (size_t)i < b->ref_lengths.size()) ? b->ref_lengths[i] : -1;
+}
+
+int mdx_bam_batch(const mdx_bam *b, mdx_batch *view, const int32_t **mtid, const int32_t **mpos,
+                  const int32_t **rg_index, const uint8_t **has_mr) {
+    if (!b || !view) return MDX_ERR_ARG;
+    view->n_reads = (int64_t)b->flag.size();
+    view->n_cigar = (int64_t)b->cigar.size();
+    view->n_bases = b->seq_off.empty() ? 0 : (int64_t)b->seq_off.back();
+    view->flag = b->flag.data(); view->lib = b->lib.data(); view->tid = b->tid.data(); view->pos = b->pos.data();
+    view->tlen = b->tlen.data(); view->cigar_off = b->cigar_off.data(); view->cigar = b->cigar.data();
+    view->seq_off = b->seq_off.data(); view->seq = b->seq.data(); view->qual = b->qual.data();
+    if (mtid) *mtid = b->mtid.data();
+    if (mpos) *mpos = b->mpos.data();
+    if (rg_index) *rg_index = b->rg_index.data();
+    if (has_mr) *has_mr = b->has_mr.data();
+    return MDX_OK;
+}
+
+int32_t mdx_bam_n_rg(const mdx_bam *b) { return b ? (int32_t)b->rg_names.size() : 0; }
+
+const char *mdx_bam_rg_name(const mdx_bam *b, int32_t i) {
+    return (b && i >= 0 && (size_t)i < b->rg_names.size()) ? b->rg_names[i].c_str() : "";
+}
+
+const char *mdx_bam_qnames(const mdx_bam *b, const uint32_t **offsets) {
+    if (!b) return "";
+    if (offsets) *offsets = b->qname_off.data();
+    return b->qnames.data();
+}
+
+}  // extern "C"

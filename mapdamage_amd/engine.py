@@ -24,6 +24,8 @@ EXPORTS = (
     "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_table_words",
     "mdx_finish_device", "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
     "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
+    "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
+    "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
 )
 
 
@@ -82,6 +84,15 @@ def load_library(path=None):
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
                  "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host"):
         getattr(lib, name).restype = ctypes.c_int
+    for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
+        getattr(lib, name).restype = ctypes.c_char_p
+    lib.mdx_bam_qnames.restype = ctypes.c_void_p
+    lib.mdx_bam_ref_length.restype = ctypes.c_int64
+    lib.mdx_bam_free.restype = None
+    for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_n_rg", "mdx_bam_free"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    for name in ("mdx_bam_ref_name", "mdx_bam_ref_length", "mdx_bam_rg_name"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p, ctypes.c_int32]
     if path is None:
         _lib = lib
     return lib

@@ -207,14 +207,72 @@ def write_bam_raw(path, raw_header, records):
         out.write(_bgzf_block(b""))
 
 
+def read_bam_native(path, threads=None):
+    """BAM -> ``Alignments`` through the C++ decoder of libmdx.so (multi-threaded BGZF inflate,
+    records unpacked straight into the SoA columns; include/mdx.h ``mdx_bam_*``)."""
+    import ctypes
+    import os
+
+    from .engine import MdxBatch, load_library
+    lib = load_library()
+    handle = ctypes.c_void_p()
+    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(16, os.cpu_count() or 1)),
+                          ctypes.byref(handle))
+    try:
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(path), lib.mdx_bam_error(handle).decode() if handle else "BAM decode failed"))
+        header = Header(lib.mdx_bam_header_text(handle).decode())
+        n_ref = lib.mdx_bam_n_ref(handle)
+        names = [lib.mdx_bam_ref_name(handle, i).decode() for i in range(n_ref)]
+        lengths = [int(lib.mdx_bam_ref_length(handle, i)) for i in range(n_ref)]
+        if not header.references:
+            header.references, header.lengths = names, lengths
+        view = MdxBatch()
+        mtid, mpos, rgi, hmr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        lib.mdx_bam_batch(handle, ctypes.byref(view), ctypes.byref(mtid), ctypes.byref(mpos), ctypes.byref(rgi),
+                          ctypes.byref(hmr))
+        n, nb, nc = view.n_reads, view.n_bases, view.n_cigar
+
+        def col(ptr, count, dtype):
+            if count == 0 or not ptr:
+                return np.zeros(0, dtype)
+            size = count * np.dtype(dtype).itemsize
+            return np.frombuffer((ctypes.c_char * size).from_address(ptr), dtype=dtype).copy()
+
+        batch = ReadBatch(col(view.flag, n, np.uint16), np.zeros(n, np.uint16), col(view.tid, n, np.int32),
+                          col(view.pos, n, np.int32), col(view.tlen, n, np.int32),
+                          col(view.cigar_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
+                          col(view.cigar, nc, np.uint32),
+                          col(view.seq_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
+                          col(view.seq, nb, np.uint8), col(view.qual, nb, np.uint8),
+                          col(mtid.value, n, np.int32), col(mpos.value, n, np.int32)).validate()
+        rg_names = [lib.mdx_bam_rg_name(handle, i).decode() for i in range(lib.mdx_bam_n_rg(handle))]
+        rg_idx = col(rgi.value, n, np.int32)
+        rgs = [rg_names[i] if i >= 0 else None for i in rg_idx]
+        offs = ctypes.c_void_p()
+        blob_ptr = lib.mdx_bam_qnames(handle, ctypes.byref(offs))
+        qoff = col(offs.value, n + 1, np.uint32) if n else np.zeros(1, np.uint32)
+        blob = bytes(col(blob_ptr, int(qoff[-1]), np.uint8)) if n else b""
+        qnames = [blob[int(qoff[i]):int(qoff[i + 1])].decode() for i in range(n)]
+        al = Alignments(header, batch, rgs, qnames)
+        al.has_mr = [bool(x) for x in col(hmr.value, n, np.uint8)]
+        return al
+    finally:
+        if handle:
+            lib.mdx_bam_free(handle)
+
+
 def read_alignments(path):
-    """SAM or BAM by content (mapdamage/reader.py:38 lets htslib sniff the format)."""
+    """SAM or BAM by content (mapdamage/reader.py:38 lets htslib sniff the format).  BAM goes through
+    the native decoder of libmdx.so; the pure-Python ``read_bam`` remains as its cross-check."""
     if str(path) == "-":
         import sys
         return read_sam(sys.stdin)
     with open(path, "rb") as handle:
         magic = handle.read(2)
-    return read_bam(path) if magic == b"\x1f\x8b" else read_sam(str(path))
+    if magic != b"\x1f\x8b":
+        return read_sam(str(path))
+    return read_bam_native(path)
 
 
 # ---------------------------------------------------------------------------- writers (tests, synthetic inputs)

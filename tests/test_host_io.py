@@ -116,3 +116,23 @@ def test_cli_parser_mirrors_reference_flags():
         p.parse_args(["-Q", "94"])
     with pytest.raises(SystemExit):
         p.parse_args(["-l", "0"])
+
+
+def test_native_bam_decoder_matches_python_decoder(files):
+    """mdx_bam_* (C++, multi-threaded inflate) against the pure-Python decoder, field by field."""
+    d, ref, batch, rg_of = files
+    py = sam.read_bam(d / "x.bam")
+    for threads in (1, 4):
+        nat = sam.read_bam_native(d / "x.bam", threads=threads)
+        for k in ("flag", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual", "mtid", "mpos"):
+            np.testing.assert_array_equal(getattr(nat.batch, k), getattr(py.batch, k), err_msg=k)
+        assert nat.rg == py.rg == rg_of
+        assert nat.qname == py.qname
+        assert nat.header.references == ref.names and nat.header.lengths == ref.lengths
+        assert nat.header.read_groups == py.header.read_groups
+
+
+def test_native_bam_decoder_rejects_garbage(tmp_path):
+    (tmp_path / "bad.bam").write_bytes(b"\x1f\x8bnot really a bam file at all")
+    with pytest.raises(ValueError):
+        sam.read_bam_native(tmp_path / "bad.bam")
