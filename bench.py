@@ -145,8 +145,8 @@ def main():
     if rank == 0:
         words = tables.cpu().numpy().view(np.uint64)
         got = eng.unpack_tables(words)
-        if not args.no_cpu:
-            # CPU baseline = the oracle, on rank 0's own batch (bounded sample), 1 thread
+        if not args.no_cpu and world == 1:
+            # CPU baseline = the oracle, on rank 0's own batch (bounded sample), 1 thread; N = 1 only
             from oracle import oracle
             n_cpu = min(args.cpu_reads, batch.n)
             sample = batch if n_cpu == batch.n else batch.slice(0, n_cpu)

@@ -159,3 +159,26 @@ def test_cli_end_to_end_byte_identical_outputs(tmp_path, fmt):
     for name in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
         assert (out / name).read_text() == g.txt[name], name
     assert (out / "Runtime_log.txt").exists()
+
+
+@pytest.mark.parametrize("config", [2, 3, 4])
+def test_hip_matches_oracle_at_scale(config):
+    """Survey configs 2/3/4 on the 10 Mb benchmark genome, 1 M records each, through a resident
+    batch tabulated twice: the doubled tables must equal twice the oracle's (parity + linearity)."""
+    from mapdamage_amd.engine import DamageEngine
+    ref = synth.make_genome()
+    make = {2: synth.config2_batch, 3: synth.config3_batch, 4: synth.config4_batch}[config]
+    batch = make(ref, 1_000_000)
+    libs = [("synthetic", "lib1")]
+    want = oracle_tableset(ref, batch, libs, 70, 10, 0, lgd_max=4096)
+    with DamageEngine(libs, 70, 10, 0, lgd_max=4096) as eng:
+        eng.set_reference(ref)
+        dev = eng.upload(batch)
+        eng.tabulate(dev)
+        eng.tabulate(dev)
+        got = eng.finish()
+        dev.free()
+    np.testing.assert_array_equal(got.mis, 2 * want.mis)
+    np.testing.assert_array_equal(got.comp, 2 * want.comp)
+    np.testing.assert_array_equal(got.lgd, 2 * want.lgd)
+    assert got.n_kept == 2 * want.n_kept
