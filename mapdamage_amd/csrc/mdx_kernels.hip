@@ -105,6 +105,26 @@ __device__ __forceinline__ void tc_bump(u32 r4, int bit, u32 base_bytes, int imm
     asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(addr) : "v"(k), "v"(base_bytes));
     asm volatile("ds_add_u32 %0, %1 offset:%2" : : "v"(addr), "v"(data), "n"(imm) : "memory");
 }
+// The four bytes of a dword in one block (no filler s_nop between separate asm statements)
+__device__ __forceinline__ void tc_bump4(u32 r4, u32 base_bytes, u32 d0, u32 d1, u32 d2, u32 d3) {
+    u32 t0, t1, t2, t3;
+    asm volatile(
+        "v_bfe_u32 %0, %4, 1, 2\n\t"
+        "v_bfe_u32 %1, %4, 9, 2\n\t"
+        "v_bfe_u32 %2, %4, 17, 2\n\t"
+        "v_bfe_u32 %3, %4, 25, 2\n\t"
+        "v_lshl_add_u32 %0, %0, 10, %5\n\t"
+        "v_lshl_add_u32 %1, %1, 10, %5\n\t"
+        "v_lshl_add_u32 %2, %2, 10, %5\n\t"
+        "v_lshl_add_u32 %3, %3, 10, %5\n\t"
+        "ds_add_u32 %0, %6\n\t"
+        "ds_add_u32 %1, %7 offset:256\n\t"
+        "ds_add_u32 %2, %8 offset:512\n\t"
+        "ds_add_u32 %3, %9 offset:768"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r4), "v"(base_bytes), "v"(d0), "v"(d1), "v"(d2), "v"(d3)
+        : "memory");
+}
 
 template <bool USE_LDS>
 __device__ __forceinline__ void bump_n(u32 *lds, u64 *raw, int idx, u32 n) {
@@ -435,10 +455,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 // optimistic: count every task byte as a plain match (the base class of the reference
                 // byte, (ascii >> 1) & 3, selects the 1 KiB plane of TC) ...
                 const u32 base_b = ((u32)base_v << 2) + __builtin_amdgcn_groupstaticsize();  // + dynamic LDS base
-                tc_bump(r4_c, 1, base_b, 0, c_d0);
-                tc_bump(r4_c, 9, base_b, 256, c_d1);
-                tc_bump(r4_c, 17, base_b, 512, c_d2);
-                tc_bump(r4_c, 25, base_b, 768, c_d3);
+                tc_bump4(r4_c, base_b, c_d0, c_d1, c_d2, c_d3);
                 // ... and queue the lanes holding a byte that is not one (drain_pass corrects them)
                 const u64 mm = __ballot(x != 0);
                 if (mm) {
