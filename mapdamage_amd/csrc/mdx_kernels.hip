@@ -215,11 +215,13 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             for (int j = 0; j < 4; j++) if (4 * m3 + j + 1 <= A) c_vm |= 0xFFu << (8 * j);
         }
     }
+    const u32 c_lane16 = (u32)lane << 4;                                           // lane field of an event word
+    const u32 c_lane4 = ((u32)lane << 2) + __builtin_amdgcn_groupstaticsize();      // LDS byte address of word `lane`
     const u32 c_d0 = c_vm & 1u, c_d1 = (c_vm >> 8) & 1u, c_d2 = (c_vm >> 16) & 1u, c_d3 = (c_vm >> 24) & 1u;
 
     // Rare-event queue of the fast path (wave-private ring in the LDS, EVQ_CAP 16-byte events):
     // event = {read dword, reference dword, x (nonzero bytes = not a plain match),
-    //          masked-quality flags [3:0] | lane [9:4] | reverse strand [10] | library [26:11]}
+    //          masked-quality flags [3:0] | lane [9:4] | reverse strand [10] | TC base of the record [26:11]}
     // Events are self-contained, so they survive tile changes and are drained in full passes of 64.
     uint4 *const queue = (uint4 *)(lds + a.queue_off) + (threadIdx.x >> 6) * EVQ_CAP;
     int qhead = 0, qcount = 0;
@@ -236,12 +238,12 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
         if (ev_ok) {
             const int ln = (int)(ev.w >> 4) & 63;
             const int rev = (int)(ev.w >> 10) & 1;
-            const int lb = (int)(ev.w >> 11) * d.w_lib;
+            const int e_tcb = (int)(ev.w >> 11);                       // TC base incl. strand (word index)
+            const int lb = e_tcb - d.off_tc() - rev * 1024;            // first word of the record's library
             const bool is_read = ln < 2 * d.nl4;
             const int side = ln >= d.nl4;
             const int m = ln - (side ? d.nl4 : 0);
             const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
-            const int e_tcb = lb + d.off_tc() + rev * 1024;
             // usually exactly one byte of the dword differs: handle the lowest non-matching byte
             // with per-lane shifts (all lanes busy), repeat only while some lane has another
             u32 xr = ev.z;
@@ -406,11 +408,11 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             const i64 refw = rbase - d.apad + 256;
             const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
             const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
-            const int wq = (nq & 0xFFFF) | (tcb << 16);  // tcb < 40960 words (160 KiB of LDS)
-            const int evw = ((w1 & D_REV) << 10) | (libid << 11);  // record part of an event's 4th word
+            // nq (15 bits) | reverse strand | TC base incl. strand (tcb < 40960 words: 160 KiB of LDS)
+            const int wq = (nq & 0x7FFF) | ((w1 & D_REV) << 15) | (tcb << 16);
             // software pipeline: four records in flight, each in its own register set (no register
             // rotation: a copy of an in-flight destination would wait for its load)
-            struct Stage { u32 s4, r4, q4; int tcb, w1, j; bool valid; };
+            struct Stage { u32 s4, r4, q4; int tcb, w1; u32 ev; bool valid; };
             u64 pending = todo;
 
             // fill() always issues its two loads (past the last record it re-reads the previous one), so
@@ -421,10 +423,10 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 const int j = st.valid ? __ffsll((long long)pending) - 1 : last_j;
                 pending &= pending - 1;
                 last_j = j;
-                st.j = j;
                 const int s_wq = rl(wq, j);
-                const int s_nq = s_wq & 0xFFFF;
+                const int s_nq = s_wq & 0x7FFF;
                 st.tcb = (int)((u32)s_wq >> 16);
+                st.ev = ((u32)s_wq >> 15) << 10;  // record part of an event's 4th word
                 if (MASK) st.w1 = rl(w1, j);
                 u64 roff = (u32)rl(rf_lo, j);
                 if (!a.ref32) roff |= (u64)(u32)rl(rf_hi, j) << 32;  // genomes of 4 Gbases and more
@@ -440,7 +442,6 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
 
             auto count = [&](const Stage &st) {
                 const u32 s4_c = st.s4, r4_c = st.r4;
-                const int base_v = st.tcb + lane;  // word index of (code 0, byte 0)
                 // x: per byte, zero iff the byte is a plain match (read == reference, reference is A/C/G/T);
                 // flank lanes only test the reference byte; bytes that are not tasks are forced to zero
                 u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
@@ -454,14 +455,14 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 x &= c_vm;
                 // optimistic: count every task byte as a plain match (the base class of the reference
                 // byte, (ascii >> 1) & 3, selects the 1 KiB plane of TC) ...
-                const u32 base_b = ((u32)base_v << 2) + __builtin_amdgcn_groupstaticsize();  // + dynamic LDS base
+                const u32 base_b = ((u32)st.tcb << 2) + c_lane4;
                 tc_bump4(r4_c, base_b, c_d0, c_d1, c_d2, c_d3);
                 // ... and queue the lanes holding a byte that is not one (drain_pass corrects them)
                 const u64 mm = __ballot(x != 0);
                 if (mm) {
                     if (x != 0) {
                         const int slot = qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                        u32 w = (u32)rl(evw, st.j) | ((u32)lane << 4);
+                        u32 w = st.ev | c_lane16;
                         if (MASK) w |= ((mq >> 7) & 1u) | ((mq >> 14) & 2u) | ((mq >> 21) & 4u) | ((mq >> 28) & 8u);
                         queue[slot & (EVQ_CAP - 1)] = make_uint4(s4_c, r4_c, x, w);
                     }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
             u64 todo_p = __ballot(kept && (w1 & D_SIMPLE) && !(w1 & D_FULL));
             todo_g &= ~todo_p;
             if (todo_p) {
-                struct PStage { u32 s4, r4, q4; int nq, tcb, w1, j; bool valid; };
+                struct PStage { u32 s4, r4, q4; int nq, tcb, w1; u32 ev; bool valid; };
                 u64 pend_p = todo_p;
                 int last_p = __ffsll((long long)todo_p) - 1;
                 auto fill_p = [&](PStage &st) {
@@ -500,11 +501,11 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                     const int j = st.valid ? __ffsll((long long)pend_p) - 1 : last_p;
                     pend_p &= pend_p - 1;
                     last_p = j;
-                    st.j = j;
                     const int s_wq = rl(wq, j);
-                    const int s_nq = s_wq & 0xFFFF;
+                    const int s_nq = s_wq & 0x7FFF;
                     st.nq = s_nq;
                     st.tcb = (int)((u32)s_wq >> 16);
+                    st.ev = ((u32)s_wq >> 15) << 10;
                     st.w1 = rl(w1, j);
                     u64 roff = (u32)rl(rf_lo, j);
                     if (!a.ref32) roff |= (u64)(u32)rl(rf_hi, j) << 32;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                         x |= mq;
                     }
                     x &= vm;
-                    const u32 base_b = ((u32)(st.tcb + lane) << 2) + __builtin_amdgcn_groupstaticsize();
+                    const u32 base_b = ((u32)st.tcb << 2) + c_lane4;
                     tc_bump(r4_c, 1, base_b, 0, vm & 1u);
                     tc_bump(r4_c, 9, base_b, 256, (vm >> 8) & 1u);
                     tc_bump(r4_c, 17, base_b, 512, (vm >> 16) & 1u);
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                     if (mm) {
                         if (x != 0) {
                             const int slot = qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                            u32 w = (u32)rl(evw, st.j) | ((u32)lane << 4);
+                            u32 w = st.ev | c_lane16;
                             if (MASK) w |= ((mq >> 7) & 1u) | ((mq >> 14) & 2u) | ((mq >> 21) & 4u) | ((mq >> 28) & 8u);
                             queue[slot & (EVQ_CAP - 1)] = make_uint4(s4_c, r4_c, x, w);
                         }
