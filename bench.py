@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--reads", type=int, default=5_000_000, help="reads per GPU per step")
     ap.add_argument("--cpu-reads", type=int, default=5_000_000, help="bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank: exercises the all-reduce path")
     ap.add_argument("--sorted", action="store_true", help="coordinate-sort the batch (like a sorted BAM)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
                     help="survey workload: 2 = headline (SE 100M reads); 3 = paired, clips + indels; 4 = 35-150 bp")
@@ -47,13 +49,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 or args.force_dist) else 0)
 
     from mapdamage_amd import build, synth
     if rank == 0:
@@ -81,7 +86,7 @@ def main():
     tables = torch.zeros(eng.table_words(), dtype=torch.int64, device=dev)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         eng.sync()
@@ -165,11 +170,15 @@ def main():
                     print(json.dumps(out))
                     raise SystemExit("GPU tables differ from the oracle")
         assert got.n_kept == total_reads, (got.n_kept, total_reads)
-        print(json.dumps(out))
     dbatch.free()
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line, last thing on stdout (RCCL prints its version banner on its own)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ def allreduce_words(words):
     """In-place SUM all-reduce of a packed table block held in a torch int64 tensor (CUDA for
     RCCL, CPU for gloo).  uint64 counters are summed as two's-complement int64: identical bits."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(words, op=dist.ReduceOp.SUM)
     return words
 
