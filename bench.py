@@ -175,7 +175,13 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
-        # the ONE JSON line, last thing on stdout (RCCL prints its version banner on its own)
+        # the ONE JSON line, last thing on stdout: RCCL's version banner (NCCL_DEBUG=VERSION) sits in the
+        # C stdio buffer until exit, so flush the C streams first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stdout.flush()
         sys.stderr.flush()
         print(json.dumps(out), flush=True)
