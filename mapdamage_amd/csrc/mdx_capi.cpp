@@ -13,7 +13,7 @@
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU
-constexpr int kLgdLds = 512;
+constexpr int kLgdLds = 256;           // fragment lengths below this are counted in the LDS
 
 struct DevBuf {
     void *p = nullptr;
@@ -133,8 +133,8 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
     c->stream = c->own_stream;
 
     const int lgd_lds = cfg->lgd_max < kLgdLds ? cfg->lgd_max : kLgdLds;
-    if ((int64_t)cfg->nlib * (4LL * cfg->length * 29 + 8LL * (2LL * cfg->length + 2LL * cfg->around + 64) +
-                              4LL * lgd_lds) > 0x7FFFFFF0LL || cfg->length > (1 << 24) || cfg->around > (1 << 24))
+    if ((int64_t)cfg->nlib * (4LL * cfg->length * 29 + 8LL * (2LL * cfg->around + 512) +
+                              4LL * lgd_lds + 128) > 0x7FFFFFF0LL || cfg->length > (1 << 24) || cfg->around > (1 << 24))
         return fail(c, MDX_ERR_ARG, "table too large (nlib * length)");
     c->dims = mdx_make_dims(cfg->length, cfg->around, cfg->nlib, cfg->lgd_max, lgd_lds);
     c->lds_bytes = mdx_k_lds_bytes(c->dims);
@@ -285,7 +285,9 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     a.lgd_over_cap = c->cfg.lgd_over_cap;
     a.n_lgd_over = c->d_n_lgd_over;
     a.err = c->d_err;
+    a.stage_off = mdx_k_stage_off(c->dims);
     a.queue_off = mdx_k_queue_off(c->dims);
+    a.n_bases = b->n_bases;
     a.ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL ? 1 : 0;
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
     const int wpb = mdx_k_block_threads() / 64;

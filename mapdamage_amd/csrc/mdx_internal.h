@@ -10,15 +10,21 @@
 //                                    0..3 (A,C,T,G order = (ascii >> 1) & 3) count the matching
 //                                    columns of gapped records
 //   CMP [strand 2][side 2][L][4]    read-base counts of columns that are not plain matches
-//   TC  [strand 2][base 4][256]     the common case of plain (ungapped, complete) records: read base ==
-//                                    reference base, or an A/C/G/T flank base.  One lane of the
-//                                    wavefront owns four consecutive bytes (one dword) of a record:
-//                                      lanes [0, nl4)            left-anchored columns 4m .. 4m+3
-//                                      lanes [nl4, 2 nl4)        right-anchored columns 4m+3 .. 4m (byte order)
-//                                      lanes [2 nl4, +nf4)       left flank, distances 4(m+1) .. 4m+1
-//                                      lanes [2 nl4 + nf4, +nf4) right flank, distances 4m+1 .. 4m+4
-//                                    and the table index of (lane, byte j) is tau = 64 j + lane, so the
-//                                    64 increments of one ds_add_u32 fall in 64 consecutive words.
+//   (padding to a multiple of 64 words: the TC planes are 256-byte aligned in the LDS)
+//   TC  [strand 2][base 4][512]     the common case of plain (ungapped) records: read base == reference
+//                                    base, or an A/C/G/T flank base.  One lane of the wavefront owns
+//                                    eight consecutive bytes of a record's window, flank and columns
+//                                    merged (the left flank is contiguous with the left columns in
+//                                    the reference, the right flank with the right columns):
+//                                      lanes [0, nl8)      left side:  window bytes b = 8m + j, b = p + A
+//                                                          (p < 0: left flank at distance -p, else column p)
+//                                      lanes [nl8, 2 nl8)  right side: e = 8m + 7 - j counted back from
+//                                                          aend + A (e < A: right flank at distance A - e,
+//                                                          else right-anchored column e - A)
+//                                    G = 2 nl8 lanes per record, so one wavefront step counts R = 64 / G
+//                                    records (slot g = lane / G); the table index of (lane, byte j) is
+//                                    tau = 64 j + lane: the 64 increments of one ds_add_u32 fall in 64
+//                                    consecutive words, and every slot has its own words.
 //   LGD [kind 2][strand 2][lgd_lds] short fragment lengths
 // followed, after the last library, by one word: number of kept reads.
 // side 0 = left-anchored (columns counted from the leftmost reference coordinate),
@@ -27,46 +33,52 @@
 // finalize_kernel.
 struct MdxDims {
     int L, A, nlib, lgd_max, lgd_lds;
-    int nl4, nf4, apad;   // dword lanes per side, per flank; 4 * nf4
-    int t_pad;            // 256
-    int w_mis, w_cmp, w_tc, w_lgd, w_lib;
+    int nl8;              // 8-byte lanes per side (0: no fast path)
+    int G, R;             // lanes per record, records per wavefront step
+    int t_pad;            // words per TC plane: 512 with the fast path
+    int w_mis, w_cmp, w_mc, w_tc, w_lgd, w_lib;
     int64_t w_total;      // nlib * w_lib + 1
     __host__ __device__ int off_cmp() const { return w_mis; }
-    __host__ __device__ int off_tc() const { return w_mis + w_cmp; }
-    __host__ __device__ int off_lgd() const { return w_mis + w_cmp + w_tc; }
-    __host__ __device__ int tau_left(int p) const { return 64 * (p & 3) + (p >> 2); }
-    __host__ __device__ int tau_right(int p) const { return 64 * (3 - (p & 3)) + nl4 + (p >> 2); }
+    __host__ __device__ int off_tc() const { return w_mc; }
+    __host__ __device__ int off_lgd() const { return w_mc + w_tc; }
+    // task -> TC index of slot 0 (slot g adds g * G)
+    __host__ __device__ int tau_left(int p) const { const int b = p + A; return 64 * (b & 7) + (b >> 3); }
+    __host__ __device__ int tau_right(int p) const { const int e = p + A; return 64 * (7 - (e & 7)) + nl8 + (e >> 3); }
     __host__ __device__ int tau_lflank(int dist) const {
-        if (nl4 == 0) return dist - 1;  // no fast path: flank tasks numbered densely
-        const int m = (dist - 1) >> 2;
-        return 64 * (4 * (m + 1) - dist) + 2 * nl4 + m;
+        if (nl8 == 0) return dist - 1;  // no fast path: flank tasks numbered densely
+        const int b = A - dist;
+        return 64 * (b & 7) + (b >> 3);
     }
     __host__ __device__ int tau_rflank(int dist) const {
-        if (nl4 == 0) return A + dist - 1;
-        const int m = (dist - 1) >> 2;
-        return 64 * (dist - 1 - 4 * m) + 2 * nl4 + nf4 + m;
+        if (nl8 == 0) return A + dist - 1;
+        const int e = A - dist;
+        return 64 * (7 - (e & 7)) + nl8 + (e >> 3);
     }
-    // the dword fast path needs all its lanes in one wavefront and its flank window in the guard band
-    __host__ __device__ bool fast_ok() const { return nl4 > 0 && apad <= 248 && L + A <= 248; }
+    // the 8-byte-lane fast path needs at least one record per wavefront and its window in the guard band
+    __host__ __device__ bool fast_ok() const { return nl8 > 0; }
 };
+
+#define MDX_MAX_R 4       // records per wavefront step (staging pad = R - 1 entries)
 
 static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd_lds) {
     MdxDims d;
     d.L = L; d.A = A; d.nlib = nlib; d.lgd_max = lgd_max; d.lgd_lds = lgd_lds;
-    d.nl4 = (L + 3) / 4;
-    d.nf4 = (A + 3) / 4;
-    d.apad = 4 * d.nf4;
-    d.t_pad = 256;
-    if (2 * d.nl4 + 2 * d.nf4 > 64 || d.apad > 248 || L + A > 248) {  // no fast path
-        d.nl4 = 0; d.nf4 = 0;
+    d.nl8 = (L + A + 7) / 8;
+    d.G = 2 * d.nl8;
+    d.t_pad = 512;
+    if (d.G > 64 || L + A > 248) {  // no fast path
+        d.nl8 = 0; d.G = 0; d.R = 0;
         d.t_pad = ((2 * A + 63) / 64) * 64;
         if (d.t_pad == 0) d.t_pad = 64;
+    } else {
+        d.R = 64 / d.G < MDX_MAX_R ? 64 / d.G : MDX_MAX_R;
     }
     d.w_mis = 2 * 2 * L * 25;
     d.w_cmp = 2 * 2 * L * 4;
+    d.w_mc = (d.w_mis + d.w_cmp + 63) / 64 * 64;
     d.w_tc = 2 * 4 * d.t_pad;
     d.w_lgd = 2 * 2 * lgd_lds;
-    d.w_lib = d.w_mis + d.w_cmp + d.w_tc + d.w_lgd;
+    d.w_lib = (d.w_mc + d.w_tc + d.w_lgd + 63) / 64 * 64;
     d.w_total = (int64_t)nlib * d.w_lib + 1;
     return d;
 }
@@ -98,14 +110,17 @@ struct MdxTabArgs {
     long long lgd_over_cap;
     unsigned long long *n_lgd_over;
     unsigned long long *err;         // min over (read_index << 8 | -code); ~0 = no error
+    int stage_off;                   // word offset of the per-wave record staging areas in the LDS
     int queue_off;                   // word offset of the per-wave rare-event queues in the LDS
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
+    int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };
 
 int mdx_k_block_threads();
 size_t mdx_k_lds_bytes(const MdxDims &d);
+int mdx_k_stage_off(const MdxDims &d);
 int mdx_k_queue_off(const MdxDims &d);
 hipError_t mdx_k_prepare(size_t lds_bytes);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);

@@ -5,14 +5,15 @@
 //   * phase 1, lane-per-record: coalesced SoA loads of the per-record columns, flag filter
 //     (reader.py:121-132), CIGAR scan (clips, reference span, column count), fragment-length
 //     update (statistics.py:117-126), soft-clip update (statistics.py:37-51), error checks;
-//   * phase 2, wavefront-per-record: the record's scalars are broadcast with v_readlane and
-//     the 64 lanes each own one *task* of the record (one left- or right-anchored alignment
-//     column, or one flank base); bases and reference symbols are read with consecutive
-//     addresses across lanes.  The loads of record j+1 are issued before record j is counted
-//     (register double-buffering) so that the gather latency of the resident genome is hidden;
+//   * phase 2, plain records: one lane owns eight consecutive bytes of a record's window (flank and
+//     columns merged), so a wavefront step counts R = 64 / G records at once (3 at --length 70
+//     --around 10); the per-record scalars are staged in the LDS by phase 1 and read back per slot.
+//     The loads of step k+4 are issued before step k is counted (four register sets) so that the
+//     gather latency of the resident genome is hidden;
 //   * the common outcome (read base == reference base, or an A/C/G/T flank base) is one
-//     conflict-free ds_add_u32 into a task-indexed LDS table; everything else (substitutions,
-//     indels, N, masked columns) takes a rare, divergent path into the MIS/CMP tables;
+//     conflict-free ds_add_u32 per byte into a (lane, byte)-indexed LDS table; everything else
+//     (substitutions, N, masked columns) is queued and counted 64 events at a time into the MIS/CMP
+//     tables; gapped records (I/D/N) walk their CIGAR per column;
 //   * at block end the LDS image is stored to a per-block slot and a second kernel sums the
 //     slots into the u64 accumulators (no global atomics on the hot path).
 // Counting is done in *reference orientation* (left-/right-anchored, no complementing); the
@@ -27,12 +28,15 @@ typedef uint8_t u8;
 typedef int8_t i8;
 typedef uint16_t u16;
 typedef uint32_t u32;
-typedef u32 __attribute__((aligned(1))) u32_u;
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((aligned(1))) u32x2_u;
 typedef unsigned long long u64;
 typedef long long i64;
 
 #define MDX_BLOCK 768                   // 12 wavefronts; two blocks per CU share the 160 KiB LDS
-#define EVQ_CAP 128                     // rare-event queue capacity per wavefront (16-byte events)
+#define EVQ_CAP 64                      // rare-event queue capacity per wavefront
+#define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
+#define STG_ENT (64 + MDX_MAX_R)        // staging entries (16 B) per wavefront: 64 records + pad
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -58,8 +62,10 @@ __constant__ u8 c_comp_col[25] = {3, 2, 1, 0, 5, 4, 7, 6, 12, 13, 14, 15, 8,
                                   9, 10, 11, 17, 16, 19, 18, 21, 20, 23, 22, 24};
 
 int mdx_k_block_threads() { return MDX_BLOCK; }
-size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)(d.w_total + 3) / 4 * 16 + (size_t)(MDX_BLOCK / 64) * EVQ_CAP * 16; }
-int mdx_k_queue_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
+// LDS image: [tables w_total words, padded to 16 B][staging, 12 x STG_ENT x 16 B][event queues, 12 x EVQ_BYTES]
+int mdx_k_stage_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
+int mdx_k_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_BLOCK / 64) * STG_ENT * 4; }
+size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4 + (size_t)(MDX_BLOCK / 64) * EVQ_BYTES; }
 
 // read byte -> class; accepted only if it is exactly the upper-case letter
 // ("nt in 'ACGT-'", statistics.py:27)
@@ -95,35 +101,86 @@ __device__ __forceinline__ void bump(u32 *lds, u64 *raw, int idx) {
     if (USE_LDS) atomicAdd(&lds[idx], 1u);
     else atomicAdd(&raw[idx], 1ull);
 }
-// TC increment of the fast path: LDS byte address = base + ((r4 >> bit) & 3) * 1024 + imm.
-// Hand-written (v_bfe_u32, v_lshl_add_u32, ds_add_u32): the compiler's own sequence is shift + and +
-// add3 per byte.  The hidden ds_add only makes the compiler's lgkmcnt waits more conservative (LDS
-// operations complete in order).
-__device__ __forceinline__ void tc_bump(u32 r4, int bit, u32 base_bytes, int imm, u32 data) {
-    u32 k, addr;
-    asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(k) : "v"(r4), "n"(bit));
-    asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(addr) : "v"(k), "v"(base_bytes));
-    asm volatile("ds_add_u32 %0, %1 offset:%2" : : "v"(addr), "v"(data), "n"(imm) : "memory");
-}
-// The four bytes of a dword in one block (no filler s_nop between separate asm statements)
-__device__ __forceinline__ void tc_bump4(u32 r4, u32 base_bytes, u32 d0, u32 d1, u32 d2, u32 d3) {
+// TC increments of the fast path, the eight bytes of a lane in one block.  LDS byte address of byte j =
+// base + ((r >> (8 j + 1)) & 3) * 2048 + 256 j (base = TC[library][strand] + 4 * lane): the base class of
+// the reference byte selects the 2 KiB plane.  Hand-written (v_bfe_u32, v_lshl_add_u32, ds_add_u32): the
+// compiler's own sequence is shift + and + add3 per byte.  The ds_adds are invisible to the compiler's
+// lgkmcnt bookkeeping, which only makes its waits more conservative (LDS operations complete in order);
+// nothing reads TC before the final barrier, which is preceded by an explicit s_waitcnt.
+__device__ __forceinline__ void tc_bump8(u32 r_lo, u32 r_hi, u32 base_bytes, u32 d0, u32 d1, u32 d2, u32 d3,
+                                         u32 d4, u32 d5, u32 d6, u32 d7) {
     u32 t0, t1, t2, t3;
     asm volatile(
         "v_bfe_u32 %0, %4, 1, 2\n\t"
         "v_bfe_u32 %1, %4, 9, 2\n\t"
         "v_bfe_u32 %2, %4, 17, 2\n\t"
         "v_bfe_u32 %3, %4, 25, 2\n\t"
-        "v_lshl_add_u32 %0, %0, 10, %5\n\t"
-        "v_lshl_add_u32 %1, %1, 10, %5\n\t"
-        "v_lshl_add_u32 %2, %2, 10, %5\n\t"
-        "v_lshl_add_u32 %3, %3, 10, %5\n\t"
+        "v_lshl_add_u32 %0, %0, 11, %5\n\t"
+        "v_lshl_add_u32 %1, %1, 11, %5\n\t"
+        "v_lshl_add_u32 %2, %2, 11, %5\n\t"
+        "v_lshl_add_u32 %3, %3, 11, %5\n\t"
         "ds_add_u32 %0, %6\n\t"
         "ds_add_u32 %1, %7 offset:256\n\t"
         "ds_add_u32 %2, %8 offset:512\n\t"
         "ds_add_u32 %3, %9 offset:768"
         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(r4), "v"(base_bytes), "v"(d0), "v"(d1), "v"(d2), "v"(d3)
+        : "v"(r_lo), "v"(base_bytes), "v"(d0), "v"(d1), "v"(d2), "v"(d3)
         : "memory");
+    asm volatile(
+        "v_bfe_u32 %0, %4, 1, 2\n\t"
+        "v_bfe_u32 %1, %4, 9, 2\n\t"
+        "v_bfe_u32 %2, %4, 17, 2\n\t"
+        "v_bfe_u32 %3, %4, 25, 2\n\t"
+        "v_lshl_add_u32 %0, %0, 11, %5\n\t"
+        "v_lshl_add_u32 %1, %1, 11, %5\n\t"
+        "v_lshl_add_u32 %2, %2, 11, %5\n\t"
+        "v_lshl_add_u32 %3, %3, 11, %5\n\t"
+        "ds_add_u32 %0, %6 offset:1024\n\t"
+        "ds_add_u32 %1, %7 offset:1280\n\t"
+        "ds_add_u32 %2, %8 offset:1536\n\t"
+        "ds_add_u32 %3, %9 offset:1792"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r_hi), "v"(base_bytes), "v"(d4), "v"(d5), "v"(d6), "v"(d7)
+        : "memory");
+}
+// The same with one increment for all eight bytes (complete records: a byte that is not a task has a
+// table word of its own that no task maps to, so counting it is harmless and saves the data registers)
+__device__ __forceinline__ void tc_bump8_all(u32 r_lo, u32 r_hi, u32 base_bytes, u32 dd) {
+    u32 t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_bfe_u32 %0, %8, 1, 2\n\t"
+        "v_bfe_u32 %1, %8, 9, 2\n\t"
+        "v_bfe_u32 %2, %8, 17, 2\n\t"
+        "v_bfe_u32 %3, %8, 25, 2\n\t"
+        "v_bfe_u32 %4, %9, 1, 2\n\t"
+        "v_bfe_u32 %5, %9, 9, 2\n\t"
+        "v_bfe_u32 %6, %9, 17, 2\n\t"
+        "v_bfe_u32 %7, %9, 25, 2\n\t"
+        "v_lshl_add_u32 %0, %0, 11, %10\n\t"
+        "v_lshl_add_u32 %1, %1, 11, %10\n\t"
+        "v_lshl_add_u32 %2, %2, 11, %10\n\t"
+        "v_lshl_add_u32 %3, %3, 11, %10\n\t"
+        "ds_add_u32 %0, %11\n\t"
+        "ds_add_u32 %1, %11 offset:256\n\t"
+        "v_lshl_add_u32 %4, %4, 11, %10\n\t"
+        "v_lshl_add_u32 %5, %5, 11, %10\n\t"
+        "ds_add_u32 %2, %11 offset:512\n\t"
+        "ds_add_u32 %3, %11 offset:768\n\t"
+        "v_lshl_add_u32 %6, %6, 11, %10\n\t"
+        "v_lshl_add_u32 %7, %7, 11, %10\n\t"
+        "ds_add_u32 %4, %11 offset:1024\n\t"
+        "ds_add_u32 %5, %11 offset:1280\n\t"
+        "ds_add_u32 %6, %11 offset:1536\n\t"
+        "ds_add_u32 %7, %11 offset:1792"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(r_lo), "v"(r_hi), "v"(base_bytes), "v"(dd)
+        : "memory");
+}
+// (pk & 0x3ff00) | lane4: TC base of the record (256-byte aligned) + the lane's word
+__device__ __forceinline__ u32 tc_base(u32 pk, u32 lane4) {
+    u32 r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x3FF00u), "v"(pk), "v"(lane4));
+    return r;
 }
 
 template <bool USE_LDS>
@@ -137,8 +194,39 @@ __device__ __forceinline__ void flag_error(u64 *err, i64 read, int code) {
 }
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int mbcnt64(u64 m, int base) {
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)base));
+}
 
-// record descriptor word w1 (one int per record, broadcast in phase 2)
+// bytes [lo, hi) of a 64-bit word, the range clamped to [0, 8)
+__device__ __forceinline__ u64 byte_range(int lo, int hi) {
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 8 ? 8 : hi;
+    if (hi <= lo) return 0ull;
+    const u64 upto = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+    return upto & ~((1ull << (8 * lo)) - 1ull);
+}
+// static byte masks of the lane (side, 8 m) of a record (MdxDims): vm = the byte is a task of a complete
+// record, em = the byte is a read column (its read byte is compared; a flank byte is only classified)
+__device__ __forceinline__ void lane_masks(const MdxDims &d, int side, int m8, u64 &vm, u64 &em) {
+    if (!side) {
+        vm = byte_range(0, d.A + d.L - m8);
+        em = vm & byte_range(d.A - m8, 8);
+    } else {
+        vm = byte_range(m8 + 8 - d.A - d.L, 8);
+        em = vm & byte_range(0, m8 + 8 - d.A);
+    }
+}
+// 8 flag bits -> bit 7 of the corresponding bytes of a 64-bit word
+__device__ __forceinline__ u64 spread_bits(u32 m) {
+    const u32 lo = (((m & 0xFu) * 0x00204081u) & 0x01010101u) << 7;
+    const u32 hi = ((((m >> 4) & 0xFu) * 0x00204081u) & 0x01010101u) << 7;
+    return (u64)lo | ((u64)hi << 32);
+}
+// bit 7 of the four bytes of v -> 4 flag bits
+__device__ __forceinline__ u32 gather_bits(u32 v) { return (((v >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu; }
+
+// record descriptor word w1 (one int per record)
 #define D_REV 1
 #define D_SIMPLE 2
 #define D_HASQ 4
@@ -171,16 +259,17 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
     }
 }
 
-// FAST: the dword-lane path for plain, complete records (MdxDims::fast_ok()); otherwise every
-// record takes the generic CIGAR walk.
+// FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
+// otherwise every record takes the generic CIGAR walk.
 template <bool USE_LDS, bool MASK, bool FAST>
 __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int waves_per_block = MDX_BLOCK / 64;
-    const i64 gwave = (i64)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const i64 gwave = (i64)blockIdx.x * waves_per_block + wave;
     const i64 nwaves = (i64)gridDim.x * waves_per_block;
     u64 *raw = a.raw;
 
@@ -189,80 +278,89 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
         __syncthreads();
     }
 
-    // per-lane constants of the dword fast path (see MdxDims): the lane's four bytes are
-    //   reference: refB[rcoef * nq + r0]  with refB = ref + rbase - apad
-    //   SEQ:       seq[scoef * nq + s0]   (flank lanes: a dummy, disabled by em = 0)
-    // byte j is a task iff bit 8j of vm is set; (side, p) of byte j: p = pbase + pstep * j.
-    int c_r0 = d.apad, c_rcoef = 0, c_s0 = 0, c_scoef = 0, c_side = 0, c_pbase = 0, c_pstep = 1;
-    int c_kind = 4, c_m4 = 0;  // lane kind: 0 left columns, 1 right columns, 2 left flank, 3 right flank, 4 none
-    u32 c_em = 0, c_vm = 0;
-    bool c_read = false;
+    // Per-lane constants of the fast path (MdxDims): slot g = lane / G holds one record of the step; within
+    // the slot, lanes [0, nl8) are the left side, [nl8, 2 nl8) the right side; lane (side, m) owns the bytes
+    //   reference: refW[rfL + c_ro + (side ? nq : 0)]     refW = ref - 256, rfL = rbase - A + 256
+    //   SEQ:       seq[sq + c_so + (side ? nq : 0)]
+    // Lanes beyond R * G idle (they shadow lane 0 and are masked out of every count).
+    int c_slot = 0, c_side = 0, c_m8 = 0;
+    u32 c_ro = 0, c_so = (u32)(-A), c_cm = 0;
+    u32 c_vm_lo = 0, c_vm_hi = 0, c_em_lo = 0, c_em_hi = 0;  // em is a subset of vm
     if (FAST) {
-        const int m0 = lane, m1 = lane - d.nl4, m2 = lane - 2 * d.nl4, m3 = lane - 2 * d.nl4 - d.nf4;
-        if (m0 < d.nl4) {
-            c_r0 = d.apad + 4 * m0; c_s0 = 4 * m0; c_em = ~0u; c_read = true; c_side = 0; c_pbase = 4 * m0; c_pstep = 1;
-            c_kind = 0; c_m4 = 4 * m0;
-            for (int j = 0; j < 4; j++) if (4 * m0 + j < L) c_vm |= 0xFFu << (8 * j);
-        } else if (m1 < d.nl4) {
-            c_rcoef = 1; c_r0 = d.apad - 4 - 4 * m1; c_scoef = 1; c_s0 = -4 - 4 * m1; c_em = ~0u; c_read = true;
-            c_side = 1; c_pbase = 4 * m1 + 3; c_pstep = -1; c_kind = 1; c_m4 = 4 * m1;
-            for (int j = 0; j < 4; j++) if (4 * m1 + 3 - j < L) c_vm |= 0xFFu << (8 * j);
-        } else if (m2 < d.nf4) {
-            c_r0 = d.apad - 4 * (m2 + 1); c_kind = 2; c_m4 = 4 * m2;
-            for (int j = 0; j < 4; j++) if (4 * (m2 + 1) - j <= A) c_vm |= 0xFFu << (8 * j);
-        } else if (m3 < d.nf4) {
-            c_rcoef = 1; c_r0 = d.apad + 4 * m3; c_kind = 3; c_m4 = 4 * m3;
-            for (int j = 0; j < 4; j++) if (4 * m3 + j + 1 <= A) c_vm |= 0xFFu << (8 * j);
+        const int g = lane / d.G, ll = lane - g * d.G;
+        if (g < d.R) {
+            c_slot = g;
+            c_side = ll >= d.nl8;
+            c_m8 = 8 * (ll - c_side * d.nl8);
+            if (c_side) {
+                c_ro = (u32)(2 * A - 8 - c_m8); c_so = (u32)(A - 8 - c_m8); c_cm = 0x7FFFu;
+            } else {
+                c_ro = (u32)c_m8; c_so = (u32)(c_m8 - A);
+            }
+            u64 vm, em;
+            lane_masks(d, c_side, c_m8, vm, em);
+            c_vm_lo = (u32)vm; c_vm_hi = (u32)(vm >> 32);
+            c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
         }
     }
-    const u32 c_lane16 = (u32)lane << 4;                                           // lane field of an event word
-    const u32 c_lane4 = ((u32)lane << 2) + __builtin_amdgcn_groupstaticsize();      // LDS byte address of word `lane`
-    const u32 c_d0 = c_vm & 1u, c_d1 = (c_vm >> 8) & 1u, c_d2 = (c_vm >> 16) & 1u, c_d3 = (c_vm >> 24) & 1u;
+    const u32 c_hivm_lo = c_vm_lo & 0x80808080u, c_hivm_hi = c_vm_hi & 0x80808080u;
+    const u32 c_lane18 = (u32)lane << 18;   // lane field of an event word
+    const u32 c_lane4 = (u32)lane << 2;     // byte offset of word `lane` (the dynamic LDS starts at address 0)
 
-    // Rare-event queue of the fast path (wave-private ring in the LDS, EVQ_CAP 16-byte events):
-    // event = {read dword, reference dword, x (nonzero bytes = not a plain match),
-    //          masked-quality flags [3:0] | lane [9:4] | reverse strand [10] | TC base of the record [26:11]}
-    // Events are self-contained, so they survive tile changes and are drained in full passes of 64.
-    uint4 *const queue = (uint4 *)(lds + a.queue_off) + (threadIdx.x >> 6) * EVQ_CAP;
-    int qhead = 0, qcount = 0;
+    // Record staging of the fast path (wave-private, LDS): phase 1 writes one 16-byte entry per plain record,
+    // complete records first, {rfL, sq, nq | nbefore << 16 | nafter << 24,
+    //                          TC base bytes [17:8] | library [29:24] | has qualities [30] | reverse strand [31]};
+    // phase 2 reads the entry of its slot with one ds_read_b128 (no v_readlane broadcast).
+    uint4 *const stg = (uint4 *)(lds + a.stage_off) + wave * STG_ENT;
+    // Rare-event queue (wave-private, LDS): the lanes holding a byte that is not a plain match append
+    // {read 8 bytes, reference 8 bytes, record word | lane << 18 | masked-quality flags [7:0]}; the queue is
+    // drained completely, 64 events in parallel, whenever the next step might not fit.
+    u32x2 *const qS = (u32x2 *)((u8 *)(lds + a.queue_off) + wave * EVQ_BYTES);
+    u32x2 *const qR = qS + EVQ_CAP;
+    u32 *const qW = (u32 *)(qR + EVQ_CAP);
+    int qcount = 0;
 
-    // One pass: undo the optimistic TC increment of each byte that was not a plain match and, for read
-    // bytes, count what the byte really is (rare_column) — lane-parallel over up to 64 events.
-    auto drain_pass = [&]() {
-        const bool ev_ok = lane < qcount;
-        uint4 ev = make_uint4(0, 0, 0, 0);
-        if (ev_ok) ev = queue[(qhead + lane) & (EVQ_CAP - 1)];
-        const int n = qcount < 64 ? qcount : 64;
-        qhead = (qhead + n) & (EVQ_CAP - 1);
-        qcount -= n;
-        if (ev_ok) {
-            const int ln = (int)(ev.w >> 4) & 63;
-            const int rev = (int)(ev.w >> 10) & 1;
-            const int e_tcb = (int)(ev.w >> 11);                       // TC base incl. strand (word index)
-            const int lb = e_tcb - d.off_tc() - rev * 1024;            // first word of the record's library
-            const bool is_read = ln < 2 * d.nl4;
-            const int side = ln >= d.nl4;
-            const int m = ln - (side ? d.nl4 : 0);
+    // Undo the optimistic TC increment of each queued byte that was not a plain match and, for read
+    // columns, count what the byte really is (rare_column) — lane-parallel over the queued events.
+    auto drain_all = [&]() {
+        if (lane < qcount) {
+            const u32x2 es = qS[lane], er = qR[lane];
+            const u32 w = qW[lane];
+            const int ln = (int)(w >> 18) & 63;
+            const int rev = (int)(w >> 31);
+            const int lb = (int)((w >> 24) & 0x3Fu) * d.w_lib;
+            const int tcw = (int)((w & 0x3FF00u) >> 2);            // first word of TC[library][strand]
+            int ll = ln;  // lane within its slot (R <= 4)
+            if (ll >= d.G) ll -= d.G;
+            if (ll >= d.G) ll -= d.G;
+            if (ll >= d.G) ll -= d.G;
+            const int side = ll >= d.nl8;
+            const int m8 = 8 * (ll - side * d.nl8);
+            u64 vm, em;
+            lane_masks(d, side, m8, vm, em);
+            const u64 s64 = (u64)es.x | ((u64)es.y << 32), r64 = (u64)er.x | ((u64)er.y << 32);
+            u64 x = (((s64 ^ r64) & em) | (r64 & 0x8080808080808080ull)) & vm;
+            if (MASK) x |= spread_bits(w & 0xFFu);
             const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
-            // usually exactly one byte of the dword differs: handle the lowest non-matching byte
-            // with per-lane shifts (all lanes busy), repeat only while some lane has another
-            u32 xr = ev.z;
-            while (xr) {
-                const int jb = (__ffs((int)xr) - 1) >> 3;
+            // usually exactly one byte of the lane differs: handle the lowest such byte (all lanes busy),
+            // repeat only while some lane has another
+            while (x) {
+                const int jb = (__ffsll((long long)x) - 1) >> 3;
                 const int sh = 8 * jb;
-                xr &= ~(0xFFu << sh);
-                const u32 rb = (ev.y >> sh) & 0xFFu;
-                bump_n<USE_LDS>(lds, raw, e_tcb + 64 * jb + ln + (int)(((rb >> 1) & 3u) << 8), 0xFFFFFFFFu);  // -1
-                if (is_read)
-                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, side ? 4 * m + 3 - jb : 4 * m + jb,
-                                         (ev.x >> sh) & 0xFFu, (int)(i8)rb, MASK && ((ev.w >> jb) & 1u));
+                x &= ~(0xFFull << sh);
+                const u32 rb = (u32)(r64 >> sh) & 0xFFu, sb = (u32)(s64 >> sh) & 0xFFu;
+                bump_n<USE_LDS>(lds, raw, tcw + (int)(((rb >> 1) & 3u) << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
+                if ((em >> sh) & 1ull)
+                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, (side ? m8 + 7 - jb : m8 + jb) - A, sb,
+                                         (int)(i8)rb, MASK && ((w >> jb) & 1u));
             }
         }
-        // nothing LDS-returning may be pending when control rejoins the hot loop: otherwise the
-        // compiler guards the loop's first instructions with s_waitcnt lgkmcnt(0), which also
-        // waits for the previous record's ds_add_u32s on every iteration
+        qcount = 0;
+        // nothing LDS-returning may be pending when control rejoins the hot loop
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     };
+
+    const u8 *const refW = a.ref - 256;  // start of the guard band: window offsets are >= 0
 
     // each wavefront owns one contiguous range of records (balanced to +-1 record), walked in tiles of 64
     const i64 r_lo = a.n_reads * gwave / nwaves, r_hi = a.n_reads * (gwave + 1) / nwaves;
@@ -272,7 +370,7 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
         const bool valid = ri < r_hi;
         const u32 fl = valid ? (u32)a.flag[ri] : 0x4u;
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
-        int w0 = 0, w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
+        int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         u32 sq = 0, cig_o = 0;
         i64 rbase = 0;
         int lkey = -1;  // fragment-length key for the LDS histogram
@@ -342,9 +440,8 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
                 const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 32768;
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
-                if (simple && nq >= 4 * d.nl4 && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
+                if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
                 if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
-                w0 = (nq & 0xFFFF) | (libid << 16);
                 // statistics.py:117-126
                 int kind = -1;
                 i64 flen = 0;
@@ -393,182 +490,36 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
         const u64 todo_all = __ballot(kept);
         if (lane == 0 && todo_all) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), (u32)__popcll(todo_all));
 
-        // ------------------------------------------------------------ phase 2a: plain records
-        // One lane = one dword (four consecutive bytes) of the record; one wavefront step = one record.
-        // Bytes that are not plain matches are not handled here: they are appended as events to a
-        // wave-private LDS queue and counted later 64 at a time (drain_pass), so the divergent
-        // classification code runs once per 64 events instead of once per record.
+        // ------------------------------------------------------------ classification of the kept records
+        // plain (no I/D/N) records whose speculative 8-byte loads stay inside the SEQ buffer take the
+        // fast path: complete ones (every task present) first, then short / contig-edge ones; their
+        // scalars go to the staging area.  Everything else walks its CIGAR (phase 2b, done first so that
+        // the per-record registers of phase 1 are dead during the fast loops).
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
+        int nF = 0, nP = 0;
         if (FAST) {
-            u64 todo = __ballot(kept && (w1 & D_FULL));
-            todo_g = todo_all & ~todo;
-            // offset of the record's reference window and its TC base, per lane (phase-1 layout)
-            // offset from the start of the guard band (>= 0; not an absolute address: keeps the loads global)
-            const i64 refw = rbase - d.apad + 256;
-            const int rf_lo = (int)(refw & 0xFFFFFFFFll), rf_hi = (int)(refw >> 32);
-            const int tcb = libid * d.w_lib + d.off_tc() + (w1 & D_REV) * 1024;
-            // nq (15 bits) | reverse strand | TC base incl. strand (tcb < 40960 words: 160 KiB of LDS)
-            const int wq = (nq & 0x7FFF) | ((w1 & D_REV) << 15) | (tcb << 16);
-            // software pipeline: four records in flight, each in its own register set (no register
-            // rotation: a copy of an in-flight destination would wait for its load)
-            struct Stage { u32 s4, r4, q4; int tcb, w1; u32 ev; bool valid; };
-            u64 pending = todo;
-
-            // fill() always issues its two loads (past the last record it re-reads the previous one), so
-            // the number of loads in flight is static and the waits before count() are counted ones
-            int last_j = todo ? __ffsll((long long)todo) - 1 : 0;
-            auto fill = [&](Stage &st) {
-                st.valid = pending != 0;
-                const int j = st.valid ? __ffsll((long long)pending) - 1 : last_j;
-                pending &= pending - 1;
-                last_j = j;
-                const int s_wq = rl(wq, j);
-                const int s_nq = s_wq & 0x7FFF;
-                st.tcb = (int)((u32)s_wq >> 16);
-                st.ev = ((u32)s_wq >> 15) << 10;  // record part of an event's 4th word
-                if (MASK) st.w1 = rl(w1, j);
-                u64 roff = (u32)rl(rf_lo, j);
-                if (!a.ref32) roff |= (u64)(u32)rl(rf_hi, j) << 32;  // genomes of 4 Gbases and more
-                const u8 *__restrict__ refB = (a.ref - 256) + roff;
-                const u32 s_sq = (u32)rl((int)sq, j);
-                const u8 *__restrict__ seqP = a.seq + s_sq;
-                const u32 ro = (u32)(c_rcoef * s_nq + c_r0);
-                const u32 so = (u32)(c_scoef * s_nq + c_s0);
-                st.r4 = *(const u32_u *)(refB + ro);
-                st.s4 = *(const u32_u *)(seqP + so);
-                if (MASK) st.q4 = *(const u32_u *)(a.qual + s_sq + so);
-            };
-
-            auto count = [&](const Stage &st) {
-                const u32 s4_c = st.s4, r4_c = st.r4;
-                // x: per byte, zero iff the byte is a plain match (read == reference, reference is A/C/G/T);
-                // flank lanes only test the reference byte; bytes that are not tasks are forced to zero
-                u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
-                u32 mq = 0;
-                if (MASK) {
-                    // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
-                    const u32 minq4 = (st.w1 & D_HASQ) ? (u32)a.minqual * 0x01010101u : 0u;
-                    mq = ~((st.q4 | 0x80808080u) - minq4) & 0x80808080u & c_em;
-                    x |= mq;
-                }
-                x &= c_vm;
-                // optimistic: count every task byte as a plain match (the base class of the reference
-                // byte, (ascii >> 1) & 3, selects the 1 KiB plane of TC) ...
-                const u32 base_b = ((u32)st.tcb << 2) + c_lane4;
-                tc_bump4(r4_c, base_b, c_d0, c_d1, c_d2, c_d3);
-                // ... and queue the lanes holding a byte that is not one (drain_pass corrects them)
-                const u64 mm = __ballot(x != 0);
-                if (mm) {
-                    if (x != 0) {
-                        const int slot = qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                        u32 w = st.ev | c_lane16;
-                        if (MASK) w |= ((mq >> 7) & 1u) | ((mq >> 14) & 2u) | ((mq >> 21) & 4u) | ((mq >> 28) & 8u);
-                        queue[slot & (EVQ_CAP - 1)] = make_uint4(s4_c, r4_c, x, w);
-                    }
-                    qcount += __popcll(mm);
-                    if (qcount >= 64) drain_pass();  // at most 63 + 64 events are ever queued
-                }
-            };
-
-            Stage st0{}, st1{}, st2{}, st3{};
-            if (todo) {
-                fill(st0); fill(st1); fill(st2); fill(st3);
-                // single-exit loop, eight loads in flight at every point of it (stages past the last record
-                // re-read it and are skipped by their valid flag): lets the compiler count its vmcnt waits
-                do {
-                    if (st0.valid) count(st0);
-                    fill(st0);
-                    if (st1.valid) count(st1);
-                    fill(st1);
-                    if (st2.valid) count(st2);
-                    fill(st2);
-                    if (st3.valid) count(st3);
-                    fill(st3);
-                } while (st0.valid);
-            }
-
-            // -------- plain records with missing tasks (shorter than the window, or at a contig edge):
-            // same dword layout, the byte-validity mask is computed per record instead of per lane
-            u64 todo_p = __ballot(kept && (w1 & D_SIMPLE) && !(w1 & D_FULL));
-            todo_g &= ~todo_p;
-            if (todo_p) {
-                struct PStage { u32 s4, r4, q4; int nq, tcb, w1; u32 ev; bool valid; };
-                u64 pend_p = todo_p;
-                int last_p = __ffsll((long long)todo_p) - 1;
-                auto fill_p = [&](PStage &st) {
-                    st.valid = pend_p != 0;
-                    const int j = st.valid ? __ffsll((long long)pend_p) - 1 : last_p;
-                    pend_p &= pend_p - 1;
-                    last_p = j;
-                    const int s_wq = rl(wq, j);
-                    const int s_nq = s_wq & 0x7FFF;
-                    st.nq = s_nq;
-                    st.tcb = (int)((u32)s_wq >> 16);
-                    st.ev = ((u32)s_wq >> 15) << 10;
-                    st.w1 = rl(w1, j);
-                    u64 roff = (u32)rl(rf_lo, j);
-                    if (!a.ref32) roff |= (u64)(u32)rl(rf_hi, j) << 32;
-                    // a right-column dword of a short record may start before the record: its window offset
-                    // is negative (down to -(4 nl4 - 1), still inside the 256-byte guard band), so bias it
-                    const u8 *__restrict__ refB = (a.ref - 512) + roff;
-                    const u32 s_sq = (u32)rl((int)sq, j);
-                    const u8 *__restrict__ seqP = a.seq + s_sq;
-                    const u32 ro = (u32)(c_rcoef * s_nq + c_r0 + 256);
-                    int so = c_scoef * s_nq + c_s0;                     // may leave the record: clamp to 0
-                    if (so < 0 || so >= s_nq) so = 0;
-                    st.r4 = *(const u32_u *)(refB + ro);
-                    st.s4 = *(const u32_u *)(seqP + (u32)so);
-                    if (MASK) st.q4 = *(const u32_u *)(a.qual + s_sq + (u32)so);
-                };
-                auto count_p = [&](const PStage &st) {
-                    const int nb = (st.w1 >> D_NB_SHIFT) & 0xFF, na = (st.w1 >> D_NA_SHIFT) & 0xFF;
-                    // valid bytes of this lane: nv of them, at the low end (left columns, right flank:
-                    // increasing position) or at the high end (right columns, left flank)
-                    const int avail = (c_kind < 2 ? st.nq : (c_kind == 2 ? nb : na)) - c_m4;
-                    const int nv = avail < 0 ? 0 : (avail > 4 ? 4 : avail);
-                    const bool top = c_kind == 1 || c_kind == 2;
-                    const u32 ones = 0xFFFFFFFFu;
-                    const u32 dyn = nv == 0 ? 0u : (top ? ones << (32 - 8 * nv) : ones >> (32 - 8 * nv));
-                    const u32 vm = c_vm & dyn;
-                    // a right-column dword that starts before the record was loaded at offset 0: shift it
-                    u32 s4_c = st.s4, q4_c = st.q4;
-                    const int before = c_m4 + 4 - st.nq;  // bytes of the dword in front of the record
-                    if (c_kind == 1 && before > 0 && before < 4) { s4_c <<= 8 * before; q4_c <<= 8 * before; }
-                    const u32 r4_c = st.r4;
-                    u32 x = ((s4_c ^ r4_c) & c_em) | (r4_c & 0x80808080u);
-                    u32 mq = 0;
-                    if (MASK) {
-                        const u32 minq4 = (st.w1 & D_HASQ) ? (u32)a.minqual * 0x01010101u : 0u;
-                        mq = ~((q4_c | 0x80808080u) - minq4) & 0x80808080u & c_em;
-                        x |= mq;
-                    }
-                    x &= vm;
-                    const u32 base_b = ((u32)st.tcb << 2) + c_lane4;
-                    tc_bump(r4_c, 1, base_b, 0, vm & 1u);
-                    tc_bump(r4_c, 9, base_b, 256, (vm >> 8) & 1u);
-                    tc_bump(r4_c, 17, base_b, 512, (vm >> 16) & 1u);
-                    tc_bump(r4_c, 25, base_b, 768, (vm >> 24) & 1u);
-                    const u64 mm = __ballot(x != 0);
-                    if (mm) {
-                        if (x != 0) {
-                            const int slot = qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                            u32 w = st.ev | c_lane16;
-                            if (MASK) w |= ((mq >> 7) & 1u) | ((mq >> 14) & 2u) | ((mq >> 21) & 4u) | ((mq >> 28) & 8u);
-                            queue[slot & (EVQ_CAP - 1)] = make_uint4(s4_c, r4_c, x, w);
-                        }
-                        qcount += __popcll(mm);
-                        if (qcount >= 64) drain_pass();
-                    }
-                };
-                PStage p0{}, p1{};
-                fill_p(p0); fill_p(p1);
-                do {
-                    if (p0.valid) count_p(p0);
-                    fill_p(p0);
-                    if (p1.valid) count_p(p1);
-                    fill_p(p1);
-                } while (p0.valid);
+            const bool plain = kept && (w1 & D_SIMPLE) && sq >= (u32)(8 * d.nl8) &&
+                               (i64)sq + nq + 8 * d.nl8 <= a.n_bases;
+            const bool isF = plain && (w1 & D_FULL);
+            const u64 mF = __ballot(isF), mP = __ballot(plain && !isF);
+            nF = __popcll(mF); nP = __popcll(mP);
+            todo_g = todo_all & ~(mF | mP);
+            if (mF | mP) {
+                const int rev = w1 & D_REV;
+                uint4 ent;
+                ent.x = (u32)(rbase - A + 256);
+                ent.y = sq;
+                ent.z = (u32)nq | ((u32)(w1 >> D_NB_SHIFT) << 16);
+                ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
+                        ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
+                if (plain) stg[isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF)] = ent;
+                // the slots past the last record of a step shadow a real record (and are masked out)
+                const int first = __ffsll((long long)(mF | mP)) - 1;
+                uint4 pad;
+                pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
+                pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
+                if (lane < d.R - 1) stg[nF + nP + lane] = pad;
             }
         }
 
@@ -692,12 +643,121 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 }
             }
         }
+
+        // ------------------------------------------------------------ phase 2a: plain records
+        // One lane = eight consecutive bytes of a record's window; one wavefront step = R records.
+        // Bytes that are not plain matches are not handled here: they are appended as events to a
+        // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
+        // classification code runs once per 64 events instead of once per record.
+        if (FAST) {
+            const int R = d.R, G = d.G;
+            struct Stage { u32x2 s8, r8, q8; u32 pk, nqz; int lim; bool valid; };
+            // complete = true: every task of the record is present (static byte masks); false: short
+            // records and contig edges (byte masks from nq / nbefore / nafter of the record)
+            auto run = [&](const int e0, const int nrec, auto complete_tag) {
+                constexpr bool complete = decltype(complete_tag)::value;
+                const int nsteps = (nrec + R - 1) / R;
+                int kf = 0;
+                // fill() always issues its loads (past the last step it re-reads it), so the number of
+                // loads in flight is static and the waits before count() are counted ones
+                auto fill = [&](Stage &st) {
+                    st.valid = kf < nsteps;
+                    const int k = st.valid ? kf : nsteps - 1;
+                    kf++;
+                    int nv = nrec - k * R;
+                    nv = nv > R ? R : nv;
+                    st.lim = nv * G;
+                    const uint4 ent = stg[e0 + k * R + c_slot];
+                    const u32 t = ent.z & c_cm;
+                    const u32 ro = ent.x + c_ro + t, so = ent.y + c_so + t;
+                    st.r8 = *(const u32x2_u *)(refW + ro);
+                    st.s8 = *(const u32x2_u *)(a.seq + so);
+                    if (MASK) st.q8 = *(const u32x2_u *)(a.qual + so);
+                    st.pk = ent.w;
+                    if (!complete) st.nqz = ent.z;
+                };
+                auto count = [&](const Stage &st) {
+                    // slots past the last record of the tile: no increments, no events
+                    const bool act = lane < st.lim;
+                    u32 s_lo = st.s8.x, s_hi = st.s8.y, r_lo = st.r8.x, r_hi = st.r8.y;
+                    u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi, hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
+                    const u32 base_b = tc_base(st.pk, c_lane4);
+                    if (complete) {
+                        // optimistic: count every byte as a plain match (the base class of the reference
+                        // byte selects the plane of TC) ...
+                        tc_bump8_all(r_lo, r_hi, base_b, act ? 1u : 0u);
+                    } else {
+                        const int nq_ = (int)(st.nqz & 0x7FFFu), nb = (int)(st.nqz >> 16) & 0xFF, na = (int)(st.nqz >> 24);
+                        const int nqL = nq_ < L ? nq_ : L;
+                        const int lo = c_side ? c_m8 + 8 - A - nqL : A - nb - c_m8;
+                        const int hi = c_side ? c_m8 + 8 - A + na : A + nqL - c_m8;
+                        const u64 dyn = act ? byte_range(lo, hi) : 0ull;
+                        const u32 dyn_lo = (u32)dyn & c_vm_lo, dyn_hi = (u32)(dyn >> 32) & c_vm_hi;
+                        emvm_lo = c_em_lo & dyn_lo; emvm_hi = c_em_hi & dyn_hi;
+                        hivm_lo = dyn_lo & 0x80808080u; hivm_hi = dyn_hi & 0x80808080u;
+                        // bytes that are not tasks of this record: a neutral matching pair in the event copy
+                        s_lo = (s_lo & dyn_lo) | (0x41414141u & ~dyn_lo); s_hi = (s_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
+                        r_lo = (r_lo & dyn_lo) | (0x41414141u & ~dyn_lo); r_hi = (r_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
+                        tc_bump8(r_lo, r_hi, base_b, dyn_lo & 1u, (dyn_lo >> 8) & 1u, (dyn_lo >> 16) & 1u, (dyn_lo >> 24) & 1u,
+                                 dyn_hi & 1u, (dyn_hi >> 8) & 1u, (dyn_hi >> 16) & 1u, (dyn_hi >> 24) & 1u);
+                    }
+                    // x: per byte, zero iff the byte is a plain match (read == reference, reference is
+                    // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
+                    u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & hivm_lo);
+                    u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & hivm_hi);
+                    u32 mq_lo = 0, mq_hi = 0;
+                    if (MASK) {
+                        // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
+                        const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
+                        mq_lo = ~((st.q8.x | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
+                        mq_hi = ~((st.q8.y | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
+                        x_lo |= mq_lo; x_hi |= mq_hi;
+                    }
+                    // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
+                    const bool ev = ((x_lo | x_hi) != 0) && (complete ? act : true);
+                    const u64 mm = __ballot(ev);
+                    if (mm) {
+                        const int n = __popcll(mm);
+                        if (qcount + n > EVQ_CAP) drain_all();
+                        if (ev) {
+                            const int slot = mbcnt64(mm, qcount);
+                            u32x2 es, er;
+                            es.x = s_lo; es.y = s_hi; er.x = r_lo; er.y = r_hi;
+                            qS[slot] = es;
+                            qR[slot] = er;
+                            u32 w = (st.pk & 0xBFFFFF00u) | c_lane18;
+                            if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
+                            qW[slot] = w;
+                        }
+                        qcount += n;
+                    }
+                };
+                // software pipeline: four steps in flight, each in its own register set (no register
+                // rotation: a copy of an in-flight destination would wait for its load); single-exit
+                // loop with the same number of loads in flight at every point of it
+                Stage st0{}, st1{}, st2{}, st3{};
+                fill(st0); fill(st1); fill(st2); fill(st3);
+                do {
+                    if (st0.valid) count(st0);
+                    fill(st0);
+                    if (st1.valid) count(st1);
+                    fill(st1);
+                    if (st2.valid) count(st2);
+                    fill(st2);
+                    if (st3.valid) count(st3);
+                    fill(st3);
+                } while (st0.valid);
+            };
+            if (nF) run(0, nF, std::true_type{});
+            if (nP) run(nF, nP, std::false_type{});
+        }
     }
 
     if (FAST) {
-        while (qcount > 0) drain_pass();
+        if (qcount > 0) drain_all();
     }
     if (USE_LDS) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // the hand-written ds_adds of this wavefront
         __syncthreads();
         u32 *out = a.partials + (i64)blockIdx.x * d.w_total;
         for (i64 i = threadIdx.x; i < d.w_total; i += MDX_BLOCK) out[i] = lds[i];
@@ -732,7 +792,7 @@ void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t l
         else launch_one<false, false, false>(a, grid, 0, s);
         return;
     }
-    if (a.dims.fast_ok()) {
+    if (a.dims.fast_ok() && a.ref32) {
         if (mask) launch_one<true, true, true>(a, grid, lds_bytes, s);
         else launch_one<true, false, true>(a, grid, lds_bytes, s);
     } else {
@@ -789,7 +849,8 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
                 const i64 row = lb + ((strand * 2 + side) * L + p) * 25;
                 // matches (gapped records / plain records) + every column whose reference symbol is k
                 v = raw[row + k];
-                if (d.nl4 > 0) v += raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p))];
+                for (int g = 0; g < d.R; g++)  // plain records: one copy per slot of the wavefront step
+                    v += raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p)) + g * d.G];
                 for (int x = 0; x < 4; x++) v += raw[row + c_refcols[k * 4 + x]];
             } else {
                 const int rc = strand ? c_comp_col[col] : col;
@@ -813,9 +874,12 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             const i64 tc = lb + d.off_tc() + (strand * 4 + k) * d.t_pad;
             if (slot >= 0) {
                 v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k];
-                if (d.nl4 > 0) v += raw[tc + (side ? d.tau_right(slot) : d.tau_left(slot))];
+                for (int g = 0; g < d.R; g++) v += raw[tc + (side ? d.tau_right(slot) : d.tau_left(slot)) + g * d.G];
+            } else {
+                v = 0;
+                const int t = side ? d.tau_rflank(dist) : d.tau_lflank(dist);
+                for (int g = 0; g < (d.R > 0 ? d.R : 1); g++) v += raw[tc + t + g * d.G];
             }
-            else v = raw[tc + (side ? d.tau_rflank(dist) : d.tau_lflank(dist))];
         } else if (i < n_mis + n_comp + n_lgd) {
             i64 x = i - n_mis - n_comp;
             const int len = x % d.lgd_max; x /= d.lgd_max;
