@@ -33,7 +33,15 @@ typedef u32x2 __attribute__((aligned(1))) u32x2_u;
 typedef unsigned long long u64;
 typedef long long i64;
 
+#ifndef MDX_BLOCK
 #define MDX_BLOCK 768                   // 12 wavefronts; two blocks per CU share the 160 KiB LDS
+#endif
+#ifndef MDX_WPS
+#define MDX_WPS 6                       // wavefronts per SIMD the register budget is sized for
+#endif
+#ifndef PIPE_DEPTH
+#define PIPE_DEPTH 2                    // wavefront steps in flight (register sets of the load pipeline)
+#endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
 #define STG_ENT (64 + MDX_MAX_R)        // staging entries (16 B) per wavefront: 64 records + pad
@@ -262,7 +270,7 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
 // FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
 // otherwise every record takes the generic CIGAR walk.
 template <bool USE_LDS, bool MASK, bool FAST>
-__global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
+__global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
@@ -736,16 +744,25 @@ __global__ __launch_bounds__(MDX_BLOCK, 6) void tabulate_kernel(MdxTabArgs a) {
                 // rotation: a copy of an in-flight destination would wait for its load); single-exit
                 // loop with the same number of loads in flight at every point of it
                 Stage st0{}, st1{}, st2{}, st3{};
-                fill(st0); fill(st1); fill(st2); fill(st3);
+                fill(st0);
+                if (PIPE_DEPTH > 1) fill(st1);
+                if (PIPE_DEPTH > 2) fill(st2);
+                if (PIPE_DEPTH > 3) fill(st3);
                 do {
                     if (st0.valid) count(st0);
                     fill(st0);
-                    if (st1.valid) count(st1);
-                    fill(st1);
-                    if (st2.valid) count(st2);
-                    fill(st2);
-                    if (st3.valid) count(st3);
-                    fill(st3);
+                    if (PIPE_DEPTH > 1) {
+                        if (st1.valid) count(st1);
+                        fill(st1);
+                    }
+                    if (PIPE_DEPTH > 2) {
+                        if (st2.valid) count(st2);
+                        fill(st2);
+                    }
+                    if (PIPE_DEPTH > 3) {
+                        if (st3.valid) count(st3);
+                        fill(st3);
+                    }
                 } while (st0.valid);
             };
             if (nF) run(0, nF, std::true_type{});
