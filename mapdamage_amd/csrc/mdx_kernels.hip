@@ -30,6 +30,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 __attribute__((aligned(1))) u32x2_u;
+struct __attribute__((packed, aligned(4))) u32x3 { u32 x, y, z; };   // global_load_dwordx3
 typedef unsigned long long u64;
 typedef long long i64;
 
@@ -368,7 +369,16 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     };
 
-    const u8 *const refW = a.ref - 256;  // start of the guard band: window offsets are >= 0
+    // Window loads are dword-aligned: a lane fetches the 12 bytes at (address & ~3) and funnel-shifts its
+    // 8-byte window out of them (v_alignbyte_b32).  Measured on gfx950 (tools/ubench_loads.hip): a wavefront
+    // load whose lane addresses are not dword-aligned costs the texture-address unit about twice as much
+    // (14.1 vs 8.4 ns for the SEQ pattern, 16.2 vs 12.6 ns for the reference pattern), and that unit is
+    // what bounds this kernel.  The bases are aligned down here, their phase goes into the lane offsets.
+    const u32 ph_ref = (u32)((size_t)(a.ref - 256) & 3), ph_seq = (u32)((size_t)a.seq & 3),
+              ph_qual = MASK ? (u32)((size_t)a.qual & 3) : 0u;
+    const u8 *const refW = a.ref - 256 - ph_ref;  // start of the guard band (dword-aligned): window offsets are >= 0
+    const u8 *const seqW = a.seq - ph_seq;
+    const u8 *const qualW = MASK ? a.qual - ph_qual : nullptr;
 
     // each wavefront owns one contiguous range of records (balanced to +-1 record), walked in tiles of 64
     const i64 r_lo = a.n_reads * gwave / nwaves, r_hi = a.n_reads * (gwave + 1) / nwaves;
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // classification code runs once per 64 events instead of once per record.
         if (FAST) {
             const int R = d.R, G = d.G;
-            struct Stage { u32x2 s8, r8, q8; u32 pk, nqz; int lim; bool valid; };
+            struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, nqz; int lim; bool valid; };
             // complete = true: every task of the record is present (static byte masks); false: short
             // records and contig edges (byte masks from nq / nbefore / nafter of the record)
             auto run = [&](const int e0, const int nrec, auto complete_tag) {
@@ -678,16 +688,21 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const uint4 ent = stg[e0 + k * R + c_slot];
                     const u32 t = ent.z & c_cm;
                     const u32 ro = ent.x + c_ro + t, so = ent.y + c_so + t;
-                    st.r8 = *(const u32x2_u *)(refW + ro);
-                    st.s8 = *(const u32x2_u *)(a.seq + so);
-                    if (MASK) st.q8 = *(const u32x2_u *)(a.qual + so);
+                    st.ro = ro + ph_ref; st.so = so + ph_seq;
+                    st.r12 = *(const u32x3 *)(refW + (st.ro & ~3u));
+                    st.s12 = *(const u32x3 *)(seqW + (st.so & ~3u));
+                    if (MASK) {
+                        st.qo = so + ph_qual;
+                        st.q12 = *(const u32x3 *)(qualW + (st.qo & ~3u));
+                    }
                     st.pk = ent.w;
                     if (!complete) st.nqz = ent.z;
                 };
                 auto count = [&](const Stage &st) {
                     // slots past the last record of the tile: no increments, no events
                     const bool act = lane < st.lim;
-                    u32 s_lo = st.s8.x, s_hi = st.s8.y, r_lo = st.r8.x, r_hi = st.r8.y;
+                    u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
+                    u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
                     u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi, hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
                     const u32 base_b = tc_base(st.pk, c_lane4);
                     if (complete) {
@@ -717,8 +732,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     if (MASK) {
                         // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
                         const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
-                        mq_lo = ~((st.q8.x | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
-                        mq_hi = ~((st.q8.y | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
+                        const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
+                        mq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
+                        mq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
                         x_lo |= mq_lo; x_hi |= mq_hi;
                     }
                     // ... and queue the lanes holding a byte that is not one (drain_all corrects them)

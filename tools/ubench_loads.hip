@@ -14,6 +14,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 __attribute__((aligned(1))) u32_u;
 typedef u32x2 __attribute__((aligned(1))) u32x2_u;
 typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+struct __attribute__((packed, aligned(4))) u32x3_a { u32 x, y, z; };
 
 // pattern: 0 = contiguous lanes (lane * W), 1 = segments of `seglanes` lanes at pseudo-random bases
 template <typename T>
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(768) void k(const uint8_t *buf, u32 mask, int iters
     const u32 gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     u32 acc = 0;
     u32 h = gw * 2654435761u + 12345u;
-    const int W = sizeof(T);
+    const int W = sizeof(T) == 12 ? 8 : sizeof(T);   // the 12-byte type reads 8-byte-strided windows + 4
     for (int i = 0; i < iters; i += 8) {
         T v[8];
 #pragma unroll
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(768) void k(const uint8_t *buf, u32 mask, int iters
         for (int u = 0; u < 8; u++) {
             if constexpr (sizeof(T) == 4) acc += v[u];
             else if constexpr (sizeof(T) == 8) acc += v[u].x ^ v[u].y;
+            else if constexpr (sizeof(T) == 12) acc += v[u].x ^ v[u].y ^ v[u].z;
             else acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
         }
     }
@@ -90,8 +92,10 @@ __global__ __launch_bounds__(768) void lds_k(int off, int iters, u32 *out, int c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 acc = 0;
     const uint8_t *base = l + wave * 1024 + off;
+    u32 o = lane * 8;
     for (int i = 0; i < iters; i++) {
-        const u32x2 v = *(const u32x2_u *)(base + lane * 8 + (i & 1) * 512);
+        asm volatile("" : "+v"(o));   // keep the read in the loop
+        const u32x2 v = *(const u32x2_u *)(base + o);
         acc += v.x ^ (v.y * 3u);
     }
     if (check) {
@@ -125,7 +129,8 @@ static void lds_test(u32 *out) {
     }
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1) { u32 *o2; hipMalloc(&o2, 1 << 20); lds_test(o2); return 0; }
     const size_t n = 8u << 20;
     uint8_t *buf; u32 *out;
     hipMalloc(&buf, n + 4096); hipMalloc(&out, 1 << 20);
@@ -154,6 +159,12 @@ int main() {
         printf("4 16 %d 16 %.2f\n", mis, run<u32x4_u>(buf, mask, mis, 4, 16, out));
         printf("4 4 %d 32 %.2f\n", mis, run<u32_u>(buf, mask, mis, 4, 32, out));
     }
-    lds_test(out);
+    printf("# alignment sweep, 8 bytes per lane: pattern 2 (ref-like) and 3 (seq-like) at byte phase 0..4\n");
+    for (int mis = 0; mis <= 4; mis++)
+        printf("phase %d: seq-like %.2f\n", mis, run<u32x2_u>(buf, mask, mis, 3, 10, out));
+    printf("# dword-aligned 12-byte loads at 8-byte lane stride (aligned-down window + one dword)\n");
+    printf("x3 aligned: seq-like %.2f  ref-like %.2f\n", run<u32x3_a>(buf, mask, 0, 3, 10, out), run<u32x3_a>(buf, mask, 0, 2, 10, out));
+    printf("x2 aligned: seq-like %.2f  ref-like %.2f\n", run<u32x2_u>(buf, mask, 0, 3, 10, out), run<u32x2_u>(buf, mask, 0, 2, 10, out));
+    printf("x2 unaligned: seq-like %.2f  ref-like %.2f\n", run<u32x2_u>(buf, mask, 1, 3, 10, out), run<u32x2_u>(buf, mask, 1, 2, 10, out));
     return 0;
 }
