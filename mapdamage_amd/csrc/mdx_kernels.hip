@@ -287,6 +287,17 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         __syncthreads();
     }
 
+    // Window loads are dword-aligned: a lane fetches the 12 bytes at (address & ~3) and funnel-shifts its
+    // 8-byte window out of them (v_alignbyte_b32).  Measured on gfx950 (tools/ubench_loads.hip): a wavefront
+    // load whose lane addresses are not dword-aligned costs the texture-address unit about twice as much
+    // (14.1 vs 8.4 ns for the SEQ pattern, 16.2 vs 12.6 ns for the reference pattern), and that unit is
+    // what bounds this kernel.  The bases are aligned down here, their phase goes into the lane offsets.
+    const u32 ph_ref = (u32)((size_t)(a.ref - 256) & 3), ph_seq = (u32)((size_t)a.seq & 3),
+              ph_qual = MASK ? (u32)((size_t)a.qual & 3) : 0u;
+    const u8 *const refW = a.ref - 256 - ph_ref;  // start of the guard band (dword-aligned): window offsets are >= 0
+    const u8 *const seqW = a.seq - ph_seq;
+    const u8 *const qualW = MASK ? a.qual - ph_qual : nullptr;
+
     // Per-lane constants of the fast path (MdxDims): slot g = lane / G holds one record of the step; within
     // the slot, lanes [0, nl8) are the left side, [nl8, 2 nl8) the right side; lane (side, m) owns the bytes
     //   reference: refW[rfL + c_ro + (side ? nq : 0)]     refW = ref - 256, rfL = rbase - A + 256
@@ -312,6 +323,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
         }
     }
+    c_ro += ph_ref;   // the phases of the aligned-down bases
+    const u32 c_qo = c_so + ph_qual;
+    c_so += ph_seq;
     const u32 c_hivm_lo = c_vm_lo & 0x80808080u, c_hivm_hi = c_vm_hi & 0x80808080u;
     const u32 c_lane18 = (u32)lane << 18;   // lane field of an event word
     const u32 c_lane4 = (u32)lane << 2;     // byte offset of word `lane` (the dynamic LDS starts at address 0)
@@ -369,16 +383,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     };
 
-    // Window loads are dword-aligned: a lane fetches the 12 bytes at (address & ~3) and funnel-shifts its
-    // 8-byte window out of them (v_alignbyte_b32).  Measured on gfx950 (tools/ubench_loads.hip): a wavefront
-    // load whose lane addresses are not dword-aligned costs the texture-address unit about twice as much
-    // (14.1 vs 8.4 ns for the SEQ pattern, 16.2 vs 12.6 ns for the reference pattern), and that unit is
-    // what bounds this kernel.  The bases are aligned down here, their phase goes into the lane offsets.
-    const u32 ph_ref = (u32)((size_t)(a.ref - 256) & 3), ph_seq = (u32)((size_t)a.seq & 3),
-              ph_qual = MASK ? (u32)((size_t)a.qual & 3) : 0u;
-    const u8 *const refW = a.ref - 256 - ph_ref;  // start of the guard band (dword-aligned): window offsets are >= 0
-    const u8 *const seqW = a.seq - ph_seq;
-    const u8 *const qualW = MASK ? a.qual - ph_qual : nullptr;
+
 
     // each wavefront owns one contiguous range of records (balanced to +-1 record), walked in tiles of 64
     const i64 r_lo = a.n_reads * gwave / nwaves, r_hi = a.n_reads * (gwave + 1) / nwaves;
@@ -386,7 +391,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // ------------------------------------------------------------ phase 1: lane per record
         const i64 ri = tbase + lane;
         const bool valid = ri < r_hi;
-        const u32 fl = valid ? (u32)a.flag[ri] : 0x4u;
+        // the per-record columns are requested together, before the flag is known (one memory round
+        // trip for the tile instead of two)
+        const i64 rj = valid ? ri : r_hi - 1;
+        const u32 fl = valid ? (u32)a.flag[rj] : 0x4u;
+        const int c_lib = a.lib[rj], c_tid = a.tid[rj], c_pos = a.pos[rj];
+        const u32 c_co0 = a.cigar_off[rj], c_co1 = a.cigar_off[rj + 1], c_so0 = a.seq_off[rj], c_so1 = a.seq_off[rj + 1];
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         u32 sq = 0, cig_o = 0;
@@ -394,13 +404,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         int lkey = -1;  // fragment-length key for the LDS histogram
         if (kept) {
             const int rev = (fl >> 4) & 1;
-            libid = a.lib[ri];
-            const int tid = a.tid[ri];
-            const i64 pos = a.pos[ri];
-            cig_o = a.cigar_off[ri];
-            cig_n = (int)(a.cigar_off[ri + 1] - cig_o);
-            const u32 so = a.seq_off[ri];
-            const i64 lseq = (i64)a.seq_off[ri + 1] - (i64)so;
+            libid = c_lib;
+            const int tid = c_tid;
+            const i64 pos = c_pos;
+            cig_o = c_co0;
+            cig_n = (int)(c_co1 - cig_o);
+            const u32 so = c_so0;
+            const i64 lseq = (i64)c_so1 - (i64)so;
             bool bad = tid < 0 || tid >= a.n_contig || libid >= d.nlib || lseq <= 0 || pos < 0;
             const int lbase = bad ? 0 : libid * d.w_lib;
 
@@ -688,11 +698,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const uint4 ent = stg[e0 + k * R + c_slot];
                     const u32 t = ent.z & c_cm;
                     const u32 ro = ent.x + c_ro + t, so = ent.y + c_so + t;
-                    st.ro = ro + ph_ref; st.so = so + ph_seq;
-                    st.r12 = *(const u32x3 *)(refW + (st.ro & ~3u));
-                    st.s12 = *(const u32x3 *)(seqW + (st.so & ~3u));
+                    st.ro = ro; st.so = so;
+                    st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
+                    st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
                     if (MASK) {
-                        st.qo = so + ph_qual;
+                        st.qo = ent.y + c_qo + t;
                         st.q12 = *(const u32x3 *)(qualW + (st.qo & ~3u));
                     }
                     st.pk = ent.w;
@@ -738,7 +748,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         x_lo |= mq_lo; x_hi |= mq_hi;
                     }
                     // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
-                    const bool ev = ((x_lo | x_hi) != 0) && (complete ? act : true);
+                    u32 xx = x_lo | x_hi;
+                    if (complete) xx = act ? xx : 0u;   // (the partial path masks by dyn already)
+                    const bool ev = xx != 0;
                     const u64 mm = __ballot(ev);
                     if (mm) {
                         const int n = __popcll(mm);
