@@ -385,9 +385,17 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
 
 
 
-    // each wavefront owns one contiguous range of records (balanced to +-1 record), walked in tiles of 64
-    const i64 r_lo = a.n_reads * gwave / nwaves, r_hi = a.n_reads * (gwave + 1) / nwaves;
-    for (i64 tbase = r_lo; tbase < r_hi; tbase += 64) {
+    // Tiles of 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
+    // an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one); the
+    // records left after the last complete round are split evenly, so every wavefront counts the same
+    // number of records to within one.
+    const i64 rounds = (a.n_reads / 64) / nwaves;
+    const i64 rem_lo = rounds * nwaves * 64, rem = a.n_reads - rem_lo;
+    const i64 t_lo = rem_lo + rem * gwave / nwaves, t_hi = rem_lo + rem * (gwave + 1) / nwaves;
+    const i64 n_it = rounds + (t_hi - t_lo + 63) / 64;
+    for (i64 it = 0; it < n_it; it++) {
+        const i64 tbase = it < rounds ? (it * nwaves + gwave) * 64 : t_lo + (it - rounds) * 64;
+        const i64 r_hi = it < rounds ? tbase + 64 : t_hi;
         // ------------------------------------------------------------ phase 1: lane per record
         const i64 ri = tbase + lane;
         const bool valid = ri < r_hi;
