@@ -40,9 +40,6 @@ typedef long long i64;
 #ifndef MDX_WPS
 #define MDX_WPS 6                       // wavefronts per SIMD the register budget is sized for
 #endif
-#ifndef PIPE_DEPTH
-#define PIPE_DEPTH 2                    // wavefront steps in flight (register sets of the load pipeline)
-#endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
 #define STG_ENT (64 + MDX_MAX_R)        // staging entries (16 B) per wavefront: 64 records + pad
@@ -776,30 +773,21 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         qcount += n;
                     }
                 };
-                // software pipeline: four steps in flight, each in its own register set (no register
-                // rotation: a copy of an in-flight destination would wait for its load); single-exit
-                // loop with the same number of loads in flight at every point of it
-                Stage st0{}, st1{}, st2{}, st3{};
+                // software pipeline: two steps in flight, each in its own register set (no register
+                // rotation: a copy of an in-flight destination would wait for its load).  Every point of
+                // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
+                // one fill per run goes past the last step.
+                Stage st0{}, st1{};
                 fill(st0);
-                if (PIPE_DEPTH > 1) fill(st1);
-                if (PIPE_DEPTH > 2) fill(st2);
-                if (PIPE_DEPTH > 3) fill(st3);
-                do {
-                    if (st0.valid) count(st0);
+                fill(st1);
+                for (int k = 2; k < nsteps; k += 2) {
+                    count(st0);
                     fill(st0);
-                    if (PIPE_DEPTH > 1) {
-                        if (st1.valid) count(st1);
-                        fill(st1);
-                    }
-                    if (PIPE_DEPTH > 2) {
-                        if (st2.valid) count(st2);
-                        fill(st2);
-                    }
-                    if (PIPE_DEPTH > 3) {
-                        if (st3.valid) count(st3);
-                        fill(st3);
-                    }
-                } while (st0.valid);
+                    count(st1);
+                    fill(st1);
+                }
+                count(st0);
+                if (st1.valid) count(st1);
             };
             if (nF) run(0, nF, std::true_type{});
             if (nP) run(nF, nP, std::false_type{});
