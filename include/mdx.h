@@ -148,6 +148,16 @@ int mdx_genome_composition(mdx_ctx *ctx, uint64_t *counts);
 int mdx_rescale_set_model(mdx_ctx *ctx, const uint8_t *lut, const double *term, int32_t len5p, int32_t len3p);
 int mdx_rescale_host(mdx_ctx *ctx, const mdx_batch *batch, const int32_t *mtid, const int32_t *mpos,
                      uint8_t *qual_out, double *mr_raw, uint8_t *status);
+/* The integer content of the `subs` dictionary that _rescale_qual_read fills through _record_subs
+ * (rescale.py:82-143) and _print_subs logs (:159-192), accumulated over every mdx_rescale_host call
+ * since mdx_rescale_set_model.  words (uint64), npos = 1 + len5p + len3p:
+ *   [0, 4)                  subs["A"], ["C"], ["G"], ["T"]: reference bases of the rescaled reads' columns
+ *   [4, 4 + 4*2*94)         [transition 0=CT,1=TC,2=GA,3=AG][0=before,1=after][Phred]: subs["CT-before"] ...
+ *   [756, 756 + 2*npos*94)  [0=C>T,1=G>A][position key][old Phred]: occurrences of each rescaled column kind,
+ *                           from which the host sums the "-pvals" terms (each is a function of that triple)
+ * mdx_rescale_summary_words returns the number of words (0 before a model is set). */
+int64_t mdx_rescale_summary_words(const mdx_ctx *ctx);
+int mdx_rescale_summary(mdx_ctx *ctx, uint64_t *words);
 
 /* Native BAM decoding (host side, no GPU involved).  Replaces opening and iterating a
  * pysam.AlignmentFile (mapdamage/reader.py:38, 83-96; pysam is not needed): the BGZF blocks are

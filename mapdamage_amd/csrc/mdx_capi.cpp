@@ -58,6 +58,7 @@ struct mdx_ctx {
     // rescale model (mdx_rescale_set_model)
     uint8_t *d_lut = nullptr;
     double *d_term = nullptr;
+    unsigned long long *d_subs = nullptr;   // rescale summary counters
     int len5p = 0, len3p = 0;
     // timing
     bool timing = false;
@@ -168,7 +169,7 @@ void mdx_destroy(mdx_ctx *c) {
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &b : c->st) b.release();
     void *ptrs[] = {c->d_ref, c->d_contig_off, c->d_raw, c->d_lgd_dense, c->d_lgd_over,
-                    c->d_n_lgd_over, c->d_err, c->d_partials, c->d_lut, c->d_term};
+                    c->d_n_lgd_over, c->d_err, c->d_partials, c->d_lut, c->d_term, c->d_subs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -444,12 +445,29 @@ int mdx_rescale_set_model(mdx_ctx *c, const uint8_t *lut, const double *term, in
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_lut) { (void)hipFree(c->d_lut); c->d_lut = nullptr; }
     if (c->d_term) { (void)hipFree(c->d_term); c->d_term = nullptr; }
+    if (c->d_subs) { (void)hipFree(c->d_subs); c->d_subs = nullptr; }
     const size_t npos = (size_t)1 + len5p + len3p;
     HIP_TRY(c, hipMalloc((void **)&c->d_lut, 2 * npos * 94));
     HIP_TRY(c, hipMalloc((void **)&c->d_term, 2 * npos * 8));
     HIP_TRY(c, hipMemcpy(c->d_lut, lut, 2 * npos * 94, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_term, term, 2 * npos * 8, hipMemcpyHostToDevice));
     c->len5p = len5p; c->len3p = len3p;
+    const size_t sub_bytes = (size_t)(756 + 2 * npos * 94) * 8;
+    HIP_TRY(c, hipMalloc((void **)&c->d_subs, sub_bytes));
+    HIP_TRY(c, hipMemset(c->d_subs, 0, sub_bytes));
+    return MDX_OK;
+}
+
+int64_t mdx_rescale_summary_words(const mdx_ctx *c) {
+    return (c && c->d_subs) ? 756 + 2 * (int64_t)(1 + c->len5p + c->len3p) * 94 : 0;
+}
+
+int mdx_rescale_summary(mdx_ctx *c, uint64_t *words) {
+    if (!c || !words) return MDX_ERR_ARG;
+    if (!c->d_subs) return fail(c, MDX_ERR_STATE, "rescale_set_model first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(words, c->d_subs, (size_t)mdx_rescale_summary_words(c) * 8, hipMemcpyDeviceToHost));
     return MDX_OK;
 }
 
@@ -481,7 +499,7 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
         a.cigar_off = dv.cigar_off; a.cigar = dv.cigar; a.seq_off = dv.seq_off; a.seq = dv.seq; a.qual = dv.qual;
         a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
         a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
-        a.qual_out = d_qout; a.mr_raw = d_mr; a.status = d_status; a.err = c->d_err;
+        a.qual_out = d_qout; a.mr_raw = d_mr; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
         int64_t want = (n + 3) / 4;
         const int cap = c->n_cu * 8;
         mdx_k_rescale(a, (int)(want < cap ? want : cap), c->stream);

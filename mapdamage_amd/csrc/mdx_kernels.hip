@@ -994,6 +994,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
     const i64 gwave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
     const int npos = 1 + a.len5p + a.len3p;
+    u32 bc[4] = {0, 0, 0, 0};   // summary (rescale.py:108-143): reference bases A,C,G,T in read orientation, per lane
     for (i64 ri = gwave; ri < a.n_reads; ri += nwaves) {
         const u32 fl = a.flag[ri];
         const u32 so = a.seq_off[ri];
@@ -1068,6 +1069,30 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
 
         const i8 *__restrict__ rp = (const i8 *)a.ref + rbase;
         const u8 *__restrict__ sp = a.seq + so + qs;
+        // reference byte under gapped-reference column jr (-1: an insertion gap)
+        auto ref_at = [&](const int jr) -> int {
+            int c2 = 0, shift = 0, rix = -2;
+            for (int k = 0; k < cn && rix == -2; k++) {
+                const u32 c = op_at(k);
+                const int op = c & 0xF, len = (int)(c >> 4);
+                if (op == 1) {
+                    if (jr < c2) rix = jr - shift;
+                    else if (jr < c2 + len) rix = -1;
+                    shift += len; c2 += len;
+                } else if (op == 0 || op == 7 || op == 8 || op == 2) c2 += len;
+            }
+            if (rix == -2) rix = jr - shift;
+            return rix < 0 ? -1 : (int)rp[rix];
+        };
+        // subs[nt_ref] += 1 (rescale.py:142-143): valid reference bytes are 'A','C','G','T'
+        auto count_ref = [&](const int rch) {
+            if (rch >= 0) {
+                const int k = (rch >> 1) & 3;       // A,C,T,G
+                int b = k ^ (k >> 1);               // A,C,G,T
+                if (rev) b = 3 - b;                 // complemented on the reverse strand
+                bc[0] += b == 0; bc[1] += b == 1; bc[2] += b == 2; bc[3] += b == 3;
+            }
+        };
         double mr = 0.0;
         for (int base = 0; base < nq; base += 64) {
             const int oq = base + lane;                 // query base in read orientation (0 = 5' end)
@@ -1085,19 +1110,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                         col += len; qoff += len;
                     } else if (op == 2) col += len;
                 }
-                const int jr = rev ? nrg - ncols + js : js;
-                int c2 = 0, shift = 0, rix = -2;
-                for (int k = 0; k < cn && rix == -2; k++) {
-                    const u32 c = op_at(k);
-                    const int op = c & 0xF, len = (int)(c >> 4);
-                    if (op == 1) {
-                        if (jr < c2) rix = jr - shift;
-                        else if (jr < c2 + len) rix = -1;
-                        shift += len; c2 += len;
-                    } else if (op == 0 || op == 7 || op == 8 || op == 2) c2 += len;
-                }
-                if (rix == -2) rix = jr - shift;
-                const int rch = rix < 0 ? -1 : (int)rp[rix];
+                const int rch = ref_at(rev ? nrg - ncols + js : js);
                 const u32 ch = sp[qi];
                 const u32 q = qin[qs + qi];
                 // read-orientation pair (T,C) -> C>T ; (A,G) -> G>A; complemented on the reverse strand
@@ -1105,16 +1118,33 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                 if (!rev) { if (ch == 'T' && rch == 'C') sub = 0; else if (ch == 'A' && rch == 'G') sub = 1; }
                 else { if (ch == 'A' && rch == 'G') sub = 0; else if (ch == 'T' && rch == 'C') sub = 1; }
                 u32 newq = q;
+                int skey = 0;
                 if (sub >= 0) {
                     // _corr_this_base, rescale.py:49-79
                     int p = oq + 1;
                     const int back = p - nq - 1;
                     if (!forward_only && p >= -back) p = back;
                     const int key = p > 0 ? (p <= a.len5p ? p : 0) : (-p <= a.len3p ? a.len5p - p : 0);
+                    skey = key;
                     term = a.term[sub * npos + key];
                     if (q <= 93) newq = a.lut[(sub * npos + key) * 94 + q];
                 }
                 qout[qs + qi] = (u8)newq;
+                if (a.subs) {
+                    // _record_subs (rescale.py:108-143): transitions by old/new quality, reference bases
+                    count_ref(rch);
+                    int st = sub == 0 ? 0 : (sub == 1 ? 2 : -1);   // 0 CT, 1 TC, 2 GA, 3 AG
+                    if (st < 0) {
+                        const bool cg = rev ? (ch == 'G' && rch == 'A') : (ch == 'C' && rch == 'T');
+                        const bool ga = rev ? (ch == 'C' && rch == 'T') : (ch == 'G' && rch == 'A');
+                        st = cg ? 1 : (ga ? 3 : -1);
+                    }
+                    if (st >= 0 && q <= 93) {
+                        atomicAdd(&a.subs[4 + (st * 2 + 0) * 94 + q], 1ull);
+                        atomicAdd(&a.subs[4 + (st * 2 + 1) * 94 + newq], 1ull);
+                        if (sub >= 0) atomicAdd(&a.subs[756 + (sub * npos + skey) * 94 + q], 1ull);
+                    }
+                }
             }
             // ordered fp64 accumulation of the non-zero terms (x + 0.0 == x exactly)
             u64 nz = __ballot(term != 0.0);
@@ -1126,6 +1156,28 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
             }
         }
         if (lane == 0) a.mr_raw[ri] = mr;
+        if (a.subs) {
+            // deletion columns pair '-' with a reference base (counted while read bases remain in the
+            // iteration order: `if pos_on_read < length_read`, rescale.py:252)
+            int col = 0, qoff = 0;
+            for (int k = 0; k < cn; k++) {
+                const u32 c = op_at(k);
+                const int op = c & 0xF, len = (int)(c >> 4);
+                if (op == 0 || op == 7 || op == 8 || op == 1) { col += len; qoff += len; }
+                else if (op == 2) {
+                    if (rev ? qoff > 0 : qoff < nq)
+                        for (int t = lane; t < len; t += 64) count_ref(ref_at(rev ? nrg - ncols + col + t : col + t));
+                    col += len;
+                }
+            }
+        }
+    }
+    if (a.subs) {
+        for (int b = 0; b < 4; b++) {
+            u32 v = bc[b];
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && v) atomicAdd(&a.subs[b], (u64)v);
+        }
     }
 }
 

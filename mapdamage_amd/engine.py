@@ -24,6 +24,7 @@ EXPORTS = (
     "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_table_words",
     "mdx_finish_device", "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
     "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
+    "mdx_rescale_summary_words", "mdx_rescale_summary",
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
 )
@@ -82,8 +83,11 @@ def load_library(path=None):
     for name in ("mdx_set_stream", "mdx_set_reference", "mdx_batch_upload", "mdx_batch_free",
                  "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_finish_device",
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
-                 "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host"):
+                 "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
+                 "mdx_rescale_summary"):
         getattr(lib, name).restype = ctypes.c_int
+    lib.mdx_rescale_summary_words.restype = ctypes.c_int64
+    lib.mdx_rescale_summary_words.argtypes = [ctypes.c_void_p]
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
         getattr(lib, name).restype = ctypes.c_char_p
     lib.mdx_bam_qnames.restype = ctypes.c_void_p
@@ -297,6 +301,14 @@ class DamageEngine:
             raise BadReadError(-1, self._lib.mdx_last_error(self._ctx).decode())
         self._check(rc)
         return qual_out, mr, status
+
+    def rescale_summary(self):
+        """Integer content of the reference's ``subs`` dictionary (rescale.py:82-143) accumulated since
+        set_rescale_model; mapdamage_amd.rescale.RescaleSummary turns it into the log lines."""
+        n = int(self._lib.mdx_rescale_summary_words(self._ctx))
+        words = np.zeros(n, np.uint64)
+        self._check(self._lib.mdx_rescale_summary(self._ctx, _ptr(words)))
+        return words
 
     def reset(self):
         self._check(self._lib.mdx_reset(self._ctx))

@@ -129,7 +129,7 @@ def rescale_qual(options):
         names = read_bam(options.filename).header.references
         ref = reference_for_bam(options.ref, names)
         with DamageEngine([("*", "*")], options.length, options.around, 0, device=options.device) as engine:
-            counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model)
+            summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model)
     except RescaleError as error:
         logger.error("%s", error)
         return 1
@@ -139,6 +139,8 @@ def rescale_qual(options):
                        counts["inward_pairs"] + counts["improper_pairs"], counts["improper_pairs"])
     if counts["without_qualities"]:
         logger.warning("Skipped %i reads without quality scores", counts["without_qualities"])
+    for line in summary.log_lines():                                     # rescale.py:361-362
+        logger.info("%s", line)
     logger.debug("Rescaling completed in %f seconds", time.time() - start)
     return 0
 

@@ -58,6 +58,7 @@ class RescaleModel:
 
     def __init__(self, corr_prob, rescale_length_5p, rescale_length_3p):
         self.len5p, self.len3p = int(rescale_length_5p), int(rescale_length_3p)
+        self.corr_prob = dict(corr_prob)
         self.npos = 1 + self.len5p + self.len3p
         self.lut = np.zeros((2, self.npos, 94), np.uint8)
         self.term = np.zeros((2, self.npos), np.float64)
@@ -76,6 +77,64 @@ class RescaleModel:
     def from_csv(cls, path, rescale_length_5p, rescale_length_3p):
         return cls(get_corr_prob(path, rescale_length_5p, rescale_length_3p), rescale_length_5p,
                    rescale_length_3p)
+
+
+class RescaleSummary:
+    """The ``subs`` dictionary of the reference (rescale.py:82-105) rebuilt from the device counters
+    (include/mdx.h, mdx_rescale_summary) and its log lines (``_qual_summary_subs`` :146-157,
+    ``_print_subs`` :159-192).  The integer entries are exact.  The six ``-pvals`` sums are
+    floating-point sums that the reference accumulates read by read; every term is a function of
+    (substitution, position key, old quality), so they are summed here from the occurrence counts with
+    ``math.fsum`` — log-only values, printed with four decimals."""
+
+    SUBS = ("CT", "TC", "GA", "AG")
+
+    def __init__(self, words, model):
+        import math
+        words = np.asarray(words, dtype=np.uint64)
+        npos = model.npos
+        assert words.shape[0] == 756 + 2 * npos * 94
+        self.bases = {b: int(words[i]) for i, b in enumerate("ACGT")}
+        hist = words[4:756].reshape(4, 2, 94)
+        self.before = {s: [int(v) for v in hist[i, 0]] for i, s in enumerate(self.SUBS)}
+        self.after = {s: [int(v) for v in hist[i, 1]] for i, s in enumerate(self.SUBS)}
+        keyhist = words[756:].reshape(2, npos, 94)
+        pseq = [1 - _phred_raw_to_pval(q) for q in range(94)]           # rescale.py:240 / :113
+        self.pvals = {}
+        for si, s in enumerate(("CT", "GA")):
+            terms = []
+            for k in range(npos):
+                position = k if k <= model.len5p else -(k - model.len5p)
+                corr = model.corr_prob.get(("C" if si == 0 else "G", "T" if si == 0 else "A", position), 0) if k else 0
+                pdam = 1 - corr                                          # rescale.py:232-239, the exact expression
+                for q in range(94):
+                    c = int(keyhist[si, k, q])
+                    if c:
+                        terms.append(c * (pdam * pseq[q]))               # prob_corr = newp (rescale.py:241, :251)
+            self.pvals[s + "-pvals"] = math.fsum(terms)
+            self.pvals[s + "-pvals_before"] = math.fsum(c * pseq[q] for q, c in enumerate(self.before[s]) if c)
+        for s in ("TC", "AG"):
+            self.pvals[s + "-pvals"] = math.fsum(c * pseq[q] for q, c in enumerate(self.before[s]) if c)
+
+    def quality_level(self, table, sub, level):
+        return sum(table[sub][level:])                                   # rescale.py:146-157
+
+    def log_lines(self):
+        lines = ["Expected substition frequencies before and after rescaling:"]
+        for sub in self.SUBS:
+            base_count = self.bases[sub[0]]
+            if base_count:
+                pvals = self.pvals[sub + "-pvals"]
+                before = self.pvals.get(sub + "-pvals_before", pvals)
+                lines.append("    %s>%s    %.4f    %.4f" % (sub[0], sub[1], before / base_count, pvals / base_count))
+            else:
+                lines.append("\t%s\tNA\t\tNA" % (sub,))
+        lines.append("Quality metrics before and after scaling:")
+        for sub in ("CT", "GA"):
+            for level in (0, 10, 20, 30, 40):
+                lines.append("    %s-Q%02i% 10i% 10i" % (sub, level, self.quality_level(self.before, sub, level),
+                                                      self.quality_level(self.after, sub, level)))
+        return lines
 
 
 def finalize_mr(raw_sum):
@@ -108,6 +167,7 @@ def rescale_bam(engine, ref, in_path, out_path, model):
                     + b"MRf" + struct.pack("<f", finalize_mr(mr_raw[i])))
         out.append(body)
     write_bam_raw(out_path, al.raw_header, out)
-    return {name: int((status == code).sum()) for name, code in
+    summary = RescaleSummary(engine.rescale_summary(), model)
+    return summary, {name: int((status == code).sum()) for name, code in
             (("unmapped", STATUS_UNMAPPED), ("without_qualities", STATUS_NO_QUAL), ("single_end", STATUS_BOTH),
              ("inward_pairs", STATUS_FORWARD), ("improper_pairs", STATUS_IMPROPER))}

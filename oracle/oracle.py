@@ -92,3 +92,48 @@ def rescale(ref, batch, corr, len5p, len3p):
     if rc != 0:
         raise OracleError(rc, bad.value)
     return qual_out, mr, status
+
+
+def rescale_with_subs(ref, batch, corr, len5p, len3p):
+    """rescale() plus the reference's ``subs`` dictionary (rescale.py:82-143) as
+    (counts u64 [4 + 4*2*130], pvals f64 [6]): see record_subs in mdx_oracle.c."""
+    bases, offs = ref.concat()
+    lib = _lib()
+    lib.mdx_oracle_rescale_subs.restype = ctypes.c_int
+    corr = np.ascontiguousarray(corr, dtype=np.float64)
+    qual_out = np.zeros_like(batch.qual)
+    mr = np.zeros(batch.n, np.float64)
+    status = np.zeros(batch.n, np.uint8)
+    counts = np.zeros(4 + 4 * 2 * 130, np.uint64)
+    pvals = np.zeros(6, np.float64)
+    bad = ctypes.c_int64(-1)
+    rc = lib.mdx_oracle_rescale_subs(
+        _p(bases), _p(offs), ctypes.c_int32(len(ref.names)), ctypes.c_int64(batch.n), _p(batch.flag),
+        _p(batch.tid), _p(batch.pos), _p(batch.cigar_off), _p(batch.cigar), _p(batch.seq_off),
+        _p(batch.seq), _p(batch.qual), _p(batch.mtid), _p(batch.mpos), _p(corr), ctypes.c_int32(len5p),
+        ctypes.c_int32(len3p), _p(qual_out), _p(mr), _p(status), ctypes.byref(bad), _p(counts), _p(pvals))
+    if rc != 0:
+        raise OracleError(rc, bad.value)
+    return qual_out, mr, status, counts, pvals
+
+
+def subs_log_lines(counts, pvals):
+    """_qual_summary_subs + _print_subs (rescale.py:146-192) over the oracle's subs."""
+    hist = np.asarray(counts[4:]).reshape(4, 2, 130)
+    names = ("CT", "TC", "GA", "AG")
+    base = dict(zip("ACGT", (int(c) for c in counts[:4])))
+    pv = {"CT": (pvals[1], pvals[0]), "TC": (pvals[2], pvals[2]), "GA": (pvals[4], pvals[3]), "AG": (pvals[5], pvals[5])}
+    lines = ["Expected substition frequencies before and after rescaling:"]
+    for sub in names:
+        n = base[sub[0]]
+        if n:
+            lines.append("    %s>%s    %.4f    %.4f" % (sub[0], sub[1], pv[sub][0] / n, pv[sub][1] / n))
+        else:
+            lines.append("\t%s\tNA\t\tNA" % (sub,))
+    lines.append("Quality metrics before and after scaling:")
+    for sub in ("CT", "GA"):
+        i = names.index(sub)
+        for lv in (0, 10, 20, 30, 40):
+            lines.append("    %s-Q%02i% 10i% 10i" % (sub, lv, int(hist[i, 0, lv:].sum()), int(hist[i, 1, lv:].sum())))
+    return lines
+

@@ -31,6 +31,13 @@ def load(tmp_path):
     return Reference(names, seqs), batch, model, get_corr_prob(path, len5p, len3p), z["qual_out"], z["mr"]
 
 
+def golden_summary_lines():
+    """The reference's own _print_subs output (rescale.py:159-192) captured by tools/ref_harness.py."""
+    log = json.loads(bytes(np.load(GOLDEN)["log"]).decode())
+    start = log.index("Expected substition frequencies before and after rescaling:")
+    return log[start:]
+
+
 def corr_table(corr_prob, model):
     corr = np.zeros((2, model.npos))
     for (r, _s, p), v in corr_prob.items():
@@ -63,15 +70,34 @@ def test_oracle_matches_reference_golden(tmp_path):
     assert int((want_qual != batch.qual).sum()) > 100       # the fixture does rescale something
 
 
+def test_oracle_summary_matches_reference_log(tmp_path):
+    """R3: the substitution summary the reference logs after rescaling."""
+    from oracle import oracle
+    ref, batch, model, corr_prob, _, _ = load(tmp_path)
+    _, _, _, counts, pvals = oracle.rescale_with_subs(ref, batch, corr_table(corr_prob, model), model.len5p, model.len3p)
+    assert oracle.subs_log_lines(counts, pvals) == golden_summary_lines()
+    assert len(golden_summary_lines()) == 16
+
+
+def summary_ints_from_oracle(counts):
+    """Oracle counts (130 qualities) -> the device layout's first 756 words (94 qualities)."""
+    hist = counts[4:].reshape(4, 2, 130)
+    assert int(hist[:, :, 94:].sum()) == 0
+    return np.concatenate([counts[:4], hist[:, :, :94].reshape(-1)])
+
+
 @pytest.mark.gpu
 def test_hip_matches_reference_golden(tmp_path):
     from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.rescale import RescaleSummary
     ref, batch, model, corr_prob, want_qual, want_mr = load(tmp_path)
     with DamageEngine([("s", "l")]) as eng:
         eng.set_reference(ref)
         eng.set_rescale_model(model)
         qual_out, mr_raw, status = eng.rescale(batch)
+        words = eng.rescale_summary()
     check(qual_out, mr_raw, want_qual, want_mr)
+    assert RescaleSummary(words, model).log_lines() == golden_summary_lines()    # R3, against the reference's log
 
 
 @pytest.mark.gpu
@@ -87,11 +113,17 @@ def test_hip_matches_oracle_seeded(tmp_path):
     b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
     b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
     b.flag = np.where(rng.random(b.n) < 0.5, b.flag & 0xF14, b.flag).astype(np.uint16)
-    want_q, want_mr, want_st = oracle.rescale(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    want_q, want_mr, want_st, want_counts, want_pvals = oracle.rescale_with_subs(
+        ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
     with DamageEngine([("s", "l")]) as eng:
         eng.set_reference(ref)
         eng.set_rescale_model(model)
         got_q, got_mr, got_st = eng.rescale(b)
+        words = eng.rescale_summary()
+    from mapdamage_amd.rescale import RescaleSummary
+    np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))      # bit-exact integers
+    assert int(words[756:].reshape(2, -1, 94).sum()) == int(want_counts[4:4 + 130].sum() + want_counts[4 + 4 * 130:4 + 5 * 130].sum())
+    assert RescaleSummary(words, model).log_lines() == oracle.subs_log_lines(want_counts, want_pvals)
     np.testing.assert_array_equal(got_q, want_q)
     np.testing.assert_array_equal(got_st, want_st)
     assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
