@@ -58,6 +58,12 @@ CASES = [
     dict(n=30_000, seed=6, kw=dict(len_range=(30, 300), frac_softclip=0.2, frac_ins=0.1, frac_del=0.1,
                                    with_qual=True), L=150, A=30, Q=12),
     dict(n=20_000, seed=7, kw=dict(read_len=50, nlib=1), L=1, A=0, Q=0),
+    # two records per wavefront step (A + L = 112: 28 lanes per record)
+    dict(n=60_000, seed=9, kw=dict(len_range=(60, 200), frac_softclip=0.1, frac_ins=0.03, frac_del=0.03,
+                                   with_qual=True), L=100, A=12, Q=10),
+    # A + L > 248: no 8-byte-lane path, every record walks its CIGAR (tables still in the LDS)
+    dict(n=5_000, seed=10, kw=dict(len_range=(50, 400), frac_softclip=0.1, frac_ins=0.03, frac_del=0.03),
+         L=260, A=5, Q=0),
 ]
 
 
@@ -76,6 +82,47 @@ def test_hip_matches_oracle_seeded(case, mid_genome):
     got = run_engine(mid_genome, batch, libs, case["L"], case["A"], case["Q"])
     assert_tables_equal(got, want)
     assert got.misincorporation_text() == want.misincorporation_text()
+
+
+def test_hip_sorted_batch_with_gap_run(mid_genome):
+    """Coordinate-sorted batch: the reads over the genome's N-run (every byte an event) are consecutive
+    records; tiles are dealt round-robin to the wavefronts."""
+    batch = synth.make_reads(mid_genome, 150_000, 13, read_len=100)
+    batch = synth._permute_fixed(batch, np.lexsort((batch.pos, batch.tid)))
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 0)
+    got = run_engine(mid_genome, batch, libs, 70, 10, 0, resident=True)
+    assert_tables_equal(got, want)
+
+
+@pytest.mark.parametrize("phase", [1, 2, 3])
+def test_hip_unaligned_column_pointers(phase, mid_genome):
+    """SEQ / QUAL device pointers that are not dword-aligned (the kernel aligns its window loads down and
+    folds the pointer phase into the lane offsets)."""
+    import torch
+    from mapdamage_amd.engine import DamageEngine
+    batch = synth.make_reads(mid_genome, 30_000, 31, len_range=(30, 140), with_qual=True, frac_softclip=0.1,
+                             frac_ins=0.03, frac_del=0.03)
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 15)
+    with DamageEngine(libs, 70, 10, 15) as eng:
+        eng.set_reference(mid_genome)
+        dev = eng.upload(batch)
+        n = int(batch.seq.shape[0])
+        tseq = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        tqual = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        tseq[phase:phase + n] = torch.from_numpy(batch.seq).cuda()
+        tqual[phase:phase + n] = torch.from_numpy(batch.qual).cuda()
+        torch.cuda.synchronize()
+        own = (dev.dev.seq, dev.dev.qual)
+        dev.dev.seq, dev.dev.qual = tseq.data_ptr() + phase, tqual.data_ptr() + phase
+        try:
+            eng.tabulate(dev)
+            got = eng.finish()
+        finally:
+            dev.dev.seq, dev.dev.qual = own
+            dev.free()
+    assert_tables_equal(got, want)
 
 
 def test_hip_global_atomic_fallback_matches_oracle(mid_genome):
