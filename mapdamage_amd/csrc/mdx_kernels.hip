@@ -40,6 +40,9 @@ typedef long long i64;
 #ifndef MDX_WPS
 #define MDX_WPS 6                       // wavefronts per SIMD the register budget is sized for
 #endif
+#ifndef MDX_PREFIX
+#define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
+#endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
 #define STG_ENT (64 + MDX_MAX_R)        // staging entries (16 B) per wavefront: 64 records + pad
@@ -237,6 +240,7 @@ __device__ __forceinline__ u32 gather_bits(u32 v) { return (((v >> 7) & 0x010101
 #define D_SIMPLE 2
 #define D_HASQ 4
 #define D_FULL 8        // plain-match record with every task present (nq >= L, both flanks complete)
+#define D_PRE 32        // gapped record whose first / last match run is counted by the fast path
 #define D_NB_SHIFT 8    // nbefore, 8 bits
 #define D_NA_SHIFT 16   // nafter, 8 bits
 
@@ -382,6 +386,81 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
 
 
 
+    // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
+    // of a step and its record words.
+    struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, nqz; int lim; bool valid; };
+    // complete = true: every task of the record is present (static byte masks); false: byte masks per
+    // record (short records, contig edges, the plain prefixes of gapped records)
+    auto count = [&](const Stage &st, auto complete_tag) {
+        constexpr bool complete = decltype(complete_tag)::value;
+        // slots past the last record of the tile: no increments, no events
+        const bool act = lane < st.lim;
+        u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
+        u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
+        u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi, hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
+        const u32 base_b = tc_base(st.pk, c_lane4);
+        if (complete) {
+            // optimistic: count every byte as a plain match (the base class of the reference
+            // byte selects the plane of TC) ...
+            tc_bump8_all(r_lo, r_hi, base_b, act ? 1u : 0u);
+        } else {
+            // columns present on this lane's side, flank bytes present: from the record's nq and flank
+            // lengths (short / contig-edge records) or, for the plain prefixes of a gapped record, given
+            int nqL, nb, na;
+            if (st.nqz & 0x8000u) {   // plain prefixes of a gapped record: columns per side, complete flanks
+                nqL = c_side ? (int)(st.nqz >> 24) : (int)(st.nqz >> 16) & 0xFF; nb = A; na = A;
+            } else {
+                const int nq_ = (int)(st.nqz & 0x7FFFu);
+                nb = (int)(st.nqz >> 16) & 0xFF; na = (int)(st.nqz >> 24);
+                nqL = nq_ < L ? nq_ : L;
+            }
+            const int lo = c_side ? c_m8 + 8 - A - nqL : A - nb - c_m8;
+            const int hi = c_side ? c_m8 + 8 - A + na : A + nqL - c_m8;
+            const u64 dyn = act ? byte_range(lo, hi) : 0ull;
+            const u32 dyn_lo = (u32)dyn & c_vm_lo, dyn_hi = (u32)(dyn >> 32) & c_vm_hi;
+            emvm_lo = c_em_lo & dyn_lo; emvm_hi = c_em_hi & dyn_hi;
+            hivm_lo = dyn_lo & 0x80808080u; hivm_hi = dyn_hi & 0x80808080u;
+            // bytes that are not tasks of this record: a neutral matching pair in the event copy
+            s_lo = (s_lo & dyn_lo) | (0x41414141u & ~dyn_lo); s_hi = (s_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
+            r_lo = (r_lo & dyn_lo) | (0x41414141u & ~dyn_lo); r_hi = (r_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
+            tc_bump8(r_lo, r_hi, base_b, dyn_lo & 1u, (dyn_lo >> 8) & 1u, (dyn_lo >> 16) & 1u, (dyn_lo >> 24) & 1u,
+                     dyn_hi & 1u, (dyn_hi >> 8) & 1u, (dyn_hi >> 16) & 1u, (dyn_hi >> 24) & 1u);
+        }
+        // x: per byte, zero iff the byte is a plain match (read == reference, reference is
+        // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
+        u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & hivm_lo);
+        u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & hivm_hi);
+        u32 mq_lo = 0, mq_hi = 0;
+        if (MASK) {
+            // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
+            const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
+            const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
+            mq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
+            mq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
+            x_lo |= mq_lo; x_hi |= mq_hi;
+        }
+        // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
+        u32 xx = x_lo | x_hi;
+        if (complete) xx = act ? xx : 0u;   // (the partial path masks by dyn already)
+        const bool ev = xx != 0;
+        const u64 mm = __ballot(ev);
+        if (mm) {
+            const int n = __popcll(mm);
+            if (qcount + n > EVQ_CAP) drain_all();
+            if (ev) {
+                const int slot = mbcnt64(mm, qcount);
+                u32x2 es, er;
+                es.x = s_lo; es.y = s_hi; er.x = r_lo; er.y = r_hi;
+                qS[slot] = es;
+                qR[slot] = er;
+                u32 w = (st.pk & 0xBFFFFF00u) | c_lane18;
+                if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
+                qW[slot] = w;
+            }
+            qcount += n;
+        }
+    };
+
     // Tiles of 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
     // an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one); the
     // records left after the last complete round are split evenly, so every wavefront counts the same
@@ -404,6 +483,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         const u32 c_co0 = a.cigar_off[rj], c_co1 = a.cigar_off[rj + 1], c_so0 = a.seq_off[rj], c_so1 = a.seq_off[rj + 1];
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
+        int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
         u32 sq = 0, cig_o = 0;
         i64 rbase = 0;
         int lkey = -1;  // fragment-length key for the LDS histogram
@@ -422,6 +502,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // CIGAR scan: pysam query_alignment_start/_end, htslib bam_endpos, parse_cigar
             i64 qs = 0, rlen = 0, qcons = 0, tl = 0, sI = 0, sDN = 0;
             bool leading = true;
+            int lead_m = 0, cur_run = 0;   // first and current run of M/=/X columns (saturating)
+            bool lead_open = true;
             for (int k = 0; k < cig_n; k++) {
                 const u32 c = a.cigar[cig_o + k];
                 const int op = c & 0xF;
@@ -430,8 +512,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     if (op == 4) qs += len;
                     else if (op != 5) leading = false;
                 }
-                if (op == 0 || op == 7 || op == 8) { tl += len; rlen += len; qcons += len; }
-                else if (op == 1) { tl += len; sI += len; qcons += len; }
+                if (op == 0 || op == 7 || op == 8) {
+                    tl += len; rlen += len; qcons += len;
+                    const int l15 = len < 0x7FFF ? (int)len : 0x7FFF;
+                    cur_run = cur_run + l15 < 0x7FFF ? cur_run + l15 : 0x7FFF;
+                    if (lead_open) lead_m = cur_run;
+                } else if (op != 4 && op != 5) { lead_open = false; cur_run = 0; }   // I, D, N, P end a run
+                if (op == 1) { tl += len; sI += len; qcons += len; }
                 else if (op == 2) { tl += len; rlen += len; sDN += len; }
                 else if (op == 3) { rlen += len; sDN += len; }
                 else if (op == 4 && !bad) {
@@ -468,6 +555,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 kept = false;
             } else {
                 nq = (int)nq64; n0 = (int)n064; ncols = (int)tl; nI = (int)sI;
+                vlr = (lead_m < L ? lead_m : L) | ((cur_run < L ? cur_run : L) << 8);
                 sq = so + (u32)qs;
                 const int nbefore = pos < A ? (int)pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
@@ -535,9 +623,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const bool plain = kept && (w1 & D_SIMPLE) && sq >= (u32)(8 * d.nl8) &&
                                (i64)sq + nq + 8 * d.nl8 <= a.n_bases;
             const bool isF = plain && (w1 & D_FULL);
-            const u64 mF = __ballot(isF), mP = __ballot(plain && !isF);
+            // gapped records with complete flanks: the columns of their first / last match run ride the
+            // partial-plain list (and the CIGAR walk starts behind them)
+            const bool gpre = MDX_PREFIX && kept && !(w1 & D_SIMPLE) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
+                              ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && n0 - nq >= -127 && n0 - nq <= 127 &&
+                              sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
+            if (gpre) w1 |= D_PRE;
+            const u64 mF = __ballot(isF), mP = __ballot((plain && !isF) || gpre);
             nF = __popcll(mF); nP = __popcll(mP);
-            todo_g = todo_all & ~(mF | mP);
+            todo_g = todo_all & ~(mF | __ballot(plain && !isF));
             if (mF | mP) {
                 const int rev = w1 & D_REV;
                 uint4 ent;
@@ -546,7 +640,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 ent.z = (u32)nq | ((u32)(w1 >> D_NB_SHIFT) << 16);
                 ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                         ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
-                if (plain) stg[isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF)] = ent;
+                if (gpre) {
+                    ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);
+                    ent.w |= (u32)(n0 - nq) & 0xFFu;
+                }
+                if (plain || gpre) stg[isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF)] = ent;
                 // the slots past the last record of a step shadow a real record (and are masked out)
                 const int first = __ffsll((long long)(mF | mP)) - 1;
                 uint4 pad;
@@ -592,12 +690,25 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 s_na = clen - (pos + s_n0) < A ? (int)(clen - (pos + s_n0)) : A;
             }
 
+            // The columns of the first match run (from the left) and of the last one (from the right) are
+            // plain: same pairing, and the same position in the misincorporation and in the composition
+            // table, as in an ungapped record.  Such a record (D_PRE) also has an entry in the partial-plain
+            // list, which counts those columns and the flanks in the fast path; the walks below start
+            // behind them.
+            int s_vl = 0, s_vr = 0;
+            const bool pre_done = FAST && (s_w1 & D_PRE);
+            if (pre_done) {
+                const int s_vlr = rl(vlr, j);
+                s_vl = s_vlr & 0xFF; s_vr = s_vlr >> 8;
+            }
+
             // misincorporation pairs, each string indexed from its own end (main.py:210-212)
             int Lm = s_ncols < s_nrg ? s_ncols : s_nrg;
             if (Lm > L) Lm = L;
-            for (int t = lane; t < 2 * Lm; t += 64) {
-                const int side = t >= Lm;
-                const int i = side ? t - Lm : t;
+            const int nml = Lm - s_vl > 0 ? Lm - s_vl : 0, nmr = Lm - s_vr > 0 ? Lm - s_vr : 0;
+            for (int t = lane; t < nml + nmr; t += 64) {
+                const int side = t >= nml;
+                const int i = side ? s_vr + (t - nml) : s_vl + t;
                 const int js = side ? s_ncols - 1 - i : i;
                 const int jr = side ? s_nrg - 1 - i : i;
                 // walk the CIGAR: query index under gapped-read column js (-1 = deletion gap),
@@ -660,14 +771,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             }
             // read composition on the ungapped, unmasked query (statistics.py:75-83)
             const int Lq = s_nq < L ? s_nq : L;
-            for (int t = lane; t < 2 * Lq; t += 64) {
-                const int side = t >= Lq;
-                const int k0 = side ? t - Lq : t;
+            const int nql = Lq - s_vl > 0 ? Lq - s_vl : 0, nqr = Lq - s_vr > 0 ? Lq - s_vr : 0;
+            for (int t = lane; t < nql + nqr; t += 64) {
+                const int side = t >= nql;
+                const int k0 = side ? s_vr + (t - nql) : s_vl + t;
                 const int s = classify_read(sp[side ? s_nq - 1 - k0 : k0]);
                 if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + k0) * 4 + s);
             }
             // flanks (statistics.py:85-93) go to their task slots
-            for (int t = lane; t < 2 * A; t += 64) {
+            for (int t = lane; !pre_done && t < 2 * A; t += 64) {
                 const int side = t >= A;
                 const int dist = (side ? t - A : t) + 1;
                 if (dist <= (side ? s_na : s_nb)) {
@@ -684,7 +796,6 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // classification code runs once per 64 events instead of once per record.
         if (FAST) {
             const int R = d.R, G = d.G;
-            struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, nqz; int lim; bool valid; };
             // complete = true: every task of the record is present (static byte masks); false: short
             // records and contig edges (byte masks from nq / nbefore / nafter of the record)
             auto run = [&](const int e0, const int nrec, auto complete_tag) {
@@ -702,7 +813,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     st.lim = nv * G;
                     const uint4 ent = stg[e0 + k * R + c_slot];
                     const u32 t = ent.z & c_cm;
-                    const u32 ro = ent.x + c_ro + t, so = ent.y + c_so + t;
+                    u32 ro = ent.x + c_ro + t;
+                    const u32 so = ent.y + c_so + t;
+                    // gapped record (partial list only): the right windows hang off aend = pos + n0, not pos + nq
+                    if (!complete) ro += c_cm ? (u32)(int)(i8)(ent.w & 0xFFu) : 0u;
                     st.ro = ro; st.so = so;
                     st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                     st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
@@ -713,66 +827,6 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     st.pk = ent.w;
                     if (!complete) st.nqz = ent.z;
                 };
-                auto count = [&](const Stage &st) {
-                    // slots past the last record of the tile: no increments, no events
-                    const bool act = lane < st.lim;
-                    u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
-                    u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
-                    u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi, hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
-                    const u32 base_b = tc_base(st.pk, c_lane4);
-                    if (complete) {
-                        // optimistic: count every byte as a plain match (the base class of the reference
-                        // byte selects the plane of TC) ...
-                        tc_bump8_all(r_lo, r_hi, base_b, act ? 1u : 0u);
-                    } else {
-                        const int nq_ = (int)(st.nqz & 0x7FFFu), nb = (int)(st.nqz >> 16) & 0xFF, na = (int)(st.nqz >> 24);
-                        const int nqL = nq_ < L ? nq_ : L;
-                        const int lo = c_side ? c_m8 + 8 - A - nqL : A - nb - c_m8;
-                        const int hi = c_side ? c_m8 + 8 - A + na : A + nqL - c_m8;
-                        const u64 dyn = act ? byte_range(lo, hi) : 0ull;
-                        const u32 dyn_lo = (u32)dyn & c_vm_lo, dyn_hi = (u32)(dyn >> 32) & c_vm_hi;
-                        emvm_lo = c_em_lo & dyn_lo; emvm_hi = c_em_hi & dyn_hi;
-                        hivm_lo = dyn_lo & 0x80808080u; hivm_hi = dyn_hi & 0x80808080u;
-                        // bytes that are not tasks of this record: a neutral matching pair in the event copy
-                        s_lo = (s_lo & dyn_lo) | (0x41414141u & ~dyn_lo); s_hi = (s_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
-                        r_lo = (r_lo & dyn_lo) | (0x41414141u & ~dyn_lo); r_hi = (r_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
-                        tc_bump8(r_lo, r_hi, base_b, dyn_lo & 1u, (dyn_lo >> 8) & 1u, (dyn_lo >> 16) & 1u, (dyn_lo >> 24) & 1u,
-                                 dyn_hi & 1u, (dyn_hi >> 8) & 1u, (dyn_hi >> 16) & 1u, (dyn_hi >> 24) & 1u);
-                    }
-                    // x: per byte, zero iff the byte is a plain match (read == reference, reference is
-                    // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
-                    u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & hivm_lo);
-                    u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & hivm_hi);
-                    u32 mq_lo = 0, mq_hi = 0;
-                    if (MASK) {
-                        // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
-                        const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
-                        const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
-                        mq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
-                        mq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
-                        x_lo |= mq_lo; x_hi |= mq_hi;
-                    }
-                    // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
-                    u32 xx = x_lo | x_hi;
-                    if (complete) xx = act ? xx : 0u;   // (the partial path masks by dyn already)
-                    const bool ev = xx != 0;
-                    const u64 mm = __ballot(ev);
-                    if (mm) {
-                        const int n = __popcll(mm);
-                        if (qcount + n > EVQ_CAP) drain_all();
-                        if (ev) {
-                            const int slot = mbcnt64(mm, qcount);
-                            u32x2 es, er;
-                            es.x = s_lo; es.y = s_hi; er.x = r_lo; er.y = r_hi;
-                            qS[slot] = es;
-                            qR[slot] = er;
-                            u32 w = (st.pk & 0xBFFFFF00u) | c_lane18;
-                            if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
-                            qW[slot] = w;
-                        }
-                        qcount += n;
-                    }
-                };
                 // software pipeline: two steps in flight, each in its own register set (no register
                 // rotation: a copy of an in-flight destination would wait for its load).  Every point of
                 // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
@@ -781,13 +835,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 fill(st0);
                 fill(st1);
                 for (int k = 2; k < nsteps; k += 2) {
-                    count(st0);
+                    count(st0, complete_tag);
                     fill(st0);
-                    count(st1);
+                    count(st1, complete_tag);
                     fill(st1);
                 }
-                count(st0);
-                if (st1.valid) count(st1);
+                count(st0, complete_tag);
+                if (st1.valid) count(st1, complete_tag);
             };
             if (nF) run(0, nF, std::true_type{});
             if (nP) run(nF, nP, std::false_type{});
