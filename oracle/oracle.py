@@ -72,6 +72,29 @@ def tabulate(ref, batch, nlib, length, around, minqual=0, lgd_max=65536):
                 n_kept=n_kept.value)
 
 
+def tabulate_parallel(ref, batch, nlib, length, around, minqual=0, lgd_max=65536, threads=None):
+    """tabulate() over contiguous slices of the batch on `threads` host threads (ctypes releases the
+    GIL around the C call; the C function keeps no state), tables summed.  The all-cores CPU baseline of
+    bench.py; same results as tabulate()."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads or avail, 64, batch.n or 1))
+    if threads == 1:
+        return tabulate(ref, batch, nlib, length, around, minqual, lgd_max), 1
+    cuts = [batch.n * t // threads for t in range(threads + 1)]
+    parts = [batch.slice(cuts[t], cuts[t + 1]) for t in range(threads)]
+    with ThreadPoolExecutor(threads) as pool:
+        res = list(pool.map(lambda b: tabulate(ref, b, nlib, length, around, minqual, lgd_max), parts))
+    out = res[0]
+    for r in res[1:]:
+        for k in ("mis", "comp", "lgd"):
+            out[k] += r[k]
+        out["lgd_over"] = np.concatenate([out["lgd_over"], r["lgd_over"]])
+        out["n_kept"] += r["n_kept"]
+    return out, threads
+
+
 def rescale(ref, batch, corr, len5p, len3p):
     """C oracle of mapdamage/rescale.py.  corr: float64 [2][1 + len5p + len3p] (see mdx_oracle.c).
     Returns (qual_out u8[n_bases], mr_raw f64[n] (NaN = not rescaled), status u8[n])."""
