@@ -843,8 +843,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 count(st0, complete_tag);
                 if (st1.valid) count(st1, complete_tag);
             };
+#ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
             if (nF) run(0, nF, std::true_type{});
             if (nP) run(nF, nP, std::false_type{});
+#endif
         }
     }
 
