@@ -71,6 +71,9 @@ def build_parser():
     g.add_argument("--rescale-length-3p", type=int)
     g = p.add_argument_group("MI355X engine")
     g.add_argument("--device", type=int, default=0, help="HIP device ordinal")
+    g.add_argument("--freq-files", action="store_true",
+                   help="EXPERIMENTAL: also write 5pCtoT_freq.txt / 3pGtoA_freq.txt (mapDamage 2.0-2.2 outputs that "
+                        "this reference snapshot no longer produces; format unpinned)")
     g.add_argument("--batch-reads", type=int, default=4_000_000, help="records per device batch")
     return p
 
@@ -197,6 +200,9 @@ def main(argv):
         logger.debug("BAM read in %f seconds", time.time() - start_time)
 
         tables.write(options.folder)
+        if options.freq_files:
+            (options.folder / "5pCtoT_freq.txt").write_text(tables.damage_frequency_text("5p", options.readplot))
+            (options.folder / "3pGtoA_freq.txt").write_text(tables.damage_frequency_text("3p", options.readplot))
         check_table_and_warn_if_dmg_freq_is_low(options.folder)
         logger.info("Successful run")
         logger.debug("Run completed in %f seconds", time.time() - start_time)

@@ -97,6 +97,23 @@ class TableSet:
                           % (sample, library, L.STRANDS[s], L.KINDS[k], ln, cnt))
         return out.getvalue()
 
+    def damage_frequency_text(self, end, readplot):
+        """EXPERIMENTAL, parity unpinned: ``5pCtoT_freq.txt`` (end "5p") or
+        ``3pGtoA_freq.txt`` (end "3p") as mapDamage 2.0-2.2 wrote them from R; the reference snapshot
+        no longer produces these files, so the format is recalled, not checked.  Per position 1..readplot:
+        sum over libraries and strands of C>T / C at the 5' end (G>A / G at the 3' end), the aggregation of
+        ``calculate.mutation.table`` (mapdamage/r/mapDamage.r:81-92)."""
+        ei = L.ENDS.index(end)
+        num_col, den_col, name = ("C>T", "C", "5pC>T") if end == "5p" else ("G>A", "G", "3pG>A")
+        num = self.mis[:, ei, :, :, L.MIS_COLS.index(num_col)].sum(axis=(0, 1))
+        den = self.mis[:, ei, :, :, L.MIS_COLS.index(den_col)].sum(axis=(0, 1))
+        out = io.StringIO()
+        out.write("pos\t%s\n" % name)
+        for p in range(min(readplot, self.length)):
+            freq = float(num[p]) / float(den[p]) if den[p] else float("nan")
+            out.write("%d\t%s\n" % (p + 1, "NaN" if freq != freq else "%.15g" % freq))
+        return out.getvalue()
+
     def write(self, folder):
         """Write the three tables into ``folder`` (mapdamage/main.py:229-231)."""
         import pathlib

@@ -136,3 +136,22 @@ def test_native_bam_decoder_rejects_garbage(tmp_path):
     (tmp_path / "bad.bam").write_bytes(b"\x1f\x8bnot really a bam file at all")
     with pytest.raises(ValueError):
         sam.read_bam_native(tmp_path / "bad.bam")
+
+
+def test_experimental_damage_frequency_files_follow_the_reference_table():
+    """N3 (experimental, format unpinned): the numbers are the aggregation of the reference's own
+    misincorporation.txt (sum over libraries and strands of C>T / C at the 5' end, G>A / G at 3')."""
+    import csv
+    import io
+
+    from tests.util import Golden, oracle_tableset
+    g = Golden("config1_L70_A10_Q0")
+    ts = oracle_tableset(g.ref, g.batch, g.libraries, g.length, g.around, g.minqual)
+    rows = list(csv.DictReader(io.StringIO(g.txt["misincorporation.txt"]), delimiter="\t"))
+    for end, num, den, name in (("5p", "C>T", "C", "5pC>T"), ("3p", "G>A", "G", "3pG>A")):
+        lines = ts.damage_frequency_text(end, 25).splitlines()
+        assert lines[0] == "pos\t" + name and len(lines) == 26
+        for p in range(1, 26):
+            sel = [r for r in rows if r["End"] == end and int(r["Pos"]) == p]
+            n, d = sum(int(r[num]) for r in sel), sum(int(r[den]) for r in sel)
+            assert lines[p] == "%d\t%s" % (p, "%.15g" % (n / d))
