@@ -41,3 +41,18 @@ def test_golden_fixture_inventory():
         g = Golden(n)
         assert g.batch.n == g.meta["n_reads"]
         assert g.mis.shape[1:] == (2, 2, g.length, 25)
+
+
+def test_parallel_oracle_equals_serial_oracle():
+    """bench.py's all-cores CPU baseline (oracle.tabulate_parallel) sums per-slice tables."""
+    import numpy as np
+    from mapdamage_amd import synth
+    from oracle import oracle
+    ref = synth.small_genome()
+    batch = synth.make_reads(ref, 4000, 5, len_range=(20, 90), frac_softclip=0.2, frac_ins=0.1, frac_del=0.1,
+                             paired=True, nlib=2)
+    one = oracle.tabulate(ref, batch, 2, 25, 4, 0, lgd_max=512)
+    many, n = oracle.tabulate_parallel(ref, batch, 2, 25, 4, 0, lgd_max=512, threads=3)
+    assert n == 3 and many["n_kept"] == one["n_kept"]
+    for k in ("mis", "comp", "lgd"):
+        np.testing.assert_array_equal(many[k], one[k])
