@@ -294,7 +294,7 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     const int wpb = mdx_k_block_threads() / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;
     int64_t want = (ntiles + wpb - 1) / wpb;
-    if (b->n_reads > (int64_t)1 << 40) return fail(c, MDX_ERR_ARG, "batch too large");
+    if (b->n_reads >= (int64_t)1 << 30) return fail(c, MDX_ERR_ARG, "batch of 2^30 records or more; split it");
     const int grid = (int)(want < c->max_grid ? want : c->max_grid);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {

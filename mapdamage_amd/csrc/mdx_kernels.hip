@@ -279,8 +279,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves_per_block = MDX_BLOCK / 64;
-    const i64 gwave = (i64)blockIdx.x * waves_per_block + wave;
-    const i64 nwaves = (i64)gridDim.x * waves_per_block;
+    const u32 gwave = blockIdx.x * waves_per_block + wave;
+    const u32 nwaves = gridDim.x * waves_per_block;
     u64 *raw = a.raw;
 
     if (USE_LDS) {
@@ -465,19 +465,21 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     // an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one); the
     // records left after the last complete round are split evenly, so every wavefront counts the same
     // number of records to within one.
-    const i64 rounds = (a.n_reads / 64) / nwaves;
-    const i64 rem_lo = rounds * nwaves * 64, rem = a.n_reads - rem_lo;
-    const i64 t_lo = rem_lo + rem * gwave / nwaves, t_hi = rem_lo + rem * (gwave + 1) / nwaves;
-    const i64 n_it = rounds + (t_hi - t_lo + 63) / 64;
-    for (i64 it = 0; it < n_it; it++) {
-        const i64 tbase = it < rounds ? (it * nwaves + gwave) * 64 : t_lo + (it - rounds) * 64;
-        const i64 r_hi = it < rounds ? tbase + 64 : t_hi;
+    // (record indices fit 32 bits: mdx_tabulate_device rejects batches of 2^30 records and more)
+    const u32 n_rec = (u32)a.n_reads;
+    const u32 rounds = (n_rec / 64) / nwaves;
+    const u32 rem_lo = rounds * nwaves * 64, rem = n_rec - rem_lo;
+    const u32 t_lo = rem_lo + (u32)((u64)rem * gwave / nwaves), t_hi = rem_lo + (u32)((u64)rem * (gwave + 1) / nwaves);
+    const u32 n_it = rounds + (t_hi - t_lo + 63) / 64;
+    for (u32 it = 0; it < n_it; it++) {
+        const u32 tbase = it < rounds ? (it * nwaves + gwave) * 64 : t_lo + (it - rounds) * 64;
+        const u32 r_hi = it < rounds ? tbase + 64 : t_hi;
         // ------------------------------------------------------------ phase 1: lane per record
-        const i64 ri = tbase + lane;
+        const u32 ri = tbase + lane;
         const bool valid = ri < r_hi;
         // the per-record columns are requested together, before the flag is known (one memory round
         // trip for the tile instead of two)
-        const i64 rj = valid ? ri : r_hi - 1;
+        const u32 rj = valid ? ri : r_hi - 1;
         const u32 fl = valid ? (u32)a.flag[rj] : 0x4u;
         const int c_lib = a.lib[rj], c_tid = a.tid[rj], c_pos = a.pos[rj];
         const u32 c_co0 = a.cigar_off[rj], c_co1 = a.cigar_off[rj + 1], c_so0 = a.seq_off[rj], c_so1 = a.seq_off[rj + 1];
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             bad = bad || cig_n == 0 || aend > clen || nq64 != qcons || tl > 0x3FFFFFFF ||
                   n064 + sI > 0x3FFFFFFF;
             if (bad) {
-                flag_error(a.err, ri, ERR_BAD_READ);
+                flag_error(a.err, (i64)ri, ERR_BAD_READ);
                 kept = false;
             } else {
                 nq = (int)nq64; n0 = (int)n064; ncols = (int)tl; nI = (int)sI;
