@@ -40,6 +40,9 @@ typedef long long i64;
 #ifndef MDX_WPS
 #define MDX_WPS 6                       // wavefronts per SIMD the register budget is sized for
 #endif
+#ifndef PIPE_DEPTH
+#define PIPE_DEPTH 2                    // wavefront steps in flight (register sets of the load pipeline)
+#endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
 #endif
@@ -829,21 +832,23 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     st.pk = ent.w;
                     if (!complete) st.nqz = ent.z;
                 };
-                // software pipeline: two steps in flight, each in its own register set (no register
+                // software pipeline: PIPE_DEPTH steps in flight, each in its own register set (no register
                 // rotation: a copy of an in-flight destination would wait for its load).  Every point of
                 // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
-                // one fill per run goes past the last step.
-                Stage st0{}, st1{};
-                fill(st0);
-                fill(st1);
-                for (int k = 2; k < nsteps; k += 2) {
-                    count(st0, complete_tag);
-                    fill(st0);
-                    count(st1, complete_tag);
-                    fill(st1);
+                // PIPE_DEPTH - 1 fills per run go past the last step.
+                Stage st[PIPE_DEPTH];
+#pragma unroll
+                for (int dd = 0; dd < PIPE_DEPTH; dd++) fill(st[dd]);
+                for (int k = PIPE_DEPTH; k < nsteps; k += PIPE_DEPTH) {
+#pragma unroll
+                    for (int dd = 0; dd < PIPE_DEPTH; dd++) {
+                        count(st[dd], complete_tag);
+                        fill(st[dd]);
+                    }
                 }
-                count(st0, complete_tag);
-                if (st1.valid) count(st1, complete_tag);
+#pragma unroll
+                for (int dd = 0; dd < PIPE_DEPTH; dd++)
+                    if (dd == 0 || st[dd].valid) count(st[dd], complete_tag);
             };
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
             if (nF) run(0, nF, std::true_type{});
