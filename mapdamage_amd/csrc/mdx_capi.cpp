@@ -495,14 +495,21 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
     if (e == hipSuccess) e = hipMemcpyAsync(d_mpos, mpos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         MdxRescaleArgs a{};
-        a.n_reads = n; a.flag = dv.flag; a.tid = dv.tid; a.pos = dv.pos; a.mtid = d_mtid; a.mpos = d_mpos;
+        a.n_reads = n; a.n_bases = h->n_bases; a.flag = dv.flag; a.tid = dv.tid; a.pos = dv.pos; a.mtid = d_mtid; a.mpos = d_mpos;
         a.cigar_off = dv.cigar_off; a.cigar = dv.cigar; a.seq_off = dv.seq_off; a.seq = dv.seq; a.qual = dv.qual;
         a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
         a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
         a.qual_out = d_qout; a.mr_raw = d_mr; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
         int64_t want = (n + 3) / 4;
         const int cap = c->n_cu * 8;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, c->stream);
         mdx_k_rescale(a, (int)(want < cap ? want : cap), c->stream);
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, c->stream);
+            c->events.emplace_back(e0, e1);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

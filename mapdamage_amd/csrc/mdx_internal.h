@@ -135,6 +135,7 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
 
 struct MdxRescaleArgs {
     int64_t n_reads;
+    int64_t n_bases;         // bytes in seq / qual / qual_out
     const uint16_t *flag;
     const int32_t *tid, *pos, *mtid, *mpos;
     const uint32_t *cigar_off, *cigar, *seq_off;
@@ -145,6 +146,7 @@ struct MdxRescaleArgs {
     const uint8_t *lut;      // [2][npos][94]
     const double *term;      // [2][npos]
     int len5p, len3p;
+    int lds_tables;          // set by mdx_k_rescale: lut and term are copied to the LDS (fast path available)
     uint8_t *qual_out;
     double *mr_raw;
     uint8_t *status;

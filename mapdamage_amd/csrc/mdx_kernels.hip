@@ -1058,7 +1058,28 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
     const int npos = 1 + a.len5p + a.len3p;
     u32 bc[4] = {0, 0, 0, 0};   // summary (rescale.py:108-143): reference bases A,C,G,T in read orientation, per lane
-    for (i64 ri = gwave; ri < a.n_reads; ri += nwaves) {
+    // In the LDS when they fit (a.lds_tables): the lookup tables of the fast path and the summary histograms
+    // (global atomics on a few hot words serialise in the L2): [lut 2 npos 94 B, padded][term 2 npos f64]
+    // [counters u32: 4 x 2 x 94 transitions | 2 x npos x 94 rescaled-column kinds], flushed at block end.
+    extern __shared__ __attribute__((aligned(16))) u8 rs_lds[];
+    const int lut_bytes = (2 * npos * 94 + 15) & ~15, n_cnt = 752 + 2 * npos * 94;
+    const u8 *const l_lut = rs_lds;
+    const double *const l_term = (const double *)(rs_lds + lut_bytes);
+    u32 *const l_cnt = (u32 *)(rs_lds + lut_bytes + 2 * npos * 8);
+    if (a.lds_tables) {
+        for (int i = threadIdx.x; i < 2 * npos * 94; i += blockDim.x) rs_lds[i] = a.lut[i];
+        for (int i = threadIdx.x; i < 2 * npos; i += blockDim.x) ((double *)(rs_lds + lut_bytes))[i] = a.term[i];
+        for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) l_cnt[i] = 0;
+        __syncthreads();
+    }
+    // summary word `idx` (>= 4) of include/mdx.h += 1
+    auto sub_bump = [&](const int idx) {
+        if (a.lds_tables) atomicAdd(&l_cnt[idx - 4], 1u);
+        else atomicAdd(&a.subs[idx], 1ull);
+    };
+
+    // ---- one record by the whole wavefront, any CIGAR: one lane per query base, CIGAR walked per base
+    auto generic = [&](const i64 ri) {
         const u32 fl = a.flag[ri];
         const u32 so = a.seq_off[ri];
         const int lseq = (int)(a.seq_off[ri + 1] - so);
@@ -1080,7 +1101,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
         if (lane == 0) { a.status[ri] = (u8)st; a.mr_raw[ri] = __builtin_nan(""); }
         if (st < 2 || st == 4) {
             for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
-            continue;
+            return;
         }
         // CIGAR: one op per lane; scan by lane 0's view via readlane
         const u32 op_lane = lane < cn ? a.cigar[co + lane] : 0u;
@@ -1099,7 +1120,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
         for (int k = cn - 1; k >= 1; k--) {
             const u32 c = op_at(k);
             const int op = c & 0xF;
-            if (op == 5) continue;
+            if (op == 5) return;
             if (op == 4) clipr += (int)(c >> 4); else break;
         }
         const int nq = lseq - qs - clipr > 0 ? lseq - qs - clipr : 0;
@@ -1124,7 +1145,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
         if (bad) {
             if (lane == 0) flag_error(a.err, ri, ERR_BAD_READ);
             for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
-            continue;
+            return;
         }
         // soft-clipped qualities are kept
         for (int b = lane; b < qs; b += 64) qout[b] = qin[b];
@@ -1203,9 +1224,9 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                         st = cg ? 1 : (ga ? 3 : -1);
                     }
                     if (st >= 0 && q <= 93) {
-                        atomicAdd(&a.subs[4 + (st * 2 + 0) * 94 + q], 1ull);
-                        atomicAdd(&a.subs[4 + (st * 2 + 1) * 94 + newq], 1ull);
-                        if (sub >= 0) atomicAdd(&a.subs[756 + (sub * npos + skey) * 94 + q], 1ull);
+                        sub_bump(4 + (st * 2 + 0) * 94 + q);
+                        sub_bump(4 + (st * 2 + 1) * 94 + newq);
+                        if (sub >= 0) sub_bump(756 + (sub * npos + skey) * 94 + q);
                     }
                 }
             }
@@ -1234,6 +1255,192 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                 }
             }
         }
+    };
+
+    // ---- tiles of 64 records.  Phase 1, lane per record: routing (rescale.py:300-342) and the records
+    // the fast path can take: unchanged ones (copied) and rescaled ones whose CIGAR is [S] M [S].
+    // Phase 2: a fast record by the whole wavefront, eight bytes per lane; only lanes holding a mismatch
+    // run the per-byte code.
+    const bool fast_ok = a.lds_tables != 0;   // 2 npos < 255 (term ids fit a byte) and the tables fit the LDS
+    const i64 ntiles = (a.n_reads + 63) / 64;
+    for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
+        const i64 ri = tile * 64 + lane;
+        const bool valid = ri < a.n_reads;
+        u32 so = 0;
+        int lseq = 0, qs = 0, nq = 0, st = 0, fwd_only = 0, rev = 0;
+        i64 rbase = 0;
+        bool fast = false;
+        if (valid) {
+            const u32 fl = a.flag[ri];
+            so = a.seq_off[ri];
+            lseq = (int)(a.seq_off[ri + 1] - so);
+            const u32 co = a.cigar_off[ri];
+            const int cn = (int)(a.cigar_off[ri + 1] - co);
+            rev = (fl >> 4) & 1;
+            const int mate_rev = (fl >> 5) & 1;
+            if (fl & 0x4) st = 0;
+            else if (lseq == 0 || a.qual[so] == 0xFF) st = 1;
+            else if (fl & 0x1) {
+                const int pos = a.pos[ri], mp = a.mpos[ri];
+                const bool same = a.tid[ri] == a.mtid[ri];
+                if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; fwd_only = 1; }
+                else st = 4;
+            } else st = 2;
+            const bool room = (i64)so + lseq + 8 <= a.n_bases;   // the 8-byte loads stay inside the columns
+            if (st < 2 || st == 4) {
+                fast = room;                                     // copied unchanged: no aligned part
+            } else if (fast_ok && room && cn >= 1 && cn <= 3) {
+                const u32 c0 = a.cigar[co], c1 = cn > 1 ? a.cigar[co + 1] : 0u, c2 = cn > 2 ? a.cigar[co + 2] : 0u;
+                const int o0 = c0 & 0xF, o1 = c1 & 0xF, o2 = c2 & 0xF;
+                auto is_m = [](int o) { return o == 0 || o == 7 || o == 8; };
+                int clipr = 0;
+                bool ok = false;
+                if (cn == 1) { ok = is_m(o0); nq = (int)(c0 >> 4); }
+                else if (cn == 2 && o0 == 4) { ok = is_m(o1); qs = (int)(c0 >> 4); nq = (int)(c1 >> 4); }
+                else if (cn == 2) { ok = is_m(o0) && o1 == 4; nq = (int)(c0 >> 4); clipr = (int)(c1 >> 4); }
+                else { ok = o0 == 4 && is_m(o1) && o2 == 4; qs = (int)(c0 >> 4); nq = (int)(c1 >> 4); clipr = (int)(c2 >> 4); }
+                const int tid = a.tid[ri];
+                const i64 pos = a.pos[ri];
+                ok = ok && nq >= 1 && qs + nq + clipr == lseq && tid >= 0 && tid < a.n_contig && pos >= 0;
+                if (ok) {
+                    const i64 c0o = a.contig_off[tid];
+                    ok = pos + nq <= a.contig_off[tid + 1] - c0o;
+                    rbase = c0o + pos;
+                }
+                fast = ok;
+                if (!ok) { qs = 0; nq = 0; }
+            }
+            if (fast) {
+                a.status[ri] = (u8)st;
+                if (st < 2 || st == 4) { a.mr_raw[ri] = __builtin_nan(""); qs = 0; nq = 0; }
+            }
+        }
+        u64 m_fast = __ballot(fast);
+        u64 m_gen = __ballot(valid && !fast);
+        const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
+        const int slot = lane >> 4, sl = lane & 15;
+        while (m_fast) {
+            // up to four fast records per step, one per 16-lane slot (128 record bytes per pass)
+            int jj[4], nrec = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (m_fast) { jj[q] = __ffsll((long long)m_fast) - 1; m_fast &= m_fast - 1; nrec++; }
+                else jj[q] = jj[0];
+            }
+            const int jsel = slot == 0 ? jj[0] : (slot == 1 ? jj[1] : (slot == 2 ? jj[2] : jj[3]));
+            const bool sact = slot < nrec;
+            const int bp = jsel << 2;
+            const u32 s_so = (u32)__builtin_amdgcn_ds_bpermute(bp, (int)so);
+            // (every lane takes part in the exchange: a lane outside the exec mask would be read as 0)
+            const int x_lseq = __builtin_amdgcn_ds_bpermute(bp, lseq);
+            const int s_lseq = sact ? x_lseq : 0;
+            const int s_qs = __builtin_amdgcn_ds_bpermute(bp, qs), s_nq = __builtin_amdgcn_ds_bpermute(bp, nq);
+            const int s_rev = __builtin_amdgcn_ds_bpermute(bp, rev), s_fwd = __builtin_amdgcn_ds_bpermute(bp, fwd_only);
+            const i64 s_rbase = ((i64)__builtin_amdgcn_ds_bpermute(bp, rb_hi) << 32) | (u32)__builtin_amdgcn_ds_bpermute(bp, rb_lo);
+            const u8 *__restrict__ qin = a.qual + s_so;
+            u8 *__restrict__ qout = a.qual_out + s_so;
+            const u8 *__restrict__ sp = a.seq + s_so;
+            const u8 *__restrict__ rp = a.ref + s_rbase - s_qs;     // reference byte under record byte b
+            const int npass = (s_lseq + 127) >> 7;
+            int maxpass = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int v = rl(npass, 16 * q); maxpass = v > maxpass ? v : maxpass; }
+            double mr_s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int pass = 0; pass < maxpass; pass++) {
+                // a reverse-strand record is walked from its last pass to its first: MR is summed in read order
+                const int off = ((s_rev ? npass - 1 - pass : pass) << 7) + 8 * sl;
+                const int nb = pass < npass ? s_lseq - off : 0;       // record bytes from this lane's first byte on
+                u32x2 q8 = {0u, 0u};
+                u64 ids = 0;                                          // per byte: 1 + sub * npos + key of a rescaled column
+                if (nb > 0) {
+                    q8 = *(const u32x2_u *)(qin + off);
+                    const u64 am = byte_range(s_qs - off, s_qs + s_nq - off);    // bytes of the aligned part
+                    if (am) {
+                        const u32x2 s8 = *(const u32x2_u *)(sp + off), r8 = *(const u32x2_u *)(rp + off);
+                        const u64 s64 = (u64)s8.x | ((u64)s8.y << 32), r64 = (u64)r8.x | ((u64)r8.y << 32);
+                        if (a.subs) {
+                            // subs[nt_ref] += 1 for every column (rescale.py:142-143): classes of the valid bytes
+                            const u64 ok7 = ~r64 & 0x8080808080808080ull & am;   // bit 7 clear: A,C,G,T
+                            const u64 b1 = (r64 << 6) & ok7, b2 = (r64 << 5) & ok7;      // bit 1, bit 2 of the byte
+                            const int nA = __popcll(ok7 & ~b1 & ~b2), nC = __popcll(b1 & ~b2), nT = __popcll(~b1 & b2), nG = __popcll(b1 & b2);
+                            if (s_rev) { bc[0] += nT; bc[1] += nG; bc[2] += nC; bc[3] += nA; }
+                            else { bc[0] += nA; bc[1] += nC; bc[2] += nG; bc[3] += nT; }
+                        }
+                        u64 x = (s64 ^ r64) & am;                     // mismatching columns: candidates
+                        u64 q64 = (u64)q8.x | ((u64)q8.y << 32);
+                        while (x) {
+                            const int i = (__ffsll((long long)x) - 1) >> 3, sh = 8 * i;
+                            x &= ~(0xFFull << sh);
+                            const u32 ch = (u32)(s64 >> sh) & 0xFFu, q = (u32)(q64 >> sh) & 0xFFu;
+                            const int rch = (int)(i8)(u8)(r64 >> sh);
+                            const int qi = off + i - s_qs;
+                            const int oq = s_rev ? s_nq - 1 - qi : qi;   // position in read orientation
+                            int sub = -1;
+                            if (!s_rev) { if (ch == 'T' && rch == 'C') sub = 0; else if (ch == 'A' && rch == 'G') sub = 1; }
+                            else { if (ch == 'A' && rch == 'G') sub = 0; else if (ch == 'T' && rch == 'C') sub = 1; }
+                            u32 newq = q;
+                            int key = 0;
+                            if (sub >= 0) {
+                                int pp = oq + 1;                         // _corr_this_base, rescale.py:49-79
+                                const int back = pp - s_nq - 1;
+                                if (!s_fwd && pp >= -back) pp = back;
+                                key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
+                                if (q <= 93) newq = l_lut[(sub * npos + key) * 94 + q];
+                                ids |= (u64)(1 + sub * npos + key) << sh;
+                                q64 = (q64 & ~(0xFFull << sh)) | ((u64)newq << sh);
+                            }
+                            if (a.subs) {
+                                int t4 = sub == 0 ? 0 : (sub == 1 ? 2 : -1);   // 0 CT, 1 TC, 2 GA, 3 AG
+                                if (t4 < 0) {
+                                    const bool cg = s_rev ? (ch == 'G' && rch == 'A') : (ch == 'C' && rch == 'T');
+                                    const bool ga = s_rev ? (ch == 'C' && rch == 'T') : (ch == 'G' && rch == 'A');
+                                    t4 = cg ? 1 : (ga ? 3 : -1);
+                                }
+                                if (t4 >= 0 && q <= 93) {
+                                    sub_bump(4 + (t4 * 2 + 0) * 94 + q);
+                                    sub_bump(4 + (t4 * 2 + 1) * 94 + newq);
+                                    if (sub >= 0) sub_bump(756 + (sub * npos + key) * 94 + q);
+                                }
+                            }
+                        }
+                        q8.x = (u32)q64; q8.y = (u32)(q64 >> 32);
+                    }
+                    if (nb >= 8) *(u32x2_u *)(qout + off) = q8;
+                    else for (int i = 0; i < nb; i++) qout[off + i] = (u8)(((i < 4 ? q8.x : q8.y) >> (8 * (i & 3))) & 0xFFu);
+                }
+                // MR: the terms of the rescaled columns, added in the reference's order (read 5' -> 3'), per slot
+                const u64 has_all = __ballot(ids != 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u64 has = has_all & (0xFFFFull << (16 * q));
+                    if (!has) continue;
+                    const int qrev = rl(s_rev, 16 * q);
+                    double acc = mr_s[q];
+                    while (has) {
+                        const int l = qrev ? 63 - __builtin_clzll(has) : __ffsll((long long)has) - 1;
+                        has &= ~(1ull << l);
+                        const u64 w = ((u64)(u32)rl((int)(ids >> 32), l) << 32) | (u32)rl((int)ids, l);
+                        for (int k = 0; k < 8; k++) {
+                            const int id = (int)(w >> (8 * (qrev ? 7 - k : k))) & 0xFF;
+                            if (id) acc += l_term[id - 1];
+                        }
+                    }
+                    mr_s[q] = acc;
+                }
+            }
+            if (sact && sl == 0 && s_nq > 0)
+                a.mr_raw[tile * 64 + jsel] = slot == 0 ? mr_s[0] : (slot == 1 ? mr_s[1] : (slot == 2 ? mr_s[2] : mr_s[3]));
+        }
+        while (m_gen) {
+            const int j = __ffsll((long long)m_gen) - 1;
+            m_gen &= m_gen - 1;
+            generic(tile * 64 + j);
+        }
+    }
+    if (a.subs && a.lds_tables) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_cnt; i += blockDim.x)
+            if (l_cnt[i]) atomicAdd(&a.subs[4 + i], (u64)l_cnt[i]);
     }
     if (a.subs) {
         for (int b = 0; b < 4; b++) {
@@ -1244,7 +1451,14 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
     }
 }
 
-void mdx_k_rescale(const MdxRescaleArgs &a, int grid, hipStream_t s) {
-    if (a.n_reads <= 0) return;
-    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(256), 0, s, a);
+void mdx_k_rescale(const MdxRescaleArgs &a0, int grid, hipStream_t s) {
+    if (a0.n_reads <= 0) return;
+    MdxRescaleArgs a = a0;
+    const int npos = 1 + a.len5p + a.len3p;
+    const size_t need = (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 + (size_t)(752 + 2 * npos * 94) * 4;
+    a.lds_tables = (2 * npos < 255 && need <= 60 * 1024) ? 1 : 0;
+    const size_t lds = a.lds_tables ? need : 0;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(256), lds, s, a);
 }
