@@ -500,12 +500,10 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
         a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
         a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
         a.qual_out = d_qout; a.mr_raw = d_mr; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
-        int64_t want = (n + 3) / 4;
-        const int cap = c->n_cu * 8;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, c->stream);
-        mdx_k_rescale(a, (int)(want < cap ? want : cap), c->stream);
+        mdx_k_rescale(a, c->n_cu, c->stream);
         if (e0 && e1) {
             (void)hipEventRecord(e1, c->stream);
             c->events.emplace_back(e0, e1);

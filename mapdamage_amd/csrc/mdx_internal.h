@@ -154,4 +154,4 @@ struct MdxRescaleArgs {
     unsigned long long *subs;   // summary counters (rescale.py:108-192), may be null:
                                 // [4 reference bases | 4 transitions x before/after x 94 | 2 x npos x 94]
 };
-void mdx_k_rescale(const MdxRescaleArgs &a, int grid, hipStream_t s);
+void mdx_k_rescale(const MdxRescaleArgs &a, int n_cu, hipStream_t s);

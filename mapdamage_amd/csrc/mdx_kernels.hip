@@ -1271,18 +1271,24 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
         i64 rbase = 0;
         bool fast = false;
         if (valid) {
+            // first round trip: the record's columns; second: what they point at
             const u32 fl = a.flag[ri];
             so = a.seq_off[ri];
             lseq = (int)(a.seq_off[ri + 1] - so);
             const u32 co = a.cigar_off[ri];
             const int cn = (int)(a.cigar_off[ri + 1] - co);
+            const int c_tid = a.tid[ri], c_pos = a.pos[ri], c_mtid = a.mtid[ri], c_mpos = a.mpos[ri];
+            const u32 q_first = lseq > 0 ? (u32)a.qual[so] : 0xFFu;
+            const u32 c0 = cn > 0 ? a.cigar[co] : 0u, c1 = cn > 1 ? a.cigar[co + 1] : 0u, c2 = cn > 2 ? a.cigar[co + 2] : 0u;
+            const bool tid_ok = c_tid >= 0 && c_tid < a.n_contig;
+            const i64 c_off0 = tid_ok ? a.contig_off[c_tid] : 0, c_off1 = tid_ok ? a.contig_off[c_tid + 1] : 0;
             rev = (fl >> 4) & 1;
             const int mate_rev = (fl >> 5) & 1;
             if (fl & 0x4) st = 0;
-            else if (lseq == 0 || a.qual[so] == 0xFF) st = 1;
+            else if (lseq == 0 || q_first == 0xFF) st = 1;
             else if (fl & 0x1) {
-                const int pos = a.pos[ri], mp = a.mpos[ri];
-                const bool same = a.tid[ri] == a.mtid[ri];
+                const int pos = c_pos, mp = c_mpos;
+                const bool same = c_tid == c_mtid;
                 if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; fwd_only = 1; }
                 else st = 4;
             } else st = 2;
@@ -1290,7 +1296,6 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
             if (st < 2 || st == 4) {
                 fast = room;                                     // copied unchanged: no aligned part
             } else if (fast_ok && room && cn >= 1 && cn <= 3) {
-                const u32 c0 = a.cigar[co], c1 = cn > 1 ? a.cigar[co + 1] : 0u, c2 = cn > 2 ? a.cigar[co + 2] : 0u;
                 const int o0 = c0 & 0xF, o1 = c1 & 0xF, o2 = c2 & 0xF;
                 auto is_m = [](int o) { return o == 0 || o == 7 || o == 8; };
                 int clipr = 0;
@@ -1299,14 +1304,9 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                 else if (cn == 2 && o0 == 4) { ok = is_m(o1); qs = (int)(c0 >> 4); nq = (int)(c1 >> 4); }
                 else if (cn == 2) { ok = is_m(o0) && o1 == 4; nq = (int)(c0 >> 4); clipr = (int)(c1 >> 4); }
                 else { ok = o0 == 4 && is_m(o1) && o2 == 4; qs = (int)(c0 >> 4); nq = (int)(c1 >> 4); clipr = (int)(c2 >> 4); }
-                const int tid = a.tid[ri];
-                const i64 pos = a.pos[ri];
-                ok = ok && nq >= 1 && qs + nq + clipr == lseq && tid >= 0 && tid < a.n_contig && pos >= 0;
-                if (ok) {
-                    const i64 c0o = a.contig_off[tid];
-                    ok = pos + nq <= a.contig_off[tid + 1] - c0o;
-                    rbase = c0o + pos;
-                }
+                const i64 pos = c_pos;
+                ok = ok && nq >= 1 && qs + nq + clipr == lseq && tid_ok && pos >= 0 && pos + nq <= c_off1 - c_off0;
+                if (ok) rbase = c_off0 + pos;
                 fast = ok;
                 if (!ok) { qs = 0; nq = 0; }
             }
@@ -1353,10 +1353,11 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                 u32x2 q8 = {0u, 0u};
                 u64 ids = 0;                                          // per byte: 1 + sub * npos + key of a rescaled column
                 if (nb > 0) {
+                    // one round trip: quality, read and reference bytes (the last two unused outside the aligned part)
                     q8 = *(const u32x2_u *)(qin + off);
+                    const u32x2 s8 = *(const u32x2_u *)(sp + off), r8 = *(const u32x2_u *)(rp + off);
                     const u64 am = byte_range(s_qs - off, s_qs + s_nq - off);    // bytes of the aligned part
                     if (am) {
-                        const u32x2 s8 = *(const u32x2_u *)(sp + off), r8 = *(const u32x2_u *)(rp + off);
                         const u64 s64 = (u64)s8.x | ((u64)s8.y << 32), r64 = (u64)r8.x | ((u64)r8.y << 32);
                         if (a.subs) {
                             // subs[nt_ref] += 1 for every column (rescale.py:142-143): classes of the valid bytes
@@ -1451,7 +1452,7 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
     }
 }
 
-void mdx_k_rescale(const MdxRescaleArgs &a0, int grid, hipStream_t s) {
+void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     if (a0.n_reads <= 0) return;
     MdxRescaleArgs a = a0;
     const int npos = 1 + a.len5p + a.len3p;
@@ -1460,5 +1461,9 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int grid, hipStream_t s) {
     const size_t lds = a.lds_tables ? need : 0;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // more blocks than fit at once (8 per CU): tiles with many gapped records take longer, and a block that
+    // finishes early makes room for the next one
+    const int64_t want = (a.n_reads + 255) / 256;
+    const int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
     hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(256), lds, s, a);
 }
