@@ -52,7 +52,10 @@ typedef struct {
 
 /* One batch of alignment records as SoA columns: exactly what main.py:165-217 reads from each
  * pysam.AlignedSegment.  `seq` is the full SEQ (soft clips included); `qual`
- * raw Phred (BAM convention, first byte 0xFF = absent) or NULL; `cigar` BAM-encoded len<<4|op. */
+ * raw Phred (BAM convention, first byte 0xFF = absent) or NULL; `cigar` BAM-encoded len<<4|op.
+ * Limits of one batch: fewer than 2^30 records, at most 4 GiB of bases (32-bit seq_off); larger inputs are
+ * fed as several batches (the context accumulates).  n_bases must be exact: it bounds the 8/12-byte window
+ * loads of the kernels (no byte outside [seq, seq + n_bases) is read). */
 typedef struct {
     int64_t n_reads;
     int64_t n_cigar;       /* == cigar_off[n_reads] */
