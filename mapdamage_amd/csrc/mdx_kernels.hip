@@ -464,19 +464,22 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
     };
 
-    // Tiles of 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
+    // Tiles of (up to) 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
     // an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one); the
     // records left after the last complete round are split evenly, so every wavefront counts the same
     // number of records to within one.
     // (record indices fit 32 bits: mdx_tabulate_device rejects batches of 2^30 records and more)
+    // A tile holds a multiple of R records (63 at three per step): the fast run of a tile of complete
+    // records ends on a full step.
     const u32 n_rec = (u32)a.n_reads;
-    const u32 rounds = (n_rec / 64) / nwaves;
-    const u32 rem_lo = rounds * nwaves * 64, rem = n_rec - rem_lo;
+    const u32 T = FAST ? 64u - 64u % (u32)d.R : 64u;
+    const u32 rounds = (n_rec / T) / nwaves;
+    const u32 rem_lo = rounds * nwaves * T, rem = n_rec - rem_lo;
     const u32 t_lo = rem_lo + (u32)((u64)rem * gwave / nwaves), t_hi = rem_lo + (u32)((u64)rem * (gwave + 1) / nwaves);
-    const u32 n_it = rounds + (t_hi - t_lo + 63) / 64;
+    const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
     for (u32 it = 0; it < n_it; it++) {
-        const u32 tbase = it < rounds ? (it * nwaves + gwave) * 64 : t_lo + (it - rounds) * 64;
-        const u32 r_hi = it < rounds ? tbase + 64 : t_hi;
+        const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
+        const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
         // ------------------------------------------------------------ phase 1: lane per record
         const u32 ri = tbase + lane;
         const bool valid = ri < r_hi;
