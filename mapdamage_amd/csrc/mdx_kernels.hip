@@ -41,7 +41,7 @@ typedef long long i64;
 #define MDX_WPS 6                       // wavefronts per SIMD the register budget is sized for
 #endif
 #ifndef PIPE_DEPTH
-#define PIPE_DEPTH 2                    // wavefront steps in flight (register sets of the load pipeline)
+#define PIPE_DEPTH 3                    // wavefront steps in flight (register sets of the load pipeline)
 #endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
