@@ -244,12 +244,23 @@ __device__ __forceinline__ u32 gather_bits(u32 v) { return (((v >> 7) & 0x010101
 #define D_HASQ 4
 #define D_FULL 8        // plain-match record with every task present (nq >= L, both flanks complete)
 #define D_PRE 32        // gapped record whose first / last match run is counted by the fast path
+#define D_ONE 64        // ... and the rest of it too: [H][S] M {I|D} M [S][H], nothing left for the CIGAR walk
+// staging entry word w / event word
+#define PK_ONE 0x00080000u     // entry of a D_ONE record
 #define D_NB_SHIFT 8    // nbefore, 8 bits
 #define D_NA_SHIFT 16   // nafter, 8 bits
 
 // (final column - 4) of substitution ref>read for classes A,C,T,G, 4 bits per [ref][read] entry
 #define SUB_LUT 0x0ba0803961072540ull
 //   A>: -,4,5,2   C>: 7,-,1,6   T>: 9,3,-,8   G>: 0,10,11,-   (entry index = ref * 4 + read)
+
+// MIS column of the pair (r, s), classes A,C,T,G,- with r != s, without a table load: substitutions from
+// SUB_LUT, deletions r>- = 16 + {0,2,1,3}[r], insertions ->s = 20 + {0,2,1,3}[s] (seq.py:6-30 order)
+__device__ __forceinline__ int mis_col(int r, int s) {
+    if (r < 4 && s < 4) return 4 + (int)((SUB_LUT >> (4 * (r * 4 + s))) & 15ull);
+    const int k = r < 4 ? r : s;
+    return (r < 4 ? 16 : 20) + (((k & 1) << 1) | (k >> 1));
+}
 
 // Rare path of a plain-match record column: (ch, rch) is not a plain match.  The read base goes to
 // CMP (statistics.py:75-83); a substitution/indel goes to its MIS column only — the accompanying
@@ -264,10 +275,7 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
     if (!masked && s <= SYM_GAP) {
         const int r = classify_ref(rch);
         if (r <= SYM_GAP && r != s) {  // statistics.py:26-35
-            int col;
-            if (r < 4 && s < 4) col = 4 + (int)((SUB_LUT >> (4 * (r * 4 + s))) & 15ull);
-            else col = c_col[r * 5 + s];
-            bump<USE_LDS>(lds, raw, b_mis + sp * 25 + col);
+            bump<USE_LDS>(lds, raw, b_mis + sp * 25 + mis_col(r, s));
         }
     }
 }
@@ -376,10 +384,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const int sh = 8 * jb;
                 x &= ~(0xFFull << sh);
                 const u32 rb = (u32)(r64 >> sh) & 0xFFu, sb = (u32)(s64 >> sh) & 0xFFu;
+                const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
                 bump_n<USE_LDS>(lds, raw, tcw + (int)(((rb >> 1) & 3u) << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
                 if ((em >> sh) & 1ull)
-                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, (side ? m8 + 7 - jb : m8 + jb) - A, sb,
-                                         (int)(i8)rb, MASK && ((w >> jb) & 1u));
+                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, p, sb, (int)(i8)rb, MASK && ((w >> jb) & 1u));
             }
         }
         qcount = 0;
@@ -391,10 +399,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
 
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
-    struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, nqz; int lim; bool valid; };
+    struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, nqz; int lim; bool valid, far; };
     // complete = true: every task of the record is present (static byte masks); false: byte masks per
     // record (short records, contig edges, the plain prefixes of gapped records)
-    auto count = [&](const Stage &st, auto complete_tag) {
+    auto count = [&](const Stage &st, auto complete_tag, const bool far) {
         constexpr bool complete = decltype(complete_tag)::value;
         // slots past the last record of the tile: no increments, no events
         const bool act = lane < st.lim;
@@ -407,27 +415,81 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // byte selects the plane of TC) ...
             tc_bump8_all(r_lo, r_hi, base_b, act ? 1u : 0u);
         } else {
-            // columns present on this lane's side, flank bytes present: from the record's nq and flank
-            // lengths (short / contig-edge records) or, for the plain prefixes of a gapped record, given
-            int nqL, nb, na;
-            if (st.nqz & 0x8000u) {   // plain prefixes of a gapped record: columns per side, complete flanks
-                nqL = c_side ? (int)(st.nqz >> 24) : (int)(st.nqz >> 16) & 0xFF; nb = A; na = A;
+            // the tasks of this lane's side as a column range [k0, k1) (negative = flank bytes): from the
+            // record's nq and flank lengths (short / contig-edge records) or, for a gapped record, from the
+            // lengths of its first / last match run:
+            //   near pass: flank + the columns of the run next to this end (u of them) — same pairing and same
+            //     positions as in an ungapped record; a D_ONE deletion adds the d deleted columns behind it (read
+            //     byte forced to '-');
+            //   far pass (D_ONE only): the columns behind the run.  Insertion of g bases: the reference window is
+            //     shifted by g (fill()), the g inserted columns pair with '-' (reference byte forced), and every
+            //     column keeps one position for both tables — the ordinary step.  Deletion: the window is
+            //     anchored at the read (composition position), the misincorporation position is g further on;
+            //     such bytes take direct increments of both tables instead of the optimistic one.
+            const u32 z = st.nqz;
+            const int nq_ = (int)(z & 0x7FFFu);
+            int k0, k1 = nq_ < L ? nq_ : L, f0 = 0, f1 = 0;
+            bool fs = false, fr = false, shifted = false;
+            if (z & 0x8000u) {
+                const int u = c_side ? (int)(z >> 24) : (int)(z >> 16) & 0xFF;
+                const int dd = (int)(i8)(st.pk & 0xFFu);
+                if (!far) {
+                    k0 = -A; k1 = u;
+                    if (!MASK && (st.pk & PK_ONE) && dd > 0) { fs = true; f0 = u; k1 = u + dd < L ? u + dd : L; f1 = k1; }
+                } else {
+                    k0 = u;
+                    if (dd < 0) { fr = true; f0 = u; f1 = u - dd; } else shifted = true;
+                }
             } else {
-                const int nq_ = (int)(st.nqz & 0x7FFFu);
-                nb = (int)(st.nqz >> 16) & 0xFF; na = (int)(st.nqz >> 24);
-                nqL = nq_ < L ? nq_ : L;
+                k0 = c_side ? -(int)(z >> 24) : -((int)(z >> 16) & 0xFF);
             }
-            const int lo = c_side ? c_m8 + 8 - A - nqL : A - nb - c_m8;
-            const int hi = c_side ? c_m8 + 8 - A + na : A + nqL - c_m8;
-            const u64 dyn = act ? byte_range(lo, hi) : 0ull;
+            const int jo = c_side ? c_m8 + 8 - A : A - c_m8;   // byte of column k: jo + k (left), jo - 1 - k (right)
+            const u64 dyn = act ? byte_range(c_side ? jo - k1 : jo + k0, c_side ? jo - k0 : jo + k1) : 0ull;
             const u32 dyn_lo = (u32)dyn & c_vm_lo, dyn_hi = (u32)(dyn >> 32) & c_vm_hi;
             emvm_lo = c_em_lo & dyn_lo; emvm_hi = c_em_hi & dyn_hi;
             hivm_lo = dyn_lo & 0x80808080u; hivm_hi = dyn_hi & 0x80808080u;
             // bytes that are not tasks of this record: a neutral matching pair in the event copy
             s_lo = (s_lo & dyn_lo) | (0x41414141u & ~dyn_lo); s_hi = (s_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
             r_lo = (r_lo & dyn_lo) | (0x41414141u & ~dyn_lo); r_hi = (r_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
-            tc_bump8(r_lo, r_hi, base_b, dyn_lo & 1u, (dyn_lo >> 8) & 1u, (dyn_lo >> 16) & 1u, (dyn_lo >> 24) & 1u,
-                     dyn_hi & 1u, (dyn_hi >> 8) & 1u, (dyn_hi >> 16) & 1u, (dyn_hi >> 24) & 1u);
+            u32 tcd_lo = dyn_lo, tcd_hi = dyn_hi;
+            if (!MASK) {
+                if (fs | fr) {
+                    const u64 fm = byte_range(c_side ? jo - f1 : jo + f0, c_side ? jo - f0 : jo + f1);
+                    const u32 fm_lo = (u32)fm & dyn_lo, fm_hi = (u32)(fm >> 32) & dyn_hi;
+                    if (fs) { s_lo = (s_lo & ~fm_lo) | (0x2D2D2D2Du & fm_lo); s_hi = (s_hi & ~fm_hi) | (0x2D2D2D2Du & fm_hi); }
+                    else { r_lo = (r_lo & ~fm_lo) | (0x84848484u & fm_lo); r_hi = (r_hi & ~fm_hi) | (0x84848484u & fm_hi); }
+                }
+                if (far && shifted) {
+                    // counted here, byte by byte, straight into CMP (position p) and MIS (position p + g; base
+                    // column on a match): no optimistic increment, no event
+                    const int g = (int)(st.pk & 0xFFu);
+                    const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
+                    const int b_mis = lbw + (rev * 2 + c_side) * L * 25, b_cmp = lbw + d.off_cmp() + (rev * 2 + c_side) * L * 4;
+#pragma unroll
+                    for (int jb = 0; jb < 8; jb++) {
+                        const u32 dw = jb < 4 ? dyn_lo : dyn_hi;
+                        if ((dw >> (8 * (jb & 3))) & 1u) {
+                            const u32 sb = ((jb < 4 ? s_lo : s_hi) >> (8 * (jb & 3))) & 0xFFu;
+                            const u32 rb = ((jb < 4 ? r_lo : r_hi) >> (8 * (jb & 3))) & 0xFFu;
+                            const int p = (c_side ? c_m8 + 7 - jb : c_m8 + jb) - A;
+                            if (sb == rb && rb < 0x80u) {   // plain match (a valid reference byte is one of A, C, G, T)
+                                const int k = (int)(rb >> 1) & 3;
+                                bump<USE_LDS>(lds, raw, b_cmp + p * 4 + k);
+                                if (p + g < L) bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + k);
+                            } else {
+                                const int s = classify_read(sb), r = classify_ref((int)(i8)rb);
+                                if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + p * 4 + s);
+                                if (p + g < L && s <= SYM_GAP && r <= SYM_GAP && (r != s || r != SYM_GAP))
+                                    bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + (r != s ? mis_col(r, s) : r));
+                            }
+                        }
+                    }
+                    tcd_lo = 0; tcd_hi = 0;
+                    emvm_lo = 0; emvm_hi = 0; hivm_lo = 0; hivm_hi = 0;
+                }
+            }
+            tc_bump8(r_lo, r_hi, base_b, tcd_lo & 1u, (tcd_lo >> 8) & 1u, (tcd_lo >> 16) & 1u, (tcd_lo >> 24) & 1u,
+                     tcd_hi & 1u, (tcd_hi >> 8) & 1u, (tcd_hi >> 16) & 1u, (tcd_hi >> 24) & 1u);
         }
         // x: per byte, zero iff the byte is a plain match (read == reference, reference is
         // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
@@ -456,7 +518,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 es.x = s_lo; es.y = s_hi; er.x = r_lo; er.y = r_hi;
                 qS[slot] = es;
                 qR[slot] = er;
-                u32 w = (st.pk & 0xBFFFFF00u) | c_lane18;
+                u32 w = (st.pk & 0xBF03FF00u) | c_lane18;
                 if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
                 qW[slot] = w;
             }
@@ -492,6 +554,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
+        bool one = false;   // [H][S] M {I|D} M [S][H]: one indel between two match runs
         u32 sq = 0, cig_o = 0;
         i64 rbase = 0;
         int lkey = -1;  // fragment-length key for the LDS histogram
@@ -512,6 +575,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             bool leading = true;
             int lead_m = 0, cur_run = 0;   // first and current run of M/=/X columns (saturating)
             bool lead_open = true;
+            int n_gap = 0;                 // I and D operations (N and P count as many)
             for (int k = 0; k < cig_n; k++) {
                 const u32 c = a.cigar[cig_o + k];
                 const int op = c & 0xF;
@@ -525,7 +589,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const int l15 = len < 0x7FFF ? (int)len : 0x7FFF;
                     cur_run = cur_run + l15 < 0x7FFF ? cur_run + l15 : 0x7FFF;
                     if (lead_open) lead_m = cur_run;
-                } else if (op != 4 && op != 5) { lead_open = false; cur_run = 0; }   // I, D, N, P end a run
+                } else if (op != 4 && op != 5) {   // I, D, N, P end a run
+                    lead_open = false; cur_run = 0;
+                    n_gap += op <= 2 ? 1 : 4;
+                }
                 if (op == 1) { tl += len; sI += len; qcons += len; }
                 else if (op == 2) { tl += len; rlen += len; sDN += len; }
                 else if (op == 3) { rlen += len; sDN += len; }
@@ -564,6 +631,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             } else {
                 nq = (int)nq64; n0 = (int)n064; ncols = (int)tl; nI = (int)sI;
                 vlr = (lead_m < L ? lead_m : L) | ((cur_run < L ? cur_run : L) << 8);
+                one = n_gap == 1 && lead_m > 0 && cur_run > 0;
                 sq = so + (u32)qs;
                 const int nbefore = pos < A ? (int)pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
@@ -626,7 +694,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // the per-record registers of phase 1 are dead during the fast loops).
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
-        int nF = 0, nP = 0;
+        int nF = 0, nP = 0, nS = 0;
         if (FAST) {
             const bool plain = kept && (w1 & D_SIMPLE) && sq >= (u32)(8 * d.nl8) &&
                                (i64)sq + nq + 8 * d.nl8 <= a.n_bases;
@@ -637,10 +705,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                               ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && n0 - nq >= -127 && n0 - nq <= 127 &&
                               sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
             if (gpre) w1 |= D_PRE;
-            const u64 mF = __ballot(isF), mP = __ballot((plain && !isF) || gpre);
-            nF = __popcll(mF); nP = __popcll(mP);
-            todo_g = todo_all & ~(mF | __ballot(plain && !isF));
-            if (mF | mP) {
+            // ... and those with a single indel between two match runs are counted by the fast path entirely:
+            // a second (far) pass over their entries takes the columns behind the first / last run (count())
+            const int dnq = n0 - nq;
+            const bool isS = !MASK && gpre && one && A + (dnq < 0 ? -dnq : dnq) <= 248;
+            if (isS) w1 |= D_ONE;
+            const u64 mF = __ballot(isF), mP = __ballot((plain && !isF) || (gpre && !isS)), mS = __ballot(isS);
+            nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS);
+            todo_g = todo_all & ~(mF | mS | __ballot(plain && !isF));
+            if (mF | mP | mS) {
                 const int rev = w1 & D_REV;
                 uint4 ent;
                 ent.x = (u32)(rbase - A + 256);
@@ -650,15 +723,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
                 if (gpre) {
                     ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);
-                    ent.w |= (u32)(n0 - nq) & 0xFFu;
+                    ent.w |= ((u32)dnq & 0xFFu) | (isS ? PK_ONE : 0u);
                 }
-                if (plain || gpre) stg[isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF)] = ent;
+                if (plain || gpre) stg[isF ? mbcnt64(mF, 0) : isS ? mbcnt64(mS, nF + nP) : mbcnt64(mP, nF)] = ent;
                 // the slots past the last record of a step shadow a real record (and are masked out)
-                const int first = __ffsll((long long)(mF | mP)) - 1;
+                const int first = __ffsll((long long)(mF | mP | mS)) - 1;
                 uint4 pad;
                 pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
                 pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
-                if (lane < d.R - 1) stg[nF + nP + lane] = pad;
+                if (lane < d.R - 1) stg[nF + nP + nS + lane] = pad;
             }
         }
 
@@ -773,7 +846,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 if (s <= SYM_GAP && r <= SYM_GAP) {
                     // the reference-base count of a mismatching column is derived at finalisation
                     const int row = b_mis + (side * L + i) * 25;
-                    if (r != s) bump<USE_LDS>(lds, raw, row + c_col[r * 5 + s]);
+                    if (r != s) bump<USE_LDS>(lds, raw, row + mis_col(r, s));
                     else if (r != SYM_GAP) bump<USE_LDS>(lds, raw, row + r);
                 }
             }
@@ -804,27 +877,34 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // classification code runs once per 64 events instead of once per record.
         if (FAST) {
             const int R = d.R, G = d.G;
+            // A run = the steps of nrec staged records from entry e0 on, followed (partial list only) by the far
+            // pass over nfar records from entry e1 on (the D_ONE records, listed last): one load pipeline for both.
             // complete = true: every task of the record is present (static byte masks); false: short
-            // records and contig edges (byte masks from nq / nbefore / nafter of the record)
-            auto run = [&](const int e0, const int nrec, auto complete_tag) {
+            // records and contig edges (byte masks from nq / nbefore / nafter of the record), gapped records
+            auto run = [&](const int e0, const int nrec, const int e1, const int nfar, auto complete_tag) {
                 constexpr bool complete = decltype(complete_tag)::value;
-                const int nsteps = (nrec + R - 1) / R;
+                const int nnear = (nrec + R - 1) / R;
+                const int nsteps = nnear + (complete ? 0 : (nfar + R - 1) / R);
                 int kf = 0;
                 // fill() always issues its loads (past the last step it re-reads it), so the number of
                 // loads in flight is static and the waits before count() are counted ones
                 auto fill = [&](Stage &st) {
                     st.valid = kf < nsteps;
-                    const int k = st.valid ? kf : nsteps - 1;
+                    int k = st.valid ? kf : nsteps - 1;
                     kf++;
-                    int nv = nrec - k * R;
+                    const bool far = !complete && k >= nnear;   // (see count())
+                    if (far) k -= nnear;
+                    int nv = (far ? nfar : nrec) - k * R;
                     nv = nv > R ? R : nv;
                     st.lim = nv * G;
-                    const uint4 ent = stg[e0 + k * R + c_slot];
+                    st.far = far;
+                    const uint4 ent = stg[(far ? e1 : e0) + k * R + c_slot];
                     const u32 t = ent.z & c_cm;
                     u32 ro = ent.x + c_ro + t;
                     const u32 so = ent.y + c_so + t;
-                    // gapped record (partial list only): the right windows hang off aend = pos + n0, not pos + nq
-                    if (!complete) ro += c_cm ? (u32)(int)(i8)(ent.w & 0xFFu) : 0u;
+                    // gapped record (partial list only), d = n0 - nq: the right windows hang off aend = pos + n0, not
+                    // pos + nq; in the far pass they hang off pos + nq and the left ones off pos + d
+                    if (!complete) ro += ((c_cm != 0u) != far) ? (u32)(int)(i8)(ent.w & 0xFFu) : 0u;
                     st.ro = ro; st.so = so;
                     st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                     st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
@@ -845,17 +925,17 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 for (int k = PIPE_DEPTH; k < nsteps; k += PIPE_DEPTH) {
 #pragma unroll
                     for (int dd = 0; dd < PIPE_DEPTH; dd++) {
-                        count(st[dd], complete_tag);
+                        count(st[dd], complete_tag, st[dd].far);
                         fill(st[dd]);
                     }
                 }
 #pragma unroll
                 for (int dd = 0; dd < PIPE_DEPTH; dd++)
-                    if (dd == 0 || st[dd].valid) count(st[dd], complete_tag);
+                    if (dd == 0 || st[dd].valid) count(st[dd], complete_tag, st[dd].far);
             };
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
-            if (nF) run(0, nF, std::true_type{});
-            if (nP) run(nF, nP, std::false_type{});
+            if (nF) run(0, nF, 0, 0, std::true_type{});
+            if (nP + nS) run(nF, nP + nS, nF + nP, nS, std::false_type{});
 #endif
         }
     }
