@@ -258,6 +258,7 @@ __device__ __forceinline__ u32 gather_bits(u32 v) { return (((v >> 7) & 0x010101
 // SUB_LUT, deletions r>- = 16 + {0,2,1,3}[r], insertions ->s = 20 + {0,2,1,3}[s] (seq.py:6-30 order)
 __device__ __forceinline__ int mis_col(int r, int s) {
     if (r < 4 && s < 4) return 4 + (int)((SUB_LUT >> (4 * (r * 4 + s))) & 15ull);
+    asm volatile("" ::: "memory");   // the rare case stays a branch (not if-converted into the common path)
     const int k = r < 4 ? r : s;
     return (r < 4 ? 16 : 20) + (((k & 1) << 1) | (k >> 1));
 }
@@ -465,23 +466,24 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const int g = (int)(st.pk & 0xFFu);
                     const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
                     const int b_mis = lbw + (rev * 2 + c_side) * L * 25, b_cmp = lbw + d.off_cmp() + (rev * 2 + c_side) * L * 4;
-#pragma unroll
-                    for (int jb = 0; jb < 8; jb++) {
-                        const u32 dw = jb < 4 ? dyn_lo : dyn_hi;
-                        if ((dw >> (8 * (jb & 3))) & 1u) {
-                            const u32 sb = ((jb < 4 ? s_lo : s_hi) >> (8 * (jb & 3))) & 0xFFu;
-                            const u32 rb = ((jb < 4 ? r_lo : r_hi) >> (8 * (jb & 3))) & 0xFFu;
-                            const int p = (c_side ? c_m8 + 7 - jb : c_m8 + jb) - A;
-                            if (sb == rb && rb < 0x80u) {   // plain match (a valid reference byte is one of A, C, G, T)
-                                const int k = (int)(rb >> 1) & 3;
-                                bump<USE_LDS>(lds, raw, b_cmp + p * 4 + k);
-                                if (p + g < L) bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + k);
-                            } else {
-                                const int s = classify_read(sb), r = classify_ref((int)(i8)rb);
-                                if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + p * 4 + s);
-                                if (p + g < L && s <= SYM_GAP && r <= SYM_GAP && (r != s || r != SYM_GAP))
-                                    bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + (r != s ? mis_col(r, s) : r));
-                            }
+                    const u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32);
+                    u64 todo = ((u64)dyn_lo | ((u64)dyn_hi << 32)) & 0x0101010101010101ull;
+                    // (a rolled loop: this code sits in every step of the partial run, and is rarely reached)
+#pragma unroll 1
+                    while (todo) {
+                        const int sh = __ffsll((long long)todo) - 1, jb = sh >> 3;
+                        todo &= todo - 1;
+                        const u32 sb = (u32)(s64 >> sh) & 0xFFu, rb = (u32)(r64 >> sh) & 0xFFu;
+                        const int p = (c_side ? c_m8 + 7 - jb : c_m8 + jb) - A;
+                        if (sb == rb && rb < 0x80u) {   // plain match (a valid reference byte is one of A, C, G, T)
+                            const int k = (int)(rb >> 1) & 3;
+                            bump<USE_LDS>(lds, raw, b_cmp + p * 4 + k);
+                            if (p + g < L) bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + k);
+                        } else {
+                            const int s = classify_read(sb), r = classify_ref((int)(i8)rb);
+                            if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + p * 4 + s);
+                            if (p + g < L && s <= SYM_GAP && r <= SYM_GAP && (r != s || r != SYM_GAP))
+                                bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + (r != s ? mis_col(r, s) : r));
                         }
                     }
                     tcd_lo = 0; tcd_hi = 0;
@@ -630,12 +632,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 kept = false;
             } else {
                 nq = (int)nq64; n0 = (int)n064; ncols = (int)tl; nI = (int)sI;
-                vlr = (lead_m < L ? lead_m : L) | ((cur_run < L ? cur_run : L) << 8);
-                one = n_gap == 1 && lead_m > 0 && cur_run > 0;
                 sq = so + (u32)qs;
                 const int nbefore = pos < A ? (int)pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
                 const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 32768;
+                if (!simple) {
+                    vlr = (lead_m < L ? lead_m : L) | ((cur_run < L ? cur_run : L) << 8);
+                    one = n_gap == 1 && lead_m > 0 && cur_run > 0;
+                }
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
                 if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
@@ -699,33 +703,40 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const bool plain = kept && (w1 & D_SIMPLE) && sq >= (u32)(8 * d.nl8) &&
                                (i64)sq + nq + 8 * d.nl8 <= a.n_bases;
             const bool isF = plain && (w1 & D_FULL);
-            // gapped records with complete flanks: the columns of their first / last match run ride the
-            // partial-plain list (and the CIGAR walk starts behind them)
-            const bool gpre = MDX_PREFIX && kept && !(w1 & D_SIMPLE) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
-                              ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && n0 - nq >= -127 && n0 - nq <= 127 &&
-                              sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
-            if (gpre) w1 |= D_PRE;
-            // ... and those with a single indel between two match runs are counted by the fast path entirely:
-            // a second (far) pass over their entries takes the columns behind the first / last run (count())
-            const int dnq = n0 - nq;
-            const bool isS = !MASK && gpre && one && A + (dnq < 0 ? -dnq : dnq) <= 248;
-            if (isS) w1 |= D_ONE;
-            const u64 mF = __ballot(isF), mP = __ballot((plain && !isF) || (gpre && !isS)), mS = __ballot(isS);
-            nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS);
-            todo_g = todo_all & ~(mF | mS | __ballot(plain && !isF));
-            if (mF | mP | mS) {
-                const int rev = w1 & D_REV;
-                uint4 ent;
-                ent.x = (u32)(rbase - A + 256);
-                ent.y = sq;
-                ent.z = (u32)nq | ((u32)(w1 >> D_NB_SHIFT) << 16);
-                ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
-                        ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
+            const u64 mF = __ballot(isF), mPp = __ballot(plain && !isF);
+            u64 mP = mPp, mS = 0;
+            const int rev = w1 & D_REV;
+            uint4 ent;
+            ent.x = (u32)(rbase - A + 256);
+            ent.y = sq;
+            ent.z = (u32)nq | ((u32)(w1 >> D_NB_SHIFT) << 16);
+            ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
+                    ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
+            bool gpre = false, isS = false;
+            if (MDX_PREFIX && __ballot(kept && !(w1 & D_SIMPLE))) {   // (wave-uniform: tiles of plain records skip this)
+                // gapped records with complete flanks: the columns of their first / last match run ride the
+                // partial-plain list (and the CIGAR walk starts behind them)
+                const int dnq = n0 - nq;
+                gpre = kept && !(w1 & D_SIMPLE) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
+                       ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && dnq >= -127 && dnq <= 127 &&
+                       sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
+                // ... and those with a single indel between two match runs are counted by the fast path entirely:
+                // a second (far) pass over their entries takes the columns behind the first / last run (count())
+                isS = !MASK && gpre && one && A + (dnq < 0 ? -dnq : dnq) <= 248;
                 if (gpre) {
+                    w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
                     ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);
                     ent.w |= ((u32)dnq & 0xFFu) | (isS ? PK_ONE : 0u);
                 }
-                if (plain || gpre) stg[isF ? mbcnt64(mF, 0) : isS ? mbcnt64(mS, nF + nP) : mbcnt64(mP, nF)] = ent;
+                mP |= __ballot(gpre && !isS);
+                mS = __ballot(isS);
+            }
+            nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS);
+            todo_g = todo_all & ~(mF | mPp | mS);
+            if (mF | mP | mS) {
+                int idx = isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF);
+                if (mS && isS) idx = mbcnt64(mS, nF + nP);
+                if (plain || gpre) stg[idx] = ent;
                 // the slots past the last record of a step shadow a real record (and are masked out)
                 const int first = __ffsll((long long)(mF | mP | mS)) - 1;
                 uint4 pad;
@@ -761,9 +772,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const i8 *__restrict__ rp = (const i8 *)a.ref + s_rbase;
             const u8 *__restrict__ sp = a.seq + s_sq;
             const u8 *__restrict__ qp = MASK ? a.qual + s_sq : nullptr;
-            // flank lengths (not from the packed descriptor: A may exceed 255 here)
-            int s_nb, s_na;
-            {
+            // flank lengths: from the packed descriptor (A < 248 with the fast path), else recomputed
+            int s_nb = (s_w1 >> D_NB_SHIFT) & 0xFF, s_na = (s_w1 >> D_NA_SHIFT) & 0xFF;
+            if (!FAST) {
                 const i64 pos = a.pos[tbase + j];
                 const int tid = a.tid[tbase + j];
                 const i64 clen = a.contig_off[tid + 1] - a.contig_off[tid];
