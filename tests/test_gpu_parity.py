@@ -229,3 +229,58 @@ def test_hip_matches_oracle_at_scale(config):
     np.testing.assert_array_equal(got.comp, 2 * want.comp)
     np.testing.assert_array_equal(got.lgd, 2 * want.lgd)
     assert got.n_kept == 2 * want.n_kept
+
+
+def _indel_records(ref, n, seed, max_gap=130):
+    """Records [H][S] aM g{I|D} bM [S][H] (and some with two indels / an N) with indels of 1..max_gap bases anywhere
+    in the read, 5 % substitutions and a few N bases: the shapes the single-indel fast path splits into a near and
+    a far entry, its limits (|n0 - nq| <= 127, A + |n0 - nq| <= 248) and its fallbacks (the CIGAR walk)."""
+    rng = np.random.default_rng(seed)
+    bases, offs = ref.concat()
+    upper = bases & np.uint8(0xDF)
+    lens = list(ref.lengths)
+    gaps = [1, 2, 3, 5, 8, 17, 56, 57, 100, 126, 127, 128, max_gap]
+    recs = []
+    for i in range(n):
+        tid = int(rng.integers(0, 2))
+        a, b = int(rng.integers(1, 130)), int(rng.integers(1, 130))
+        g = int(gaps[rng.integers(0, len(gaps))]) if rng.random() < 0.5 else int(rng.integers(1, 4))
+        kind = int(rng.integers(0, 10))          # 0-3 I, 4-7 D, 8 two indels, 9 indel + N
+        ops = [(0, a), (1 if kind < 4 or kind == 8 else 2, g), (0, b)]
+        if kind == 8:
+            ops += [(2, int(rng.integers(1, 4))), (0, int(rng.integers(1, 40)))]
+        if kind == 9:
+            ops += [(3, int(rng.integers(20, 300))), (0, int(rng.integers(1, 40)))]
+        span = sum(ln for op, ln in ops if op in (0, 2, 3))
+        margin = 0 if rng.random() < 0.03 else 260   # a few at the very start of a contig (incomplete flank)
+        pos = int(rng.integers(margin, lens[tid] - span - 260))
+        seq, r = [], offs[tid] + pos
+        for op, ln in ops:
+            if op == 0:
+                seq.append(upper[r:r + ln].copy()); r += ln
+            elif op == 1:
+                seq.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), ln))
+            else:
+                r += ln
+        sl, sr = (int(rng.integers(1, 9)) if rng.random() < 0.2 else 0 for _ in range(2))
+        seq = np.concatenate([rng.choice(np.frombuffer(b"ACGT", np.uint8), sl)] + seq +
+                             [rng.choice(np.frombuffer(b"ACGT", np.uint8), sr)])
+        mut = rng.random(seq.shape[0])
+        seq = np.where(mut < 0.05, rng.choice(np.frombuffer(b"ACGTN", np.uint8), seq.shape[0]), seq)
+        cig = ([(5, 3)] if rng.random() < 0.05 else []) + ([(4, sl)] if sl else []) + ops + \
+              ([(4, sr)] if sr else []) + ([(5, 2)] if rng.random() < 0.05 else [])
+        recs.append(dict(flag=int(rng.choice([0, 16])), tid=tid, pos=pos, cigar=cig, seq=seq.tobytes().decode(),
+                         qual=None, lib=int(rng.integers(0, 2)), tlen=0))
+    return recs
+
+
+@pytest.mark.parametrize("L,A", [(70, 10), (8, 3), (1, 0), (150, 30), (100, 12), (240, 8), (30, 200), (120, 128),
+                                 (250, 10)])
+def test_hip_single_indel_shapes(L, A, mid_genome):
+    """Every place and size of a single indel against the oracle, at window geometries of 1-3 records per step,
+    at the limit of the shifted windows (A + indel <= 248) and without the fast path (A + L > 248)."""
+    batch = batch_from_records(_indel_records(mid_genome, 6000, 100 + L))
+    libs = [("s", "a"), ("s", "b")]
+    want = oracle_tableset(mid_genome, batch, libs, L, A, 0)
+    got = run_engine(mid_genome, batch, libs, L, A, 0, resident=True)
+    assert_tables_equal(got, want)
