@@ -10,10 +10,25 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <utility>
+#include <memory>
 #include <vector>
+
+// vector whose resize() leaves new elements uninitialised (the decoder overwrites every one of them; a
+// value-initialising resize would touch hundreds of megabytes on one thread first)
+template <class T>
+struct no_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { typedef no_init_alloc<U> other; };
+    no_init_alloc() = default;
+    template <class U> no_init_alloc(const no_init_alloc<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+};
+typedef std::vector<uint8_t, no_init_alloc<uint8_t>> raw_bytes;
 
 struct mdx_bam {
     std::string error;
@@ -24,7 +39,7 @@ struct mdx_bam {
     std::vector<uint16_t> flag, lib;
     std::vector<int32_t> tid, pos, tlen, mtid, mpos, rg_index;
     std::vector<uint32_t> cigar_off, cigar, seq_off, qname_off;
-    std::vector<uint8_t> seq, qual;
+    raw_bytes seq, qual;
     std::string qnames;
     std::vector<std::string> rg_names;
     std::vector<uint8_t> has_mr;
@@ -124,7 +139,7 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
     std::vector<Block> blocks;
     size_t total = 0;
     if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
-    std::vector<uint8_t> data(total + 8);
+    raw_bytes data(total + 8);
     std::atomic<bool> ok{true};
     parallel_for(blocks.size(), threads, [&](size_t i) {
         const Block &k = blocks[i];
@@ -178,7 +193,10 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
     b->cigar_off = coff; b->seq_off = soff; b->qname_off = noff;
     b->cigar.resize(coff.back()); b->seq.resize((size_t)soff.back() + 64); b->qual.resize((size_t)soff.back() + 64);
     b->qnames.resize(noff.back());
-    std::vector<std::pair<const char *, uint32_t>> rg(n, {nullptr, 0});
+    // read-group ids -> small integers (header order is resolved by the caller): a thread looks its last
+    // id up first, the shared map only when the id changes
+    std::mutex rg_mu;
+    std::unordered_map<std::string, int32_t> rg_map;
     static const char DEC[17] = "=ACMGRSVTWYHKDBN";
     // pass 2 (parallel): unpack every record into the columns
     parallel_for(n, threads, [&](size_t i) {
@@ -209,7 +227,24 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
             if (ty == 'Z' || ty == 'H') {
                 const uint8_t *z = (const uint8_t *)std::memchr(p, 0, (size_t)(end - p));
                 if (!z) break;
-                if (t0 == 'R' && t1 == 'G' && ty == 'Z') rg[i] = {(const char *)p, (uint32_t)(z - p)};
+                if (t0 == 'R' && t1 == 'G' && ty == 'Z') {
+                    static thread_local const mdx_bam *owner = nullptr;
+                    static thread_local std::string last;
+                    static thread_local int32_t last_id = -1;
+                    const size_t len = (size_t)(z - p);
+                    if (owner != b || last.size() != len || std::memcmp(last.data(), p, len) != 0) {
+                        last.assign((const char *)p, len);
+                        owner = b;
+                        std::lock_guard<std::mutex> guard(rg_mu);
+                        auto it = rg_map.find(last);
+                        if (it == rg_map.end()) {
+                            it = rg_map.emplace(last, (int32_t)b->rg_names.size()).first;
+                            b->rg_names.push_back(last);
+                        }
+                        last_id = it->second;
+                    }
+                    b->rg_index[i] = last_id;
+                }
                 p = z + 1;
             } else if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
             else if (ty == 's' || ty == 'S') p += 2;
@@ -223,18 +258,6 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
             } else break;
         }
     });
-    // read-group ids -> small integers (header order is resolved by the caller)
-    std::unordered_map<std::string, int32_t> index;
-    for (size_t i = 0; i < n; i++) {
-        if (!rg[i].first) continue;
-        std::string key(rg[i].first, rg[i].second);
-        auto it = index.find(key);
-        if (it == index.end()) {
-            it = index.emplace(key, (int32_t)b->rg_names.size()).first;
-            b->rg_names.push_back(key);
-        }
-        b->rg_index[i] = it->second;
-    }
     return MDX_OK;
 }
 

@@ -78,14 +78,27 @@ class BAMReader:
         if self._merge_libraries:
             return np.zeros(len(indices), np.uint16)
         index_of = {rg: libs.index(lib) for rg, lib in self._readgroups.items()}
+        h = self.handle
+        if h._rg is None and h.rg_index is not None:
+            # native decoder: read groups are small integers already — one table lookup for all records
+            ri = h.rg_index[np.asarray(indices, dtype=np.int64)]
+            lut = np.asarray([index_of.get(name, -1) for name in h.rg_names] + [-1], dtype=np.int64)
+            lib = lut[ri]     # (index -1 = no RG tag -> the trailing -1)
+            bad = np.nonzero(lib < 0)[0]
+            if bad.size:
+                self._raise_readgroup(int(indices[int(bad[0])]), None if ri[bad[0]] < 0 else h.rg_names[int(ri[bad[0]])])
+            return lib.astype(np.uint16)
         out = np.zeros(len(indices), np.uint16)
         for k, i in enumerate(indices):
-            rg = self.handle.rg[i]
-            if rg is None:
-                raise BAMError("Read %r has no read-group. Either fix BAM or use --merge-libraries"
-                               % (self.handle.qname[i],))
-            if rg not in index_of:
-                raise BAMError("Read %r has read-group not listed in BAM header (%r); either fix BAM "
-                               "or use --merge-libraries" % (self.handle.qname[i], rg))
+            rg = h.rg[i]
+            if rg is None or rg not in index_of:
+                self._raise_readgroup(i, rg)
             out[k] = index_of[rg]
         return out
+
+    def _raise_readgroup(self, i, rg):
+        if rg is None:
+            raise BAMError("Read %r has no read-group. Either fix BAM or use --merge-libraries"
+                           % (self.handle.qname_at(i),))
+        raise BAMError("Read %r has read-group not listed in BAM header (%r); either fix BAM "
+                       "or use --merge-libraries" % (self.handle.qname_at(i), rg))

@@ -159,7 +159,7 @@ def rescale_bam(engine, ref, in_path, out_path, model):
     for i, body in enumerate(al.raw):
         if status[i] in (STATUS_BOTH, STATUS_FORWARD):
             if al.has_mr[i]:
-                raise SystemExit("Read: %s already has a MR tag, can't rescale" % al.qname[i])   # rescale.py:277-278
+                raise SystemExit("Read: %s already has a MR tag, can't rescale" % al.qname_at(i))   # rescale.py:277-278
             l_read_name, n_cigar, l_seq = body[8], struct.unpack_from("<H", body, 12)[0], struct.unpack_from("<i", body, 16)[0]
             qoff = 32 + l_read_name + 4 * n_cigar + (l_seq + 1) // 2
             s0 = int(batch.seq_off[i])

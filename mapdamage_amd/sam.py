@@ -49,8 +49,38 @@ class Alignments:
     in front of the first record, so that a rewritten file keeps every field it does not touch."""
 
     def __init__(self, header, batch, rg, qname):
-        self.header, self.batch, self.rg, self.qname = header, batch, rg, qname
+        self.header, self.batch, self._rg, self._qname = header, batch, rg, qname
         self.raw, self.raw_header, self.has_mr = None, None, None
+        # native decoder: per-record read-group index (-1 = no RG tag) into rg_names, and the query names as one
+        # blob + offsets; the Python lists are only built when somebody asks for them
+        self.rg_index, self.rg_names, self._qblob, self._qoff = None, None, None, None
+
+    @property
+    def rg(self):
+        if self._rg is None:
+            names = self.rg_names
+            self._rg = [names[i] if i >= 0 else None for i in self.rg_index.tolist()]
+        return self._rg
+
+    @rg.setter
+    def rg(self, value):
+        self._rg = value
+
+    @property
+    def qname(self):
+        if self._qname is None:
+            blob, off = self._qblob, self._qoff.tolist()
+            self._qname = [blob[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+        return self._qname
+
+    @qname.setter
+    def qname(self, value):
+        self._qname = value
+
+    def qname_at(self, i):
+        if self._qname is not None:
+            return self._qname[i]
+        return self._qblob[int(self._qoff[i]):int(self._qoff[i + 1])].decode()
 
 
 def _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames):
@@ -216,7 +246,7 @@ def read_bam_native(path, threads=None):
     from .engine import MdxBatch, load_library
     lib = load_library()
     handle = ctypes.c_void_p()
-    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(16, os.cpu_count() or 1)),
+    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(32, os.cpu_count() or 1)),
                           ctypes.byref(handle))
     try:
         if rc != 0:
@@ -246,16 +276,14 @@ def read_bam_native(path, threads=None):
                           col(view.seq_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
                           col(view.seq, nb, np.uint8), col(view.qual, nb, np.uint8),
                           col(mtid.value, n, np.int32), col(mpos.value, n, np.int32)).validate()
-        rg_names = [lib.mdx_bam_rg_name(handle, i).decode() for i in range(lib.mdx_bam_n_rg(handle))]
-        rg_idx = col(rgi.value, n, np.int32)
-        rgs = [rg_names[i] if i >= 0 else None for i in rg_idx]
+        al = Alignments(header, batch, None, None)
+        al.rg_names = [lib.mdx_bam_rg_name(handle, i).decode() for i in range(lib.mdx_bam_n_rg(handle))]
+        al.rg_index = col(rgi.value, n, np.int32)
         offs = ctypes.c_void_p()
         blob_ptr = lib.mdx_bam_qnames(handle, ctypes.byref(offs))
-        qoff = col(offs.value, n + 1, np.uint32) if n else np.zeros(1, np.uint32)
-        blob = bytes(col(blob_ptr, int(qoff[-1]), np.uint8)) if n else b""
-        qnames = [blob[int(qoff[i]):int(qoff[i + 1])].decode() for i in range(n)]
-        al = Alignments(header, batch, rgs, qnames)
-        al.has_mr = [bool(x) for x in col(hmr.value, n, np.uint8)]
+        al._qoff = col(offs.value, n + 1, np.uint32) if n else np.zeros(1, np.uint32)
+        al._qblob = bytes(col(blob_ptr, int(al._qoff[-1]), np.uint8)) if n else b""
+        al.has_mr = col(hmr.value, n, np.uint8).astype(bool)
         return al
     finally:
         if handle:
