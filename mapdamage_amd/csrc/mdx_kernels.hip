@@ -1481,7 +1481,8 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                                 if (!s_fwd && pp >= -back) pp = back;
                                 key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
                                 if (q <= 93) newq = l_lut[(sub * npos + key) * 94 + q];
-                                ids |= (u64)(1 + sub * npos + key) << sh;
+                                // (a zero term — key 0, positions outside the model — adds nothing to MR: x + 0.0 == x)
+                                if (l_term[sub * npos + key] != 0.0) ids |= (u64)(1 + sub * npos + key) << sh;
                                 q64 = (q64 & ~(0xFFull << sh)) | ((u64)newq << sh);
                             }
                             if (a.subs) {
@@ -1514,10 +1515,11 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                     while (has) {
                         const int l = qrev ? 63 - __builtin_clzll(has) : __ffsll((long long)has) - 1;
                         has &= ~(1ull << l);
-                        const u64 w = ((u64)(u32)rl((int)(ids >> 32), l) << 32) | (u32)rl((int)ids, l);
-                        for (int k = 0; k < 8; k++) {
-                            const int id = (int)(w >> (8 * (qrev ? 7 - k : k))) & 0xFF;
-                            if (id) acc += l_term[id - 1];
+                        u64 w = ((u64)(u32)rl((int)(ids >> 32), l) << 32) | (u32)rl((int)ids, l);
+                        while (w) {   // the non-zero bytes of the lane, in read order
+                            const int sh = (qrev ? 63 - __builtin_clzll(w) : __ffsll((long long)w) - 1) & ~7;
+                            acc += l_term[(int)((w >> sh) & 0xFFull) - 1];
+                            w &= ~(0xFFull << sh);
                         }
                     }
                     mr_s[q] = acc;
