@@ -467,7 +467,30 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
                     const int b_mis = lbw + (rev * 2 + c_side) * L * 25, b_cmp = lbw + d.off_cmp() + (rev * 2 + c_side) * L * 4;
                     const u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32);
-                    u64 todo = ((u64)dyn_lo | ((u64)dyn_hi << 32)) & 0x0101010101010101ull;
+                    // 0x01 per task byte that is not a plain match (read != reference, or an invalid reference byte)
+                    const u32 xl = ((s_lo ^ r_lo) | (r_lo & 0x80808080u)) & dyn_lo, xh = ((s_hi ^ r_hi) | (r_hi & 0x80808080u)) & dyn_hi;
+                    const u32 nzl = ((((xl & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xl) >> 7) & 0x01010101u;
+                    const u32 nzh = ((((xh & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xh) >> 7) & 0x01010101u;
+                    u64 todo;
+                    if (USE_LDS) {
+                        // the plain matches of all eight bytes at once: CMP[p][base] and (p + g < L) MIS[p + g][base]
+                        // with a 0/1 increment per byte; only the other bytes take the loop below
+                        const u32 ml = dyn_lo & 0x01010101u & ~nzl, mh = dyn_hi & 0x01010101u & ~nzh;
+                        const int p0 = (c_side ? c_m8 + 7 : c_m8) - A, stp = c_side ? -1 : 1;
+#pragma unroll
+                        for (int jb = 0; jb < 8; jb++) {
+                            const u32 k = ((jb < 4 ? r_lo : r_hi) >> (8 * (jb & 3) + 1)) & 3u;
+                            const u32 dc = ((jb < 4 ? ml : mh) >> (8 * (jb & 3))) & 1u;
+                            const int p = p0 + stp * jb;
+                            const int ic = b_cmp + p * 4 + (int)k;
+                            const bool mok = dc && p + g < L;
+                            atomicAdd(&lds[ic], dc);                                        // (a byte that is no task adds 0
+                            atomicAdd(&lds[mok ? b_mis + (p + g) * 25 + (int)k : ic], mok ? 1u : 0u);   //  to a valid word)
+                        }
+                        todo = (u64)nzl | ((u64)nzh << 32);
+                    } else {
+                        todo = ((u64)dyn_lo | ((u64)dyn_hi << 32)) & 0x0101010101010101ull;
+                    }
                     // (a rolled loop: this code sits in every step of the partial run, and is rarely reached)
 #pragma unroll 1
                     while (todo) {

@@ -20,6 +20,11 @@ VARIANTS = [
     ("skip 0.2%", dict(frac_skip=0.002)),
     ("hardclip 0.1%", dict(frac_hardclip=0.001)),
     ("config 3", dict(frac_softclip=0.10, frac_ins=0.04, frac_del=0.04, frac_skip=0.002, frac_hardclip=0.001)),
+    ("len 70-150", dict(len_range=(70, 150))),
+    ("len 35-150", dict(len_range=(35, 150))),
+    ("len 35-69", dict(len_range=(35, 69))),
+    ("config 4", dict(len_range=(35, 150), frac_softclip=0.10, frac_ins=0.04, frac_del=0.04, frac_skip=0.002,
+                      frac_hardclip=0.001)),
 ]
 
 
@@ -29,7 +34,7 @@ def main():
     with DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
         eng.set_reference(ref)
         for name, kw in VARIANTS:
-            b = synth.make_reads(ref, n, 3, read_len=100, paired=True, contigs=[0, 1], **kw)
+            b = synth.make_reads(ref, n, 3, **dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw))
             db = eng.upload(b)
             eng.tabulate(db)
             eng.sync()
