@@ -284,3 +284,52 @@ def test_hip_single_indel_shapes(L, A, mid_genome):
     want = oracle_tableset(mid_genome, batch, libs, L, A, 0)
     got = run_engine(mid_genome, batch, libs, L, A, 0, resident=True)
     assert_tables_equal(got, want)
+
+
+def _cigar_records(ref, specs, seed):
+    """Records from (tid, pos, flag, [(op, len), ...]) with the read copied from the reference (5 % substitutions,
+    random inserted / clipped bases)."""
+    rng = np.random.default_rng(seed)
+    bases, offs = ref.concat()
+    upper = bases & np.uint8(0xDF)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    recs = []
+    for tid, pos, flag, ops in specs:
+        seq, r = [], offs[tid] + pos
+        for op, ln in ops:
+            if op in (0, 7, 8):
+                seq.append(upper[r:r + ln].copy()); r += ln
+            elif op in (1, 4):
+                seq.append(rng.choice(acgt, ln))
+            elif op in (2, 3):
+                r += ln
+        seq = np.concatenate(seq)
+        seq = np.where(rng.random(seq.shape[0]) < 0.05, rng.choice(acgt, seq.shape[0]), seq)
+        recs.append(dict(flag=flag, tid=tid, pos=pos, cigar=list(ops), seq=seq.tobytes().decode(), qual=None, lib=0,
+                         tlen=0))
+    return recs
+
+
+@pytest.mark.parametrize("L,A", [(70, 10), (300, 20)])
+def test_hip_long_reads_and_long_cigars(L, A, mid_genome):
+    """Reads of 32 KiB and more (no 15-bit query length: the CIGAR walk), CIGARs of more than 64 operations (beyond
+    the one-operation-per-lane preload), single-indel reads too long for the fast path, between ordinary reads."""
+    many = []
+    for k in range(60):
+        many += [(0, 37), (1, 1 + k % 3), (0, 41), (2, 1 + k % 2)]
+    many += [(0, 50)]
+    specs = [(0, 1000, 0, [(0, 40000)]), (0, 50000, 16, [(0, 33000)]),
+             (0, 100000, 0, [(0, 20000), (1, 5), (0, 20000)]), (0, 150000, 16, [(0, 17000), (2, 7), (0, 17000)]),
+             (0, 200000, 0, [(4, 3)] + many + [(4, 2)]), (1, 20000, 16, many),
+             (1, 40000, 0, [(0, 32767)]), (1, 1000, 0, [(0, 32768)]),
+             (0, 250000, 0, [(0, 30), (3, 200), (0, 30), (1, 2), (0, 30)])]
+    rng = np.random.default_rng(5)
+    for i in range(300):   # ordinary records around them (tiles mix the kinds)
+        specs.insert(int(rng.integers(0, len(specs) + 1)),
+                     (int(rng.integers(0, 2)), int(rng.integers(300, 90000)), int(rng.choice([0, 16])),
+                      [(0, int(rng.integers(1, 150)))]))
+    batch = batch_from_records(_cigar_records(mid_genome, specs, 77))
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, L, A, 0)
+    got = run_engine(mid_genome, batch, libs, L, A, 0, resident=True)
+    assert_tables_equal(got, want)
