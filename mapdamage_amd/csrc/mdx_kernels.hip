@@ -30,6 +30,8 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 __attribute__((aligned(1))) u32x2_u;
+typedef u32 __attribute__((aligned(1))) u32_u;
+typedef u16 __attribute__((aligned(1))) u16_u;
 struct __attribute__((packed, aligned(4))) u32x3 { u32 x, y, z; };   // global_load_dwordx3
 typedef unsigned long long u64;
 typedef long long i64;
@@ -1169,7 +1171,18 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
 // accumulated in the reference's column order (fp64, bit-exact).  The new quality is a byte lookup
 // LUT[sub][position key][old quality] prepared on the host with the reference's floating-point
 // expressions (mapdamage_amd/rescale.py).
-__global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
+// 512-thread blocks, three per CU (their LDS tables: ~27 KB each), six wavefronts per SIMD (80 VGPRs): measured
+// against 256 x 5 (93 VGPRs, LDS-limited) -8 %; eight per SIMD spill (43 VGPRs) and lose 30 %
+#ifndef RS_BLOCK
+#define RS_BLOCK 512
+#endif
+#ifndef RS_WPS
+#define RS_WPS 6
+#endif
+#ifndef RS_BPC
+#define RS_BPC 3
+#endif
+__global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArgs a) {
     const int lane = threadIdx.x & 63;
     const i64 gwave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
@@ -1525,7 +1538,13 @@ __global__ __launch_bounds__(256) void rescale_kernel(MdxRescaleArgs a) {
                         q8.x = (u32)q64; q8.y = (u32)(q64 >> 32);
                     }
                     if (nb >= 8) *(u32x2_u *)(qout + off) = q8;
-                    else for (int i = 0; i < nb; i++) qout[off + i] = (u8)(((i < 4 ? q8.x : q8.y) >> (8 * (i & 3))) & 0xFFu);
+                    else {   // the last lane of a record: 4 + 2 + 1 bytes, never past the record's end
+                        u64 t = (u64)q8.x | ((u64)q8.y << 32);
+                        int o = off;
+                        if (nb & 4) { *(u32_u *)(qout + o) = (u32)t; t >>= 32; o += 4; }
+                        if (nb & 2) { *(u16_u *)(qout + o) = (u16)t; t >>= 16; o += 2; }
+                        if (nb & 1) qout[o] = (u8)t;
+                    }
                 }
                 // MR: the terms of the rescaled columns, added in the reference's order (read 5' -> 3'), per slot
                 const u64 has_all = __ballot(ids != 0);
@@ -1580,9 +1599,8 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     const size_t lds = a.lds_tables ? need : 0;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    // more blocks than fit at once (8 per CU): tiles with many gapped records take longer, and a block that
-    // finishes early makes room for the next one
-    const int64_t want = (a.n_reads + 255) / 256;
-    const int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
-    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(256), lds, s, a);
+    // one launch-sized grid (RS_BPC blocks per CU); the tiles are dealt round-robin to the wavefronts
+    const int64_t want = (a.n_reads + RS_BLOCK - 1) / RS_BLOCK;
+    const int grid = (int)(want < (int64_t)n_cu * RS_BPC ? want : (int64_t)n_cu * RS_BPC);
+    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(RS_BLOCK), lds, s, a);
 }
