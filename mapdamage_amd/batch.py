@@ -49,34 +49,50 @@ class ReadBatch:
             assert self.qual.dtype == np.uint8 and self.qual.shape == self.seq.shape
         return self
 
-    def slice(self, lo, hi):
-        """Records [lo, hi) as an independent batch (offsets rebased)."""
+    def slice(self, lo, hi, copy=True):
+        """Records [lo, hi) as a batch of their own (offsets rebased).  ``copy=False``: the columns are views of
+        this batch (only the two rebased offset columns are new arrays)."""
         lo = max(0, lo)
         hi = min(self.n, hi)
         if hi < lo:
             hi = lo
         c0, c1 = int(self.cigar_off[lo]), int(self.cigar_off[hi])
         s0, s1 = int(self.seq_off[lo]), int(self.seq_off[hi])
+        own = (lambda a: a.copy()) if copy else (lambda a: a)
         return ReadBatch(
-            flag=self.flag[lo:hi].copy(),
-            lib=self.lib[lo:hi].copy(),
-            tid=self.tid[lo:hi].copy(),
-            pos=self.pos[lo:hi].copy(),
-            tlen=self.tlen[lo:hi].copy(),
+            flag=own(self.flag[lo:hi]),
+            lib=own(self.lib[lo:hi]),
+            tid=own(self.tid[lo:hi]),
+            pos=own(self.pos[lo:hi]),
+            tlen=own(self.tlen[lo:hi]),
             cigar_off=(self.cigar_off[lo:hi + 1] - np.uint32(c0)).astype(np.uint32),
-            cigar=self.cigar[c0:c1].copy(),
+            cigar=own(self.cigar[c0:c1]),
             seq_off=(self.seq_off[lo:hi + 1] - np.uint32(s0)).astype(np.uint32),
-            seq=self.seq[s0:s1].copy(),
-            qual=None if self.qual is None else self.qual[s0:s1].copy(),
-            mtid=None if self.mtid is None else self.mtid[lo:hi].copy(),
-            mpos=None if self.mpos is None else self.mpos[lo:hi].copy(),
+            seq=own(self.seq[s0:s1]),
+            qual=None if self.qual is None else own(self.qual[s0:s1]),
+            mtid=None if self.mtid is None else own(self.mtid[lo:hi]),
+            mpos=None if self.mpos is None else own(self.mpos[lo:hi]),
         )
 
     def take(self, index):
-        """Records selected by an integer index array, in that order."""
+        """Records selected by an integer index array, in that order (vectorised gather of the ragged columns)."""
         index = np.asarray(index, dtype=np.int64)
-        recs = [self.record(int(i)) for i in index]
-        return batch_from_records(recs, with_qual=self.qual is not None)
+
+        def ragged(off, data):
+            off = off.astype(np.int64)
+            lens = off[index + 1] - off[index]
+            new_off = np.zeros(index.shape[0] + 1, np.int64)
+            np.cumsum(lens, out=new_off[1:])
+            # element k of record j comes from off[index[j]] + k
+            src = np.arange(int(new_off[-1]), dtype=np.int64) + np.repeat(off[index] - new_off[:-1], lens)
+            return new_off.astype(np.uint32), [d[src] if d is not None else None for d in data]
+
+        cigar_off, (cigar,) = ragged(self.cigar_off, [self.cigar])
+        seq_off, (seq, qual) = ragged(self.seq_off, [self.seq, self.qual])
+        return ReadBatch(flag=self.flag[index], lib=self.lib[index], tid=self.tid[index], pos=self.pos[index],
+                         tlen=self.tlen[index], cigar_off=cigar_off, cigar=cigar, seq_off=seq_off, seq=seq, qual=qual,
+                         mtid=None if self.mtid is None else self.mtid[index],
+                         mpos=None if self.mpos is None else self.mpos[index])
 
     def shard(self, rank, world):
         """Contiguous shard ``rank`` of ``world`` (shard-by-read)."""

@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -124,6 +126,15 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
     mdx_bam *b = new (std::nothrow) mdx_bam();
     if (!b) return MDX_ERR_ARG;
     *out = b;
+    // MDX_BAM_TIMING=1: stage times on stderr
+    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mdx_bam_read %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<uint8_t> file;
     {
         FILE *fp = std::fopen(path, "rb");
@@ -136,9 +147,11 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
         std::fclose(fp);
         if (got != file.size()) { b->error = "short read"; return MDX_ERR_ARG; }
     }
+    lap("file read");
     std::vector<Block> blocks;
     size_t total = 0;
     if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
+    lap("block scan");
     raw_bytes data(total + 8);
     std::atomic<bool> ok{true};
     parallel_for(blocks.size(), threads, [&](size_t i) {
@@ -146,6 +159,7 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
         if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
     });
     if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
+    lap("inflate");
     std::vector<uint8_t>().swap(file);
 
     if (total < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) { b->error = "not a BAM file"; return MDX_ERR_ARG; }
@@ -188,6 +202,7 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
         off += 4 + (size_t)bs;
     }
     const size_t n = rec.size();
+    lap("record scan");
     b->flag.resize(n); b->lib.assign(n, 0); b->tid.resize(n); b->pos.resize(n); b->tlen.resize(n);
     b->mtid.resize(n); b->mpos.resize(n); b->rg_index.assign(n, -1); b->has_mr.assign(n, 0);
     b->cigar_off = coff; b->seq_off = soff; b->qname_off = noff;
@@ -197,6 +212,7 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
     // id up first, the shared map only when the id changes
     std::mutex rg_mu;
     std::unordered_map<std::string, int32_t> rg_map;
+    lap("allocate");
     static const char DEC[17] = "=ACMGRSVTWYHKDBN";
     // pass 2 (parallel): unpack every record into the columns
     parallel_for(n, threads, [&](size_t i) {
@@ -258,6 +274,7 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
             } else break;
         }
     });
+    lap("unpack");
     return MDX_OK;
 }
 

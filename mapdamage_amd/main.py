@@ -194,7 +194,7 @@ def main(argv):
                           device=options.device) as engine:
             engine.set_reference(ref)
             for lo in range(0, batch.n, options.batch_reads):
-                engine.tabulate(batch.slice(lo, lo + options.batch_reads))
+                engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
             tables = engine.finish()
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)

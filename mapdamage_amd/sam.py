@@ -69,7 +69,7 @@ class Alignments:
     @property
     def qname(self):
         if self._qname is None:
-            blob, off = self._qblob, self._qoff.tolist()
+            blob, off = bytes(self._qblob), self._qoff.tolist()
             self._qname = [blob[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
         return self._qname
 
@@ -80,7 +80,7 @@ class Alignments:
     def qname_at(self, i):
         if self._qname is not None:
             return self._qname[i]
-        return self._qblob[int(self._qoff[i]):int(self._qoff[i + 1])].decode()
+        return bytes(self._qblob[int(self._qoff[i]):int(self._qoff[i + 1])]).decode()
 
 
 def _finish(header, flags, tids, poss, tlens, cigs, cig_counts, seqs, quals, rgs, qnames):
@@ -237,57 +237,68 @@ def write_bam_raw(path, raw_header, records):
         out.write(_bgzf_block(b""))
 
 
+class _NativeBam:
+    """Owner of a decoded BAM inside libmdx.so (``mdx_bam_free`` when the last array viewing it is gone)."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._handle = lib, handle
+
+    def __del__(self):
+        if self._handle:
+            self._lib.mdx_bam_free(self._handle)
+            self._handle = None
+
+
 def read_bam_native(path, threads=None):
     """BAM -> ``Alignments`` through the C++ decoder of libmdx.so (multi-threaded BGZF inflate,
-    records unpacked straight into the SoA columns; include/mdx.h ``mdx_bam_*``)."""
+    records unpacked straight into the SoA columns; include/mdx.h ``mdx_bam_*``).  The columns are numpy
+    views of the decoder's buffers (no copy); every view keeps the decoder alive."""
     import ctypes
     import os
 
     from .engine import MdxBatch, load_library
     lib = load_library()
     handle = ctypes.c_void_p()
-    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(32, os.cpu_count() or 1)),
+    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
                           ctypes.byref(handle))
-    try:
-        if rc != 0:
-            raise ValueError("%r: %s" % (str(path), lib.mdx_bam_error(handle).decode() if handle else "BAM decode failed"))
-        header = Header(lib.mdx_bam_header_text(handle).decode())
-        n_ref = lib.mdx_bam_n_ref(handle)
-        names = [lib.mdx_bam_ref_name(handle, i).decode() for i in range(n_ref)]
-        lengths = [int(lib.mdx_bam_ref_length(handle, i)) for i in range(n_ref)]
-        if not header.references:
-            header.references, header.lengths = names, lengths
-        view = MdxBatch()
-        mtid, mpos, rgi, hmr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-        lib.mdx_bam_batch(handle, ctypes.byref(view), ctypes.byref(mtid), ctypes.byref(mpos), ctypes.byref(rgi),
-                          ctypes.byref(hmr))
-        n, nb, nc = view.n_reads, view.n_bases, view.n_cigar
+    owner = _NativeBam(lib, handle)
+    if rc != 0:
+        raise ValueError("%r: %s" % (str(path), lib.mdx_bam_error(handle).decode() if handle else "BAM decode failed"))
+    header = Header(lib.mdx_bam_header_text(handle).decode())
+    n_ref = lib.mdx_bam_n_ref(handle)
+    names = [lib.mdx_bam_ref_name(handle, i).decode() for i in range(n_ref)]
+    lengths = [int(lib.mdx_bam_ref_length(handle, i)) for i in range(n_ref)]
+    if not header.references:
+        header.references, header.lengths = names, lengths
+    view = MdxBatch()
+    mtid, mpos, rgi, hmr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    lib.mdx_bam_batch(handle, ctypes.byref(view), ctypes.byref(mtid), ctypes.byref(mpos), ctypes.byref(rgi),
+                      ctypes.byref(hmr))
+    n, nb, nc = view.n_reads, view.n_bases, view.n_cigar
 
-        def col(ptr, count, dtype):
-            if count == 0 or not ptr:
-                return np.zeros(0, dtype)
-            size = count * np.dtype(dtype).itemsize
-            return np.frombuffer((ctypes.c_char * size).from_address(ptr), dtype=dtype).copy()
+    def col(ptr, count, dtype):
+        if count == 0 or not ptr:
+            return np.zeros(0, dtype)
+        raw = (ctypes.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        raw._owner = owner          # the view (and every view of it) keeps the decoder's buffers alive
+        return np.frombuffer(raw, dtype=dtype)
 
-        batch = ReadBatch(col(view.flag, n, np.uint16), np.zeros(n, np.uint16), col(view.tid, n, np.int32),
-                          col(view.pos, n, np.int32), col(view.tlen, n, np.int32),
-                          col(view.cigar_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
-                          col(view.cigar, nc, np.uint32),
-                          col(view.seq_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
-                          col(view.seq, nb, np.uint8), col(view.qual, nb, np.uint8),
-                          col(mtid.value, n, np.int32), col(mpos.value, n, np.int32)).validate()
-        al = Alignments(header, batch, None, None)
-        al.rg_names = [lib.mdx_bam_rg_name(handle, i).decode() for i in range(lib.mdx_bam_n_rg(handle))]
-        al.rg_index = col(rgi.value, n, np.int32)
-        offs = ctypes.c_void_p()
-        blob_ptr = lib.mdx_bam_qnames(handle, ctypes.byref(offs))
-        al._qoff = col(offs.value, n + 1, np.uint32) if n else np.zeros(1, np.uint32)
-        al._qblob = bytes(col(blob_ptr, int(al._qoff[-1]), np.uint8)) if n else b""
-        al.has_mr = col(hmr.value, n, np.uint8).astype(bool)
-        return al
-    finally:
-        if handle:
-            lib.mdx_bam_free(handle)
+    batch = ReadBatch(col(view.flag, n, np.uint16), np.zeros(n, np.uint16), col(view.tid, n, np.int32),
+                      col(view.pos, n, np.int32), col(view.tlen, n, np.int32),
+                      col(view.cigar_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
+                      col(view.cigar, nc, np.uint32),
+                      col(view.seq_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
+                      col(view.seq, nb, np.uint8), col(view.qual, nb, np.uint8),
+                      col(mtid.value, n, np.int32), col(mpos.value, n, np.int32)).validate()
+    al = Alignments(header, batch, None, None)
+    al.rg_names = [lib.mdx_bam_rg_name(handle, i).decode() for i in range(lib.mdx_bam_n_rg(handle))]
+    al.rg_index = col(rgi.value, n, np.int32)
+    offs = ctypes.c_void_p()
+    blob_ptr = lib.mdx_bam_qnames(handle, ctypes.byref(offs))
+    al._qoff = col(offs.value, n + 1, np.uint32) if n else np.zeros(1, np.uint32)
+    al._qblob = col(blob_ptr, int(al._qoff[-1]), np.uint8) if n else np.zeros(0, np.uint8)
+    al.has_mr = col(hmr.value, n, np.uint8).view(bool)
+    return al
 
 
 def read_alignments(path):

@@ -132,6 +132,21 @@ def test_native_bam_decoder_matches_python_decoder(files):
         assert nat.header.read_groups == py.header.read_groups
 
 
+def test_native_bam_views_keep_the_decoder_alive(files):
+    """The columns are views of the decoder's buffers: a slice must stay valid after the Alignments object and
+    the batch it came from are gone."""
+    import gc
+    d, ref, batch, rg_of = files
+    al = sam.read_bam_native(d / "x.bam")
+    part = al.batch.slice(3, 40)
+    seq, want = part.seq[5:200], bytes(batch.slice(3, 40).seq[5:200])
+    del al, part
+    gc.collect()
+    junk = [np.ones(1 << 20, np.uint8) for _ in range(8)]    # churn the allocator
+    del junk
+    assert bytes(seq) == want
+
+
 def test_native_bam_decoder_rejects_garbage(tmp_path):
     (tmp_path / "bad.bam").write_bytes(b"\x1f\x8bnot really a bam file at all")
     with pytest.raises(ValueError):
@@ -155,3 +170,19 @@ def test_experimental_damage_frequency_files_follow_the_reference_table():
             sel = [r for r in rows if r["End"] == end and int(r["Pos"]) == p]
             n, d = sum(int(r[num]) for r in sel), sum(int(r[den]) for r in sel)
             assert lines[p] == "%d\t%s" % (p, "%.15g" % (n / d))
+
+
+def test_batch_take_and_view_slices():
+    """Vectorised ``take`` equals the record-by-record gather; ``slice(copy=False)`` equals ``slice``."""
+    from mapdamage_amd.batch import batch_from_records
+    ref = synth.small_genome()
+    b = synth.make_edge_reads(ref)
+    idx = np.array([5, 0, 7, 7, 3, b.n - 1])
+    got = b.take(idx).validate()
+    want = batch_from_records([b.record(int(i)) for i in idx], with_qual=b.qual is not None)
+    for k in ("flag", "lib", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual"):
+        np.testing.assert_array_equal(getattr(got, k), getattr(want, k), err_msg=k)
+    assert b.take(np.zeros(0, np.int64)).validate().n == 0
+    a, v = b.slice(3, 17), b.slice(3, 17, copy=False).validate()
+    for k in ("flag", "lib", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(v, k), err_msg=k)
