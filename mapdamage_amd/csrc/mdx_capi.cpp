@@ -38,6 +38,7 @@ struct mdx_ctx {
     int mode = MDX_MODE_LDS;
     int n_cu = 256;
     int max_grid = 0;
+    int lib_group = 0;     // LDS mode: libraries per launch (as many as fit the LDS; all of them in one launch if they do)
     size_t lds_bytes = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -142,15 +143,19 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
                               4LL * lgd_lds + 128) > 0x7FFFFFF0LL || cfg->length > (1 << 24) || cfg->around > (1 << 24))
         return fail(c, MDX_ERR_ARG, "table too large (nlib * length)");
     c->dims = mdx_make_dims(cfg->length, cfg->around, cfg->nlib, cfg->lgd_max, lgd_lds);
-    c->lds_bytes = mdx_k_lds_bytes(c->dims);
+    // the tables of as many libraries as fit the LDS are counted per launch (all of them in one launch if they
+    // fit); not even one fits: global-atomic fallback
+    int group = cfg->nlib;
+    while (group > 1 && mdx_k_lds_bytes(mdx_make_dims(cfg->length, cfg->around, group, cfg->lgd_max, lgd_lds)) > kLdsLimit)
+        group--;
+    const MdxDims gdims = mdx_make_dims(cfg->length, cfg->around, group, cfg->lgd_max, lgd_lds);
+    c->lds_bytes = mdx_k_lds_bytes(gdims);
     if (c->lds_bytes <= kLdsLimit) {
         c->mode = MDX_MODE_LDS;
-        int per_cu = (int)(kLdsLimit / c->lds_bytes);
-        const int by_threads = 2048 / mdx_k_block_threads();
-        if (per_cu > by_threads) per_cu = by_threads;
-        c->max_grid = c->n_cu * per_cu;
+        c->lib_group = group;
+        c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
         HIP_TRY(c, mdx_k_prepare(c->lds_bytes));
-        HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * c->dims.w_total * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * gdims.w_total * 4));
     } else {
         c->mode = MDX_MODE_GLOBAL;  // tables do not fit the LDS: global-atomic fallback
         c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
@@ -301,24 +306,46 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
     const int wpb = mdx_k_block_threads() / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;
-    int64_t want = (ntiles + wpb - 1) / wpb;
+    const int64_t want = (ntiles + wpb - 1) / wpb;
     if (b->n_reads >= (int64_t)1 << 30) return fail(c, MDX_ERR_ARG, "batch of 2^30 records or more; split it");
-    const int grid = (int)(want < c->max_grid ? want : c->max_grid);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing) {
-        HIP_TRY(c, hipEventCreate(&e0));
-        HIP_TRY(c, hipEventCreate(&e1));
-        HIP_TRY(c, hipEventRecord(e0, c->stream));
-    }
-    mdx_k_tabulate(a, c->mode, mask, grid, c->mode == MDX_MODE_LDS ? c->lds_bytes : 0, c->stream);
-    if (c->timing) {
-        HIP_TRY(c, hipEventRecord(e1, c->stream));
-        c->events.emplace_back(e0, e1);
-    }
-    HIP_TRY(c, hipGetLastError());
-    if (c->mode == MDX_MODE_LDS) {
-        mdx_k_reduce_partials(c->d_partials, c->d_raw, c->dims.w_total, grid, c->stream);
+    a.nlib_total = c->cfg.nlib;
+    // LDS mode: one launch per group of libraries (usually a single one); every launch scans all records and
+    // counts those of its group
+    const int group = c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib;
+    for (int lo = 0; lo < c->cfg.nlib; lo += group) {
+        const int gn = c->cfg.nlib - lo < group ? c->cfg.nlib - lo : group;
+        a.lib_lo = lo;
+        size_t lds = 0;
+        int max_grid = c->max_grid;
+        if (c->mode == MDX_MODE_LDS) {
+            a.dims = gn == c->cfg.nlib ? c->dims : mdx_make_dims(c->cfg.length, c->cfg.around, gn, c->cfg.lgd_max, c->dims.lgd_lds);
+            a.raw = c->d_raw + (size_t)lo * c->dims.w_lib;
+            a.lgd_dense = c->d_lgd_dense + (size_t)lo * 4 * c->cfg.lgd_max;
+            lds = mdx_k_lds_bytes(a.dims);
+            int per_cu = (int)(kLdsLimit / lds);
+            const int by_threads = 2048 / mdx_k_block_threads();
+            if (per_cu > by_threads) per_cu = by_threads;
+            max_grid = c->n_cu * per_cu;
+        }
+        a.stage_off = mdx_k_stage_off(a.dims);
+        a.queue_off = mdx_k_queue_off(a.dims);
+        const int grid = (int)(want < max_grid ? want : max_grid);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing) {
+            HIP_TRY(c, hipEventCreate(&e0));
+            HIP_TRY(c, hipEventCreate(&e1));
+            HIP_TRY(c, hipEventRecord(e0, c->stream));
+        }
+        mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);
+        if (c->timing) {
+            HIP_TRY(c, hipEventRecord(e1, c->stream));
+            c->events.emplace_back(e0, e1);
+        }
         HIP_TRY(c, hipGetLastError());
+        if (c->mode == MDX_MODE_LDS) {
+            mdx_k_reduce_partials(c->d_partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream);
+            HIP_TRY(c, hipGetLastError());
+        }
     }
     return MDX_OK;
 }

@@ -114,6 +114,7 @@ struct MdxTabArgs {
     int queue_off;                   // word offset of the per-wave rare-event queues in the LDS
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
+    int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };
@@ -125,8 +126,8 @@ int mdx_k_queue_off(const MdxDims &d);
 hipError_t mdx_k_prepare(size_t lds_bytes);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
-void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, int64_t w_total, int grid,
-                           hipStream_t s);
+void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
+                           int64_t w_total, int grid, hipStream_t s);
 void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
                     const unsigned long long *n_lgd_over, MdxDims d, unsigned long long *out,
                     hipStream_t s);

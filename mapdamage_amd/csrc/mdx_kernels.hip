@@ -579,6 +579,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         const int c_lib = a.lib[rj], c_tid = a.tid[rj], c_pos = a.pos[rj];
         const u32 c_co0 = a.cigar_off[rj], c_co1 = a.cigar_off[rj + 1], c_so0 = a.seq_off[rj], c_so1 = a.seq_off[rj + 1];
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
+        // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
+        // the others are left to their own launch (a library id beyond the last one is an error in every launch)
+        if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
         bool one = false;   // [H][S] M {I|D} M [S][H]: one indel between two match runs
@@ -587,14 +590,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         int lkey = -1;  // fragment-length key for the LDS histogram
         if (kept) {
             const int rev = (fl >> 4) & 1;
-            libid = c_lib;
+            libid = c_lib - a.lib_lo;
             const int tid = c_tid;
             const i64 pos = c_pos;
             cig_o = c_co0;
             cig_n = (int)(c_co1 - cig_o);
             const u32 so = c_so0;
             const i64 lseq = (i64)c_so1 - (i64)so;
-            bool bad = tid < 0 || tid >= a.n_contig || libid >= d.nlib || lseq <= 0 || pos < 0;
+            bool bad = tid < 0 || tid >= a.n_contig || c_lib >= a.nlib_total || lseq <= 0 || pos < 0;
             const int lbase = bad ? 0 : libid * d.w_lib;
 
             // CIGAR scan: pysam query_alignment_start/_end, htslib bam_endpos, parse_cigar
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     } else {
                         const u64 slot = atomicAdd(a.n_lgd_over, 1ull);
                         if ((i64)slot < a.lgd_over_cap) {
-                            a.lgd_over[4 * slot + 0] = libid;
+                            a.lgd_over[4 * slot + 0] = libid + a.lib_lo;
                             a.lgd_over[4 * slot + 1] = kind;
                             a.lgd_over[4 * slot + 2] = rev;
                             a.lgd_over[4 * slot + 3] = flen;
@@ -1025,24 +1028,25 @@ void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t l
 }
 
 // raw[w] += sum over block slots; blocks are split into `parts` groups to expose parallelism
-__global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__restrict__ raw, i64 w_total,
-                                       int grid, int parts) {
+// (the last word, the number of kept reads, goes to *raw_tail: a launch may hold a group of the libraries only)
+__global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__restrict__ raw, u64 *__restrict__ raw_tail,
+                                       i64 w_total, int grid, int parts) {
     const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= w_total) return;
     const int part = blockIdx.y;
     const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
     u64 acc = 0;
     for (int b = b0; b < b1; b++) acc += partials[(i64)b * w_total + w];
-    if (acc) atomicAdd(&raw[w], acc);
+    if (acc) atomicAdd(w == w_total - 1 ? raw_tail : &raw[w], acc);
 }
 
-void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, int64_t w_total, int grid,
-                           hipStream_t s) {
+void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
+                           int64_t w_total, int grid, hipStream_t s) {
     const int threads = 256;
     const int blocks = (int)((w_total + threads - 1) / threads);
     int parts = grid < 32 ? grid : 32;
     if (parts < 1) parts = 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts), dim3(threads), 0, s, partials, raw,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts), dim3(threads), 0, s, partials, raw, raw_tail,
                        (i64)w_total, grid, parts);
 }
 

@@ -125,15 +125,51 @@ def test_hip_unaligned_column_pointers(phase, mid_genome):
     assert_tables_equal(got, want)
 
 
-def test_hip_global_atomic_fallback_matches_oracle(mid_genome):
-    """Tables too large for the LDS (many libraries) take the global-atomic path."""
+@pytest.mark.parametrize("nlib,Q", [(2, 0), (3, 0), (7, 15), (8, 0)])
+def test_hip_library_groups_match_oracle(nlib, Q, mid_genome):
+    """More libraries than fit the LDS at once: one launch per group of libraries, every launch counting the
+    records of its group (tables stay in the LDS)."""
     from mapdamage_amd.engine import DamageEngine
-    nlib = 7
     batch = synth.make_reads(mid_genome, 40_000, 8, len_range=(30, 120), nlib=nlib, frac_softclip=0.1,
-                             frac_ins=0.05, frac_del=0.05, with_qual=True)
+                             frac_ins=0.05, frac_del=0.05, with_qual=True, paired=True)
     libs = [("S%d" % i, "L%d" % i) for i in range(nlib)]
-    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 15)
-    with DamageEngine(libs, 70, 10, 15) as eng:
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, Q, lgd_max=300)
+    with DamageEngine(libs, 70, 10, Q, lgd_max=300) as eng:     # (lengths >= 300 take the overflow list)
+        assert eng.table_mode == "lds"
+        eng.set_reference(mid_genome)
+        eng.tabulate(batch)
+        eng.tabulate(batch.slice(0, 1000))
+        got = eng.finish()
+    want2 = oracle_tableset(mid_genome, batch.slice(0, 1000), libs, 70, 10, Q, lgd_max=300)
+    np.testing.assert_array_equal(got.mis, want.mis + want2.mis)
+    np.testing.assert_array_equal(got.comp, want.comp + want2.comp)
+    assert got.n_kept == want.n_kept + want2.n_kept
+    merged = {}
+    for key in want.lgd_sparse() + want2.lgd_sparse():
+        merged[key[:-1]] = merged.get(key[:-1], 0) + key[-1]
+    assert sorted(got.lgd_sparse()) == sorted(k + (v,) for k, v in merged.items())
+
+
+def test_hip_library_id_beyond_the_last_is_an_error(mid_genome):
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    batch = synth.make_reads(mid_genome, 5_000, 8, read_len=60, nlib=5)
+    batch.lib[1234] = 7
+    with DamageEngine([("S%d" % i, "L") for i in range(5)]) as eng:
+        eng.set_reference(mid_genome)
+        eng.tabulate(batch)
+        with pytest.raises(BadReadError) as err:
+            eng.sync()
+    assert "1234" in str(err.value)
+
+
+def test_hip_global_atomic_fallback_matches_oracle(mid_genome):
+    """Tables of a single library too large for the LDS (very large --length) take the global-atomic path."""
+    from mapdamage_amd.engine import DamageEngine
+    batch = synth.make_reads(mid_genome, 20_000, 8, len_range=(30, 900), nlib=2, frac_softclip=0.1,
+                             frac_ins=0.05, frac_del=0.05, with_qual=True)
+    libs = [("S%d" % i, "L%d" % i) for i in range(2)]
+    want = oracle_tableset(mid_genome, batch, libs, 700, 10, 15)
+    with DamageEngine(libs, 700, 10, 15) as eng:
         assert eng.table_mode == "global"
         eng.set_reference(mid_genome)
         eng.tabulate(batch)
