@@ -91,7 +91,7 @@ int64_t comp_words(const mdx_ctx *c) { return (int64_t)c->cfg.nlib * 4 * (c->cfg
 
 int zero_accumulators(mdx_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->d_raw, 0, (size_t)c->dims.w_total * 8, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_lgd_dense, 0, (size_t)lgd_words(c) * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_lgd_dense, 0, (size_t)lgd_words(c) * 8 * MDX_LGD_COPIES, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_n_lgd_over, 0, 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, 8, c->stream));
     return MDX_OK;
@@ -161,7 +161,7 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
         c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
     }
     HIP_TRY(c, hipMalloc((void **)&c->d_raw, (size_t)c->dims.w_total * 8));
-    HIP_TRY(c, hipMalloc((void **)&c->d_lgd_dense, (size_t)lgd_words(c) * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_lgd_dense, (size_t)lgd_words(c) * 8 * MDX_LGD_COPIES));
     HIP_TRY(c, hipMalloc((void **)&c->d_lgd_over, (size_t)(cfg->lgd_over_cap > 0 ? cfg->lgd_over_cap : 1) * 32));
     HIP_TRY(c, hipMalloc((void **)&c->d_n_lgd_over, 8));
     HIP_TRY(c, hipMalloc((void **)&c->d_err, 8));

@@ -479,10 +479,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         // with a 0/1 increment per byte; only the other bytes take the loop below
                         const u32 ml = dyn_lo & 0x01010101u & ~nzl, mh = dyn_hi & 0x01010101u & ~nzh;
                         const int p0 = (c_side ? c_m8 + 7 : c_m8) - A, stp = c_side ? -1 : 1;
-#pragma unroll
-                        for (int jb = 0; jb < 8; jb++) {
-                            const u32 k = ((jb < 4 ? r_lo : r_hi) >> (8 * (jb & 3) + 1)) & 3u;
-                            const u32 dc = ((jb < 4 ? ml : mh) >> (8 * (jb & 3))) & 1u;
+                        const u64 r64m = (u64)r_lo | ((u64)r_hi << 32), m64 = (u64)ml | ((u64)mh << 32);
+#pragma unroll 1
+                        for (int jb = 0; jb < 8; jb++) {   // (rolled: register pressure of this rarely used block)
+                            const u32 k = (u32)(r64m >> (8 * jb + 1)) & 3u;
+                            const u32 dc = (u32)(m64 >> (8 * jb)) & 1u;
                             const int p = p0 + stp * jb;
                             const int ic = b_cmp + p * 4 + (int)k;
                             const bool mok = dc && p + g < L;
@@ -688,7 +689,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     if (flen < d.lgd_lds) {
                         lkey = lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen;
                     } else if (flen < d.lgd_max) {
-                        atomicAdd(&a.lgd_dense[(((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
+                        atomicAdd(&a.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
+                                               (((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
                     } else {
                         const u64 slot = atomicAdd(a.n_lgd_over, 1ull);
                         if ((i64)slot < a.lgd_over_cap) {
@@ -1112,7 +1114,8 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             const int len = x % d.lgd_max; x /= d.lgd_max;
             const int strand = x % 2; x /= 2;
             const int kind = x % 2; x /= 2;
-            v = lgd_dense[i - n_mis - n_comp];
+            v = 0;
+            for (int c = 0; c < MDX_LGD_COPIES; c++) v += lgd_dense[(i64)c * n_lgd + (i - n_mis - n_comp)];
             if (len < d.lgd_lds) v += raw[x * d.w_lib + d.off_lgd() + (kind * 2 + strand) * d.lgd_lds + len];
         } else if (i == total - 2) {
             v = raw[d.w_total - 1];
