@@ -1,0 +1,38 @@
+"""Kernel time with --min-basequal (the MASK variant: a third column load and the quality compare per step; gapped
+records walk their CIGAR) against the default, 2 M records with qualities.  Run on the GPU box."""
+import json
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from mapdamage_amd import synth  # noqa: E402
+from mapdamage_amd.engine import DamageEngine  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    ref = synth.make_genome()
+    for name, kw in (("config 2 + qualities", dict(read_len=100)),
+                     ("config 3 + qualities", dict(read_len=100, paired=True, frac_softclip=0.10, frac_ins=0.04,
+                                                   frac_del=0.04, frac_skip=0.002, frac_hardclip=0.001))):
+        b = synth.make_reads(ref, n, 3, contigs=[0, 1], with_qual=True, **kw)
+        for q in (0, 20):
+            with DamageEngine([("s", "l")], 70, 10, q, lgd_max=4096) as eng:
+                eng.set_reference(ref)
+                db = eng.upload(b)
+                eng.tabulate(db)
+                eng.sync()
+                eng.timing(True)
+                for _ in range(5):
+                    eng.tabulate(db)
+                eng.sync()
+                n_launch, ms = eng.timing_read()
+                db.free()
+                print(json.dumps({"workload": name, "min_basequal": q, "kernel_ms": ms / 5,
+                                  "Greads_per_s": n / (ms / 5 * 1e-3) / 1e9}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
