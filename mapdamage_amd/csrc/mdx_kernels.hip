@@ -530,6 +530,36 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
             mq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
             mq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
+            if (USE_LDS) {
+                // a masked column counts its read base (CMP) and nothing else (align.py:65-71 turns both symbols into
+                // N): corrected here — the optimistic TC increment undone, CMP bumped — one byte per iteration, as
+                // many iterations as the fullest lane has masked bytes; such bytes raise no event
+                // (worth it when many lanes hold masked bytes; a few of them are cheaper as events)
+                u64 m = act ? ((u64)mq_lo | ((u64)mq_hi << 32)) : 0ull;
+                const bool many = __popcll(__ballot(m != 0)) > 16;
+                if (!many) m = 0;
+                if (m) {
+                    const u32 t_lo = mq_lo >> 7, t_hi = mq_hi >> 7;
+                    x_lo &= ~((t_lo << 8) - t_lo); x_hi &= ~((t_hi << 8) - t_hi);
+                    const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
+                    const int b_cmp = lbw + d.off_cmp() + (rev * 2 + c_side) * L * 4;
+                    const u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32);
+#pragma unroll 1
+                    while (m) {
+                        const int sh = (__ffsll((long long)m) - 1) & ~7, jb = sh >> 3;
+                        m &= m - 1;
+                        const u32 sb = (u32)(s64 >> sh) & 0xFFu, rb = (u32)(r64 >> sh) & 0xFFu;
+                        atomicAdd(&lds[(base_b >> 2) + (((rb >> 1) & 3u) << 9) + 64 * jb], 0xFFFFFFFFu);   // -1
+                        const int sc = classify_read(sb);
+                        if (sc < 4) atomicAdd(&lds[b_cmp + ((c_side ? c_m8 + 7 - jb : c_m8 + jb) - A) * 4 + sc], 1u);
+                    }
+                    // (a neutral matching pair in the event copy: drain_all must not look at these bytes again)
+                    const u32 mb_lo = (t_lo << 8) - t_lo, mb_hi = (t_hi << 8) - t_hi;
+                    s_lo = (s_lo & ~mb_lo) | (0x41414141u & mb_lo); s_hi = (s_hi & ~mb_hi) | (0x41414141u & mb_hi);
+                    r_lo = (r_lo & ~mb_lo) | (0x41414141u & mb_lo); r_hi = (r_hi & ~mb_hi) | (0x41414141u & mb_hi);
+                }
+                if (many) { mq_lo = 0; mq_hi = 0; }
+            }
             x_lo |= mq_lo; x_hi |= mq_hi;
         }
         // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
@@ -960,18 +990,20 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // rotation: a copy of an in-flight destination would wait for its load).  Every point of
                 // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
                 // PIPE_DEPTH - 1 fills per run go past the last step.
-                Stage st[PIPE_DEPTH];
+                // (--min-basequal loads a third column per step: two steps in flight keep it inside the register budget)
+                constexpr int PD = MASK ? 2 : PIPE_DEPTH;
+                Stage st[PD];
 #pragma unroll
-                for (int dd = 0; dd < PIPE_DEPTH; dd++) fill(st[dd]);
-                for (int k = PIPE_DEPTH; k < nsteps; k += PIPE_DEPTH) {
+                for (int dd = 0; dd < PD; dd++) fill(st[dd]);
+                for (int k = PD; k < nsteps; k += PD) {
 #pragma unroll
-                    for (int dd = 0; dd < PIPE_DEPTH; dd++) {
+                    for (int dd = 0; dd < PD; dd++) {
                         count(st[dd], complete_tag, st[dd].far);
                         fill(st[dd]);
                     }
                 }
 #pragma unroll
-                for (int dd = 0; dd < PIPE_DEPTH; dd++)
+                for (int dd = 0; dd < PD; dd++)
                     if (dd == 0 || st[dd].valid) count(st[dd], complete_tag, st[dd].far);
             };
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only

@@ -18,7 +18,12 @@ def main():
                      ("config 3 + qualities", dict(read_len=100, paired=True, frac_softclip=0.10, frac_ins=0.04,
                                                    frac_del=0.04, frac_skip=0.002, frac_hardclip=0.001))):
         b = synth.make_reads(ref, n, 3, contigs=[0, 1], with_qual=True, **kw)
-        for q in (0, 20):
+        for q, skew in ((0, False), (20, False), (20, True)):
+            if skew:   # a sequencer-like distribution: 5 % of the bases below Phred 20, the rest 30..41
+                import numpy as np
+                rng = np.random.default_rng(9)
+                low = rng.random(b.qual.shape[0]) < 0.05
+                b.qual = np.where(low, rng.integers(2, 20, b.qual.shape[0]), rng.integers(30, 42, b.qual.shape[0])).astype(np.uint8)
             with DamageEngine([("s", "l")], 70, 10, q, lgd_max=4096) as eng:
                 eng.set_reference(ref)
                 db = eng.upload(b)
@@ -30,7 +35,8 @@ def main():
                 eng.sync()
                 n_launch, ms = eng.timing_read()
                 db.free()
-                print(json.dumps({"workload": name, "min_basequal": q, "kernel_ms": ms / 5,
+                print(json.dumps({"workload": name + (", 5 % of the bases below Phred 20" if skew else ", uniform Phred 2..41"),
+                                  "min_basequal": q, "kernel_ms": ms / 5,
                                   "Greads_per_s": n / (ms / 5 * 1e-3) / 1e9}), flush=True)
 
 
