@@ -79,7 +79,9 @@ int mdx_k_block_threads() { return MDX_BLOCK; }
 // LDS image: [tables w_total words, padded to 16 B][staging, 12 x STG_ENT x 16 B][event queues, 12 x EVQ_BYTES]
 int mdx_k_stage_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
 int mdx_k_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_BLOCK / 64) * STG_ENT * 4; }
-size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4 + (size_t)(MDX_BLOCK / 64) * EVQ_BYTES; }
+// ... [byte-mask table: 9 x u64, entry n = the low n bytes set]
+#define LT_BYTES 72
+size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4 + (size_t)(MDX_BLOCK / 64) * EVQ_BYTES + LT_BYTES; }
 
 // read byte -> class; accepted only if it is exactly the upper-case letter
 // ("nt in 'ACGT-'", statistics.py:27)
@@ -297,8 +299,17 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const u32 nwaves = gridDim.x * waves_per_block;
     u64 *raw = a.raw;
 
+    // bytes [lo, hi) of a 64-bit word from a nine-entry LDS table (entry n = the low n bytes set) instead of
+    // 64-bit shifts: the per-record byte masks of the partial steps
+    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (MDX_BLOCK / 64) * EVQ_BYTES);
+    auto brange = [&](int lo, int hi) -> u64 {
+        lo = lo < 0 ? 0 : (lo > 8 ? 8 : lo);
+        hi = hi < 0 ? 0 : (hi > 8 ? 8 : hi);
+        return ltab[hi] & ~ltab[lo];
+    };
     if (USE_LDS) {
         for (i64 i = threadIdx.x; i < d.w_total; i += MDX_BLOCK) lds[i] = 0;
+        if (FAST && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
         __syncthreads();
     }
 
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 k0 = c_side ? -(int)(z >> 24) : -((int)(z >> 16) & 0xFF);
             }
             const int jo = c_side ? c_m8 + 8 - A : A - c_m8;   // byte of column k: jo + k (left), jo - 1 - k (right)
-            const u64 dyn = act ? byte_range(c_side ? jo - k1 : jo + k0, c_side ? jo - k0 : jo + k1) : 0ull;
+            const u64 dyn = act ? brange(c_side ? jo - k1 : jo + k0, c_side ? jo - k0 : jo + k1) : 0ull;
             const u32 dyn_lo = (u32)dyn & c_vm_lo, dyn_hi = (u32)(dyn >> 32) & c_vm_hi;
             emvm_lo = c_em_lo & dyn_lo; emvm_hi = c_em_hi & dyn_hi;
             hivm_lo = dyn_lo & 0x80808080u; hivm_hi = dyn_hi & 0x80808080u;
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             u32 tcd_lo = dyn_lo, tcd_hi = dyn_hi;
             if (!MASK) {
                 if (fs | fr) {
-                    const u64 fm = byte_range(c_side ? jo - f1 : jo + f0, c_side ? jo - f0 : jo + f1);
+                    const u64 fm = brange(c_side ? jo - f1 : jo + f0, c_side ? jo - f0 : jo + f1);
                     const u32 fm_lo = (u32)fm & dyn_lo, fm_hi = (u32)(fm >> 32) & dyn_hi;
                     if (fs) { s_lo = (s_lo & ~fm_lo) | (0x2D2D2D2Du & fm_lo); s_hi = (s_hi & ~fm_hi) | (0x2D2D2D2Du & fm_hi); }
                     else { r_lo = (r_lo & ~fm_lo) | (0x84848484u & fm_lo); r_hi = (r_hi & ~fm_hi) | (0x84848484u & fm_hi); }
