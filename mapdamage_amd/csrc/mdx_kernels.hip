@@ -424,6 +424,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
         u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi, hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
         const u32 base_b = tc_base(st.pk, c_lane4);
+        // MASK: bit 7 of the bytes whose quality is below --min-basequal (align.py:65-71)
+        u32 lowq_lo = 0, lowq_hi = 0;
+        if (MASK) {
+            const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
+            const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
+            lowq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u;
+            lowq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u;
+        }
         if (complete) {
             // optimistic: count every byte as a plain match (the base class of the reference
             // byte selects the plane of TC) ...
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const int dd = (int)(i8)(st.pk & 0xFFu);
                 if (!far) {
                     k0 = -A; k1 = u;
-                    if (!MASK && (st.pk & PK_ONE) && dd > 0) { fs = true; f0 = u; k1 = u + dd < L ? u + dd : L; f1 = k1; }
+                    if ((st.pk & PK_ONE) && dd > 0) { fs = true; f0 = u; k1 = u + dd < L ? u + dd : L; f1 = k1; }
                 } else {
                     k0 = u;
                     if (dd < 0) { fr = true; f0 = u; f1 = u - dd; } else shifted = true;
@@ -466,11 +474,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             s_lo = (s_lo & dyn_lo) | (0x41414141u & ~dyn_lo); s_hi = (s_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
             r_lo = (r_lo & dyn_lo) | (0x41414141u & ~dyn_lo); r_hi = (r_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
             u32 tcd_lo = dyn_lo, tcd_hi = dyn_hi;
-            if (!MASK) {
+            {
                 if (fs | fr) {
                     const u64 fm = brange(c_side ? jo - f1 : jo + f0, c_side ? jo - f0 : jo + f1);
                     const u32 fm_lo = (u32)fm & dyn_lo, fm_hi = (u32)(fm >> 32) & dyn_hi;
-                    if (fs) { s_lo = (s_lo & ~fm_lo) | (0x2D2D2D2Du & fm_lo); s_hi = (s_hi & ~fm_hi) | (0x2D2D2D2Du & fm_hi); }
+                    if (fs) {   // (a deleted column has no quality of its own: never masked, align.py:67)
+                        s_lo = (s_lo & ~fm_lo) | (0x2D2D2D2Du & fm_lo); s_hi = (s_hi & ~fm_hi) | (0x2D2D2D2Du & fm_hi);
+                        lowq_lo &= ~fm_lo; lowq_hi &= ~fm_hi;
+                    }
                     else { r_lo = (r_lo & ~fm_lo) | (0x84848484u & fm_lo); r_hi = (r_hi & ~fm_hi) | (0x84848484u & fm_hi); }
                 }
                 if (far && shifted) {
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                             const u32 dc = (u32)(m64 >> (8 * jb)) & 1u;
                             const int p = p0 + stp * jb;
                             const int ic = b_cmp + p * 4 + (int)k;
-                            const bool mok = dc && p + g < L;
+                            const bool mok = dc && p + g < L && !(MASK && (((jb < 4 ? lowq_lo : lowq_hi) >> (8 * (jb & 3) + 7)) & 1u));
                             atomicAdd(&lds[ic], dc);                                        // (a byte that is no task adds 0
                             atomicAdd(&lds[mok ? b_mis + (p + g) * 25 + (int)k : ic], mok ? 1u : 0u);   //  to a valid word)
                         }
@@ -512,14 +523,16 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         todo &= todo - 1;
                         const u32 sb = (u32)(s64 >> sh) & 0xFFu, rb = (u32)(r64 >> sh) & 0xFFu;
                         const int p = (c_side ? c_m8 + 7 - jb : c_m8 + jb) - A;
+                        // (a masked column counts its read base only)
+                        const bool msk = MASK && (((jb < 4 ? lowq_lo : lowq_hi) >> (8 * (jb & 3) + 7)) & 1u);
                         if (sb == rb && rb < 0x80u) {   // plain match (a valid reference byte is one of A, C, G, T)
                             const int k = (int)(rb >> 1) & 3;
                             bump<USE_LDS>(lds, raw, b_cmp + p * 4 + k);
-                            if (p + g < L) bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + k);
+                            if (p + g < L && !msk) bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + k);
                         } else {
                             const int s = classify_read(sb), r = classify_ref((int)(i8)rb);
                             if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + p * 4 + s);
-                            if (p + g < L && s <= SYM_GAP && r <= SYM_GAP && (r != s || r != SYM_GAP))
+                            if (!msk && p + g < L && s <= SYM_GAP && r <= SYM_GAP && (r != s || r != SYM_GAP))
                                 bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + (r != s ? mis_col(r, s) : r));
                         }
                     }
@@ -536,11 +549,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & hivm_hi);
         u32 mq_lo = 0, mq_hi = 0;
         if (MASK) {
-            // bytes whose quality is below --min-basequal (align.py:65-71): bit 7 of the byte
-            const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
-            const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
-            mq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u & emvm_lo;
-            mq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u & emvm_hi;
+            // the masked columns of this lane: bit 7 of the byte
+            mq_lo = lowq_lo & emvm_lo;
+            mq_hi = lowq_hi & emvm_hi;
             if (USE_LDS) {
                 // a masked column counts its read base (CMP) and nothing else (align.py:65-71 turns both symbols into
                 // N): corrected here — the optimistic TC increment undone, CMP bumped — one byte per iteration, as
@@ -627,6 +638,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
         bool one = false;   // [H][S] M {I|D} M [S][H]: one indel between two match runs
+        bool skips = false; // an N or P operation (or four and more indels)
         u32 sq = 0, cig_o = 0;
         i64 rbase = 0;
         int lkey = -1;  // fragment-length key for the LDS histogram
@@ -709,6 +721,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 if (!simple) {
                     vlr = (lead_m < L ? lead_m : L) | ((cur_run < L ? cur_run : L) << 8);
                     one = n_gap == 1 && lead_m > 0 && cur_run > 0;
+                    skips = n_gap >= 4;
                 }
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
@@ -788,12 +801,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // gapped records with complete flanks: the columns of their first / last match run ride the
                 // partial-plain list (and the CIGAR walk starts behind them)
                 const int dnq = n0 - nq;
-                gpre = kept && !(w1 & D_SIMPLE) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
+                // (with --min-basequal a reference symbol is masked by the read column of the same *left* index,
+                // align.py:65-71: behind an N operation that is another base than the one it pairs with from the right
+                // end — such records keep the full CIGAR walk, which follows the quirk)
+                gpre = kept && !(w1 & D_SIMPLE) && !(MASK && skips) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
                        ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && dnq >= -127 && dnq <= 127 &&
                        sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
                 // ... and those with a single indel between two match runs are counted by the fast path entirely:
                 // a second (far) pass over their entries takes the columns behind the first / last run (count())
-                isS = !MASK && gpre && one && A + (dnq < 0 ? -dnq : dnq) <= 248;
+                isS = gpre && one && A + (dnq < 0 ? -dnq : dnq) <= 248;
                 if (gpre) {
                     w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
                     ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);

@@ -267,7 +267,7 @@ def test_hip_matches_oracle_at_scale(config):
     assert got.n_kept == 2 * want.n_kept
 
 
-def _indel_records(ref, n, seed, max_gap=130):
+def _indel_records(ref, n, seed, max_gap=130, with_qual=False):
     """Records [H][S] aM g{I|D} bM [S][H] (and some with two indels / an N) with indels of 1..max_gap bases anywhere
     in the read, 5 % substitutions and a few N bases: the shapes the single-indel fast path splits into a near and
     a far entry, its limits (|n0 - nq| <= 127, A + |n0 - nq| <= 248) and its fallbacks (the CIGAR walk)."""
@@ -305,8 +305,14 @@ def _indel_records(ref, n, seed, max_gap=130):
         seq = np.where(mut < 0.05, rng.choice(np.frombuffer(b"ACGTN", np.uint8), seq.shape[0]), seq)
         cig = ([(5, 3)] if rng.random() < 0.05 else []) + ([(4, sl)] if sl else []) + ops + \
               ([(4, sr)] if sr else []) + ([(5, 2)] if rng.random() < 0.05 else [])
+        qual = None
+        if with_qual:   # a fifth of the bases below Phred 20, a few records without qualities
+            qual = np.where(rng.random(seq.shape[0]) < 0.2, rng.integers(2, 20, seq.shape[0]),
+                            rng.integers(20, 42, seq.shape[0])).astype(np.uint8)
+            if rng.random() < 0.03:
+                qual = None
         recs.append(dict(flag=int(rng.choice([0, 16])), tid=tid, pos=pos, cigar=cig, seq=seq.tobytes().decode(),
-                         qual=None, lib=int(rng.integers(0, 2)), tlen=0))
+                         qual=qual, lib=int(rng.integers(0, 2)), tlen=0))
     return recs
 
 
@@ -368,4 +374,15 @@ def test_hip_long_reads_and_long_cigars(L, A, mid_genome):
     libs = [("s", "l")]
     want = oracle_tableset(mid_genome, batch, libs, L, A, 0)
     got = run_engine(mid_genome, batch, libs, L, A, 0, resident=True)
+    assert_tables_equal(got, want)
+
+
+@pytest.mark.parametrize("L,A", [(70, 10), (8, 3), (150, 30), (100, 12)])
+def test_hip_single_indel_shapes_with_min_basequal(L, A, mid_genome):
+    """The same shapes under --min-basequal 20: masked columns in the near and far entries, inserted columns that are
+    masked, deleted columns (never masked), records without qualities."""
+    batch = batch_from_records(_indel_records(mid_genome, 6000, 300 + L, with_qual=True), with_qual=True)
+    libs = [("s", "a"), ("s", "b")]
+    want = oracle_tableset(mid_genome, batch, libs, L, A, 20)
+    got = run_engine(mid_genome, batch, libs, L, A, 20, resident=True)
     assert_tables_equal(got, want)
