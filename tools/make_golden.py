@@ -116,10 +116,25 @@ def rescale_batch(ref, n=1500, seed=5):
     return b
 
 
+def indel_shape_cases(mref):
+    from mapdamage_amd.batch import batch_from_records
+    from tests.test_gpu_parity import _indel_records
+    save_case("indelshapes_L70_A10_Q0", mref, batch_from_records(_indel_records(mref, 2500, 901)), LIBS2, 70, 10, 0)
+    save_case("indelshapes_L70_A10_Q20", mref,
+              batch_from_records(_indel_records(mref, 2500, 902, with_qual=True), with_qual=True), LIBS2, 70, 10, 20)
+    save_case("indelshapes_L8_A3_Q20", mref,
+              batch_from_records(_indel_records(mref, 1500, 903, with_qual=True), with_qual=True), LIBS2, 8, 3, 20)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-indel-shapes", action="store_true")
     ap.add_argument("--time", action="store_true")
     args = ap.parse_args()
+    if args.only_indel_shapes:
+        indel_shape_cases(synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)),
+                                            n_run=500, lower_run=3000))
+        return
 
     # Appendix D hand vectors, tiny windows, with per-read gapped strings
     ref, batch = appendix_d_case()
@@ -155,6 +170,11 @@ def main():
     save_case("config3s_L70_A10_Q15", mref, synth.config3_batch(mref, 3000, seed=33, with_qual=True),
               LIBS1, 70, 10, 15)
     save_case("config4s_L70_A10", mref, synth.config4_batch(mref, 4000, seed=4), LIBS1, 70, 10, 0)
+
+    # single-indel shapes (indels of 1..130 bases anywhere in the read, two indels, indel + N, clips), with and
+    # without qualities: the shapes the fast path splits into near / far entries, and the mask-by-left-index quirk
+    # of align.py:65-71 behind an N operation
+    indel_shape_cases(mref)
 
     # dnacomp_genome.csv through the reference's composition.write_base_comp, with its own native
     # seqtk extension compiled into oracle/_ref (never copied): SURVEY §8f N4
