@@ -131,6 +131,37 @@ def test_hip_matches_oracle_seeded(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", range(3))
+def test_hip_rescale_fuzzed_cigars_match_oracle(k, tmp_path):
+    """The rescaling pass on the fuzzed CIGARs of tools/fuzz_vs_reference.py (without hard clips: the reference cannot
+    write a record whose clips are not plain S at the ends, rescale.py:266-271): qualities, MR, status, summary."""
+    from mapdamage_amd.batch import batch_from_records
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    from tools.fuzz_vs_reference import fuzz_records
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500,
+                            lower_run=3000)
+    recs = [r for r in fuzz_records(ref, 5000, 8100 + k, with_qual=True) if all(op != 5 for op, _ in r["cigar"])]
+    b = batch_from_records(recs, with_qual=True)
+    rng = np.random.default_rng(30 + k)
+    b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
+    b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
+    want_q, want_mr, want_st, want_counts, want_pvals = oracle.rescale_with_subs(
+        ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        got_q, got_mr, got_st = eng.rescale(b)
+        words = eng.rescale_summary()
+    np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))
+    np.testing.assert_array_equal(got_q, want_q)
+    np.testing.assert_array_equal(got_st, want_st)
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+
+
+@pytest.mark.gpu
 def test_cli_rescale_only_rewrites_bam(tmp_path):
     """`--rescale-only`: every record written back, new qualities + MR:f on the rescaled ones,
     untouched fields preserved."""
