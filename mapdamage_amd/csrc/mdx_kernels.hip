@@ -685,7 +685,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const int side = tl == 0 ? 0 : 1;
                     const int m = len < L ? (int)len : L;
                     const int base = lbase + ((rev * 2 + side) * L) * 25 + COL_S;
-                    for (int x = 0; x < m; x++) bump<USE_LDS>(lds, raw, base + x * 25);
+                    // positions [0, m) as a difference: +1 at 0, -1 at m (finalize_kernel sums the prefix; the
+                    // partial tables are folded as signed words) instead of m increments
+                    if (m > 0) {
+                        bump<USE_LDS>(lds, raw, base);
+                        if (m < L) {
+                            if (USE_LDS) atomicAdd(&lds[base + m * 25], 0xFFFFFFFFu);
+                            else atomicAdd(&raw[base + m * 25], ~0ull);
+                        }
+                    }
                 }
             }
             i64 qe = lseq;
@@ -1097,7 +1105,7 @@ __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__
     const int part = blockIdx.y;
     const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
     u64 acc = 0;
-    for (int b = b0; b < b1; b++) acc += partials[(i64)b * w_total + w];
+    for (int b = b0; b < b1; b++) acc += (u64)(i64)(int)partials[(i64)b * w_total + w];   // signed (soft-clip differences)
     if (acc) atomicAdd(w == w_total - 1 ? raw_tail : &raw[w], acc);
 }
 
@@ -1142,7 +1150,12 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
                 for (int x = 0; x < 4; x++) v += raw[row + c_refcols[k * 4 + x]];
             } else {
                 const int rc = strand ? c_comp_col[col] : col;
-                v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
+                if (col == COL_S) {   // soft clips are stored as differences over the positions
+                    v = 0;
+                    for (int q = 0; q <= p; q++) v += raw[lb + ((strand * 2 + side) * L + q) * 25 + COL_S];
+                } else {
+                    v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
+                }
             }
         } else if (i < n_mis + n_comp) {
             i64 x = i - n_mis;

@@ -56,7 +56,7 @@ def _damage_probs(maxlen):
 def make_reads(ref, n, seed, read_len=100, len_range=None, nlib=1, paired=False,
                frac_reverse=0.5, frac_softclip=0.0, frac_ins=0.0, frac_del=0.0,
                frac_skip=0.0, frac_hardclip=0.0, frac_filtered=0.0, frac_n_base=0.0,
-               with_qual=False, damage=True, contigs=None, chunk=500_000, sort=False):
+               with_qual=False, damage=True, contigs=None, chunk=500_000, sort=False, clip_max=10):
     """Vectorised read generator.  Returns a ``ReadBatch``.
 
     ``len_range=(lo, hi)`` draws SEQ lengths uniformly (config 4); otherwise all reads
@@ -78,7 +78,7 @@ def make_reads(ref, n, seed, read_len=100, len_range=None, nlib=1, paired=False,
         out.append(_make_chunk(rng, m, upper, offs, lens, contigs, weights, read_len, len_range,
                                nlib, paired, frac_reverse, frac_softclip, frac_ins, frac_del,
                                frac_skip, frac_hardclip, frac_filtered, frac_n_base, with_qual,
-                               damage))
+                               damage, clip_max))
         done += m
     batch = out[0] if len(out) == 1 else concat_batches(out)
     if sort:
@@ -107,7 +107,7 @@ def _permute_fixed(batch, order):
 
 def _make_chunk(rng, n, upper, offs, lens, contigs, weights, read_len, len_range, nlib, paired,
                 frac_reverse, frac_softclip, frac_ins, frac_del, frac_skip, frac_hardclip,
-                frac_filtered, frac_n_base, with_qual, damage):
+                frac_filtered, frac_n_base, with_qual, damage, clip_max=10):
     from numpy.lib.stride_tricks import sliding_window_view
     if len_range is None:
         qlen = np.full(n, read_len, dtype=np.int64)
@@ -120,8 +120,8 @@ def _make_chunk(rng, n, upper, offs, lens, contigs, weights, read_len, len_range
     u = rng.random(n)
     has_clip = u < frac_softclip
     side = rng.integers(0, 3, size=n)  # 0 left, 1 right, 2 both
-    a = np.where(has_clip & (side != 1), rng.integers(1, 11, size=n), 0).astype(np.int64)
-    b = np.where(has_clip & (side != 0), rng.integers(1, 11, size=n), 0).astype(np.int64)
+    a = np.where(has_clip & (side != 1), rng.integers(1, clip_max + 1, size=n), 0).astype(np.int64)
+    b = np.where(has_clip & (side != 0), rng.integers(1, clip_max + 1, size=n), 0).astype(np.int64)
     over = (a + b) > (qlen - 20)  # keep at least 20 aligned bases
     a[over] = 0
     b[over] = 0

@@ -23,6 +23,8 @@ VARIANTS = [
     ("len 70-150", dict(len_range=(70, 150))),
     ("len 35-150", dict(len_range=(35, 150))),
     ("len 35-69", dict(len_range=(35, 69))),
+    ("softclip 30%, 1-40 bases (local alignment)", dict(read_len=150, frac_softclip=0.30, clip_max=40)),
+    ("150 bp, no clips", dict(read_len=150)),
     ("config 4", dict(len_range=(35, 150), frac_softclip=0.10, frac_ins=0.04, frac_del=0.04, frac_skip=0.002,
                       frac_hardclip=0.001)),
 ]
