@@ -99,7 +99,9 @@ int mdx_batch_free(mdx_ctx *ctx, mdx_batch *dev);
  * (reader.py:121-132), coordinates/flanks (align.py:14-35), CIGAR gapping with optional
  * quality masking (align.py:38-88), strand step (main.py:200-205), and the accumulator
  * updates (statistics.py:22-51,75-93,117-126).  Accumulates; may be called repeatedly.
- * _host: columns in host memory (staged H2D on the stream); _device: columns already in HBM. */
+ * _host: columns in (pageable) host memory, copied through two pinned bounce buffers of the context, the call
+ * returns when the last column has left the caller's buffers; _device: columns already in HBM.
+ * More libraries than fit the LDS at once: one kernel launch per group of libraries, transparently. */
 int mdx_tabulate_host(mdx_ctx *ctx, const mdx_batch *batch);
 int mdx_tabulate_device(mdx_ctx *ctx, const mdx_batch *batch);
 
