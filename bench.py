@@ -9,8 +9,9 @@ RCCL all-reduce at the end of the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (240 B/read x reads) / average tabulation-kernel duration measured with HIP
-events on the launch stream.  `cpu_baseline` = the C oracle (oracle/mdx_oracle.c, 1 thread)
-on the same batch, which also serves as the bit-exactness check of the GPU tables.
+events on the launch stream.  `cpu_baseline` = the C oracle (oracle/mdx_oracle.c) on the same
+batch on the host's threads (`cores`; the one-thread rate is quoted in `sample`), which also
+serves as the bit-exactness check of the GPU tables.
 """
 
 import argparse
