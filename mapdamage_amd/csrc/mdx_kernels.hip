@@ -804,7 +804,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             ent.z = (u32)nq | ((u32)(w1 >> D_NB_SHIFT) << 16);
             ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                     ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
-            bool gpre = false, isS = false;
+            bool gpre = false, isS = false, covered = false;
             if (MDX_PREFIX && __ballot(kept && !(w1 & D_SIMPLE))) {   // (wave-uniform: tiles of plain records skip this)
                 // gapped records with complete flanks: the columns of their first / last match run ride the
                 // partial-plain list (and the CIGAR walk starts behind them)
@@ -813,21 +813,25 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // align.py:65-71: behind an N operation that is another base than the one it pairs with from the right
                 // end — such records keep the full CIGAR walk, which follows the quirk)
                 gpre = kept && !(w1 & D_SIMPLE) && !(MASK && skips) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
-                       ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && dnq >= -127 && dnq <= 127 &&
+                       ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && dnq >= -1023 && dnq <= 1023 &&
                        sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
                 // ... and those with a single indel between two match runs are counted by the fast path entirely:
                 // a second (far) pass over their entries takes the columns behind the first / last run (count())
-                isS = gpre && one && A + (dnq < 0 ? -dnq : dnq) <= 248;
+                isS = gpre && one && dnq >= -127 && dnq <= 127 && A + (dnq < 0 ? -dnq : dnq) <= 248;
                 if (gpre) {
                     w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
                     ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);
-                    ent.w |= ((u32)dnq & 0xFFu) | (isS ? PK_ONE : 0u);
+                    // n0 - nq: 11 bits, the low eight in the low byte (all a D_ONE entry needs), the rest in [23:21]
+                    ent.w |= ((u32)dnq & 0xFFu) | ((((u32)dnq >> 8) & 7u) << 21) | (isS ? PK_ONE : 0u);
+                    // both runs reach --length: the entry covers every task of the record, nothing is left to walk
+                    // (an N between two long match runs: a spliced read)
+                    covered = !isS && (vlr & 0xFF) == L && (vlr >> 8) == L;
                 }
                 mP |= __ballot(gpre && !isS);
                 mS = __ballot(isS);
             }
             nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS);
-            todo_g = todo_all & ~(mF | mPp | mS);
+            todo_g = todo_all & ~(mF | mPp | mS | __ballot(covered));
             if (mF | mP | mS) {
                 int idx = isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF);
                 if (mS && isS) idx = mbcnt64(mS, nF + nP);
@@ -1010,7 +1014,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const u32 so = ent.y + c_so + t;
                     // gapped record (partial list only), d = n0 - nq: the right windows hang off aend = pos + n0, not
                     // pos + nq; in the far pass they hang off pos + nq and the left ones off pos + d
-                    if (!complete) ro += ((c_cm != 0u) != far) ? (u32)(int)(i8)(ent.w & 0xFFu) : 0u;
+                    if (!complete) {
+                        const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));   // n0 - nq, 11 bits signed
+                        ro += ((c_cm != 0u) != far) ? (u32)((dd11 << 21) >> 21) : 0u;
+                    }
                     st.ro = ro; st.so = so;
                     st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                     st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
