@@ -185,6 +185,20 @@ int32_t mdx_bam_n_rg(const mdx_bam *bam);
 const char *mdx_bam_rg_name(const mdx_bam *bam, int32_t i);
 const char *mdx_bam_qnames(const mdx_bam *bam, const uint32_t **offsets);
 
+/* Streaming form of the same decoder, for files larger than host memory and to overlap decoding with
+ * tabulation (the reference iterates its AlignmentFile record by record, mapdamage/main.py:165; here the
+ * unit is a chunk of records).  mdx_bam_open parses the header (mdx_bam_stream_header: a record-less
+ * mdx_bam for the accessors above, owned by the stream, whose mdx_bam_error also carries stream errors).
+ * mdx_bam_next returns the complete records within the next chunk_bytes of uncompressed BAM data as a new
+ * mdx_bam (caller frees with mdx_bam_free; independent of the stream), *out = NULL at end of file.  Records
+ * come in file order; rg_index of a chunk indexes that chunk's own mdx_bam_rg_name().  One thread per
+ * stream; chunks may be consumed on other threads. */
+typedef struct mdx_bam_stream mdx_bam_stream;
+int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out);
+const mdx_bam *mdx_bam_stream_header(const mdx_bam_stream *stream);
+int mdx_bam_next(mdx_bam_stream *stream, int64_t chunk_bytes, mdx_bam **out);
+void mdx_bam_close(mdx_bam_stream *stream);
+
 /* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
 int mdx_table_mode(const mdx_ctx *ctx);
 

@@ -47,6 +47,18 @@ struct mdx_bam {
     std::vector<uint8_t> has_mr;
 };
 
+
+// Streaming decode: the file is consumed a slab of BGZF blocks at a time, so host memory is bounded by the
+// chunk size and the caller can tabulate chunk k while chunk k+1 is being decoded.
+struct mdx_bam_stream {
+    mdx_bam head;                    // header text + reference dictionary (no records); also carries the error text
+    FILE *fp = nullptr;
+    int threads = 1;
+    bool eof = false;
+    std::vector<uint8_t> cbuf;       // compressed bytes read but not inflated yet (a partial block at most, between calls)
+    raw_bytes pending;               // inflated bytes not unpacked yet (a partial record at most, between calls)
+};
+
 namespace {
 
 struct Block { size_t in_off, in_size, out_off, out_size; };
@@ -55,22 +67,29 @@ inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); 
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
 
-bool scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, size_t &total, std::string &err) {
+// `partial`: the buffer may end inside a block (streaming); the scan stops there and `consumed` says how far
+// it got.  Otherwise a truncated block is an error.
+bool scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, size_t &total, std::string &err,
+                 bool partial = false, size_t *consumed = nullptr) {
     size_t off = 0;
     total = 0;
+    if (consumed) *consumed = 0;
     while (off < file.size()) {
+        if (partial && off + 18 > file.size()) break;
         if (off + 18 > file.size() || file[off] != 0x1f || file[off + 1] != 0x8b || !(file[off + 3] & 4)) {
             err = "not a BGZF-compressed file";
             return false;
         }
         const size_t xlen = rd16(&file[off + 10]);
         size_t x = off + 12, xend = x + xlen;
+        if (partial && xend > file.size()) break;
         size_t bsize = 0;
         while (x + 4 <= xend && xend <= file.size()) {
             const size_t slen = rd16(&file[x + 2]);
             if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&file[x + 4]) + 1;
             x += 4 + slen;
         }
+        if (partial && bsize && bsize >= xlen + 20 && off + bsize > file.size()) break;
         if (!bsize || off + bsize > file.size() || bsize < xlen + 20) { err = "corrupt BGZF block"; return false; }
         Block b;
         b.in_off = off + 12 + xlen;
@@ -80,6 +99,7 @@ bool scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, s
         total += b.out_size;
         blocks.push_back(b);
         off += bsize;
+        if (consumed) *consumed = off;
     }
     return true;
 }
@@ -117,75 +137,50 @@ void parallel_for(size_t n, int threads, F body) {
     for (auto &th : pool) th.join();
 }
 
-}  // namespace
-
-extern "C" {
-
-int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
-    if (!path || !out) return MDX_ERR_ARG;
-    mdx_bam *b = new (std::nothrow) mdx_bam();
-    if (!b) return MDX_ERR_ARG;
-    *out = b;
-    // MDX_BAM_TIMING=1: stage times on stderr
-    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "mdx_bam_read %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
-    std::vector<uint8_t> file;
-    {
-        FILE *fp = std::fopen(path, "rb");
-        if (!fp) { b->error = std::string("cannot open ") + path; return MDX_ERR_ARG; }
-        std::fseek(fp, 0, SEEK_END);
-        const long sz = std::ftell(fp);
-        std::fseek(fp, 0, SEEK_SET);
-        file.resize(sz > 0 ? (size_t)sz : 0);
-        const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), fp);
-        std::fclose(fp);
-        if (got != file.size()) { b->error = "short read"; return MDX_ERR_ARG; }
-    }
-    lap("file read");
-    std::vector<Block> blocks;
-    size_t total = 0;
-    if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
-    lap("block scan");
-    raw_bytes data(total + 8);
-    std::atomic<bool> ok{true};
-    parallel_for(blocks.size(), threads, [&](size_t i) {
-        const Block &k = blocks[i];
-        if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
-    });
-    if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
-    lap("inflate");
-    std::vector<uint8_t>().swap(file);
-
-    if (total < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) { b->error = "not a BAM file"; return MDX_ERR_ARG; }
+// BAM magic, header text and reference dictionary at the start of the uncompressed stream.  Returns 0 and the
+// offset of the first record, 1 when `partial` and the header is not complete yet, -1 on a corrupt header.
+int parse_header(mdx_bam *b, const uint8_t *data, size_t total, bool partial, size_t *first_record) {
+    b->header_text.clear(); b->ref_names.clear(); b->ref_lengths.clear();
+    if (total < 12) { if (partial) return 1; b->error = "not a BAM file"; return -1; }
+    if (std::memcmp(data, "BAM\1", 4) != 0) { b->error = "not a BAM file"; return -1; }
     size_t off = 4;
     const int32_t l_text = rdi32(&data[off]);
     off += 4;
-    if (l_text < 0 || off + (size_t)l_text + 4 > total) { b->error = "corrupt BAM header"; return MDX_ERR_ARG; }
-    b->header_text.assign((const char *)&data[off], std::strlen((const char *)&data[off]) < (size_t)l_text
-                                                         ? std::strlen((const char *)&data[off]) : (size_t)l_text);
+    if (l_text < 0) { b->error = "corrupt BAM header"; return -1; }
+    if (off + (size_t)l_text + 4 > total) { if (partial) return 1; b->error = "corrupt BAM header"; return -1; }
+    b->header_text.assign((const char *)&data[off], strnlen((const char *)&data[off], (size_t)l_text));
     off += l_text;
     const int32_t n_ref = rdi32(&data[off]);
     off += 4;
     for (int32_t i = 0; i < n_ref; i++) {
-        if (off + 4 > total) { b->error = "corrupt BAM header"; return MDX_ERR_ARG; }
+        if (off + 4 > total) { if (partial) return 1; b->error = "corrupt BAM header"; return -1; }
         const int32_t l_name = rdi32(&data[off]);
-        if (l_name < 1 || off + 8 + (size_t)l_name > total) { b->error = "corrupt BAM header"; return MDX_ERR_ARG; }
+        if (l_name < 1) { b->error = "corrupt BAM header"; return -1; }
+        if (off + 8 + (size_t)l_name > total) { if (partial) return 1; b->error = "corrupt BAM header"; return -1; }
         b->ref_names.emplace_back((const char *)&data[off + 4], (size_t)l_name - 1);
         b->ref_lengths.push_back(rdi32(&data[off + 4 + l_name]));
         off += 8 + l_name;
     }
+    *first_record = off;
+    return 0;
+}
+
+// Records of data[off, total) -> the SoA columns of `b`.  `partial`: data may end inside a record; `consumed`
+// is the offset of the first byte not unpacked.
+template <class Lap>
+int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, int threads, bool partial,
+                   size_t *consumed, Lap lap) {
     // pass 1 (sequential): record starts and the prefix sums that size the ragged columns
     std::vector<size_t> rec;
     std::vector<uint32_t> coff{0}, soff{0}, noff{0};
     while (off + 4 <= total) {
         const int32_t bs = rdi32(&data[off]);
-        if (bs < 32 || off + 4 + (size_t)bs > total) { b->error = "corrupt BAM record"; return MDX_ERR_ARG; }
+        if (bs < 32) { b->error = "corrupt BAM record"; return MDX_ERR_ARG; }
+        if (off + 4 + (size_t)bs > total) {
+            if (partial) break;      // the record continues in the next chunk
+            b->error = "corrupt BAM record";
+            return MDX_ERR_ARG;
+        }
         const uint8_t *r = &data[off + 4];
         const uint32_t l_name = r[8], n_cig = rd16(r + 12);
         const int32_t l_seq = rdi32(r + 16);
@@ -202,6 +197,7 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
         off += 4 + (size_t)bs;
     }
     const size_t n = rec.size();
+    *consumed = off;
     lap("record scan");
     b->flag.resize(n); b->lib.assign(n, 0); b->tid.resize(n); b->pos.resize(n); b->tlen.resize(n);
     b->mtid.resize(n); b->mpos.resize(n); b->rg_index.assign(n, -1); b->has_mr.assign(n, 0);
@@ -278,6 +274,83 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
     return MDX_OK;
 }
 
+// Reads about `want` compressed bytes, inflates every complete block among them and appends the result to
+// s->pending.  Returns false on an I/O or format error (text in s->head.error).
+bool stream_fill(mdx_bam_stream *s, size_t want) {
+    if (s->eof) return true;
+    const size_t have = s->cbuf.size();
+    s->cbuf.resize(have + want);
+    const size_t got = std::fread(s->cbuf.data() + have, 1, want, s->fp);
+    s->cbuf.resize(have + got);
+    if (got < want) {
+        if (std::ferror(s->fp)) { s->head.error = "read error"; return false; }
+        s->eof = true;
+    }
+    std::vector<Block> blocks;
+    size_t total = 0, consumed = 0;
+    if (!scan_blocks(s->cbuf, blocks, total, s->head.error, !s->eof, &consumed)) return false;
+    const size_t base = s->pending.size();
+    s->pending.resize(base + total);
+    std::atomic<bool> ok{true};
+    parallel_for(blocks.size(), s->threads, [&](size_t i) {
+        const Block &k = blocks[i];
+        if (!inflate_block(&s->cbuf[k.in_off], k.in_size, &s->pending[base + k.out_off], k.out_size)) ok = false;
+    });
+    if (!ok) { s->head.error = "inflate failed"; return false; }
+    s->cbuf.erase(s->cbuf.begin(), s->cbuf.begin() + (std::ptrdiff_t)consumed);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
+    if (!path || !out) return MDX_ERR_ARG;
+    mdx_bam *b = new (std::nothrow) mdx_bam();
+    if (!b) return MDX_ERR_ARG;
+    *out = b;
+    // MDX_BAM_TIMING=1: stage times on stderr
+    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mdx_bam_read %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    std::vector<uint8_t> file;
+    {
+        FILE *fp = std::fopen(path, "rb");
+        if (!fp) { b->error = std::string("cannot open ") + path; return MDX_ERR_ARG; }
+        std::fseek(fp, 0, SEEK_END);
+        const long sz = std::ftell(fp);
+        std::fseek(fp, 0, SEEK_SET);
+        file.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), fp);
+        std::fclose(fp);
+        if (got != file.size()) { b->error = "short read"; return MDX_ERR_ARG; }
+    }
+    lap("file read");
+    std::vector<Block> blocks;
+    size_t total = 0;
+    if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
+    lap("block scan");
+    raw_bytes data(total + 8);
+    std::atomic<bool> ok{true};
+    parallel_for(blocks.size(), threads, [&](size_t i) {
+        const Block &k = blocks[i];
+        if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
+    });
+    if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
+    lap("inflate");
+    std::vector<uint8_t>().swap(file);
+
+    size_t off = 0, used = 0;
+    if (parse_header(b, data.data(), total, false, &off) != 0) return MDX_ERR_ARG;
+    return unpack_records(b, data.data(), off, total, threads, false, &used, lap);
+}
+
 void mdx_bam_free(mdx_bam *b) { delete b; }
 
 const char *mdx_bam_error(const mdx_bam *b) { return b ? b->error.c_str() : "null handle"; }
@@ -320,6 +393,62 @@ const char *mdx_bam_qnames(const mdx_bam *b, const uint32_t **offsets) {
     if (!b) return "";
     if (offsets) *offsets = b->qname_off.data();
     return b->qnames.data();
+}
+
+int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
+    if (!path || !out) return MDX_ERR_ARG;
+    mdx_bam_stream *s = new (std::nothrow) mdx_bam_stream();
+    if (!s) return MDX_ERR_ARG;
+    *out = s;
+    s->threads = threads < 1 ? 1 : threads;
+    s->fp = std::fopen(path, "rb");
+    if (!s->fp) { s->head.error = std::string("cannot open ") + path; return MDX_ERR_ARG; }
+    // the header may span several blocks: inflate until it parses
+    for (;;) {
+        if (!stream_fill(s, (size_t)1 << 20)) return MDX_ERR_ARG;
+        size_t first = 0;
+        const int rc = parse_header(&s->head, s->pending.data(), s->pending.size(), !s->eof, &first);
+        if (rc < 0) return MDX_ERR_ARG;
+        if (rc == 0) {
+            s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)first);
+            return MDX_OK;
+        }
+    }
+}
+
+const mdx_bam *mdx_bam_stream_header(const mdx_bam_stream *s) { return s ? &s->head : nullptr; }
+
+int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
+    if (!s || !out || !s->fp) return MDX_ERR_ARG;
+    *out = nullptr;
+    size_t limit = chunk_bytes < 64 ? 64 : (size_t)chunk_bytes;       // uncompressed BAM bytes per chunk
+    for (;;) {
+        // BGZF members hold at most 64 KiB each; BAM compresses about 3-4x
+        while (!s->eof && s->pending.size() < limit)
+            if (!stream_fill(s, std::max<size_t>(limit / 4, (size_t)1 << 16))) return MDX_ERR_ARG;
+        const size_t total = std::min(limit, s->pending.size());
+        const bool partial = !(s->eof && total == s->pending.size());
+        if (!partial && total < 4) return MDX_OK;                      // end of file: *out stays NULL
+        mdx_bam *b = new (std::nothrow) mdx_bam();
+        if (!b) return MDX_ERR_ARG;
+        b->header_text = s->head.header_text;
+        b->ref_names = s->head.ref_names;
+        b->ref_lengths = s->head.ref_lengths;
+        size_t used = 0;
+        const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, [](const char *) {});
+        if (rc != MDX_OK) { s->head.error = b->error; delete b; return rc; }
+        s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
+        if (!b->flag.empty()) { *out = b; return MDX_OK; }
+        delete b;
+        if (!partial) return MDX_OK;
+        limit *= 2;                                                    // a record larger than the chunk: widen
+    }
+}
+
+void mdx_bam_close(mdx_bam_stream *s) {
+    if (!s) return;
+    if (s->fp) std::fclose(s->fp);
+    delete s;
 }
 
 }  // extern "C"

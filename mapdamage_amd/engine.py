@@ -27,6 +27,7 @@ EXPORTS = (
     "mdx_rescale_summary_words", "mdx_rescale_summary",
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
+    "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
 )
 
 
@@ -97,6 +98,11 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
     for name in ("mdx_bam_ref_name", "mdx_bam_ref_length", "mdx_bam_rg_name"):
         getattr(lib, name).argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mdx_bam_stream_header.restype = ctypes.c_void_p
+    lib.mdx_bam_stream_header.argtypes = [ctypes.c_void_p]
+    lib.mdx_bam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.mdx_bam_close.restype = None
+    lib.mdx_bam_close.argtypes = [ctypes.c_void_p]
     if path is None:
         _lib = lib
     return lib

@@ -75,6 +75,9 @@ def build_parser():
                    help="EXPERIMENTAL: also write 5pCtoT_freq.txt / 3pGtoA_freq.txt (mapDamage 2.0-2.2 outputs that "
                         "this reference snapshot no longer produces; format unpinned)")
     g.add_argument("--batch-reads", type=int, default=4_000_000, help="records per device batch")
+    g.add_argument("--chunk-mb", type=_ranged(float, 0), default=1024,
+                   help="decode a BAM file in chunks of this many MiB of uncompressed records, overlapped with "
+                        "the tabulation of the previous chunk (0: decode the whole file first)")
     return p
 
 
@@ -167,7 +170,8 @@ def main(argv):
             logger.info("Starting rescaling...")
             return rescale_qual(options)
         reader = BAMReader(options.filename, merge_libraries=options.merge_libraries,
-                           downsample_to=options.downsample, downsample_seed=options.downsample_seed)
+                           downsample_to=options.downsample, downsample_seed=options.downsample_seed,
+                           chunk_bytes=int(options.chunk_mb * (1 << 20)))
         reflengths = reader.get_references()
         fai_lengths = read_fasta_index(str(options.ref) + ".fai")
         if not fai_lengths:
@@ -182,19 +186,19 @@ def main(argv):
             logger.info("Filtering out bases with a Phred score < %d", options.minqual)
         logger.info("Writing results to '%s/'", options.folder)
 
-        indices = reader.kept_indices()
-        batch = reader.handle.batch
-        if len(indices) != batch.n:
-            batch = batch.take(indices)
-        batch.lib = reader.library_column(indices)
-        if options.minqual and batch.n and not (batch.qual != 0xFF).any():
-            logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
-
         with DamageEngine(libraries, options.length, options.around, options.minqual,
                           device=options.device) as engine:
             engine.set_reference(ref)
-            for lo in range(0, batch.n, options.batch_reads):
-                engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
+            n_reads, any_qual = 0, False
+            # a BAM file arrives in chunks (bounded host memory; chunk k+1 is decoded while chunk k is tabulated)
+            for batch in reader.iter_batches():
+                n_reads += batch.n
+                if options.minqual and not any_qual:
+                    any_qual = bool((batch.qual != 0xFF).any())
+                for lo in range(0, batch.n, options.batch_reads):
+                    engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
+            if options.minqual and n_reads and not any_qual:
+                logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
             tables = engine.finish()
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)

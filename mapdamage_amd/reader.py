@@ -8,17 +8,32 @@ import random
 import numpy as np
 
 from . import layout as L
-from .sam import Alignments, BAMError, read_alignments
+from .batch import ReadBatch
+from .sam import Alignments, BamStream, BAMError, is_bam, read_alignments
 
 
 class BAMReader:
-    def __init__(self, filepath, merge_libraries=False, downsample_to=None, downsample_seed=None):
+    def __init__(self, filepath, merge_libraries=False, downsample_to=None, downsample_seed=None,
+                 chunk_bytes=None):
+        """``chunk_bytes``: decode a BAM file in chunks of that many uncompressed bytes (``iter_batches``
+        then yields one batch per chunk and ``handle`` holds the header only) instead of all at once.
+        Downsampling to a fixed number of reads needs the whole file (reservoir + coordinate sort,
+        reader.py:148-164) and SAM text is small-file territory: both keep the one-piece decode."""
         log = logging.getLogger(__name__)
         self.filepath = filepath
         self.downsample_to = downsample_to
         self.downsample_seed = downsample_seed
         self.is_stream = str(filepath) == "-"
-        self.handle: Alignments = read_alignments(filepath)
+        self._chunks = None
+        if chunk_bytes and is_bam(filepath) and (downsample_to is None or downsample_to < 1):
+            self._chunks = BamStream(filepath, chunk_bytes=chunk_bytes)
+            empty = ReadBatch(np.zeros(0, np.uint16), np.zeros(0, np.uint16), np.zeros(0, np.int32),
+                              np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(1, np.uint32),
+                              np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros(0, np.uint8),
+                              np.zeros(0, np.uint8))
+            self.handle = Alignments(self._chunks.header, empty, [], [])
+        else:
+            self.handle: Alignments = read_alignments(filepath)
         self._merge_libraries = merge_libraries
         self._readgroups = {}
         self._libraries = {}
@@ -48,14 +63,45 @@ class BAMReader:
                                "--merge-libraries" % (readgroup.get("ID", "Unnamed readgroup"), error))
         return readgroups
 
-    def kept_indices(self):
+    def iter_batches(self):
+        """The records the reference would iterate over (reader.py:83-96, 121-164), in its order, as
+        ``ReadBatch``es with the library column filled in: one per decoded chunk, or the whole file
+        at once.  The decode of chunk k+1 runs on a helper thread while the caller works on chunk k."""
+        if self._chunks is None:
+            indices = self.kept_indices()
+            batch = self.handle.batch
+            if len(indices) != batch.n:
+                batch = batch.take(indices)
+            batch.lib = self.library_column(indices)
+            yield batch
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        rand = random.Random(self.downsample_seed)
+        with ThreadPoolExecutor(1) as pool:
+            pending = pool.submit(self._chunks.next_chunk)
+            while True:
+                chunk = pending.result()
+                if chunk is None:
+                    break
+                pending = pool.submit(self._chunks.next_chunk)
+                indices = self.kept_indices(chunk, rand)
+                batch = chunk.batch
+                if len(indices) != batch.n:
+                    batch = batch.take(indices)
+                batch.lib = self.library_column(indices, chunk)
+                yield batch
+        self._chunks.close()
+
+    def kept_indices(self, handle=None, rand=None):
         """Indices of the records the reference would iterate over, in its order
-        (reader.py:83-96, 121-164)."""
-        flag = self.handle.batch.flag
+        (reader.py:83-96, 121-164).  ``handle``/``rand``: one chunk of a file decoded in pieces, and
+        the generator that carries the --downsample stream of draws across chunks."""
+        flag = (handle or self.handle).batch.flag
         kept = np.nonzero((flag & L.FLAG_FILTER) == 0)[0]
         if self.downsample_to is None:
             return kept
-        rand = random.Random(self.downsample_seed)
+        if rand is None:
+            rand = random.Random(self.downsample_seed)
         if self.downsample_to < 1:
             return np.asarray([i for i in kept if rand.random() < self.downsample_to], dtype=np.int64)
         size = int(self.downsample_to)
@@ -71,14 +117,14 @@ class BAMReader:
         result.sort(key=lambda r: (int(b.tid[r]), int(b.pos[r])))
         return np.asarray(result, dtype=np.int64)
 
-    def library_column(self, indices):
+    def library_column(self, indices, handle=None):
         """Library id (index into ``get_libraries()``) of each selected record; raises
         ``BAMError`` like reader.py:63-81 for a missing or unknown read group."""
         libs = self.get_libraries()
         if self._merge_libraries:
             return np.zeros(len(indices), np.uint16)
         index_of = {rg: libs.index(lib) for rg, lib in self._readgroups.items()}
-        h = self.handle
+        h = handle or self.handle
         if h._rg is None and h.rg_index is not None:
             # native decoder: read groups are small integers already — one table lookup for all records
             ri = h.rg_index[np.asarray(indices, dtype=np.int64)]
@@ -86,19 +132,20 @@ class BAMReader:
             lib = lut[ri]     # (index -1 = no RG tag -> the trailing -1)
             bad = np.nonzero(lib < 0)[0]
             if bad.size:
-                self._raise_readgroup(int(indices[int(bad[0])]), None if ri[bad[0]] < 0 else h.rg_names[int(ri[bad[0]])])
+                self._raise_readgroup(int(indices[int(bad[0])]), None if ri[bad[0]] < 0 else h.rg_names[int(ri[bad[0]])], h)
             return lib.astype(np.uint16)
         out = np.zeros(len(indices), np.uint16)
         for k, i in enumerate(indices):
             rg = h.rg[i]
             if rg is None or rg not in index_of:
-                self._raise_readgroup(i, rg)
+                self._raise_readgroup(i, rg, h)
             out[k] = index_of[rg]
         return out
 
-    def _raise_readgroup(self, i, rg):
+    def _raise_readgroup(self, i, rg, handle=None):
+        handle = handle or self.handle
         if rg is None:
             raise BAMError("Read %r has no read-group. Either fix BAM or use --merge-libraries"
-                           % (self.handle.qname_at(i),))
+                           % (handle.qname_at(i),))
         raise BAMError("Read %r has read-group not listed in BAM header (%r); either fix BAM "
-                       "or use --merge-libraries" % (self.handle.qname_at(i), rg))
+                       "or use --merge-libraries" % (handle.qname_at(i), rg))

@@ -249,27 +249,23 @@ class _NativeBam:
             self._handle = None
 
 
-def read_bam_native(path, threads=None):
-    """BAM -> ``Alignments`` through the C++ decoder of libmdx.so (multi-threaded BGZF inflate,
-    records unpacked straight into the SoA columns; include/mdx.h ``mdx_bam_*``).  The columns are numpy
-    views of the decoder's buffers (no copy); every view keeps the decoder alive."""
-    import ctypes
-    import os
-
-    from .engine import MdxBatch, load_library
-    lib = load_library()
-    handle = ctypes.c_void_p()
-    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
-                          ctypes.byref(handle))
-    owner = _NativeBam(lib, handle)
-    if rc != 0:
-        raise ValueError("%r: %s" % (str(path), lib.mdx_bam_error(handle).decode() if handle else "BAM decode failed"))
+def _native_header(lib, handle):
     header = Header(lib.mdx_bam_header_text(handle).decode())
     n_ref = lib.mdx_bam_n_ref(handle)
-    names = [lib.mdx_bam_ref_name(handle, i).decode() for i in range(n_ref)]
-    lengths = [int(lib.mdx_bam_ref_length(handle, i)) for i in range(n_ref)]
     if not header.references:
-        header.references, header.lengths = names, lengths
+        header.references = [lib.mdx_bam_ref_name(handle, i).decode() for i in range(n_ref)]
+        header.lengths = [int(lib.mdx_bam_ref_length(handle, i)) for i in range(n_ref)]
+    return header
+
+
+def _native_alignments(lib, handle, owner, header=None):
+    """``Alignments`` over the columns of a decoded ``mdx_bam`` (numpy views, no copy; every view keeps
+    ``owner`` and with it the decoder's buffers alive)."""
+    import ctypes
+
+    from .engine import MdxBatch
+    if header is None:
+        header = _native_header(lib, handle)
     view = MdxBatch()
     mtid, mpos, rgi, hmr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
     lib.mdx_bam_batch(handle, ctypes.byref(view), ctypes.byref(mtid), ctypes.byref(mpos), ctypes.byref(rgi),
@@ -299,6 +295,90 @@ def read_bam_native(path, threads=None):
     al._qblob = col(blob_ptr, int(al._qoff[-1]), np.uint8) if n else np.zeros(0, np.uint8)
     al.has_mr = col(hmr.value, n, np.uint8).view(bool)
     return al
+
+
+def read_bam_native(path, threads=None):
+    """BAM -> ``Alignments`` through the C++ decoder of libmdx.so (multi-threaded BGZF inflate,
+    records unpacked straight into the SoA columns; include/mdx.h ``mdx_bam_*``).  The columns are numpy
+    views of the decoder's buffers (no copy); every view keeps the decoder alive."""
+    import ctypes
+    import os
+
+    from .engine import MdxBatch, load_library
+    lib = load_library()
+    handle = ctypes.c_void_p()
+    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
+                          ctypes.byref(handle))
+    owner = _NativeBam(lib, handle)
+    if rc != 0:
+        raise ValueError("%r: %s" % (str(path), lib.mdx_bam_error(handle).decode() if handle else "BAM decode failed"))
+    return _native_alignments(lib, handle, owner)
+
+
+class BamStream:
+    """Chunked form of ``read_bam_native`` (include/mdx.h ``mdx_bam_open`` / ``mdx_bam_next``): iterating yields
+    ``Alignments`` of consecutive records, at most ``chunk_bytes`` of uncompressed BAM data each, so host memory stays
+    bounded and the caller can tabulate one chunk while the next is decoded (the ctypes call drops the GIL)."""
+
+    def __init__(self, path, threads=None, chunk_bytes=256 << 20):
+        import ctypes
+        import os
+
+        from .engine import load_library
+        self._lib = load_library()
+        self._stream = ctypes.c_void_p()
+        self.path, self.chunk_bytes = path, int(chunk_bytes)
+        rc = self._lib.mdx_bam_open(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
+                                    ctypes.byref(self._stream))
+        if rc != 0:
+            message = self._error()
+            self.close()
+            raise ValueError("%r: %s" % (str(path), message))
+        self.header = _native_header(self._lib, self._lib.mdx_bam_stream_header(self._stream))
+
+    def _error(self):
+        if not self._stream:
+            return "BAM decode failed"
+        return self._lib.mdx_bam_error(self._lib.mdx_bam_stream_header(self._stream)).decode()
+
+    def next_chunk(self):
+        """The next ``Alignments`` or None at the end of the file."""
+        import ctypes
+        handle = ctypes.c_void_p()
+        rc = self._lib.mdx_bam_next(self._stream, self.chunk_bytes, ctypes.byref(handle))
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
+        if not handle:
+            return None
+        return _native_alignments(self._lib, handle, _NativeBam(self._lib, handle), self.header)
+
+    def __iter__(self):
+        while True:
+            chunk = self.next_chunk()
+            if chunk is None:
+                return
+            yield chunk
+
+    def close(self):
+        if self._stream:
+            self._lib.mdx_bam_close(self._stream)
+            self._stream = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def is_bam(path):
+    if str(path) == "-":
+        return False
+    with open(path, "rb") as handle:
+        return handle.read(2) == b"\x1f\x8b"
 
 
 def read_alignments(path):

@@ -242,6 +242,14 @@ def test_cli_end_to_end_byte_identical_outputs(tmp_path, fmt):
     for name in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
         assert (out / name).read_text() == g.txt[name], name
     assert (out / "Runtime_log.txt").exists()
+    if fmt == "bam":
+        # the same file decoded in ~4 KiB chunks (records and BGZF blocks straddle the borders) and in one piece
+        for chunk_mb in ("0.004", "0"):
+            out2 = tmp_path / ("res" + chunk_mb)
+            assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out2), "-Q", "20", "--no-stats",
+                         "--chunk-mb", chunk_mb]) == 0
+            for name in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
+                assert (out2 / name).read_text() == g.txt[name], (chunk_mb, name)
 
 
 @pytest.mark.parametrize("config", [2, 3, 4])

@@ -186,3 +186,66 @@ def test_batch_take_and_view_slices():
     a, v = b.slice(3, 17), b.slice(3, 17, copy=False).validate()
     for k in ("flag", "lib", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual"):
         np.testing.assert_array_equal(getattr(a, k), getattr(v, k), err_msg=k)
+
+
+@pytest.mark.parametrize("chunk_bytes", [64, 1000, 4096, 50_000, 1 << 30])
+def test_native_bam_stream_matches_whole_file_decode(files, chunk_bytes):
+    """mdx_bam_open / mdx_bam_next: the chunks, concatenated, are the records of mdx_bam_read in file order,
+    whatever the chunk size (records and BGZF blocks straddle chunk borders)."""
+    from mapdamage_amd.batch import concat_batches
+    d, ref, batch, rg_of = files
+    whole = sam.read_bam_native(d / "x.bam")
+    with sam.BamStream(d / "x.bam", threads=3, chunk_bytes=chunk_bytes) as stream:
+        assert stream.header.references == ref.names and stream.header.lengths == ref.lengths
+        assert stream.header.read_groups == whole.header.read_groups
+        chunks = list(stream)
+    if chunk_bytes < 50_000:
+        assert len(chunks) > 3
+    got = concat_batches([c.batch for c in chunks])
+    for k in ("flag", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual"):
+        np.testing.assert_array_equal(getattr(got, k), getattr(whole.batch, k), err_msg=k)
+    assert [r for c in chunks for r in c.rg] == whole.rg == rg_of
+    assert [q for c in chunks for q in c.qname] == whole.qname
+
+
+def test_native_bam_stream_rejects_garbage_and_truncation(files, tmp_path):
+    d = files[0]
+    (tmp_path / "bad.bam").write_bytes(b"\x1f\x8bnot really a bam file at all")
+    with pytest.raises(ValueError):
+        sam.BamStream(tmp_path / "bad.bam")
+    data = (d / "x.bam").read_bytes()
+    (tmp_path / "cut.bam").write_bytes(data[:len(data) // 2])
+    with pytest.raises(ValueError):
+        with sam.BamStream(tmp_path / "cut.bam", chunk_bytes=4096) as stream:
+            list(stream)
+
+
+@pytest.mark.parametrize("downsample", [None, 0.3])
+def test_reader_in_chunks_yields_the_same_records(files, downsample):
+    """BAMReader(chunk_bytes=...): the batches of a BAM file decoded in pieces, concatenated, are the batch
+    of the one-piece decode — flag filter, library column and the --downsample stream of draws included."""
+    from mapdamage_amd.batch import concat_batches
+    d, ref, batch, rg_of = files
+    (whole,) = list(BAMReader(d / "x.bam", downsample_to=downsample, downsample_seed=5).iter_batches())
+    reader = BAMReader(d / "x.bam", downsample_to=downsample, downsample_seed=5, chunk_bytes=3000)
+    assert reader.get_libraries() == [("Zed", "libB"), ("Alpha", "libA")]
+    assert reader.get_references() == dict(zip(ref.names, ref.lengths))
+    parts = list(reader.iter_batches())
+    assert len(parts) > 5
+    got = concat_batches(parts)
+    for k in ("flag", "lib", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq", "qual"):
+        np.testing.assert_array_equal(getattr(got, k), getattr(whole, k), err_msg=k)
+    # a fixed-size sample and SAM text keep the one-piece decode
+    assert len(list(BAMReader(d / "x.bam", downsample_to=50, chunk_bytes=3000).iter_batches())) == 1
+    assert len(list(BAMReader(d / "x.sam", chunk_bytes=3000).iter_batches())) == 1
+
+
+def test_reader_in_chunks_reports_readgroup_errors(files, tmp_path):
+    d, ref, batch, rg_of = files
+    bad = list(rg_of)
+    bad[len(bad) // 2] = "nope"
+    keep = np.nonzero((batch.flag & 0xF04) == 0)[0]
+    bad[int(keep[len(keep) // 2])] = "nope"
+    sam.write_bam(tmp_path / "bad.bam", batch, ref.names, ref.lengths, RGS, bad)
+    with pytest.raises(BAMError, match="not listed in BAM header"):
+        list(BAMReader(tmp_path / "bad.bam", chunk_bytes=3000).iter_batches())
