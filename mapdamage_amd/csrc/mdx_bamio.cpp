@@ -4,6 +4,10 @@
 // 121-132) without pysam.  Pure host code (zlib); no HIP calls.
 #include "../../include/mdx.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -21,14 +25,33 @@
 #include <vector>
 
 // vector whose resize() leaves new elements uninitialised (the decoder overwrites every one of them; a
-// value-initialising resize would touch hundreds of megabytes on one thread first)
+// value-initialising resize would touch hundreds of megabytes on one thread first).  Large blocks come straight
+// from mmap with MADV_HUGEPAGE: the decoder first-touches and later returns hundreds of megabytes at a time, and
+// with 4 KiB pages both are per-page work under the process-wide mmap lock (releasing the 800 MB inflated stream
+// of a 4 M-record file held that lock for 100 ms, stalling whoever allocated next).
 template <class T>
-struct no_init_alloc : std::allocator<T> {
+struct no_init_alloc {
+    typedef T value_type;
+    static constexpr size_t kBig = (size_t)4 << 20, kHuge = (size_t)2 << 20;
     template <class U> struct rebind { typedef no_init_alloc<U> other; };
     no_init_alloc() = default;
     template <class U> no_init_alloc(const no_init_alloc<U> &) {}
+    static size_t span(size_t n) { return (n * sizeof(T) + kHuge - 1) / kHuge * kHuge; }
+    T *allocate(size_t n) {
+        if (n * sizeof(T) < kBig) return static_cast<T *>(::operator new(n * sizeof(T)));
+        void *p = mmap(nullptr, span(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(p, span(n), MADV_HUGEPAGE);
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t n) noexcept {
+        if (n * sizeof(T) < kBig) ::operator delete(p);
+        else (void)munmap(p, span(n));
+    }
     template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
     template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+    template <class U> bool operator==(const no_init_alloc<U> &) const { return true; }
+    template <class U> bool operator!=(const no_init_alloc<U> &) const { return false; }
 };
 typedef std::vector<uint8_t, no_init_alloc<uint8_t>> raw_bytes;
 
@@ -45,17 +68,23 @@ struct mdx_bam {
     std::string qnames;
     std::vector<std::string> rg_names;
     std::vector<uint8_t> has_mr;
+    // returning hundreds of megabytes of touched pages to the system takes tens of milliseconds: the inflated
+    // stream of mdx_bam_read is released on this thread while the caller already works on the columns
+    std::thread reaper;
+    ~mdx_bam() { if (reaper.joinable()) reaper.join(); }
 };
 
+
+namespace { struct MappedFile; }
 
 // Streaming decode: the file is consumed a slab of BGZF blocks at a time, so host memory is bounded by the
 // chunk size and the caller can tabulate chunk k while chunk k+1 is being decoded.
 struct mdx_bam_stream {
     mdx_bam head;                    // header text + reference dictionary (no records); also carries the error text
-    FILE *fp = nullptr;
+    MappedFile *file = nullptr;
+    size_t coff = 0;                 // compressed offset of the first block not inflated yet
     int threads = 1;
     bool eof = false;
-    std::vector<uint8_t> cbuf;       // compressed bytes read but not inflated yet (a partial block at most, between calls)
     raw_bytes pending;               // inflated bytes not unpacked yet (a partial record at most, between calls)
 };
 
@@ -63,18 +92,46 @@ namespace {
 
 struct Block { size_t in_off, in_size, out_off, out_size; };
 
+// The compressed file, mapped read-only: the inflating threads read the page cache directly (an fread of the
+// whole file into a buffer first was a single-threaded copy, a quarter of the decode time on a 64-thread host).
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    bool open(const char *path, std::string &err) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) { err = std::string("cannot open ") + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); err = std::string("not a regular file: ") + path; return false; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); n = 0; err = std::string("cannot map ") + path; return false; }
+            (void)madvise(m, n, MADV_SEQUENTIAL);
+            p = (const uint8_t *)m;
+        }
+        ::close(fd);
+        return true;
+    }
+    void close() { if (p) munmap((void *)p, n); p = nullptr; n = 0; }
+    ~MappedFile() { close(); }
+    size_t size() const { return n; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+};
+
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
 
 // `partial`: the buffer may end inside a block (streaming); the scan stops there and `consumed` says how far
 // it got.  Otherwise a truncated block is an error.
-bool scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, size_t &total, std::string &err,
-                 bool partial = false, size_t *consumed = nullptr) {
-    size_t off = 0;
+// `from`/`want`: scan from that offset and stop after about `want` compressed bytes (streaming).
+bool scan_blocks(const MappedFile &file, std::vector<Block> &blocks, size_t &total, std::string &err,
+                 size_t from = 0, size_t want = ~(size_t)0, size_t *consumed = nullptr) {
+    size_t off = from;
+    const bool partial = false;      // a mapped file is all there: a block running past its end is corrupt
     total = 0;
-    if (consumed) *consumed = 0;
-    while (off < file.size()) {
+    if (consumed) *consumed = from;
+    while (off < file.size() && off - from < want) {
         if (partial && off + 18 > file.size()) break;
         if (off + 18 > file.size() || file[off] != 0x1f || file[off + 1] != 0x8b || !(file[off + 3] & 4)) {
             err = "not a BGZF-compressed file";
@@ -278,26 +335,20 @@ int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, in
 // s->pending.  Returns false on an I/O or format error (text in s->head.error).
 bool stream_fill(mdx_bam_stream *s, size_t want) {
     if (s->eof) return true;
-    const size_t have = s->cbuf.size();
-    s->cbuf.resize(have + want);
-    const size_t got = std::fread(s->cbuf.data() + have, 1, want, s->fp);
-    s->cbuf.resize(have + got);
-    if (got < want) {
-        if (std::ferror(s->fp)) { s->head.error = "read error"; return false; }
-        s->eof = true;
-    }
     std::vector<Block> blocks;
-    size_t total = 0, consumed = 0;
-    if (!scan_blocks(s->cbuf, blocks, total, s->head.error, !s->eof, &consumed)) return false;
+    size_t total = 0, consumed = s->coff;
+    if (!scan_blocks(*s->file, blocks, total, s->head.error, s->coff, want, &consumed)) return false;
     const size_t base = s->pending.size();
     s->pending.resize(base + total);
     std::atomic<bool> ok{true};
+    const MappedFile &file = *s->file;
     parallel_for(blocks.size(), s->threads, [&](size_t i) {
         const Block &k = blocks[i];
-        if (!inflate_block(&s->cbuf[k.in_off], k.in_size, &s->pending[base + k.out_off], k.out_size)) ok = false;
+        if (!inflate_block(&file[k.in_off], k.in_size, &s->pending[base + k.out_off], k.out_size)) ok = false;
     });
     if (!ok) { s->head.error = "inflate failed"; return false; }
-    s->cbuf.erase(s->cbuf.begin(), s->cbuf.begin() + (std::ptrdiff_t)consumed);
+    s->coff = consumed;
+    if (s->coff >= file.size()) s->eof = true;
     return true;
 }
 
@@ -319,19 +370,9 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
         std::fprintf(stderr, "mdx_bam_read %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    std::vector<uint8_t> file;
-    {
-        FILE *fp = std::fopen(path, "rb");
-        if (!fp) { b->error = std::string("cannot open ") + path; return MDX_ERR_ARG; }
-        std::fseek(fp, 0, SEEK_END);
-        const long sz = std::ftell(fp);
-        std::fseek(fp, 0, SEEK_SET);
-        file.resize(sz > 0 ? (size_t)sz : 0);
-        const size_t got = file.empty() ? 0 : std::fread(file.data(), 1, file.size(), fp);
-        std::fclose(fp);
-        if (got != file.size()) { b->error = "short read"; return MDX_ERR_ARG; }
-    }
-    lap("file read");
+    MappedFile file;
+    if (!file.open(path, b->error)) return MDX_ERR_ARG;
+    lap("file map");
     std::vector<Block> blocks;
     size_t total = 0;
     if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
@@ -344,14 +385,23 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
     });
     if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
     lap("inflate");
-    std::vector<uint8_t>().swap(file);
+    file.close();
 
     size_t off = 0, used = 0;
     if (parse_header(b, data.data(), total, false, &off) != 0) return MDX_ERR_ARG;
-    return unpack_records(b, data.data(), off, total, threads, false, &used, lap);
+    const int rc = unpack_records(b, data.data(), off, total, threads, false, &used, lap);
+    b->reaper = std::thread([](raw_bytes d) { raw_bytes().swap(d); }, std::move(data));
+    lap("release");
+    return rc;
 }
 
-void mdx_bam_free(mdx_bam *b) { delete b; }
+void mdx_bam_free(mdx_bam *b) {
+    if (!b) return;
+    // a large handle (its columns are hundreds of megabytes) is torn down off the caller's thread: in the chunked
+    // pipeline this call sits between two tabulations
+    if (b->seq.size() >= ((size_t)64 << 20)) std::thread([b]() { delete b; }).detach();
+    else delete b;
+}
 
 const char *mdx_bam_error(const mdx_bam *b) { return b ? b->error.c_str() : "null handle"; }
 
@@ -401,8 +451,9 @@ int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
     if (!s) return MDX_ERR_ARG;
     *out = s;
     s->threads = threads < 1 ? 1 : threads;
-    s->fp = std::fopen(path, "rb");
-    if (!s->fp) { s->head.error = std::string("cannot open ") + path; return MDX_ERR_ARG; }
+    s->file = new (std::nothrow) MappedFile();
+    if (!s->file || !s->file->open(path, s->head.error)) return MDX_ERR_ARG;
+    if (s->file->size() == 0) s->eof = true;
     // the header may span several blocks: inflate until it parses
     for (;;) {
         if (!stream_fill(s, (size_t)1 << 20)) return MDX_ERR_ARG;
@@ -419,13 +470,22 @@ int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
 const mdx_bam *mdx_bam_stream_header(const mdx_bam_stream *s) { return s ? &s->head : nullptr; }
 
 int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
-    if (!s || !out || !s->fp) return MDX_ERR_ARG;
+    if (!s || !out || !s->file) return MDX_ERR_ARG;
     *out = nullptr;
     size_t limit = chunk_bytes < 64 ? 64 : (size_t)chunk_bytes;       // uncompressed BAM bytes per chunk
+    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mdx_bam_next %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     for (;;) {
         // BGZF members hold at most 64 KiB each; BAM compresses about 3-4x
         while (!s->eof && s->pending.size() < limit)
             if (!stream_fill(s, std::max<size_t>(limit / 4, (size_t)1 << 16))) return MDX_ERR_ARG;
+        lap("inflate");
         const size_t total = std::min(limit, s->pending.size());
         const bool partial = !(s->eof && total == s->pending.size());
         if (!partial && total < 4) return MDX_OK;                      // end of file: *out stays NULL
@@ -435,9 +495,10 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
         b->ref_names = s->head.ref_names;
         b->ref_lengths = s->head.ref_lengths;
         size_t used = 0;
-        const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, [](const char *) {});
+        const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, lap);
         if (rc != MDX_OK) { s->head.error = b->error; delete b; return rc; }
         s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
+        lap("carry");
         if (!b->flag.empty()) { *out = b; return MDX_OK; }
         delete b;
         if (!partial) return MDX_OK;
@@ -447,7 +508,7 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
 
 void mdx_bam_close(mdx_bam_stream *s) {
     if (!s) return;
-    if (s->fp) std::fclose(s->fp);
+    delete s->file;
     delete s;
 }
 

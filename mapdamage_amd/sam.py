@@ -279,7 +279,7 @@ def _native_alignments(lib, handle, owner, header=None):
         raw._owner = owner          # the view (and every view of it) keeps the decoder's buffers alive
         return np.frombuffer(raw, dtype=dtype)
 
-    batch = ReadBatch(col(view.flag, n, np.uint16), np.zeros(n, np.uint16), col(view.tid, n, np.int32),
+    batch = ReadBatch(col(view.flag, n, np.uint16), col(view.lib, n, np.uint16), col(view.tid, n, np.int32),
                       col(view.pos, n, np.int32), col(view.tlen, n, np.int32),
                       col(view.cigar_off, n + 1, np.uint32) if n else np.zeros(1, np.uint32),
                       col(view.cigar, nc, np.uint32),
