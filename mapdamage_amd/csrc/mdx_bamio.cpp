@@ -86,6 +86,7 @@ struct mdx_bam_stream {
     int threads = 1;
     bool eof = false;
     raw_bytes pending;               // inflated bytes not unpacked yet (a partial record at most, between calls)
+    std::vector<size_t> hints;       // offsets into `pending` where a BGZF block began (unpack_records)
 };
 
 namespace {
@@ -222,40 +223,122 @@ int parse_header(mdx_bam *b, const uint8_t *data, size_t total, bool partial, si
     return 0;
 }
 
+// One step of the record chain at `off`: 1 = a complete record (sizes returned), 0 = data ends inside it
+// (or fewer than 4 bytes are left), -1 = corrupt.
+inline int record_at(const uint8_t *data, size_t off, size_t total, uint32_t *n_cig, uint32_t *l_seq, uint32_t *l_qname,
+                     size_t *next) {
+    if (off + 4 > total) return 0;
+    const int32_t bs = rdi32(&data[off]);
+    if (bs < 32) return -1;
+    if (off + 4 + (size_t)bs > total) return 0;
+    const uint8_t *r = &data[off + 4];
+    const uint32_t l_name = r[8];
+    const int32_t ls = rdi32(r + 16);
+    *n_cig = rd16(r + 12);
+    if (ls < 0 || 32 + l_name + 4 * (size_t)*n_cig + ((size_t)ls + 1) / 2 + (size_t)ls > (size_t)bs) return -1;
+    *l_seq = (uint32_t)ls;
+    *l_qname = l_name ? l_name - 1 : 0;
+    *next = off + 4 + (size_t)bs;
+    return 1;
+}
+
+struct ScanSegment {
+    size_t begin = 0, end = 0;       // the chain is followed from `begin` until it reaches or passes `end`
+    size_t landed = 0;               // where it left the segment
+    std::vector<size_t> rec;
+    std::vector<uint32_t> n_cig, l_seq, l_qname;
+    uint64_t cig = 0, seq = 0, name = 0;
+    int state = 1;                   // as record_at at the point the segment stopped (1: ran to `end`)
+};
+
 // Records of data[off, total) -> the SoA columns of `b`.  `partial`: data may end inside a record; `consumed`
-// is the offset of the first byte not unpacked.
+// is the offset of the first byte not unpacked.  `hints`: ascending offsets into `data` where a record probably
+// starts (the first byte of each BGZF block: htslib closes a block early rather than split a record,
+// bgzf_flush_try in bam_write1).  The record chain is a linked list, so the scan that sizes the columns is
+// serial by nature (half of the decode time on a 64-thread host); with hints, segments of the chain are followed
+// in parallel from hinted starts and accepted only if every segment's chain lands exactly on the start of the
+// next one - otherwise the serial scan runs as if there had been no hints.  Same result either way.
 template <class Lap>
 int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, int threads, bool partial,
-                   size_t *consumed, Lap lap) {
-    // pass 1 (sequential): record starts and the prefix sums that size the ragged columns
+                   size_t *consumed, Lap lap, const std::vector<size_t> *hints = nullptr) {
     std::vector<size_t> rec;
     std::vector<uint32_t> coff{0}, soff{0}, noff{0};
-    while (off + 4 <= total) {
-        const int32_t bs = rdi32(&data[off]);
-        if (bs < 32) { b->error = "corrupt BAM record"; return MDX_ERR_ARG; }
-        if (off + 4 + (size_t)bs > total) {
-            if (partial) break;      // the record continues in the next chunk
-            b->error = "corrupt BAM record";
-            return MDX_ERR_ARG;
+    bool scanned = false;
+    // MDX_BAM_PARALLEL_SCAN_MIN: smallest input (bytes) worth the parallel scan; tests set it to 0
+    static const size_t scan_min = std::getenv("MDX_BAM_PARALLEL_SCAN_MIN")
+                                       ? (size_t)std::strtoull(std::getenv("MDX_BAM_PARALLEL_SCAN_MIN"), nullptr, 10)
+                                       : ((size_t)8 << 20);
+    if (hints && threads > 1 && !hints->empty() && total - std::min(off, total) >= scan_min) {
+        // pass 1, speculative: one segment per ~1/(4 threads) of the data, cut at hinted offsets
+        const size_t want = (size_t)threads * 4, stride = (total - off) / want + 1;
+        std::vector<ScanSegment> seg(1);
+        seg[0].begin = off;
+        for (auto it = std::upper_bound(hints->begin(), hints->end(), off); it != hints->end() && *it < total;) {
+            seg.back().end = *it;
+            seg.emplace_back();
+            seg.back().begin = *it;
+            it = std::lower_bound(it + 1, hints->end(), *it + stride);
         }
-        const uint8_t *r = &data[off + 4];
-        const uint32_t l_name = r[8], n_cig = rd16(r + 12);
-        const int32_t l_seq = rdi32(r + 16);
-        if (l_seq < 0 || 32 + l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) {
-            b->error = "corrupt BAM record";
-            return MDX_ERR_ARG;
+        seg.back().end = total;
+        parallel_for(seg.size(), threads, [&](size_t i) {
+            ScanSegment &g = seg[i];
+            const size_t guess = (g.end - g.begin) / 128 + 16;
+            g.rec.reserve(guess); g.n_cig.reserve(guess); g.l_seq.reserve(guess); g.l_qname.reserve(guess);
+            size_t o = g.begin, next = 0;
+            uint32_t nc = 0, ls = 0, ln = 0;
+            while (o < g.end && (g.state = record_at(data, o, total, &nc, &ls, &ln, &next)) == 1) {
+                g.rec.push_back(o + 4); g.n_cig.push_back(nc); g.l_seq.push_back(ls); g.l_qname.push_back(ln);
+                g.cig += nc; g.seq += ls; g.name += ln;
+                o = next;
+            }
+            g.landed = o;
+        });
+        bool good = true;
+        for (size_t i = 0; i < seg.size() && good; i++) {
+            const bool last = i + 1 == seg.size();
+            if (!last) good = seg[i].state == 1 && seg[i].landed == seg[i + 1].begin;
+            else good = seg[i].state == 1 || (seg[i].state == 0 && (partial || seg[i].landed + 4 > total));
         }
+        uint64_t n_all = 0, cig = 0, sq = 0, nm = 0;
+        std::vector<uint64_t> base(seg.size() * 4);
+        for (size_t i = 0; i < seg.size(); i++) {
+            base[4 * i] = n_all; base[4 * i + 1] = cig; base[4 * i + 2] = sq; base[4 * i + 3] = nm;
+            n_all += seg[i].rec.size(); cig += seg[i].cig; sq += seg[i].seq; nm += seg[i].name;
+        }
+        if (good && sq <= 0xFFFFFFFFull && cig <= 0xFFFFFFFFull && nm <= 0xFFFFFFFFull) {
+            rec.resize(n_all); coff.resize(n_all + 1); soff.resize(n_all + 1); noff.resize(n_all + 1);
+            parallel_for(seg.size(), threads, [&](size_t i) {
+                const ScanSegment &g = seg[i];
+                size_t k = base[4 * i];
+                uint32_t c = (uint32_t)base[4 * i + 1], q = (uint32_t)base[4 * i + 2], m = (uint32_t)base[4 * i + 3];
+                for (size_t j = 0; j < g.rec.size(); j++, k++) {
+                    rec[k] = g.rec[j];
+                    c += g.n_cig[j]; q += g.l_seq[j]; m += g.l_qname[j];
+                    coff[k + 1] = c; soff[k + 1] = q; noff[k + 1] = m;
+                }
+            });
+            off = seg.back().landed;
+            scanned = true;
+        }
+    }
+    // pass 1 (sequential): record starts and the prefix sums that size the ragged columns
+    while (!scanned) {
+        uint32_t n_cig = 0, l_seq = 0, l_qname = 0;
+        size_t next = 0;
+        const int state = record_at(data, off, total, &n_cig, &l_seq, &l_qname, &next);
+        if (state < 0 || (state == 0 && !partial && off + 4 <= total)) { b->error = "corrupt BAM record"; return MDX_ERR_ARG; }
+        if (state == 0) break;       // the record continues in the next chunk (or fewer than 4 bytes are left)
         const uint64_t ns = (uint64_t)soff.back() + (uint64_t)l_seq;
         if (ns > 0xFFFFFFFFull) { b->error = "more than 4 Gbases in one file: split it"; return MDX_ERR_ARG; }
         rec.push_back(off + 4);
         coff.push_back(coff.back() + n_cig);
         soff.push_back((uint32_t)ns);
-        noff.push_back(noff.back() + (l_name ? l_name - 1 : 0));
-        off += 4 + (size_t)bs;
+        noff.push_back(noff.back() + l_qname);
+        off = next;
     }
     const size_t n = rec.size();
     *consumed = off;
-    lap("record scan");
+    lap(scanned ? "scan (par.)" : "record scan");
     b->flag.resize(n); b->lib.assign(n, 0); b->tid.resize(n); b->pos.resize(n); b->tlen.resize(n);
     b->mtid.resize(n); b->mpos.resize(n); b->rg_index.assign(n, -1); b->has_mr.assign(n, 0);
     b->cigar_off = coff; b->seq_off = soff; b->qname_off = noff;
@@ -347,6 +430,7 @@ bool stream_fill(mdx_bam_stream *s, size_t want) {
         if (!inflate_block(&file[k.in_off], k.in_size, &s->pending[base + k.out_off], k.out_size)) ok = false;
     });
     if (!ok) { s->head.error = "inflate failed"; return false; }
+    for (const Block &k : blocks) s->hints.push_back(base + k.out_off);
     s->coff = consumed;
     if (s->coff >= file.size()) s->eof = true;
     return true;
@@ -389,7 +473,9 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
 
     size_t off = 0, used = 0;
     if (parse_header(b, data.data(), total, false, &off) != 0) return MDX_ERR_ARG;
-    const int rc = unpack_records(b, data.data(), off, total, threads, false, &used, lap);
+    std::vector<size_t> hints(blocks.size());
+    for (size_t i = 0; i < blocks.size(); i++) hints[i] = blocks[i].out_off;
+    const int rc = unpack_records(b, data.data(), off, total, threads, false, &used, lap, &hints);
     b->reaper = std::thread([](raw_bytes d) { raw_bytes().swap(d); }, std::move(data));
     lap("release");
     return rc;
@@ -462,6 +548,9 @@ int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
         if (rc < 0) return MDX_ERR_ARG;
         if (rc == 0) {
             s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)first);
+            size_t kept = 0;
+            for (size_t h : s->hints) if (h >= first) s->hints[kept++] = h - first;
+            s->hints.resize(kept);
             return MDX_OK;
         }
     }
@@ -495,9 +584,14 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
         b->ref_names = s->head.ref_names;
         b->ref_lengths = s->head.ref_lengths;
         size_t used = 0;
-        const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, lap);
+        const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, lap, &s->hints);
         if (rc != MDX_OK) { s->head.error = b->error; delete b; return rc; }
         s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
+        {
+            size_t kept = 0;
+            for (size_t h : s->hints) if (h >= used) s->hints[kept++] = h - used;
+            s->hints.resize(kept);
+        }
         lap("carry");
         if (!b->flag.empty()) { *out = b; return MDX_OK; }
         delete b;

@@ -428,13 +428,22 @@ def write_sam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
             out.write("\t".join(fields) + "\n")
 
 
-def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None):
+def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None, htslib_blocks=True):
+    """``htslib_blocks``: lay the BGZF blocks out as htslib does (the header flushed on its own, and a block closed
+    early when the next record would not fit, ``bgzf_flush_try`` in ``bam_write1``), so that every block starts
+    at a record — what the files mapDamage sees in practice look like, and what the native decoder's parallel
+    record scan speculates on.  False: blocks of 0xFF00 bytes cut anywhere (records straddle them)."""
     text = header_text(ref_names, ref_lengths, read_groups).encode()
     raw = io.BytesIO()
+    pieces = []                      # htslib layout: uncompressed payload of each block
+    room = 0xFF00
     raw.write(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names)))
     for name, ln in zip(ref_names, ref_lengths):
         nb = name.encode() + b"\x00"
         raw.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln))
+    if htslib_blocks:
+        head = raw.getvalue()
+        pieces = [bytearray(head[lo:lo + room]) for lo in range(0, len(head), room)] + [bytearray()]
     for i in range(batch.n):
         c0, c1 = int(batch.cigar_off[i]), int(batch.cigar_off[i + 1])
         s0, s1 = int(batch.seq_off[i]), int(batch.seq_off[i + 1])
@@ -454,11 +463,23 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
         body = struct.pack("<iiBBHHHiiii", int(batch.tid[i]), int(batch.pos[i]), len(name), 30, 4680,
                            c1 - c0, int(batch.flag[i]), l_seq, ntid, npos, int(batch.tlen[i]))
         body += name + batch.cigar[c0:c1].astype("<u4").tobytes() + packed + qual + aux
-        raw.write(struct.pack("<i", len(body)) + body)
-    data = raw.getvalue()
+        record = struct.pack("<i", len(body)) + body
+        if not htslib_blocks:
+            raw.write(record)
+            continue
+        if pieces[-1] and len(pieces[-1]) + len(record) > room:
+            pieces.append(bytearray())
+        pieces[-1] += record
+        while len(pieces[-1]) > room:            # a record larger than a block spills over
+            pieces.append(pieces[-1][room:])
+            del pieces[-2][room:]
+    if not htslib_blocks:
+        data = raw.getvalue()
+        pieces = [data[lo:lo + room] for lo in range(0, len(data), room)]
     with open(path, "wb") as out:
-        for lo in range(0, len(data), 0xFF00):
-            out.write(_bgzf_block(data[lo:lo + 0xFF00]))
+        for piece in pieces:
+            if len(piece):
+                out.write(_bgzf_block(bytes(piece)))
         out.write(_bgzf_block(b""))
 
 

@@ -249,3 +249,47 @@ def test_reader_in_chunks_reports_readgroup_errors(files, tmp_path):
     sam.write_bam(tmp_path / "bad.bam", batch, ref.names, ref.lengths, RGS, bad)
     with pytest.raises(BAMError, match="not listed in BAM header"):
         list(BAMReader(tmp_path / "bad.bam", chunk_bytes=3000).iter_batches())
+
+
+def _decode_in_subprocess(path, chunk_bytes, scan_min):
+    """Decoded columns (whole file or chunked) from a fresh interpreter with MDX_BAM_PARALLEL_SCAN_MIN set: the
+    threshold is read once per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, hashlib\n"
+        "import numpy as np\n"
+        "from mapdamage_amd import sam\n"
+        "from mapdamage_amd.batch import concat_batches\n"
+        "path, chunk = sys.argv[1], int(sys.argv[2])\n"
+        "if chunk:\n"
+        "    with sam.BamStream(path, threads=4, chunk_bytes=chunk) as st:\n"
+        "        parts = list(st)\n"
+        "    b = concat_batches([p.batch for p in parts]); names = [q for p in parts for q in p.qname]\n"
+        "else:\n"
+        "    al = sam.read_bam_native(path, threads=4); b = al.batch; names = al.qname\n"
+        "h = hashlib.sha256()\n"
+        "for k in ('flag', 'tid', 'pos', 'tlen', 'cigar_off', 'cigar', 'seq_off', 'seq', 'qual'):\n"
+        "    h.update(np.ascontiguousarray(getattr(b, k)).tobytes())\n"
+        "h.update('\\n'.join(names).encode())\n"
+        "print(json.dumps({'n': b.n, 'sha': h.hexdigest()}))\n")
+    env = dict(os.environ, MDX_BAM_PARALLEL_SCAN_MIN=str(scan_min))
+    out = subprocess.run([sys.executable, "-c", code, str(path), str(chunk_bytes)], env=env, check=True,
+                         capture_output=True, text=True, cwd=str(__import__("pathlib").Path(__file__).parent.parent))
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("htslib_blocks", [True, False])
+def test_native_bam_parallel_record_scan_equals_serial_scan(files, tmp_path, htslib_blocks):
+    """The speculative parallel record scan (segments started at BGZF block starts, accepted only when every
+    chain lands on the next start) against the serial scan: equal columns when the speculation holds (htslib
+    block layout) and when it cannot (records straddling blocks -> serial fallback), whole file and chunked."""
+    d, ref, batch, rg_of = files
+    path = tmp_path / "layout.bam"
+    sam.write_bam(path, batch, ref.names, ref.lengths, RGS, rg_of, htslib_blocks=htslib_blocks)
+    want = _decode_in_subprocess(path, 0, 1 << 40)            # serial scan
+    assert want["n"] == batch.n
+    for chunk in (0, 70_000, 5_000):
+        assert _decode_in_subprocess(path, chunk, 0) == want, chunk
