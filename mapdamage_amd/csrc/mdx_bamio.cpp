@@ -29,24 +29,74 @@
 // from mmap with MADV_HUGEPAGE: the decoder first-touches and later returns hundreds of megabytes at a time, and
 // with 4 KiB pages both are per-page work under the process-wide mmap lock (releasing the 800 MB inflated stream
 // of a 4 M-record file held that lock for 100 ms, stalling whoever allocated next).
+// Released blocks are kept (up to kPoolBytes) and handed out again: the chunked decoder allocates and releases the
+// same few hundred megabytes every chunk, and a recycled block needs neither page faults nor an munmap.
+class BigBlocks {
+  public:
+    static constexpr size_t kHuge = (size_t)2 << 20, kPoolBytes = (size_t)3 << 30, kPoolBlock = (size_t)1 << 30;
+    static BigBlocks &get() { static BigBlocks *pool = new BigBlocks(); return *pool; }   // never destroyed: detached
+                                                                                          // threads may still free
+    void *take(size_t bytes) {
+        const size_t need = (bytes + kHuge - 1) / kHuge * kHuge;
+        {
+            std::lock_guard<std::mutex> guard(mu_);
+            size_t best = idle_.size();
+            for (size_t i = 0; i < idle_.size(); i++)
+                if (idle_[i].second >= need && idle_[i].second <= need + need / 2 &&
+                    (best == idle_.size() || idle_[i].second < idle_[best].second)) best = i;
+            if (best != idle_.size()) {
+                void *p = idle_[best].first;
+                live_[p] = idle_[best].second;
+                idle_bytes_ -= idle_[best].second;
+                idle_.erase(idle_.begin() + (std::ptrdiff_t)best);
+                return p;
+            }
+        }
+        void *p = mmap(nullptr, need, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(p, need, MADV_HUGEPAGE);
+        std::lock_guard<std::mutex> guard(mu_);
+        live_[p] = need;
+        return p;
+    }
+    void give(void *p) {
+        size_t span = 0;
+        {
+            std::lock_guard<std::mutex> guard(mu_);
+            auto it = live_.find(p);
+            if (it == live_.end()) return;
+            span = it->second;
+            live_.erase(it);
+            if (span <= kPoolBlock && idle_bytes_ + span <= kPoolBytes) {
+                idle_.emplace_back(p, span);
+                idle_bytes_ += span;
+                return;
+            }
+        }
+        (void)munmap(p, span);
+    }
+
+  private:
+    std::mutex mu_;
+    std::unordered_map<void *, size_t> live_;
+    std::vector<std::pair<void *, size_t>> idle_;
+    size_t idle_bytes_ = 0;
+};
+
 template <class T>
 struct no_init_alloc {
     typedef T value_type;
-    static constexpr size_t kBig = (size_t)4 << 20, kHuge = (size_t)2 << 20;
+    static constexpr size_t kBig = (size_t)4 << 20;
     template <class U> struct rebind { typedef no_init_alloc<U> other; };
     no_init_alloc() = default;
     template <class U> no_init_alloc(const no_init_alloc<U> &) {}
-    static size_t span(size_t n) { return (n * sizeof(T) + kHuge - 1) / kHuge * kHuge; }
     T *allocate(size_t n) {
         if (n * sizeof(T) < kBig) return static_cast<T *>(::operator new(n * sizeof(T)));
-        void *p = mmap(nullptr, span(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (p == MAP_FAILED) throw std::bad_alloc();
-        (void)madvise(p, span(n), MADV_HUGEPAGE);
-        return static_cast<T *>(p);
+        return static_cast<T *>(BigBlocks::get().take(n * sizeof(T)));
     }
     void deallocate(T *p, size_t n) noexcept {
         if (n * sizeof(T) < kBig) ::operator delete(p);
-        else (void)munmap(p, span(n));
+        else BigBlocks::get().give(p);
     }
     template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
     template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
