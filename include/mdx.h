@@ -34,6 +34,8 @@ extern "C" {
                                      contig end (pysam ValueError from align.py:33 / main.py:180),
                                      tid/library out of range, CIGAR/SEQ length mismatch */
 
+#define MDX_ERR_COMM (-7)         /* RCCL failure, or another rank of the communicator reported an error */
+
 #define MDX_N_MIS_COLS 25         /* mapdamage/seq.py:6-30 without the derived "Total" */
 
 typedef struct mdx_ctx mdx_ctx;
@@ -114,14 +116,39 @@ int mdx_sync(mdx_ctx *ctx, int64_t *bad_read);
 int64_t mdx_table_words(const mdx_ctx *ctx);
 
 /* Writes the canonical tables (layout: mapdamage_amd/layout.py) into a *device* buffer of
- * mdx_table_words() uint64 — the buffer a caller all-reduces (RCCL, sum) across GPUs. */
+ * mdx_table_words() uint64 — this context's own counts; mdx_finish_allreduce sums them across GPUs
+ * (or the caller all-reduces the buffer itself, e.g. with torch.distributed). */
 int mdx_finish_device(mdx_ctx *ctx, uint64_t *d_tables);
 
 /* Replaces reading the `.data` dicts before `.write()` (main.py:229-231): synchronises and
  * copies the canonical tables to host memory.  lgd_over receives (lib, kind, strand, length)
- * quadruples for lengths >= lgd_max (at most lgd_over_cap); any pointer may be NULL. */
+ * quadruples for lengths >= lgd_max (at most lgd_over_cap); any pointer may be NULL.
+ * With a communicator attached (mdx_comm_init / mdx_comm_adopt) the call is collective and returns the
+ * totals over all ranks on every rank. */
 int mdx_finish(mdx_ctx *ctx, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t *lgd_over,
                int64_t lgd_over_cap, int64_t *n_lgd_over, int64_t *n_kept);
+
+/* Cross-device reduction (SURVEY.md §8b "finish() performs cross-device reduction", §8e).  The reference has no
+ * counterpart (it is a single process); what makes the reduction legal is that every accumulator update is a
+ * `+= 1` (statistics.py:30,35,40,103,124,126).  One context per GPU / per process; records are sharded over
+ * the contexts with no data-path exchange, and the tables are summed with one ncclAllReduce(ncclUint64, ncclSum)
+ * over xGMI on the context's stream.  librccl.so.1 is resolved at run time (dlopen) by the first of these calls;
+ * a process that never calls them does not need RCCL.
+ *   mdx_comm_unique_id  rank 0 obtains the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other
+ *                       ranks by any means (MPI, a file, torch.distributed's store);
+ *   mdx_comm_init       every rank: ncclCommInitRank on the context's device (collective, blocks until all joined);
+ *   mdx_comm_adopt      alternatively use an ncclComm_t the caller already owns (not destroyed by mdx_destroy);
+ *   mdx_finish_allreduce  mdx_finish_device + in-place all-reduce of the packed block: every rank ends up with
+ *                       the totals in its device buffer.  Enqueued on the context's stream; collective.
+ * With a communicator attached, mdx_finish itself performs the reduction: an error flag is agreed on first (a rank
+ * whose mdx_sync fails makes every rank return — MDX_ERR_COMM on the healthy ones — instead of leaving them in
+ * the collective), then the tables are all-reduced and the out-of-range length lists all-gathered in rank order. */
+#define MDX_COMM_ID_BYTES 128
+int mdx_comm_unique_id(uint8_t *id /* MDX_COMM_ID_BYTES */);
+int mdx_comm_init(mdx_ctx *ctx, const uint8_t *id, int32_t nranks, int32_t rank);
+int mdx_comm_adopt(mdx_ctx *ctx, void *rccl_comm, int32_t nranks, int32_t rank);
+int mdx_comm_size(const mdx_ctx *ctx);   /* 0 = no communicator attached */
+int mdx_finish_allreduce(mdx_ctx *ctx, uint64_t *d_tables);
 
 /* Zero all accumulators (new run with the same options and reference). */
 int mdx_reset(mdx_ctx *ctx);

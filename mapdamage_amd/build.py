@@ -34,7 +34,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
            "-x", "hip", "-Wall", "-Wno-unused-function"]
     cmd += list(extra_flags)
     cmd += [str(CSRC / s) for s in SOURCES]
-    cmd += ["-lz", "-lpthread", "-o", str(LIB)]
+    cmd += ["-lz", "-lpthread", "-ldl", "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -3,8 +3,11 @@
 #include "../../include/mdx.h"
 #include "mdx_internal.h"
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -32,7 +35,48 @@ struct DevBuf {
 
 }  // namespace
 
+// RCCL entry points, resolved with dlopen on first use (a process that never reduces across GPUs does not need
+// the library; when torch has already loaded its own librccl.so the same image is reused)
+namespace {
+struct RcclId { char internal[MDX_COMM_ID_BYTES]; };
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+constexpr int kNcclInt64 = 4, kNcclUint64 = 5, kNcclSum = 0;
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl *rccl() {
+    std::call_once(g_rccl_once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.handle) break;
+        }
+        if (!g_rccl.handle) { g_rccl.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(g_rccl.handle, n); if (!p) g_rccl.err = std::string("librccl: missing ") + n; return p; };
+        g_rccl.GetUniqueId = (int (*)(RcclId *))sym("ncclGetUniqueId");
+        g_rccl.CommInitRank = (int (*)(void **, int, RcclId, int))sym("ncclCommInitRank");
+        g_rccl.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+        g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllGather");
+        g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    });
+    return g_rccl.err.empty() ? &g_rccl : nullptr;
+}
+}  // namespace
+
 struct mdx_ctx {
+    void *comm = nullptr;      // ncclComm_t
+    bool comm_owned = false;
+    int comm_size = 0, comm_rank = 0;
     mdx_config cfg{};
     MdxDims dims{};
     int mode = MDX_MODE_LDS;
@@ -78,6 +122,13 @@ int fail(mdx_ctx *c, int code, const std::string &msg) {
     return code;
 }
 
+#define RCCL_TRY(ctx, r, call)                                                                  \
+    do {                                                                                        \
+        int e_ = (call);                                                                        \
+        if (e_ != 0)                                                                            \
+            return fail((ctx), MDX_ERR_COMM, std::string(#call) + ": " + (r)->GetErrorString(e_)); \
+    } while (0)
+
 #define HIP_TRY(ctx, call)                                                                     \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -112,6 +163,7 @@ const char *mdx_strerror(int code) {
         case MDX_ERR_MASK_INDEX: return "masked column beyond gapped reference";
         case MDX_ERR_LGD_OVERFLOW: return "fragment-length overflow list full";
         case MDX_ERR_BAD_READ: return "record cannot be processed (alignment past contig end, bad tid/library, CIGAR/SEQ mismatch)";
+        case MDX_ERR_COMM: return "RCCL failure, or another rank reported an error";
     }
     return "unknown error";
 }
@@ -175,6 +227,7 @@ void mdx_destroy(mdx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && c->comm_owned && rccl()) (void)rccl()->CommDestroy(c->comm);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &b : c->st) b.release();
     for (int i = 0; i < 2; i++) {
@@ -423,15 +476,114 @@ int mdx_finish_device(mdx_ctx *c, uint64_t *d_tables) {
     return MDX_OK;
 }
 
+int mdx_comm_unique_id(uint8_t *id) {
+    if (!id) return MDX_ERR_ARG;
+    const Rccl *r = rccl();
+    if (!r) return MDX_ERR_COMM;
+    RcclId u;
+    if (r->GetUniqueId(&u) != 0) return MDX_ERR_COMM;
+    std::memcpy(id, u.internal, MDX_COMM_ID_BYTES);
+    return MDX_OK;
+}
+
+int mdx_comm_init(mdx_ctx *c, const uint8_t *id, int32_t nranks, int32_t rank) {
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MDX_ERR_ARG, "comm_init: bad arguments");
+    if (c->comm) return fail(c, MDX_ERR_STATE, "a communicator is already attached");
+    const Rccl *r = rccl();
+    if (!r) return fail(c, MDX_ERR_COMM, g_rccl.err);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    RcclId u;
+    std::memcpy(u.internal, id, MDX_COMM_ID_BYTES);
+    void *comm = nullptr;
+    RCCL_TRY(c, r, r->CommInitRank(&comm, nranks, u, rank));
+    c->comm = comm; c->comm_owned = true; c->comm_size = nranks; c->comm_rank = rank;
+    return MDX_OK;
+}
+
+int mdx_comm_adopt(mdx_ctx *c, void *rccl_comm, int32_t nranks, int32_t rank) {
+    if (!c || !rccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MDX_ERR_ARG, "comm_adopt: bad arguments");
+    if (c->comm) return fail(c, MDX_ERR_STATE, "a communicator is already attached");
+    if (!rccl()) return fail(c, MDX_ERR_COMM, g_rccl.err);
+    c->comm = rccl_comm; c->comm_owned = false; c->comm_size = nranks; c->comm_rank = rank;
+    return MDX_OK;
+}
+
+int mdx_comm_size(const mdx_ctx *c) { return c && c->comm ? c->comm_size : 0; }
+
+int mdx_finish_allreduce(mdx_ctx *c, uint64_t *d_tables) {
+    if (!c || !d_tables) return MDX_ERR_ARG;
+    if (!c->comm) return fail(c, MDX_ERR_STATE, "mdx_comm_init / mdx_comm_adopt first");
+    const Rccl *r = rccl();
+    int rc = mdx_finish_device(c, d_tables);
+    if (rc != MDX_OK) return rc;
+    RCCL_TRY(c, r, r->AllReduce(d_tables, d_tables, (size_t)mdx_table_words(c), kNcclUint64, kNcclSum, c->comm, c->stream));
+    return MDX_OK;
+}
+
 int mdx_finish(mdx_ctx *c, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t *lgd_over,
                int64_t lgd_over_cap, int64_t *n_lgd_over, int64_t *n_kept) {
     if (!c) return MDX_ERR_ARG;
     int rc = mdx_sync(c, nullptr);
-    if (rc != MDX_OK) return rc;
+    const Rccl *r = c->comm ? rccl() : nullptr;
     const int64_t words = mdx_table_words(c);
-    uint64_t *d = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d, (size_t)words * 8));
-    rc = mdx_finish_device(c, d);
+    uint64_t *d = nullptr;      // [tables | error flag | this rank's list length]
+    if (r) {
+        // agree on an error flag first: a rank that failed must not leave the others in the collective
+        const std::string own = c->err;
+        HIP_TRY(c, hipMalloc((void **)&d, (size_t)(words + 2) * 8));
+        const uint64_t flag = rc != MDX_OK ? 1 : 0;
+        hipError_t e = hipMemcpyAsync(d + words, &flag, 8, hipMemcpyHostToDevice, c->stream);
+        int ne = e == hipSuccess ? r->AllReduce(d + words, d + words, 1, kNcclUint64, kNcclSum, c->comm, c->stream) : 0;
+        uint64_t any = 0;
+        if (e == hipSuccess && ne == 0) e = hipMemcpyAsync(&any, d + words, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && ne == 0) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess || ne != 0) {
+            (void)hipFree(d);
+            return fail(c, e != hipSuccess ? MDX_ERR_HIP : MDX_ERR_COMM, e != hipSuccess ? hipGetErrorString(e) : r->GetErrorString(ne));
+        }
+        if (rc != MDX_OK) { (void)hipFree(d); c->err = own; return rc; }
+        if (any) { (void)hipFree(d); return fail(c, MDX_ERR_COMM, "another rank of the communicator reported an error"); }
+    } else {
+        if (rc != MDX_OK) return rc;
+        HIP_TRY(c, hipMalloc((void **)&d, (size_t)words * 8));
+    }
+    rc = r ? mdx_finish_allreduce(c, d) : mdx_finish_device(c, d);
+    std::vector<int64_t> gathered;   // the out-of-range lists of all ranks, rank order
+    if (rc == MDX_OK && r) {
+        // list lengths of all ranks, then the lists padded to the longest
+        unsigned long long own_n = 0;
+        hipError_t e = hipMemcpy(&own_n, c->d_n_lgd_over, 8, hipMemcpyDeviceToHost);
+        if ((int64_t)own_n > c->cfg.lgd_over_cap) own_n = (unsigned long long)c->cfg.lgd_over_cap;
+        uint64_t *d_cnt = nullptr;
+        std::vector<uint64_t> cnt((size_t)c->comm_size, 0);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, (size_t)(c->comm_size + 1) * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_cnt + c->comm_size, &own_n, 8, hipMemcpyHostToDevice, c->stream);
+        int ne = 0;
+        if (e == hipSuccess) ne = r->AllGather(d_cnt + c->comm_size, d_cnt, 1, kNcclUint64, c->comm, c->stream);
+        if (e == hipSuccess && ne == 0) e = hipMemcpyAsync(cnt.data(), d_cnt, (size_t)c->comm_size * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && ne == 0) e = hipStreamSynchronize(c->stream);
+        uint64_t longest = 0;
+        for (uint64_t v : cnt) longest = v > longest ? v : longest;
+        if (e == hipSuccess && ne == 0 && longest > 0) {
+            int64_t *d_all = nullptr, *d_own = nullptr;
+            e = hipMalloc((void **)&d_all, (size_t)c->comm_size * longest * 32);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_own, (size_t)longest * 32);
+            if (e == hipSuccess) e = hipMemsetAsync(d_own, 0, (size_t)longest * 32, c->stream);
+            if (e == hipSuccess && own_n) e = hipMemcpyAsync(d_own, c->d_lgd_over, (size_t)own_n * 32, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) ne = r->AllGather(d_own, d_all, (size_t)longest * 4, kNcclInt64, c->comm, c->stream);
+            std::vector<int64_t> all((size_t)c->comm_size * longest * 4);
+            if (e == hipSuccess && ne == 0) e = hipMemcpyAsync(all.data(), d_all, all.size() * 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && ne == 0) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess && ne == 0)
+                for (int k = 0; k < c->comm_size; k++)
+                    gathered.insert(gathered.end(), all.begin() + (size_t)k * longest * 4, all.begin() + ((size_t)k * longest + cnt[k]) * 4);
+            if (d_all) (void)hipFree(d_all);
+            if (d_own) (void)hipFree(d_own);
+        }
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (e != hipSuccess) rc = fail(c, MDX_ERR_HIP, hipGetErrorString(e));
+        else if (ne != 0) rc = fail(c, MDX_ERR_COMM, r->GetErrorString(ne));
+    }
     if (rc == MDX_OK) {
         hipError_t e = hipStreamSynchronize(c->stream);
         const int64_t nm = mis_words(c), nc = comp_words(c), nl = lgd_words(c);
@@ -446,7 +598,12 @@ int mdx_finish(mdx_ctx *c, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t
             if (n_lgd_over) *n_lgd_over = nov;
             if (lgd_over && nov > 0) {
                 if (nov > lgd_over_cap) nov = lgd_over_cap;
-                e = hipMemcpy(lgd_over, c->d_lgd_over, (size_t)nov * 32, hipMemcpyDeviceToHost);
+                if (r) {
+                    if (nov > (int64_t)gathered.size() / 4) nov = (int64_t)gathered.size() / 4;
+                    std::memcpy(lgd_over, gathered.data(), (size_t)nov * 32);
+                } else {
+                    e = hipMemcpy(lgd_over, c->d_lgd_over, (size_t)nov * 32, hipMemcpyDeviceToHost);
+                }
             }
         }
         if (e != hipSuccess) rc = fail(c, MDX_ERR_HIP, hipGetErrorString(e));

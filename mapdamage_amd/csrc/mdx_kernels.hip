@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         for (int k = cn - 1; k >= 1; k--) {
             const u32 c = op_at(k);
             const int op = c & 0xF;
-            if (op == 5) return;
+            if (op == 5) continue;
             if (op == 4) clipr += (int)(c >> 4); else break;
         }
         const int nq = lseq - qs - clipr > 0 ? lseq - qs - clipr : 0;

@@ -25,6 +25,7 @@ EXPORTS = (
     "mdx_finish_device", "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
     "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
     "mdx_rescale_summary_words", "mdx_rescale_summary",
+    "mdx_comm_unique_id", "mdx_comm_init", "mdx_comm_adopt", "mdx_comm_size", "mdx_finish_allreduce",
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
@@ -85,8 +86,10 @@ def load_library(path=None):
                  "mdx_tabulate_host", "mdx_tabulate_device", "mdx_sync", "mdx_finish_device",
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
                  "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
-                 "mdx_rescale_summary"):
+                 "mdx_rescale_summary", "mdx_comm_unique_id", "mdx_comm_init", "mdx_comm_adopt", "mdx_comm_size",
+                 "mdx_finish_allreduce"):
         getattr(lib, name).restype = ctypes.c_int
+    lib.mdx_comm_size.argtypes = [ctypes.c_void_p]
     lib.mdx_rescale_summary_words.restype = ctypes.c_int64
     lib.mdx_rescale_summary_words.argtypes = [ctypes.c_void_p]
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
@@ -219,8 +222,9 @@ class DamageEngine:
         else:
             hb = _host_batch(batch)
             self._check(self._lib.mdx_tabulate_host(self._ctx, ctypes.byref(hb)))
-            # host columns may be released once the staged copies are enqueued and done
-            self._lib.mdx_sync(self._ctx, None)
+            # host columns may be released once the staged copies are enqueued and done; a record the
+            # reference cannot process surfaces here, with its index within this batch
+            self.sync()
 
     def tabulate_pointers(self, n_reads, n_cigar, n_bases, **ptrs):
         """Device pointers owned by the caller (e.g. torch tensors): zero-copy entry."""
@@ -245,14 +249,39 @@ class DamageEngine:
         """Write the packed canonical tables to a device buffer (for RCCL all-reduce)."""
         self._check(self._lib.mdx_finish_device(self._ctx, ctypes.c_void_p(device_ptr)))
 
+    # ------------------------------------------------------------------ cross-device reduction (RCCL in the ABI)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rendezvous id for ``comm_init`` (ncclGetUniqueId): rank 0 creates it, every rank receives a copy."""
+        buf = (ctypes.c_uint8 * 128)()
+        rc = load_library().mdx_comm_unique_id(buf)
+        if rc != 0:
+            raise MdxError(rc, "mdx_comm_unique_id: librccl.so.1 could not be loaded")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        """Join the communicator (collective).  Afterwards ``finish()`` returns the totals over all ranks."""
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.mdx_comm_init(self._ctx, buf, ctypes.c_int32(nranks), ctypes.c_int32(rank)))
+
+    @property
+    def comm_size(self):
+        return int(self._lib.mdx_comm_size(self._ctx))
+
+    def finish_allreduce(self, device_ptr):
+        """finish_device + in-place ncclAllReduce(uint64, sum) on the context's stream (collective)."""
+        self._check(self._lib.mdx_finish_allreduce(self._ctx, ctypes.c_void_p(device_ptr)))
+
     def unpack_tables(self, words: np.ndarray, lgd_over=None) -> TableSet:
         """Split a packed table block (host copy of ``finish_device`` output)."""
         from .tables import unpack_words
         return unpack_words(words, self.libraries, self.length, self.around, self.lgd_max, lgd_over)
 
     def finish(self) -> TableSet:
-        """Synchronise and fetch the canonical tables (main.py:229-231 reads them next)."""
-        self.sync()
+        """Synchronise and fetch the canonical tables (main.py:229-231 reads them next).  With a communicator
+        attached (``comm_init``) the call is collective and returns the totals over all ranks."""
+        if not self.comm_size:
+            self.sync()
         nlib, Ln, A = len(self.libraries), self.length, self.around
         mis = np.zeros((nlib, 2, 2, Ln, L.N_MIS_COLS), np.uint64)
         comp = np.zeros((nlib, 2, 2, Ln + A, 4), np.uint64)
@@ -261,9 +290,11 @@ class DamageEngine:
         over = np.zeros((cap, 4), np.int64)
         n_over = ctypes.c_int64(0)
         n_kept = ctypes.c_int64(0)
-        self._check(self._lib.mdx_finish(self._ctx, _ptr(mis), _ptr(comp), _ptr(lgd), _ptr(over),
-                                         ctypes.c_int64(cap), ctypes.byref(n_over),
-                                         ctypes.byref(n_kept)))
+        rc = self._lib.mdx_finish(self._ctx, _ptr(mis), _ptr(comp), _ptr(lgd), _ptr(over),
+                                  ctypes.c_int64(cap), ctypes.byref(n_over), ctypes.byref(n_kept))
+        if rc == L.MDX_ERR_BAD_READ:
+            self.sync()     # raises BadReadError with the record's index
+        self._check(rc)
         return TableSet(self.libraries, Ln, A, mis, comp, lgd, over[:n_over.value].copy(),
                         n_kept.value)
 

@@ -66,6 +66,7 @@ MDX_ERR_STATE = -3
 MDX_ERR_MASK_INDEX = -4   # align.py:69-71 IndexError (masked column beyond gapped reference)
 MDX_ERR_LGD_OVERFLOW = -5
 MDX_ERR_BAD_READ = -6     # tid/pos outside the contig table, CIGAR/SEQ length mismatch
+MDX_ERR_COMM = -7         # RCCL failure, or another rank of the communicator reported an error
 
 
 def comp_positions(end_index, length, around):

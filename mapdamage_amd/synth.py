@@ -381,6 +381,38 @@ def config3_batch(ref, n, seed=3, with_qual=False):
                       with_qual=with_qual)
 
 
+_PAR_REF = None
+
+
+def _par_worker(job):
+    maker, n, seed = job
+    return globals()[maker](_PAR_REF, n, seed=seed)
+
+
+def parallel_batch(maker, ref, n, seed, workers=None, shard=500_000):
+    """``maker`` ("config2_batch" | "config3_batch" | "config4_batch") over ``n`` records as independent shards
+    of ``shard`` records, shard k seeded ``[seed, k]``, generated on a pool of forked worker processes and
+    concatenated in shard order — the full-size workloads (50 M records) in tens of seconds instead of minutes.
+    Deterministic in (maker, n, seed, shard); NOT the same records as ``maker(ref, n, seed)``.
+    Call it before the process touches the GPU (the workers are forked)."""
+    import multiprocessing as mp
+    import os
+    global _PAR_REF
+    jobs = [(maker, min(shard, n - lo), [seed, k]) for k, lo in enumerate(range(0, n, shard))]
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(workers or avail, len(jobs)))
+    _PAR_REF = ref
+    try:
+        if workers == 1:
+            parts = [_par_worker(j) for j in jobs]
+        else:
+            with mp.get_context("fork").Pool(workers) as pool:
+                parts = pool.map(_par_worker, jobs, chunksize=1)
+    finally:
+        _PAR_REF = None
+    return parts[0] if len(parts) == 1 else concat_batches(parts)
+
+
 def config4_batch(ref, n, seed=4):
     return make_reads(ref, n, seed, len_range=(35, 150), paired=True, frac_softclip=0.10,
                       frac_ins=0.04, frac_del=0.04, frac_skip=0.002, frac_hardclip=0.001,

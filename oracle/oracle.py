@@ -79,7 +79,7 @@ def tabulate_parallel(ref, batch, nlib, length, around, minqual=0, lgd_max=65536
     import os
     from concurrent.futures import ThreadPoolExecutor
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(threads or avail, 64, batch.n or 1))
+    threads = max(1, min(threads or avail, batch.n or 1))
     if threads == 1:
         return tabulate(ref, batch, nlib, length, around, minqual, lgd_max), 1
     cuts = [batch.n * t // threads for t in range(threads + 1)]

@@ -133,16 +133,16 @@ def test_hip_matches_oracle_seeded(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", range(3))
 def test_hip_rescale_fuzzed_cigars_match_oracle(k, tmp_path):
-    """The rescaling pass on the fuzzed CIGARs of tools/fuzz_vs_reference.py (without hard clips: the reference cannot
-    write a record whose clips are not plain S at the ends, rescale.py:266-271): qualities, MR, status, summary."""
+    """The rescaling pass on the fuzzed CIGARs of tools/fuzz_vs_reference.py (hard clips only where the reference
+    can write the record — not outside a soft clip, rescale.py:266-271): qualities, MR, status, summary."""
     from mapdamage_amd.batch import batch_from_records
     from mapdamage_amd.engine import DamageEngine
     from oracle import oracle
-    from tools.fuzz_vs_reference import fuzz_records
+    from tools.fuzz_vs_reference import fuzz_records, rescale_writable
     _, _, model, corr_prob, _, _ = load(tmp_path)
     ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500,
                             lower_run=3000)
-    recs = [r for r in fuzz_records(ref, 5000, 8100 + k, with_qual=True) if all(op != 5 for op, _ in r["cigar"])]
+    recs = [r for r in fuzz_records(ref, 5000, 8100 + k, with_qual=True) if rescale_writable(r["cigar"])]
     b = batch_from_records(recs, with_qual=True)
     rng = np.random.default_rng(30 + k)
     b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
@@ -159,6 +159,68 @@ def test_hip_rescale_fuzzed_cigars_match_oracle(k, tmp_path):
     np.testing.assert_array_equal(got_st, want_st)
     assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+
+
+def hardclip_records(ref, n=600, seed=5):
+    """Records whose CIGAR ends in a hard clip (bwa-mem supplementary alignments; rescaling applies no flag filter):
+    50M5H, 5H50M, 5H50M5H, also around a soft clip on the other side and with an indel."""
+    rng = np.random.default_rng(seed)
+    bases, offs = ref.concat()
+    upper = bases & np.uint8(0xDF)
+    shapes = [[(0, 50), (5, 5)], [(5, 5), (0, 50)], [(5, 5), (0, 50), (5, 5)], [(4, 4), (0, 40), (5, 7)],
+              [(5, 3), (0, 30), (1, 2), (0, 20), (5, 9)], [(5, 6), (0, 25), (2, 3), (0, 25), (4, 5)]]
+    recs = []
+    for i in range(n):
+        cig = shapes[i % len(shapes)]
+        span = sum(ln for op, ln in cig if op in (0, 2))
+        pos = int(rng.integers(20, ref.lengths[0] - span - 20))
+        seq, r = [], int(offs[0]) + pos
+        for op, ln in cig:
+            if op == 0:
+                seq.append(upper[r:r + ln].copy()); r += ln
+            elif op == 2:
+                r += ln
+            elif op in (1, 4):
+                seq.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), ln))
+        seq = np.concatenate(seq)
+        # damage-like substitutions so that something is rescaled
+        seq = np.where((seq == ord("C")) & (rng.random(seq.shape[0]) < 0.3), ord("T"), seq)
+        seq = np.where((seq == ord("G")) & (rng.random(seq.shape[0]) < 0.3), ord("A"), seq).astype(np.uint8)
+        recs.append(dict(flag=int(rng.choice([0, 16, 0x800, 0x810])), tid=0, pos=pos, cigar=cig, seq=seq.tobytes().decode(),
+                         qual=rng.integers(2, 42, seq.shape[0]).astype(np.uint8), lib=0, tlen=0))
+    return recs
+
+
+def test_oracle_rescales_hard_clipped_records(tmp_path):
+    """a CIGAR ending in H is rescaled like any other (rescale.py:266-271 only re-attaches S clips)."""
+    from mapdamage_amd.batch import batch_from_records
+    from oracle import oracle
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.small_genome()
+    b = batch_from_records(hardclip_records(ref), with_qual=True)
+    b.mtid = b.tid.copy(); b.mpos = b.pos.copy()
+    q, mr, st = oracle.rescale(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    assert set(np.unique(st)) == {2} and not np.isnan(mr).any()
+    assert int((q != b.qual).sum()) > 50
+
+
+@pytest.mark.gpu
+def test_hip_rescales_hard_clipped_records(tmp_path):
+    from mapdamage_amd.batch import batch_from_records
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.small_genome()
+    b = batch_from_records(hardclip_records(ref), with_qual=True)
+    b.mtid = b.tid.copy(); b.mpos = b.pos.copy()
+    want_q, want_mr, want_st = oracle.rescale(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        got_q, got_mr, got_st = eng.rescale(b)
+    np.testing.assert_array_equal(got_q, want_q)
+    np.testing.assert_array_equal(got_st, want_st)
+    np.testing.assert_array_equal(got_mr, want_mr)
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """Fuzz of the rescaling pass: the reference's own _rescale_qual_core (tools/ref_harness.py, build container only)
-against the C oracle on the random CIGARs of tools/fuzz_vs_reference.py (no hard clips): new qualities and MR tags.
+against the C oracle on the random CIGARs of tools/fuzz_vs_reference.py (hard clips only where the reference can write the record: not outside a soft clip): new qualities and MR tags.
 usage: python tools/fuzz_rescale_vs_reference.py [rounds]"""
 import pathlib
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, str(ROOT))
 from mapdamage_amd import synth  # noqa: E402
 from mapdamage_amd.batch import batch_from_records  # noqa: E402
 from mapdamage_amd.rescale import RescaleModel, get_corr_prob  # noqa: E402
-from tools.fuzz_vs_reference import fuzz_records  # noqa: E402
+from tools.fuzz_vs_reference import fuzz_records, rescale_writable  # noqa: E402
 
 
 def main():
@@ -31,7 +31,7 @@ def main():
     for (r, _s, p), v in cp.items():
         corr[0 if r == "C" else 1, p if p > 0 else model.len5p - p] = v
     for k in range(rounds):
-        recs = [r for r in fuzz_records(ref, 1200, 9100 + k, with_qual=True) if all(op != 5 for op, _ in r["cigar"])]
+        recs = [r for r in fuzz_records(ref, 1200, 9100 + k, with_qual=True) if rescale_writable(r["cigar"])]
         b = batch_from_records(recs, with_qual=True)
         rng = np.random.default_rng(k)
         b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
