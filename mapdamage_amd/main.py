@@ -10,6 +10,8 @@ import sys
 import time
 from pathlib import Path
 
+import numpy as np
+
 from . import __version__
 from .engine import BadReadError, DamageEngine
 from .fasta import compare_sequence_dicts, read_fasta_index, reference_for_bam
@@ -189,16 +191,24 @@ def main(argv):
         with DamageEngine(libraries, options.length, options.around, options.minqual,
                           device=options.device) as engine:
             engine.set_reference(ref)
-            n_reads, any_qual = 0, False
+            n_reads, warned_about_quals = 0, False
             # a BAM file arrives in chunks (bounded host memory; chunk k+1 is decoded while chunk k is tabulated)
             for batch in reader.iter_batches():
-                n_reads += batch.n
-                if options.minqual and not any_qual:
-                    any_qual = bool((batch.qual != 0xFF).any())
+                if options.minqual and not warned_about_quals and batch.n:
+                    # main.py:185-192: the first iterated read without qualities (`not read.qual`: absent or
+                    # empty) triggers the warning, once
+                    lens = np.diff(batch.seq_off.astype(np.int64))
+                    first = np.minimum(batch.seq_off[:-1].astype(np.int64), max(0, batch.seq.shape[0] - 1))
+                    if batch.qual is None or bool(((lens == 0) | (batch.qual[first] == 0xFF)).any()):
+                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                        warned_about_quals = True
                 for lo in range(0, batch.n, options.batch_reads):
-                    engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
-            if options.minqual and n_reads and not any_qual:
-                logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                    try:
+                        engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
+                    except BadReadError as error:
+                        # index within the records iterated so far (the reference would name the read)
+                        raise BadReadError(n_reads + lo + error.read_index, str(error)) from None
+                n_reads += batch.n
             tables = engine.finish()
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)

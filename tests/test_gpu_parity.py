@@ -156,8 +156,10 @@ def test_hip_library_id_beyond_the_last_is_an_error(mid_genome):
     batch.lib[1234] = 7
     with DamageEngine([("S%d" % i, "L") for i in range(5)]) as eng:
         eng.set_reference(mid_genome)
-        eng.tabulate(batch)
-        with pytest.raises(BadReadError) as err:
+        with pytest.raises(BadReadError) as err:     # a host batch reports at once, with the index within the batch
+            eng.tabulate(batch)
+        assert err.value.read_index == 1234
+        with pytest.raises(BadReadError) as err:     # ... and the context stays in error until reset
             eng.sync()
     assert "1234" in str(err.value)
 
@@ -185,10 +187,12 @@ def test_hip_rejects_alignment_past_contig_end():
             dict(flag=0, tid=2, pos=n_last - 10, cigar=[(0, 25)], seq="A" * 25, qual=None, lib=0, tlen=0)]
     with DamageEngine([("s", "l")]) as eng:
         eng.set_reference(ref)
-        eng.tabulate(batch_from_records(recs))
+        dev = eng.upload(batch_from_records(recs))   # a resident batch is only enqueued: the error surfaces at finish
+        eng.tabulate(dev)
         with pytest.raises(BadReadError) as e:
             eng.finish()
         assert e.value.read_index == 1
+        dev.free()
 
 
 def test_hip_empty_and_all_filtered_batches():
