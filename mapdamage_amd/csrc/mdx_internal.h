@@ -5,12 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Raw (reference-orientation) accumulator layout, in words, per library:
+// Raw (reference-orientation) accumulator layout, in words, per library (order: TC, MIS, CMP, LGD):
 //   MIS [strand 2][side 2][L][25]   rare events: substitutions, indels, soft clips; base columns
 //                                    0..3 (A,C,T,G order = (ascii >> 1) & 3) count the matching
 //                                    columns of gapped records
 //   CMP [strand 2][side 2][L][4]    read-base counts of columns that are not plain matches
-//   (padding to a multiple of 64 words: the TC planes are 256-byte aligned in the LDS)
 //   TC  [strand 2][base 4][512]     the common case of plain (ungapped) records: read base == reference
 //                                    base, or an A/C/G/T flank base.  One lane of the wavefront owns
 //                                    eight consecutive bytes of a record's window, flank and columns
@@ -38,9 +37,13 @@ struct MdxDims {
     int t_pad;            // words per TC plane: 512 with the fast path
     int w_mis, w_cmp, w_mc, w_tc, w_lgd, w_lib;
     int64_t w_total;      // nlib * w_lib + 1
-    __host__ __device__ int off_cmp() const { return w_mis; }
-    __host__ __device__ int off_tc() const { return w_mc; }
-    __host__ __device__ int off_lgd() const { return w_mc + w_tc; }
+    // word offsets within a library: TC first (256-byte aligned planes; the optimistic increments of a gapped record
+    // behind a deletion address MIS / CMP rows by position — for bytes that are not tasks the position can be a few
+    // rows below row 0: such adds of 0 then fall into the TC words instead of outside the table)
+    __host__ __device__ int off_tc() const { return 0; }
+    __host__ __device__ int off_mis() const { return w_tc; }
+    __host__ __device__ int off_cmp() const { return w_tc + w_mis; }
+    __host__ __device__ int off_lgd() const { return w_tc + w_mc; }
     // task -> TC index of slot 0 (slot g adds g * G)
     __host__ __device__ int tau_left(int p) const { const int b = p + A; return 64 * (b & 7) + (b >> 3); }
     __host__ __device__ int tau_right(int p) const { const int e = p + A; return 64 * (7 - (e & 7)) + nl8 + (e >> 3); }
@@ -79,10 +82,10 @@ static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd
     }
     d.w_mis = 2 * 2 * L * 25;
     d.w_cmp = 2 * 2 * L * 4;
-    d.w_mc = (d.w_mis + d.w_cmp + 63) / 64 * 64;
+    d.w_mc = d.w_mis + d.w_cmp;
     d.w_tc = 2 * 4 * d.t_pad;
     d.w_lgd = 2 * 2 * lgd_lds;
-    d.w_lib = (d.w_mc + d.w_tc + d.w_lgd + 63) / 64 * 64;
+    d.w_lib = (d.w_tc + d.w_mc + d.w_lgd + 63) / 64 * 64;
     d.w_total = (int64_t)nlib * d.w_lib + 1;
     return d;
 }

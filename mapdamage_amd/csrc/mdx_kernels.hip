@@ -273,15 +273,31 @@ __device__ __forceinline__ int mis_col(int r, int s) {
 // sum of the r>x columns).
 template <bool USE_LDS>
 __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b_cmp, int L, int side,
-                                            int p, u32 ch, int rch, bool masked) {
+                                            int p, int pc, u32 ch, int rch, bool masked) {
+    // p: misincorporation position (column), pc: composition position (query index; differs behind a deletion)
     const int s = classify_read(ch);
     const int sp = side * L + p;
-    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + sp * 4 + s);
+    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + pc) * 4 + s);
     if (!masked && s <= SYM_GAP) {
         const int r = classify_ref(rch);
         if (r <= SYM_GAP && r != s) {  // statistics.py:26-35
             bump<USE_LDS>(lds, raw, b_mis + sp * 25 + mis_col(r, s));
         }
+    }
+}
+
+enum { STEP_C = 0, STEP_P = 1, STEP_GI = 2, STEP_GD = 3 };   // kinds of fast-path steps (tabulate_kernel::count)
+
+// Eight optimistic increments by position: word (base_bytes / 4) + (STRIDE / 4) j + class of reference byte j gets
+// bit 0 of byte j of the mask (MIS rows: STRIDE 100, CMP rows: STRIDE 16).  LDS only.
+template <int STRIDE>
+__device__ __forceinline__ void direct8(u32 *lds, u32 r_lo, u32 r_hi, u32 base_bytes, u32 m_lo, u32 m_hi) {
+    u32 *const row = lds + (base_bytes >> 2);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u32 r = j < 4 ? r_lo : r_hi, m = j < 4 ? m_lo : m_hi;
+        const u32 k = (r >> (8 * (j & 3) + 1)) & 3u;
+        atomicAdd(&row[j * (STRIDE / 4) + k], (m >> (8 * (j & 3))) & 1u);
     }
 }
 
@@ -299,14 +315,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const u32 nwaves = gridDim.x * waves_per_block;
     u64 *raw = a.raw;
 
-    // bytes [lo, hi) of a 64-bit word from a nine-entry LDS table (entry n = the low n bytes set) instead of
-    // 64-bit shifts: the per-record byte masks of the partial steps
+    // nine-entry LDS table of byte masks (entry n = the low n bytes of a 64-bit word set): the per-record byte masks
+    // of the partial steps are two or three lookups instead of 64-bit shifts
     u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (MDX_BLOCK / 64) * EVQ_BYTES);
-    auto brange = [&](int lo, int hi) -> u64 {
-        lo = lo < 0 ? 0 : (lo > 8 ? 8 : lo);
-        hi = hi < 0 ? 0 : (hi > 8 ? 8 : hi);
-        return ltab[hi] & ~ltab[lo];
-    };
     if (USE_LDS) {
         for (i64 i = threadIdx.x; i < d.w_total; i += MDX_BLOCK) lds[i] = 0;
         if (FAST && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
@@ -369,8 +380,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     u32 *const qW = (u32 *)(qR + EVQ_CAP);
     int qcount = 0;
 
-    // Undo the optimistic TC increment of each queued byte that was not a plain match and, for read
+    // Undo the optimistic increment of each queued byte that was not a plain match and, for read
     // columns, count what the byte really is (rare_column) — lane-parallel over the queued events.
+    // Event word: [7:0] masked-quality flags (MASK) | [17:8] TC base of the record (bytes >> 8) | [23:18] lane |
+    // [29:24] library | [30] the entry is a single deletion (then [10:8] = deleted bases g, [14:11] = first byte of
+    // the lane that lies behind the deletion — on the right side: the bytes below it — and the TC base is recomputed)
+    // | [31] reverse strand.
     auto drain_all = [&]() {
         if (lane < qcount) {
             const u32x2 es = qS[lane], er = qR[lane];
@@ -378,7 +393,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const int ln = (int)(w >> 18) & 63;
             const int rev = (int)(w >> 31);
             const int lb = (int)((w >> 24) & 0x3Fu) * d.w_lib;
-            const int tcw = (int)((w & 0x3FF00u) >> 2);            // first word of TC[library][strand]
+            const bool del = (w >> 30) & 1u;
+            const int g = del ? (int)(w >> 8) & 7 : 0, bnd = (int)(w >> 11) & 15;
+            const int tcw = del ? lb + d.off_tc() + rev * 4 * 512 : (int)((w & 0x3FF00u) >> 2);   // first word of TC[library][strand]
             int ll = ln;  // lane within its slot (R <= 4)
             if (ll >= d.G) ll -= d.G;
             if (ll >= d.G) ll -= d.G;
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const u64 s64 = (u64)es.x | ((u64)es.y << 32), r64 = (u64)er.x | ((u64)er.y << 32);
             u64 x = (((s64 ^ r64) & em) | (r64 & 0x8080808080808080ull)) & vm;
             if (MASK) x |= spread_bits(w & 0xFFu);
-            const int b_mis = lb + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+            const int b_mis = lb + d.off_mis() + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
             // usually exactly one byte of the lane differs: handle the lowest such byte (all lanes busy),
             // repeat only while some lane has another
             while (x) {
@@ -399,9 +416,18 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 x &= ~(0xFFull << sh);
                 const u32 rb = (u32)(r64 >> sh) & 0xFFu, sb = (u32)(s64 >> sh) & 0xFFu;
                 const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
-                bump_n<USE_LDS>(lds, raw, tcw + (int)(((rb >> 1) & 3u) << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
+                // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
+                // CMP[p - g] (its query index) instead of TC
+                const bool direct = del && (side ? jb < bnd : jb >= bnd);
+                const int pc = direct ? p - g : p;
+                if (direct) {
+                    bump_n<USE_LDS>(lds, raw, b_mis + (side * L + p) * 25 + (int)((rb >> 1) & 3u), 0xFFFFFFFFu);
+                    bump_n<USE_LDS>(lds, raw, b_cmp + (side * L + pc) * 4 + (int)((rb >> 1) & 3u), 0xFFFFFFFFu);
+                } else {
+                    bump_n<USE_LDS>(lds, raw, tcw + (int)(((rb >> 1) & 3u) << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
+                }
                 if ((em >> sh) & 1ull)
-                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, p, sb, (int)(i8)rb, MASK && ((w >> jb) & 1u));
+                    rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, p, pc, sb, (int)(i8)rb, MASK && ((w >> jb) & 1u));
             }
         }
         qcount = 0;
@@ -409,139 +435,111 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     };
 
-
-
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
-    struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, nqz; int lim; bool valid, far; };
-    // complete = true: every task of the record is present (static byte masks); false: byte masks per
-    // record (short records, contig edges, the plain prefixes of gapped records)
-    auto count = [&](const Stage &st, auto complete_tag, const bool far) {
-        constexpr bool complete = decltype(complete_tag)::value;
+    struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, aux; int lim; bool valid; };
+    // Three kinds of steps (one instantiation each):
+    //   STEP_C  complete records: every task present, static byte masks;
+    //   STEP_P  a column range per side: short records and contig edges ([-flank, min(nq, L))), gapped records whose
+    //           first / last match run is counted here and the rest by the CIGAR walk ([-A, run)), records gapped by
+    //           N / P operations only ([-A, min(nq, L)): both windows are an ungapped record's);
+    //   STEP_G  records with one short insertion or deletion ([H][S] M {I|D} M [S][H], D_ONE), the whole record in one
+    //           entry.  Lanes work in *column* space.  On the left side column c of the string that carries the gap
+    //           (reference for an insertion, read for a deletion) is byte c of its window in front of the gap
+    //           (c < u, the first match run), the gap symbol for u <= c < u + g, and byte c - g behind it: a lane
+    //           whose first column lies at or behind the gap loads its window g bytes lower (fill()), the lane that
+    //           straddles the gap shifts its own bytes up by g.  The right side mirrors this from aend.
+    //           An insertion keeps one position per column for both tables: the ordinary optimistic step.  Behind a
+    //           deletion the composition position (query index) is g less than the misincorporation position
+    //           (column): those bytes are counted, still optimistically, straight into MIS[c][base] and CMP[c - g][base]
+    //           (direct8) instead of TC, and their events say so (drain_all).
+    auto count = [&](const Stage &st, auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
         // slots past the last record of the tile: no increments, no events
         const bool act = lane < st.lim;
         u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
         u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
-        u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi, hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
+        u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi;
+        const u32 hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
         const u32 base_b = tc_base(st.pk, c_lane4);
-        // MASK: bit 7 of the bytes whose quality is below --min-basequal (align.py:65-71)
-        u32 lowq_lo = 0, lowq_hi = 0;
+        u32 q_lo = 0, q_hi = 0;
         if (MASK) {
-            const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
-            const u32 q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo), q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
-            lowq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u;
-            lowq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u;
+            q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo);
+            q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
         }
-        if (complete) {
+        u32 evw = st.pk & 0xBF03FF00u;    // event word of this lane (without lane and quality bits)
+        if (KIND == STEP_C) {
             // optimistic: count every byte as a plain match (the base class of the reference
             // byte selects the plane of TC) ...
             tc_bump8_all(r_lo, r_hi, base_b, act ? 1u : 0u);
         } else {
-            // the tasks of this lane's side as a column range [k0, k1) (negative = flank bytes): from the
-            // record's nq and flank lengths (short / contig-edge records) or, for a gapped record, from the
-            // lengths of its first / last match run:
-            //   near pass: flank + the columns of the run next to this end (u of them) — same pairing and same
-            //     positions as in an ungapped record; a D_ONE deletion adds the d deleted columns behind it (read
-            //     byte forced to '-');
-            //   far pass (D_ONE only): the columns behind the run.  Insertion of g bases: the reference window is
-            //     shifted by g (fill()), the g inserted columns pair with '-' (reference byte forced), and every
-            //     column keeps one position for both tables — the ordinary step.  Deletion: the window is
-            //     anchored at the read (composition position), the misincorporation position is g further on;
-            //     such bytes take direct increments of both tables instead of the optimistic one.
-            const u32 z = st.nqz;
-            const int nq_ = (int)(z & 0x7FFFu);
-            int k0, k1 = nq_ < L ? nq_ : L, f0 = 0, f1 = 0;
-            bool fs = false, fr = false, shifted = false;
-            if (z & 0x8000u) {
-                const int u = c_side ? (int)(z >> 24) : (int)(z >> 16) & 0xFF;
-                const int dd = (int)(i8)(st.pk & 0xFFu);
-                if (!far) {
-                    k0 = -A; k1 = u;
-                    if ((st.pk & PK_ONE) && dd > 0) { fs = true; f0 = u; k1 = u + dd < L ? u + dd : L; f1 = k1; }
-                } else {
-                    k0 = u;
-                    if (dd < 0) { fr = true; f0 = u; f1 = u - dd; } else shifted = true;
-                }
+            // byte thresholds of this lane, computed by fill() (times eight: offsets into the byte-mask table)
+            const u32 aux = st.aux;
+            u32 dyn_lo, dyn_hi, tcd_lo, tcd_hi;
+            if (KIND == STEP_P) {
+                // tasks = bytes [lo, hi)
+                const u64 Lo = *(const u64 *)((const u8 *)ltab + (aux & 0x7Fu)), Hi = *(const u64 *)((const u8 *)ltab + ((aux >> 7) & 0x7Fu));
+                dyn_lo = (u32)Hi & ~(u32)Lo & c_vm_lo; dyn_hi = (u32)(Hi >> 32) & ~(u32)(Lo >> 32) & c_vm_hi;
+                tcd_lo = dyn_lo; tcd_hi = dyn_hi;
             } else {
-                k0 = c_side ? -(int)(z >> 24) : -((int)(z >> 16) & 0xFF);
-            }
-            const int jo = c_side ? c_m8 + 8 - A : A - c_m8;   // byte of column k: jo + k (left), jo - 1 - k (right)
-            const u64 dyn = act ? brange(c_side ? jo - k1 : jo + k0, c_side ? jo - k0 : jo + k1) : 0ull;
-            const u32 dyn_lo = (u32)dyn & c_vm_lo, dyn_hi = (u32)(dyn >> 32) & c_vm_hi;
-            emvm_lo = c_em_lo & dyn_lo; emvm_hi = c_em_hi & dyn_hi;
-            hivm_lo = dyn_lo & 0x80808080u; hivm_hi = dyn_hi & 0x80808080u;
-            // bytes that are not tasks of this record: a neutral matching pair in the event copy
-            s_lo = (s_lo & dyn_lo) | (0x41414141u & ~dyn_lo); s_hi = (s_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
-            r_lo = (r_lo & dyn_lo) | (0x41414141u & ~dyn_lo); r_hi = (r_hi & dyn_hi) | (0x41414141u & ~dyn_hi);
-            u32 tcd_lo = dyn_lo, tcd_hi = dyn_hi;
-            {
-                if (fs | fr) {
-                    const u64 fm = brange(c_side ? jo - f1 : jo + f0, c_side ? jo - f0 : jo + f1);
-                    const u32 fm_lo = (u32)fm & dyn_lo, fm_hi = (u32)(fm >> 32) & dyn_hi;
-                    if (fs) {   // (a deleted column has no quality of its own: never masked, align.py:67)
-                        s_lo = (s_lo & ~fm_lo) | (0x2D2D2D2Du & fm_lo); s_hi = (s_hi & ~fm_hi) | (0x2D2D2D2Du & fm_hi);
-                        lowq_lo &= ~fm_lo; lowq_hi &= ~fm_hi;
+                // [ta, tb) = the gap, tasks end at byte tl (left side; on the right side they start there)
+                const u64 X = *(const u64 *)((const u8 *)ltab + (aux & 0x7Fu)), Y = *(const u64 *)((const u8 *)ltab + ((aux >> 7) & 0x7Fu)),
+                          T = *(const u64 *)((const u8 *)ltab + ((aux >> 14) & 0x7Fu));
+                const u32 sm = 0u - (u32)c_side;                         // all ones on the right side
+                dyn_lo = ((u32)T ^ sm) & c_vm_lo; dyn_hi = ((u32)(T >> 32) ^ sm) & c_vm_hi;
+                // the string that carries the gap (reference for an insertion, read for a deletion): its bytes in front
+                // of the gap as loaded (a lane at or behind the gap holds none), the gap symbol, its bytes behind the
+                // gap moved by g within the lane that straddles it (shb = 8 g there, 0 elsewhere)
+                const u32 shb = ((aux >> 21) & 7u) << 3, shr = shb & sm, shl = shb & ~sm;
+                const u64 star = KIND == STEP_GD ? ((u64)s_lo | ((u64)s_hi << 32)) : ((u64)r_lo | ((u64)r_hi << 32));
+                const u64 low = star >> shr, high = star << shl;
+                const u32 gapc = KIND == STEP_GD ? 0x2D2D2D2Du : 0x84848484u;
+                const u32 X_lo = (u32)X, X_hi = (u32)(X >> 32), Y_lo = (u32)Y, Y_hi = (u32)(Y >> 32);
+                u32 m_lo = (X_lo & (u32)low) | (~X_lo & gapc), m_hi = (X_hi & (u32)(low >> 32)) | (~X_hi & gapc);
+                m_lo = (Y_lo & m_lo) | (~Y_lo & (u32)high); m_hi = (Y_hi & m_hi) | (~Y_hi & (u32)(high >> 32));
+                tcd_lo = dyn_lo; tcd_hi = dyn_hi;
+                if (KIND == STEP_GD) {
+                    s_lo = m_lo; s_hi = m_hi;
+                    if (MASK) {
+                        // the qualities travel with the read; a deleted column has none (never masked, align.py:67)
+                        const u64 q64 = (u64)q_lo | ((u64)q_hi << 32), ql = q64 >> shr, qh = q64 << shl;
+                        q_lo = (X_lo & (u32)ql) | ~X_lo; q_hi = (X_hi & (u32)(ql >> 32)) | ~X_hi;
+                        q_lo = (Y_lo & q_lo) | (~Y_lo & (u32)qh); q_hi = (Y_hi & q_hi) | (~Y_hi & (u32)(qh >> 32));
                     }
-                    else { r_lo = (r_lo & ~fm_lo) | (0x84848484u & fm_lo); r_hi = (r_hi & ~fm_hi) | (0x84848484u & fm_hi); }
-                }
-                if (far && shifted) {
-                    // counted here, byte by byte, straight into CMP (position p) and MIS (position p + g; base
-                    // column on a match): no optimistic increment, no event
-                    const int g = (int)(st.pk & 0xFFu);
-                    const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
-                    const int b_mis = lbw + (rev * 2 + c_side) * L * 25, b_cmp = lbw + d.off_cmp() + (rev * 2 + c_side) * L * 4;
-                    const u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32);
-                    // 0x01 per task byte that is not a plain match (read != reference, or an invalid reference byte)
-                    const u32 xl = ((s_lo ^ r_lo) | (r_lo & 0x80808080u)) & dyn_lo, xh = ((s_hi ^ r_hi) | (r_hi & 0x80808080u)) & dyn_hi;
-                    const u32 nzl = ((((xl & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xl) >> 7) & 0x01010101u;
-                    const u32 nzh = ((((xh & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xh) >> 7) & 0x01010101u;
-                    u64 todo;
-                    if (USE_LDS) {
-                        // the plain matches of all eight bytes at once: CMP[p][base] and (p + g < L) MIS[p + g][base]
-                        // with a 0/1 increment per byte; only the other bytes take the loop below
-                        const u32 ml = dyn_lo & 0x01010101u & ~nzl, mh = dyn_hi & 0x01010101u & ~nzh;
-                        const int p0 = (c_side ? c_m8 + 7 : c_m8) - A, stp = c_side ? -1 : 1;
-                        const u64 r64m = (u64)r_lo | ((u64)r_hi << 32), m64 = (u64)ml | ((u64)mh << 32);
-#pragma unroll 1
-                        for (int jb = 0; jb < 8; jb++) {   // (rolled: register pressure of this rarely used block)
-                            const u32 k = (u32)(r64m >> (8 * jb + 1)) & 3u;
-                            const u32 dc = (u32)(m64 >> (8 * jb)) & 1u;
-                            const int p = p0 + stp * jb;
-                            const int ic = b_cmp + p * 4 + (int)k;
-                            const bool mok = dc && p + g < L && !(MASK && (((jb < 4 ? lowq_lo : lowq_hi) >> (8 * (jb & 3) + 7)) & 1u));
-                            atomicAdd(&lds[ic], dc);                                        // (a byte that is no task adds 0
-                            atomicAdd(&lds[mok ? b_mis + (p + g) * 25 + (int)k : ic], mok ? 1u : 0u);   //  to a valid word)
-                        }
-                        todo = (u64)nzl | ((u64)nzh << 32);
-                    } else {
-                        todo = ((u64)dyn_lo | ((u64)dyn_hi << 32)) & 0x0101010101010101ull;
+                    // bytes behind the deletion (left: from tb on, right: below ta): MIS[column][base] and
+                    // CMP[column - g][base], one increment each like tc_bump8 (bytes in position order: reversed on the
+                    // right side), instead of TC
+                    const u32 beh_lo = (X_lo & sm) | (~Y_lo & ~sm), beh_hi = (X_hi & sm) | (~Y_hi & ~sm);
+                    const u32 dm_lo = dyn_lo & beh_lo, dm_hi = dyn_hi & beh_hi;
+                    tcd_lo &= ~beh_lo; tcd_hi &= ~beh_hi;
+                    evw = (st.pk & 0xBF000000u) | 0x40000000u | (((aux >> 24) & 0x7Fu) << 8);
+                    if (__ballot((dm_lo | dm_hi) != 0u)) {
+                        const int g = (int)((aux >> 24) & 7u);
+                        const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
+                        const int row = (rev * 2 + c_side) * L + c_m8 - A;        // row of the lane's lowest position
+                        const u32 p_lo = c_side ? 0x04050607u : 0x03020100u, p_hi = c_side ? 0x00010203u : 0x07060504u;
+                        const u32 rr_lo = __builtin_amdgcn_perm(r_hi, r_lo, p_lo), rr_hi = __builtin_amdgcn_perm(r_hi, r_lo, p_hi);
+                        const u32 mm_lo = __builtin_amdgcn_perm(dm_hi, dm_lo, p_lo), mm_hi = __builtin_amdgcn_perm(dm_hi, dm_lo, p_hi);
+                        direct8<100>(lds, rr_lo, rr_hi, (u32)(4 * (lbw + d.off_mis() + row * 25)), mm_lo, mm_hi);
+                        direct8<16>(lds, rr_lo, rr_hi, (u32)(4 * (lbw + d.off_cmp() + (row - g) * 4)), mm_lo, mm_hi);
                     }
-                    // (a rolled loop: this code sits in every step of the partial run, and is rarely reached)
-#pragma unroll 1
-                    while (todo) {
-                        const int sh = __ffsll((long long)todo) - 1, jb = sh >> 3;
-                        todo &= todo - 1;
-                        const u32 sb = (u32)(s64 >> sh) & 0xFFu, rb = (u32)(r64 >> sh) & 0xFFu;
-                        const int p = (c_side ? c_m8 + 7 - jb : c_m8 + jb) - A;
-                        // (a masked column counts its read base only)
-                        const bool msk = MASK && (((jb < 4 ? lowq_lo : lowq_hi) >> (8 * (jb & 3) + 7)) & 1u);
-                        if (sb == rb && rb < 0x80u) {   // plain match (a valid reference byte is one of A, C, G, T)
-                            const int k = (int)(rb >> 1) & 3;
-                            bump<USE_LDS>(lds, raw, b_cmp + p * 4 + k);
-                            if (p + g < L && !msk) bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + k);
-                        } else {
-                            const int s = classify_read(sb), r = classify_ref((int)(i8)rb);
-                            if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + p * 4 + s);
-                            if (!msk && p + g < L && s <= SYM_GAP && r <= SYM_GAP && (r != s || r != SYM_GAP))
-                                bump<USE_LDS>(lds, raw, b_mis + (p + g) * 25 + (r != s ? mis_col(r, s) : r));
-                        }
-                    }
-                    tcd_lo = 0; tcd_hi = 0;
-                    emvm_lo = 0; emvm_hi = 0; hivm_lo = 0; hivm_hi = 0;
+                } else {
+                    r_lo = m_lo; r_hi = m_hi;
                 }
             }
+            // bytes that are not tasks of this record: zero in both strings (a pair that raises no event and that
+            // drain_all passes over)
+            s_lo &= dyn_lo; s_hi &= dyn_hi; r_lo &= dyn_lo; r_hi &= dyn_hi;
+            if (MASK) { emvm_lo &= dyn_lo; emvm_hi &= dyn_hi; }   // (the quality bytes are not zeroed)
             tc_bump8(r_lo, r_hi, base_b, tcd_lo & 1u, (tcd_lo >> 8) & 1u, (tcd_lo >> 16) & 1u, (tcd_lo >> 24) & 1u,
                      tcd_hi & 1u, (tcd_hi >> 8) & 1u, (tcd_hi >> 16) & 1u, (tcd_hi >> 24) & 1u);
+        }
+        // MASK: bit 7 of the bytes whose quality is below --min-basequal (align.py:65-71)
+        u32 lowq_lo = 0, lowq_hi = 0;
+        if (MASK) {
+            const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
+            lowq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u;
+            lowq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u;
         }
         // x: per byte, zero iff the byte is a plain match (read == reference, reference is
         // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
@@ -552,7 +550,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // the masked columns of this lane: bit 7 of the byte
             mq_lo = lowq_lo & emvm_lo;
             mq_hi = lowq_hi & emvm_hi;
-            if (USE_LDS) {
+            if (USE_LDS && KIND != STEP_GI && KIND != STEP_GD) {
                 // a masked column counts its read base (CMP) and nothing else (align.py:65-71 turns both symbols into
                 // N): corrected here — the optimistic TC increment undone, CMP bumped — one byte per iteration, as
                 // many iterations as the fullest lane has masked bytes; such bytes raise no event
@@ -575,10 +573,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         const int sc = classify_read(sb);
                         if (sc < 4) atomicAdd(&lds[b_cmp + ((c_side ? c_m8 + 7 - jb : c_m8 + jb) - A) * 4 + sc], 1u);
                     }
-                    // (a neutral matching pair in the event copy: drain_all must not look at these bytes again)
+                    // (a matching pair in the event copy: drain_all must not look at these bytes again)
                     const u32 mb_lo = (t_lo << 8) - t_lo, mb_hi = (t_hi << 8) - t_hi;
-                    s_lo = (s_lo & ~mb_lo) | (0x41414141u & mb_lo); s_hi = (s_hi & ~mb_hi) | (0x41414141u & mb_hi);
-                    r_lo = (r_lo & ~mb_lo) | (0x41414141u & mb_lo); r_hi = (r_hi & ~mb_hi) | (0x41414141u & mb_hi);
+                    s_lo &= ~mb_lo; s_hi &= ~mb_hi; r_lo &= ~mb_lo; r_hi &= ~mb_hi;
                 }
                 if (many) { mq_lo = 0; mq_hi = 0; }
             }
@@ -586,7 +583,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
         // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
         u32 xx = x_lo | x_hi;
-        if (complete) xx = act ? xx : 0u;   // (the partial path masks by dyn already)
+        if (KIND == STEP_C) xx = act ? xx : 0u;   // (the other kinds mask by dyn already)
         const bool ev = xx != 0;
         const u64 mm = __ballot(ev);
         if (mm) {
@@ -598,7 +595,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 es.x = s_lo; es.y = s_hi; er.x = r_lo; er.y = r_hi;
                 qS[slot] = es;
                 qR[slot] = er;
-                u32 w = (st.pk & 0xBF03FF00u) | c_lane18;
+                u32 w = evw | c_lane18;
                 if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
                 qW[slot] = w;
             }
@@ -629,7 +626,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // trip for the tile instead of two)
         const u32 rj = valid ? ri : r_hi - 1;
         const u32 fl = valid ? (u32)a.flag[rj] : 0x4u;
-        const int c_lib = a.lib[rj], c_tid = a.tid[rj], c_pos = a.pos[rj];
+        const int c_lib = a.lib[rj], c_tid = a.tid[rj], c_pos = a.pos[rj], c_tlen = a.tlen[rj];
         const u32 c_co0 = a.cigar_off[rj], c_co1 = a.cigar_off[rj + 1], c_so0 = a.seq_off[rj], c_so1 = a.seq_off[rj + 1];
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
         // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
@@ -639,6 +636,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
         bool one = false;   // [H][S] M {I|D} M [S][H]: one indel between two match runs
         bool skips = false; // an N or P operation (or four and more indels)
+        bool nonly = false; // gapped by N / P operations only
         u32 sq = 0, cig_o = 0;
         i64 rbase = 0;
         int lkey = -1;  // fragment-length key for the LDS histogram
@@ -646,83 +644,128 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const int rev = (fl >> 4) & 1;
             libid = c_lib - a.lib_lo;
             const int tid = c_tid;
-            const i64 pos = c_pos;
+            const int pos = c_pos;
             cig_o = c_co0;
             cig_n = (int)(c_co1 - cig_o);
             const u32 so = c_so0;
             const i64 lseq = (i64)c_so1 - (i64)so;
             bool bad = tid < 0 || tid >= a.n_contig || c_lib >= a.nlib_total || lseq <= 0 || pos < 0;
             const int lbase = bad ? 0 : libid * d.w_lib;
-
-            // CIGAR scan: pysam query_alignment_start/_end, htslib bam_endpos, parse_cigar
-            i64 qs = 0, rlen = 0, qcons = 0, tl = 0, sI = 0, sDN = 0;
-            bool leading = true;
-            int lead_m = 0, cur_run = 0;   // first and current run of M/=/X columns (saturating)
-            bool lead_open = true;
-            int n_gap = 0;                 // I and D operations (N and P count as many)
-            for (int k = 0; k < cig_n; k++) {
-                const u32 c = a.cigar[cig_o + k];
-                const int op = c & 0xF;
-                const i64 len = c >> 4;
-                if (leading) {
-                    if (op == 4) qs += len;
-                    else if (op != 5) leading = false;
-                }
-                if (op == 0 || op == 7 || op == 8) {
-                    tl += len; rlen += len; qcons += len;
-                    const int l15 = len < 0x7FFF ? (int)len : 0x7FFF;
-                    cur_run = cur_run + l15 < 0x7FFF ? cur_run + l15 : 0x7FFF;
-                    if (lead_open) lead_m = cur_run;
-                } else if (op != 4 && op != 5) {   // I, D, N, P end a run
-                    lead_open = false; cur_run = 0;
-                    n_gap += op <= 2 ? 1 : 4;
-                }
-                if (op == 1) { tl += len; sI += len; qcons += len; }
-                else if (op == 2) { tl += len; rlen += len; sDN += len; }
-                else if (op == 3) { rlen += len; sDN += len; }
-                else if (op == 4 && !bad) {
-                    // statistics.py:37-51: left side iff no alignment column precedes the clip
-                    const int side = tl == 0 ? 0 : 1;
-                    const int m = len < L ? (int)len : L;
-                    const int base = lbase + ((rev * 2 + side) * L) * 25 + COL_S;
-                    // positions [0, m) as a difference: +1 at 0, -1 at m (finalize_kernel sums the prefix; the
-                    // partial tables are folded as signed words) instead of m increments
-                    if (m > 0) {
-                        bump<USE_LDS>(lds, raw, base);
-                        if (m < L) {
-                            if (USE_LDS) atomicAdd(&lds[base + m * 25], 0xFFFFFFFFu);
-                            else atomicAdd(&raw[base + m * 25], ~0ull);
-                        }
+            // second round trip of the tile: the first CIGAR operation and the contig bounds together
+            const u32 cg0 = cig_n > 0 ? a.cigar[cig_o] : 0u;
+            i64 c0 = 0, clen = 0;
+            if (!bad) {
+                c0 = a.contig_off[tid];
+                clen = a.contig_off[tid + 1] - c0;
+            }
+            // statistics.py:37-51: positions [0, min(len, L)) of a soft clip, left side iff no alignment column precedes
+            // it — as a difference: +1 at 0, -1 at m (finalize_kernel sums the prefix; the partial tables are folded as
+            // signed words) instead of m increments
+            auto clip = [&](const int side, const i64 len) {
+                const int m = len < (i64)L ? (int)len : L;
+                const int base = lbase + d.off_mis() + ((rev * 2 + side) * L) * 25 + COL_S;
+                if (m > 0 && !bad) {
+                    bump<USE_LDS>(lds, raw, base);
+                    if (m < L) {
+                        if (USE_LDS) atomicAdd(&lds[base + m * 25], 0xFFFFFFFFu);
+                        else atomicAdd(&raw[base + m * 25], ~0ull);
                     }
                 }
+            };
+
+            // CIGAR scan: pysam query_alignment_start/_end, htslib bam_endpos, parse_cigar.  One forward pass in 32-bit
+            // arithmetic, branch-free but for soft clips: sums of the match (M = X), query-consuming, reference-
+            // consuming and column operations (the I / D / N totals follow from them), first and last match run, leading
+            // and trailing soft clips.  Exact for CIGARs of at most 16 operations shorter than 2^24 with at most one soft
+            // clip per side; anything else is redone by the 64-bit pass below (ordinary data never takes it).
+            u32 sM = 0, sQ = 0, sR = 0, sC = 0, qs = 0, trail = 0;
+            int lead_m = 0, cur_run = 0;   // first and current (at the end: last) run of M/=/X columns
+            int nID = 0, nE = 0;           // I / D operations; operations that end a run (I, D, N, P, unknown ones)
+            bool redo = cig_n > 16;
+            if (!redo) {
+                u32 big = 0, cl_l = 0, cl_r = 0, lopen = ~0u, leading = ~0u;
+                for (int k = 0; k < cig_n; k++) {
+                    const u32 c = k == 0 ? cg0 : a.cigar[cig_o + k];
+                    const u32 op = c & 0xFu, len = c >> 4;
+                    big |= len >> 24;
+                    const u32 m = (0x181u >> op) & 1u, e = (0xFE4Eu >> op) & 1u, keep = e - 1u;
+                    sM = __umul24(len, m) + sM;
+                    sQ = __umul24(len, (0x183u >> op) & 1u) + sQ;
+                    sR = __umul24(len, (0x18Du >> op) & 1u) + sR;
+                    const u32 run = __umul24(len, m) + (u32)cur_run;
+                    lead_m = (int)((run & lopen) | ((u32)lead_m & ~lopen));
+                    cur_run = (int)(run & keep);
+                    lopen &= keep;
+                    nID += (int)((6u >> op) & 1u);
+                    nE += (int)e;
+                    const u32 clipop = 0u - ((0x30u >> op) & 1u);     // S or H: neither ends the leading clips nor the trailing ones
+                    trail &= clipop; leading &= clipop;
+                    if (op == 4u) {
+                        qs += len & leading;
+                        if (k >= 1) trail += len;
+                        if (sC == 0) { redo = redo || cl_l != 0; cl_l = len; }
+                        else { redo = redo || cl_r != 0; cl_r = len; }
+                    }
+                    sC = __umul24(len, (0x187u >> op) & 1u) + sC;
+                }
+                redo = redo || big != 0;
+                if (!redo) {
+                    if (cl_l) clip(0, (i64)cl_l);
+                    if (cl_r) clip(1, (i64)cl_r);
+                }
             }
-            i64 qe = lseq;
-            for (int k = cig_n - 1; k >= 1; k--) {
-                const u32 c = a.cigar[cig_o + k];
-                const int op = c & 0xF;
-                if (op == 5) continue;
-                if (op == 4) qe -= (i64)(c >> 4);
-                else break;
+            bool over = false;             // sums beyond what a batch can hold (64-bit pass only)
+            if (__ballot(redo)) {
+                if (redo) {
+                    i64 w_qs = 0, w_M = 0, w_Q = 0, w_R = 0, w_C = 0, w_trail = 0;
+                    bool leading = true, lead_open = true;
+                    lead_m = 0; cur_run = 0; nID = 0; nE = 0;
+                    for (int k = 0; k < cig_n; k++) {
+                        const u32 c = a.cigar[cig_o + k];
+                        const int op = c & 0xF;
+                        const i64 len = c >> 4;
+                        if (op == 0 || op == 7 || op == 8) {
+                            w_C += len; w_R += len; w_Q += len; w_M += len;
+                            const int l15 = len < 0x7FFF ? (int)len : 0x7FFF;
+                            cur_run = cur_run + l15 < 0x7FFF ? cur_run + l15 : 0x7FFF;
+                            if (lead_open) lead_m = cur_run;
+                            leading = false; w_trail = 0;
+                        } else if (op == 4) {
+                            if (leading) w_qs += len;
+                            if (k >= 1) w_trail += len;
+                            clip(w_C == 0 ? 0 : 1, len);
+                        } else if (op != 5) {   // I, D, N, P end a run
+                            lead_open = false; cur_run = 0; leading = false; w_trail = 0;
+                            nE++;
+                            if (op == 1) { w_C += len; w_Q += len; nID++; }
+                            else if (op == 2) { w_C += len; w_R += len; nID++; }
+                            else if (op == 3) w_R += len;
+                        }
+                    }
+                    over = w_C > 0x3FFFFFFF || w_R + (w_Q - w_M) > 0x3FFFFFFF;
+                    sM = (u32)w_M; sQ = (u32)w_Q; sR = (u32)w_R; sC = (u32)w_C;
+                    // (clips beyond any SEQ length saturate: the aligned query is empty either way)
+                    qs = w_qs < 0xFFFFFFFFll ? (u32)w_qs : 0xFFFFFFFFu; trail = w_trail < 0xFFFFFFFFll ? (u32)w_trail : 0xFFFFFFFFu;
+                }
             }
-            const i64 nq64 = qe > qs ? qe - qs : 0;
-            const i64 n064 = rlen ? rlen : 1;
-            const i64 aend = pos + n064;
-            i64 clen = 0;
-            if (!bad) {
-                const i64 c0 = a.contig_off[tid];
-                clen = a.contig_off[tid + 1] - c0;
-                rbase = c0 + pos;
-            }
+            // totals of the I, D and N operations
+            const u32 sI = sQ - sM, sD = sC - sQ, sN = sR - sM - sD;
+            const i64 qcl = (i64)qs + (i64)trail;
+            const i64 nq64 = lseq > qcl ? lseq - qcl : 0;
+            const u32 n0u = sR ? sR : 1u;
+            const i64 aend = (i64)pos + (i64)n0u;
+            rbase = c0 + pos;
             // align.py:33 / main.py:180: fetch(start > end) raises once aend > contig length;
             // a CIGAR that disagrees with SEQ cannot come out of htslib
-            bad = bad || cig_n == 0 || aend > clen || nq64 != qcons || tl > 0x3FFFFFFF ||
-                  n064 + sI > 0x3FFFFFFF;
+            bad = bad || over || cig_n == 0 || aend > clen || nq64 != (i64)sQ || sC > 0x3FFFFFFFu || n0u + sI > 0x3FFFFFFFu;
             if (bad) {
                 flag_error(a.err, (i64)ri, ERR_BAD_READ);
                 kept = false;
             } else {
-                nq = (int)nq64; n0 = (int)n064; ncols = (int)tl; nI = (int)sI;
-                sq = so + (u32)qs;
+                const int n_gap = nID + 4 * (nE - nID);
+                const u32 sDN = sD + sN, rlen = sR;
+                nq = (int)nq64; n0 = (int)n0u; ncols = (int)sC; nI = (int)sI;
+                sq = so + qs;
                 const int nbefore = pos < A ? (int)pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
                 const bool simple = sI == 0 && sDN == 0 && rlen > 0 && nq < 32768;
@@ -730,6 +773,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     vlr = (lead_m < L ? lead_m : L) | ((cur_run < L ? cur_run : L) << 8);
                     one = n_gap == 1 && lead_m > 0 && cur_run > 0;
                     skips = n_gap >= 4;
+                    // N (and P) operations only: align.py:38-50 inserts nothing for them, so both strings are indexed
+                    // like an ungapped record's from either end — the left window hangs off pos, the right one off
+                    // aend, and the whole record is covered by its staging entry (no CIGAR walk)
+                    nonly = sI == 0 && sD == 0;
+                    if (nonly) vlr = (nq < L ? nq : L) * 0x101;
                 }
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
@@ -740,12 +788,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 if (fl & 0x1) {
                     if ((fl & 0x40) && (fl & 0x2)) {
                         kind = 0;
-                        const i64 t = a.tlen[ri];
+                        const i64 t = c_tlen;
                         flen = t < 0 ? -t : t;
                     }
                 } else {
                     kind = 1;
-                    flen = n064;
+                    flen = (i64)n0u;
                 }
                 if (kind >= 0) {
                     if (flen < d.lgd_lds) {
@@ -790,13 +838,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // the per-record registers of phase 1 are dead during the fast loops).
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
-        int nF = 0, nP = 0, nS = 0;
+        int nF = 0, nP = 0, nS = 0, nSI = 0;
         if (FAST) {
             const bool plain = kept && (w1 & D_SIMPLE) && sq >= (u32)(8 * d.nl8) &&
                                (i64)sq + nq + 8 * d.nl8 <= a.n_bases;
             const bool isF = plain && (w1 & D_FULL);
             const u64 mF = __ballot(isF), mPp = __ballot(plain && !isF);
-            u64 mP = mPp, mS = 0;
+            u64 mP = mPp, mS = 0, mSI = 0;
+            bool isD = false;
             const int rev = w1 & D_REV;
             uint4 ent;
             ent.x = (u32)(rbase - A + 256);
@@ -815,9 +864,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 gpre = kept && !(w1 & D_SIMPLE) && !(MASK && skips) && ((w1 >> D_NB_SHIFT) & 0xFF) == A &&
                        ((w1 >> D_NA_SHIFT) & 0xFF) == A && nq < 32768 && dnq >= -1023 && dnq <= 1023 &&
                        sq >= (u32)(8 * d.nl8 + 16) && (i64)sq + nq + 8 * d.nl8 + 16 <= a.n_bases;
-                // ... and those with a single indel between two match runs are counted by the fast path entirely:
-                // a second (far) pass over their entries takes the columns behind the first / last run (count())
-                isS = gpre && one && dnq >= -127 && dnq <= 127 && A + (dnq < 0 ? -dnq : dnq) <= 248;
+                // ... and those with a single short indel between two match runs are counted by the fast path entirely,
+                // one entry each (STEP_G in count())
+                // (up to seven bases: three bits of the event word; longer ones keep the CIGAR walk)
+                isS = gpre && one && dnq >= -7 && dnq <= 7;
                 if (gpre) {
                     w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
                     ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);
@@ -825,16 +875,35 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     ent.w |= ((u32)dnq & 0xFFu) | ((((u32)dnq >> 8) & 7u) << 21) | (isS ? PK_ONE : 0u);
                     // both runs reach --length: the entry covers every task of the record, nothing is left to walk
                     // (an N between two long match runs: a spliced read)
-                    covered = !isS && (vlr & 0xFF) == L && (vlr >> 8) == L;
+                    covered = !isS && (((vlr & 0xFF) == L && (vlr >> 8) == L) || nonly);
                 }
                 mP |= __ballot(gpre && !isS);
                 mS = __ballot(isS);
+                mSI = __ballot(isS && dnq < 0);      // insertions first, then deletions (one kind of step each)
+                isD = isS && dnq > 0;
+                if (__ballot(isS && dnq > 0)) {
+                    // A single deletion of g bases: the lanes of its entry work in column space and reach query index
+                    // min(n0, L) - g - 1 at most; the read bases of the (up to g) composition positions above that,
+                    // per side, are counted here (statistics.py:75-83).
+                    if (isS && dnq > 0) {
+                        const int g = dnq, u = vlr & 0xFF, v = vlr >> 8, Lq = nq < L ? nq : L;
+                        const int b_cmp = libid * d.w_lib + d.off_cmp() + rev * 2 * L * 4;
+                        for (int q = u > L - g ? u : L - g; q < Lq; q++) {
+                            const int sc = classify_read(a.seq[sq + q]);
+                            if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + q * 4 + sc);
+                        }
+                        for (int i = v > L - g ? v : L - g; i < Lq; i++) {
+                            const int sc = classify_read(a.seq[sq + nq - 1 - i]);
+                            if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + (L + i) * 4 + sc);
+                        }
+                    }
+                }
             }
-            nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS);
+            nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS); nSI = __popcll(mSI);
             todo_g = todo_all & ~(mF | mPp | mS | __ballot(covered));
             if (mF | mP | mS) {
                 int idx = isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF);
-                if (mS && isS) idx = mbcnt64(mS, nF + nP);
+                if (mS && isS) idx = isD ? mbcnt64(mS & ~mSI, nF + nP + nSI) : mbcnt64(mSI, nF + nP);
                 if (plain || gpre) stg[idx] = ent;
                 // the slots past the last record of a step shadow a real record (and are masked out)
                 const int first = __ffsll((long long)(mF | mP | mS)) - 1;
@@ -865,7 +934,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const int rev = s_w1 & D_REV;
             const bool hasq = MASK && (s_w1 & D_HASQ);
             const int lb = rl(libid, j) * d.w_lib;
-            const int b_mis = lb + rev * 2 * L * 25;
+            const int b_mis = lb + d.off_mis() + rev * 2 * L * 25;
             const int b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
             const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad;
             const i8 *__restrict__ rp = (const i8 *)a.ref + s_rbase;
@@ -987,70 +1056,101 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // classification code runs once per 64 events instead of once per record.
         if (FAST) {
             const int R = d.R, G = d.G;
-            // A run = the steps of nrec staged records from entry e0 on, followed (partial list only) by the far
-            // pass over nfar records from entry e1 on (the D_ONE records, listed last): one load pipeline for both.
-            // complete = true: every task of the record is present (static byte masks); false: short
-            // records and contig edges (byte masks from nq / nbefore / nafter of the record), gapped records
-            auto run = [&](const int e0, const int nrec, const int e1, const int nfar, auto complete_tag) {
-                constexpr bool complete = decltype(complete_tag)::value;
-                const int nnear = (nrec + R - 1) / R;
-                const int nsteps = nnear + (complete ? 0 : (nfar + R - 1) / R);
+            // A run = the steps of the nrec staged records from entry e0 on, all of one kind (count())
+            auto run = [&](const int e0, const int nrec, auto kind_tag) {
+                constexpr int KIND = decltype(kind_tag)::value;
+                const int nsteps = (nrec + R - 1) / R;
                 int kf = 0;
                 // fill() always issues its loads (past the last step it re-reads it), so the number of
                 // loads in flight is static and the waits before count() are counted ones
                 auto fill = [&](Stage &st) {
                     st.valid = kf < nsteps;
-                    int k = st.valid ? kf : nsteps - 1;
+                    const int k = st.valid ? kf : nsteps - 1;
                     kf++;
-                    const bool far = !complete && k >= nnear;   // (see count())
-                    if (far) k -= nnear;
-                    int nv = (far ? nfar : nrec) - k * R;
+                    int nv = nrec - k * R;
                     nv = nv > R ? R : nv;
                     st.lim = nv * G;
-                    st.far = far;
-                    const uint4 ent = stg[(far ? e1 : e0) + k * R + c_slot];
+                    const uint4 ent = stg[e0 + k * R + c_slot];
                     const u32 t = ent.z & c_cm;
                     u32 ro = ent.x + c_ro + t;
-                    const u32 so = ent.y + c_so + t;
-                    // gapped record (partial list only), d = n0 - nq: the right windows hang off aend = pos + n0, not
-                    // pos + nq; in the far pass they hang off pos + nq and the left ones off pos + d
-                    if (!complete) {
-                        const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));   // n0 - nq, 11 bits signed
-                        ro += ((c_cm != 0u) != far) ? (u32)((dd11 << 21) >> 21) : 0u;
+                    u32 so = ent.y + c_so + t;
+                    // gapped record, n0 - nq in the entry (11 bits signed): the right windows hang off aend = pos + n0,
+                    // not pos + nq
+                    if (KIND != STEP_C) {
+                        const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
+                        ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
+                        // byte thresholds of the lane for count(), clamped to [0, 8] and times eight.  Byte of column k:
+                        // jo + k on the left side, jo - 1 - k on the right side (sgn = +1 / -1)
+                        const u32 z = ent.z;
+                        const int nq_ = (int)(z & 0x7FFFu);
+                        const int t8 = (int)((z >> (16 + 8 * c_side)) & 0xFFu);      // flank length / run length of this side
+                        const int jo = c_side ? c_m8 + 8 - A : A - c_m8, sgn = 1 - 2 * c_side;
+                        const bool act = lane < st.lim;
+                        auto c8 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 8 ? 8 : v)) << 3; };
+                        if (KIND == STEP_P) {
+                            // tasks = columns [k0, k1): entries of gapped records ([15] of z set) carry their run lengths,
+                            // plain ones their flank lengths
+                            const bool pre = (z & 0x8000u) != 0;
+                            const int k0 = pre ? -A : -t8;
+                            const int k1 = pre ? t8 : (nq_ < L ? nq_ : L);
+                            const int m0 = jo + sgn * k0, m1 = jo + sgn * k1;
+                            const int lo = m0 < m1 ? m0 : m1, hi = act ? (m0 < m1 ? m1 : m0) : 0;
+                            st.aux = c8(lo) | (c8(hi) << 7);
+                        } else {
+                            // one indel of g bases behind the first (left) / last (right) match run of t8 columns: the gap
+                            // is bytes [ta, tb), the tasks end (left) / start (right) at byte tl.  A lane whose first
+                            // column, seen from its end of the record, lies at or behind the gap reads the string that
+                            // carries the gap g bytes nearer to that end; the lane that straddles the gap moves its own
+                            // bytes (count()).
+                            const int dd = (int)(i8)(ent.w & 0xFFu);
+                            const int g = KIND == STEP_GD ? dd : -dd;
+                            const int ncol = KIND == STEP_GD ? nq_ + g : nq_;
+                            const int Lm = ncol < L ? ncol : L;
+                            const int ta = jo + sgn * t8 - (c_side ? g : 0), tb = ta + g;
+                            const int tl = act ? jo + sgn * Lm : (c_side ? 8 : 0);
+                            const bool blane = c_side ? tb >= 8 : ta <= 0;
+                            const u32 off = blane ? (u32)(-sgn * g) : 0u;
+                            if (KIND == STEP_GD) so += off; else ro += off;
+                            const int bnd = c_side ? ta : tb;
+                            st.aux = c8(ta) | (c8(tb) << 7) | (c8(tl) << 14) | ((blane ? 0u : (u32)g) << 21) | ((u32)g << 24) |
+                                     ((c8(bnd) >> 3) << 27);
+                        }
                     }
                     st.ro = ro; st.so = so;
                     st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                     st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
                     if (MASK) {
-                        st.qo = ent.y + c_qo + t;
+                        st.qo = so - c_so + c_qo;
                         st.q12 = *(const u32x3 *)(qualW + (st.qo & ~3u));
                     }
                     st.pk = ent.w;
-                    if (!complete) st.nqz = ent.z;
                 };
                 // software pipeline: PIPE_DEPTH steps in flight, each in its own register set (no register
                 // rotation: a copy of an in-flight destination would wait for its load).  Every point of
                 // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
                 // PIPE_DEPTH - 1 fills per run go past the last step.
                 // (--min-basequal loads a third column per step: two steps in flight keep it inside the register budget)
-                constexpr int PD = MASK ? 2 : PIPE_DEPTH;
+                // (the runs of gapped records are a step or two long: two register sets)
+                constexpr int PD = (MASK || KIND == STEP_GI || KIND == STEP_GD) ? 2 : PIPE_DEPTH;
                 Stage st[PD];
 #pragma unroll
                 for (int dd = 0; dd < PD; dd++) fill(st[dd]);
                 for (int k = PD; k < nsteps; k += PD) {
 #pragma unroll
                     for (int dd = 0; dd < PD; dd++) {
-                        count(st[dd], complete_tag, st[dd].far);
+                        count(st[dd], kind_tag);
                         fill(st[dd]);
                     }
                 }
 #pragma unroll
                 for (int dd = 0; dd < PD; dd++)
-                    if (dd == 0 || st[dd].valid) count(st[dd], complete_tag, st[dd].far);
+                    if (dd == 0 || st[dd].valid) count(st[dd], kind_tag);
             };
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
-            if (nF) run(0, nF, 0, 0, std::true_type{});
-            if (nP + nS) run(nF, nP + nS, nF + nP, nS, std::false_type{});
+            if (nF) run(0, nF, std::integral_constant<int, STEP_C>{});
+            if (nP) run(nF, nP, std::integral_constant<int, STEP_P>{});
+            if (nSI) run(nF + nP, nSI, std::integral_constant<int, STEP_GI>{});
+            if (nS - nSI) run(nF + nP + nSI, nS - nSI, std::integral_constant<int, STEP_GD>{});
 #endif
         }
     }
@@ -1149,7 +1249,7 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             if (col < 4) {
                 const int b = strand ? 3 - col : col;        // complement on the reverse strand
                 const int k = b ^ (b >> 1);                  // A,C,G,T -> device class A,C,T,G
-                const i64 row = lb + ((strand * 2 + side) * L + p) * 25;
+                const i64 row = lb + d.off_mis() + ((strand * 2 + side) * L + p) * 25;
                 // matches (gapped records / plain records) + every column whose reference symbol is k
                 v = raw[row + k];
                 for (int g = 0; g < d.R; g++)  // plain records: one copy per slot of the wavefront step
@@ -1159,9 +1259,9 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
                 const int rc = strand ? c_comp_col[col] : col;
                 if (col == COL_S) {   // soft clips are stored as differences over the positions
                     v = 0;
-                    for (int q = 0; q <= p; q++) v += raw[lb + ((strand * 2 + side) * L + q) * 25 + COL_S];
+                    for (int q = 0; q <= p; q++) v += raw[lb + d.off_mis() + ((strand * 2 + side) * L + q) * 25 + COL_S];
                 } else {
-                    v = raw[lb + ((strand * 2 + side) * L + p) * 25 + rc];
+                    v = raw[lb + d.off_mis() + ((strand * 2 + side) * L + p) * 25 + rc];
                 }
             }
         } else if (i < n_mis + n_comp) {

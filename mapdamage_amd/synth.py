@@ -386,11 +386,14 @@ _PAR_REF = None
 
 def _par_worker(job):
     maker, n, seed = job
+    if isinstance(maker, dict):      # keyword arguments of make_reads
+        return make_reads(_PAR_REF, n, seed, **maker)
     return globals()[maker](_PAR_REF, n, seed=seed)
 
 
 def parallel_batch(maker, ref, n, seed, workers=None, shard=500_000):
-    """``maker`` ("config2_batch" | "config3_batch" | "config4_batch") over ``n`` records as independent shards
+    """``maker`` ("config2_batch" | "config3_batch" | "config4_batch", or a dict of ``make_reads`` keyword
+    arguments) over ``n`` records as independent shards
     of ``shard`` records, shard k seeded ``[seed, k]``, generated on a pool of forked worker processes and
     concatenated in shard order — the full-size workloads (50 M records) in tens of seconds instead of minutes.
     Deterministic in (maker, n, seed, shard); NOT the same records as ``maker(ref, n, seed)``.

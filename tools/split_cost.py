@@ -1,6 +1,7 @@
 """Where the time of survey config 3 goes: kernel-only time of the tabulation pass over 2 M 100 bp records
 with one ingredient of the config-3 CIGAR mix at a time.  Run on the GPU box: python tools/split_cost.py [reads]"""
 import json
+import os
 import pathlib
 import sys
 
@@ -32,16 +33,22 @@ VARIANTS = [
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    only = [v for v in sys.argv[2].split("|") if v] if len(sys.argv) > 2 else []
     ref = synth.make_genome()
+    # generated before the GPU is touched (forked workers)
+    batches = {name: synth.parallel_batch(dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw), ref, n, 3, workers=int(os.environ.get('MDX_GEN_WORKERS', '64')))
+               for name, kw in VARIANTS if not only or name in only}
     with DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
         eng.set_reference(ref)
         for name, kw in VARIANTS:
-            b = synth.make_reads(ref, n, 3, **dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw))
+            if only and name not in only:
+                continue
+            b = batches[name]
             db = eng.upload(b)
             eng.tabulate(db)
             eng.sync()
             eng.timing(True)
-            for _ in range(10):
+            for _ in range(20):
                 eng.tabulate(db)
             eng.sync()
             n_launch, ms = eng.timing_read()
