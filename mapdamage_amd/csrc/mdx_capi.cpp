@@ -101,6 +101,7 @@ struct mdx_ctx {
     // staging for mdx_tabulate_host: device columns, and two pinned bounce buffers the host columns go through
     // (the CPU fills one while the DMA engine drains the other)
     DevBuf st[10];
+    DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_done[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
@@ -230,6 +231,7 @@ void mdx_destroy(mdx_ctx *c) {
     if (c->comm && c->comm_owned && rccl()) (void)rccl()->CommDestroy(c->comm);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &b : c->st) b.release();
+    c->lists.release();
     for (int i = 0; i < 2; i++) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
@@ -383,6 +385,13 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
         a.stage_off = mdx_k_stage_off(a.dims);
         a.queue_off = mdx_k_queue_off(a.dims);
         const int grid = (int)(want < max_grid ? want : max_grid);
+        {
+            // a wavefront classifies at most ceil(n / wavefronts) records, rounded up to whole tiles
+            const int64_t nwaves = (int64_t)grid * wpb;
+            a.list_cap = (b->n_reads + nwaves - 1) / nwaves + 128;
+            HIP_TRY(c, c->lists.reserve((size_t)nwaves * 2 * a.list_cap * 16));
+            a.lists = (uint4 *)c->lists.p;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {
             HIP_TRY(c, hipEventCreate(&e0));

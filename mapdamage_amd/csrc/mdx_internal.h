@@ -122,6 +122,12 @@ struct MdxTabArgs {
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
+    // Per-wavefront lists of staging entries (16 bytes each) of the records that are not complete plain ones:
+    // wavefront w owns lists[w * 2 * list_cap .. (w + 1) * 2 * list_cap) — partial records upwards from 0, single
+    // insertions upwards from list_cap, single deletions downwards from 2 list_cap - 1; list_cap >= the records a
+    // wavefront classifies.  Written in the tile loop, read back by the same wavefront behind it.
+    uint4 *lists;
+    int64_t list_cap;
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };

@@ -603,6 +603,99 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
     };
 
+    // ---- the fast path's runs (used by the tile loop for the complete records and, behind it, for the lists)
+        const int R = d.R, G = d.G;
+        // A run = the steps of the nrec staged records from entry e0 on, all of one kind (count())
+        auto run = [&](const int e0, const int nrec, auto kind_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            const int nsteps = (nrec + R - 1) / R;
+            int kf = 0;
+            // fill() always issues its loads (past the last step it re-reads it), so the number of
+            // loads in flight is static and the waits before count() are counted ones
+            auto fill = [&](Stage &st) {
+                st.valid = kf < nsteps;
+                const int k = st.valid ? kf : nsteps - 1;
+                kf++;
+                int nv = nrec - k * R;
+                nv = nv > R ? R : nv;
+                st.lim = nv * G;
+                const uint4 ent = stg[e0 + k * R + c_slot];
+                const u32 t = ent.z & c_cm;
+                u32 ro = ent.x + c_ro + t;
+                u32 so = ent.y + c_so + t;
+                // gapped record, n0 - nq in the entry (11 bits signed): the right windows hang off aend = pos + n0,
+                // not pos + nq
+                if (KIND != STEP_C) {
+                    const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
+                    ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
+                    // byte thresholds of the lane for count(), clamped to [0, 8] and times eight.  Byte of column k:
+                    // jo + k on the left side, jo - 1 - k on the right side (sgn = +1 / -1)
+                    const u32 z = ent.z;
+                    const int nq_ = (int)(z & 0x7FFFu);
+                    const int t8 = (int)((z >> (16 + 8 * c_side)) & 0xFFu);      // flank length / run length of this side
+                    const int jo = c_side ? c_m8 + 8 - A : A - c_m8, sgn = 1 - 2 * c_side;
+                    const bool act = lane < st.lim;
+                    auto c8 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 8 ? 8 : v)) << 3; };
+                    if (KIND == STEP_P) {
+                        // tasks = columns [k0, k1): entries of gapped records ([15] of z set) carry their run lengths,
+                        // plain ones their flank lengths
+                        const bool pre = (z & 0x8000u) != 0;
+                        const int k0 = pre ? -A : -t8;
+                        const int k1 = pre ? t8 : (nq_ < L ? nq_ : L);
+                        const int m0 = jo + sgn * k0, m1 = jo + sgn * k1;
+                        const int lo = m0 < m1 ? m0 : m1, hi = act ? (m0 < m1 ? m1 : m0) : 0;
+                        st.aux = c8(lo) | (c8(hi) << 7);
+                    } else {
+                        // one indel of g bases behind the first (left) / last (right) match run of t8 columns: the gap
+                        // is bytes [ta, tb), the tasks end (left) / start (right) at byte tl.  A lane whose first
+                        // column, seen from its end of the record, lies at or behind the gap reads the string that
+                        // carries the gap g bytes nearer to that end; the lane that straddles the gap moves its own
+                        // bytes (count()).
+                        const int dd = (int)(i8)(ent.w & 0xFFu);
+                        const int g = KIND == STEP_GD ? dd : -dd;
+                        const int ncol = KIND == STEP_GD ? nq_ + g : nq_;
+                        const int Lm = ncol < L ? ncol : L;
+                        const int ta = jo + sgn * t8 - (c_side ? g : 0), tb = ta + g;
+                        const int tl = act ? jo + sgn * Lm : (c_side ? 8 : 0);
+                        const bool blane = c_side ? tb >= 8 : ta <= 0;
+                        const u32 off = blane ? (u32)(-sgn * g) : 0u;
+                        if (KIND == STEP_GD) so += off; else ro += off;
+                        const int bnd = c_side ? ta : tb;
+                        st.aux = c8(ta) | (c8(tb) << 7) | (c8(tl) << 14) | ((blane ? 0u : (u32)g) << 21) | ((u32)g << 24) |
+                                 ((c8(bnd) >> 3) << 27);
+                    }
+                }
+                st.ro = ro; st.so = so;
+                st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
+                st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
+                if (MASK) {
+                    st.qo = so - c_so + c_qo;
+                    st.q12 = *(const u32x3 *)(qualW + (st.qo & ~3u));
+                }
+                st.pk = ent.w;
+            };
+            // software pipeline: PIPE_DEPTH steps in flight, each in its own register set (no register
+            // rotation: a copy of an in-flight destination would wait for its load).  Every point of
+            // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
+            // PIPE_DEPTH - 1 fills per run go past the last step.
+            // (--min-basequal loads a third column per step: two steps in flight keep it inside the register budget)
+            // (the runs of gapped records are a step or two long: two register sets)
+            constexpr int PD = (MASK || KIND == STEP_GI || KIND == STEP_GD) ? 2 : PIPE_DEPTH;
+            Stage st[PD];
+    #pragma unroll
+            for (int dd = 0; dd < PD; dd++) fill(st[dd]);
+            for (int k = PD; k < nsteps; k += PD) {
+    #pragma unroll
+                for (int dd = 0; dd < PD; dd++) {
+                    count(st[dd], kind_tag);
+                    fill(st[dd]);
+                }
+            }
+    #pragma unroll
+            for (int dd = 0; dd < PD; dd++)
+                if (dd == 0 || st[dd].valid) count(st[dd], kind_tag);
+        };
+
     // Tiles of (up to) 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
     // an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one); the
     // records left after the last complete round are split evenly, so every wavefront counts the same
@@ -616,6 +709,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const u32 rem_lo = rounds * nwaves * T, rem = n_rec - rem_lo;
     const u32 t_lo = rem_lo + (u32)((u64)rem * gwave / nwaves), t_hi = rem_lo + (u32)((u64)rem * (gwave + 1) / nwaves);
     const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
+    // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
+    uint4 *const lists = a.lists + (i64)gwave * 2 * a.list_cap;
+    int lP = 0, lI = 0, lD = 0;
     for (u32 it = 0; it < n_it; it++) {
         const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
         const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
@@ -901,16 +997,24 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             }
             nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS); nSI = __popcll(mSI);
             todo_g = todo_all & ~(mF | mPp | mS | __ballot(covered));
-            if (mF | mP | mS) {
-                int idx = isF ? mbcnt64(mF, 0) : mbcnt64(mP, nF);
-                if (mS && isS) idx = isD ? mbcnt64(mS & ~mSI, nF + nP + nSI) : mbcnt64(mSI, nF + nP);
-                if (plain || gpre) stg[idx] = ent;
+            if (mF) {
+                if (isF) stg[mbcnt64(mF, 0)] = ent;
                 // the slots past the last record of a step shadow a real record (and are masked out)
-                const int first = __ffsll((long long)(mF | mP | mS)) - 1;
+                const int first = __ffsll((long long)mF) - 1;
                 uint4 pad;
                 pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
                 pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
-                if (lane < d.R - 1) stg[nF + nP + nS + lane] = pad;
+                if (lane < d.R - 1) stg[nF + lane] = pad;
+            }
+            if (mP | mS) {
+                // partial and single-indel records: appended to the wavefront's lists (counted behind the tile loop, in
+                // full steps): partial ones upwards from 0, insertions upwards from list_cap, deletions downwards
+                // from 2 list_cap - 1
+                i64 at = -1;
+                if ((plain && !isF) || (gpre && !isS)) at = lP + mbcnt64(mP, 0);
+                else if (isS) at = isD ? 2 * a.list_cap - 1 - (lD + mbcnt64(mS & ~mSI, 0)) : a.list_cap + lI + mbcnt64(mSI, 0);
+                if (at >= 0) lists[at] = ent;
+                lP += nP; lI += nSI; lD += nS - nSI;
             }
         }
 
@@ -1055,106 +1159,34 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
         // classification code runs once per 64 events instead of once per record.
         if (FAST) {
-            const int R = d.R, G = d.G;
-            // A run = the steps of the nrec staged records from entry e0 on, all of one kind (count())
-            auto run = [&](const int e0, const int nrec, auto kind_tag) {
-                constexpr int KIND = decltype(kind_tag)::value;
-                const int nsteps = (nrec + R - 1) / R;
-                int kf = 0;
-                // fill() always issues its loads (past the last step it re-reads it), so the number of
-                // loads in flight is static and the waits before count() are counted ones
-                auto fill = [&](Stage &st) {
-                    st.valid = kf < nsteps;
-                    const int k = st.valid ? kf : nsteps - 1;
-                    kf++;
-                    int nv = nrec - k * R;
-                    nv = nv > R ? R : nv;
-                    st.lim = nv * G;
-                    const uint4 ent = stg[e0 + k * R + c_slot];
-                    const u32 t = ent.z & c_cm;
-                    u32 ro = ent.x + c_ro + t;
-                    u32 so = ent.y + c_so + t;
-                    // gapped record, n0 - nq in the entry (11 bits signed): the right windows hang off aend = pos + n0,
-                    // not pos + nq
-                    if (KIND != STEP_C) {
-                        const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
-                        ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
-                        // byte thresholds of the lane for count(), clamped to [0, 8] and times eight.  Byte of column k:
-                        // jo + k on the left side, jo - 1 - k on the right side (sgn = +1 / -1)
-                        const u32 z = ent.z;
-                        const int nq_ = (int)(z & 0x7FFFu);
-                        const int t8 = (int)((z >> (16 + 8 * c_side)) & 0xFFu);      // flank length / run length of this side
-                        const int jo = c_side ? c_m8 + 8 - A : A - c_m8, sgn = 1 - 2 * c_side;
-                        const bool act = lane < st.lim;
-                        auto c8 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 8 ? 8 : v)) << 3; };
-                        if (KIND == STEP_P) {
-                            // tasks = columns [k0, k1): entries of gapped records ([15] of z set) carry their run lengths,
-                            // plain ones their flank lengths
-                            const bool pre = (z & 0x8000u) != 0;
-                            const int k0 = pre ? -A : -t8;
-                            const int k1 = pre ? t8 : (nq_ < L ? nq_ : L);
-                            const int m0 = jo + sgn * k0, m1 = jo + sgn * k1;
-                            const int lo = m0 < m1 ? m0 : m1, hi = act ? (m0 < m1 ? m1 : m0) : 0;
-                            st.aux = c8(lo) | (c8(hi) << 7);
-                        } else {
-                            // one indel of g bases behind the first (left) / last (right) match run of t8 columns: the gap
-                            // is bytes [ta, tb), the tasks end (left) / start (right) at byte tl.  A lane whose first
-                            // column, seen from its end of the record, lies at or behind the gap reads the string that
-                            // carries the gap g bytes nearer to that end; the lane that straddles the gap moves its own
-                            // bytes (count()).
-                            const int dd = (int)(i8)(ent.w & 0xFFu);
-                            const int g = KIND == STEP_GD ? dd : -dd;
-                            const int ncol = KIND == STEP_GD ? nq_ + g : nq_;
-                            const int Lm = ncol < L ? ncol : L;
-                            const int ta = jo + sgn * t8 - (c_side ? g : 0), tb = ta + g;
-                            const int tl = act ? jo + sgn * Lm : (c_side ? 8 : 0);
-                            const bool blane = c_side ? tb >= 8 : ta <= 0;
-                            const u32 off = blane ? (u32)(-sgn * g) : 0u;
-                            if (KIND == STEP_GD) so += off; else ro += off;
-                            const int bnd = c_side ? ta : tb;
-                            st.aux = c8(ta) | (c8(tb) << 7) | (c8(tl) << 14) | ((blane ? 0u : (u32)g) << 21) | ((u32)g << 24) |
-                                     ((c8(bnd) >> 3) << 27);
-                        }
-                    }
-                    st.ro = ro; st.so = so;
-                    st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
-                    st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
-                    if (MASK) {
-                        st.qo = so - c_so + c_qo;
-                        st.q12 = *(const u32x3 *)(qualW + (st.qo & ~3u));
-                    }
-                    st.pk = ent.w;
-                };
-                // software pipeline: PIPE_DEPTH steps in flight, each in its own register set (no register
-                // rotation: a copy of an in-flight destination would wait for its load).  Every point of
-                // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
-                // PIPE_DEPTH - 1 fills per run go past the last step.
-                // (--min-basequal loads a third column per step: two steps in flight keep it inside the register budget)
-                // (the runs of gapped records are a step or two long: two register sets)
-                constexpr int PD = (MASK || KIND == STEP_GI || KIND == STEP_GD) ? 2 : PIPE_DEPTH;
-                Stage st[PD];
-#pragma unroll
-                for (int dd = 0; dd < PD; dd++) fill(st[dd]);
-                for (int k = PD; k < nsteps; k += PD) {
-#pragma unroll
-                    for (int dd = 0; dd < PD; dd++) {
-                        count(st[dd], kind_tag);
-                        fill(st[dd]);
-                    }
-                }
-#pragma unroll
-                for (int dd = 0; dd < PD; dd++)
-                    if (dd == 0 || st[dd].valid) count(st[dd], kind_tag);
-            };
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
             if (nF) run(0, nF, std::integral_constant<int, STEP_C>{});
-            if (nP) run(nF, nP, std::integral_constant<int, STEP_P>{});
-            if (nSI) run(nF + nP, nSI, std::integral_constant<int, STEP_GI>{});
-            if (nS - nSI) run(nF + nP + nSI, nS - nSI, std::integral_constant<int, STEP_GD>{});
 #endif
         }
     }
 
+#ifndef MDX_ONLY_PHASE1
+    if (FAST && (lP | lI | lD)) {
+        // the entries this wavefront appended (its own stores: complete before they are read back)
+        // (workgroup scope: the stores have reached the L2 and no line of the lists was read before, so nothing
+        // stale can sit in this CU's L1; an agent-scope release would write the whole L2 back, once per wavefront)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int TL = 64 - 64 % d.R;       // entries per pass: whole steps, all but the last pass of a list
+        auto list_runs = [&](const i64 first, const int dir, const int n, auto kind_tag) {
+            for (int e = 0; e < n; e += TL) {
+                const int m = n - e < TL ? n - e : TL;
+                const uint4 ent = lists[first + (i64)dir * (e + (lane < m ? lane : 0))];
+                if (lane < m) stg[lane] = ent;
+                if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
+                run(0, m, kind_tag);
+            }
+        };
+        list_runs(0, 1, lP, std::integral_constant<int, STEP_P>{});
+        list_runs(a.list_cap, 1, lI, std::integral_constant<int, STEP_GI>{});
+        list_runs(2 * a.list_cap - 1, -1, lD, std::integral_constant<int, STEP_GD>{});
+    }
+#endif
     if (FAST) {
         if (qcount > 0) drain_all();
     }
