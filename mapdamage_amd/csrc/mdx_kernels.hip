@@ -301,6 +301,12 @@ __device__ __forceinline__ void direct8(u32 *lds, u32 r_lo, u32 r_hi, u32 base_b
     }
 }
 
+// element idx of a column, the byte offset computed in 32 bits (batches hold fewer than 2^30 records)
+template <class T>
+__device__ __forceinline__ T ld32(const T *base, u32 idx) {
+    return *(const T *)((const char *)base + (size_t)(idx * (u32)sizeof(T)));
+}
+
 // FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
 // otherwise every record takes the generic CIGAR walk.
 template <bool USE_LDS, bool MASK, bool FAST>
@@ -710,9 +716,16 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const u32 t_lo = rem_lo + (u32)((u64)rem * gwave / nwaves), t_hi = rem_lo + (u32)((u64)rem * (gwave + 1) / nwaves);
     const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
     // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
+    const MdxTabArgs *const ka = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     uint4 *const lists = a.lists + (i64)gwave * 2 * a.list_cap;
     int lP = 0, lI = 0, lD = 0;
     for (u32 it = 0; it < n_it; it++) {
+        // the arguments phase 1 needs are read from the kernel-argument segment when they are used (scalar loads through
+        // the constant cache) instead of living in SGPRs across the whole kernel: the kernel wants far more scalar
+        // registers than there are, and every spilled one costs a v_readlane per use
+        const MdxTabArgs *kp = ka;
+        asm volatile("" : "+s"(kp));
+        const MdxTabArgs &p = *kp;
         const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
         const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
         // ------------------------------------------------------------ phase 1: lane per record
@@ -721,9 +734,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // the per-record columns are requested together, before the flag is known (one memory round
         // trip for the tile instead of two)
         const u32 rj = valid ? ri : r_hi - 1;
-        const u32 fl = valid ? (u32)a.flag[rj] : 0x4u;
-        const int c_lib = a.lib[rj], c_tid = a.tid[rj], c_pos = a.pos[rj], c_tlen = a.tlen[rj];
-        const u32 c_co0 = a.cigar_off[rj], c_co1 = a.cigar_off[rj + 1], c_so0 = a.seq_off[rj], c_so1 = a.seq_off[rj + 1];
+        const u32 fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
+        const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
+        const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
         bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
         // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
         // the others are left to their own launch (a library id beyond the last one is an error in every launch)
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // a CIGAR that disagrees with SEQ cannot come out of htslib
             bad = bad || over || cig_n == 0 || aend > clen || nq64 != (i64)sQ || sC > 0x3FFFFFFFu || n0u + sI > 0x3FFFFFFFu;
             if (bad) {
-                flag_error(a.err, (i64)ri, ERR_BAD_READ);
+                flag_error(p.err, (i64)ri, ERR_BAD_READ);
                 kept = false;
             } else {
                 const int n_gap = nID + 4 * (nE - nID);
@@ -895,15 +908,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     if (flen < d.lgd_lds) {
                         lkey = lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen;
                     } else if (flen < d.lgd_max) {
-                        atomicAdd(&a.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
+                        atomicAdd(&p.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
                                                (((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
                     } else {
-                        const u64 slot = atomicAdd(a.n_lgd_over, 1ull);
-                        if ((i64)slot < a.lgd_over_cap) {
-                            a.lgd_over[4 * slot + 0] = libid + a.lib_lo;
-                            a.lgd_over[4 * slot + 1] = kind;
-                            a.lgd_over[4 * slot + 2] = rev;
-                            a.lgd_over[4 * slot + 3] = flen;
+                        const u64 slot = atomicAdd(p.n_lgd_over, 1ull);
+                        if ((i64)slot < p.lgd_over_cap) {
+                            p.lgd_over[4 * slot + 0] = libid + a.lib_lo;
+                            p.lgd_over[4 * slot + 1] = kind;
+                            p.lgd_over[4 * slot + 2] = rev;
+                            p.lgd_over[4 * slot + 3] = flen;
                         }
                     }
                 }
