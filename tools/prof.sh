@@ -1,29 +1,36 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun): kernel trace + stats, then PMC passes.
-# Usage: tools/prof.sh <tag> [bench args...]
+# Profiling recipe (run on the GPU box through gpurun): kernel trace + stats of the bench command, then separate PMC
+# passes, then the FETCH_SIZE / WRITE_SIZE calibration (tools/calib_fetch.hip).
+# Usage: tools/prof.sh <tag> [bench args...]      -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
+R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu $*"
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+# one launch = 25 M records (the bench's resident batches); the generator's forked workers do not run under
+# rocprofv3, so a plain run fills the batch cache first
+BENCH="python $R/bench.py --reads 25000000 --steps 5 --warmup 1 --no-cpu --no-secondary --batch-cache /tmp/mdx_bc $*"
+$BENCH > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 for f in $(find $OUT/trace -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done
 pmc() { # name counters...
   local name=$1; shift
-  timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_$name.log 2>&1
   for f in $(find $OUT/pmc_$name -name '*counter_collection.csv'); do
-    python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $f tabulate_kernel > $OUT/pmc_$name.txt 2>&1
+    python3 $R/tools/pmc_summary.py $f tabulate_kernel > $OUT/pmc_$name.txt 2>&1
   done
 }
 pmc inst SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
 pmc wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM
-pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_INSTS_LDS GRBM_GUI_ACTIVE
 pmc fetch FETCH_SIZE
-pmc lat SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES
-pmc tcp TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum
-pmc tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
 pmc write WRITE_SIZE
 pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-rm -rf $OUT/trace $OUT/pmc_*/ 2>/dev/null
+# counter calibration on known byte counts beyond the Infinity Cache
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/calib_fetch.hip -o /tmp/calib_fetch 2> $OUT/calib_build.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OUT/calib_$c -o pmc -- /tmp/calib_fetch 2 > $OUT/calib_$c.log 2>&1
+  for f in $(find $OUT/calib_$c -name '*counter_collection.csv'); do python3 $R/tools/pmc_summary.py $f > $OUT/calib_$c.txt 2>&1; done
+done
+rm -rf $OUT/trace $OUT/pmc_*/ $OUT/calib_*/ 2>/dev/null
 ls -la $OUT
