@@ -194,6 +194,7 @@ bool scan_blocks(const MappedFile &file, std::vector<Block> &blocks, size_t &tot
         size_t bsize = 0;
         while (x + 4 <= xend && xend <= file.size()) {
             const size_t slen = rd16(&file[x + 2]);
+            if (x + 4 + slen > xend) break;                     // (a subfield may not run past the extra field)
             if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&file[x + 4]) + 1;
             x += 4 + slen;
         }
@@ -203,6 +204,8 @@ bool scan_blocks(const MappedFile &file, std::vector<Block> &blocks, size_t &tot
         b.in_off = off + 12 + xlen;
         b.in_size = bsize - xlen - 20;
         b.out_size = rd32(&file[off + bsize - 4]);
+        // ISIZE comes from the file: a BGZF block inflates to at most 64 KiB (SAM specification 4.1)
+        if (b.out_size > 65536) { err = "corrupt BGZF block (ISIZE beyond 64 KiB)"; return false; }
         b.out_off = total;
         total += b.out_size;
         blocks.push_back(b);
@@ -491,44 +494,53 @@ bool stream_fill(mdx_bam_stream *s, size_t want) {
 extern "C" {
 
 int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
-    if (!path || !out) return MDX_ERR_ARG;
-    mdx_bam *b = new (std::nothrow) mdx_bam();
-    if (!b) return MDX_ERR_ARG;
-    *out = b;
-    // MDX_BAM_TIMING=1: stage times on stderr
-    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "mdx_bam_read %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
-    MappedFile file;
-    if (!file.open(path, b->error)) return MDX_ERR_ARG;
-    lap("file map");
-    std::vector<Block> blocks;
-    size_t total = 0;
-    if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
-    lap("block scan");
-    raw_bytes data(total + 8);
-    std::atomic<bool> ok{true};
-    parallel_for(blocks.size(), threads, [&](size_t i) {
-        const Block &k = blocks[i];
-        if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
-    });
-    if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
-    lap("inflate");
-    file.close();
-
-    size_t off = 0, used = 0;
-    if (parse_header(b, data.data(), total, false, &off) != 0) return MDX_ERR_ARG;
-    std::vector<size_t> hints(blocks.size());
-    for (size_t i = 0; i < blocks.size(); i++) hints[i] = blocks[i].out_off;
-    const int rc = unpack_records(b, data.data(), off, total, threads, false, &used, lap, &hints);
-    b->reaper = std::thread([](raw_bytes d) { raw_bytes().swap(d); }, std::move(data));
-    lap("release");
-    return rc;
+    try {
+        if (!path || !out) return MDX_ERR_ARG;
+        mdx_bam *b = new (std::nothrow) mdx_bam();
+        if (!b) return MDX_ERR_ARG;
+        *out = b;
+        // MDX_BAM_TIMING=1: stage times on stderr
+        const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "mdx_bam_read %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
+        MappedFile file;
+        if (!file.open(path, b->error)) return MDX_ERR_ARG;
+        lap("file map");
+        std::vector<Block> blocks;
+        size_t total = 0;
+        if (!scan_blocks(file, blocks, total, b->error)) return MDX_ERR_ARG;
+        lap("block scan");
+        raw_bytes data(total + 8);
+        std::atomic<bool> ok{true};
+        parallel_for(blocks.size(), threads, [&](size_t i) {
+            const Block &k = blocks[i];
+            if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
+        });
+        if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
+        lap("inflate");
+        file.close();
+    
+        size_t off = 0, used = 0;
+        if (parse_header(b, data.data(), total, false, &off) != 0) return MDX_ERR_ARG;
+        std::vector<size_t> hints(blocks.size());
+        for (size_t i = 0; i < blocks.size(); i++) hints[i] = blocks[i].out_off;
+        const int rc = unpack_records(b, data.data(), off, total, threads, false, &used, lap, &hints);
+        b->reaper = std::thread([](raw_bytes d) { raw_bytes().swap(d); }, std::move(data));
+        lap("release");
+        return rc;
+    
+    } catch (const std::exception &e) {
+        if (out && *out) (*out)->error = std::string("mdx_bam_read: ") + e.what();
+        return MDX_ERR_ARG;
+    } catch (...) {
+        if (out && *out) (*out)->error = "mdx_bam_read: unknown failure";
+        return MDX_ERR_ARG;
+    }
 }
 
 void mdx_bam_free(mdx_bam *b) {
@@ -582,71 +594,87 @@ const char *mdx_bam_qnames(const mdx_bam *b, const uint32_t **offsets) {
 }
 
 int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
-    if (!path || !out) return MDX_ERR_ARG;
-    mdx_bam_stream *s = new (std::nothrow) mdx_bam_stream();
-    if (!s) return MDX_ERR_ARG;
-    *out = s;
-    s->threads = threads < 1 ? 1 : threads;
-    s->file = new (std::nothrow) MappedFile();
-    if (!s->file || !s->file->open(path, s->head.error)) return MDX_ERR_ARG;
-    if (s->file->size() == 0) s->eof = true;
-    // the header may span several blocks: inflate until it parses
-    for (;;) {
-        if (!stream_fill(s, (size_t)1 << 20)) return MDX_ERR_ARG;
-        size_t first = 0;
-        const int rc = parse_header(&s->head, s->pending.data(), s->pending.size(), !s->eof, &first);
-        if (rc < 0) return MDX_ERR_ARG;
-        if (rc == 0) {
-            s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)first);
-            size_t kept = 0;
-            for (size_t h : s->hints) if (h >= first) s->hints[kept++] = h - first;
-            s->hints.resize(kept);
-            return MDX_OK;
+    try {
+        if (!path || !out) return MDX_ERR_ARG;
+        mdx_bam_stream *s = new (std::nothrow) mdx_bam_stream();
+        if (!s) return MDX_ERR_ARG;
+        *out = s;
+        s->threads = threads < 1 ? 1 : threads;
+        s->file = new (std::nothrow) MappedFile();
+        if (!s->file || !s->file->open(path, s->head.error)) return MDX_ERR_ARG;
+        if (s->file->size() == 0) s->eof = true;
+        // the header may span several blocks: inflate until it parses
+        for (;;) {
+            if (!stream_fill(s, (size_t)1 << 20)) return MDX_ERR_ARG;
+            size_t first = 0;
+            const int rc = parse_header(&s->head, s->pending.data(), s->pending.size(), !s->eof, &first);
+            if (rc < 0) return MDX_ERR_ARG;
+            if (rc == 0) {
+                s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)first);
+                size_t kept = 0;
+                for (size_t h : s->hints) if (h >= first) s->hints[kept++] = h - first;
+                s->hints.resize(kept);
+                return MDX_OK;
+            }
         }
+    
+    } catch (const std::exception &e) {
+        if (out && *out) (*out)->head.error = std::string("mdx_bam_open: ") + e.what();
+        return MDX_ERR_ARG;
+    } catch (...) {
+        return MDX_ERR_ARG;
     }
 }
 
 const mdx_bam *mdx_bam_stream_header(const mdx_bam_stream *s) { return s ? &s->head : nullptr; }
 
 int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
-    if (!s || !out || !s->file) return MDX_ERR_ARG;
-    *out = nullptr;
-    size_t limit = chunk_bytes < 64 ? 64 : (size_t)chunk_bytes;       // uncompressed BAM bytes per chunk
-    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "mdx_bam_next %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
-    for (;;) {
-        // BGZF members hold at most 64 KiB each; BAM compresses about 3-4x
-        while (!s->eof && s->pending.size() < limit)
-            if (!stream_fill(s, std::max<size_t>(limit / 4, (size_t)1 << 16))) return MDX_ERR_ARG;
-        lap("inflate");
-        const size_t total = std::min(limit, s->pending.size());
-        const bool partial = !(s->eof && total == s->pending.size());
-        if (!partial && total < 4) return MDX_OK;                      // end of file: *out stays NULL
-        mdx_bam *b = new (std::nothrow) mdx_bam();
-        if (!b) return MDX_ERR_ARG;
-        b->header_text = s->head.header_text;
-        b->ref_names = s->head.ref_names;
-        b->ref_lengths = s->head.ref_lengths;
-        size_t used = 0;
-        const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, lap, &s->hints);
-        if (rc != MDX_OK) { s->head.error = b->error; delete b; return rc; }
-        s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
-        {
-            size_t kept = 0;
-            for (size_t h : s->hints) if (h >= used) s->hints[kept++] = h - used;
-            s->hints.resize(kept);
+    try {
+        if (!s || !out || !s->file) return MDX_ERR_ARG;
+        *out = nullptr;
+        size_t limit = chunk_bytes < 64 ? 64 : (size_t)chunk_bytes;       // uncompressed BAM bytes per chunk
+        const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "mdx_bam_next %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
+        for (;;) {
+            // BGZF members hold at most 64 KiB each; BAM compresses about 3-4x
+            while (!s->eof && s->pending.size() < limit)
+                if (!stream_fill(s, std::max<size_t>(limit / 4, (size_t)1 << 16))) return MDX_ERR_ARG;
+            lap("inflate");
+            const size_t total = std::min(limit, s->pending.size());
+            const bool partial = !(s->eof && total == s->pending.size());
+            if (!partial && total < 4) return MDX_OK;                      // end of file: *out stays NULL
+            mdx_bam *b = new (std::nothrow) mdx_bam();
+            if (!b) return MDX_ERR_ARG;
+            b->header_text = s->head.header_text;
+            b->ref_names = s->head.ref_names;
+            b->ref_lengths = s->head.ref_lengths;
+            size_t used = 0;
+            const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, lap, &s->hints);
+            if (rc != MDX_OK) { s->head.error = b->error; delete b; return rc; }
+            s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
+            {
+                size_t kept = 0;
+                for (size_t h : s->hints) if (h >= used) s->hints[kept++] = h - used;
+                s->hints.resize(kept);
+            }
+            lap("carry");
+            if (!b->flag.empty()) { *out = b; return MDX_OK; }
+            delete b;
+            if (!partial) return MDX_OK;
+            limit *= 2;                                                    // a record larger than the chunk: widen
         }
-        lap("carry");
-        if (!b->flag.empty()) { *out = b; return MDX_OK; }
-        delete b;
-        if (!partial) return MDX_OK;
-        limit *= 2;                                                    // a record larger than the chunk: widen
+    
+    } catch (const std::exception &e) {
+        if (s) s->head.error = std::string("mdx_bam_next: ") + e.what();
+        return MDX_ERR_ARG;
+    } catch (...) {
+        return MDX_ERR_ARG;
     }
 }
 

@@ -38,55 +38,72 @@ def write_fasta(path, ref: Reference, width=60):
             offset += len(seq) + (len(seq) + width - 1) // width
 
 
-def read_fasta_index(filename):
-    """.fai -> {name: length}; None (with logged errors) when malformed (seq.py:38-72)."""
-    logger = logging.getLogger(__name__)
-    fai = {}
+class _FaiError(ValueError):
+    """A malformed .fai line: carries the log message and its arguments."""
+
+    def __init__(self, message, *args):
+        super().__init__(message % args)
+        self.message, self.args_ = message, args
+
+
+def _fai_records(filename):
+    """(name, length) per line of a samtools faidx index; raises _FaiError on the first malformed line."""
     with open(filename, "r") as handle:
         for lineno, line in enumerate(handle, 1):
-            fields = line.split("\t")
-            if len(fields) != 5:
-                logger.error("Line %i in %r contains wrong number of fields, found %i, expected 5:",
-                             lineno, filename, len(fields))
-                return None
-            try:
-                fai[fields[0]] = int(fields[1])
-            except ValueError:
-                logger.error("Length at line %i in %r is not a number; found %r", lineno, filename, fields[1])
-                return None
-    if not fai:
-        logger.error("Error: Index for %r does contain any sequences.", filename)
-        logger.error("Please ensure that FASTA file is valid, and")
-        logger.error("re-index file using 'samtool faidx'.")
+            columns = line.split("\t")
+            if len(columns) != 5:
+                raise _FaiError("Line %i in %r contains wrong number of fields, found %i, expected 5:",
+                                lineno, filename, len(columns))
+            name, length = columns[0], columns[1]
+            if not length.strip().lstrip("+-").isdigit():
+                raise _FaiError("Length at line %i in %r is not a number; found %r", lineno, filename, length)
+            yield name, int(length)
+
+
+def read_fasta_index(filename):
+    """.fai -> {name: length}, or None after logging what is wrong with it (the reference's
+    seq.read_fasta_index contract: same messages, same None)."""
+    logger = logging.getLogger(__name__)
+    try:
+        lengths = dict(_fai_records(filename))
+    except _FaiError as error:
+        logger.error(error.message, *error.args_)
         return None
-    return fai
+    if lengths:
+        return lengths
+    for message, args in (("Error: Index for %r does contain any sequences.", (filename,)),
+                          ("Please ensure that FASTA file is valid, and", ()),
+                          ("re-index file using 'samtool faidx'.", ())):
+        logger.error(message, *args)
+    return None
 
 
 def compare_sequence_dicts(fasta_dict, bam_dict):
-    """True when every BAM sequence exists in the FASTA with the same length (seq.py:75-112)."""
+    """Does the FASTA provide every sequence of the BAM header at the same length?  Logs the reference's
+    messages (seq.compare_sequence_dicts): length mismatches and sequences missing from the FASTA are errors,
+    sequences only the FASTA has a warning."""
     if fasta_dict == bam_dict:
         return True
     logger = logging.getLogger(__name__)
-    common = set(fasta_dict) & set(bam_dict)
-    if not common:
+    shared = fasta_dict.keys() & bam_dict.keys()
+    if not shared:
         logger.error("BAM and FASTA file have no sequence names in common")
         return False
-    different = [(k, fasta_dict[k], bam_dict[k]) for k in sorted(common) if fasta_dict[k] != bam_dict[k]]
-    if different:
-        logger.error("Length of required FASTA sequences differ:")
-        for values in different:
-            logger.error(" - %s: %i vs %i bp" % values)
-    bam_only = set(bam_dict) - common
-    if bam_only:
-        logger.error("Sequences not found in FASTA:")
-        for key in bam_only:
-            logger.error("%s (%i bp)", key, bam_dict[key])
-    fasta_only = set(fasta_dict) - common
-    if fasta_only:
-        logger.warning("FASTA file contains extra sequences:")
-        for key in fasta_only:
-            logger.warning(" - %s = %i bp", key, fasta_dict[key])
-    return not (different or bam_only)
+    problems = {
+        "mismatched": [(name, fasta_dict[name], bam_dict[name]) for name in sorted(shared)
+                       if fasta_dict[name] != bam_dict[name]],
+        "missing": [(name, bam_dict[name]) for name in bam_dict.keys() - shared],
+        "extra": [(name, fasta_dict[name]) for name in fasta_dict.keys() - shared],
+    }
+    reports = (("mismatched", logger.error, "Length of required FASTA sequences differ:", " - %s: %i vs %i bp"),
+               ("missing", logger.error, "Sequences not found in FASTA:", "%s (%i bp)"),
+               ("extra", logger.warning, "FASTA file contains extra sequences:", " - %s = %i bp"))
+    for kind, log, title, row in reports:
+        if problems[kind]:
+            log(title)
+            for values in problems[kind]:
+                log(row % values)
+    return not (problems["mismatched"] or problems["missing"])
 
 
 def reference_for_bam(fasta_path, bam_names):

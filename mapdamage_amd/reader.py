@@ -35,15 +35,12 @@ class BAMReader:
         else:
             self.handle: Alignments = read_alignments(filepath)
         self._merge_libraries = merge_libraries
-        self._readgroups = {}
+        # read group id -> (sample, library); with --merge-libraries every record, tagged or not, is ("*", "*")
+        self._readgroups = {None: ("*", "*")} if merge_libraries else self._collect_readgroups(log, self.handle)
+        # libraries in first-appearance order (the order of the header's @RG lines), each with its read groups
         self._libraries = {}
-        if merge_libraries:
-            self._readgroups[None] = ("*", "*")
-            self._libraries[("*", "*")] = {None}
-        else:
-            self._readgroups = self._collect_readgroups(log, self.handle)
-            for readgroup, library in self._readgroups.items():
-                self._libraries.setdefault(library, set()).add(readgroup)
+        for readgroup, library in self._readgroups.items():
+            self._libraries.setdefault(library, set()).add(readgroup)
         log.info("Found %i libraries in BAM file", len(self._libraries))
 
     def get_references(self):
@@ -52,15 +49,17 @@ class BAMReader:
     def get_libraries(self):
         return list(self._libraries.keys())
 
-    @classmethod
-    def _collect_readgroups(cls, log, handle):
+    @staticmethod
+    def _collect_readgroups(log, handle):
+        """{ID: (SM, LB)} of the header's @RG lines; a line without one of the three tags is the reference's
+        BAMError (reader.py:99-118)."""
         readgroups = {}
-        for readgroup in handle.header.get("RG", ()):
-            try:
-                readgroups[readgroup["ID"]] = (readgroup["SM"], readgroup["LB"])
-            except KeyError as error:
+        for line in handle.header.get("RG", ()):
+            missing = [tag for tag in ("ID", "SM", "LB") if tag not in line]
+            if missing:
                 raise BAMError("Incomplete readgroup found: %s is missing %s. Either fix BAM or use "
-                               "--merge-libraries" % (readgroup.get("ID", "Unnamed readgroup"), error))
+                               "--merge-libraries" % (line.get("ID", "Unnamed readgroup"), KeyError(missing[0])))
+            readgroups[line["ID"]] = (line["SM"], line["LB"])
         return readgroups
 
     def iter_batches(self):

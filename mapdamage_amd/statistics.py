@@ -103,30 +103,48 @@ class FragmentLengths:
                                      % (sample, library, strand, kind, length, reads[(kind, strand)][length]))
 
 
+def _position_one_totals(path):
+    """Sums of the C / C>T columns of the 5p rows and of the G / G>A columns of the 3p rows at position 1 of a
+    misincorporation table, over all samples, libraries and strands.  Raises KeyError / ValueError / OSError on a
+    table that cannot be read that way; returns None for an empty file."""
+    wanted = {"5p": ("C", "C>T"), "3p": ("G", "G>A")}
+    totals = {("5p", "C"): 0, ("5p", "C>T"): 0, ("3p", "G"): 0, ("3p", "G>A"): 0}
+    with open(path, newline="") as handle:
+        lines = (line.rstrip("\r\n") for line in handle)
+        header = next(lines, None)
+        if not header:
+            return None
+        column = {name: i for i, name in enumerate(header.split("\t"))}
+        for line in lines:
+            fields = line.split("\t")
+            if int(fields[column["Pos"]]) != 1:
+                continue
+            end = fields[column["End"]]
+            for name in wanted[end]:
+                totals[(end, name)] += int(fields[column[name]])
+    return totals
+
+
 def check_table_and_warn_if_dmg_freq_is_low(folder):
-    """True unless the table is unusable; warns when 5p C>T + 3p G>A at position 1 is < 1 %
-    (mapdamage/statistics.py:140-184)."""
+    """The reference's check of the same name (used by its main flow right after the tables are written): False when
+    `misincorporation.txt` is unusable, True otherwise, with a warning when the first-position damage — 5p C>T plus
+    3p G>A frequency — is below 1 %.  Same messages as the reference."""
     logger = logging.getLogger(__name__)
     filename = "misincorporation.txt"
-    counts = {"5p": {"C": 0, "C>T": 0}, "3p": {"G": 0, "G>A": 0}}
     try:
-        with open(os.path.join(folder, filename), newline="") as handle:
-            reader = csv.DictReader(handle, delimiter="\t")
-            if not reader.fieldnames:
-                logger.error("%r is empty; please re-run mapDamage", filename)
-                return False
-            for row in reader:
-                if int(row["Pos"]) == 1:
-                    for key in counts[row["End"]]:
-                        counts[row["End"]][key] += int(row[key])
-    except (csv.Error, IOError, OSError, KeyError) as error:
+        totals = _position_one_totals(os.path.join(folder, filename))
+    except (OSError, KeyError, ValueError, IndexError) as error:
         logger.error("Error reading misincorporation table: %s", error)
         return False
-    if not (counts["5p"]["C"] and counts["3p"]["G"]):
+    if totals is None:
+        logger.error("%r is empty; please re-run mapDamage", filename)
+        return False
+    c_sites, g_sites = totals[("5p", "C")], totals[("3p", "G")]
+    if c_sites == 0 or g_sites == 0:
         logger.error("Insufficient data in %r; cannot perform Bayesian computation", filename)
         return False
-    total = counts["5p"]["C>T"] / counts["5p"]["C"] + counts["3p"]["G>A"] / counts["3p"]["G"]
-    if total < 0.01:
+    damage = totals[("5p", "C>T")] / c_sites + totals[("3p", "G>A")] / g_sites
+    if damage < 0.01:
         logger.warning("DNA damage levels are too low, the Bayesian computation should not be "
-                       "performed (%f < 0.01)", total)
+                       "performed (%f < 0.01)", damage)
     return True

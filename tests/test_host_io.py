@@ -293,3 +293,32 @@ def test_native_bam_parallel_record_scan_equals_serial_scan(files, tmp_path, hts
     assert want["n"] == batch.n
     for chunk in (0, 70_000, 5_000):
         assert _decode_in_subprocess(path, chunk, 0) == want, chunk
+
+
+def test_native_decoder_rejects_hostile_bgzf_sizes(tmp_path):
+    """ISIZE is read from the file — 70 000 tiny blocks claiming 4 GiB each must be refused (not
+    allocated), a subfield may not run past the extra field, and no C++ exception may leave the C boundary."""
+    import struct
+    import zlib
+
+    from mapdamage_amd import sam
+
+    def block(payload, isize=None, extra=None):
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        data = comp.compress(payload) + comp.flush()
+        if extra is None:
+            extra = b"BC" + struct.pack("<HH", 2, 12 + 6 + len(data) + 8 - 1)
+        hdr = b"\x1f\x8b\x08\x04" + b"\0" * 6 + struct.pack("<H", len(extra)) + extra
+        return hdr + data + struct.pack("<II", zlib.crc32(payload), len(payload) if isize is None else isize)
+
+    huge = tmp_path / "huge_isize.bam"
+    huge.write_bytes(b"".join(block(b"x", isize=0xFFFFFFFF) for _ in range(70000)))
+    with pytest.raises((ValueError, sam.BAMError), match="BGZF"):
+        sam.read_bam_native(huge)
+    with pytest.raises((ValueError, sam.BAMError), match="BGZF"):
+        sam.BamStream(huge)
+    # a subfield whose declared length runs past the extra field (and past the end of the file)
+    odd = tmp_path / "subfield.bam"
+    odd.write_bytes(b"\x1f\x8b\x08\x04" + b"\0" * 6 + struct.pack("<H", 6) + b"XY" + struct.pack("<H", 60000) + b"\0\0")
+    with pytest.raises((ValueError, sam.BAMError)):
+        sam.read_bam_native(odd)
