@@ -180,6 +180,16 @@ int mdx_genome_composition(mdx_ctx *ctx, uint64_t *counts);
 int mdx_rescale_set_model(mdx_ctx *ctx, const uint8_t *lut, const double *term, int32_t len5p, int32_t len3p);
 int mdx_rescale_host(mdx_ctx *ctx, const mdx_batch *batch, const int32_t *mtid, const int32_t *mpos,
                      uint8_t *qual_out, double *mr_raw, uint8_t *status);
+/* The same for a batch resident in HBM (device pointers throughout, enqueued on the context's stream; errors surface
+ * at mdx_sync), and — BASELINE configs[4], "rescaling fused into the same pass" — both results of one resident
+ * batch in one call: the count tables (main.py:165-217) and the rescaled qualities (rescale.py:300-344) from the
+ * same columns, uploaded once.  mdx_rescale_timing_read: kernel time of the rescale launches (HIP events, like
+ * mdx_timing_read for the tabulation kernel; enabled by mdx_timing_enable). */
+int mdx_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
+                       uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
+int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
+                                uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
+int mdx_rescale_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
 /* The integer content of the `subs` dictionary that _rescale_qual_read fills through _record_subs
  * (rescale.py:82-143) and _print_subs logs (:159-192), accumulated over every mdx_rescale_host call
  * since mdx_rescale_set_model.  words (uint64), npos = 1 + len5p + len3p:

@@ -112,7 +112,8 @@ struct mdx_ctx {
     int len5p = 0, len3p = 0;
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;      // tabulation kernel
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rs_events;   // rescale kernel
     std::string err;
 };
 
@@ -230,6 +231,7 @@ void mdx_destroy(mdx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->comm_owned && rccl()) (void)rccl()->CommDestroy(c->comm);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &ev : c->rs_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &b : c->st) b.release();
     c->lists.release();
     for (int i = 0; i < 2; i++) {
@@ -688,6 +690,40 @@ int mdx_rescale_summary(mdx_ctx *c, uint64_t *words) {
     return MDX_OK;
 }
 
+int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, const int32_t *d_mpos, uint8_t *d_qual_out,
+                       double *d_mr_raw, uint8_t *d_status) {
+    int rc = check_batch(c, b);
+    if (rc != MDX_OK) return rc;
+    if (!c->d_ref || !c->d_lut) return fail(c, MDX_ERR_STATE, "set_reference and rescale_set_model first");
+    if (!b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status) return fail(c, MDX_ERR_ARG, "null column");
+    if (b->n_reads == 0) return MDX_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    MdxRescaleArgs a{};
+    a.n_reads = b->n_reads; a.n_bases = b->n_bases; a.flag = b->flag; a.tid = b->tid; a.pos = b->pos; a.mtid = d_mtid; a.mpos = d_mpos;
+    a.cigar_off = b->cigar_off; a.cigar = b->cigar; a.seq_off = b->seq_off; a.seq = b->seq; a.qual = b->qual;
+    a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
+    a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
+    a.qual_out = d_qual_out; a.mr_raw = d_mr_raw; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+        (void)hipEventRecord(e0, c->stream);
+    mdx_k_rescale(a, c->n_cu, c->stream);
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, c->stream);
+        c->rs_events.emplace_back(e0, e1);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, const int32_t *d_mpos,
+                                uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status) {
+    // one pass over one resident batch: the tables and, from the same columns in HBM, the rescaled qualities
+    int rc = mdx_tabulate_device(c, b);
+    if (rc != MDX_OK) return rc;
+    return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);
+}
+
 int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const int32_t *mpos, uint8_t *qual_out,
                      double *mr_raw, uint8_t *status) {
     int rc = check_batch(c, h);
@@ -711,21 +747,8 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
     if (e == hipSuccess) e = hipMemcpyAsync(d_mtid, mtid, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_mpos, mpos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        MdxRescaleArgs a{};
-        a.n_reads = n; a.n_bases = h->n_bases; a.flag = dv.flag; a.tid = dv.tid; a.pos = dv.pos; a.mtid = d_mtid; a.mpos = d_mpos;
-        a.cigar_off = dv.cigar_off; a.cigar = dv.cigar; a.seq_off = dv.seq_off; a.seq = dv.seq; a.qual = dv.qual;
-        a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
-        a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
-        a.qual_out = d_qout; a.mr_raw = d_mr; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-            (void)hipEventRecord(e0, c->stream);
-        mdx_k_rescale(a, c->n_cu, c->stream);
-        if (e0 && e1) {
-            (void)hipEventRecord(e1, c->stream);
-            c->events.emplace_back(e0, e1);
-        }
-        e = hipGetLastError();
+        rc = mdx_rescale_device(c, &dv, d_mtid, d_mpos, d_qout, d_mr, d_status);
+        if (rc != MDX_OK) e = hipErrorUnknown;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(qual_out, d_qout, (size_t)h->n_bases, hipMemcpyDeviceToHost);
@@ -734,8 +757,26 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
     void *tmp[] = {d_mtid, d_mpos, d_qout, d_status, d_mr};
     for (void *p : tmp) if (p) (void)hipFree(p);
     (void)mdx_batch_free(c, &dv);
+    if (rc != MDX_OK) return rc;
     if (e != hipSuccess) return fail(c, MDX_ERR_HIP, hipGetErrorString(e));
     return mdx_sync(c, nullptr);
+}
+
+int mdx_rescale_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
+    if (!c) return MDX_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    int64_t n = 0;
+    for (auto &ev : c->rs_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; n++; }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    c->rs_events.clear();
+    if (n_launches) *n_launches = n;
+    if (total_ms) *total_ms = tot;
+    return MDX_OK;
 }
 
 int mdx_genome_composition(mdx_ctx *c, uint64_t *counts) {

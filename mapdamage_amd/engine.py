@@ -26,6 +26,7 @@ EXPORTS = (
     "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
     "mdx_rescale_summary_words", "mdx_rescale_summary",
     "mdx_comm_unique_id", "mdx_comm_init", "mdx_comm_adopt", "mdx_comm_size", "mdx_finish_allreduce",
+    "mdx_rescale_device", "mdx_tabulate_rescale_device", "mdx_rescale_timing_read",
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
@@ -87,7 +88,7 @@ def load_library(path=None):
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
                  "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
                  "mdx_rescale_summary", "mdx_comm_unique_id", "mdx_comm_init", "mdx_comm_adopt", "mdx_comm_size",
-                 "mdx_finish_allreduce"):
+                 "mdx_finish_allreduce", "mdx_rescale_device", "mdx_tabulate_rescale_device", "mdx_rescale_timing_read"):
         getattr(lib, name).restype = ctypes.c_int
     lib.mdx_comm_size.argtypes = [ctypes.c_void_p]
     lib.mdx_rescale_summary_words.restype = ctypes.c_int64
@@ -338,6 +339,19 @@ class DamageEngine:
             raise BadReadError(-1, self._lib.mdx_last_error(self._ctx).decode())
         self._check(rc)
         return qual_out, mr, status
+
+    def rescale_device(self, dbatch, d_mtid, d_mpos, d_qual_out, d_mr, d_status, with_tables=False):
+        """Rescale a resident batch (``DeviceBatch`` with qualities; the other arguments are device pointers as
+        integers); ``with_tables``: count the batch into the tables in the same call (BASELINE configs[4])."""
+        fn = self._lib.mdx_tabulate_rescale_device if with_tables else self._lib.mdx_rescale_device
+        self._check(fn(self._ctx, ctypes.byref(dbatch.dev), ctypes.c_void_p(d_mtid), ctypes.c_void_p(d_mpos),
+                       ctypes.c_void_p(d_qual_out), ctypes.c_void_p(d_mr), ctypes.c_void_p(d_status)))
+
+    def rescale_timing_read(self):
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0)
+        self._check(self._lib.mdx_rescale_timing_read(self._ctx, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
 
     def rescale_summary(self):
         """Integer content of the reference's ``subs`` dictionary (rescale.py:82-143) accumulated since

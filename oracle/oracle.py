@@ -160,3 +160,17 @@ def subs_log_lines(counts, pvals):
             lines.append("    %s-Q%02i% 10i% 10i" % (sub, lv, int(hist[i, 0, lv:].sum()), int(hist[i, 1, lv:].sum())))
     return lines
 
+
+
+def rescale_parallel(ref, batch, corr, len5p, len3p, threads=None):
+    """rescale() over contiguous slices of the batch on `threads` host threads (the C function keeps no state)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads or avail, batch.n or 1))
+    cuts = [batch.n * t // threads for t in range(threads + 1)]
+    parts = [batch.slice(cuts[t], cuts[t + 1]) for t in range(threads)]
+    with ThreadPoolExecutor(threads) as pool:
+        res = list(pool.map(lambda b: rescale(ref, b, corr, len5p, len3p), parts))
+    return (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]),
+            np.concatenate([r[2] for r in res]), threads)

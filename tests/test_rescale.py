@@ -224,6 +224,48 @@ def test_hip_rescales_hard_clipped_records(tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_tabulate_and_rescale_in_one_pass(tmp_path):
+    """BASELINE configs[4]: one resident batch, one call — the count tables and the rescaled qualities
+    (mdx_tabulate_rescale_device) — against the oracle's tabulation and the oracle's rescaling."""
+    import torch
+
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    from tests.util import assert_tables_equal, oracle_tableset
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500,
+                            lower_run=3000)
+    b = synth.make_reads(ref, 80_000, 23, len_range=(30, 150), paired=True, frac_softclip=0.15, frac_ins=0.06,
+                         frac_del=0.06, frac_skip=0.01, with_qual=True, frac_filtered=0.03)
+    rng = np.random.default_rng(4)
+    b.mtid = b.tid.copy()
+    b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
+    libs = [("s", "l")]
+    want_tables = oracle_tableset(ref, b, libs, 70, 10, 0)
+    want_q, want_mr, want_st = oracle.rescale(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    dev = torch.device("cuda", 0)
+    with DamageEngine(libs, 70, 10, 0) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        db = eng.upload(b)
+        mtid, mpos = torch.from_numpy(b.mtid).to(dev), torch.from_numpy(b.mpos).to(dev)
+        qout = torch.zeros(b.seq.shape[0] + 64, dtype=torch.uint8, device=dev)
+        mr = torch.zeros(b.n, dtype=torch.float64, device=dev)
+        st = torch.zeros(b.n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.rescale_device(db, mtid.data_ptr(), mpos.data_ptr(), qout.data_ptr(), mr.data_ptr(), st.data_ptr(),
+                           with_tables=True)
+        got_tables = eng.finish()
+        db.free()
+    assert_tables_equal(got_tables, want_tables)
+    np.testing.assert_array_equal(qout.cpu().numpy()[:b.seq.shape[0]], want_q)
+    np.testing.assert_array_equal(st.cpu().numpy(), want_st)
+    got_mr = mr.cpu().numpy()
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+
+
+@pytest.mark.gpu
 def test_cli_rescale_only_rewrites_bam(tmp_path):
     """`--rescale-only`: every record written back, new qualities + MR:f on the rescaled ones,
     untouched fields preserved."""

@@ -47,7 +47,7 @@ def main():
         reps = 5
         for _ in range(reps):
             q, mr, st = eng.rescale(b)
-        n_launch, ms = eng.timing_read()
+        n_launch, ms = eng.rescale_timing_read()
     t0 = time.perf_counter()
     wq, wmr, wst = oracle.rescale(ref, b, corr, model.len5p, model.len3p)
     cpu = time.perf_counter() - t0
