@@ -235,6 +235,16 @@ int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out);
 const mdx_bam *mdx_bam_stream_header(const mdx_bam_stream *stream);
 int mdx_bam_next(mdx_bam_stream *stream, int64_t chunk_bytes, mdx_bam **out);
 void mdx_bam_close(mdx_bam_stream *stream);
+/* Rewriting a BAM (the `--rescale-only` output of mapdamage/rescale.py:285-365, which writes every record back
+ * through pysam): with mdx_bam_stream_keep_raw(stream, 1) each chunk keeps its encoded records as they stood in
+ * the file; mdx_bam_raw returns them (rec_off[i] = offset of record i's block_size field, rec_off[n] = end);
+ * mdx_bam_patch_rescaled writes the chunk's records to `out` (capacity out_cap bytes: raw size + 7 per rescaled
+ * record suffices), those with rescaled[i] != 0 with their QUAL replaced by qual_out[seq_off[i] ...] and an `MR:f`
+ * tag (mr[i]) appended, every other byte unchanged. */
+int mdx_bam_stream_keep_raw(mdx_bam_stream *stream, int on);
+int mdx_bam_raw(const mdx_bam *bam, const uint8_t **data, const uint64_t **rec_off);
+int mdx_bam_patch_rescaled(const mdx_bam *bam, const uint8_t *qual_out, const float *mr, const uint8_t *rescaled,
+                           uint8_t *out, int64_t out_cap, int64_t *out_len);
 
 /* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
 int mdx_table_mode(const mdx_ctx *ctx);

@@ -118,6 +118,10 @@ struct mdx_bam {
     std::string qnames;
     std::vector<std::string> rg_names;
     std::vector<uint8_t> has_mr;
+    // the chunk's encoded records as they stood in the file (mdx_bam_stream_keep_raw): rewriting a BAM preserves every
+    // byte it does not change.  rec_off[i] = offset of record i's block_size field, rec_off[n] = end
+    raw_bytes raw;
+    std::vector<uint64_t> rec_off;
     // returning hundreds of megabytes of touched pages to the system takes tens of milliseconds: the inflated
     // stream of mdx_bam_read is released on this thread while the caller already works on the columns
     std::thread reaper;
@@ -135,6 +139,7 @@ struct mdx_bam_stream {
     size_t coff = 0;                 // compressed offset of the first block not inflated yet
     int threads = 1;
     bool eof = false;
+    bool keep_raw = false;           // chunks keep their encoded records (mdx_bam_raw)
     raw_bytes pending;               // inflated bytes not unpacked yet (a partial record at most, between calls)
     std::vector<size_t> hints;       // offsets into `pending` where a BGZF block began (unpack_records)
 };
@@ -657,6 +662,13 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
             size_t used = 0;
             const int rc = unpack_records(b, s->pending.data(), 0, total, s->threads, partial, &used, lap, &s->hints);
             if (rc != MDX_OK) { s->head.error = b->error; delete b; return rc; }
+            if (s->keep_raw && !b->flag.empty()) {
+                b->raw.assign(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
+                b->rec_off.resize(b->flag.size() + 1);
+                size_t o = 0;
+                for (size_t i = 0; i < b->flag.size(); i++) { b->rec_off[i] = o; o += 4 + (size_t)rd32(&b->raw[o]); }
+                b->rec_off[b->flag.size()] = o;
+            }
             s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)used);
             {
                 size_t kept = 0;
@@ -676,6 +688,46 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
     } catch (...) {
         return MDX_ERR_ARG;
     }
+}
+
+int mdx_bam_stream_keep_raw(mdx_bam_stream *s, int on) {
+    if (!s) return MDX_ERR_ARG;
+    s->keep_raw = on != 0;
+    return MDX_OK;
+}
+
+int mdx_bam_raw(const mdx_bam *b, const uint8_t **data, const uint64_t **rec_off) {
+    if (!b || b->rec_off.empty()) return MDX_ERR_STATE;
+    if (data) *data = b->raw.data();
+    if (rec_off) *rec_off = b->rec_off.data();
+    return MDX_OK;
+}
+
+int mdx_bam_patch_rescaled(const mdx_bam *b, const uint8_t *qual_out, const float *mr, const uint8_t *rescaled,
+                           uint8_t *out, int64_t out_cap, int64_t *out_len) {
+    if (!b || b->rec_off.empty() || !qual_out || !mr || !rescaled || !out || !out_len) return MDX_ERR_ARG;
+    const size_t n = b->flag.size();
+    size_t o = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t r0 = (size_t)b->rec_off[i], sz = (size_t)b->rec_off[i + 1] - r0;     // 4 + block_size
+        const size_t need = sz + (rescaled[i] ? 7 : 0);
+        if ((int64_t)(o + need) > out_cap) return MDX_ERR_ARG;
+        std::memcpy(out + o, &b->raw[r0], sz);
+        if (rescaled[i]) {
+            const uint8_t *rec = &b->raw[r0];
+            const size_t l_read_name = rec[12], n_cigar = rd16(rec + 16), l_seq = rd32(rec + 20);
+            const size_t qoff = 4 + 32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2;
+            if (qoff + l_seq > sz) return MDX_ERR_ARG;
+            std::memcpy(out + o + qoff, qual_out + b->seq_off[i], l_seq);
+            out[o + sz] = 'M'; out[o + sz + 1] = 'R'; out[o + sz + 2] = 'f';
+            std::memcpy(out + o + sz + 3, &mr[i], 4);
+            const uint32_t bs = (uint32_t)(sz - 4 + 7);
+            std::memcpy(out + o, &bs, 4);
+        }
+        o += need;
+    }
+    *out_len = (int64_t)o;
+    return MDX_OK;
 }
 
 void mdx_bam_close(mdx_bam_stream *s) {

@@ -30,6 +30,7 @@ EXPORTS = (
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
+    "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled",
 )
 
 

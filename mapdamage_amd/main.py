@@ -127,15 +127,20 @@ def parse_args(argv):
 def rescale_qual(options):
     """Mirror of rescale.rescale_qual (mapdamage/rescale.py:368-383) for --rescale-only."""
     from .rescale import RescaleError, RescaleModel, rescale_bam
-    from .sam import read_bam
+    from .sam import BamStream
     logger = logging.getLogger(__name__)
     logger.info("Rescaling BAM: '%s' -> '%s'", options.filename, options.rescale_out)
     start = time.time()
     try:
         model = RescaleModel.from_csv(options.folder / "Stats_out_MCMC_correct_prob.csv",
                                       options.rescale_length_5p, options.rescale_length_3p)
-        names = read_bam(options.filename).header.references
-        ref = reference_for_bam(options.ref, names)
+        # the header only (the records are streamed by rescale_bam); the FASTA must provide the BAM's sequences
+        with BamStream(options.filename) as probe:
+            header = probe.header
+        fai_lengths = read_fasta_index(str(options.ref) + ".fai")
+        if not fai_lengths or not compare_sequence_dicts(fai_lengths, dict(zip(header.references, header.lengths))):
+            return 1
+        ref = reference_for_bam(options.ref, header.references)
         with DamageEngine([("*", "*")], options.length, options.around, 0, device=options.device) as engine:
             summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model)
     except RescaleError as error:

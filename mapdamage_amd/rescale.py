@@ -142,32 +142,33 @@ def finalize_mr(raw_sum):
     return float("%.5f" % raw_sum)
 
 
-def rescale_bam(engine, ref, in_path, out_path, model):
+def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20):
     """File-level mirror of ``_rescale_qual_core`` (rescale.py:285-365): every record of the BAM is
     written back, rescaled records get their new qualities and an ``MR:f`` tag, everything else in
     the record (name, MAPQ, mate fields, other tags) is preserved byte for byte.
-    Returns the per-status record counts."""
-    import struct
-
-    from .sam import read_bam, write_bam_raw
-    al = read_bam(in_path, keep_raw=True)
-    batch = al.batch
+    The file goes through in chunks: native decode (the encoded records kept), one rescale launch per chunk, the
+    records patched natively, BGZF blocks deflated on a thread pool — host memory is bounded by the chunk and no
+    per-record Python work is done.  Returns (substitution summary, per-status record counts)."""
+    from .sam import BamStream, BgzfWriter, bam_header_bytes
     engine.set_reference(ref)
     engine.set_rescale_model(model)
-    qual_out, mr_raw, status = engine.rescale(batch)
-    out = []
-    for i, body in enumerate(al.raw):
-        if status[i] in (STATUS_BOTH, STATUS_FORWARD):
-            if al.has_mr[i]:
-                raise SystemExit("Read: %s already has a MR tag, can't rescale" % al.qname_at(i))   # rescale.py:277-278
-            l_read_name, n_cigar, l_seq = body[8], struct.unpack_from("<H", body, 12)[0], struct.unpack_from("<i", body, 16)[0]
-            qoff = 32 + l_read_name + 4 * n_cigar + (l_seq + 1) // 2
-            s0 = int(batch.seq_off[i])
-            body = (body[:qoff] + qual_out[s0:s0 + l_seq].tobytes() + body[qoff + l_seq:]
-                    + b"MRf" + struct.pack("<f", finalize_mr(mr_raw[i])))
-        out.append(body)
-    write_bam_raw(out_path, al.raw_header, out)
+    counts = np.zeros(5, np.int64)
+    with BamStream(in_path, chunk_bytes=chunk_bytes, keep_raw=True) as stream, BgzfWriter(out_path) as out:
+        out.write(bam_header_bytes(stream.header))
+        for chunk in stream:
+            batch = chunk.batch
+            qual_out, mr_raw, status = engine.rescale(batch)
+            rescaled = (status == STATUS_BOTH) | (status == STATUS_FORWARD)
+            clash = rescaled & (np.asarray(chunk.has_mr) != 0)
+            if clash.any():      # rescale.py:277-278
+                raise SystemExit("Read: %s already has a MR tag, can't rescale" % chunk.qname_at(int(np.nonzero(clash)[0][0])))
+            # float("%.5f" % x), element by element in C (rescale.py:275)
+            mr = np.zeros(batch.n, np.float32)
+            if rescaled.any():
+                mr[rescaled] = np.char.mod("%.5f", mr_raw[rescaled]).astype(np.float64).astype(np.float32)
+            out.write(stream.patch_rescaled(chunk, qual_out, mr, rescaled))
+            counts += np.bincount(status, minlength=5)[:5]
     summary = RescaleSummary(engine.rescale_summary(), model)
-    return summary, {name: int((status == code).sum()) for name, code in
+    return summary, {name: int(counts[code]) for name, code in
             (("unmapped", STATUS_UNMAPPED), ("without_qualities", STATUS_NO_QUAL), ("single_end", STATUS_BOTH),
              ("inward_pairs", STATUS_FORWARD), ("improper_pairs", STATUS_IMPROPER))}

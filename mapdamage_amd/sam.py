@@ -237,6 +237,54 @@ def write_bam_raw(path, raw_header, records):
         out.write(_bgzf_block(b""))
 
 
+class BgzfWriter:
+    """BGZF output stream: 0xFF00-byte blocks deflated on a pool of threads (zlib drops the GIL), written in order."""
+
+    def __init__(self, path, threads=None):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        self._out = open(path, "wb")
+        self._pool = ThreadPoolExecutor(threads or min(32, os.cpu_count() or 1))
+        self._tail = b""
+
+    def write(self, data):
+        """Append bytes (anything with the buffer protocol)."""
+        view = memoryview(data).cast("B")
+        if self._tail:
+            view = memoryview(self._tail + view.tobytes())
+        whole = len(view) // 0xFF00 * 0xFF00
+        blocks = [view[lo:lo + 0xFF00] for lo in range(0, whole, 0xFF00)]
+        self._tail = view[whole:].tobytes()
+        for encoded in self._pool.map(_bgzf_block, blocks):
+            self._out.write(encoded)
+
+    def close(self):
+        if self._out is None:
+            return
+        if self._tail:
+            self._out.write(_bgzf_block(self._tail))
+        self._out.write(_bgzf_block(b""))
+        self._out.close()
+        self._out = None
+        self._pool.shutdown()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def bam_header_bytes(header):
+    """The uncompressed BAM header block (magic, text, reference dictionary) of a parsed ``Header``."""
+    text = header.text.encode()
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(header.references)))
+    for name, length in zip(header.references, header.lengths):
+        raw = name.encode() + b"\0"
+        out += struct.pack("<i", len(raw)) + raw + struct.pack("<i", int(length))
+    return bytes(out)
+
+
 class _NativeBam:
     """Owner of a decoded BAM inside libmdx.so (``mdx_bam_free`` when the last array viewing it is gone)."""
 
@@ -320,14 +368,14 @@ class BamStream:
     ``Alignments`` of consecutive records, at most ``chunk_bytes`` of uncompressed BAM data each, so host memory stays
     bounded and the caller can tabulate one chunk while the next is decoded (the ctypes call drops the GIL)."""
 
-    def __init__(self, path, threads=None, chunk_bytes=256 << 20):
+    def __init__(self, path, threads=None, chunk_bytes=256 << 20, keep_raw=False):
         import ctypes
         import os
 
         from .engine import load_library
         self._lib = load_library()
         self._stream = ctypes.c_void_p()
-        self.path, self.chunk_bytes = path, int(chunk_bytes)
+        self.path, self.chunk_bytes, self.keep_raw = path, int(chunk_bytes), bool(keep_raw)
         rc = self._lib.mdx_bam_open(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
                                     ctypes.byref(self._stream))
         if rc != 0:
@@ -335,6 +383,8 @@ class BamStream:
             self.close()
             raise ValueError("%r: %s" % (str(path), message))
         self.header = _native_header(self._lib, self._lib.mdx_bam_stream_header(self._stream))
+        if self.keep_raw:
+            self._lib.mdx_bam_stream_keep_raw(self._stream, 1)
 
     def _error(self):
         if not self._stream:
@@ -350,7 +400,31 @@ class BamStream:
             raise ValueError("%r: %s" % (str(self.path), self._error()))
         if not handle:
             return None
-        return _native_alignments(self._lib, handle, _NativeBam(self._lib, handle), self.header)
+        chunk = _native_alignments(self._lib, handle, _NativeBam(self._lib, handle), self.header)
+        chunk.native = handle          # (kept alive by the chunk's owner object) for patch_rescaled()
+        return chunk
+
+    def patch_rescaled(self, chunk, qual_out, mr, rescaled):
+        """The encoded records of ``chunk`` (decoded with ``keep_raw``) with the QUAL of the records flagged in
+        ``rescaled`` replaced from ``qual_out`` and an ``MR:f`` tag appended; every other byte as in the file."""
+        import ctypes
+        n = chunk.batch.n
+        qual_out = np.ascontiguousarray(qual_out, np.uint8)
+        mr = np.ascontiguousarray(mr, np.float32)
+        rescaled = np.ascontiguousarray(rescaled, np.uint8)
+        data, rec_off = ctypes.c_void_p(), ctypes.c_void_p()
+        if self._lib.mdx_bam_raw(chunk.native, ctypes.byref(data), ctypes.byref(rec_off)) != 0:
+            raise ValueError("the stream was not opened with keep_raw")
+        end = int(np.ctypeslib.as_array(ctypes.cast(rec_off, ctypes.POINTER(ctypes.c_uint64)), (n + 1,))[n])
+        out = np.empty(end + 7 * int(rescaled.sum()) + 8, np.uint8)
+        out_len = ctypes.c_int64(0)
+        rc = self._lib.mdx_bam_patch_rescaled(chunk.native, qual_out.ctypes.data_as(ctypes.c_void_p),
+                                              mr.ctypes.data_as(ctypes.c_void_p), rescaled.ctypes.data_as(ctypes.c_void_p),
+                                              out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(out.shape[0]),
+                                              ctypes.byref(out_len))
+        if rc != 0:
+            raise ValueError("mdx_bam_patch_rescaled failed (%d)" % rc)
+        return out[:out_len.value]
 
     def __iter__(self):
         while True:

@@ -322,3 +322,47 @@ def test_native_decoder_rejects_hostile_bgzf_sizes(tmp_path):
     odd.write_bytes(b"\x1f\x8b\x08\x04" + b"\0" * 6 + struct.pack("<H", 6) + b"XY" + struct.pack("<H", 60000) + b"\0\0")
     with pytest.raises((ValueError, sam.BAMError)):
         sam.read_bam_native(odd)
+
+
+def test_native_patch_of_rescaled_records_and_bgzf_writer(tmp_path):
+    """`--rescale-only` writes every record back: the native decoder keeps the encoded records of a chunk, the
+    patch replaces QUAL and appends MR:f on the flagged ones and leaves every other byte alone; the threaded BGZF
+    writer produces a file the decoders read back."""
+    import struct
+
+    from mapdamage_amd import sam
+    ref, batch = synth.config1_batch()
+    path = tmp_path / "in.bam"
+    sam.write_bam(path, batch, ref.names, ref.lengths, RGS, ["rgA" if i % 2 else "rgB" for i in range(batch.n)])
+    whole = sam.read_bam(path, keep_raw=True)
+    rng = np.random.default_rng(1)
+    with sam.BamStream(path, chunk_bytes=40_000, keep_raw=True) as stream, sam.BgzfWriter(tmp_path / "out.bam", threads=3) as out:
+        out.write(sam.bam_header_bytes(stream.header))
+        first, picked, new_q, mrs = 0, [], [], []
+        for chunk in stream:
+            b = chunk.batch
+            flags = (rng.random(b.n) < 0.4).astype(np.uint8)
+            qual_out = rng.integers(0, 42, b.seq.shape[0]).astype(np.uint8)
+            mr = rng.random(b.n).astype(np.float32)
+            # nothing flagged: the records come back byte for byte
+            same = stream.patch_rescaled(chunk, qual_out, mr, np.zeros(b.n, np.uint8))
+            want = b"".join(struct.pack("<i", len(r)) + r for r in whole.raw[first:first + b.n])
+            assert same.tobytes() == want
+            out.write(stream.patch_rescaled(chunk, qual_out, mr, flags))
+            for i in np.nonzero(flags)[0]:
+                picked.append(first + int(i))
+                new_q.append(qual_out[int(b.seq_off[i]):int(b.seq_off[i + 1])].copy())
+                mrs.append(mr[i])
+            first += b.n
+    assert first == batch.n and len(picked) > 100
+    back = sam.read_bam(tmp_path / "out.bam", keep_raw=True)
+    assert back.batch.n == batch.n and back.header.text == whole.header.text
+    np.testing.assert_array_equal(back.batch.seq, batch.seq)
+    chosen = set(picked)
+    for k, i in enumerate(picked):
+        s0, s1 = int(batch.seq_off[i]), int(batch.seq_off[i + 1])
+        np.testing.assert_array_equal(back.batch.qual[s0:s1], new_q[k])
+        assert back.raw[i][-7:-4] == b"MRf" and struct.unpack("<f", back.raw[i][-4:])[0] == mrs[k]
+    for i in range(batch.n):
+        if i not in chosen:
+            assert back.raw[i] == whole.raw[i]
