@@ -36,6 +36,12 @@ extern "C" {
 
 #define MDX_ERR_COMM (-7)         /* RCCL failure, or another rank of the communicator reported an error */
 
+/* Optional hint in the `flag` column (a bit SAM does not define): every base quality of the record is at least
+ * --min-basequal, so nothing of it can be masked (align.py:65-71 masks only qualities below the threshold).  The
+ * kernel then skips the record's quality window loads.  The caller vouches for it (mdx_bam_qmin gives the lowest
+ * quality of each record; mapdamage_amd.batch.mark_unmaskable sets the bit); without the bit nothing changes. */
+#define MDX_FLAG_QUAL_ABOVE_MIN 0x8000
+
 #define MDX_N_MIS_COLS 25         /* mapdamage/seq.py:6-30 without the derived "Total" */
 
 typedef struct mdx_ctx mdx_ctx;
@@ -218,6 +224,7 @@ const char *mdx_bam_ref_name(const mdx_bam *bam, int32_t i);
 int64_t mdx_bam_ref_length(const mdx_bam *bam, int32_t i);
 int mdx_bam_batch(const mdx_bam *bam, mdx_batch *view, const int32_t **mtid, const int32_t **mpos,
                   const int32_t **rg_index, const uint8_t **has_mr);
+const uint8_t *mdx_bam_qmin(const mdx_bam *bam);     /* lowest quality per record (0xFF: none) */
 int32_t mdx_bam_n_rg(const mdx_bam *bam);
 const char *mdx_bam_rg_name(const mdx_bam *bam, int32_t i);
 const char *mdx_bam_qnames(const mdx_bam *bam, const uint32_t **offsets);

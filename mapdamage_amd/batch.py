@@ -170,6 +170,33 @@ def batch_from_records(records, with_qual=None):
                      np.asarray(cig, dtype=np.uint32), seq_off, seq, qual).validate()
 
 
+FLAG_QUAL_ABOVE_MIN = 0x8000     # include/mdx.h MDX_FLAG_QUAL_ABOVE_MIN
+
+
+def record_min_quality(batch):
+    """Lowest quality of each record (0xFF for a record without bases or without qualities)."""
+    if batch.qual is None:
+        return np.full(batch.n, 0xFF, np.uint8)
+    out = np.full(batch.n, 0xFF, np.uint8)
+    off = batch.seq_off.astype(np.int64)
+    nonempty = off[1:] > off[:-1]
+    if nonempty.any():
+        out[nonempty] = np.minimum.reduceat(batch.qual[:int(off[-1])], off[:-1][nonempty])
+    return out
+
+
+def mark_unmaskable(batch, minqual, qmin=None):
+    """Set the MDX_FLAG_QUAL_ABOVE_MIN hint on the records none of whose qualities is below ``minqual`` (their
+    quality windows are not loaded by the kernel) and say whether *no* record of the batch can be masked — the batch
+    may then be tabulated without its quality column (the unmasked kernel).  Returns (batch, nothing_to_mask)."""
+    if not minqual or batch.qual is None:
+        return batch, True
+    qmin = record_min_quality(batch) if qmin is None else np.asarray(qmin)
+    fine = qmin >= minqual            # (0xFF: no qualities at all — never masked either)
+    batch.flag = np.where(fine, batch.flag | np.uint16(FLAG_QUAL_ABOVE_MIN), batch.flag).astype(np.uint16)
+    return batch, bool(fine.all())
+
+
 def concat_batches(batches):
     batches = [b for b in batches if b.n]
     if not batches:

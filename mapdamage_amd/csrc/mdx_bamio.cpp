@@ -118,6 +118,7 @@ struct mdx_bam {
     std::string qnames;
     std::vector<std::string> rg_names;
     std::vector<uint8_t> has_mr;
+    std::vector<uint8_t> qmin;       // lowest quality of each record (0xFF: no bases)
     // the chunk's encoded records as they stood in the file (mdx_bam_stream_keep_raw): rewriting a BAM preserves every
     // byte it does not change.  rec_off[i] = offset of record i's block_size field, rec_off[n] = end
     raw_bytes raw;
@@ -398,7 +399,7 @@ int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, in
     *consumed = off;
     lap(scanned ? "scan (par.)" : "record scan");
     b->flag.resize(n); b->lib.assign(n, 0); b->tid.resize(n); b->pos.resize(n); b->tlen.resize(n);
-    b->mtid.resize(n); b->mpos.resize(n); b->rg_index.assign(n, -1); b->has_mr.assign(n, 0);
+    b->mtid.resize(n); b->mpos.resize(n); b->rg_index.assign(n, -1); b->has_mr.assign(n, 0); b->qmin.resize(n);
     b->cigar_off = coff; b->seq_off = soff; b->qname_off = noff;
     b->cigar.resize(coff.back()); b->seq.resize((size_t)soff.back() + 64); b->qual.resize((size_t)soff.back() + 64);
     b->qnames.resize(noff.back());
@@ -428,6 +429,11 @@ int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, in
         }
         p += ((size_t)l_seq + 1) / 2;
         std::memcpy(&b->qual[soff[i]], p, (size_t)l_seq);
+        {
+            uint8_t lowest = 0xFF;
+            for (int32_t k = 0; k < l_seq; k++) lowest = p[k] < lowest ? p[k] : lowest;
+            b->qmin[i] = lowest;
+        }
         p += l_seq;
         const uint8_t *end = r + bs;
         while (p + 3 <= end) {
@@ -585,6 +591,8 @@ int mdx_bam_batch(const mdx_bam *b, mdx_batch *view, const int32_t **mtid, const
     if (has_mr) *has_mr = b->has_mr.data();
     return MDX_OK;
 }
+
+const uint8_t *mdx_bam_qmin(const mdx_bam *b) { return b ? b->qmin.data() : nullptr; }
 
 int32_t mdx_bam_n_rg(const mdx_bam *b) { return b ? (int32_t)b->rg_names.size() : 0; }
 

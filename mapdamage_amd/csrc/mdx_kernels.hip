@@ -443,7 +443,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
 
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
-    struct Stage { u32x3 s12, r12, q12; u32 ro, so, qo, pk, aux; int lim; bool valid; };
+    struct Stage { u32x3 s12, r12; u32 ro, so, pk, aux; int lim; bool valid; };
     // Three kinds of steps (one instantiation each):
     //   STEP_C  complete records: every task present, static byte masks;
     //   STEP_P  a column range per side: short records and contig edges ([-flank, min(nq, L))), gapped records whose
@@ -468,10 +468,24 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi;
         const u32 hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
         const u32 base_b = tc_base(st.pk, c_lane4);
-        u32 q_lo = 0, q_hi = 0;
+        u32 q_lo = 0, q_hi = 0, qo_ = 0;
+        u32x3 q12_ = {0u, 0u, 0u};
+        bool q_ready = false;
+        auto qwin = [&]() {
+            if (!q_ready) {
+                q_lo = __builtin_amdgcn_alignbyte(q12_.y, q12_.x, qo_);
+                q_hi = __builtin_amdgcn_alignbyte(q12_.z, q12_.y, qo_);
+                q_ready = true;
+            }
+        };
         if (MASK) {
-            q_lo = __builtin_amdgcn_alignbyte(st.q12.y, st.q12.x, st.qo);
-            q_hi = __builtin_amdgcn_alignbyte(st.q12.z, st.q12.y, st.qo);
+            // the quality window is requested here, at the start of the step that uses it, not a step or two ahead like
+            // the other two: three more registers per step in flight are more than the kernel has (the hot loop
+            // spilled), and what a step does before it needs the qualities covers part of the latency.  Records that
+            // cannot be masked — no qualities, or the caller's hint — read one fixed line instead of their window.
+            const u32 qo = st.so - c_so + c_qo;
+            const u32x3 q12 = *(const u32x3 *)(qualW + ((st.pk & 0x40000000u) ? (qo & ~3u) : 0u));
+            q12_ = q12; qo_ = qo;       // (funnelled out where the qualities are first needed: the wait sits there)
         }
         u32 evw = st.pk & 0xBF03FF00u;    // event word of this lane (without lane and quality bits)
         if (KIND == STEP_C) {
@@ -508,6 +522,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     s_lo = m_lo; s_hi = m_hi;
                     if (MASK) {
                         // the qualities travel with the read; a deleted column has none (never masked, align.py:67)
+                        qwin();
                         const u64 q64 = (u64)q_lo | ((u64)q_hi << 32), ql = q64 >> shr, qh = q64 << shl;
                         q_lo = (X_lo & (u32)ql) | ~X_lo; q_hi = (X_hi & (u32)(ql >> 32)) | ~X_hi;
                         q_lo = (Y_lo & q_lo) | (~Y_lo & (u32)qh); q_hi = (Y_hi & q_hi) | (~Y_hi & (u32)(qh >> 32));
@@ -543,6 +558,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // MASK: bit 7 of the bytes whose quality is below --min-basequal (align.py:65-71)
         u32 lowq_lo = 0, lowq_hi = 0;
         if (MASK) {
+            qwin();
             const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
             lowq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u;
             lowq_hi = ~((q_hi | 0x80808080u) - minq4) & 0x80808080u;
@@ -674,19 +690,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 st.ro = ro; st.so = so;
                 st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                 st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
-                if (MASK) {
-                    st.qo = so - c_so + c_qo;
-                    st.q12 = *(const u32x3 *)(qualW + (st.qo & ~3u));
-                }
                 st.pk = ent.w;
             };
             // software pipeline: PIPE_DEPTH steps in flight, each in its own register set (no register
             // rotation: a copy of an in-flight destination would wait for its load).  Every point of
             // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
             // PIPE_DEPTH - 1 fills per run go past the last step.
-            // (--min-basequal loads a third column per step: two steps in flight keep it inside the register budget)
             // (the runs of gapped records are a step or two long: two register sets)
-            constexpr int PD = (MASK || KIND == STEP_GI || KIND == STEP_GD) ? 2 : PIPE_DEPTH;
+            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? 2 : PIPE_DEPTH;
             Stage st[PD];
     #pragma unroll
             for (int dd = 0; dd < PD; dd++) fill(st[dd]);
@@ -890,7 +901,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 }
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
-                if (MASK && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
+                // (flag bit 0x8000, include/mdx.h: the caller vouches that no quality of the record is below the threshold)
+                if (MASK && !(fl & 0x8000u) && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
                 // statistics.py:117-126
                 int kind = -1;
                 i64 flen = 0;

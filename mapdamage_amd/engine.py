@@ -30,7 +30,7 @@ EXPORTS = (
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
-    "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled",
+    "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled", "mdx_bam_qmin",
 )
 
 
@@ -97,6 +97,8 @@ def load_library(path=None):
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
         getattr(lib, name).restype = ctypes.c_char_p
     lib.mdx_bam_qnames.restype = ctypes.c_void_p
+    lib.mdx_bam_qmin.restype = ctypes.c_void_p
+    lib.mdx_bam_qmin.argtypes = [ctypes.c_void_p]
     lib.mdx_bam_ref_length.restype = ctypes.c_int64
     lib.mdx_bam_free.restype = None
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_n_rg", "mdx_bam_free"):

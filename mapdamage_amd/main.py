@@ -5,6 +5,7 @@ per-read loop replaced by ``DamageEngine`` (HIP).  R plotting, the Bayesian stag
 are out of scope: their flags are parsed, and asking for them is an error."""
 
 import argparse
+import dataclasses
 import logging
 import sys
 import time
@@ -13,6 +14,7 @@ from pathlib import Path
 import numpy as np
 
 from . import __version__
+from .batch import mark_unmaskable
 from .engine import BadReadError, DamageEngine
 from .fasta import compare_sequence_dicts, read_fasta_index, reference_for_bam
 from .reader import BAMReader
@@ -207,6 +209,12 @@ def main(argv):
                     if batch.qual is None or bool(((lens == 0) | (batch.qual[first] == 0xFF)).any()):
                         logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
                         warned_about_quals = True
+                if options.minqual:
+                    # records none of whose qualities is below the threshold cannot be masked: the kernel skips their
+                    # quality windows; a chunk without a single maskable base goes through the unmasked kernel
+                    batch, nothing_to_mask = mark_unmaskable(batch, options.minqual)
+                    if nothing_to_mask:
+                        batch = dataclasses.replace(batch, qual=None)
                 for lo in range(0, batch.n, options.batch_reads):
                     try:
                         engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))

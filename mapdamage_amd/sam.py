@@ -342,6 +342,7 @@ def _native_alignments(lib, handle, owner, header=None):
     al._qoff = col(offs.value, n + 1, np.uint32) if n else np.zeros(1, np.uint32)
     al._qblob = col(blob_ptr, int(al._qoff[-1]), np.uint8) if n else np.zeros(0, np.uint8)
     al.has_mr = col(hmr.value, n, np.uint8).view(bool)
+    al.qmin = col(lib.mdx_bam_qmin(handle), n, np.uint8)     # lowest quality of each record
     return al
 
 

@@ -413,3 +413,30 @@ def test_hip_fuzzed_cigars_match_oracle(k, mid_genome):
     want = oracle_tableset(mid_genome, batch, libs, L, A, Q)
     got = run_engine(mid_genome, batch, libs, L, A, Q)
     assert_tables_equal(got, want)
+
+
+def test_hip_quality_hint_skips_nothing_that_matters(mid_genome):
+    """MDX_FLAG_QUAL_ABOVE_MIN: records whose lowest quality is at or above --min-basequal carry the hint (their
+    quality windows are not loaded); the tables must equal the oracle's, which never sees the bit.  Mixed batch:
+    clean records, records with low bases, records without qualities."""
+    from mapdamage_amd.batch import concat_batches, mark_unmaskable, record_min_quality
+    from mapdamage_amd.engine import DamageEngine
+    rng = np.random.default_rng(12)
+    parts = []
+    for k, clean in enumerate((True, False, True)):
+        b = synth.make_reads(mid_genome, 30_000, 40 + k, len_range=(30, 140), paired=True, frac_softclip=0.1, frac_ins=0.05,
+                             frac_del=0.05, frac_skip=0.01, with_qual=True, frac_filtered=0.02)
+        if clean:
+            b.qual = rng.integers(25, 42, b.qual.shape[0]).astype(np.uint8)
+        parts.append(b)
+    batch = concat_batches(parts)
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 25)
+    hinted, nothing = mark_unmaskable(batch, 25)
+    assert not nothing and 0.5 < ((hinted.flag & 0x8000) != 0).mean() < 0.8
+    assert (record_min_quality(batch)[(hinted.flag & 0x8000) != 0] >= 25).all()
+    with DamageEngine(libs, 70, 10, 25) as eng:
+        eng.set_reference(mid_genome)
+        eng.tabulate(hinted)
+        got = eng.finish()
+    assert_tables_equal(got, want)
