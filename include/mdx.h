@@ -28,7 +28,9 @@ extern "C" {
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
 #define MDX_ERR_HIP (-2)          /* HIP runtime failure */
 #define MDX_ERR_STATE (-3)        /* call order violated (e.g. tabulate before set_reference) */
-#define MDX_ERR_MASK_INDEX (-4)   /* align.py:69-71 IndexError (kept for ABI completeness) */
+#define MDX_ERR_MASK_INDEX (-4)   /* reserved, never returned: the IndexError of align.py:69-71 (a masked column beyond
+                                     the gapped reference) needs a reference slice cut short by its contig end, and
+                                     such a record is MDX_ERR_BAD_READ already (the reference raises at align.py:33) */
 #define MDX_ERR_LGD_OVERFLOW (-5) /* more out-of-range fragment lengths than lgd_over_cap */
 #define MDX_ERR_BAD_READ (-6)     /* record the reference cannot process: alignment past the
                                      contig end (pysam ValueError from align.py:33 / main.py:180),

@@ -339,7 +339,7 @@ class DamageEngine:
         rc = self._lib.mdx_rescale_host(self._ctx, ctypes.byref(hb), _ptr(mtid), _ptr(mpos), _ptr(qual_out),
                                         _ptr(mr), _ptr(status))
         if rc == L.MDX_ERR_BAD_READ:
-            raise BadReadError(-1, self._lib.mdx_last_error(self._ctx).decode())
+            self.sync()     # raises BadReadError with the record's index within the batch
         self._check(rc)
         return qual_out, mr, status
 

@@ -266,6 +266,25 @@ def test_hip_tabulate_and_rescale_in_one_pass(tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_rescale_names_the_record_it_cannot_process(tmp_path):
+    """A record running past its contig end (the reference's fetch raises there) is reported with its index."""
+    from mapdamage_amd.batch import batch_from_records
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    _, _, model, _, _, _ = load(tmp_path)
+    ref = synth.small_genome()
+    recs = hardclip_records(ref, n=40)
+    recs[17] = dict(recs[17], pos=ref.lengths[0] - 10, cigar=[(0, 50)], seq="A" * 50, qual=np.full(50, 30, np.uint8))
+    b = batch_from_records(recs, with_qual=True)
+    b.mtid = b.tid.copy(); b.mpos = b.pos.copy()
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        with pytest.raises(BadReadError) as err:
+            eng.rescale(b)
+    assert err.value.read_index == 17
+
+
+@pytest.mark.gpu
 def test_cli_rescale_only_rewrites_bam(tmp_path):
     """`--rescale-only`: every record written back, new qualities + MR:f on the rescaled ones,
     untouched fields preserved."""
