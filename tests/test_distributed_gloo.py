@@ -40,3 +40,17 @@ def test_two_rank_gloo_allreduce_matches_single_pass():
     out = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "dist ok: world=2" in out.stdout
+
+
+def test_bench_gpus_n_relaunches_itself_under_torchrun():
+    """`python bench.py --gpus 8` must become one rank per GPU (--gpus used to be parsed and ignored)."""
+    import json
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "7", "--print-launch"],
+                         cwd=str(ROOT), env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")},
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "7"] or ("--gpus" in cmd and "--steps" in cmd)
+    assert any(part.endswith("bench.py") for part in cmd)
