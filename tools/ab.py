@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--variants", default="plain paired|softclip 10%|ins 8%|del 8%|skip 0.2%|config 3|len 35-69|config 4")
     ap.add_argument("--fuzz", type=int, default=0)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--length", type=int, default=70)
     args = ap.parse_args()
     only = [v for v in args.variants.split("|") if v]
     ref = synth.make_genome()
@@ -31,7 +32,7 @@ def main():
         path = ROOT / "mapdamage_amd" / "libmdx.so" if tag == "cur" else ROOT / "tools" / "bin" / ("libmdx_%s.so" % tag)
         engine._lib = engine.load_library(str(path))
         rows = []
-        with engine.DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
+        with engine.DamageEngine([("s", "l")], args.length, 10, 0, lgd_max=4096) as eng:
             eng.set_reference(ref)
             for name in only:
                 db = eng.upload(batches[name])
