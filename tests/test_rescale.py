@@ -161,34 +161,47 @@ def test_hip_rescale_fuzzed_cigars_match_oracle(k, tmp_path):
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
 
 
-def hardclip_records(ref, n=600, seed=5):
-    """Records whose CIGAR ends in a hard clip (bwa-mem supplementary alignments; rescaling applies no flag filter):
-    50M5H, 5H50M, 5H50M5H, also around a soft clip on the other side and with an indel."""
-    rng = np.random.default_rng(seed)
-    bases, offs = ref.concat()
-    upper = bases & np.uint8(0xDF)
-    shapes = [[(0, 50), (5, 5)], [(5, 5), (0, 50)], [(5, 5), (0, 50), (5, 5)], [(4, 4), (0, 40), (5, 7)],
-              [(5, 3), (0, 30), (1, 2), (0, 20), (5, 9)], [(5, 6), (0, 25), (2, 3), (0, 25), (4, 5)]]
-    recs = []
-    for i in range(n):
-        cig = shapes[i % len(shapes)]
-        span = sum(ln for op, ln in cig if op in (0, 2))
-        pos = int(rng.integers(20, ref.lengths[0] - span - 20))
-        seq, r = [], int(offs[0]) + pos
-        for op, ln in cig:
-            if op == 0:
-                seq.append(upper[r:r + ln].copy()); r += ln
-            elif op == 2:
-                r += ln
-            elif op in (1, 4):
-                seq.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), ln))
-        seq = np.concatenate(seq)
-        # damage-like substitutions so that something is rescaled
-        seq = np.where((seq == ord("C")) & (rng.random(seq.shape[0]) < 0.3), ord("T"), seq)
-        seq = np.where((seq == ord("G")) & (rng.random(seq.shape[0]) < 0.3), ord("A"), seq).astype(np.uint8)
-        recs.append(dict(flag=int(rng.choice([0, 16, 0x800, 0x810])), tid=0, pos=pos, cigar=cig, seq=seq.tobytes().decode(),
-                         qual=rng.integers(2, 42, seq.shape[0]).astype(np.uint8), lib=0, tlen=0))
-    return recs
+from tools.make_golden_hardclip import hardclip_records  # noqa: E402
+
+
+HARDCLIP_GOLDEN = pathlib.Path(__file__).resolve().parent / "golden" / "genome_rescale_hardclip.npz"
+
+
+def load_hardclip(tmp_path):
+    z = np.load(HARDCLIP_GOLDEN)
+    names = json.loads(bytes(z["names"]).decode())
+    seqs, o = [], 0
+    bases = bytes(z["ref_bases"])
+    for ln in z["ref_lengths"]:
+        seqs.append(bases[o:o + int(ln)])
+        o += int(ln)
+    batch = ReadBatch(z["flag"], np.zeros(len(z["flag"]), np.uint16), z["tid"], z["pos"], z["tlen"], z["cigar_off"],
+                      z["cigar"], z["seq_off"], z["seq"], z["qual"], z["mtid"], z["mpos"]).validate()
+    path = tmp_path / "hc.csv"
+    path.write_bytes(bytes(z["csv"]))
+    model = RescaleModel.from_csv(path, int(z["len5p"]), int(z["len3p"]))
+    return Reference(names, seqs), batch, model, get_corr_prob(path, int(z["len5p"]), int(z["len3p"])), z["qual_out"], z["mr"]
+
+
+def test_oracle_matches_reference_golden_with_hard_clips(tmp_path):
+    """The reference's own _rescale_qual_core over 50M5H / 5H50M / 5H50M5H / clip + indel records
+    (tools/make_golden_hardclip.py): every such record is rescaled and written (rescale.py:266-271)."""
+    from oracle import oracle
+    ref, batch, model, corr_prob, want_qual, want_mr = load_hardclip(tmp_path)
+    qual_out, mr_raw, status = oracle.rescale(ref, batch, corr_table(corr_prob, model), model.len5p, model.len3p)
+    check(qual_out, mr_raw, want_qual, want_mr)
+    assert not np.isnan(want_mr).any() and int((want_qual != batch.qual).sum()) > 50
+
+
+@pytest.mark.gpu
+def test_hip_matches_reference_golden_with_hard_clips(tmp_path):
+    from mapdamage_amd.engine import DamageEngine
+    ref, batch, model, _corr_prob, want_qual, want_mr = load_hardclip(tmp_path)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        qual_out, mr_raw, _status = eng.rescale(batch)
+    check(qual_out, mr_raw, want_qual, want_mr)
 
 
 def test_oracle_rescales_hard_clipped_records(tmp_path):
