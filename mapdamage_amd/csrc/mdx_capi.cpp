@@ -707,6 +707,10 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, co
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
         (void)hipEventRecord(e0, c->stream);
+    // qual_out starts as a copy of qual (one streaming copy at memory speed): the kernel then only stores the bytes
+    // it rescales (a few per read) instead of moving every quality through its lanes — the timed region holds both
+    if (d_qual_out != b->qual)
+        HIP_TRY(c, hipMemcpyAsync(d_qual_out, b->qual, (size_t)b->n_bases, hipMemcpyDeviceToDevice, c->stream));
     mdx_k_rescale(a, c->n_cu, c->stream);
     if (e0 && e1) {
         (void)hipEventRecord(e1, c->stream);

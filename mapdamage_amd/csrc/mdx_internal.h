@@ -161,7 +161,7 @@ struct MdxRescaleArgs {
     const double *term;      // [2][npos]
     int len5p, len3p;
     int lds_tables;          // set by mdx_k_rescale: lut and term are copied to the LDS (fast path available)
-    uint8_t *qual_out;
+    uint8_t *qual_out;       // on entry a copy of qual (the kernel stores the rescaled bytes only, and whole gapped records)
     double *mr_raw;
     uint8_t *status;
     unsigned long long *err;

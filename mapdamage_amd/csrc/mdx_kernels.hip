@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         u32 so = 0;
         int lseq = 0, qs = 0, nq = 0, st = 0, fwd_only = 0, rev = 0;
         i64 rbase = 0;
-        bool fast = false;
+        bool fast = false, handled = false;
         if (valid) {
             // first round trip: the record's columns; second: what they point at
             const u32 fl = a.flag[ri];
@@ -1667,7 +1667,11 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
             } else st = 2;
             const bool room = (i64)so + lseq + 8 <= a.n_bases;   // the 8-byte loads stay inside the columns
             if (st < 2 || st == 4) {
-                fast = room;                                     // copied unchanged: no aligned part
+                // written back unchanged: qual_out already holds the record's qualities (mdx_rescale_device copies the
+                // column before the launch), only the status and the MR marker are left to set
+                a.status[ri] = (u8)st;
+                a.mr_raw[ri] = __builtin_nan("");
+                handled = true;
             } else if (fast_ok && room && cn >= 1 && cn <= 3) {
                 const int o0 = c0 & 0xF, o1 = c1 & 0xF, o2 = c2 & 0xF;
                 auto is_m = [](int o) { return o == 0 || o == 7 || o == 8; };
@@ -1683,13 +1687,10 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                 fast = ok;
                 if (!ok) { qs = 0; nq = 0; }
             }
-            if (fast) {
-                a.status[ri] = (u8)st;
-                if (st < 2 || st == 4) { a.mr_raw[ri] = __builtin_nan(""); qs = 0; nq = 0; }
-            }
+            if (fast) a.status[ri] = (u8)st;
         }
         u64 m_fast = __ballot(fast);
-        u64 m_gen = __ballot(valid && !fast);
+        u64 m_gen = __ballot(valid && !fast && !handled);
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         const int slot = lane >> 4, sl = lane & 15;
         while (m_fast) {
@@ -1723,11 +1724,11 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                 // a reverse-strand record is walked from its last pass to its first: MR is summed in read order
                 const int off = ((s_rev ? npass - 1 - pass : pass) << 7) + 8 * sl;
                 const int nb = pass < npass ? s_lseq - off : 0;       // record bytes from this lane's first byte on
-                u32x2 q8 = {0u, 0u};
                 u64 ids = 0;                                          // per byte: 1 + sub * npos + key of a rescaled column
                 if (nb > 0) {
-                    // one round trip: quality, read and reference bytes (the last two unused outside the aligned part)
-                    q8 = *(const u32x2_u *)(qin + off);
+                    // one round trip: read and reference bytes (unused outside the aligned part).  The qualities are
+                    // not streamed through the kernel: qual_out starts as a copy of qual, a lane fetches its eight
+                    // qualities only when it holds a mismatch and stores the rescaled bytes one by one (a few per read)
                     const u32x2 s8 = *(const u32x2_u *)(sp + off), r8 = *(const u32x2_u *)(rp + off);
                     const u64 am = byte_range(s_qs - off, s_qs + s_nq - off);    // bytes of the aligned part
                     if (am) {
@@ -1741,52 +1742,48 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                             else { bc[0] += nA; bc[1] += nC; bc[2] += nG; bc[3] += nT; }
                         }
                         u64 x = (s64 ^ r64) & am;                     // mismatching columns: candidates
-                        u64 q64 = (u64)q8.x | ((u64)q8.y << 32);
-                        while (x) {
-                            const int i = (__ffsll((long long)x) - 1) >> 3, sh = 8 * i;
-                            x &= ~(0xFFull << sh);
-                            const u32 ch = (u32)(s64 >> sh) & 0xFFu, q = (u32)(q64 >> sh) & 0xFFu;
-                            const int rch = (int)(i8)(u8)(r64 >> sh);
-                            const int qi = off + i - s_qs;
-                            const int oq = s_rev ? s_nq - 1 - qi : qi;   // position in read orientation
-                            int sub = -1;
-                            if (!s_rev) { if (ch == 'T' && rch == 'C') sub = 0; else if (ch == 'A' && rch == 'G') sub = 1; }
-                            else { if (ch == 'A' && rch == 'G') sub = 0; else if (ch == 'T' && rch == 'C') sub = 1; }
-                            u32 newq = q;
-                            int key = 0;
-                            if (sub >= 0) {
-                                int pp = oq + 1;                         // _corr_this_base, rescale.py:49-79
-                                const int back = pp - s_nq - 1;
-                                if (!s_fwd && pp >= -back) pp = back;
-                                key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
-                                if (q <= 93) newq = l_lut[(sub * npos + key) * 94 + q];
-                                // (a zero term — key 0, positions outside the model — adds nothing to MR: x + 0.0 == x)
-                                if (l_term[sub * npos + key] != 0.0) ids |= (u64)(1 + sub * npos + key) << sh;
-                                q64 = (q64 & ~(0xFFull << sh)) | ((u64)newq << sh);
-                            }
-                            if (a.subs) {
-                                int t4 = sub == 0 ? 0 : (sub == 1 ? 2 : -1);   // 0 CT, 1 TC, 2 GA, 3 AG
-                                if (t4 < 0) {
-                                    const bool cg = s_rev ? (ch == 'G' && rch == 'A') : (ch == 'C' && rch == 'T');
-                                    const bool ga = s_rev ? (ch == 'C' && rch == 'T') : (ch == 'G' && rch == 'A');
-                                    t4 = cg ? 1 : (ga ? 3 : -1);
+                        if (x) {
+                            // (the record's bytes from `off` on: at least one is inside the aligned part, and the column
+                            // holds 8 readable bytes behind every record the fast path takes, see `room`)
+                            const u32x2 q8 = *(const u32x2_u *)(qin + off);
+                            const u64 q64 = (u64)q8.x | ((u64)q8.y << 32);
+                            while (x) {
+                                const int i = (__ffsll((long long)x) - 1) >> 3, sh = 8 * i;
+                                x &= ~(0xFFull << sh);
+                                const u32 ch = (u32)(s64 >> sh) & 0xFFu, q = (u32)(q64 >> sh) & 0xFFu;
+                                const int rch = (int)(i8)(u8)(r64 >> sh);
+                                const int qi = off + i - s_qs;
+                                const int oq = s_rev ? s_nq - 1 - qi : qi;   // position in read orientation
+                                int sub = -1;
+                                if (!s_rev) { if (ch == 'T' && rch == 'C') sub = 0; else if (ch == 'A' && rch == 'G') sub = 1; }
+                                else { if (ch == 'A' && rch == 'G') sub = 0; else if (ch == 'T' && rch == 'C') sub = 1; }
+                                u32 newq = q;
+                                int key = 0;
+                                if (sub >= 0) {
+                                    int pp = oq + 1;                         // _corr_this_base, rescale.py:49-79
+                                    const int back = pp - s_nq - 1;
+                                    if (!s_fwd && pp >= -back) pp = back;
+                                    key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
+                                    if (q <= 93) newq = l_lut[(sub * npos + key) * 94 + q];
+                                    // (a zero term — key 0, positions outside the model — adds nothing to MR: x + 0.0 == x)
+                                    if (l_term[sub * npos + key] != 0.0) ids |= (u64)(1 + sub * npos + key) << sh;
+                                    if (newq != q) qout[off + i] = (u8)newq;
                                 }
-                                if (t4 >= 0 && q <= 93) {
-                                    sub_bump(4 + (t4 * 2 + 0) * 94 + q);
-                                    sub_bump(4 + (t4 * 2 + 1) * 94 + newq);
-                                    if (sub >= 0) sub_bump(756 + (sub * npos + key) * 94 + q);
+                                if (a.subs) {
+                                    int t4 = sub == 0 ? 0 : (sub == 1 ? 2 : -1);   // 0 CT, 1 TC, 2 GA, 3 AG
+                                    if (t4 < 0) {
+                                        const bool cg = s_rev ? (ch == 'G' && rch == 'A') : (ch == 'C' && rch == 'T');
+                                        const bool ga = s_rev ? (ch == 'C' && rch == 'T') : (ch == 'G' && rch == 'A');
+                                        t4 = cg ? 1 : (ga ? 3 : -1);
+                                    }
+                                    if (t4 >= 0 && q <= 93) {
+                                        sub_bump(4 + (t4 * 2 + 0) * 94 + q);
+                                        sub_bump(4 + (t4 * 2 + 1) * 94 + newq);
+                                        if (sub >= 0) sub_bump(756 + (sub * npos + key) * 94 + q);
+                                    }
                                 }
                             }
                         }
-                        q8.x = (u32)q64; q8.y = (u32)(q64 >> 32);
-                    }
-                    if (nb >= 8) *(u32x2_u *)(qout + off) = q8;
-                    else {   // the last lane of a record: 4 + 2 + 1 bytes, never past the record's end
-                        u64 t = (u64)q8.x | ((u64)q8.y << 32);
-                        int o = off;
-                        if (nb & 4) { *(u32_u *)(qout + o) = (u32)t; t >>= 32; o += 4; }
-                        if (nb & 2) { *(u16_u *)(qout + o) = (u16)t; t >>= 16; o += 2; }
-                        if (nb & 1) qout[o] = (u8)t;
                     }
                 }
                 // MR: the terms of the rescaled columns, added in the reference's order (read 5' -> 3'), per slot
