@@ -102,6 +102,8 @@ struct mdx_ctx {
     // (the CPU fills one while the DMA engine drains the other)
     DevBuf st[10];
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
+    DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
+    DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_done[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
@@ -109,6 +111,8 @@ struct mdx_ctx {
     uint8_t *d_lut = nullptr;
     double *d_term = nullptr;
     unsigned long long *d_subs = nullptr;   // rescale summary counters
+    std::vector<uint8_t> h_lut;             // host copy of the LUT (the summary's "after" histograms follow from it)
+    bool key0_plain = false;                // key 0 keeps every quality and adds 0.0 to MR
     int len5p = 0, len3p = 0;
     // timing
     bool timing = false;
@@ -234,6 +238,8 @@ void mdx_destroy(mdx_ctx *c) {
     for (auto &ev : c->rs_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &b : c->st) b.release();
     c->lists.release();
+    c->rs_part.release();
+    c->rs_lists.release();
     for (int i = 0; i < 2; i++) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
@@ -671,6 +677,15 @@ int mdx_rescale_set_model(mdx_ctx *c, const uint8_t *lut, const double *term, in
     HIP_TRY(c, hipMemcpy(c->d_lut, lut, 2 * npos * 94, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_term, term, 2 * npos * 8, hipMemcpyHostToDevice));
     c->len5p = len5p; c->len3p = len3p;
+    c->h_lut.assign(lut, lut + 2 * npos * 94);
+    // the fast path of the kernel walks only the end windows of a record: that needs the columns outside them
+    // (position key 0) to stay as they are — true of every model get_corr_prob builds (probability 0 there)
+    c->key0_plain = true;
+    for (int sub = 0; sub < 2; sub++) {
+        if (term[(size_t)sub * npos] != 0.0) c->key0_plain = false;
+        for (int q = 0; q < 94; q++)
+            if (lut[((size_t)sub * npos) * 94 + q] != (uint8_t)q) c->key0_plain = false;
+    }
     const size_t sub_bytes = (size_t)(756 + 2 * npos * 94) * 8;
     HIP_TRY(c, hipMalloc((void **)&c->d_subs, sub_bytes));
     HIP_TRY(c, hipMemset(c->d_subs, 0, sub_bytes));
@@ -686,7 +701,29 @@ int mdx_rescale_summary(mdx_ctx *c, uint64_t *words) {
     if (!c->d_subs) return fail(c, MDX_ERR_STATE, "rescale_set_model first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(words, c->d_subs, (size_t)mdx_rescale_summary_words(c) * 8, hipMemcpyDeviceToHost));
+    const int64_t nw = mdx_rescale_summary_words(c);
+    HIP_TRY(c, hipMemcpy(words, c->d_subs, (size_t)nw * 8, hipMemcpyDeviceToHost));
+    // The kernel counts one word per column: occurrences per (substitution, key, old quality) for C>T / G>A, one
+    // histogram for T>C / A>G (in their "before" words).  The before / after histograms of _record_subs
+    // (rescale.py:108-141) follow: a rescaled column of old quality q has the new quality lut[sub][key][q].
+    const int64_t npos = 1 + (int64_t)c->len5p + c->len3p;
+    for (int t4 = 0; t4 < 4; t4++) {
+        uint64_t *before = words + 4 + (t4 * 2 + 0) * 94, *after = words + 4 + (t4 * 2 + 1) * 94;
+        if (t4 & 1) {
+            for (int q = 0; q < 94; q++) after[q] = before[q];
+            continue;
+        }
+        for (int q = 0; q < 94; q++) before[q] = after[q] = 0;
+        const int sub = t4 >> 1;
+        for (int64_t key = 0; key < npos; key++)
+            for (int q = 0; q < 94; q++) {
+                const uint64_t n = words[756 + (sub * npos + key) * 94 + q];
+                if (!n) continue;
+                before[q] += n;
+                const uint8_t nq = c->h_lut[(size_t)((sub * npos + key) * 94 + q)];
+                after[nq < 94 ? nq : 93] += n;
+            }
+    }
     return MDX_OK;
 }
 
@@ -702,8 +739,16 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, co
     a.n_reads = b->n_reads; a.n_bases = b->n_bases; a.flag = b->flag; a.tid = b->tid; a.pos = b->pos; a.mtid = d_mtid; a.mpos = d_mpos;
     a.cigar_off = b->cigar_off; a.cigar = b->cigar; a.seq_off = b->seq_off; a.seq = b->seq; a.qual = b->qual;
     a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
-    a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p;
+    a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p; a.key0_plain = c->key0_plain ? 1 : 0;
     a.qual_out = d_qual_out; a.mr_raw = d_mr_raw; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
+    HIP_TRY(c, c->rs_part.reserve(mdx_k_rescale_part_bytes(c->len5p, c->len3p, c->n_cu)));
+    a.subs_part = (uint32_t *)c->rs_part.p;
+    int64_t list_waves = 0, list_cap = 0;
+    mdx_k_rescale_lists(b->n_reads, c->n_cu, &list_waves, &list_cap);
+    HIP_TRY(c, c->rs_lists.reserve((size_t)list_waves * (size_t)(list_cap + 1) * 4));
+    a.gen_count = (uint32_t *)c->rs_lists.p;
+    a.gen_list = a.gen_count + list_waves;
+    a.gen_cap = list_cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
         (void)hipEventRecord(e0, c->stream);

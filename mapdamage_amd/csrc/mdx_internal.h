@@ -160,12 +160,25 @@ struct MdxRescaleArgs {
     const uint8_t *lut;      // [2][npos][94]
     const double *term;      // [2][npos]
     int len5p, len3p;
-    int lds_tables;          // set by mdx_k_rescale: lut and term are copied to the LDS (fast path available)
+    int key0_plain;          // position key 0 (columns outside both end windows) is the identity in lut and 0.0 in term
+    int lds_tables;          // set by mdx_k_rescale: lut, term and the summary counters live in the LDS
     uint8_t *qual_out;       // on entry a copy of qual (the kernel stores the rescaled bytes only, and whole gapped records)
     double *mr_raw;
     uint8_t *status;
     unsigned long long *err;
     unsigned long long *subs;   // summary counters (rescale.py:108-192), may be null:
-                                // [4 reference bases | 4 transitions x before/after x 94 | 2 x npos x 94]
+                                // [4 reference bases | 4 transitions x before/after x 94 | 2 x npos x 94]; of the middle
+                                // part the kernel fills only the "before" words of T>C and A>G — the rest follows from the
+                                // last part and the LUT (mdx_rescale_summary)
+    uint32_t *subs_part;        // [blocks][752 + 2 npos 94]: the blocks' own counters (mdx_k_rescale_part_bytes), summed
+                                // into subs by a second small kernel
+    // records rescale_kernel leaves to rescale_walk_kernel: wavefront w appends record indices to
+    // gen_list[w * gen_cap ..] and stores their number in gen_count[w] (mdx_k_rescale_lists sizes both)
+    uint32_t *gen_list;
+    uint32_t *gen_count;
+    int64_t gen_cap;
+    int row_base;               // first row of subs_part the walk kernel's blocks write (set by mdx_k_rescale)
 };
 void mdx_k_rescale(const MdxRescaleArgs &a, int n_cu, hipStream_t s);
+size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu);
+void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *cap);

@@ -1409,12 +1409,15 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
 }
 
 // ------------------------------------------------------------------------------------------------
-// Quality rescaling (mapdamage/rescale.py:195-365; BASELINE config[4]).  One wavefront per record;
-// one lane per query base, walked in the read's own 5'->3' order so that the MR sum is
-// accumulated in the reference's column order (fp64, bit-exact).  The new quality is a byte lookup
-// LUT[sub][position key][old quality] prepared on the host with the reference's floating-point
-// expressions (mapdamage_amd/rescale.py).
-// 512-thread blocks, three per CU (their LDS tables: ~27 KB each), six wavefronts per SIMD (80 VGPRs): measured
+// Quality rescaling (mapdamage/rescale.py:195-365; BASELINE config[4]).  The new quality is a byte lookup
+// LUT[sub][position key][old quality] prepared on the host with the reference's floating-point expressions
+// (mapdamage_amd/rescale.py); MR is the fp64 sum of term[sub][key] over the rescaled columns in the read's own
+// 5'->3' order (bit-exact).  Only columns within len5p of the 5' end or len3p of the 3' end have a key other than 0,
+// and key 0 leaves the quality as it is and adds 0.0 (checked on the host: MdxRescaleArgs::lds_tables), so a record
+// whose CIGAR is [S] M [S] is rescaled by ONE lane walking its two end windows (phase E); the whole read is streamed
+// only for the substitution summary of rescale.py:108-192 (phase S, eight bytes per lane).  Any other record is
+// walked column by column by a whole wavefront (`generic`).
+// 512-thread blocks, three per CU (their LDS tables: ~35 KB each), six wavefronts per SIMD (80 VGPRs): measured
 // against 256 x 5 (93 VGPRs, LDS-limited) -8 %; eight per SIMD spill (43 VGPRs) and lose 30 %
 #ifndef RS_BLOCK
 #define RS_BLOCK 512
@@ -1425,19 +1428,354 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
 #ifndef RS_BPC
 #define RS_BPC 3
 #endif
+#ifndef RS_SPF
+#define RS_SPF 0
+#endif
+#ifndef RS_SQU
+#define RS_SQU 0
+#endif
+#ifndef RS_EG
+#define RS_EG 4           // 8-byte groups of the end windows fetched per round trip of phase E (2: one window; 4: both)
+#endif
+#define RS_STG 192        // staging entries per wavefront: at most three per record of a tile
 __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArgs a) {
     const int lane = threadIdx.x & 63;
     const i64 gwave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
     const int npos = 1 + a.len5p + a.len3p;
     u32 bc[4] = {0, 0, 0, 0};   // summary (rescale.py:108-143): reference bases A,C,G,T in read orientation, per lane
-    // In the LDS when they fit (a.lds_tables): the lookup tables of the fast path and the summary histograms
+    // In the LDS (the kernel is launched only when they fit, a.lds_tables): the lookup tables and the summary histograms
     // (global atomics on a few hot words serialise in the L2): [lut 2 npos 94 B, padded][term 2 npos f64]
-    // [counters u32: 4 x 2 x 94 transitions | 2 x npos x 94 rescaled-column kinds], flushed at block end.
+    // [counters u32: 4 x 2 x 94 transitions | 2 x npos x 94 rescaled-column kinds, padded to 16 B], flushed at block
+    // end, [staging: RS_STG entries of 16 B per wavefront].
     extern __shared__ __attribute__((aligned(16))) u8 rs_lds[];
     const int lut_bytes = (2 * npos * 94 + 15) & ~15, n_cnt = 752 + 2 * npos * 94;
     const u8 *const l_lut = rs_lds;
     const double *const l_term = (const double *)(rs_lds + lut_bytes);
+    u32 *const l_cnt = (u32 *)(rs_lds + lut_bytes + 2 * npos * 8);
+    uint4 *const stg = (uint4 *)(rs_lds + lut_bytes + 2 * npos * 8 + ((n_cnt * 4 + 15) & ~15)) + (threadIdx.x >> 6) * RS_STG;
+    {
+        for (int i = threadIdx.x; i < 2 * npos * 94; i += blockDim.x) rs_lds[i] = a.lut[i];
+        for (int i = threadIdx.x; i < 2 * npos; i += blockDim.x) ((double *)(rs_lds + lut_bytes))[i] = a.term[i];
+        for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) l_cnt[i] = 0;
+        __syncthreads();
+    }
+    // ---- tiles of 64 records.  Phase 1, lane per record: routing (rescale.py:300-342) and the records the fast
+    // path can take: unchanged ones (qual_out already holds their qualities) and rescaled ones whose CIGAR is
+    // [S] M [S].  Phase E, still lane per record: the two end windows of a fast record — candidate columns by a
+    // byte-parallel test, LUT, MR.  Phase S (summary only): the aligned part of four fast records per step, eight
+    // bytes per lane.
+    const i64 ntiles = (a.n_reads + 63) / 64;
+    u32 *__restrict__ my_list = a.gen_list + gwave * a.gen_cap;
+    u32 n_list = 0;
+    const int slot = lane >> 4, sl = lane & 15;
+    auto load8 = [](const u8 *ptr) -> u64 {
+        const u32x2 v = *(const u32x2_u *)ptr;
+        return (u64)v.x | ((u64)v.y << 32);
+    };
+    for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
+        const i64 ri = tile * 64 + lane;
+        const bool valid = ri < a.n_reads;
+        u32 so = 0;
+        int lseq = 0, qs = 0, nq = 0, st = 0, fwd_only = 0, rev = 0;
+        int m1 = 0, gi = 0, gd = 0;   // a fast record is M(m1) [I(gi) | D(gd)] M(nq - m1 - gi) between its soft clips
+        i64 rbase = 0;
+        bool fast = false, handled = false;
+        if (valid) {
+            // first round trip: the record's columns; second: what they point at
+            const u32 fl = a.flag[ri];
+            so = a.seq_off[ri];
+            lseq = (int)(a.seq_off[ri + 1] - so);
+            const u32 co = a.cigar_off[ri];
+            const int cn = (int)(a.cigar_off[ri + 1] - co);
+            const int c_tid = a.tid[ri], c_pos = a.pos[ri], c_mtid = a.mtid[ri], c_mpos = a.mpos[ri];
+            const u32 q_first = lseq > 0 ? (u32)a.qual[so] : 0xFFu;
+            const u32 c0 = cn > 0 ? a.cigar[co] : 0u, c1 = cn > 1 ? a.cigar[co + 1] : 0u, c2 = cn > 2 ? a.cigar[co + 2] : 0u;
+            const u32 c3 = cn > 3 ? a.cigar[co + 3] : 0u, c4 = cn > 4 ? a.cigar[co + 4] : 0u;
+            const bool tid_ok = c_tid >= 0 && c_tid < a.n_contig;
+            const i64 c_off0 = tid_ok ? a.contig_off[c_tid] : 0, c_off1 = tid_ok ? a.contig_off[c_tid + 1] : 0;
+            rev = (fl >> 4) & 1;
+            const int mate_rev = (fl >> 5) & 1;
+            if (fl & 0x4) st = 0;
+            else if (lseq == 0 || q_first == 0xFF) st = 1;
+            else if (fl & 0x1) {
+                const int pos = c_pos, mp = c_mpos;
+                const bool same = c_tid == c_mtid;
+                if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; fwd_only = 1; }
+                else st = 4;
+            } else st = 2;
+            const bool room = (i64)so + lseq + 8 <= a.n_bases;   // the 8-byte loads stay inside the columns
+            if (st < 2 || st == 4) {
+                // written back unchanged: qual_out already holds the record's qualities (mdx_rescale_device copies the
+                // column before the launch), only the status and the MR marker are left to set
+                a.status[ri] = (u8)st;
+                a.mr_raw[ri] = __builtin_nan("");
+                handled = true;
+            } else if (room && cn >= 1 && cn <= 5) {
+                // [S] M [S] or [S] M (I | D) M [S], both runs of the second form at least as long as the end windows
+                auto is_m = [](u32 c) { const u32 o = c & 0xF; return o == 0 || o == 7 || o == 8; };
+                const int lead = (c0 & 0xF) == 4 ? 1 : 0;
+                const u32 cl = cn == 1 ? c0 : (cn == 2 ? c1 : (cn == 3 ? c2 : (cn == 4 ? c3 : c4)));
+                const int trail = (cn > 1 && (cl & 0xF) == 4) ? 1 : 0;
+                const int core = cn - lead - trail;
+                const u32 k0 = lead ? c1 : c0, k1 = lead ? c2 : c1, k2 = lead ? c3 : c2;
+                qs = lead ? (int)(c0 >> 4) : 0;
+                const int clipr = trail ? (int)(cl >> 4) : 0;
+                bool ok = (core == 1 || core == 3) && is_m(k0);
+                m1 = (int)(k0 >> 4);
+                int m2 = 0;
+                if (core == 3) {
+                    const int ox = k1 & 0xF, g = (int)(k1 >> 4);
+                    const int wreq = a.len5p > a.len3p ? a.len5p : a.len3p;
+                    m2 = (int)(k2 >> 4);
+                    ok = ok && is_m(k2) && (ox == 1 || ox == 2) && g >= 1 && m1 >= 1 && m2 >= 1 && m1 >= wreq && m2 >= wreq;
+                    gi = ox == 1 ? g : 0;
+                    gd = ox == 2 ? g : 0;
+                }
+                nq = m1 + gi + m2;
+                const i64 pos = c_pos;
+                // (so + qs >= 8: a reverse-strand window is loaded as the eight bytes that end at its last column;
+                //  nq, and with it every run, fits 16 bits of a staging entry)
+                ok = ok && nq >= 1 && nq <= 0xFFFF && gd <= 0xFFFF && qs + nq + clipr == lseq && tid_ok && pos >= 0 &&
+                     pos + m1 + gd + m2 <= c_off1 - c_off0 && so + (u32)qs >= 8u;
+                if (ok) rbase = c_off0 + pos;
+                fast = ok;
+                if (!ok) { qs = 0; nq = 0; m1 = 0; gi = 0; gd = 0; }
+            }
+        }
+        const u64 m_fast = __ballot(fast);
+        const bool walk = valid && !fast && !handled;   // left to rescale_walk_kernel
+        const u64 m_gen = __ballot(walk);
+
+        // ---- phase E: lane per fast record.  Columns [0, n5) and [s3, nq) in read orientation are the only ones
+        // that can carry a key (_corr_this_base, rescale.py:49-79); every other column keeps its quality and adds 0.
+        if (fast) {
+            const u32 sb = so + (u32)qs;          // 32-bit offsets into the read / quality columns (scalar base pointers)
+            // reference byte under query base qi: at rbase + qi in the left run, rbase + gd - gi + qi in the right one
+            // (the same when there is no gap); the 5' window lies in the left run of a forward read, the right run of a
+            // reverse one
+            const int rshift = gd - gi;
+            const int n5 = a.len5p < nq ? a.len5p : nq;
+            const int s3 = nq - a.len3p > n5 ? nq - a.len3p : n5;
+            const int n3 = fwd_only ? 0 : nq - s3;
+            // stored pair (read byte | reference byte << 8) of a C>T / G>A column of the read's own strand
+            const u32 pair0 = rev ? ('A' | 'G' << 8) : ('T' | 'C' << 8), pair1 = rev ? ('T' | 'C' << 8) : ('A' | 'G' << 8);
+            double mr = 0.0;
+            // A round takes up to 16 columns of the 5' window and 16 of the 3' window as four groups of eight bytes,
+            // all fetched (read, reference, quality) before any is looked at — one round trip.  Byte j of a group is
+            // column oq0 + j (a reverse-strand group is loaded from its far end and byte-swapped), so the candidates
+            // come out in the reference's order: 5' window first, then the 3' window.  Windows longer than 16 take
+            // their own rounds, all of the 5' window before the 3' one.
+            const int ra = (a.len5p + 15) >> 4, rb = (a.len3p + 15) >> 4;
+            const bool one = RS_EG == 4 && ra <= 1 && rb <= 1;
+            const int rounds = one ? 1 : ra + rb;
+            for (int r = 0; r < rounds; r++) {
+                int w[2] = {0, 0}, c[2] = {0, 0};
+                if (one) { c[0] = n5; w[1] = s3; c[1] = n3; }
+                else if (r < ra) { w[0] = 16 * r; c[0] = n5 - 16 * r; }
+                else { w[1] = s3 + 16 * (r - ra); c[1] = n3 - 16 * (r - ra); }
+                u64 sg[4], rg[4], qg[4];
+                int qi0[4];
+#if RS_EG == 2
+                const int hw = r < ra ? 0 : 1;         // a round is one window: two groups
+#define RS_H(h) (hw * 2 + (h))
+#else
+#define RS_H(h) (h)
+#endif
+#pragma unroll
+                for (int h0 = 0; h0 < RS_EG; h0++) {
+                    const int h = RS_H(h0);
+                    const int oq0 = w[h >> 1] + 8 * (h & 1), cnt = c[h >> 1] - 8 * (h & 1);
+                    qi0[h0] = rev ? nq - 8 - oq0 : oq0;
+                    sg[h0] = 0; rg[h0] = 0; qg[h0] = 0;
+                    if (cnt > 0) {
+                        sg[h0] = load8(a.seq + (u32)(sb + qi0[h0]));
+                        rg[h0] = load8(a.ref + (rbase + (((h >> 1) ^ rev) ? rshift : 0) + qi0[h0]));
+                        qg[h0] = load8(a.qual + (u32)(sb + qi0[h0]));
+                    }
+                }
+#pragma unroll
+                for (int h0 = 0; h0 < RS_EG; h0++) {
+                    const int h = RS_H(h0);
+                    const int oq0 = w[h >> 1] + 8 * (h & 1), cnt = c[h >> 1] - 8 * (h & 1);
+                    if (cnt <= 0) continue;
+                    u64 s8 = sg[h0], r8 = rg[h0], q8 = qg[h0];
+                    if (rev) { s8 = __builtin_bswap64(s8); r8 = __builtin_bswap64(r8); q8 = __builtin_bswap64(q8); }
+                    // a transition differs in bits 1 and 2 of the byte ('A'^'G' = 0x06, 'C'^'T' = 0x17), no other
+                    // pair of bases does: the exact test is left to the few candidates
+                    const u64 x = s8 ^ r8;
+                    u64 cd = x & (x >> 1) & 0x0202020202020202ull & byte_range(0, cnt);
+                    while (cd) {
+                        const int sh = (__ffsll((long long)cd) - 1) & ~7;
+                        cd &= cd - 1;
+                        const u32 pr = ((u32)(s8 >> sh) & 0xFFu) | (((u32)(r8 >> sh) & 0xFFu) << 8);
+                        const int sub = pr == pair0 ? 0 : (pr == pair1 ? 1 : -1);
+                        if (sub < 0) continue;
+                        const int oq = oq0 + (sh >> 3);
+                        int pp = oq + 1;                                 // _corr_this_base, rescale.py:49-79
+                        const int back = pp - nq - 1;
+                        if (!fwd_only && pp >= -back) pp = back;
+                        const int key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
+                        const int ti = sub * npos + key;
+                        mr += l_term[ti];                                // (x + 0.0 == x: a zero term changes nothing)
+                        const u32 q = (u32)(q8 >> sh) & 0xFFu;
+                        if (q <= 93) {
+                            const u32 newq = l_lut[ti * 94 + q];
+                            if (newq != q) a.qual_out[(u32)(sb + (rev ? nq - 1 - oq : oq))] = (u8)newq;
+                        }
+                    }
+                }
+            }
+            a.status[ri] = (u8)st;
+            a.mr_raw[ri] = mr;
+        }
+
+        // ---- phase S: the substitution summary of the fast records (rescale.py:108-143), four records per step; the
+        // first 128 columns of the next four are fetched before the current ones are counted
+        if (a.subs && m_fast) {
+            // staging entries (16 B): a run of columns [seq/qual byte offset, reference offset lo, reference offset hi (8)
+            // | rev << 8 | 5'-only << 9 | deletion << 10 | first query base of the run << 16, columns | nq << 16]; a
+            // deleted stretch is an entry of its own whose "read" is the reference itself (base counts, no transition)
+            const int ne = fast ? (m1 + gi == nq ? 1 : (gd ? 3 : 2)) : 0;
+            const int e0 = mbcnt64(__ballot(ne & 1), 0) + 2 * mbcnt64(__ballot(ne & 2), 0);
+            if (fast) {
+                const u32 fl2 = ((u32)rev << 8) | ((u32)fwd_only << 9), nqh = (u32)nq << 16;
+                const u32 sb = so + (u32)qs;
+                auto entry = [&](const u32 soff, const i64 roff, const u32 flags, const int qoff, const int len) {
+                    return make_uint4(soff, (u32)(roff & 0xFFFFFFFFll), (u32)(roff >> 32) | flags | ((u32)qoff << 16), (u32)len | nqh);
+                };
+                stg[e0] = entry(sb, rbase, fl2, 0, m1 + gi == nq ? nq : m1);
+                if (ne >= 2) stg[e0 + ne - 1] = entry(sb + m1 + gi, rbase + m1 + gd, fl2, m1 + gi, nq - m1 - gi);
+                if (ne == 3) stg[e0 + 1] = entry(0, rbase + m1, fl2 | (1u << 10), 0, gd);
+            }
+            const int nfast = rl(e0 + ne, 63);     // entries of the tile
+            struct Step { uint4 e; int nq; u64 s, r, q; };
+            auto fetch = [&](const int i0) -> Step {
+                Step t;
+                const bool sact = i0 + slot < nfast;
+                t.e = stg[sact ? i0 + slot : 0];
+                t.nq = sact ? (int)(t.e.w & 0xFFFFu) : 0;
+                t.s = 0; t.r = 0; t.q = 0;
+                if (t.nq > 8 * sl) {
+                    const i64 rb = ((i64)(t.e.z & 0xFFu) << 32) | t.e.y;
+                    t.r = load8(a.ref + rb + 8 * sl);
+                    t.s = (t.e.z >> 10) & 1 ? t.r : load8(a.seq + t.e.x + 8 * sl);
+#if RS_SQU
+                    if (!((t.e.z >> 10) & 1)) t.q = load8(a.qual + t.e.x + 8 * sl);
+#endif
+                }
+                return t;
+            };
+#if RS_SPF
+            Step nx = fetch(0);
+#endif
+            for (int i0 = 0; i0 < nfast; i0 += 4) {
+#if RS_SPF
+                const Step cur = nx;
+                if (i0 + 4 < nfast) nx = fetch(i0 + 4);
+#else
+                const Step cur = fetch(i0);
+#endif
+                const int s_nq = cur.nq;                                 // columns of the run
+                const int s_rev = (cur.e.z >> 8) & 1, s_fwd = (cur.e.z >> 9) & 1;
+                const int s_qoff = (int)(cur.e.z >> 16), s_tot = (int)(cur.e.w >> 16);
+                const int npass = (s_nq + 127) >> 7;
+                int maxpass = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int v = rl(npass, 16 * q); maxpass = v > maxpass ? v : maxpass; }
+                for (int pass = 0; pass < maxpass; pass++) {
+                    const int off = (pass << 7) + 8 * sl;
+                    const int nb = s_nq - off;                           // columns from this lane's first byte on
+                    if (nb <= 0) continue;
+                    u64 s64 = cur.s, r64 = cur.r, q64 = cur.q;
+                    if (pass > 0) {
+                        // (the column holds 8 readable bytes behind every record the fast path takes, see `room`)
+                        const i64 rb = ((i64)(cur.e.z & 0xFFu) << 32) | cur.e.y;
+                        r64 = load8(a.ref + rb + off);
+                        s64 = (cur.e.z >> 10) & 1 ? r64 : load8(a.seq + cur.e.x + off);
+#if RS_SQU
+                        q64 = load8(a.qual + cur.e.x + off);
+#endif
+                    }
+                    const u64 am = byte_range(0, nb);
+                    {
+                        // subs[nt_ref] += 1 for every column (rescale.py:142-143): classes of the valid bytes
+                        const u64 ok7 = ~r64 & 0x8080808080808080ull & am;   // bit 7 clear: A,C,G,T
+                        const u64 b1 = (r64 << 6) & ok7, b2 = (r64 << 5) & ok7;      // bit 1, bit 2 of the byte
+                        const int nA = __popcll(ok7 & ~b1 & ~b2), nC = __popcll(b1 & ~b2), nT = __popcll(~b1 & b2), nG = __popcll(b1 & b2);
+                        if (s_rev) { bc[0] += nT; bc[1] += nG; bc[2] += nC; bc[3] += nA; }
+                        else { bc[0] += nA; bc[1] += nC; bc[2] += nG; bc[3] += nT; }
+                    }
+                    const u64 x = s64 ^ r64;
+                    u64 cd = x & (x >> 1) & 0x0202020202020202ull & am;   // transitions (and junk bytes that look like one)
+#if !RS_SQU
+                    if (cd) q64 = load8(a.qual + cur.e.x + off);
+#endif
+                    while (cd) {
+                        const int sh = (__ffsll((long long)cd) - 1) & ~7;
+                        cd &= cd - 1;
+                        const u32 q = (u32)(q64 >> sh) & 0xFFu;
+                        if (q > 93) continue;
+                        const u32 pr = ((u32)(s64 >> sh) & 0xFFu) | (((u32)(r64 >> sh) & 0xFFu) << 8);
+                        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
+                        int kind = -1;
+                        if (pr == ('T' | 'C' << 8)) kind = s_rev;
+                        else if (pr == ('A' | 'G' << 8)) kind = 1 - s_rev;
+                        else if (pr == ('C' | 'T' << 8)) kind = 2 + s_rev;
+                        else if (pr == ('G' | 'A' << 8)) kind = 3 - s_rev;
+                        if (kind < 0) continue;
+                        if (kind < 2) {
+                            const int qi = s_qoff + off + (sh >> 3);
+                            int pp = (s_rev ? s_tot - 1 - qi : qi) + 1;
+                            const int back = pp - s_tot - 1;
+                            if (!s_fwd && pp >= -back) pp = back;
+                            const int key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
+                            atomicAdd(&l_cnt[752 + (kind * npos + key) * 94 + q], 1u);
+                        } else {
+                            atomicAdd(&l_cnt[(kind == 2 ? 2 : 6) * 94 + q], 1u);   // "before" words of T>C / A>G
+                        }
+                    }
+                }
+            }
+        }
+        if (m_gen) {
+            if (walk) my_list[n_list + (u32)mbcnt64(m_gen, 0)] = (u32)ri;
+            n_list += (u32)__popcll(m_gen);
+        }
+    }
+    if (lane == 0) a.gen_count[gwave] = n_list;
+    if (a.subs) {
+        // The block's counters go to its own row of subs_part (plain stores; rescale_reduce_kernel adds the rows up):
+        // atomics of every block on the same few thousand words cost 0.3 ms per launch whatever its size.
+        // The four reference-base counts of the block are collected in the first counter words no transition uses
+        // ("before" of C>T).
+        __syncthreads();
+        for (int b = 0; b < 4; b++) {
+            u32 v = bc[b];
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && v) atomicAdd(&l_cnt[b], v);
+        }
+        __syncthreads();
+        u32 *__restrict__ row = a.subs_part + (size_t)blockIdx.x * n_cnt;
+        for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) row[i] = l_cnt[i];
+    }
+}
+
+// The records rescale_kernel leaves out — any CIGAR — one lane per record: the lane walks the record's CIGAR in the
+// read's own 5'->3' order (operations and bytes backwards on the reverse strand), eight columns of a match run at a
+// time, so that MR is summed in the reference's order (rescale.py:226-262).  Wavefront w takes the list
+// rescale_kernel's wavefront w wrote (a.gen_list), 64 records at a time, or — without that kernel (tables too large
+// for its LDS image, or key 0 not the identity) — every (number of wavefronts)-th tile of the batch.
+__global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a) {
+    const int lane = threadIdx.x & 63;
+    const i64 gwave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    const int npos = 1 + a.len5p + a.len3p;
+    u32 bc[4] = {0, 0, 0, 0};   // summary (rescale.py:108-143): reference bases A,C,G,T in read orientation, per lane
+    // In the LDS when they fit (a.lds_tables): [lut 2 npos 94 B, padded][term 2 npos f64][counters u32: 4 x 2 x 94
+    // transitions | 2 x npos x 94 rescaled-column kinds], the counters flushed at block end.
+    extern __shared__ __attribute__((aligned(16))) u8 rs_lds[];
+    const int lut_bytes = (2 * npos * 94 + 15) & ~15, n_cnt = 752 + 2 * npos * 94;
     u32 *const l_cnt = (u32 *)(rs_lds + lut_bytes + 2 * npos * 8);
     if (a.lds_tables) {
         for (int i = threadIdx.x; i < 2 * npos * 94; i += blockDim.x) rs_lds[i] = a.lut[i];
@@ -1445,14 +1783,18 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) l_cnt[i] = 0;
         __syncthreads();
     }
+    const u8 *const t_lut = a.lds_tables ? (const u8 *)rs_lds : a.lut;
+    const double *const t_term = a.lds_tables ? (const double *)(rs_lds + lut_bytes) : a.term;
     // summary word `idx` (>= 4) of include/mdx.h += 1
     auto sub_bump = [&](const int idx) {
         if (a.lds_tables) atomicAdd(&l_cnt[idx - 4], 1u);
         else atomicAdd(&a.subs[idx], 1ull);
     };
 
-    // ---- one record by the whole wavefront, any CIGAR: one lane per query base, CIGAR walked per base
-    auto generic = [&](const i64 ri) {
+    // ---- one record by the whole wavefront, any CIGAR: one lane per query base, CIGAR walked per base, column by
+    // column as the reference does it.  Only for what the lane walk below cannot follow: a reverse-strand read with a
+    // reference skip (see there).
+    auto generic = [&](const i64 ri) __attribute__((always_inline)) {
         const u32 fl = a.flag[ri];
         const u32 so = a.seq_off[ri];
         const int lseq = (int)(a.seq_off[ri + 1] - so);
@@ -1596,10 +1938,10 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                         const bool ga = rev ? (ch == 'C' && rch == 'T') : (ch == 'G' && rch == 'A');
                         st = cg ? 1 : (ga ? 3 : -1);
                     }
+                    // (one counter per column, as in the lane walk)
                     if (st >= 0 && q <= 93) {
-                        sub_bump(4 + (st * 2 + 0) * 94 + q);
-                        sub_bump(4 + (st * 2 + 1) * 94 + newq);
                         if (sub >= 0) sub_bump(756 + (sub * npos + skey) * 94 + q);
+                        else sub_bump(4 + (st * 2 + 0) * 94 + q);
                     }
                 }
             }
@@ -1630,198 +1972,188 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         }
     };
 
-    // ---- tiles of 64 records.  Phase 1, lane per record: routing (rescale.py:300-342) and the records
-    // the fast path can take: unchanged ones (copied) and rescaled ones whose CIGAR is [S] M [S].
-    // Phase 2: a fast record by the whole wavefront, eight bytes per lane; only lanes holding a mismatch
-    // run the per-byte code.
-    const bool fast_ok = a.lds_tables != 0;   // 2 npos < 255 (term ids fit a byte) and the tables fit the LDS
-    const i64 ntiles = (a.n_reads + 63) / 64;
-    for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
-        const i64 ri = tile * 64 + lane;
-        const bool valid = ri < a.n_reads;
-        u32 so = 0;
-        int lseq = 0, qs = 0, nq = 0, st = 0, fwd_only = 0, rev = 0;
+    // ---- one record by one lane; true: left to the whole wavefront
+    auto walk = [&](const i64 ri) __attribute__((always_inline)) -> bool {
+        const u32 fl = a.flag[ri];
+        const u32 so = a.seq_off[ri];
+        const int lseq = (int)(a.seq_off[ri + 1] - so);
+        const u32 co = a.cigar_off[ri];
+        const int cn = (int)(a.cigar_off[ri + 1] - co);
+        const int rev = (fl >> 4) & 1, mate_rev = (fl >> 5) & 1;
+        const int tid = a.tid[ri];
+        const i64 pos = a.pos[ri];
+        // record routing, rescale.py:300-342
+        int st, fwd_only = 0;
+        if (fl & 0x4) st = 0;
+        else if (lseq == 0 || a.qual[so] == 0xFF) st = 1;
+        else if (fl & 0x1) {
+            const int mp = a.mpos[ri];
+            const bool same = tid == a.mtid[ri];
+            if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; fwd_only = 1; }
+            else st = 4;
+        } else st = 2;
+        a.status[ri] = (u8)st;
+        a.mr_raw[ri] = __builtin_nan("");
+        if (st < 2 || st == 4) return false;     // written back unchanged: qual_out starts as a copy of qual
+        // CIGAR: clips, spans
+        auto opk = [&](const int k) -> u32 { return a.cigar[co + k]; };
+        int qs = 0, clipr = 0, rlen = 0, qcons = 0, n_skip = 0;
+        u32 c_first = 0, c_last = 0;
+        bool leading = true;
+        for (int k = 0; k < cn; k++) {
+            const u32 c = opk(k);
+            const int op = c & 0xF, len = (int)(c >> 4);
+            if (k == 0) c_first = c;
+            c_last = c;
+            if (leading) { if (op == 4) qs += len; else if (op != 5) leading = false; }
+            if (op == 0 || op == 7 || op == 8) { rlen += len; qcons += len; }
+            else if (op == 1) qcons += len;
+            else if (op == 2) rlen += len;
+            else if (op == 3) { rlen += len; n_skip += len; }
+            // soft clips behind the last operation that is not a clip (the first operation never counts)
+            if (k >= 1) { if (op == 4) clipr += len; else if (op != 5) clipr = 0; }
+        }
+        const int nq = lseq - qs - clipr > 0 ? lseq - qs - clipr : 0;
+        const int n0 = rlen ? rlen : 1;
+        bool bad = cn == 0 || tid < 0 || tid >= a.n_contig || pos < 0 || nq != qcons;
         i64 rbase = 0;
-        bool fast = false, handled = false;
-        if (valid) {
-            // first round trip: the record's columns; second: what they point at
-            const u32 fl = a.flag[ri];
-            so = a.seq_off[ri];
-            lseq = (int)(a.seq_off[ri + 1] - so);
-            const u32 co = a.cigar_off[ri];
-            const int cn = (int)(a.cigar_off[ri + 1] - co);
-            const int c_tid = a.tid[ri], c_pos = a.pos[ri], c_mtid = a.mtid[ri], c_mpos = a.mpos[ri];
-            const u32 q_first = lseq > 0 ? (u32)a.qual[so] : 0xFFu;
-            const u32 c0 = cn > 0 ? a.cigar[co] : 0u, c1 = cn > 1 ? a.cigar[co + 1] : 0u, c2 = cn > 2 ? a.cigar[co + 2] : 0u;
-            const bool tid_ok = c_tid >= 0 && c_tid < a.n_contig;
-            const i64 c_off0 = tid_ok ? a.contig_off[c_tid] : 0, c_off1 = tid_ok ? a.contig_off[c_tid + 1] : 0;
-            rev = (fl >> 4) & 1;
-            const int mate_rev = (fl >> 5) & 1;
-            if (fl & 0x4) st = 0;
-            else if (lseq == 0 || q_first == 0xFF) st = 1;
-            else if (fl & 0x1) {
-                const int pos = c_pos, mp = c_mpos;
-                const bool same = c_tid == c_mtid;
-                if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; fwd_only = 1; }
-                else st = 4;
-            } else st = 2;
-            const bool room = (i64)so + lseq + 8 <= a.n_bases;   // the 8-byte loads stay inside the columns
-            if (st < 2 || st == 4) {
-                // written back unchanged: qual_out already holds the record's qualities (mdx_rescale_device copies the
-                // column before the launch), only the status and the MR marker are left to set
-                a.status[ri] = (u8)st;
-                a.mr_raw[ri] = __builtin_nan("");
-                handled = true;
-            } else if (fast_ok && room && cn >= 1 && cn <= 3) {
-                const int o0 = c0 & 0xF, o1 = c1 & 0xF, o2 = c2 & 0xF;
-                auto is_m = [](int o) { return o == 0 || o == 7 || o == 8; };
-                int clipr = 0;
-                bool ok = false;
-                if (cn == 1) { ok = is_m(o0); nq = (int)(c0 >> 4); }
-                else if (cn == 2 && o0 == 4) { ok = is_m(o1); qs = (int)(c0 >> 4); nq = (int)(c1 >> 4); }
-                else if (cn == 2) { ok = is_m(o0) && o1 == 4; nq = (int)(c0 >> 4); clipr = (int)(c1 >> 4); }
-                else { ok = o0 == 4 && is_m(o1) && o2 == 4; qs = (int)(c0 >> 4); nq = (int)(c1 >> 4); clipr = (int)(c2 >> 4); }
-                const i64 pos = c_pos;
-                ok = ok && nq >= 1 && qs + nq + clipr == lseq && tid_ok && pos >= 0 && pos + nq <= c_off1 - c_off0;
-                if (ok) rbase = c_off0 + pos;
-                fast = ok;
-                if (!ok) { qs = 0; nq = 0; }
-            }
-            if (fast) a.status[ri] = (u8)st;
+        if (!bad) {
+            const i64 c0 = a.contig_off[tid];
+            bad = pos + n0 > a.contig_off[tid + 1] - c0;
+            rbase = c0 + pos;
         }
-        u64 m_fast = __ballot(fast);
-        u64 m_gen = __ballot(valid && !fast && !handled);
-        const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
-        const int slot = lane >> 4, sl = lane & 15;
-        while (m_fast) {
-            // up to four fast records per step, one per 16-lane slot (128 record bytes per pass)
-            int jj[4], nrec = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (m_fast) { jj[q] = __ffsll((long long)m_fast) - 1; m_fast &= m_fast - 1; nrec++; }
-                else jj[q] = jj[0];
-            }
-            const int jsel = slot == 0 ? jj[0] : (slot == 1 ? jj[1] : (slot == 2 ? jj[2] : jj[3]));
-            const bool sact = slot < nrec;
-            const int bp = jsel << 2;
-            const u32 s_so = (u32)__builtin_amdgcn_ds_bpermute(bp, (int)so);
-            // (every lane takes part in the exchange: a lane outside the exec mask would be read as 0)
-            const int x_lseq = __builtin_amdgcn_ds_bpermute(bp, lseq);
-            const int s_lseq = sact ? x_lseq : 0;
-            const int s_qs = __builtin_amdgcn_ds_bpermute(bp, qs), s_nq = __builtin_amdgcn_ds_bpermute(bp, nq);
-            const int s_rev = __builtin_amdgcn_ds_bpermute(bp, rev), s_fwd = __builtin_amdgcn_ds_bpermute(bp, fwd_only);
-            const i64 s_rbase = ((i64)__builtin_amdgcn_ds_bpermute(bp, rb_hi) << 32) | (u32)__builtin_amdgcn_ds_bpermute(bp, rb_lo);
-            const u8 *__restrict__ qin = a.qual + s_so;
-            u8 *__restrict__ qout = a.qual_out + s_so;
-            const u8 *__restrict__ sp = a.seq + s_so;
-            const u8 *__restrict__ rp = a.ref + s_rbase - s_qs;     // reference byte under record byte b
-            const int npass = (s_lseq + 127) >> 7;
-            int maxpass = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int v = rl(npass, 16 * q); maxpass = v > maxpass ? v : maxpass; }
-            double mr_s[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int pass = 0; pass < maxpass; pass++) {
-                // a reverse-strand record is walked from its last pass to its first: MR is summed in read order
-                const int off = ((s_rev ? npass - 1 - pass : pass) << 7) + 8 * sl;
-                const int nb = pass < npass ? s_lseq - off : 0;       // record bytes from this lane's first byte on
-                u64 ids = 0;                                          // per byte: 1 + sub * npos + key of a rescaled column
-                if (nb > 0) {
-                    // one round trip: read and reference bytes (unused outside the aligned part).  The qualities are
-                    // not streamed through the kernel: qual_out starts as a copy of qual, a lane fetches its eight
-                    // qualities only when it holds a mismatch and stores the rescaled bytes one by one (a few per read)
-                    const u32x2 s8 = *(const u32x2_u *)(sp + off), r8 = *(const u32x2_u *)(rp + off);
-                    const u64 am = byte_range(s_qs - off, s_qs + s_nq - off);    // bytes of the aligned part
-                    if (am) {
-                        const u64 s64 = (u64)s8.x | ((u64)s8.y << 32), r64 = (u64)r8.x | ((u64)r8.y << 32);
-                        if (a.subs) {
-                            // subs[nt_ref] += 1 for every column (rescale.py:142-143): classes of the valid bytes
-                            const u64 ok7 = ~r64 & 0x8080808080808080ull & am;   // bit 7 clear: A,C,G,T
-                            const u64 b1 = (r64 << 6) & ok7, b2 = (r64 << 5) & ok7;      // bit 1, bit 2 of the byte
-                            const int nA = __popcll(ok7 & ~b1 & ~b2), nC = __popcll(b1 & ~b2), nT = __popcll(~b1 & b2), nG = __popcll(b1 & b2);
-                            if (s_rev) { bc[0] += nT; bc[1] += nG; bc[2] += nC; bc[3] += nA; }
-                            else { bc[0] += nA; bc[1] += nC; bc[2] += nG; bc[3] += nT; }
-                        }
-                        u64 x = (s64 ^ r64) & am;                     // mismatching columns: candidates
-                        if (x) {
-                            // (the record's bytes from `off` on: at least one is inside the aligned part, and the column
-                            // holds 8 readable bytes behind every record the fast path takes, see `room`)
-                            const u32x2 q8 = *(const u32x2_u *)(qin + off);
-                            const u64 q64 = (u64)q8.x | ((u64)q8.y << 32);
-                            while (x) {
-                                const int i = (__ffsll((long long)x) - 1) >> 3, sh = 8 * i;
-                                x &= ~(0xFFull << sh);
-                                const u32 ch = (u32)(s64 >> sh) & 0xFFu, q = (u32)(q64 >> sh) & 0xFFu;
-                                const int rch = (int)(i8)(u8)(r64 >> sh);
-                                const int qi = off + i - s_qs;
-                                const int oq = s_rev ? s_nq - 1 - qi : qi;   // position in read orientation
-                                int sub = -1;
-                                if (!s_rev) { if (ch == 'T' && rch == 'C') sub = 0; else if (ch == 'A' && rch == 'G') sub = 1; }
-                                else { if (ch == 'A' && rch == 'G') sub = 0; else if (ch == 'T' && rch == 'C') sub = 1; }
-                                u32 newq = q;
-                                int key = 0;
-                                if (sub >= 0) {
-                                    int pp = oq + 1;                         // _corr_this_base, rescale.py:49-79
-                                    const int back = pp - s_nq - 1;
-                                    if (!s_fwd && pp >= -back) pp = back;
-                                    key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
-                                    if (q <= 93) newq = l_lut[(sub * npos + key) * 94 + q];
-                                    // (a zero term — key 0, positions outside the model — adds nothing to MR: x + 0.0 == x)
-                                    if (l_term[sub * npos + key] != 0.0) ids |= (u64)(1 + sub * npos + key) << sh;
-                                    if (newq != q) qout[off + i] = (u8)newq;
-                                }
-                                if (a.subs) {
-                                    int t4 = sub == 0 ? 0 : (sub == 1 ? 2 : -1);   // 0 CT, 1 TC, 2 GA, 3 AG
-                                    if (t4 < 0) {
-                                        const bool cg = s_rev ? (ch == 'G' && rch == 'A') : (ch == 'C' && rch == 'T');
-                                        const bool ga = s_rev ? (ch == 'C' && rch == 'T') : (ch == 'G' && rch == 'A');
-                                        t4 = cg ? 1 : (ga ? 3 : -1);
-                                    }
-                                    if (t4 >= 0 && q <= 93) {
-                                        sub_bump(4 + (t4 * 2 + 0) * 94 + q);
-                                        sub_bump(4 + (t4 * 2 + 1) * 94 + newq);
-                                        if (sub >= 0) sub_bump(756 + (sub * npos + key) * 94 + q);
-                                    }
-                                }
+        // rescale.py:266-271 re-attaches clips only when the first / last op is S: any other clip
+        // layout (H before S) leaves a quality string of the wrong length, which pysam rejects
+        if (!bad) {
+            const int pre = (c_first & 0xF) == 4 ? (int)(c_first >> 4) : 0, suf = (c_last & 0xF) == 4 ? (int)(c_last >> 4) : 0;
+            bad = pre != qs || suf != clipr || (cn == 1 && (c_first & 0xF) == 4);
+        }
+        if (bad) { flag_error(a.err, ri, ERR_BAD_READ); return false; }
+
+        const u32 sb = so + (u32)qs;
+        const bool room = (i64)so + lseq + 8 <= a.n_bases;      // eight bytes can be loaded from any byte of the record
+        auto col8 = [&](const u8 *__restrict__ colp, const u32 off, const int cnt) -> u64 {
+            if (room) { const u32x2 v = *(const u32x2_u *)(colp + off); return (u64)v.x | ((u64)v.y << 32); }
+            u64 v = 0;
+            for (int j = 0; j < cnt; j++) v |= (u64)colp[off + j] << (8 * j);
+            return v;
+        };
+        auto count_bases = [&](const u64 r64, const u64 am) {
+            // subs[nt_ref] += 1 (rescale.py:142-143): A,C,G,T of the reference, complemented on the reverse strand
+            const u64 ok7 = ~r64 & 0x8080808080808080ull & am;   // bit 7 clear: a base
+            const u64 b1 = (r64 << 6) & ok7, b2 = (r64 << 5) & ok7;      // bit 1, bit 2 of the byte
+            const int nA = __popcll(ok7 & ~b1 & ~b2), nC = __popcll(b1 & ~b2), nT = __popcll(~b1 & b2), nG = __popcll(b1 & b2);
+            if (rev) { bc[0] += nT; bc[1] += nG; bc[2] += nC; bc[3] += nA; }
+            else { bc[0] += nA; bc[1] += nC; bc[2] += nG; bc[3] += nT; }
+        };
+        double mr = 0.0;
+        // A reverse-strand read with a reference skip: the reference's alignment strings hold gaps for insertions and
+        // deletions only (align.py:53-73), the fetched reference still holds the skipped stretch, and both strings
+        // are reversed from their own ends (rescale.py:221-224) — read column js then faces column js + (skipped
+        // bases) of the gapped reference, whose insertion gaps stay where the forward walk put them.  No runs to
+        // follow: left to `generic`.
+        if (rev && n_skip > 0) return true;
+        int q = rev ? nq : 0, r = rev ? rlen : 0;     // query bases / reference bases in front of the next operation
+        for (int t = 0; t < cn; t++) {
+            const u32 c = opk(rev ? cn - 1 - t : t);
+            const int op = c & 0xF, len = (int)(c >> 4);
+            const int step = rev ? -len : len;
+            if (op == 0 || op == 7 || op == 8) {
+                for (int done = 0; done < len; done += 8) {
+                    const int cnt = len - done < 8 ? len - done : 8;
+                    const int q0 = rev ? q - done - cnt : q + done, r0 = rev ? r - done - cnt : r + done;
+                    const u64 s64 = col8(a.seq, sb + (u32)q0, cnt);
+                    const u32x2 rv = *(const u32x2_u *)(a.ref + rbase + r0);     // (guard band behind the last contig)
+                    const u64 r64 = (u64)rv.x | ((u64)rv.y << 32);
+                    const u64 am = byte_range(0, cnt);
+                    if (a.subs) count_bases(r64, am);
+                    const u64 x = s64 ^ r64;
+                    u64 cd = x & (x >> 1) & 0x0202020202020202ull & am;   // transitions (and junk bytes that look like one)
+                    if (!cd) continue;
+                    const u64 q64 = col8(a.qual, sb + (u32)q0, cnt);
+                    while (cd) {
+                        // the next candidate in read order
+                        const int sh = (rev ? 63 - __builtin_clzll(cd) : __ffsll((long long)cd) - 1) & ~7;
+                        cd &= ~(0xFFull << sh);
+                        const u32 pr = ((u32)(s64 >> sh) & 0xFFu) | (((u32)(r64 >> sh) & 0xFFu) << 8);
+                        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
+                        int kind = -1;
+                        if (pr == ('T' | 'C' << 8)) kind = rev;
+                        else if (pr == ('A' | 'G' << 8)) kind = 1 - rev;
+                        else if (pr == ('C' | 'T' << 8)) kind = 2 + rev;
+                        else if (pr == ('G' | 'A' << 8)) kind = 3 - rev;
+                        if (kind < 0) continue;
+                        const u32 qv = (u32)(q64 >> sh) & 0xFFu;
+                        if (kind < 2) {
+                            const int qi = q0 + (sh >> 3);
+                            int pp = (rev ? nq - 1 - qi : qi) + 1;          // _corr_this_base, rescale.py:49-79
+                            const int back = pp - nq - 1;
+                            if (!fwd_only && pp >= -back) pp = back;
+                            const int key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
+                            const int ti = kind * npos + key;
+                            mr += t_term[ti];                                // (x + 0.0 == x: a zero term changes nothing)
+                            if (qv <= 93) {
+                                const u32 newq = t_lut[ti * 94 + qv];
+                                if (newq != qv) a.qual_out[sb + (u32)qi] = (u8)newq;
+                                if (a.subs) sub_bump(756 + ti * 94 + qv);
                             }
+                        } else if (qv <= 93 && a.subs) {
+                            sub_bump(4 + (kind == 2 ? 2 : 6) * 94 + qv);    // "before" words of T>C / A>G
                         }
                     }
                 }
-                // MR: the terms of the rescaled columns, added in the reference's order (read 5' -> 3'), per slot
-                const u64 has_all = __ballot(ids != 0);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    u64 has = has_all & (0xFFFFull << (16 * q));
-                    if (!has) continue;
-                    const int qrev = rl(s_rev, 16 * q);
-                    double acc = mr_s[q];
-                    while (has) {
-                        const int l = qrev ? 63 - __builtin_clzll(has) : __ffsll((long long)has) - 1;
-                        has &= ~(1ull << l);
-                        u64 w = ((u64)(u32)rl((int)(ids >> 32), l) << 32) | (u32)rl((int)ids, l);
-                        while (w) {   // the non-zero bytes of the lane, in read order
-                            const int sh = (qrev ? 63 - __builtin_clzll(w) : __ffsll((long long)w) - 1) & ~7;
-                            acc += l_term[(int)((w >> sh) & 0xFFull) - 1];
-                            w &= ~(0xFFull << sh);
-                        }
+                q += step; r += step;
+            } else if (op == 1) {
+                q += step;
+            } else if (op == 2) {
+                // deletion columns pair '-' with a reference base, counted while read bases remain in the
+                // iteration order (`if pos_on_read < length_read`, rescale.py:252)
+                if (a.subs && (rev ? q > 0 : q < nq)) {
+                    const int r0 = rev ? r - len : r;
+                    for (int done = 0; done < len; done += 8) {
+                        const u32x2 rv = *(const u32x2_u *)(a.ref + rbase + r0 + done);
+                        count_bases((u64)rv.x | ((u64)rv.y << 32), byte_range(0, len - done < 8 ? len - done : 8));
                     }
-                    mr_s[q] = acc;
                 }
+                r += step;
             }
-            if (sact && sl == 0 && s_nq > 0)
-                a.mr_raw[tile * 64 + jsel] = slot == 0 ? mr_s[0] : (slot == 1 ? mr_s[1] : (slot == 2 ? mr_s[2] : mr_s[3]));
+            // (a reference skip, N, moves nothing: the reference's alignment strings know insertions and deletions
+            //  only — align.py:53-73 — so the bases behind a skip face the skipped stretch itself)
         }
-        while (m_gen) {
-            const int j = __ffsll((long long)m_gen) - 1;
-            m_gen &= m_gen - 1;
-            generic(tile * 64 + j);
+        a.mr_raw[ri] = mr;
+        return false;
+    };
+
+    // 64 records at a time, then one by one those the lanes handed back
+    auto pass = [&](const bool have, const i64 ri) __attribute__((always_inline)) {
+        const bool hand = have && walk(ri);
+        u64 m = __ballot(hand);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            generic(((i64)rl((int)(ri >> 32), j) << 32) | (u32)rl((int)(ri & 0xFFFFFFFFll), j));
         }
+    };
+    if (a.gen_list) {
+        const u32 *__restrict__ mine = a.gen_list + gwave * a.gen_cap;
+        const u32 n = a.gen_count[gwave];
+        for (u32 k0 = 0; k0 < n; k0 += 64) pass(k0 + lane < n, k0 + lane < n ? (i64)mine[k0 + lane] : 0);
+    } else {
+        const i64 ntiles = (a.n_reads + 63) / 64;
+        for (i64 tile = gwave; tile < ntiles; tile += nwaves) pass(tile * 64 + lane < a.n_reads, tile * 64 + lane);
     }
     if (a.subs && a.lds_tables) {
+        // the block's own row of subs_part, as in rescale_kernel (rows a.row_base ..)
         __syncthreads();
-        for (int i = threadIdx.x; i < n_cnt; i += blockDim.x)
-            if (l_cnt[i]) atomicAdd(&a.subs[4 + i], (u64)l_cnt[i]);
-    }
-    if (a.subs) {
+        for (int b = 0; b < 4; b++) {
+            u32 v = bc[b];
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && v) atomicAdd(&l_cnt[b], v);
+        }
+        __syncthreads();
+        u32 *__restrict__ row = a.subs_part + (size_t)(a.row_base + blockIdx.x) * n_cnt;
+        for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) row[i] = l_cnt[i];
+    } else if (a.subs) {
         for (int b = 0; b < 4; b++) {
             u32 v = bc[b];
             for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
@@ -1830,17 +2162,65 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
     }
 }
 
+// subs[4 + i] += sum over the blocks' rows of word i; words 0..3 of a row are the block's reference-base counts.
+// blockIdx.y picks every RS_RED_Y-th row (one thread walking all rows of a word took 0.18 ms on its own).
+#define RS_RED_Y 32
+__global__ void rescale_reduce_kernel(const u32 *__restrict__ part, int rows, int n_cnt, u64 *__restrict__ subs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cnt) return;
+    u64 v = 0;
+#pragma unroll 4
+    for (int r = blockIdx.y; r < rows; r += RS_RED_Y) v += part[(size_t)r * n_cnt + i];
+    if (v) atomicAdd(&subs[i < 4 ? i : 4 + i], v);
+}
+
+static size_t rs_lds_bytes(int npos, bool staging) {
+    return (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 + (((size_t)(752 + 2 * npos * 94) * 4 + 15) & ~(size_t)15) +
+           (staging ? (size_t)(RS_BLOCK / 64) * RS_STG * 16 : 0);
+}
+
 void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     if (a0.n_reads <= 0) return;
     MdxRescaleArgs a = a0;
     const int npos = 1 + a.len5p + a.len3p;
-    const size_t need = (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 + (size_t)(752 + 2 * npos * 94) * 4;
-    a.lds_tables = (2 * npos < 255 && need <= 60 * 1024) ? 1 : 0;
-    const size_t lds = a.lds_tables ? need : 0;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t need = rs_lds_bytes(npos, true);
+    a.lds_tables = (a.key0_plain && 2 * npos < 255 && need <= 60 * 1024 && a.gen_list && a.gen_count && a.subs_part) ? 1 : 0;
     // one launch-sized grid (RS_BPC blocks per CU); the tiles are dealt round-robin to the wavefronts
     const int64_t want = (a.n_reads + RS_BLOCK - 1) / RS_BLOCK;
     const int grid = (int)(want < (int64_t)n_cu * RS_BPC ? want : (int64_t)n_cu * RS_BPC);
-    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(RS_BLOCK), lds, s, a);
+    const int n_cnt = 752 + 2 * npos * 94;
+    if (a.lds_tables) {
+        if (need > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(RS_BLOCK), need, s, a);
+        // what it left out (same grid: wavefront w reads the list wavefront w wrote), then the summary rows of both
+        a.row_base = grid;
+        hipLaunchKernelGGL(rescale_walk_kernel, dim3(grid), dim3(RS_BLOCK), rs_lds_bytes(npos, false), s, a);
+        if (a.subs)
+            hipLaunchKernelGGL(rescale_reduce_kernel, dim3((n_cnt + 255) / 256, RS_RED_Y), dim3(256), 0, s, a.subs_part, 2 * grid, n_cnt, a.subs);
+    } else {
+        // no fast path: every record by the walk; summary counters in the LDS when those alone fit
+        const size_t walk_lds = rs_lds_bytes(npos, false);
+        a.gen_list = nullptr;
+        a.row_base = 0;
+        a.lds_tables = (2 * npos < 255 && walk_lds <= 60 * 1024 && a.subs_part) ? 1 : 0;
+        if (a.lds_tables && walk_lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)rescale_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+        hipLaunchKernelGGL(rescale_walk_kernel, dim3(grid), dim3(RS_BLOCK), a.lds_tables ? walk_lds : 0, s, a);
+        if (a.subs && a.lds_tables)
+            hipLaunchKernelGGL(rescale_reduce_kernel, dim3((n_cnt + 255) / 256, RS_RED_Y), dim3(256), 0, s, a.subs_part, grid, n_cnt, a.subs);
+    }
+}
+
+// wavefronts of a launch over n_reads records, and the list entries each may need (its tiles x 64)
+void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *cap) {
+    const int64_t want = (n_reads + RS_BLOCK - 1) / RS_BLOCK;
+    const int64_t grid = want < (int64_t)n_cu * RS_BPC ? want : (int64_t)n_cu * RS_BPC;
+    const int64_t nw = grid * (RS_BLOCK / 64), ntiles = (n_reads + 63) / 64;
+    *n_waves = nw > 0 ? nw : 1;
+    *cap = ((ntiles + *n_waves - 1) / *n_waves) * 64;
+}
+
+size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu) {
+    return (size_t)2 * n_cu * RS_BPC * (size_t)(752 + 2 * (1 + len5p + len3p) * 94) * 4;   // rows of both kernels
 }

@@ -161,6 +161,122 @@ def test_hip_rescale_fuzzed_cigars_match_oracle(k, tmp_path):
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("l5,l3", [(0, 0), (1, 30), (30, 2), (16, 16), (17, 17), (60, 45), (130, 130)])
+def test_hip_rescale_window_lengths_match_oracle(l5, l3):
+    """Models of other lengths than the usual 12 + 12: the end windows of the kernel's fast path take one round (up to
+    16 columns each), several (longer), or the model does not fit its LDS image at all (130 + 130: every record by
+    the walk kernel).  Short reads make the two windows meet or overlap."""
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.rescale import RescaleModel
+    from oracle import oracle
+    rng = np.random.default_rng(100 * l5 + l3)
+    corr_prob = {}
+    for p in list(range(1, l5 + 1)) + list(range(-l3, 0)):
+        # (a few exact zeros: columns inside the windows whose key adds nothing)
+        corr_prob[("C", "T", p)] = 0.0 if rng.random() < 0.1 else float(rng.random() * 0.6)
+        corr_prob[("G", "A", p)] = 0.0 if rng.random() < 0.1 else float(rng.random() * 0.6)
+    model = RescaleModel(corr_prob, l5, l3)
+    ref = synth.make_genome(seed=12, sizes=(("chr1", 200_000), ("chr2", 50_000)), n_run=300, lower_run=2000)
+    b = synth.make_reads(ref, 30_000, 40 + l5, len_range=(8, 200), paired=True, frac_softclip=0.2, frac_ins=0.1,
+                         frac_del=0.1, frac_skip=0.01, with_qual=True, frac_filtered=0.03)
+    b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
+    b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
+    b.flag = np.where(rng.random(b.n) < 0.5, b.flag & 0xF14, b.flag).astype(np.uint16)
+    want_q, want_mr, want_st, want_counts, want_pvals = oracle.rescale_with_subs(
+        ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        got_q, got_mr, got_st = eng.rescale(b)
+        words = eng.rescale_summary()
+    from mapdamage_amd.rescale import RescaleSummary
+    np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))
+    assert RescaleSummary(words, model).log_lines() == oracle.subs_log_lines(want_counts, want_pvals)
+    np.testing.assert_array_equal(got_q, want_q)
+    np.testing.assert_array_equal(got_st, want_st)
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+
+
+def short_records(ref, seed, n=6000):
+    """Records of 1 .. 45 bases — [S] M [S] and [S] M (I | D) M [S] with runs from one base up, both strands, paired
+    and single, damage-like substitutions at a high rate so that nearly every window holds candidates, qualities at
+    both ends of the 0..93 range and bytes that are not bases."""
+    rng = np.random.default_rng(seed)
+    bases, offs = ref.concat()
+    upper = bases & np.uint8(0xDF)
+    lens = list(ref.lengths)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    recs = []
+    for i in range(n):
+        tid = int(rng.integers(0, 2))
+        kind = int(rng.integers(0, 3))           # 0 plain, 1 insertion, 2 deletion
+        m1 = int(rng.integers(1, 46))
+        ops = [(int(rng.choice([0, 7, 8])), m1)]
+        if kind:
+            ops += [(kind, int(rng.integers(1, 6))), (0, int(rng.integers(1, 46)))]
+        span = sum(ln for op, ln in ops if op != 1)
+        pos = int(rng.integers(0, 6)) if i % 50 == 0 else int(rng.integers(0, lens[tid] - span))
+        seq, r = [], offs[tid] + pos
+        for op, ln in ops:
+            if op == 1:
+                seq.append(rng.choice(acgt, ln))
+            elif op == 2:
+                r += ln
+            else:
+                seq.append(upper[r:r + ln].copy()); r += ln
+        body = np.concatenate(seq)
+        u = rng.random(body.shape[0])
+        body = np.where((body == ord("C")) & (u < 0.35), ord("T"), body)
+        body = np.where((body == ord("G")) & (u > 0.65), ord("A"), body)
+        body = np.where(rng.random(body.shape[0]) < 0.05, rng.choice(np.frombuffer(b"ACGTNE", np.uint8), body.shape[0]), body)
+        sl, sr = (int(rng.integers(1, 12)) if rng.random() < 0.3 else 0 for _ in range(2))
+        seq = np.concatenate([rng.choice(acgt, sl), body, rng.choice(acgt, sr)]).astype(np.uint8)
+        cig = ([(4, sl)] if sl else []) + ops + ([(4, sr)] if sr else [])
+        flag = int(rng.choice([0, 16]))
+        if rng.random() < 0.5:
+            flag |= 0x1 | int(rng.choice([0x40, 0x80])) | (0x20 if rng.random() < 0.5 else 0)
+        qual = np.where(rng.random(seq.shape[0]) < 0.05, rng.choice([0, 1, 92, 93], seq.shape[0]),
+                        rng.integers(2, 42, seq.shape[0])).astype(np.uint8)
+        recs.append(dict(flag=flag, tid=tid, pos=pos, cigar=cig, seq=seq.tobytes().decode("latin-1"), qual=qual, lib=0, tlen=0))
+    return recs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l5,l3", [(12, 12), (3, 20), (25, 7)])
+def test_hip_rescale_short_records_match_oracle(l5, l3):
+    """Reads shorter than the end windows (the windows meet, overlap, or a run of a gapped read is shorter than a
+    window and the record goes to the walk kernel), the first records of the batch (no eight bytes in front of them)."""
+    from mapdamage_amd.batch import batch_from_records
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.rescale import RescaleModel
+    from oracle import oracle
+    rng = np.random.default_rng(7 * l5 + l3)
+    corr_prob = {}
+    for p in list(range(1, l5 + 1)) + list(range(-l3, 0)):
+        corr_prob[("C", "T", p)] = float(rng.random() * 0.7)
+        corr_prob[("G", "A", p)] = float(rng.random() * 0.7)
+    model = RescaleModel(corr_prob, l5, l3)
+    ref = synth.make_genome(seed=13, sizes=(("chr1", 100_000), ("chr2", 30_000)), n_run=200, lower_run=1000)
+    b = batch_from_records(short_records(ref, 500 + l5), with_qual=True)
+    b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
+    b.mpos = (b.pos + rng.integers(-100, 100, size=b.n)).astype(np.int32)
+    want_q, want_mr, want_st, want_counts, want_pvals = oracle.rescale_with_subs(
+        ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    assert ((want_st == 2) | (want_st == 3)).sum() > b.n // 2 and (want_q != b.qual).sum() > b.n
+    with DamageEngine([("s", "l")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        got_q, got_mr, got_st = eng.rescale(b)
+        words = eng.rescale_summary()
+    np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))
+    np.testing.assert_array_equal(got_q, want_q)
+    np.testing.assert_array_equal(got_st, want_st)
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+
+
 from tools.make_golden_hardclip import hardclip_records  # noqa: E402
 
 
