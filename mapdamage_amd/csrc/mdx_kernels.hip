@@ -30,6 +30,8 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 __attribute__((aligned(1))) u32x2_u;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 typedef u32 __attribute__((aligned(1))) u32_u;
 typedef u16 __attribute__((aligned(1))) u16_u;
 struct __attribute__((packed, aligned(4))) u32x3 { u32 x, y, z; };   // global_load_dwordx3
@@ -1428,12 +1430,6 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
 #ifndef RS_BPC
 #define RS_BPC 3
 #endif
-#ifndef RS_SPF
-#define RS_SPF 0
-#endif
-#ifndef RS_SQU
-#define RS_SQU 0
-#endif
 #ifndef RS_EG
 #define RS_EG 4           // 8-byte groups of the end windows fetched per round trip of phase E (2: one window; 4: both)
 #endif
@@ -1443,7 +1439,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
     const i64 gwave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
     const int npos = 1 + a.len5p + a.len3p;
-    u32 bc[4] = {0, 0, 0, 0};   // summary (rescale.py:108-143): reference bases A,C,G,T in read orientation, per lane
+    u32 bc[4] = {0, 0, 0, 0};   // summary (rescale.py:108-143): raw reference-base counts per lane, see phase S
     // In the LDS (the kernel is launched only when they fit, a.lds_tables): the lookup tables and the summary histograms
     // (global atomics on a few hot words serialise in the L2): [lut 2 npos 94 B, padded][term 2 npos f64]
     // [counters u32: 4 x 2 x 94 transitions | 2 x npos x 94 rescaled-column kinds, padded to 16 B], flushed at block
@@ -1468,7 +1464,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
     const i64 ntiles = (a.n_reads + 63) / 64;
     u32 *__restrict__ my_list = a.gen_list + gwave * a.gen_cap;
     u32 n_list = 0;
-    const int slot = lane >> 4, sl = lane & 15;
+    const int slot = lane >> 3, sl = lane & 7;     // phase S: eight runs per step, sixteen bytes per lane
     auto load8 = [](const u8 *ptr) -> u64 {
         const u32x2 v = *(const u32x2_u *)ptr;
         return (u64)v.x | ((u64)v.y << 32);
@@ -1504,7 +1500,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                 if ((!rev && mate_rev && mp > pos && same) || (rev && !mate_rev && mp < pos && same)) { st = 3; fwd_only = 1; }
                 else st = 4;
             } else st = 2;
-            const bool room = (i64)so + lseq + 8 <= a.n_bases;   // the 8-byte loads stay inside the columns
+            const bool room = (i64)so + lseq + 16 <= a.n_bases;  // the 8- and 16-byte loads stay inside the columns
             if (st < 2 || st == 4) {
                 // written back unchanged: qual_out already holds the record's qualities (mdx_rescale_device copies the
                 // column before the launch), only the status and the MR marker are left to set
@@ -1646,94 +1642,72 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                 };
                 stg[e0] = entry(sb, rbase, fl2, 0, m1 + gi == nq ? nq : m1);
                 if (ne >= 2) stg[e0 + ne - 1] = entry(sb + m1 + gi, rbase + m1 + gd, fl2, m1 + gi, nq - m1 - gi);
-                if (ne == 3) stg[e0 + 1] = entry(0, rbase + m1, fl2 | (1u << 10), 0, gd);
+                if (ne == 3) stg[e0 + 1] = entry(sb, rbase + m1, fl2 | (1u << 10), 0, gd);
             }
             const int nfast = rl(e0 + ne, 63);     // entries of the tile
-            struct Step { uint4 e; int nq; u64 s, r, q; };
-            auto fetch = [&](const int i0) -> Step {
-                Step t;
+            for (int i0 = 0; i0 < nfast; i0 += 8) {
                 const bool sact = i0 + slot < nfast;
-                t.e = stg[sact ? i0 + slot : 0];
-                t.nq = sact ? (int)(t.e.w & 0xFFFFu) : 0;
-                t.s = 0; t.r = 0; t.q = 0;
-                if (t.nq > 8 * sl) {
-                    const i64 rb = ((i64)(t.e.z & 0xFFu) << 32) | t.e.y;
-                    t.r = load8(a.ref + rb + 8 * sl);
-                    t.s = (t.e.z >> 10) & 1 ? t.r : load8(a.seq + t.e.x + 8 * sl);
-#if RS_SQU
-                    if (!((t.e.z >> 10) & 1)) t.q = load8(a.qual + t.e.x + 8 * sl);
-#endif
-                }
-                return t;
-            };
-#if RS_SPF
-            Step nx = fetch(0);
-#endif
-            for (int i0 = 0; i0 < nfast; i0 += 4) {
-#if RS_SPF
-                const Step cur = nx;
-                if (i0 + 4 < nfast) nx = fetch(i0 + 4);
-#else
-                const Step cur = fetch(i0);
-#endif
-                const int s_nq = cur.nq;                                 // columns of the run
-                const int s_rev = (cur.e.z >> 8) & 1, s_fwd = (cur.e.z >> 9) & 1;
-                const int s_qoff = (int)(cur.e.z >> 16), s_tot = (int)(cur.e.w >> 16);
-                const int npass = (s_nq + 127) >> 7;
-                int maxpass = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const int v = rl(npass, 16 * q); maxpass = v > maxpass ? v : maxpass; }
-                for (int pass = 0; pass < maxpass; pass++) {
-                    const int off = (pass << 7) + 8 * sl;
+                const uint4 e = stg[sact ? i0 + slot : 0];
+                const int s_nq = sact ? (int)(e.w & 0xFFFFu) : 0;        // columns of the run
+                const int s_rev = (e.z >> 8) & 1, s_fwd = (e.z >> 9) & 1, s_del = (e.z >> 10) & 1;
+                const int s_qoff = (int)(e.z >> 16), s_tot = (int)(e.w >> 16);
+                const i64 rb = ((i64)(e.z & 0xFFu) << 32) | e.y;
+                const u32 fx = s_rev ? 0x04040404u : 0u;    // A <-> T, C <-> G in the two class bits: counts in read orientation
+                // passes of 128 columns per run (one, unless a run is longer)
+                for (int off = 16 * sl; __ballot(off < s_nq); off += 128) {
                     const int nb = s_nq - off;                           // columns from this lane's first byte on
                     if (nb <= 0) continue;
-                    u64 s64 = cur.s, r64 = cur.r, q64 = cur.q;
-                    if (pass > 0) {
-                        // (the column holds 8 readable bytes behind every record the fast path takes, see `room`)
-                        const i64 rb = ((i64)(cur.e.z & 0xFFu) << 32) | cur.e.y;
-                        r64 = load8(a.ref + rb + off);
-                        s64 = (cur.e.z >> 10) & 1 ? r64 : load8(a.seq + cur.e.x + off);
-#if RS_SQU
-                        q64 = load8(a.qual + cur.e.x + off);
-#endif
+                    // both loads in one round trip (the entry of a deleted stretch points at its record's first base;
+                    // the columns hold 16 readable bytes behind every record the fast path takes, see `room`)
+                    const u32x4 rv = *(const u32x4_u *)(a.ref + rb + off);
+                    const u32x4 sl16 = *(const u32x4_u *)(a.seq + (e.x + (s_del ? 0u : (u32)off)));
+                    const u32x4 sv = s_del ? rv : sl16;
+                    const int n_lo = nb < 8 ? nb : 8, n_hi = nb < 16 ? nb - 8 : 8;
+                    const u64 am0 = ~0ull >> (64 - 8 * n_lo), am1 = n_hi > 0 ? ~0ull >> (64 - 8 * n_hi) : 0ull;
+                    const u32 am[4] = {(u32)am0, (u32)(am0 >> 32), (u32)am1, (u32)(am1 >> 32)};
+                    u32 cany = 0, cd[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        // subs[nt_ref] += 1 for every column (rescale.py:142-143).  Raw per-lane counts: valid bytes
+                        // (bit 7 clear: A,C,G,T), class bit 1 set (C,G), class bit 2 set (T,G), both (G) — in read
+                        // orientation; A,C,G,T follow at the end of the kernel
+                        const u32 ok = ~rv[w] & 0x80808080u & am[w];
+                        const u32 b1 = (rv[w] << 6) & ok, b2 = ((rv[w] ^ fx) << 5) & ok;
+                        bc[0] += __popc(ok); bc[1] += __popc(b1); bc[2] += __popc(b2); bc[3] += __popc(b1 & b2);
+                        // transitions (and junk bytes that look like one): bits 1 and 2 of the byte differ
+                        const u32 x = sv[w] ^ rv[w];
+                        cd[w] = x & (x >> 1) & 0x02020202u & am[w];
+                        cany |= cd[w];
                     }
-                    const u64 am = byte_range(0, nb);
-                    {
-                        // subs[nt_ref] += 1 for every column (rescale.py:142-143): classes of the valid bytes
-                        const u64 ok7 = ~r64 & 0x8080808080808080ull & am;   // bit 7 clear: A,C,G,T
-                        const u64 b1 = (r64 << 6) & ok7, b2 = (r64 << 5) & ok7;      // bit 1, bit 2 of the byte
-                        const int nA = __popcll(ok7 & ~b1 & ~b2), nC = __popcll(b1 & ~b2), nT = __popcll(~b1 & b2), nG = __popcll(b1 & b2);
-                        if (s_rev) { bc[0] += nT; bc[1] += nG; bc[2] += nC; bc[3] += nA; }
-                        else { bc[0] += nA; bc[1] += nC; bc[2] += nG; bc[3] += nT; }
-                    }
-                    const u64 x = s64 ^ r64;
-                    u64 cd = x & (x >> 1) & 0x0202020202020202ull & am;   // transitions (and junk bytes that look like one)
-#if !RS_SQU
-                    if (cd) q64 = load8(a.qual + cur.e.x + off);
-#endif
-                    while (cd) {
-                        const int sh = (__ffsll((long long)cd) - 1) & ~7;
-                        cd &= cd - 1;
-                        const u32 q = (u32)(q64 >> sh) & 0xFFu;
-                        if (q > 93) continue;
-                        const u32 pr = ((u32)(s64 >> sh) & 0xFFu) | (((u32)(r64 >> sh) & 0xFFu) << 8);
-                        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
-                        int kind = -1;
-                        if (pr == ('T' | 'C' << 8)) kind = s_rev;
-                        else if (pr == ('A' | 'G' << 8)) kind = 1 - s_rev;
-                        else if (pr == ('C' | 'T' << 8)) kind = 2 + s_rev;
-                        else if (pr == ('G' | 'A' << 8)) kind = 3 - s_rev;
-                        if (kind < 0) continue;
-                        if (kind < 2) {
-                            const int qi = s_qoff + off + (sh >> 3);
-                            int pp = (s_rev ? s_tot - 1 - qi : qi) + 1;
-                            const int back = pp - s_tot - 1;
-                            if (!s_fwd && pp >= -back) pp = back;
-                            const int key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
-                            atomicAdd(&l_cnt[752 + (kind * npos + key) * 94 + q], 1u);
-                        } else {
-                            atomicAdd(&l_cnt[(kind == 2 ? 2 : 6) * 94 + q], 1u);   // "before" words of T>C / A>G
-                        }
+                    if (!cany) continue;
+                    const u32x4 qv = *(const u32x4_u *)(a.qual + (e.x + (u32)off));
+                    // one bit per candidate byte
+                    u32 m16 = (((cd[0] >> 1) * 0x00204081u >> 21) & 0xFu) | (((cd[1] >> 1) * 0x00204081u >> 17) & 0xF0u) |
+                              (((cd[2] >> 1) * 0x00204081u >> 13) & 0xF00u) | (((cd[3] >> 1) * 0x00204081u >> 9) & 0xF000u);
+                    // read-orientation position of byte 0, and the step to byte j
+                    const int oq0 = s_rev ? s_tot - 1 - s_qoff - off : s_qoff + off, dq = s_rev ? -1 : 1;
+                    while (m16) {
+                        const int j = __ffs((int)m16) - 1;
+                        m16 &= m16 - 1;
+                        const u32 bo = (u32)(j & 3) * 8u;
+                        const int w = j >> 2;
+                        const u32 qw = w == 0 ? qv[0] : (w == 1 ? qv[1] : (w == 2 ? qv[2] : qv[3]));
+                        const u32 sw = w == 0 ? sv[0] : (w == 1 ? sv[1] : (w == 2 ? sv[2] : sv[3]));
+                        const u32 rw = w == 0 ? rv[0] : (w == 1 ? rv[1] : (w == 2 ? rv[2] : rv[3]));
+                        const u32 q = __builtin_amdgcn_ubfe(qw, bo, 8u);
+                        const u32 pr = __builtin_amdgcn_ubfe(sw, bo, 8u) | (__builtin_amdgcn_ubfe(rw, bo, 8u) << 8);
+                        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G;
+                        // -1: not a transition of two bases (sums of 0/1 terms: no branches)
+                        const int kind = (int)(pr == ('T' | 'C' << 8)) * (1 + s_rev) + (int)(pr == ('A' | 'G' << 8)) * (2 - s_rev) +
+                                         (int)(pr == ('C' | 'T' << 8)) * (3 + s_rev) + (int)(pr == ('G' | 'A' << 8)) * (4 - s_rev) - 1;
+                        int pp = oq0 + dq * j + 1;                           // _corr_this_base, rescale.py:49-79
+                        const int back = pp - s_tot - 1;
+                        pp = (!s_fwd && pp >= -back) ? back : pp;
+                        const int k5 = pp <= a.len5p ? pp : 0, k3 = -pp <= a.len3p ? a.len5p - pp : 0;
+                        const int key = pp > 0 ? k5 : k3;
+                        // "before" words of T>C / A>G, or the occurrences of (substitution, key, old quality)
+                        const int idx = kind >= 2 ? (kind == 2 ? 2 : 6) * 94 : 752 + (kind * npos + key) * 94;
+                        if (kind >= 0 && q <= 93) atomicAdd(&l_cnt[idx + (int)q], 1u);
                     }
                 }
             }
@@ -1750,10 +1724,19 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         // The four reference-base counts of the block are collected in the first counter words no transition uses
         // ("before" of C>T).
         __syncthreads();
-        for (int b = 0; b < 4; b++) {
-            u32 v = bc[b];
-            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0 && v) atomicAdd(&l_cnt[b], v);
+        {
+            u32 v[4];
+            for (int b = 0; b < 4; b++) {
+                v[b] = bc[b];
+                for (int o = 32; o; o >>= 1) v[b] += __shfl_xor(v[b], o);
+            }
+            // valid, bit 1 (C,G), bit 2 (T,G), both (G) -> A, C, G, T
+            if (lane == 0) {
+                atomicAdd(&l_cnt[0], v[0] - v[1] - v[2] + v[3]);
+                atomicAdd(&l_cnt[1], v[1] - v[3]);
+                atomicAdd(&l_cnt[2], v[3]);
+                atomicAdd(&l_cnt[3], v[2] - v[3]);
+            }
         }
         __syncthreads();
         u32 *__restrict__ row = a.subs_part + (size_t)blockIdx.x * n_cnt;

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_rescale
 mkdir -p $OUT
-B="python $GRAFT_REPO_ROOT/tools/rescale_bench.py 2000000 $*"
+B="python $GRAFT_REPO_ROOT/tools/rescale_bench.py ${READS:-2000000} $*"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B > $OUT/trace.log 2>&1
 for f in $(find $OUT/trace -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done
 pmc() { local name=$1; shift
