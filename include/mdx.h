@@ -191,8 +191,10 @@ int mdx_rescale_host(mdx_ctx *ctx, const mdx_batch *batch, const int32_t *mtid, 
 /* The same for a batch resident in HBM (device pointers throughout, enqueued on the context's stream; errors surface
  * at mdx_sync), and — BASELINE configs[4], "rescaling fused into the same pass" — both results of one resident
  * batch in one call: the count tables (main.py:165-217) and the rescaled qualities (rescale.py:300-344) from the
- * same columns, uploaded once.  mdx_rescale_timing_read: kernel time of the rescale launches (HIP events, like
- * mdx_timing_read for the tabulation kernel; enabled by mdx_timing_enable). */
+ * same columns, uploaded once.  d_qual_out is a column of its own (n_bases bytes; it must not be the batch's quality
+ * column: MDX_ERR_ARG), filled completely — the qualities of records written back unchanged included.
+ * mdx_rescale_timing_read: time of the rescale launches (the rescale kernels with the copy of the quality column
+ * they contain; HIP events, like mdx_timing_read for the tabulation kernel; enabled by mdx_timing_enable). */
 int mdx_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
                        uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
 int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,

@@ -733,6 +733,10 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, co
     if (rc != MDX_OK) return rc;
     if (!c->d_ref || !c->d_lut) return fail(c, MDX_ERR_STATE, "set_reference and rescale_set_model first");
     if (!b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status) return fail(c, MDX_ERR_ARG, "null column");
+    // (the kernels read the old qualities of a record after they have stored its new ones; offsets up to a few hundred
+    //  bytes past the column are formed in 32 bits)
+    if (d_qual_out == b->qual) return fail(c, MDX_ERR_ARG, "qual_out must not be the batch's own quality column");
+    if (b->n_bases > 0xFFFF0000LL) return fail(c, MDX_ERR_ARG, "batch exceeds 32-bit offsets; split it");
     if (b->n_reads == 0) return MDX_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     MdxRescaleArgs a{};
@@ -752,10 +756,8 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, co
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
         (void)hipEventRecord(e0, c->stream);
-    // qual_out starts as a copy of qual (one streaming copy at memory speed): the kernel then only stores the bytes
-    // it rescales (a few per read) instead of moving every quality through its lanes — the timed region holds both
-    if (d_qual_out != b->qual)
-        HIP_TRY(c, hipMemcpyAsync(d_qual_out, b->qual, (size_t)b->n_bases, hipMemcpyDeviceToDevice, c->stream));
+    // qual_out becomes a copy of qual inside the launch (mdx_k_rescale): the kernels then only store the bytes they
+    // rescale (a few per read) — the timed region holds both
     mdx_k_rescale(a, c->n_cu, c->stream);
     if (e0 && e1) {
         (void)hipEventRecord(e1, c->stream);

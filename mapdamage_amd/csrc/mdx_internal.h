@@ -162,7 +162,8 @@ struct MdxRescaleArgs {
     int len5p, len3p;
     int key0_plain;          // position key 0 (columns outside both end windows) is the identity in lut and 0.0 in term
     int lds_tables;          // set by mdx_k_rescale: lut, term and the summary counters live in the LDS
-    uint8_t *qual_out;       // on entry a copy of qual (the kernel stores the rescaled bytes only, and whole gapped records)
+    uint8_t *qual_out;       // becomes a copy of qual (by rescale_kernel, tile by tile, or by a device copy in front of the walk
+                             // kernel when that runs alone); the kernels then store the rescaled bytes only
     double *mr_raw;
     uint8_t *status;
     unsigned long long *err;
@@ -178,6 +179,7 @@ struct MdxRescaleArgs {
     uint32_t *gen_count;
     int64_t gen_cap;
     int row_base;               // first row of subs_part the walk kernel's blocks write (set by mdx_k_rescale)
+    int copy_qual;              // set by mdx_k_rescale: rescale_kernel copies qual to qual_out tile by tile
 };
 void mdx_k_rescale(const MdxRescaleArgs &a, int n_cu, hipStream_t s);
 size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu);

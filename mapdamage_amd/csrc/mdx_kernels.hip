@@ -1433,6 +1433,9 @@ void mdx_k_genome_comp(const uint8_t *ref, const int64_t *contig_off, int n_cont
 #ifndef RS_EG
 #define RS_EG 4           // 8-byte groups of the end windows fetched per round trip of phase E (2: one window; 4: both)
 #endif
+#ifndef RS_WG
+#define RS_WG 2          // 8-column groups the walk kernel fetches per round trip
+#endif
 #define RS_STG 192        // staging entries per wavefront: at most three per record of a tile
 __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArgs a) {
     const int lane = threadIdx.x & 63;
@@ -1470,6 +1473,26 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         return (u64)v.x | ((u64)v.y << 32);
     };
     for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
+        if (a.copy_qual) {
+            // qual_out starts as a copy of qual: the tile's own stretch of the column, 16 bytes per lane, before any
+            // lane of this wavefront stores a rescaled byte into it (the stretch belongs to this tile alone: its first
+            // and last partial 16 bytes are moved byte by byte, never a neighbour's).  The lines it reads are the ones
+            // phase 1 needs the first quality of every record from.
+            const i64 r1 = tile * 64 + 64 < a.n_reads ? tile * 64 + 64 : a.n_reads;
+            const u32 b0 = a.seq_off[tile * 64], b1 = a.seq_off[r1];
+            const u32 nu = (b1 - b0) >> 4;                           // whole 16-byte units, then up to 15 single bytes
+            for (u32 u = (u32)lane; u < nu; u += 128u) {
+                const u32 o0 = b0 + 16u * u, o1 = o0 + 1024u;
+                const bool two = u + 64u < nu;
+                const u32x4 v0 = *(const u32x4_u *)(a.qual + o0);
+                u32x4 v1 = v0;
+                if (two) v1 = *(const u32x4_u *)(a.qual + o1);
+                *(u32x4_u *)(a.qual_out + o0) = v0;
+                if (two) *(u32x4_u *)(a.qual_out + o1) = v1;
+            }
+            const u32 t0 = b0 + 16u * nu + (u32)lane;
+            if (t0 < b1) a.qual_out[t0] = a.qual[t0];
+        }
         const i64 ri = tile * 64 + lane;
         const bool valid = ri < a.n_reads;
         u32 so = 0;
@@ -1539,6 +1562,9 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                 if (!ok) { qs = 0; nq = 0; m1 = 0; gi = 0; gd = 0; }
             }
         }
+        // (the tile's quality copy has long been written back — two round trips ago — but nothing orders the stores of
+        //  different lanes to one address, so the rescaled bytes wait for it explicitly)
+        if (a.copy_qual) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
         const u64 m_fast = __ballot(fast);
         const bool walk = valid && !fast && !handled;   // left to rescale_walk_kernel
         const u64 m_gen = __ballot(walk);
@@ -2042,46 +2068,73 @@ __global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a
             const int op = c & 0xF, len = (int)(c >> 4);
             const int step = rev ? -len : len;
             if (op == 0 || op == 7 || op == 8) {
-                for (int done = 0; done < len; done += 8) {
-                    const int cnt = len - done < 8 ? len - done : 8;
-                    const int q0 = rev ? q - done - cnt : q + done, r0 = rev ? r - done - cnt : r + done;
-                    const u64 s64 = col8(a.seq, sb + (u32)q0, cnt);
-                    const u32x2 rv = *(const u32x2_u *)(a.ref + rbase + r0);     // (guard band behind the last contig)
-                    const u64 r64 = (u64)rv.x | ((u64)rv.y << 32);
-                    const u64 am = byte_range(0, cnt);
-                    if (a.subs) count_bases(r64, am);
-                    const u64 x = s64 ^ r64;
-                    u64 cd = x & (x >> 1) & 0x0202020202020202ull & am;   // transitions (and junk bytes that look like one)
-                    if (!cd) continue;
-                    const u64 q64 = col8(a.qual, sb + (u32)q0, cnt);
-                    while (cd) {
-                        // the next candidate in read order
-                        const int sh = (rev ? 63 - __builtin_clzll(cd) : __ffsll((long long)cd) - 1) & ~7;
-                        cd &= ~(0xFFull << sh);
-                        const u32 pr = ((u32)(s64 >> sh) & 0xFFu) | (((u32)(r64 >> sh) & 0xFFu) << 8);
-                        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
-                        int kind = -1;
-                        if (pr == ('T' | 'C' << 8)) kind = rev;
-                        else if (pr == ('A' | 'G' << 8)) kind = 1 - rev;
-                        else if (pr == ('C' | 'T' << 8)) kind = 2 + rev;
-                        else if (pr == ('G' | 'A' << 8)) kind = 3 - rev;
-                        if (kind < 0) continue;
-                        const u32 qv = (u32)(q64 >> sh) & 0xFFu;
-                        if (kind < 2) {
-                            const int qi = q0 + (sh >> 3);
-                            int pp = (rev ? nq - 1 - qi : qi) + 1;          // _corr_this_base, rescale.py:49-79
-                            const int back = pp - nq - 1;
-                            if (!fwd_only && pp >= -back) pp = back;
-                            const int key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
-                            const int ti = kind * npos + key;
-                            mr += t_term[ti];                                // (x + 0.0 == x: a zero term changes nothing)
-                            if (qv <= 93) {
-                                const u32 newq = t_lut[ti * 94 + qv];
-                                if (newq != qv) a.qual_out[sb + (u32)qi] = (u8)newq;
-                                if (a.subs) sub_bump(756 + ti * 94 + qv);
+                // RS_WG groups of eight columns at a time, all fetched before any is looked at: a lane waits for every
+                // round trip to memory, and little else runs beside it in this kernel
+                for (int done = 0; done < len; done += 8 * RS_WG) {
+                    u64 sg[RS_WG], rg[RS_WG], cdg[RS_WG];
+                    int q0g[RS_WG];
+#pragma unroll
+                    for (int g = 0; g < RS_WG; g++) {
+                        const int d = done + 8 * g, cnt = len - d < 8 ? len - d : 8;
+                        q0g[g] = rev ? q - d - cnt : q + d;
+                        sg[g] = 0; rg[g] = 0;
+                        if (cnt > 0) {
+                            sg[g] = col8(a.seq, sb + (u32)q0g[g], cnt);
+                            const u32x2 rv = *(const u32x2_u *)(a.ref + rbase + (rev ? r - d - cnt : r + d));   // (guard band)
+                            rg[g] = (u64)rv.x | ((u64)rv.y << 32);
+                        }
+                    }
+                    u64 any = 0;
+#pragma unroll
+                    for (int g = 0; g < RS_WG; g++) {
+                        const int d = done + 8 * g, cnt = len - d < 8 ? len - d : 8;
+                        const u64 am = cnt > 0 ? byte_range(0, cnt) : 0ull;
+                        if (a.subs) count_bases(rg[g], am);
+                        const u64 x = sg[g] ^ rg[g];
+                        cdg[g] = x & (x >> 1) & 0x0202020202020202ull & am;   // transitions (and junk bytes that look like one)
+                        any |= cdg[g];
+                    }
+                    if (!any) continue;
+                    u64 qg[RS_WG];
+#pragma unroll
+                    for (int g = 0; g < RS_WG; g++) {
+                        const int d = done + 8 * g, cnt = len - d < 8 ? len - d : 8;
+                        qg[g] = cdg[g] ? col8(a.qual, sb + (u32)q0g[g], cnt) : 0ull;
+                    }
+#pragma unroll
+                    for (int g = 0; g < RS_WG; g++) {
+                        u64 cd = cdg[g];
+                        const u64 s64 = sg[g], r64 = rg[g], q64 = qg[g];
+                        const int q0 = q0g[g];
+                        while (cd) {
+                            // the next candidate in read order
+                            const int sh = (rev ? 63 - __builtin_clzll(cd) : __ffsll((long long)cd) - 1) & ~7;
+                            cd &= ~(0xFFull << sh);
+                            const u32 pr = ((u32)(s64 >> sh) & 0xFFu) | (((u32)(r64 >> sh) & 0xFFu) << 8);
+                            // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
+                            int kind = -1;
+                            if (pr == ('T' | 'C' << 8)) kind = rev;
+                            else if (pr == ('A' | 'G' << 8)) kind = 1 - rev;
+                            else if (pr == ('C' | 'T' << 8)) kind = 2 + rev;
+                            else if (pr == ('G' | 'A' << 8)) kind = 3 - rev;
+                            if (kind < 0) continue;
+                            const u32 qv = (u32)(q64 >> sh) & 0xFFu;
+                            if (kind < 2) {
+                                const int qi = q0 + (sh >> 3);
+                                int pp = (rev ? nq - 1 - qi : qi) + 1;          // _corr_this_base, rescale.py:49-79
+                                const int back = pp - nq - 1;
+                                if (!fwd_only && pp >= -back) pp = back;
+                                const int key = pp > 0 ? (pp <= a.len5p ? pp : 0) : (-pp <= a.len3p ? a.len5p - pp : 0);
+                                const int ti = kind * npos + key;
+                                mr += t_term[ti];                                // (x + 0.0 == x: a zero term changes nothing)
+                                if (qv <= 93) {
+                                    const u32 newq = t_lut[ti * 94 + qv];
+                                    if (newq != qv) a.qual_out[sb + (u32)qi] = (u8)newq;
+                                    if (a.subs) sub_bump(756 + ti * 94 + qv);
+                                }
+                            } else if (qv <= 93 && a.subs) {
+                                sub_bump(4 + (kind == 2 ? 2 : 6) * 94 + qv);    // "before" words of T>C / A>G
                             }
-                        } else if (qv <= 93 && a.subs) {
-                            sub_bump(4 + (kind == 2 ? 2 : 6) * 94 + qv);    // "before" words of T>C / A>G
                         }
                     }
                 }
@@ -2173,6 +2226,7 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     const int grid = (int)(want < (int64_t)n_cu * RS_BPC ? want : (int64_t)n_cu * RS_BPC);
     const int n_cnt = 752 + 2 * npos * 94;
     if (a.lds_tables) {
+        a.copy_qual = a.qual_out != a.qual ? 1 : 0;      // the fast kernel copies the quality column as it goes
         if (need > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
         hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(RS_BLOCK), need, s, a);
@@ -2184,6 +2238,8 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     } else {
         // no fast path: every record by the walk; summary counters in the LDS when those alone fit
         const size_t walk_lds = rs_lds_bytes(npos, false);
+        if (a.qual_out != a.qual)
+            (void)hipMemcpyAsync(a.qual_out, a.qual, (size_t)a.n_bases, hipMemcpyDeviceToDevice, s);
         a.gen_list = nullptr;
         a.row_base = 0;
         a.lds_tables = (2 * npos < 255 && walk_lds <= 60 * 1024 && a.subs_part) ? 1 : 0;
