@@ -36,6 +36,7 @@ extern "C" {
                                      contig end (pysam ValueError from align.py:33 / main.py:180),
                                      tid/library out of range, CIGAR/SEQ length mismatch */
 
+#define MDX_ERR_UNSUPPORTED (-8)  /* mdx_gbam_*: a file layout the GPU decode path does not take (use mdx_bam_*) */
 #define MDX_ERR_COMM (-7)         /* RCCL failure, or another rank of the communicator reported an error */
 
 /* Optional hint in the `flag` column (a bit SAM does not define): every base quality of the record is at least
@@ -259,6 +260,30 @@ int mdx_bam_patch_rescaled(const mdx_bam *bam, const uint8_t *qual_out, const fl
 
 /* Introspection for tests/benchmarks: 0 = LDS-privatised path, 1 = global-atomic fallback. */
 int mdx_table_mode(const mdx_ctx *ctx);
+
+/* ---- GPU-side BAM decode.  The device counterpart of mdx_bam_open / mdx_bam_next — and with them of
+ * pysam.AlignmentFile behind mapdamage/reader.py:20-46: the compressed file goes to HBM a slab of BGZF blocks at a
+ * time, is inflated there (one wavefront per block; RFC 1951, mapdamage_amd/csrc/mdx_inflate.h) and unpacked there
+ * into the columns of an mdx_batch that never exist on the host; the view mdx_gbam_next fills holds DEVICE pointers,
+ * ready for mdx_tabulate_device / mdx_rescale_device, valid until the next mdx_gbam_next / mdx_gbam_close (which
+ * wait for the context's stream first).  The header is parsed on the host (mdx_gbam_header: for the mdx_bam_*
+ * accessors).  mdx_gbam_configure: the header's read-group ids with the library of each, the library of a record
+ * without RG tag (-1: none — such a record gets library 0xFFFF, MDX_ERR_BAD_READ at mdx_sync if it is one the kernel
+ * counts, as is a read group the header does not list), and whether the quality and mate columns are wanted.
+ * Every BGZF block must start at a record (htslib writes them so: bgzf_flush_try in bam_write1) and the header must
+ * fill blocks of its own: any other layout is MDX_ERR_UNSUPPORTED, and the caller decodes on the host instead.  The
+ * CRC32 of a block is not checked (its ISIZE is).  mdx_gbam_next at the end of the file: MDX_OK, n_reads 0,
+ * mdx_gbam_at_end 1.  mdx_ctx_stream: the HIP stream (hipStream_t) and device the context works on. */
+typedef struct mdx_gbam mdx_gbam;
+int mdx_ctx_stream(mdx_ctx *ctx, void **stream, int *device);
+int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out);
+const mdx_bam *mdx_gbam_header(const mdx_gbam *g);
+const char *mdx_gbam_error(const mdx_gbam *g);
+int mdx_gbam_configure(mdx_gbam *g, int32_t n_rg, const char *const *rg_ids, const int32_t *lib_of_rg, int32_t lib_default,
+                       int want_qual, int want_mate);
+int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *dev_view, const int32_t **d_mtid, const int32_t **d_mpos);
+int mdx_gbam_at_end(const mdx_gbam *g);
+void mdx_gbam_close(mdx_gbam *g);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // mdx_batch — the counterpart of iterating a pysam.AlignmentFile (mapdamage/reader.py:38,83-96,
 // 121-132) without pysam.  Pure host code (zlib); no HIP calls.
 #include "../../include/mdx.h"
+#include "mdx_internal.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -143,6 +144,8 @@ struct mdx_bam_stream {
     bool keep_raw = false;           // chunks keep their encoded records (mdx_bam_raw)
     raw_bytes pending;               // inflated bytes not unpacked yet (a partial record at most, between calls)
     std::vector<size_t> hints;       // offsets into `pending` where a BGZF block began (unpack_records)
+    size_t inflated = 0;             // uncompressed bytes inflated so far
+    size_t header_bytes = 0;         // uncompressed size of the BAM header (set by mdx_bam_open)
 };
 
 namespace {
@@ -623,6 +626,7 @@ int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
             const int rc = parse_header(&s->head, s->pending.data(), s->pending.size(), !s->eof, &first);
             if (rc < 0) return MDX_ERR_ARG;
             if (rc == 0) {
+                s->header_bytes = first;
                 s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)first);
                 size_t kept = 0;
                 for (size_t h : s->hints) if (h >= first) s->hints[kept++] = h - first;
@@ -742,6 +746,209 @@ void mdx_bam_close(mdx_bam_stream *s) {
     if (!s) return;
     delete s->file;
     delete s;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// GPU-side decode (mdx_gbam.hip): the compressed file goes to HBM a slab of BGZF blocks at a time, is inflated and
+// unpacked there, and the batch columns never exist on the host.
+struct mdx_gbam {
+    mdx_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    mdx_bam_stream *hs = nullptr;        // header (parsed on the host) and the mapped file
+    std::vector<Block> blocks;           // every BGZF block of the file
+    size_t next_block = 0;               // first block not decoded yet
+    std::string error;
+    bool want_qual = false, want_mate = false;
+    // read groups
+    std::vector<uint8_t> rg_names;
+    std::vector<uint32_t> rg_off;
+    std::vector<int32_t> lib_of_rg;
+    int lib_default = -1;
+    void *d_rg_names = nullptr, *d_rg_off = nullptr, *d_lib_of_rg = nullptr;
+    // device buffers, grown on demand
+    struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
+        cigar_off, cigar, seq_off, seq, qual, small;
+    std::vector<Buf *> all() {
+        return {&comp, &blk, &status, &unc, &cnt, &pre, &rec_off, &flag, &lib, &tid, &pos, &tlen, &mtid, &mpos, &cigar_off, &cigar,
+                &seq_off, &seq, &qual, &small};
+    }
+    bool reserve(Buf &b, size_t bytes) {
+        if (bytes <= b.cap) return true;
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&b.p, want) != hipSuccess) { error = "out of device memory"; return false; }
+        b.cap = want;
+        return true;
+    }
+};
+
+int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out) {
+    try {
+        if (!ctx || !path || !out) return MDX_ERR_ARG;
+        mdx_gbam *g = new (std::nothrow) mdx_gbam();
+        if (!g) return MDX_ERR_ARG;
+        *out = g;
+        g->ctx = ctx;
+        void *st = nullptr;
+        if (mdx_ctx_stream(ctx, &st, &g->device) != MDX_OK) { g->error = "no context"; return MDX_ERR_ARG; }
+        g->stream = (hipStream_t)st;
+        int rc = mdx_bam_open(path, 4, &g->hs);
+        if (rc != MDX_OK) { g->error = g->hs ? g->hs->head.error : "cannot open"; return rc; }
+        size_t total = 0;
+        if (!scan_blocks(*g->hs->file, g->blocks, total, g->error)) return MDX_ERR_ARG;
+        // the records must start where a block starts (htslib flushes the header into blocks of its own)
+        size_t k = 0;
+        while (k < g->blocks.size() && g->blocks[k].out_off < g->hs->header_bytes) k++;
+        if (k < g->blocks.size() ? g->blocks[k].out_off != g->hs->header_bytes : total != g->hs->header_bytes) {
+            g->error = "the BAM header does not end at a BGZF block boundary";
+            return MDX_ERR_UNSUPPORTED;
+        }
+        g->next_block = k;
+        if (hipSetDevice(g->device) != hipSuccess || mdx_k_gbam_prepare() != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+        return MDX_OK;
+    } catch (const std::exception &e) {
+        if (out && *out) (*out)->error = std::string("mdx_gbam_open: ") + e.what();
+        return MDX_ERR_ARG;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
+}
+
+const mdx_bam *mdx_gbam_header(const mdx_gbam *g) { return (g && g->hs) ? &g->hs->head : nullptr; }
+const char *mdx_gbam_error(const mdx_gbam *g) { return g ? g->error.c_str() : "null handle"; }
+
+int mdx_gbam_configure(mdx_gbam *g, int32_t n_rg, const char *const *rg_ids, const int32_t *lib_of_rg, int32_t lib_default,
+                       int want_qual, int want_mate) {
+    try {
+        if (!g || n_rg < 0 || (n_rg > 0 && (!rg_ids || !lib_of_rg))) return MDX_ERR_ARG;
+        g->rg_names.clear(); g->rg_off.assign(1, 0); g->lib_of_rg.clear();
+        for (int i = 0; i < n_rg; i++) {
+            const size_t len = std::strlen(rg_ids[i]);
+            g->rg_names.insert(g->rg_names.end(), (const uint8_t *)rg_ids[i], (const uint8_t *)rg_ids[i] + len);
+            g->rg_off.push_back((uint32_t)g->rg_names.size());
+            g->lib_of_rg.push_back(lib_of_rg[i]);
+        }
+        g->lib_default = lib_default;
+        g->want_qual = want_qual != 0; g->want_mate = want_mate != 0;
+        if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+        for (void **p : {&g->d_rg_names, &g->d_rg_off, &g->d_lib_of_rg}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (n_rg > 0) {
+            if (hipMalloc(&g->d_rg_names, g->rg_names.size() + 1) != hipSuccess || hipMalloc(&g->d_rg_off, g->rg_off.size() * 4) != hipSuccess ||
+                hipMalloc(&g->d_lib_of_rg, g->lib_of_rg.size() * 4) != hipSuccess) { g->error = "out of device memory"; return MDX_ERR_HIP; }
+            (void)hipMemcpy(g->d_rg_names, g->rg_names.data(), g->rg_names.size(), hipMemcpyHostToDevice);
+            (void)hipMemcpy(g->d_rg_off, g->rg_off.data(), g->rg_off.size() * 4, hipMemcpyHostToDevice);
+            (void)hipMemcpy(g->d_lib_of_rg, g->lib_of_rg.data(), g->lib_of_rg.size() * 4, hipMemcpyHostToDevice);
+        }
+        return MDX_OK;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
+}
+
+int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32_t **d_mtid, const int32_t **d_mpos) {
+    try {
+        if (!g || !view) return MDX_ERR_ARG;
+        std::memset(view, 0, sizeof(*view));
+        if (d_mtid) *d_mtid = nullptr;
+        if (d_mpos) *d_mpos = nullptr;
+        if (g->next_block >= g->blocks.size()) return MDX_OK;             // end of file: an empty view
+        if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+        const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
+        // the slab: blocks [b0, b1), about `want` compressed bytes, less than 4 GiB inflated
+        const size_t b0 = g->next_block;
+        size_t b1 = b0, unc_bytes = 0;
+        const size_t in0 = g->blocks[b0].in_off;
+        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && unc_bytes + g->blocks[b1].out_size < 0xF0000000ull))) {
+            unc_bytes += g->blocks[b1].out_size;
+            b1++;
+        }
+        const size_t nb = b1 - b0;
+        const size_t in1 = g->blocks[b1 - 1].in_off + g->blocks[b1 - 1].in_size;
+        const size_t comp_bytes = in1 - in0;
+        const size_t out0 = g->blocks[b0].out_off;
+        std::vector<uint32_t> blk(4 * nb);
+        for (size_t i = 0; i < nb; i++) {
+            const Block &b = g->blocks[b0 + i];
+            blk[4 * i] = (uint32_t)(b.in_off - in0); blk[4 * i + 1] = (uint32_t)b.in_size;
+            blk[4 * i + 2] = (uint32_t)(b.out_off - out0); blk[4 * i + 3] = (uint32_t)b.out_size;
+        }
+        // upper bounds of the columns from the inflated size: a record is at least 36 bytes, and holds its bases
+        // twice over (4 bits + a quality byte each): l_seq <= 2/3 of its size
+        const size_t rec_cap = unc_bytes / 36 + 2, cig_cap = unc_bytes / 4 + 2, seq_cap = unc_bytes + 64;
+        if (!g->reserve(g->comp, comp_bytes + 64) || !g->reserve(g->blk, nb * 16) || !g->reserve(g->status, nb * 4) ||
+            !g->reserve(g->unc, unc_bytes + 64) || !g->reserve(g->cnt, nb * 16) || !g->reserve(g->pre, nb * 16) ||
+            !g->reserve(g->small, 64) || !g->reserve(g->rec_off, rec_cap * 4) || !g->reserve(g->flag, rec_cap * 2) ||
+            !g->reserve(g->lib, rec_cap * 2) || !g->reserve(g->tid, rec_cap * 4) || !g->reserve(g->pos, rec_cap * 4) ||
+            !g->reserve(g->tlen, rec_cap * 4) || !g->reserve(g->cigar_off, rec_cap * 4) || !g->reserve(g->seq_off, rec_cap * 4) ||
+            !g->reserve(g->cigar, cig_cap * 4) || !g->reserve(g->seq, seq_cap) ||
+            (g->want_qual && !g->reserve(g->qual, seq_cap)) ||
+            (g->want_mate && (!g->reserve(g->mtid, rec_cap * 4) || !g->reserve(g->mpos, rec_cap * 4))))
+            return MDX_ERR_HIP;
+        hipStream_t st = g->stream;
+        // the previous slab's columns may still be read by the tabulation kernel
+        if (hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
+        if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(g->blk.p, blk.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
+        unsigned long long *d_tot = (unsigned long long *)g->small.p;
+        int *d_bad = (int *)((char *)g->small.p + 32);
+        const int no_bad = 0x7FFFFFFF;
+        (void)hipMemcpyAsync(d_bad, &no_bad, 4, hipMemcpyHostToDevice, st);
+        mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nb, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)nb, (uint4 *)g->cnt.p,
+                        (uint4 *)g->pre.p, d_tot, d_bad, st);
+        unsigned long long tot[3] = {0, 0, 0};
+        int bad = no_bad;
+        if (hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            g->error = std::string("GPU decode failed: ") + hipGetErrorString(hipGetLastError());
+            return MDX_ERR_HIP;
+        }
+        if (bad != no_bad) {
+            int stv = 0;
+            (void)hipMemcpy(&stv, (const int *)g->status.p + bad, 4, hipMemcpyDeviceToHost);
+            if (stv < 0) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad) + " (inflate code " + std::to_string(stv) + ")"; return MDX_ERR_ARG; }
+            g->error = "BGZF block " + std::to_string(b0 + (size_t)bad) + " does not hold whole records";
+            return MDX_ERR_UNSUPPORTED;
+        }
+        if (tot[0] > rec_cap - 2 || tot[1] > cig_cap - 2 || tot[2] > seq_cap - 64 || tot[2] > 0xFFFFFFFFull) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
+        MdxGbamCols c{};
+        c.flag = (uint16_t *)g->flag.p; c.lib = (uint16_t *)g->lib.p; c.tid = (int32_t *)g->tid.p; c.pos = (int32_t *)g->pos.p;
+        c.tlen = (int32_t *)g->tlen.p; c.mtid = g->want_mate ? (int32_t *)g->mtid.p : nullptr; c.mpos = g->want_mate ? (int32_t *)g->mpos.p : nullptr;
+        c.cigar_off = (uint32_t *)g->cigar_off.p; c.cigar = (uint32_t *)g->cigar.p; c.seq_off = (uint32_t *)g->seq_off.p;
+        c.seq = (uint8_t *)g->seq.p; c.qual = g->want_qual ? (uint8_t *)g->qual.p : nullptr;
+        c.rg_names = (const uint8_t *)g->d_rg_names; c.rg_off = (const uint32_t *)g->d_rg_off; c.lib_of_rg = (const int32_t *)g->d_lib_of_rg;
+        c.n_rg = (int)g->lib_of_rg.size(); c.lib_default = g->lib_default;
+        mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
+                          (uint32_t)tot[0], (uint32_t *)g->rec_off.p, c, st);
+        if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
+        view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
+        view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
+        view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
+        if (d_mtid) *d_mtid = c.mtid;
+        if (d_mpos) *d_mpos = c.mpos;
+        g->next_block = b1;
+        return MDX_OK;
+    } catch (const std::exception &e) {
+        if (g) g->error = std::string("mdx_gbam_next: ") + e.what();
+        return MDX_ERR_ARG;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
+}
+
+int mdx_gbam_at_end(const mdx_gbam *g) { return (!g || g->next_block >= g->blocks.size()) ? 1 : 0; }
+
+void mdx_gbam_close(mdx_gbam *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (auto *b : g->all()) if (b->p) (void)hipFree(b->p);
+    for (void *p : {g->d_rg_names, g->d_rg_off, g->d_lib_of_rg}) if (p) (void)hipFree(p);
+    if (g->hs) mdx_bam_close(g->hs);
+    delete g;
 }
 
 }  // extern "C"

@@ -664,6 +664,13 @@ int mdx_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
 
 int mdx_table_mode(const mdx_ctx *c) { return c ? c->mode : -1; }
 
+int mdx_ctx_stream(mdx_ctx *c, void **stream, int *device) {
+    if (!c) return MDX_ERR_ARG;
+    if (stream) *stream = (void *)c->stream;
+    if (device) *device = c->cfg.device;
+    return MDX_OK;
+}
+
 int mdx_rescale_set_model(mdx_ctx *c, const uint8_t *lut, const double *term, int32_t len5p, int32_t len3p) {
     if (!c || !lut || !term || len5p < 0 || len3p < 0 || len5p + len3p > 100000) return fail(c, MDX_ERR_ARG, "rescale model");
     HIP_TRY(c, hipSetDevice(c->cfg.device));

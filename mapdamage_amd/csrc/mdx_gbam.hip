@@ -1,0 +1,232 @@
+// GPU-side BAM decode: BGZF blocks inflated and BAM records unpacked into the batch columns without
+// leaving HBM — the device counterpart of mdx_bamio.cpp, which is the counterpart of pysam.AlignmentFile behind
+// mapdamage/reader.py:20-46.  Host orchestration: mdx_gbam_* in mdx_bamio.cpp.
+//
+//   gbam_inflate_kernel   one wavefront per BGZF block (mdx_inflate.h): window and tables in the LDS (~69 KB: two
+//                         blocks per CU), output copied to HBM 16 bytes per lane
+//   gbam_scan_kernel      one lane per BGZF block: follows the chain of block_size fields (htslib starts every BGZF
+//                         block at a record: bgzf_flush_try in bam_write1), counts records, CIGAR operations, bases
+//   gbam_prefix_kernel    exclusive prefix sums of the three counts over the blocks (one workgroup)
+//   gbam_offsets_kernel   one lane per BGZF block again: record offsets and the cigar_off / seq_off columns
+//   gbam_unpack_kernel    one lane per record: fixed fields, CIGAR, 4-bit bases -> ASCII, qualities, RG:Z -> library
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdx_inflate.h"
+#include "mdx_internal.h"
+
+namespace {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+__device__ __forceinline__ u32 g16(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8); }
+__device__ __forceinline__ u32 g32(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+
+__global__ __launch_bounds__(64) void gbam_inflate_kernel(const u8 *__restrict__ comp, const uint4 *__restrict__ blk,
+                                                           u8 *__restrict__ unc, int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    u8 *const win = lds;                                                       // 64 KiB
+    mdx_inflate::Tables &t = *(mdx_inflate::Tables *)(lds + 65536);
+    const uint4 b = blk[blockIdx.x];                                           // in_off, in_size, out_off, out_size
+    const int lane = threadIdx.x;
+    int r = 0;
+    if (b.w > 0) {
+        r = mdx_inflate::inflate_block(comp + b.x, b.y, win, 65536u, t);
+        if (r >= 0 && (u32)r != b.w) r = -4;                                   // ISIZE disagrees
+    }
+    if (lane == 0) status[blockIdx.x] = r;
+    if (r <= 0) return;
+    __builtin_amdgcn_wave_barrier();
+    u8 *__restrict__ dst = unc + b.z;
+    const u32 n = (u32)r;
+    for (u32 o = 16u * (u32)lane; o < n; o += 1024u) {
+        if (o + 16u <= n) {
+            u32 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                w[k] = (u32)win[o + 4 * k] | ((u32)win[o + 4 * k + 1] << 8) | ((u32)win[o + 4 * k + 2] << 16) | ((u32)win[o + 4 * k + 3] << 24);
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+            u32x4 v = {w[0], w[1], w[2], w[3]};
+            *(u32x4_u *)(dst + o) = v;
+        } else {
+            for (u32 j = o; j < n; j++) dst[j] = win[j];
+        }
+    }
+}
+
+// cnt[b] = (records, CIGAR operations, bases, 0) of BGZF block b; status < 0: the chain of records does not end at
+// the block's end (a record straddles two blocks, or the data is not BAM)
+__global__ void gbam_scan_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk, const int *__restrict__ inflated,
+                                 int n_blocks, uint4 *__restrict__ cnt, int *__restrict__ bad) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint4 e = blk[b];
+    u32 n_rec = 0, n_cig = 0, n_seq = 0;
+    if (inflated[b] < 0) { atomicMin(bad, b); cnt[b] = make_uint4(0, 0, 0, 0); return; }
+    const u8 *__restrict__ p = unc + e.z;
+    u32 off = 0;
+    while (off + 4u <= e.w) {
+        const u32 bs = g32(p + off);
+        if (bs < 32u || bs > e.w - off - 4u) { atomicMin(bad, b); break; }
+        const u8 *r = p + off + 4;
+        const u32 l_name = r[8], n_c = g16(r + 12), l_seq = g32(r + 16);
+        if (32u + l_name + 4u * n_c + (l_seq + 1u) / 2u + l_seq > bs || l_seq > 0x7FFFFFFFu) { atomicMin(bad, b); break; }
+        n_rec++; n_cig += n_c; n_seq += l_seq;
+        off += 4u + bs;
+    }
+    if (off != e.w) atomicMin(bad, b);
+    cnt[b] = make_uint4(n_rec, n_cig, n_seq, 0);
+}
+
+// pre[b] = exclusive prefix sums of cnt over the blocks; tot = the three totals
+__global__ __launch_bounds__(1024) void gbam_prefix_kernel(const uint4 *__restrict__ cnt, int n_blocks, uint4 *__restrict__ pre,
+                                                            unsigned long long *__restrict__ tot) {
+    __shared__ unsigned long long part[3][1024];
+    const int t = threadIdx.x;
+    const int per = (n_blocks + 1023) / 1024;
+    const int lo = t * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    for (int i = lo; i < hi; i++) { const uint4 c = cnt[i]; s0 += c.x; s1 += c.y; s2 += c.z; }
+    part[0][t] = s0; part[1][t] = s1; part[2][t] = s2;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long a0 = 0, a1 = 0, a2 = 0;
+        for (int i = 0; i < 1024; i++) {
+            const unsigned long long v0 = part[0][i], v1 = part[1][i], v2 = part[2][i];
+            part[0][i] = a0; part[1][i] = a1; part[2][i] = a2;
+            a0 += v0; a1 += v1; a2 += v2;
+        }
+        tot[0] = a0; tot[1] = a1; tot[2] = a2;
+    }
+    __syncthreads();
+    unsigned long long a0 = part[0][t], a1 = part[1][t], a2 = part[2][t];
+    for (int i = lo; i < hi; i++) {
+        const uint4 c = cnt[i];
+        pre[i] = make_uint4((u32)a0, (u32)a1, (u32)a2, 0);       // (the host has checked that the totals fit 32 bits)
+        a0 += c.x; a1 += c.y; a2 += c.z;
+    }
+}
+
+// rec_off[r] = offset of record r's first field (behind block_size) in `unc`; cigar_off / seq_off: the columns
+__global__ void gbam_offsets_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk, const uint4 *__restrict__ pre,
+                                    const uint4 *__restrict__ cnt, int n_blocks, u32 *__restrict__ rec_off,
+                                    u32 *__restrict__ cigar_off, u32 *__restrict__ seq_off) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint4 e = blk[b], s = pre[b], c = cnt[b];
+    const u8 *__restrict__ p = unc + e.z;
+    u32 off = 0, r = s.x, co = s.y, so = s.z;
+    for (u32 k = 0; k < c.x; k++) {
+        const u32 bs = g32(p + off);
+        const u8 *q = p + off + 4;
+        rec_off[r] = e.z + off + 4u;
+        cigar_off[r] = co; seq_off[r] = so;
+        co += g16(q + 12); so += g32(q + 16);
+        r++;
+        off += 4u + bs;
+    }
+    if (b == n_blocks - 1) { cigar_off[r] = co; seq_off[r] = so; }     // the columns' closing entries
+}
+
+__global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__restrict__ rec_off, u32 n_rec, MdxGbamCols c) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const u8 *__restrict__ p = unc + rec_off[r];
+    const u32 bs = g32(p - 4);
+    const u32 l_name = p[8], n_cig = g16(p + 12), l_seq = g32(p + 16);
+    const u32 flag = g16(p + 14);
+    c.flag[r] = (uint16_t)flag;
+    c.tid[r] = (int32_t)g32(p); c.pos[r] = (int32_t)g32(p + 4);
+    c.tlen[r] = (int32_t)g32(p + 28);
+    if (c.mtid) { c.mtid[r] = (int32_t)g32(p + 20); c.mpos[r] = (int32_t)g32(p + 24); }
+    const u8 *q = p + 32 + l_name;
+    u32 *__restrict__ cg = c.cigar + c.cigar_off[r];
+    for (u32 k = 0; k < n_cig; k++) cg[k] = g32(q + 4 * k);
+    q += 4u * n_cig;
+    // bases: two per byte, "=ACMGRSVTWYHKDBN"
+    u8 *__restrict__ s = c.seq + c.seq_off[r];
+    // the 16 letters as two 64-bit constants (registers, no table in memory)
+    const u64 lo8 = ((u64)'=') | ((u64)'A' << 8) | ((u64)'C' << 16) | ((u64)'M' << 24) | ((u64)'G' << 32) | ((u64)'R' << 40) | ((u64)'S' << 48) | ((u64)'V' << 56);
+    const u64 hi8 = ((u64)'T') | ((u64)'W' << 8) | ((u64)'Y' << 16) | ((u64)'H' << 24) | ((u64)'K' << 32) | ((u64)'D' << 40) | ((u64)'B' << 48) | ((u64)'N' << 56);
+    for (u32 k = 0; k < l_seq; k++) {
+        const u32 byte = q[k >> 1];
+        const u32 nib = (k & 1u) ? (byte & 15u) : (byte >> 4);
+        s[k] = (u8)(((nib < 8u ? lo8 : hi8) >> (8u * (nib & 7u))) & 0xFFu);
+    }
+    q += (l_seq + 1u) / 2u;
+    if (c.qual) {
+        u8 *__restrict__ ql = c.qual + c.seq_off[r];
+        for (u32 k = 0; k < l_seq; k++) ql[k] = q[k];
+    }
+    q += l_seq;
+    // library: the RG:Z tag against the header's read groups
+    int lib = c.lib_default;
+    if (c.n_rg > 0) {
+        const u8 *end = p + bs;
+        bool found = false;
+        while (q + 3 <= end && !found) {
+            const u32 t0 = q[0], t1 = q[1], ty = q[2];
+            q += 3;
+            if (ty == 'Z' || ty == 'H') {
+                const u8 *z = q;
+                while (z < end && *z) z++;
+                if (z >= end) break;
+                if (t0 == 'R' && t1 == 'G' && ty == 'Z') {
+                    const u32 len = (u32)(z - q);
+                    lib = 0xFFFF;                        // a read group the header does not list
+                    for (int g = 0; g < c.n_rg; g++) {
+                        const u32 a0 = c.rg_off[g], a1 = c.rg_off[g + 1];
+                        if (a1 - a0 != len) continue;
+                        bool same = true;
+                        for (u32 j = 0; j < len && same; j++) same = c.rg_names[a0 + j] == q[j];
+                        if (same) { lib = c.lib_of_rg[g]; break; }
+                    }
+                    found = true;
+                }
+                q = z + 1;
+            } else if (ty == 'A' || ty == 'c' || ty == 'C') q += 1;
+            else if (ty == 's' || ty == 'S') q += 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') q += 4;
+            else if (ty == 'B') {
+                if (q + 5 > end) break;
+                const u32 sub = q[0], cntb = g32(q + 1);
+                const u32 w = (sub == 'c' || sub == 'C') ? 1u : ((sub == 's' || sub == 'S') ? 2u : 4u);
+                if ((u64)cntb * w > (u64)(end - q)) break;
+                q += 5 + cntb * w;
+            } else break;
+        }
+    }
+    c.lib[r] = (uint16_t)(lib < 0 ? 0xFFFF : lib);
+}
+
+}  // namespace
+
+size_t mdx_k_gbam_inflate_lds() { return 65536 + sizeof(mdx_inflate::Tables); }
+
+hipError_t mdx_k_gbam_prepare() {
+    return hipFuncSetAttribute((const void *)gbam_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mdx_k_gbam_inflate_lds());
+}
+
+void mdx_k_gbam_inflate(const uint8_t *comp, const uint4 *blk, int n_blocks, uint8_t *unc, int *status, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(gbam_inflate_kernel, dim3(n_blocks), dim3(64), mdx_k_gbam_inflate_lds(), s, comp, blk, unc, status);
+}
+
+void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, uint4 *cnt, uint4 *pre,
+                     unsigned long long *tot, int *bad, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(gbam_scan_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, s, unc, blk, status, n_blocks, cnt, bad);
+    hipLaunchKernelGGL(gbam_prefix_kernel, dim3(1), dim3(1024), 0, s, cnt, n_blocks, pre, tot);
+}
+
+void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *blk, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec,
+                       uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(gbam_offsets_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, s, unc, blk, pre, cnt, n_blocks, rec_off,
+                       c.cigar_off, c.seq_off);
+    if (n_rec > 0)
+        hipLaunchKernelGGL(gbam_unpack_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, s, unc, rec_off, n_rec, c);
+}

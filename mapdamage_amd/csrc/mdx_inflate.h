@@ -1,0 +1,316 @@
+// Raw DEFLATE (RFC 1951) decoder for one BGZF block — at most 64 KiB out (SAM specification 4.1) — written so
+// that the same code runs on the host (tests against zlib) and, one block per wavefront, on the GPU
+// (mdx_gbam.hip).  On the device every lane of the wavefront executes the decoder with the same values (the
+// Huffman state machine is serial by nature; it costs the same as one lane executing it), which lets the lanes
+// share the work wherever there is any: a match is copied 64 bytes at a time, the tables are filled 64 entries at a
+// time, and the compressed bytes are fetched 512 at a time (each lane holds eight of them).
+//
+// Replaces, for the GPU decode path, zlib's inflate() behind pysam.AlignmentFile (reader.py:20-46 of the
+// reference).  Not a general inflater: one block, all of its input present, output window = the block itself.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define MDX_HD __host__ __device__ __forceinline__
+#else
+#define MDX_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MDX_ON_DEVICE 1
+#else
+#define MDX_ON_DEVICE 0
+#endif
+
+namespace mdx_inflate {
+
+enum { FAST_LL = 10, FAST_D = 8 };   // bits resolved by one table lookup (longer codes: canonical walk)
+
+// Decoder tables of one block; on the device they live in the LDS (one set per wavefront).
+struct Tables {
+    uint16_t fast_ll[1 << FAST_LL];  // (symbol << 4) | code length, 0 = longer than FAST_LL bits
+    uint16_t fast_d[1 << FAST_D];
+    uint16_t count_ll[16], count_d[16];
+    uint16_t sym_ll[288], sym_d[32];
+    uint8_t lens[352];               // code lengths while a dynamic header is read: [code-length code 19][..32][literal/length + distance <= 316]
+};
+
+// lane id and width of the group that executes the decoder in lock step (1 on the host)
+MDX_HD int lane_id() {
+#if MDX_ON_DEVICE
+    return (int)(threadIdx.x & 63);
+#else
+    return 0;
+#endif
+}
+MDX_HD int lane_count() { return MDX_ON_DEVICE ? 64 : 1; }
+
+// Compressed input, consumed as a bit stream (LSB first).  Device: 512 bytes at a time are held by the lanes
+// (8 each) and handed out by readlane; host: straight from memory.
+struct BitIn {
+    const uint8_t *p;
+    uint32_t n;          // bytes of input
+    uint32_t pos;        // next byte to move into the bit buffer
+    uint64_t bits;
+    int nbits;
+#if MDX_ON_DEVICE
+    uint32_t held_lo, held_hi;   // this lane's eight bytes of the 512-byte stretch starting at `held_at`
+    uint32_t held_at;
+#endif
+    MDX_HD void init(const uint8_t *src, uint32_t len) {
+        p = src; n = len; pos = 0; bits = 0; nbits = 0;
+#if MDX_ON_DEVICE
+        held_at = 0xFFFFFFFFu; held_lo = held_hi = 0;
+#endif
+    }
+    // the eight bytes at byte offset `at` (at % 8 == 0), zero beyond the end
+    MDX_HD uint64_t word_at(uint32_t at) {
+#if MDX_ON_DEVICE
+        if ((at & ~511u) != held_at) {
+            held_at = at & ~511u;
+            const uint32_t mine = held_at + 8u * (uint32_t)lane_id();
+            uint64_t w = 0;
+            if (mine + 8u <= n) {
+                // (the block's payload starts at an arbitrary byte of the file: byte loads would cost eight
+                //  instructions; an unaligned 8-byte load is one)
+                typedef uint64_t u64u __attribute__((aligned(1)));
+                w = *(const u64u *)(p + mine);
+            } else {
+                for (uint32_t j = 0; j < 8u; j++) if (mine + j < n) w |= (uint64_t)p[mine + j] << (8 * j);
+            }
+            held_lo = (uint32_t)w; held_hi = (uint32_t)(w >> 32);
+        }
+        const int src = (int)((at & 511u) >> 3);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)held_lo, src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)held_hi, src);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+#else
+        uint64_t w = 0;
+        for (uint32_t j = 0; j < 8u; j++) if (at + j < n) w |= (uint64_t)p[at + j] << (8 * j);
+        return w;
+#endif
+    }
+    // at least 32 valid bits in `bits` afterwards (zeros beyond the end of the input)
+    MDX_HD void refill() {
+        if (nbits >= 32) return;
+        // take 4 bytes at `pos`
+        const uint32_t at = pos & ~7u, sh = (pos & 7u) * 8u;
+        uint64_t w = word_at(at) >> sh;
+        if (sh > 32u) w |= word_at(at + 8u) << (64u - sh);
+        bits |= (w & 0xFFFFFFFFull) << nbits;
+        nbits += 32;
+        pos += 4;
+    }
+    MDX_HD uint32_t peek(int k) const { return (uint32_t)(bits & ((1ull << k) - 1ull)); }
+    MDX_HD void drop(int k) { bits >>= k; nbits -= k; }
+    MDX_HD uint32_t take(int k) { const uint32_t v = peek(k); drop(k); return v; }
+    // bytes consumed so far (whole bytes still in the buffer are given back)
+    MDX_HD uint32_t consumed() const { return pos - (uint32_t)(nbits >> 3); }
+    MDX_HD bool overrun() const { return consumed() > n; }
+};
+
+MDX_HD uint32_t bitrev(uint32_t v, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; i++) r |= ((v >> i) & 1u) << (len - 1 - i);
+    return r;
+}
+
+// Canonical Huffman tables from code lengths (RFC 1951 3.2.2).  false: over-subscribed or incomplete set
+// (a single code of length 1 is accepted, as zlib does for distance codes).
+MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, uint16_t *fast, int fast_bits, bool may_be_empty = false) {
+    const int lane = lane_id(), nl = lane_count();
+    for (int i = lane; i < 16; i += nl) count[i] = 0;
+    for (int i = lane; i < (1 << fast_bits); i += nl) fast[i] = 0;
+#if MDX_ON_DEVICE
+    __builtin_amdgcn_wave_barrier();
+#endif
+    // (serial parts: every lane computes the same values; only lane 0 stores)
+    uint16_t cnt[16];
+    for (int i = 0; i < 16; i++) cnt[i] = 0;
+    for (int i = 0; i < n; i++) cnt[lens[i]]++;
+    if (cnt[0] == n) {                            // no codes at all: fine for distances (a block of literals only)
+        if (lane == 0) for (int i = 0; i < 16; i++) count[i] = 0;
+        return may_be_empty;
+    }
+    int left = 1;
+    for (int len = 1; len < 16; len++) {
+        left <<= 1;
+        left -= cnt[len];
+        if (left < 0) return false;              // over-subscribed
+    }
+    if (left > 0 && !(n - cnt[0] == 1 && cnt[1] == 1)) return false;   // incomplete
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + cnt[len]);
+    if (lane == 0) {
+        for (int i = 0; i < 16; i++) count[i] = cnt[i];
+        for (int s = 0; s < n; s++) if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
+    }
+#if MDX_ON_DEVICE
+    __builtin_amdgcn_wave_barrier();
+#endif
+    // fast table: every index whose low `len` bits are the (bit-reversed) code
+    uint32_t code = 0;
+    int first_index = 0;
+    for (int len = 1; len <= fast_bits; len++) {
+        for (int k = 0; k < cnt[len]; k++) {
+            const uint32_t rev = bitrev(code + (uint32_t)k, len);
+            const uint16_t entry = (uint16_t)((sym[first_index + k] << 4) | len);
+            for (uint32_t idx = rev + ((uint32_t)lane << len); idx < (1u << fast_bits); idx += (uint32_t)nl << len) fast[idx] = entry;
+        }
+        code = (code + cnt[len]) << 1;
+        first_index += cnt[len];
+    }
+#if MDX_ON_DEVICE
+    __builtin_amdgcn_wave_barrier();
+#endif
+    return true;
+}
+
+// one symbol; -1: invalid code
+MDX_HD int decode(BitIn &in, const uint16_t *count, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
+    in.refill();
+    const uint16_t e = fast[in.peek(fast_bits)];
+    if (e) { in.drop(e & 15); return e >> 4; }
+    // canonical walk, one bit at a time (codes longer than fast_bits: rare symbols)
+    int code = 0, first = 0, index = 0;
+    uint64_t b = in.bits;
+    for (int len = 1; len <= 15; len++) {
+        code |= (int)(b & 1); b >>= 1;
+        const int c = count[len];
+        if (code - c < first) { in.drop(len); return sym[index + (code - first)]; }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+// Inflate one raw DEFLATE stream of `in_len` bytes into `win` (capacity `cap` <= 65536 bytes: on the device an
+// LDS array, so that a match reads what the lanes have just written).  Returns the number of bytes produced, or
+// a negative code: -1 corrupt stream, -2 output beyond `cap`, -3 input exhausted.
+MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint32_t cap, Tables &t) {
+    static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    static const uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    const int lane = lane_id(), nl = lane_count();
+    BitIn in;
+    in.init(src, in_len);
+    uint32_t out = 0;
+    for (;;) {
+        in.refill();
+        const uint32_t last = in.take(1), type = in.take(2);
+        if (type == 0) {
+            in.drop(in.nbits & 7);                       // to the next byte boundary
+            in.refill();
+            const uint32_t len = in.take(16);
+            in.refill();
+            const uint32_t nlen = in.take(16);
+            if ((len ^ nlen) != 0xFFFFu) return -1;
+            const uint32_t at = in.consumed();
+            if (at + len > in_len) return -3;
+            if (out + len > cap) return -2;
+            for (uint32_t i = (uint32_t)lane; i < len; i += (uint32_t)nl) win[out + i] = src[at + i];
+            out += len;
+            in.pos = at + len; in.bits = 0; in.nbits = 0;
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {
+                for (int i = lane; i < 288; i += nl) t.lens[i] = (uint8_t)(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+                for (int i = lane; i < 32; i += nl) t.lens[288 + i] = 5;     // (30 and 31 never occur in a valid stream)
+#if MDX_ON_DEVICE
+                __builtin_amdgcn_wave_barrier();
+#endif
+                if (!build(t.lens, 288, t.count_ll, t.sym_ll, t.fast_ll, FAST_LL)) return -1;
+                if (!build(t.lens + 288, 32, t.count_d, t.sym_d, t.fast_d, FAST_D)) return -1;
+            } else {
+                in.refill();
+                const int nlen = (int)in.take(5) + 257, ndist = (int)in.take(5) + 1, ncode = (int)in.take(4) + 4;
+                if (nlen > 286 || ndist > 30) return -1;
+                for (int i = lane; i < 19; i += nl) t.lens[i] = 0;
+#if MDX_ON_DEVICE
+                __builtin_amdgcn_wave_barrier();
+#endif
+                for (int i = 0; i < ncode; i++) {
+                    in.refill();
+                    const uint32_t v = in.take(3);
+                    if (lane == 0) t.lens[ORDER[i]] = (uint8_t)v;
+                }
+#if MDX_ON_DEVICE
+                __builtin_amdgcn_wave_barrier();
+#endif
+                // the code-length code shares the distance tables' storage until those are built
+                if (!build(t.lens, 19, t.count_d, t.sym_d, t.fast_d, 7)) return -1;
+#if MDX_ON_DEVICE
+                __builtin_amdgcn_wave_barrier();
+#endif
+                int i = 0;
+                while (i < nlen + ndist) {
+                    int s = decode(in, t.count_d, t.sym_d, t.fast_d, 7);
+                    if (s < 0) return -1;
+                    if (s < 16) { if (lane == 0) t.lens[32 + i] = (uint8_t)s; i++; continue; }
+                    int prev = 0, rep;
+                    in.refill();
+                    if (s == 16) {
+                        if (i == 0) return -1;
+#if MDX_ON_DEVICE
+                        __builtin_amdgcn_wave_barrier();
+#endif
+                        prev = t.lens[32 + i - 1];
+                        rep = 3 + (int)in.take(2);
+                    } else if (s == 17) rep = 3 + (int)in.take(3);
+                    else rep = 11 + (int)in.take(7);
+                    if (i + rep > nlen + ndist) return -1;
+                    for (int k = lane; k < rep; k += nl) t.lens[32 + i + k] = (uint8_t)prev;
+                    i += rep;
+                }
+#if MDX_ON_DEVICE
+                __builtin_amdgcn_wave_barrier();
+#endif
+                if (t.lens[32 + 256] == 0) return -1;    // no end-of-block code
+                if (!build(t.lens + 32, nlen, t.count_ll, t.sym_ll, t.fast_ll, FAST_LL)) return -1;
+                if (!build(t.lens + 32 + nlen, ndist, t.count_d, t.sym_d, t.fast_d, FAST_D, true)) return -1;
+            }
+#if MDX_ON_DEVICE
+            __builtin_amdgcn_wave_barrier();
+#endif
+            for (;;) {
+                int s = decode(in, t.count_ll, t.sym_ll, t.fast_ll, FAST_LL);
+                if (s < 0) return -1;
+                if (s < 256) {
+                    if (out >= cap) return -2;
+                    if (lane == 0) win[out] = (uint8_t)s;
+                    out++;
+                    continue;
+                }
+                if (s == 256) break;
+                s -= 257;
+                if (s >= 29) return -1;
+                in.refill();
+                const uint32_t len = LBASE[s] + in.take(LEXT[s]);
+                const int ds = decode(in, t.count_d, t.sym_d, t.fast_d, FAST_D);
+                if (ds < 0 || ds >= 30) return -1;
+                in.refill();
+                const uint32_t dist = DBASE[ds] + in.take(DEXT[ds]);
+                if (dist > out) return -1;
+                if (out + len > cap) return -2;
+#if MDX_ON_DEVICE
+                __builtin_amdgcn_wave_barrier();       // the literals lane 0 has written are there for every lane
+                // byte i of the match is byte (i mod dist) of the `dist` bytes in front of it
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win[out + i] = win[out - dist + (i % dist)];
+                __builtin_amdgcn_wave_barrier();
+#else
+                for (uint32_t i = 0; i < len; i++) win[out + i] = win[out - dist + i];
+#endif
+                out += len;
+                if (in.overrun()) return -3;
+            }
+        } else {
+            return -1;
+        }
+        if (in.overrun()) return -3;
+        if (last) break;
+    }
+    return (int)out;
+}
+
+}  // namespace mdx_inflate

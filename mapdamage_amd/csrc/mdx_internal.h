@@ -184,3 +184,25 @@ struct MdxRescaleArgs {
 void mdx_k_rescale(const MdxRescaleArgs &a, int n_cu, hipStream_t s);
 size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu);
 void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *cap);
+
+// ---- GPU-side BAM decode (mdx_gbam.hip; host side: mdx_gbam_* in mdx_bamio.cpp)
+struct MdxGbamCols {
+    uint16_t *flag, *lib;
+    int32_t *tid, *pos, *tlen, *mtid, *mpos;     // mtid / mpos may be null
+    uint32_t *cigar_off, *cigar, *seq_off;
+    uint8_t *seq, *qual;                         // qual may be null (not wanted)
+    // read groups of the header: names concatenated, rg_off[n_rg + 1], library of each; lib_default: library of a
+    // record without RG tag (-1: none -> 0xFFFF, which the tabulation kernel reports if the record is counted)
+    const uint8_t *rg_names;
+    const uint32_t *rg_off;
+    const int32_t *lib_of_rg;
+    int n_rg, lib_default;
+};
+size_t mdx_k_gbam_inflate_lds();
+hipError_t mdx_k_gbam_prepare();
+// blk[b] = (payload offset in comp, payload bytes, offset in unc, bytes out)
+void mdx_k_gbam_inflate(const uint8_t *comp, const uint4 *blk, int n_blocks, uint8_t *unc, int *status, hipStream_t s);
+void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, uint4 *cnt, uint4 *pre,
+                     unsigned long long *tot, int *bad, hipStream_t s);
+void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *blk, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec,
+                       uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s);

@@ -31,6 +31,8 @@ EXPORTS = (
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
     "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled", "mdx_bam_qmin",
+    "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
+    "mdx_gbam_at_end", "mdx_gbam_close",
 )
 
 
@@ -110,6 +112,17 @@ def load_library(path=None):
     lib.mdx_bam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.mdx_bam_close.restype = None
     lib.mdx_bam_close.argtypes = [ctypes.c_void_p]
+    lib.mdx_gbam_open.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+    lib.mdx_gbam_header.restype = ctypes.c_void_p
+    lib.mdx_gbam_header.argtypes = [ctypes.c_void_p]
+    lib.mdx_gbam_error.restype = ctypes.c_char_p
+    lib.mdx_gbam_error.argtypes = [ctypes.c_void_p]
+    lib.mdx_gbam_configure.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                       ctypes.c_int, ctypes.c_int]
+    lib.mdx_gbam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mdx_gbam_at_end.argtypes = [ctypes.c_void_p]
+    lib.mdx_gbam_close.restype = None
+    lib.mdx_gbam_close.argtypes = [ctypes.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -229,6 +242,10 @@ class DamageEngine:
             # host columns may be released once the staged copies are enqueued and done; a record the
             # reference cannot process surfaces here, with its index within this batch
             self.sync()
+
+    def tabulate_view(self, view):
+        """An ``MdxBatch`` of device pointers (``sam.GpuBamStream.next_view``): enqueued, errors at ``sync``."""
+        self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(view)))
 
     def tabulate_pointers(self, n_reads, n_cigar, n_bases, **ptrs):
         """Device pointers owned by the caller (e.g. torch tensors): zero-copy entry."""

@@ -364,6 +364,74 @@ def read_bam_native(path, threads=None):
     return _native_alignments(lib, handle, owner)
 
 
+class GpuBamStream:
+    """GPU-side decode of a BAM file (include/mdx.h ``mdx_gbam_*``): the compressed file goes to HBM a slab of BGZF
+    blocks at a time and is inflated and unpacked there; ``next_view`` returns an ``MdxBatch`` of DEVICE pointers for
+    ``DamageEngine.tabulate_view`` (valid until the next call), or None at the end of the file.  ``readgroups``: the
+    header's read-group ids with the library index of each; ``lib_default``: library of a record without RG tag
+    (None: such a record is an error when it is counted).  Raises ``GpuDecodeUnsupported`` for a file whose BGZF blocks
+    do not start at records — the caller then decodes on the host (``BamStream``)."""
+
+    def __init__(self, engine, path, readgroups=(), lib_default=None, chunk_bytes=256 << 20, want_qual=False,
+                 want_mate=False):
+        import ctypes
+        self._lib = engine._lib
+        self._engine = engine
+        self._g = ctypes.c_void_p()
+        self.path, self.chunk_bytes = path, int(chunk_bytes)
+        rc = self._lib.mdx_gbam_open(engine._ctx, str(path).encode(), ctypes.byref(self._g))
+        if rc != 0:
+            message = self._error()
+            self.close()
+            if rc == -8:
+                raise GpuDecodeUnsupported("%r: %s" % (str(path), message))
+            raise ValueError("%r: %s" % (str(path), message))
+        self.header = _native_header(self._lib, self._lib.mdx_gbam_header(self._g))
+        ids = [str(rg).encode() for rg, _ in readgroups]
+        arr = (ctypes.c_char_p * max(1, len(ids)))(*ids)
+        libs = (ctypes.c_int32 * max(1, len(ids)))(*[int(lib) for _, lib in readgroups])
+        rc = self._lib.mdx_gbam_configure(self._g, len(ids), arr, libs, -1 if lib_default is None else int(lib_default),
+                                          int(bool(want_qual)), int(bool(want_mate)))
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(path), self._error()))
+
+    def _error(self):
+        return self._lib.mdx_gbam_error(self._g).decode() if self._g else "GPU BAM decode failed"
+
+    def next_view(self):
+        import ctypes
+        from .engine import MdxBatch
+        view = MdxBatch()
+        mtid, mpos = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = self._lib.mdx_gbam_next(self._g, self.chunk_bytes, ctypes.byref(view), ctypes.byref(mtid), ctypes.byref(mpos))
+        if rc == -8:
+            raise GpuDecodeUnsupported("%r: %s" % (str(self.path), self._error()))
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
+        if view.n_reads == 0 and self._lib.mdx_gbam_at_end(self._g):
+            return None
+        view.mtid, view.mpos = mtid.value, mpos.value       # (python attributes: not fields of the C struct)
+        return view
+
+    def close(self):
+        if self._g:
+            self._lib.mdx_gbam_close(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+class GpuDecodeUnsupported(ValueError):
+    """The file's layout is not one the GPU decode path takes (MDX_ERR_UNSUPPORTED)."""
+
+
 class BamStream:
     """Chunked form of ``read_bam_native`` (include/mdx.h ``mdx_bam_open`` / ``mdx_bam_next``): iterating yields
     ``Alignments`` of consecutive records, at most ``chunk_bytes`` of uncompressed BAM data each, so host memory stays

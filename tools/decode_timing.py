@@ -23,7 +23,7 @@ with tempfile.TemporaryDirectory() as tmp:
     path = os.path.join(tmp, "c3.bam")
     sam.write_bam(path, batch, ref.names, ref.lengths, [{"ID": "rg1", "SM": "synthetic", "LB": "lib1"}],
                   rg_of_record=["rg1"] * n)
-    for threads in (64, 32):
+    for threads in (int(os.environ.get("MDX_THREADS", "64")), 32):
         t = time.perf_counter()
         al = sam.read_bam_native(path, threads=threads)
         print("whole file, threads %d: total %.1f ms (%d records)" % (threads, 1e3 * (time.perf_counter() - t), al.batch.n), file=sys.stderr)
