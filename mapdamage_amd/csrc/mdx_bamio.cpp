@@ -856,6 +856,16 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         if (d_mpos) *d_mpos = nullptr;
         if (g->next_block >= g->blocks.size()) return MDX_OK;             // end of file: an empty view
         if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+        // MDX_BAM_TIMING=1: stage times on stderr (each lap waits for the stream)
+        const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            (void)hipStreamSynchronize(g->stream);
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "mdx_gbam_next %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
         // the slab: blocks [b0, b1), about `want` compressed bytes, less than 4 GiB inflated
         const size_t b0 = g->next_block;
@@ -888,6 +898,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             (g->want_mate && (!g->reserve(g->mtid, rec_cap * 4) || !g->reserve(g->mpos, rec_cap * 4))))
             return MDX_ERR_HIP;
         hipStream_t st = g->stream;
+        lap("allocate");
         // the previous slab's columns may still be read by the tabulation kernel
         if (hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
         if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -896,9 +907,12 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         int *d_bad = (int *)((char *)g->small.p + 32);
         const int no_bad = 0x7FFFFFFF;
         (void)hipMemcpyAsync(d_bad, &no_bad, 4, hipMemcpyHostToDevice, st);
+        lap("upload");
         mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nb, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        lap("inflate");
         mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)nb, (uint4 *)g->cnt.p,
                         (uint4 *)g->pre.p, d_tot, d_bad, st);
+        lap("scan");
         unsigned long long tot[3] = {0, 0, 0};
         int bad = no_bad;
         if (hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -924,6 +938,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
                           (uint32_t)tot[0], (uint32_t *)g->rec_off.p, c, st);
         if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
+        lap("unpack");
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
         view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
         view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;

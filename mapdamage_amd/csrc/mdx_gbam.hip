@@ -2,8 +2,8 @@
 // leaving HBM — the device counterpart of mdx_bamio.cpp, which is the counterpart of pysam.AlignmentFile behind
 // mapdamage/reader.py:20-46.  Host orchestration: mdx_gbam_* in mdx_bamio.cpp.
 //
-//   gbam_inflate_kernel   one wavefront per BGZF block (mdx_inflate.h): window and tables in the LDS (~69 KB: two
-//                         blocks per CU), output copied to HBM 16 bytes per lane
+//   gbam_inflate_kernel   one wavefront per BGZF block (mdx_inflate.h): 32 KiB window and tables in the LDS (~36 KB:
+//                         four blocks per CU, one per SIMD), output written to HBM 16 KiB at a time, 16 bytes per lane
 //   gbam_scan_kernel      one lane per BGZF block: follows the chain of block_size fields (htslib starts every BGZF
 //                         block at a record: bgzf_flush_try in bam_write1), counts records, CIGAR operations, bases
 //   gbam_prefix_kernel    exclusive prefix sums of the three counts over the blocks (one workgroup)
@@ -27,34 +27,16 @@ __device__ __forceinline__ u32 g32(const u8 *p) { return (u32)p[0] | ((u32)p[1] 
 __global__ __launch_bounds__(64) void gbam_inflate_kernel(const u8 *__restrict__ comp, const uint4 *__restrict__ blk,
                                                            u8 *__restrict__ unc, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    u8 *const win = lds;                                                       // 64 KiB
-    mdx_inflate::Tables &t = *(mdx_inflate::Tables *)(lds + 65536);
+    u8 *const win = lds;                                                       // the 32 KiB window
+    mdx_inflate::Tables &t = *(mdx_inflate::Tables *)(lds + mdx_inflate::RING);
     const uint4 b = blk[blockIdx.x];                                           // in_off, in_size, out_off, out_size
-    const int lane = threadIdx.x;
     int r = 0;
     if (b.w > 0) {
-        r = mdx_inflate::inflate_block(comp + b.x, b.y, win, 65536u, t);
+        // (the output leaves the window for HBM 16 KiB at a time; b.w <= 65536 was checked on the host)
+        r = mdx_inflate::inflate_block(comp + b.x, b.y, win, unc + b.z, b.w, t);
         if (r >= 0 && (u32)r != b.w) r = -4;                                   // ISIZE disagrees
     }
-    if (lane == 0) status[blockIdx.x] = r;
-    if (r <= 0) return;
-    __builtin_amdgcn_wave_barrier();
-    u8 *__restrict__ dst = unc + b.z;
-    const u32 n = (u32)r;
-    for (u32 o = 16u * (u32)lane; o < n; o += 1024u) {
-        if (o + 16u <= n) {
-            u32 w[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                w[k] = (u32)win[o + 4 * k] | ((u32)win[o + 4 * k + 1] << 8) | ((u32)win[o + 4 * k + 2] << 16) | ((u32)win[o + 4 * k + 3] << 24);
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            typedef u32x4 __attribute__((aligned(1))) u32x4_u;
-            u32x4 v = {w[0], w[1], w[2], w[3]};
-            *(u32x4_u *)(dst + o) = v;
-        } else {
-            for (u32 j = o; j < n; j++) dst[j] = win[j];
-        }
-    }
+    if (threadIdx.x == 0) status[blockIdx.x] = r;
 }
 
 // cnt[b] = (records, CIGAR operations, bases, 0) of BGZF block b; status < 0: the chain of records does not end at
@@ -204,7 +186,7 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
 
 }  // namespace
 
-size_t mdx_k_gbam_inflate_lds() { return 65536 + sizeof(mdx_inflate::Tables); }
+size_t mdx_k_gbam_inflate_lds() { return mdx_inflate::RING + sizeof(mdx_inflate::Tables); }
 
 hipError_t mdx_k_gbam_prepare() {
     return hipFuncSetAttribute((const void *)gbam_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mdx_k_gbam_inflate_lds());

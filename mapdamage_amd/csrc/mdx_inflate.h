@@ -16,6 +16,12 @@
 #define MDX_HD inline
 #endif
 
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define MDX_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define MDX_NOINLINE __attribute__((noinline))
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MDX_ON_DEVICE 1
 #else
@@ -23,6 +29,16 @@
 #endif
 
 namespace mdx_inflate {
+
+// A value every lane of the wavefront holds alike, told to the compiler: what follows from it is computed once, on
+// the scalar unit, instead of 64 times over on the vector unit (the decoder's state is such a value throughout).
+MDX_HD uint32_t uni(uint32_t v) {
+#if MDX_ON_DEVICE
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
 
 enum { FAST_LL = 10, FAST_D = 8 };   // bits resolved by one table lookup (longer codes: canonical walk)
 
@@ -45,8 +61,30 @@ MDX_HD int lane_id() {
 }
 MDX_HD int lane_count() { return MDX_ON_DEVICE ? 64 : 1; }
 
+
+// eight bytes at byte offset `at` of the n input bytes, zero beyond the end
+MDX_HD uint64_t load8(const uint8_t *p, uint32_t n, uint32_t at) {
+    if (at + 8u <= n) {
+        // (a block's payload starts at an arbitrary byte of the file: an unaligned 8-byte load is one instruction)
+        typedef uint64_t u64u __attribute__((aligned(1)));
+        return *(const u64u *)(p + at);
+    }
+    uint64_t w = 0;
+    for (uint32_t j = 0; j < 8u; j++) if (at + j < n) w |= (uint64_t)p[at + j] << (8 * j);
+    return w;
+}
+struct Held { uint32_t lo, hi, nlo, nhi; };
+#if MDX_ON_DEVICE
+MDX_HD Held fetch(const uint8_t *p, uint32_t n, uint32_t stretch) {
+    const uint64_t w = load8(p, n, stretch + 8u * (uint32_t)lane_id()), x = load8(p, n, stretch + 512u);
+    Held h;
+    h.lo = (uint32_t)w; h.hi = (uint32_t)(w >> 32); h.nlo = (uint32_t)x; h.nhi = (uint32_t)(x >> 32);
+    return h;
+}
+#endif
+
 // Compressed input, consumed as a bit stream (LSB first).  Device: 512 bytes at a time are held by the lanes
-// (8 each) and handed out by readlane; host: straight from memory.
+// (8 each, plus the 8 bytes behind them in every lane) and handed out by readlane; host: straight from memory.
 struct BitIn {
     const uint8_t *p;
     uint32_t n;          // bytes of input
@@ -55,51 +93,49 @@ struct BitIn {
     int nbits;
 #if MDX_ON_DEVICE
     uint32_t held_lo, held_hi;   // this lane's eight bytes of the 512-byte stretch starting at `held_at`
+    uint32_t next_lo, next_hi;   // the eight bytes behind the stretch (the same in every lane)
     uint32_t held_at;
 #endif
     MDX_HD void init(const uint8_t *src, uint32_t len) {
         p = src; n = len; pos = 0; bits = 0; nbits = 0;
 #if MDX_ON_DEVICE
-        held_at = 0xFFFFFFFFu; held_lo = held_hi = 0;
+        held_at = 0xFFFFFFFFu; held_lo = held_hi = next_lo = next_hi = 0;
 #endif
     }
-    // the eight bytes at byte offset `at` (at % 8 == 0), zero beyond the end
+#if MDX_ON_DEVICE
+    // (one call every 512 bytes of input: kept out of line — by value, so that the reader's state stays in
+    //  registers — and the decoder's loops stay small)
+    MDX_HD void reload(uint32_t at) {
+        held_at = at & ~511u;
+        const Held h = fetch(p, n, held_at);
+        held_lo = h.lo; held_hi = h.hi; next_lo = h.nlo; next_hi = h.nhi;
+    }
+#endif
+    // the eight bytes at byte offset `at` (at % 8 == 0) of the stretch held, or right behind it
     MDX_HD uint64_t word_at(uint32_t at) {
 #if MDX_ON_DEVICE
-        if ((at & ~511u) != held_at) {
-            held_at = at & ~511u;
-            const uint32_t mine = held_at + 8u * (uint32_t)lane_id();
-            uint64_t w = 0;
-            if (mine + 8u <= n) {
-                // (the block's payload starts at an arbitrary byte of the file: byte loads would cost eight
-                //  instructions; an unaligned 8-byte load is one)
-                typedef uint64_t u64u __attribute__((aligned(1)));
-                w = *(const u64u *)(p + mine);
-            } else {
-                for (uint32_t j = 0; j < 8u; j++) if (mine + j < n) w |= (uint64_t)p[mine + j] << (8 * j);
-            }
-            held_lo = (uint32_t)w; held_hi = (uint32_t)(w >> 32);
-        }
-        const int src = (int)((at & 511u) >> 3);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)held_lo, src);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)held_hi, src);
+        const uint32_t k = (at - held_at) >> 3;                  // 0 .. 64
+        const int src = (int)(k & 63u);
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)held_lo, src);
+        uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)held_hi, src);
+        if (k == 64u) { lo = uni(next_lo); hi = uni(next_hi); }
         return (uint64_t)lo | ((uint64_t)hi << 32);
 #else
-        uint64_t w = 0;
-        for (uint32_t j = 0; j < 8u; j++) if (at + j < n) w |= (uint64_t)p[at + j] << (8 * j);
-        return w;
+        return load8(p, n, at);
 #endif
     }
-    // at least 32 valid bits in `bits` afterwards (zeros beyond the end of the input)
+    // 56 .. 63 valid bits in `bits` afterwards (zeros beyond the end of the input): enough for a literal/length
+    // code, its extra bits, a distance code and its extra bits (48) without another look
     MDX_HD void refill() {
-        if (nbits >= 32) return;
-        // take 4 bytes at `pos`
+#if MDX_ON_DEVICE
+        if ((pos & ~511u) != held_at) reload(pos);
+#endif
         const uint32_t at = pos & ~7u, sh = (pos & 7u) * 8u;
         uint64_t w = word_at(at) >> sh;
-        if (sh > 32u) w |= word_at(at + 8u) << (64u - sh);
-        bits |= (w & 0xFFFFFFFFull) << nbits;
-        nbits += 32;
-        pos += 4;
+        if (sh) w |= word_at(at + 8u) << (64u - sh);
+        bits |= w << nbits;                       // (bits beyond nbits + 8 k are the input's next ones: or-ed in again later)
+        pos += (uint32_t)(63 - nbits) >> 3;
+        nbits |= 56;
     }
     MDX_HD uint32_t peek(int k) const { return (uint32_t)(bits & ((1ull << k) - 1ull)); }
     MDX_HD void drop(int k) { bits >>= k; nbits -= k; }
@@ -127,7 +163,7 @@ MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, ui
     // (serial parts: every lane computes the same values; only lane 0 stores)
     uint16_t cnt[16];
     for (int i = 0; i < 16; i++) cnt[i] = 0;
-    for (int i = 0; i < n; i++) cnt[lens[i]]++;
+    for (int i = 0; i < n; i++) cnt[uni(lens[i])]++;
     if (cnt[0] == n) {                            // no codes at all: fine for distances (a block of literals only)
         if (lane == 0) for (int i = 0; i < 16; i++) count[i] = 0;
         return may_be_empty;
@@ -144,7 +180,7 @@ MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, ui
     for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + cnt[len]);
     if (lane == 0) {
         for (int i = 0; i < 16; i++) count[i] = cnt[i];
-        for (int s = 0; s < n; s++) if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
+        for (int s = 0; s < n; s++) { const uint32_t l = uni(lens[s]); if (l) sym[offs[l]++] = (uint16_t)s; }
     }
 #if MDX_ON_DEVICE
     __builtin_amdgcn_wave_barrier();
@@ -155,7 +191,7 @@ MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, ui
     for (int len = 1; len <= fast_bits; len++) {
         for (int k = 0; k < cnt[len]; k++) {
             const uint32_t rev = bitrev(code + (uint32_t)k, len);
-            const uint16_t entry = (uint16_t)((sym[first_index + k] << 4) | len);
+            const uint16_t entry = (uint16_t)((uni(sym[first_index + k]) << 4) | (uint32_t)len);
             for (uint32_t idx = rev + ((uint32_t)lane << len); idx < (1u << fast_bits); idx += (uint32_t)nl << len) fast[idx] = entry;
         }
         code = (code + cnt[len]) << 1;
@@ -169,25 +205,49 @@ MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, ui
 
 // one symbol; -1: invalid code
 MDX_HD int decode(BitIn &in, const uint16_t *count, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
-    in.refill();
-    const uint16_t e = fast[in.peek(fast_bits)];
-    if (e) { in.drop(e & 15); return e >> 4; }
+    const uint32_t e = uni(fast[in.peek(fast_bits)]);
+    if (e) { in.drop((int)(e & 15u)); return (int)(e >> 4); }
     // canonical walk, one bit at a time (codes longer than fast_bits: rare symbols)
     int code = 0, first = 0, index = 0;
     uint64_t b = in.bits;
     for (int len = 1; len <= 15; len++) {
         code |= (int)(b & 1); b >>= 1;
-        const int c = count[len];
-        if (code - c < first) { in.drop(len); return sym[index + (code - first)]; }
+        const int c = (int)uni(count[len]);
+        if (code - c < first) { in.drop(len); return (int)uni(sym[index + (code - first)]); }
         index += c; first += c; first <<= 1; code <<= 1;
     }
     return -1;
 }
 
-// Inflate one raw DEFLATE stream of `in_len` bytes into `win` (capacity `cap` <= 65536 bytes: on the device an
-// LDS array, so that a match reads what the lanes have just written).  Returns the number of bytes produced, or
-// a negative code: -1 corrupt stream, -2 output beyond `cap`, -3 input exhausted.
-MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint32_t cap, Tables &t) {
+enum { RING = 32768, SEG = 16384 };   // the window (RFC 1951: distances up to 32 KiB) and the stretch written out at a time
+
+// bytes [from, to) of the output, which the ring still holds, to `dst`
+MDX_HD void flush(const uint8_t *win, uint8_t *dst, uint32_t from, uint32_t to) {
+#if MDX_ON_DEVICE
+    __builtin_amdgcn_wave_barrier();
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+    for (uint32_t o = from + 16u * (uint32_t)lane_id(); o < to; o += 1024u) {
+        if (o + 16u <= to) {
+            // (from is a multiple of SEG: the 16 bytes do not wrap around the ring; LDS reads of 4 aligned bytes)
+            const uint32_t *w = (const uint32_t *)(win + (o & (RING - 1)));
+            const u32x4 v = {w[0], w[1], w[2], w[3]};
+            *(u32x4_u *)(dst + o) = v;
+        } else {
+            for (uint32_t j = o; j < to; j++) dst[j] = win[j & (RING - 1)];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#else
+    for (uint32_t j = from; j < to; j++) dst[j] = win[j & (RING - 1)];
+#endif
+}
+
+// Inflate one raw DEFLATE stream of `in_len` bytes to `dst` (capacity `cap` <= 65536 bytes).  `win`: RING bytes —
+// on the device in the LDS, so that a match reads what the lanes have just written; the output leaves it SEG bytes
+// at a time.  Returns the number of bytes produced, or a negative code: -1 corrupt stream, -2 output beyond `cap`,
+// -3 input exhausted (dst then holds a part of the output).
+MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint8_t *dst, uint32_t cap, Tables &t) {
     static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -196,7 +256,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
     const int lane = lane_id(), nl = lane_count();
     BitIn in;
     in.init(src, in_len);
-    uint32_t out = 0;
+    uint32_t out = 0, flushed = 0;           // bytes produced; bytes already written to dst (a multiple of SEG)
     for (;;) {
         in.refill();
         const uint32_t last = in.take(1), type = in.take(2);
@@ -210,7 +270,11 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
             const uint32_t at = in.consumed();
             if (at + len > in_len) return -3;
             if (out + len > cap) return -2;
-            for (uint32_t i = (uint32_t)lane; i < len; i += (uint32_t)nl) win[out + i] = src[at + i];
+            // (a stored stretch can be longer than the ring: out to dst directly, and into the ring for later matches;
+            //  what the ring alone holds so far goes out first)
+            if (out > flushed) flush(win, dst, flushed, out);
+            for (uint32_t i = (uint32_t)lane; i < len; i += (uint32_t)nl) { const uint8_t v = src[at + i]; win[(out + i) & (RING - 1)] = v; dst[out + i] = v; }
+            flushed = (out + len) & ~(uint32_t)(SEG - 1);
             out += len;
             in.pos = at + len; in.bits = 0; in.nbits = 0;
         } else if (type == 1 || type == 2) {
@@ -245,17 +309,17 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #endif
                 int i = 0;
                 while (i < nlen + ndist) {
+                    in.refill();
                     int s = decode(in, t.count_d, t.sym_d, t.fast_d, 7);
                     if (s < 0) return -1;
                     if (s < 16) { if (lane == 0) t.lens[32 + i] = (uint8_t)s; i++; continue; }
                     int prev = 0, rep;
-                    in.refill();
                     if (s == 16) {
                         if (i == 0) return -1;
 #if MDX_ON_DEVICE
                         __builtin_amdgcn_wave_barrier();
 #endif
-                        prev = t.lens[32 + i - 1];
+                        prev = (int)uni(t.lens[32 + i - 1]);
                         rep = 3 + (int)in.take(2);
                     } else if (s == 17) rep = 3 + (int)in.take(3);
                     else rep = 11 + (int)in.take(7);
@@ -274,34 +338,43 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
             __builtin_amdgcn_wave_barrier();
 #endif
             for (;;) {
+                in.refill();               // 56 bits: the whole symbol pair below needs at most 48
                 int s = decode(in, t.count_ll, t.sym_ll, t.fast_ll, FAST_LL);
                 if (s < 0) return -1;
                 if (s < 256) {
                     if (out >= cap) return -2;
-                    if (lane == 0) win[out] = (uint8_t)s;
+                    win[out & (RING - 1)] = (uint8_t)s;  // (every lane stores the same byte: cheaper than masking 63 off)
                     out++;
+                    if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                     continue;
                 }
                 if (s == 256) break;
                 s -= 257;
                 if (s >= 29) return -1;
-                in.refill();
                 const uint32_t len = LBASE[s] + in.take(LEXT[s]);
                 const int ds = decode(in, t.count_d, t.sym_d, t.fast_d, FAST_D);
                 if (ds < 0 || ds >= 30) return -1;
-                in.refill();
                 const uint32_t dist = DBASE[ds] + in.take(DEXT[ds]);
                 if (dist > out) return -1;
                 if (out + len > cap) return -2;
 #if MDX_ON_DEVICE
-                __builtin_amdgcn_wave_barrier();       // the literals lane 0 has written are there for every lane
-                // byte i of the match is byte (i mod dist) of the `dist` bytes in front of it
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win[out + i] = win[out - dist + (i % dist)];
+                __builtin_amdgcn_wave_barrier();
+                if (dist >= 64u) {
+                    // 64 bytes at a time: their sources lie in front of the stretch being written
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
+                        win[(out + i) & (RING - 1)] = win[(out - dist + i) & (RING - 1)];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    // a short period: byte i of the match is byte (i mod dist) of the `dist` bytes in front of it
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win[(out + i) & (RING - 1)] = win[(out - dist + (i % dist)) & (RING - 1)];
+                }
                 __builtin_amdgcn_wave_barrier();
 #else
-                for (uint32_t i = 0; i < len; i++) win[out + i] = win[out - dist + i];
+                for (uint32_t i = 0; i < len; i++) win[(out + i) & (RING - 1)] = win[(out - dist + i) & (RING - 1)];
 #endif
                 out += len;
+                if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                 if (in.overrun()) return -3;
             }
         } else {
@@ -310,6 +383,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
         if (in.overrun()) return -3;
         if (last) break;
     }
+    if (out > flushed) flush(win, dst, flushed, out);
     return (int)out;
 }
 

@@ -8,7 +8,7 @@
 #include "mdx_inflate.h"
 
 int main() {
-    std::vector<uint8_t> in, want, got(65536);
+    std::vector<uint8_t> in, want, got(65536), ring(mdx_inflate::RING);
     static mdx_inflate::Tables t;
     long n = 0, bad = 0;
     for (;;) {
@@ -18,7 +18,7 @@ int main() {
         in.resize(hdr[0]); want.resize(expect_error ? 0 : hdr[1]);
         if (hdr[0] && fread(in.data(), 1, hdr[0], stdin) != hdr[0]) return 2;
         if (!want.empty() && fread(want.data(), 1, want.size(), stdin) != want.size()) return 2;
-        const int r = mdx_inflate::inflate_block(in.data(), hdr[0], got.data(), 65536, t);
+        const int r = mdx_inflate::inflate_block(in.data(), hdr[0], ring.data(), got.data(), 65536, t);
         n++;
         if (expect_error) {
             // random bytes: whatever zlib makes of them (a few are valid streams)

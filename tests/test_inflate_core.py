@@ -24,6 +24,9 @@ def test_inflate_core_agrees_with_zlib(tmp_path):
     datas = [b"", b"a", b"abc" * 1000, bytes(rnd.getrandbits(8) for _ in range(60000)),
              bytes(rnd.choice(b"ACGT") for _ in range(65536)), b"\x00" * 65536, os.urandom(100),
              bytes(rnd.choice(b"ACGTN!#$%&'()*+,-./0123456789") for _ in range(30000))]
+    # one stream, several deflate blocks of different kinds (a stored one behind compressed ones and the other way round)
+    datas.append(b"ACGT" * 3000 + os.urandom(30000) + b"TTTTGGGG" * 2000)
+    datas.append(os.urandom(20000) + bytes(rnd.choice(b"ACGT") for _ in range(40000)))
     blob = bytearray()
     n = 0
     for d in datas:

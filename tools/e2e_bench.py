@@ -65,17 +65,39 @@ def main():
                 got_s = eng.finish()
                 t6 = time.perf_counter()
                 streamed[chunk_mb] = (t6 - t5, n_chunks, got_s)
+            # the same file decoded on the GPU (mdx_gbam_*): compressed bytes to HBM, inflate + unpack + tabulation there
+            gpu = {}
+            for chunk_mb in (64, 256):
+                eng.reset()
+                eng.sync()
+                t7 = time.perf_counter()
+                n_chunks = 0
+                with sam.GpuBamStream(eng, path, readgroups=[("rg1", 0)], chunk_bytes=chunk_mb << 20) as g:
+                    while True:
+                        view = g.next_view()
+                        if view is None:
+                            break
+                        n_chunks += 1
+                        eng.tabulate_view(view)
+                    got_g = eng.finish()
+                t8 = time.perf_counter()
+                gpu[chunk_mb] = (t8 - t7, n_chunks, got_g)
     want = oracle.tabulate(ref, batch, 1, 70, 10, 0, 65536)
     ok = (np.array_equal(got.mis, want["mis"]) and np.array_equal(got.comp, want["comp"]) and got.n_kept == want["n_kept"])
     for chunk_mb, (_, _, got_s) in streamed.items():
         ok = ok and np.array_equal(got_s.mis, want["mis"]) and np.array_equal(got_s.comp, want["comp"]) \
             and np.array_equal(got_s.lgd, got.lgd) and got_s.n_kept == want["n_kept"]
+    for chunk_mb, (_, _, got_g) in gpu.items():
+        ok = ok and np.array_equal(got_g.mis, want["mis"]) and np.array_equal(got_g.comp, want["comp"]) \
+            and np.array_equal(got_g.lgd, got.lgd) and got_g.n_kept == want["n_kept"]
     print(json.dumps({
         "workload": "config 3, %d records, BAM %.1f MB (BGZF level of sam.write_bam)" % (n, size / 1e6),
         "decode_s": t1 - t0, "decode_reads_per_s": n / (t1 - t0), "host_threads": min(64, os.cpu_count() or 1),
         "filter_library_s": t2 - t1,
         "tabulate_host_s": t4 - t3, "tabulate_host_reads_per_s": b.n / (t4 - t3),
         "end_to_end_reads_per_s": n / ((t2 - t0) + (t4 - t3)),
+        "gpu_decode": {"%d MiB compressed per slab" % mb: {"slabs": k, "s": dt, "end_to_end_reads_per_s": n / dt}
+                       for mb, (dt, k, _) in gpu.items()},
         "streamed": {"%d MiB chunks" % mb: {"chunks": k, "s": dt, "end_to_end_reads_per_s": n / dt}
                      for mb, (dt, k, _) in streamed.items()},
         "parity": "bit-exact vs oracle" if ok else "MISMATCH"}))
