@@ -79,6 +79,10 @@ def build_parser():
                    help="EXPERIMENTAL: also write 5pCtoT_freq.txt / 3pGtoA_freq.txt (mapDamage 2.0-2.2 outputs that "
                         "this reference snapshot no longer produces; format unpinned)")
     g.add_argument("--batch-reads", type=int, default=4_000_000, help="records per device batch")
+    g.add_argument("--gpu-decode", action="store_true",
+                   help="inflate and unpack a BAM file on the GPU (include/mdx.h mdx_gbam_*): the compressed file goes "
+                        "to HBM, the batch columns never exist on the host.  Falls back to the host decoder for SAM "
+                        "input, --downsample, --min-basequal and files whose BGZF blocks do not start at records")
     g.add_argument("--chunk-mb", type=_ranged(float, 0), default=1024,
                    help="decode a BAM file in chunks of this many MiB of uncompressed records, overlapped with "
                         "the tabulation of the previous chunk (0: decode the whole file first)")
@@ -160,6 +164,73 @@ def rescale_qual(options):
     return 0
 
 
+def _tabulate_on_host(options, reader, ref, libraries, logger):
+    """The records decoded on the host (native BGZF/BAM decoder or SAM text), uploaded batch by batch."""
+    with DamageEngine(libraries, options.length, options.around, options.minqual,
+                      device=options.device) as engine:
+        engine.set_reference(ref)
+        n_reads, warned_about_quals = 0, False
+        # a BAM file arrives in chunks (bounded host memory; chunk k+1 is decoded while chunk k is tabulated)
+        for batch in reader.iter_batches():
+            if options.minqual and not warned_about_quals and batch.n:
+                # main.py:185-192: the first iterated read without qualities (`not read.qual`: absent or
+                # empty) triggers the warning, once
+                lens = np.diff(batch.seq_off.astype(np.int64))
+                first = np.minimum(batch.seq_off[:-1].astype(np.int64), max(0, batch.seq.shape[0] - 1))
+                if batch.qual is None or bool(((lens == 0) | (batch.qual[first] == 0xFF)).any()):
+                    logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                    warned_about_quals = True
+            if options.minqual:
+                # records none of whose qualities is below the threshold cannot be masked: the kernel skips their
+                # quality windows; a chunk without a single maskable base goes through the unmasked kernel
+                batch, nothing_to_mask = mark_unmaskable(batch, options.minqual)
+                if nothing_to_mask:
+                    batch = dataclasses.replace(batch, qual=None)
+            for lo in range(0, batch.n, options.batch_reads):
+                try:
+                    engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
+                except BadReadError as error:
+                    # index within the records iterated so far (the reference would name the read)
+                    raise BadReadError(n_reads + lo + error.read_index, str(error)) from None
+            n_reads += batch.n
+        tables = engine.finish()
+    return tables
+
+
+def _tabulate_on_device(options, reader, ref, libraries, logger):
+    """--gpu-decode: the file inflated, unpacked and counted on the GPU.  None: not a case for it (the caller decodes
+    on the host, which also words the errors the way the reference does)."""
+    from .sam import GpuBamStream, GpuDecodeUnsupported, is_bam
+    if (str(options.filename) == "-" or not is_bam(options.filename) or options.downsample is not None
+            or options.minqual != 0):
+        logger.info("--gpu-decode does not apply to this run; decoding on the host")
+        return None
+    if options.merge_libraries:
+        readgroups, lib_default = [], 0
+    else:
+        readgroups = [(rg, libraries.index(lib)) for rg, lib in reader._readgroups.items()]
+        lib_default = None
+    try:
+        with DamageEngine(libraries, options.length, options.around, 0, device=options.device) as engine:
+            engine.set_reference(ref)
+            # (a slab of compressed bytes inflates to about four times its size)
+            slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
+            with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
+                              chunk_bytes=slab) as stream:
+                while True:
+                    view = stream.next_view()
+                    if view is None:
+                        break
+                    engine.tabulate_view(view)
+                return engine.finish()
+    except GpuDecodeUnsupported as error:
+        logger.info("%s; decoding on the host", error)
+    except BadReadError:
+        # a record the reference cannot process, or one without a usable read group: the host path names it
+        logger.info("the GPU decode path met a record it cannot count; decoding on the host")
+    return None
+
+
 def main(argv):
     start_time = time.time()
     logging.basicConfig(format=_LOG_FORMAT, datefmt="%H:%M:%S")
@@ -195,34 +266,9 @@ def main(argv):
             logger.info("Filtering out bases with a Phred score < %d", options.minqual)
         logger.info("Writing results to '%s/'", options.folder)
 
-        with DamageEngine(libraries, options.length, options.around, options.minqual,
-                          device=options.device) as engine:
-            engine.set_reference(ref)
-            n_reads, warned_about_quals = 0, False
-            # a BAM file arrives in chunks (bounded host memory; chunk k+1 is decoded while chunk k is tabulated)
-            for batch in reader.iter_batches():
-                if options.minqual and not warned_about_quals and batch.n:
-                    # main.py:185-192: the first iterated read without qualities (`not read.qual`: absent or
-                    # empty) triggers the warning, once
-                    lens = np.diff(batch.seq_off.astype(np.int64))
-                    first = np.minimum(batch.seq_off[:-1].astype(np.int64), max(0, batch.seq.shape[0] - 1))
-                    if batch.qual is None or bool(((lens == 0) | (batch.qual[first] == 0xFF)).any()):
-                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
-                        warned_about_quals = True
-                if options.minqual:
-                    # records none of whose qualities is below the threshold cannot be masked: the kernel skips their
-                    # quality windows; a chunk without a single maskable base goes through the unmasked kernel
-                    batch, nothing_to_mask = mark_unmaskable(batch, options.minqual)
-                    if nothing_to_mask:
-                        batch = dataclasses.replace(batch, qual=None)
-                for lo in range(0, batch.n, options.batch_reads):
-                    try:
-                        engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
-                    except BadReadError as error:
-                        # index within the records iterated so far (the reference would name the read)
-                        raise BadReadError(n_reads + lo + error.read_index, str(error)) from None
-                n_reads += batch.n
-            tables = engine.finish()
+        tables = _tabulate_on_device(options, reader, ref, libraries, logger) if options.gpu_decode else None
+        if tables is None:
+            tables = _tabulate_on_host(options, reader, ref, libraries, logger)
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)
 

@@ -92,3 +92,68 @@ def test_tables_from_device_decode_equal_oracle(tmp_path):
     np.testing.assert_array_equal(got.mis, want["mis"])
     np.testing.assert_array_equal(got.comp, want["comp"])
     assert got.n_kept == want["n_kept"]
+
+
+@pytest.mark.parametrize("golden,extra", [("config1_L70_A10_Q0", []), ("config1_merged_L70_A10_Q0", ["--merge-libraries"]),
+                                          ("indelshapes_L70_A10_Q0", []), ("edge_L70_A10_Q0", []), ("config4s_L70_A10", [])])
+def test_cli_gpu_decode_writes_the_reference_tables(tmp_path, golden, extra):
+    """`python -m mapdamage_amd --gpu-decode`: the three tables of the reference, byte for byte, from a file that was
+    inflated and unpacked on the GPU (several slabs)."""
+    import pathlib
+
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    from tests.util import Golden
+    g = Golden(golden)
+    rgs = [{"ID": "rg%d" % i, "SM": s, "LB": l} for i, (s, l) in enumerate(g.meta["libraries"])]
+    raw_lib = np.load(str(pathlib.Path(__file__).parent / "golden" / (golden + ".npz")))["lib"]
+    if extra:
+        rgs = [{"ID": "rg0", "SM": "a", "LB": "b"}, {"ID": "rg1", "SM": "c", "LB": "d"}]
+        rg_of = ["rg%d" % (i % 2) for i in range(g.batch.n)]
+    else:
+        rg_of = ["rg%d" % int(l) for l in raw_lib]
+    path = tmp_path / "in.bam"
+    sam.write_bam(path, g.batch, g.ref.names, g.ref.lengths, rgs, rg_of)
+    fasta.write_fasta(tmp_path / "ref.fa", g.ref)
+    for chunk_mb in ("1024", "0.3"):
+        out = tmp_path / ("res" + chunk_mb)
+        assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "--gpu-decode",
+                     "--chunk-mb", chunk_mb] + extra) == 0
+        for name in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
+            assert (out / name).read_text() == g.txt[name], (chunk_mb, name)
+        assert "decoding on the host" not in (out / "Runtime_log.txt").read_text()
+
+
+def test_layouts_the_device_path_does_not_take(tmp_path):
+    """Records straddling BGZF blocks (not what htslib writes): MDX_ERR_UNSUPPORTED, and the command line falls back to
+    the host decoder with the same tables; a corrupt block is an error."""
+    from mapdamage_amd import fasta
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.main import main
+    ref, b, rg, path = _write(tmp_path, n=5000)
+    odd = tmp_path / "odd.bam"
+    sam.write_bam(str(odd), b, ref.names, ref.lengths, RGS, rg_of_record=rg, htslib_blocks=False)
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        with pytest.raises(sam.GpuDecodeUnsupported):
+            with sam.GpuBamStream(eng, str(odd), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)]) as g:
+                while g.next_view() is not None:
+                    pass
+        # a flipped byte in the middle of a block's payload
+        raw = bytearray(path.read_bytes())
+        raw[len(raw) // 2] ^= 0x5A
+        broken = tmp_path / "broken.bam"
+        broken.write_bytes(bytes(raw))
+        with pytest.raises(ValueError):
+            with sam.GpuBamStream(eng, str(broken), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)]) as g:
+                while (v := g.next_view()) is not None:
+                    eng.tabulate_view(v)
+                eng.sync()
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    outs = []
+    for name, flags in (("host", []), ("dev", ["--gpu-decode"])):
+        out = tmp_path / name
+        assert main(["-i", str(odd), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
+        outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
+    assert outs[0] == outs[1]
+    assert "decoding on the host" in (tmp_path / "dev" / "Runtime_log.txt").read_text()
