@@ -151,7 +151,8 @@ MDX_HD uint32_t bitrev(uint32_t v, int len) {
     return r;
 }
 
-// Canonical Huffman tables from code lengths (RFC 1951 3.2.2).  false: over-subscribed or incomplete set
+// Canonical Huffman tables from code lengths (RFC 1951 3.2.2).  (Inlined at its five call sites like everything
+// else here: out of line the kernel is a third of the size and a fifth slower — a call pins the decoder's registers.)  false: over-subscribed or incomplete set
 // (a single code of length 1 is accepted, as zlib does for distance codes).
 MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, uint16_t *fast, int fast_bits, bool may_be_empty = false) {
     const int lane = lane_id(), nl = lane_count();
@@ -248,10 +249,6 @@ MDX_HD void flush(const uint8_t *win, uint8_t *dst, uint32_t from, uint32_t to) 
 // at a time.  Returns the number of bytes produced, or a negative code: -1 corrupt stream, -2 output beyond `cap`,
 // -3 input exhausted (dst then holds a part of the output).
 MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint8_t *dst, uint32_t cap, Tables &t) {
-    static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     static const uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     const int lane = lane_id(), nl = lane_count();
     BitIn in;
@@ -351,10 +348,16 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 if (s == 256) break;
                 s -= 257;
                 if (s >= 29) return -1;
-                const uint32_t len = LBASE[s] + in.take(LEXT[s]);
+                // length and distance codes -> base + extra bits (RFC 1951 3.2.5), computed: a table in memory costs a
+                // round trip per look-up on the device, four of them in the middle of every match
+                const int lx = s < 8 ? 0 : (s == 28 ? 0 : (s >> 2) - 1);
+                const uint32_t lb = s < 8 ? 3u + (uint32_t)s : (s == 28 ? 258u : ((4u + ((uint32_t)s & 3u)) << lx) + 3u);
+                const uint32_t len = lb + in.take(lx);
                 const int ds = decode(in, t.count_d, t.sym_d, t.fast_d, FAST_D);
                 if (ds < 0 || ds >= 30) return -1;
-                const uint32_t dist = DBASE[ds] + in.take(DEXT[ds]);
+                const int dx = ds < 4 ? 0 : (ds >> 1) - 1;
+                const uint32_t db = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
+                const uint32_t dist = db + in.take(dx);
                 if (dist > out) return -1;
                 if (out + len > cap) return -2;
 #if MDX_ON_DEVICE
