@@ -205,15 +205,28 @@ MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, ui
 }
 
 // one symbol; -1: invalid code
-MDX_HD int decode(BitIn &in, const uint16_t *count, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
+// The numbers of codes of each length, read once per block into registers (on the device: scalar registers —
+// the walk below then costs a few scalar instructions per bit instead of an LDS round trip per bit, which is what
+// a distance code longer than the fast table's eight bits used to cost: two thirds of the whole kernel's time)
+struct Counts { uint32_t c[16]; };
+MDX_HD Counts counts_of(const uint16_t *count) {
+    Counts k;
+#pragma unroll
+    for (int i = 0; i < 16; i++) k.c[i] = uni(count[i]);
+    return k;
+}
+
+// one symbol; -1: invalid code
+MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
     const uint32_t e = uni(fast[in.peek(fast_bits)]);
     if (e) { in.drop((int)(e & 15u)); return (int)(e >> 4); }
-    // canonical walk, one bit at a time (codes longer than fast_bits: rare symbols)
+    // canonical walk, one bit at a time (codes longer than fast_bits)
     int code = 0, first = 0, index = 0;
     uint64_t b = in.bits;
+#pragma unroll
     for (int len = 1; len <= 15; len++) {
         code |= (int)(b & 1); b >>= 1;
-        const int c = (int)uni(count[len]);
+        const int c = (int)k.c[len];
         if (code - c < first) { in.drop(len); return (int)uni(sym[index + (code - first)]); }
         index += c; first += c; first <<= 1; code <<= 1;
     }
@@ -304,10 +317,11 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #if MDX_ON_DEVICE
                 __builtin_amdgcn_wave_barrier();
 #endif
+                const Counts kcl = counts_of(t.count_d);
                 int i = 0;
                 while (i < nlen + ndist) {
                     in.refill();
-                    int s = decode(in, t.count_d, t.sym_d, t.fast_d, 7);
+                    int s = decode(in, kcl, t.sym_d, t.fast_d, 7);
                     if (s < 0) return -1;
                     if (s < 16) { if (lane == 0) t.lens[32 + i] = (uint8_t)s; i++; continue; }
                     int prev = 0, rep;
@@ -334,9 +348,42 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #if MDX_ON_DEVICE
             __builtin_amdgcn_wave_barrier();
 #endif
+            const Counts kll = counts_of(t.count_ll), kd = counts_of(t.count_d);
             for (;;) {
                 in.refill();               // 56 bits: the whole symbol pair below needs at most 48
-                int s = decode(in, t.count_ll, t.sym_ll, t.fast_ll, FAST_LL);
+                int s;
+#if MDX_ON_DEVICE
+                {
+                    // Lane L looks up the symbol that would begin at bit L of the buffer — one LDS access for all 64
+                    // candidates; the symbols that really follow one another are then picked out of the lanes'
+                    // registers (readlane: a few cycles each, where a look-up of its own costs a round trip to the
+                    // LDS).  A run of up to eight literals leaves in one step.
+                    const uint32_t e = t.fast_ll[(uint32_t)(in.bits >> lane) & ((1u << FAST_LL) - 1u)];
+                    int pbit = 0;
+                    uint32_t nlit = 0, ep = 0;
+                    uint64_t lits = 0;
+                    while (nlit < 8u && pbit + FAST_LL <= in.nbits) {
+                        ep = (uint32_t)__builtin_amdgcn_readlane((int)e, pbit);
+                        if (ep == 0u || (ep >> 4) >= 256u) break;         // a long code, a length or the end of the block
+                        lits |= (uint64_t)(ep >> 4) << (8u * nlit);
+                        nlit++;
+                        pbit += (int)(ep & 15u);
+                    }
+                    if (nlit) {
+                        if (out + nlit > cap) return -2;
+                        if ((uint32_t)lane < nlit) win[(out + (uint32_t)lane) & (RING - 1)] = (uint8_t)(lits >> (8u * (uint32_t)lane));
+                        out += nlit;
+                        in.drop(pbit);
+                        if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
+                        continue;
+                    }
+                    // the symbol at bit 0 is no literal with a short code
+                    if (ep) { s = (int)(ep >> 4); in.drop((int)(ep & 15u)); }
+                    else s = decode(in, kll, t.sym_ll, t.fast_ll, FAST_LL);
+                }
+#else
+                s = decode(in, kll, t.sym_ll, t.fast_ll, FAST_LL);
+#endif
                 if (s < 0) return -1;
                 if (s < 256) {
                     if (out >= cap) return -2;
@@ -353,7 +400,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 const int lx = s < 8 ? 0 : (s == 28 ? 0 : (s >> 2) - 1);
                 const uint32_t lb = s < 8 ? 3u + (uint32_t)s : (s == 28 ? 258u : ((4u + ((uint32_t)s & 3u)) << lx) + 3u);
                 const uint32_t len = lb + in.take(lx);
-                const int ds = decode(in, t.count_d, t.sym_d, t.fast_d, FAST_D);
+                const int ds = decode(in, kd, t.sym_d, t.fast_d, FAST_D);
                 if (ds < 0 || ds >= 30) return -1;
                 const int dx = ds < 4 ? 0 : (ds >> 1) - 1;
                 const uint32_t db = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;

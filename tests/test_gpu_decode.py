@@ -157,3 +157,41 @@ def test_layouts_the_device_path_does_not_take(tmp_path):
         outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
     assert outs[0] == outs[1]
     assert "decoding on the host" in (tmp_path / "dev" / "Runtime_log.txt").read_text()
+
+
+def test_empty_file_and_records_without_read_group(tmp_path):
+    """A BAM that holds a header and nothing else; records without RG tag: counted under --merge-libraries, the
+    reference's BAMError (through the host path, which names the read) otherwise."""
+    from mapdamage_amd import fasta
+    from mapdamage_amd.batch import ReadBatch
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.main import main
+    from mapdamage_amd.sam import BAMError
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500, lower_run=3000)
+    empty = ReadBatch(np.zeros(0, np.uint16), np.zeros(0, np.uint16), np.zeros(0, np.int32), np.zeros(0, np.int32),
+                      np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint32),
+                      np.zeros(0, np.uint8), np.zeros(0, np.uint8))
+    p0 = tmp_path / "empty.bam"
+    sam.write_bam(str(p0), empty, ref.names, ref.lengths, RGS, rg_of_record=[])
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        with sam.GpuBamStream(eng, str(p0), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)]) as g:
+            n = 0
+            while (v := g.next_view()) is not None:
+                n += int(v.n_reads)
+                eng.tabulate_view(v)
+            assert n == 0
+        assert eng.finish().n_kept == 0
+    b = synth.make_reads(ref, 3000, 5, len_range=(30, 120), frac_softclip=0.1)
+    p1 = tmp_path / "norg.bam"
+    sam.write_bam(str(p1), b, ref.names, ref.lengths, RGS, rg_of_record=None)
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    outs = []
+    for name, flags in (("host", []), ("dev", ["--gpu-decode"])):
+        out = tmp_path / name
+        assert main(["-i", str(p1), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "--merge-libraries"] + flags) == 0
+        outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
+    assert outs[0] == outs[1]
+    assert "decoding on the host" not in (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    with pytest.raises(BAMError, match="has no read-group"):
+        main(["-i", str(p1), "-r", str(tmp_path / "ref.fa"), "-d", str(tmp_path / "err"), "--no-stats", "--gpu-decode"])

@@ -24,7 +24,7 @@ with tempfile.TemporaryDirectory() as tmp:
         for rep in range(3):
             eng.reset(); eng.sync()
             t0 = time.perf_counter()
-            with sam.GpuBamStream(eng, path, readgroups=[("rg1", 0)], chunk_bytes=256 << 20) as g:
+            with sam.GpuBamStream(eng, path, readgroups=[("rg1", 0)], chunk_bytes=int(float(os.environ.get("MDX_SLAB_MB", "256")) * (1 << 20))) as g:
                 t1 = time.perf_counter()
                 while True:
                     v = g.next_view()
