@@ -409,7 +409,10 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 if (out + len > cap) return -2;
 #if MDX_ON_DEVICE
                 __builtin_amdgcn_wave_barrier();
-                if (dist >= 64u) {
+                if (len <= 64u && dist >= len) {
+                    // the common case (a match is 15 bytes on average): one byte per lane, sources in front of the stretch
+                    if ((uint32_t)lane < len) win[(out + (uint32_t)lane) & (RING - 1)] = win[(out - dist + (uint32_t)lane) & (RING - 1)];
+                } else if (dist >= 64u) {
                     // 64 bytes at a time: their sources lie in front of the stretch being written
                     for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
                         win[(out + i) & (RING - 1)] = win[(out - dist + i) & (RING - 1)];
@@ -425,7 +428,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #endif
                 out += len;
                 if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
-                if (in.overrun()) return -3;
+                // (input that ends early decodes as zeros: caught at the end of the block, the output is bounded by cap)
             }
         } else {
             return -1;
