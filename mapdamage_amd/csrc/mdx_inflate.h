@@ -40,7 +40,13 @@ MDX_HD uint32_t uni(uint32_t v) {
 #endif
 }
 
-enum { FAST_LL = 10, FAST_D = 8 };   // bits resolved by one table lookup (longer codes: canonical walk)
+#ifndef MDX_FAST_LL
+#define MDX_FAST_LL 11
+#endif
+#ifndef MDX_FAST_D
+#define MDX_FAST_D 8
+#endif
+enum { FAST_LL = MDX_FAST_LL, FAST_D = MDX_FAST_D };   // bits resolved by one table lookup (longer codes: canonical walk)
 
 // Decoder tables of one block; on the device they live in the LDS (one set per wavefront).
 struct Tables {
