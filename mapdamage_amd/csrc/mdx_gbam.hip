@@ -8,7 +8,7 @@
 //                         block at a record: bgzf_flush_try in bam_write1), counts records, CIGAR operations, bases
 //   gbam_prefix_kernel    exclusive prefix sums of the three counts over the blocks (one workgroup)
 //   gbam_offsets_kernel   one lane per BGZF block again: record offsets and the cigar_off / seq_off columns
-//   gbam_unpack_kernel    one lane per record: fixed fields, CIGAR, 4-bit bases -> ASCII, qualities, RG:Z -> library
+//   gbam_unpack_kernel    eight lanes per record: fixed fields, CIGAR, 4-bit bases -> ASCII, qualities, RG:Z -> library
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -113,36 +113,50 @@ __global__ void gbam_offsets_kernel(const u8 *__restrict__ unc, const uint4 *__r
     if (b == n_blocks - 1) { cigar_off[r] = co; seq_off[r] = so; }     // the columns' closing entries
 }
 
+// eight lanes per record: the fixed fields and the read group by the first of them, the CIGAR, the bases (four per
+// step: two bytes in, one unaligned dword out) and the qualities (four per step) spread over all eight
 __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__restrict__ rec_off, u32 n_rec, MdxGbamCols c) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 r = t >> 3, j = t & 7u;
     if (r >= n_rec) return;
+    typedef u32 u32u __attribute__((aligned(1)));
     const u8 *__restrict__ p = unc + rec_off[r];
     const u32 bs = g32(p - 4);
     const u32 l_name = p[8], n_cig = g16(p + 12), l_seq = g32(p + 16);
-    const u32 flag = g16(p + 14);
-    c.flag[r] = (uint16_t)flag;
-    c.tid[r] = (int32_t)g32(p); c.pos[r] = (int32_t)g32(p + 4);
-    c.tlen[r] = (int32_t)g32(p + 28);
-    if (c.mtid) { c.mtid[r] = (int32_t)g32(p + 20); c.mpos[r] = (int32_t)g32(p + 24); }
+    if (j == 0) {
+        c.flag[r] = (uint16_t)g16(p + 14);
+        c.tid[r] = (int32_t)g32(p); c.pos[r] = (int32_t)g32(p + 4);
+        c.tlen[r] = (int32_t)g32(p + 28);
+        if (c.mtid) { c.mtid[r] = (int32_t)g32(p + 20); c.mpos[r] = (int32_t)g32(p + 24); }
+    }
     const u8 *q = p + 32 + l_name;
     u32 *__restrict__ cg = c.cigar + c.cigar_off[r];
-    for (u32 k = 0; k < n_cig; k++) cg[k] = g32(q + 4 * k);
+    for (u32 k = j; k < n_cig; k += 8u) cg[k] = g32(q + 4 * k);
     q += 4u * n_cig;
-    // bases: two per byte, "=ACMGRSVTWYHKDBN"
-    u8 *__restrict__ s = c.seq + c.seq_off[r];
-    // the 16 letters as two 64-bit constants (registers, no table in memory)
+    // bases: two per byte, "=ACMGRSVTWYHKDBN" — the 16 letters as two 64-bit constants (registers, no table in memory)
+    const u32 so = c.seq_off[r];
+    u8 *__restrict__ s = c.seq + so;
     const u64 lo8 = ((u64)'=') | ((u64)'A' << 8) | ((u64)'C' << 16) | ((u64)'M' << 24) | ((u64)'G' << 32) | ((u64)'R' << 40) | ((u64)'S' << 48) | ((u64)'V' << 56);
     const u64 hi8 = ((u64)'T') | ((u64)'W' << 8) | ((u64)'Y' << 16) | ((u64)'H' << 24) | ((u64)'K' << 32) | ((u64)'D' << 40) | ((u64)'B' << 48) | ((u64)'N' << 56);
-    for (u32 k = 0; k < l_seq; k++) {
-        const u32 byte = q[k >> 1];
-        const u32 nib = (k & 1u) ? (byte & 15u) : (byte >> 4);
-        s[k] = (u8)(((nib < 8u ? lo8 : hi8) >> (8u * (nib & 7u))) & 0xFFu);
+    auto letter = [&](const u32 nib) -> u32 { return (u32)(((nib < 8u ? lo8 : hi8) >> (8u * (nib & 7u))) & 0xFFu); };
+    const u32 n4 = l_seq >> 2;
+    for (u32 k = j; k < n4; k += 8u) {
+        const u32 b0 = q[2 * k], b1 = q[2 * k + 1];
+        *(u32u *)(s + 4 * k) = letter(b0 >> 4) | (letter(b0 & 15u) << 8) | (letter(b1 >> 4) << 16) | (letter(b1 & 15u) << 24);
     }
+    if (j == 0)
+        for (u32 k = 4 * n4; k < l_seq; k++) {
+            const u32 byte = q[k >> 1];
+            s[k] = (u8)letter((k & 1u) ? (byte & 15u) : (byte >> 4));
+        }
     q += (l_seq + 1u) / 2u;
     if (c.qual) {
-        u8 *__restrict__ ql = c.qual + c.seq_off[r];
-        for (u32 k = 0; k < l_seq; k++) ql[k] = q[k];
+        u8 *__restrict__ ql = c.qual + so;
+        for (u32 k = j; k < n4; k += 8u) *(u32u *)(ql + 4 * k) = g32(q + 4 * k);
+        if (j == 0)
+            for (u32 k = 4 * n4; k < l_seq; k++) ql[k] = q[k];
     }
+    if (j != 0) return;
     q += l_seq;
     // library: the RG:Z tag against the header's read groups
     int lib = c.lib_default;
@@ -210,5 +224,5 @@ void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *blk, const uint4 *pre, c
     hipLaunchKernelGGL(gbam_offsets_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, s, unc, blk, pre, cnt, n_blocks, rec_off,
                        c.cigar_off, c.seq_off);
     if (n_rec > 0)
-        hipLaunchKernelGGL(gbam_unpack_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, s, unc, rec_off, n_rec, c);
+        hipLaunchKernelGGL(gbam_unpack_kernel, dim3((n_rec + 31) / 32), dim3(256), 0, s, unc, rec_off, n_rec, c);
 }
