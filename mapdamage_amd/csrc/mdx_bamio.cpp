@@ -769,11 +769,8 @@ struct mdx_gbam {
     void *d_rg_names = nullptr, *d_rg_off = nullptr, *d_lib_of_rg = nullptr;
     // device buffers, grown on demand
     struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
-        cigar_off, cigar, seq_off, seq, qual, small;
-    std::vector<Buf *> all() {
-        return {&comp, &blk, &status, &unc, &cnt, &pre, &rec_off, &flag, &lib, &tid, &pos, &tlen, &mtid, &mpos, &cigar_off, &cigar,
-                &seq_off, &seq, &qual, &small};
-    }
+        cigar_off, cigar, seq_off, seq, qual, small, arena;     // (all but `arena` point into it)
+    std::vector<Buf *> all() { return {&arena}; }
     bool reserve(Buf &b, size_t bytes) {
         if (bytes <= b.cap) return true;
         if (b.p) (void)hipFree(b.p);
@@ -888,15 +885,23 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         // upper bounds of the columns from the inflated size: a record is at least 36 bytes, and holds its bases
         // twice over (4 bits + a quality byte each): l_seq <= 2/3 of its size
         const size_t rec_cap = unc_bytes / 36 + 2, cig_cap = unc_bytes / 4 + 2, seq_cap = unc_bytes + 64;
-        if (!g->reserve(g->comp, comp_bytes + 64) || !g->reserve(g->blk, nb * 16) || !g->reserve(g->status, nb * 4) ||
-            !g->reserve(g->unc, unc_bytes + 64) || !g->reserve(g->cnt, nb * 16) || !g->reserve(g->pre, nb * 16) ||
-            !g->reserve(g->small, 64) || !g->reserve(g->rec_off, rec_cap * 4) || !g->reserve(g->flag, rec_cap * 2) ||
-            !g->reserve(g->lib, rec_cap * 2) || !g->reserve(g->tid, rec_cap * 4) || !g->reserve(g->pos, rec_cap * 4) ||
-            !g->reserve(g->tlen, rec_cap * 4) || !g->reserve(g->cigar_off, rec_cap * 4) || !g->reserve(g->seq_off, rec_cap * 4) ||
-            !g->reserve(g->cigar, cig_cap * 4) || !g->reserve(g->seq, seq_cap) ||
-            (g->want_qual && !g->reserve(g->qual, seq_cap)) ||
-            (g->want_mate && (!g->reserve(g->mtid, rec_cap * 4) || !g->reserve(g->mpos, rec_cap * 4))))
-            return MDX_ERR_HIP;
+        // one allocation for everything (twenty hipMalloc / hipFree pairs were a tenth of a small file's time)
+        {
+            struct Want { mdx_gbam::Buf *b; size_t bytes; };
+            const Want wants[] = {
+                {&g->comp, comp_bytes + 64}, {&g->blk, nb * 16}, {&g->status, nb * 4}, {&g->unc, unc_bytes + 64}, {&g->cnt, nb * 16},
+                {&g->pre, nb * 16}, {&g->small, 64}, {&g->rec_off, rec_cap * 4}, {&g->flag, rec_cap * 2}, {&g->lib, rec_cap * 2},
+                {&g->tid, rec_cap * 4}, {&g->pos, rec_cap * 4}, {&g->tlen, rec_cap * 4}, {&g->cigar_off, rec_cap * 4},
+                {&g->seq_off, rec_cap * 4}, {&g->cigar, cig_cap * 4}, {&g->seq, seq_cap}, {&g->qual, g->want_qual ? seq_cap : 0},
+                {&g->mtid, g->want_mate ? rec_cap * 4 : 0}, {&g->mpos, g->want_mate ? rec_cap * 4 : 0}};
+            size_t total_bytes = 0;
+            for (const Want &w : wants) total_bytes += (w.bytes + 255) & ~(size_t)255;
+            // (the previous slab's columns may still be read by the tabulation kernel: wait before the arena moves)
+            if (total_bytes > g->arena.cap && hipStreamSynchronize(g->stream) != hipSuccess) return MDX_ERR_HIP;
+            if (!g->reserve(g->arena, total_bytes)) return MDX_ERR_HIP;
+            size_t at = 0;
+            for (const Want &w : wants) { w.b->p = w.bytes ? (char *)g->arena.p + at : nullptr; w.b->cap = 0; at += (w.bytes + 255) & ~(size_t)255; }
+        }
         hipStream_t st = g->stream;
         lap("allocate");
         // the previous slab's columns may still be read by the tabulation kernel
