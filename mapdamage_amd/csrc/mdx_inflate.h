@@ -130,9 +130,10 @@ struct BitIn {
         return load8(p, n, at);
 #endif
     }
-    // 56 .. 63 valid bits in `bits` afterwards (zeros beyond the end of the input): enough for a literal/length
+    // 48 .. 63 valid bits in `bits` afterwards (zeros beyond the end of the input): enough for a literal/length
     // code, its extra bits, a distance code and its extra bits (48) without another look
     MDX_HD void refill() {
+        if (nbits >= 48) return;                  // (still enough for a whole symbol pair)
 #if MDX_ON_DEVICE
         if ((pos & ~511u) != held_at) reload(pos);
 #endif
