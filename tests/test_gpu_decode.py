@@ -195,3 +195,36 @@ def test_empty_file_and_records_without_read_group(tmp_path):
     assert "decoding on the host" not in (tmp_path / "dev" / "Runtime_log.txt").read_text()
     with pytest.raises(BAMError, match="has no read-group"):
         main(["-i", str(p1), "-r", str(tmp_path / "ref.fa"), "-d", str(tmp_path / "err"), "--no-stats", "--gpu-decode"])
+
+
+def test_damaged_files_end_in_an_error_not_a_hang(tmp_path):
+    """Sixty copies of a small BAM with a few bytes changed somewhere behind the header: the device path either
+    reports the damage (a corrupt block, records that do not add up) or — a change the DEFLATE stream and ISIZE
+    survive, the block CRC32 is not checked — returns columns; it never hangs or faults."""
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    ref, b, rg, path = _write(tmp_path, n=4000)
+    raw = path.read_bytes()
+    rng = np.random.default_rng(77)
+    outcomes = {"error": 0, "unsupported": 0, "decoded": 0}
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        for k in range(60):
+            data = bytearray(raw)
+            for _ in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(2000, len(data) - 28))
+                data[i] ^= int(rng.integers(1, 256))
+            bad = tmp_path / ("bad%d.bam" % k)
+            bad.write_bytes(bytes(data))
+            try:
+                with sam.GpuBamStream(eng, str(bad), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)], chunk_bytes=1 << 18) as g:
+                    while (v := g.next_view()) is not None:
+                        eng.tabulate_view(v)
+                    eng.sync()
+                outcomes["decoded"] += 1
+            except sam.GpuDecodeUnsupported:
+                outcomes["unsupported"] += 1
+            except (ValueError, BadReadError):
+                outcomes["error"] += 1
+            eng.reset()
+            bad.unlink()
+    assert outcomes["error"] + outcomes["unsupported"] > 30, outcomes
