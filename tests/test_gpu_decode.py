@@ -228,3 +228,52 @@ def test_damaged_files_end_in_an_error_not_a_hang(tmp_path):
             eng.reset()
             bad.unlink()
     assert outcomes["error"] + outcomes["unsupported"] > 30, outcomes
+
+
+def test_rescaling_from_device_decoded_columns(tmp_path):
+    """Qualities and mate columns unpacked on the GPU feed `mdx_tabulate_rescale_device` directly: the rescaled
+    qualities, MR sums and routing equal those of the host-decoded batch, and the tables equal the oracle's."""
+    import types
+
+    import torch
+
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.rescale import RescaleModel
+    from oracle import oracle
+    ref, b, rg, path = _write(tmp_path, n=20_000, seed=6)
+    rng = np.random.default_rng(5)
+    corr_prob = {}
+    for p in list(range(1, 13)) + list(range(-12, 0)):
+        corr_prob[("C", "T", p)] = float(rng.random() * 0.5)
+        corr_prob[("G", "A", p)] = float(rng.random() * 0.5)
+    model = RescaleModel(corr_prob, 12, 12)
+    host = sam.read_bam_native(str(path))
+    hb = host.batch
+    lib_of = {"rgA": 0, "rg_b2": 1, "x": 0}
+    hb.lib = np.asarray([lib_of[host.rg_names[i]] for i in host.rg_index], np.uint16)
+    want_tables = oracle.tabulate(ref, hb, 2, 70, 10)
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        want_q, want_mr, want_st = eng.rescale(hb)
+        eng.reset()
+        got_q, got_mr, got_st = [], [], []
+        with sam.GpuBamStream(eng, str(path), readgroups=list(lib_of.items()), chunk_bytes=1 << 19, want_qual=True, want_mate=True) as g:
+            while (v := g.next_view()) is not None:
+                n, nb = int(v.n_reads), int(v.n_bases)
+                q_out = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
+                mr = torch.empty(max(n, 1), dtype=torch.float64, device="cuda")
+                st = torch.empty(max(n, 1), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                eng.rescale_device(types.SimpleNamespace(dev=v), v.mtid, v.mpos, q_out.data_ptr(), mr.data_ptr(), st.data_ptr(),
+                                   with_tables=True)
+                eng.sync()
+                got_q.append(q_out.cpu().numpy()[:nb]); got_mr.append(mr.cpu().numpy()[:n]); got_st.append(st.cpu().numpy()[:n])
+        tables = eng.finish()
+    got_q, got_mr, got_st = np.concatenate(got_q), np.concatenate(got_mr), np.concatenate(got_st)
+    np.testing.assert_array_equal(got_q, want_q)
+    np.testing.assert_array_equal(got_st, want_st)
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+    np.testing.assert_array_equal(tables.mis, want_tables["mis"])
+    np.testing.assert_array_equal(tables.comp, want_tables["comp"])
