@@ -150,7 +150,7 @@ struct mdx_bam_stream {
 
 namespace {
 
-struct Block { size_t in_off, in_size, out_off, out_size; };
+struct Block { size_t in_off, in_size, out_off, out_size; uint32_t crc; };   // crc: CRC32 of the inflated bytes (gzip trailer)
 
 // The compressed file, mapped read-only: the inflating threads read the page cache directly (an fread of the
 // whole file into a buffer first was a single-threaded copy, a quarter of the decode time on a 64-thread host).
@@ -213,6 +213,7 @@ bool scan_blocks(const MappedFile &file, std::vector<Block> &blocks, size_t &tot
         b.in_off = off + 12 + xlen;
         b.in_size = bsize - xlen - 20;
         b.out_size = rd32(&file[off + bsize - 4]);
+        b.crc = rd32(&file[off + bsize - 8]);
         // ISIZE comes from the file: a BGZF block inflates to at most 64 KiB (SAM specification 4.1)
         if (b.out_size > 65536) { err = "corrupt BGZF block (ISIZE beyond 64 KiB)"; return false; }
         b.out_off = total;
@@ -224,8 +225,9 @@ bool scan_blocks(const MappedFile &file, std::vector<Block> &blocks, size_t &tot
     return true;
 }
 
-bool inflate_block(const uint8_t *src, size_t n, uint8_t *dst, size_t m) {
-    if (m == 0) return true;
+// (the gzip trailer's CRC32 is checked like its ISIZE: htslib, behind pysam, refuses a block whose bytes do not match)
+bool inflate_block(const uint8_t *src, size_t n, uint8_t *dst, size_t m, uint32_t crc) {
+    if (m == 0) return crc == 0;
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -235,7 +237,7 @@ bool inflate_block(const uint8_t *src, size_t n, uint8_t *dst, size_t m) {
     zs.avail_out = (uInt)m;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
-    return rc == Z_STREAM_END && zs.avail_out == 0;
+    return rc == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(0L, dst, (uInt)m) == crc;
 }
 
 template <class F>
@@ -494,9 +496,9 @@ bool stream_fill(mdx_bam_stream *s, size_t want) {
     const MappedFile &file = *s->file;
     parallel_for(blocks.size(), s->threads, [&](size_t i) {
         const Block &k = blocks[i];
-        if (!inflate_block(&file[k.in_off], k.in_size, &s->pending[base + k.out_off], k.out_size)) ok = false;
+        if (!inflate_block(&file[k.in_off], k.in_size, &s->pending[base + k.out_off], k.out_size, k.crc)) ok = false;
     });
-    if (!ok) { s->head.error = "inflate failed"; return false; }
+    if (!ok) { s->head.error = "inflate failed (corrupt BGZF block: DEFLATE stream, ISIZE or CRC32)"; return false; }
     for (const Block &k : blocks) s->hints.push_back(base + k.out_off);
     s->coff = consumed;
     if (s->coff >= file.size()) s->eof = true;
@@ -533,9 +535,9 @@ int mdx_bam_read(const char *path, int threads, mdx_bam **out) {
         std::atomic<bool> ok{true};
         parallel_for(blocks.size(), threads, [&](size_t i) {
             const Block &k = blocks[i];
-            if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size)) ok = false;
+            if (!inflate_block(&file[k.in_off], k.in_size, &data[k.out_off], k.out_size, k.crc)) ok = false;
         });
-        if (!ok) { b->error = "inflate failed"; return MDX_ERR_ARG; }
+        if (!ok) { b->error = "inflate failed (corrupt BGZF block: DEFLATE stream, ISIZE or CRC32)"; return MDX_ERR_ARG; }
         lap("inflate");
         file.close();
     

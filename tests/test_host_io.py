@@ -366,3 +366,33 @@ def test_native_patch_of_rescaled_records_and_bgzf_writer(tmp_path):
     for i in range(batch.n):
         if i not in chosen:
             assert back.raw[i] == whole.raw[i]
+
+
+def test_bgzf_block_crc_is_checked(tmp_path):
+    """A block whose bytes inflate but do not match its CRC32 is refused (htslib, behind the reference's pysam, does
+    the same), by the one-piece and by the chunked decoder."""
+    import struct
+
+    import pytest
+
+    from mapdamage_amd import sam, synth
+    ref = synth.make_genome(seed=2, sizes=(("c1", 50_000),), n_run=50, lower_run=300)
+    b = synth.make_reads(ref, 3000, 3, len_range=(30, 100))
+    path = tmp_path / "x.bam"
+    sam.write_bam(str(path), b, ref.names, ref.lengths, [{"ID": "r", "SM": "s", "LB": "l"}], rg_of_record=["r"] * b.n)
+    raw = bytearray(path.read_bytes())
+    # walk to the third block and damage its CRC32 field (the DEFLATE stream and ISIZE stay valid)
+    off = 0
+    for _ in range(2):
+        off += struct.unpack_from("<H", raw, off + 16)[0] + 1
+    bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+    raw[off + bsize - 8] ^= 0x01
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(bytes(raw))
+    assert sam.read_bam_native(str(path)).batch.n == b.n
+    with pytest.raises(ValueError, match="CRC32"):
+        sam.read_bam_native(str(bad))
+    with pytest.raises(ValueError, match="CRC32"):
+        with sam.BamStream(str(bad), chunk_bytes=1 << 16) as stream:
+            for _ in stream:
+                pass
