@@ -4,6 +4,7 @@
 // 121-132) without pysam.  Pure host code (zlib); no HIP calls.
 #include "../../include/mdx.h"
 #include "mdx_internal.h"
+#include "mdx_crc32.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -769,8 +770,9 @@ struct mdx_gbam {
     std::vector<int32_t> lib_of_rg;
     int lib_default = -1;
     void *d_rg_names = nullptr, *d_rg_off = nullptr, *d_lib_of_rg = nullptr;
+    void *d_crc_tables = nullptr;        // mdx_crc32::Tables
     // device buffers, grown on demand
-    struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
+    struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, crc, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
         cigar_off, cigar, seq_off, seq, qual, small, arena;     // (all but `arena` point into it)
     std::vector<Buf *> all() { return {&arena}; }
     bool reserve(Buf &b, size_t bytes) {
@@ -807,6 +809,13 @@ int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out) {
         }
         g->next_block = k;
         if (hipSetDevice(g->device) != hipSuccess || mdx_k_gbam_prepare() != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+        {
+            static mdx_crc32::Tables tables;
+            static std::once_flag once;
+            std::call_once(once, [] { mdx_crc32::make_tables(tables); });
+            if (hipMalloc(&g->d_crc_tables, sizeof(tables)) != hipSuccess ||
+                hipMemcpy(g->d_crc_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+        }
         return MDX_OK;
     } catch (const std::exception &e) {
         if (out && *out) (*out)->error = std::string("mdx_gbam_open: ") + e.what();
@@ -878,9 +887,10 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         const size_t in1 = g->blocks[b1 - 1].in_off + g->blocks[b1 - 1].in_size;
         const size_t comp_bytes = in1 - in0;
         const size_t out0 = g->blocks[b0].out_off;
-        std::vector<uint32_t> blk(4 * nb);
+        std::vector<uint32_t> blk(4 * nb), crcs(nb);
         for (size_t i = 0; i < nb; i++) {
             const Block &b = g->blocks[b0 + i];
+            crcs[i] = b.crc;
             blk[4 * i] = (uint32_t)(b.in_off - in0); blk[4 * i + 1] = (uint32_t)b.in_size;
             blk[4 * i + 2] = (uint32_t)(b.out_off - out0); blk[4 * i + 3] = (uint32_t)b.out_size;
         }
@@ -891,7 +901,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         {
             struct Want { mdx_gbam::Buf *b; size_t bytes; };
             const Want wants[] = {
-                {&g->comp, comp_bytes + 64}, {&g->blk, nb * 16}, {&g->status, nb * 4}, {&g->unc, unc_bytes + 64}, {&g->cnt, nb * 16},
+                {&g->comp, comp_bytes + 64}, {&g->blk, nb * 16}, {&g->crc, nb * 4}, {&g->status, nb * 4}, {&g->unc, unc_bytes + 64}, {&g->cnt, nb * 16},
                 {&g->pre, nb * 16}, {&g->small, 64}, {&g->rec_off, rec_cap * 4}, {&g->flag, rec_cap * 2}, {&g->lib, rec_cap * 2},
                 {&g->tid, rec_cap * 4}, {&g->pos, rec_cap * 4}, {&g->tlen, rec_cap * 4}, {&g->cigar_off, rec_cap * 4},
                 {&g->seq_off, rec_cap * 4}, {&g->cigar, cig_cap * 4}, {&g->seq, seq_cap}, {&g->qual, g->want_qual ? seq_cap : 0},
@@ -909,21 +919,26 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         // the previous slab's columns may still be read by the tabulation kernel
         if (hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
         if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(g->blk.p, blk.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
+            hipMemcpyAsync(g->blk.p, blk.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(g->crc.p, crcs.data(), nb * 4, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
         unsigned long long *d_tot = (unsigned long long *)g->small.p;
-        int *d_bad = (int *)((char *)g->small.p + 32);
+        int *d_bad = (int *)((char *)g->small.p + 32), *d_bad_crc = (int *)((char *)g->small.p + 40);
         const int no_bad = 0x7FFFFFFF;
         (void)hipMemcpyAsync(d_bad, &no_bad, 4, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_bad_crc, &no_bad, 4, hipMemcpyHostToDevice, st);
         lap("upload");
         mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nb, (uint8_t *)g->unc.p, (int *)g->status.p, st);
         lap("inflate");
+        mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nb, d_bad_crc, st);
+        lap("crc32");
         mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)nb, (uint4 *)g->cnt.p,
                         (uint4 *)g->pre.p, d_tot, d_bad, st);
         lap("scan");
         unsigned long long tot[3] = {0, 0, 0};
-        int bad = no_bad;
+        int bad = no_bad, bad_crc = no_bad;
         if (hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&bad_crc, d_bad_crc, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             g->error = std::string("GPU decode failed: ") + hipGetErrorString(hipGetLastError());
             return MDX_ERR_HIP;
         }
@@ -931,9 +946,11 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             int stv = 0;
             (void)hipMemcpy(&stv, (const int *)g->status.p + bad, 4, hipMemcpyDeviceToHost);
             if (stv < 0) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad) + " (inflate code " + std::to_string(stv) + ")"; return MDX_ERR_ARG; }
+            if (bad_crc != no_bad && bad_crc <= bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
             g->error = "BGZF block " + std::to_string(b0 + (size_t)bad) + " does not hold whole records";
             return MDX_ERR_UNSUPPORTED;
         }
+        if (bad_crc != no_bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
         if (tot[0] > rec_cap - 2 || tot[1] > cig_cap - 2 || tot[2] > seq_cap - 64 || tot[2] > 0xFFFFFFFFull) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
         MdxGbamCols c{};
         c.flag = (uint16_t *)g->flag.p; c.lib = (uint16_t *)g->lib.p; c.tid = (int32_t *)g->tid.p; c.pos = (int32_t *)g->pos.p;
@@ -968,7 +985,7 @@ void mdx_gbam_close(mdx_gbam *g) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     for (auto *b : g->all()) if (b->p) (void)hipFree(b->p);
-    for (void *p : {g->d_rg_names, g->d_rg_off, g->d_lib_of_rg}) if (p) (void)hipFree(p);
+    for (void *p : {g->d_rg_names, g->d_rg_off, g->d_lib_of_rg, g->d_crc_tables}) if (p) (void)hipFree(p);
     if (g->hs) mdx_bam_close(g->hs);
     delete g;
 }

@@ -4,6 +4,7 @@
 //
 //   gbam_inflate_kernel   one wavefront per BGZF block (mdx_inflate.h): 32 KiB window and tables in the LDS (~36 KB:
 //                         four blocks per CU, one per SIMD), output written to HBM 16 KiB at a time, 16 bytes per lane
+//   gbam_crc_kernel       one wavefront per BGZF block: CRC32 of the inflated bytes against the gzip trailer
 //   gbam_scan_kernel      one lane per BGZF block: follows the chain of block_size fields (htslib starts every BGZF
 //                         block at a record: bgzf_flush_try in bam_write1), counts records, CIGAR operations, bases
 //   gbam_prefix_kernel    exclusive prefix sums of the three counts over the blocks (one workgroup)
@@ -12,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mdx_crc32.h"
 #include "mdx_inflate.h"
 #include "mdx_internal.h"
 
@@ -37,6 +39,32 @@ __global__ __launch_bounds__(64) void gbam_inflate_kernel(const u8 *__restrict__
         if (r >= 0 && (u32)r != b.w) r = -4;                                   // ISIZE disagrees
     }
     if (threadIdx.x == 0) status[blockIdx.x] = r;
+}
+
+// The CRC32 of every block's inflated bytes against the one in its gzip trailer (htslib, behind the reference's pysam,
+// refuses a block that fails it): one wavefront per block, 1 KiB per lane through the byte table (in the LDS), the 64
+// partial values joined by lane 0 with the "append n zero bytes" matrices.  bad = the lowest failing block.
+__global__ __launch_bounds__(64) void gbam_crc_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk,
+                                                       const u32 *__restrict__ want, const mdx_crc32::Tables *__restrict__ tb,
+                                                       int *__restrict__ bad) {
+    __shared__ u32 tab[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) tab[i] = tb->tab[i];
+    __syncthreads();
+    const uint4 e = blk[blockIdx.x];
+    const u32 n = e.w;
+    const u32 lo = 1024u * (u32)lane;
+    const u32 m = lo < n ? (n - lo < 1024u ? n - lo : 1024u) : 0u;
+    const u32 mine = mdx_crc32::crc_bytes(tab, unc + e.z + lo, m);
+    // (lane 0 alone: 63 matrix products of 32 steps each)
+    u32 total = (u32)__builtin_amdgcn_readlane((int)mine, 0);
+    for (int i = 1; i < 64; i++) {
+        const u32 li = 1024u * (u32)i;
+        if (li >= n) break;
+        const u32 mi = n - li < 1024u ? n - li : 1024u;
+        total = mdx_crc32::shift(tb->mat, total, mi) ^ (u32)__builtin_amdgcn_readlane((int)mine, i);
+    }
+    if (lane == 0 && total != want[blockIdx.x]) atomicMin(bad, (int)blockIdx.x);
 }
 
 // cnt[b] = (records, CIGAR operations, bases, 0) of BGZF block b; status < 0: the chain of records does not end at
@@ -209,6 +237,11 @@ hipError_t mdx_k_gbam_prepare() {
 void mdx_k_gbam_inflate(const uint8_t *comp, const uint4 *blk, int n_blocks, uint8_t *unc, int *status, hipStream_t s) {
     if (n_blocks <= 0) return;
     hipLaunchKernelGGL(gbam_inflate_kernel, dim3(n_blocks), dim3(64), mdx_k_gbam_inflate_lds(), s, comp, blk, unc, status);
+}
+
+void mdx_k_gbam_crc(const uint8_t *unc, const uint4 *blk, const uint32_t *want, const void *tables, int n_blocks, int *bad, hipStream_t s) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(gbam_crc_kernel, dim3(n_blocks), dim3(64), 0, s, unc, blk, want, (const mdx_crc32::Tables *)tables, bad);
 }
 
 void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, uint4 *cnt, uint4 *pre,

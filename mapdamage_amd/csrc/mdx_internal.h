@@ -202,6 +202,8 @@ size_t mdx_k_gbam_inflate_lds();
 hipError_t mdx_k_gbam_prepare();
 // blk[b] = (payload offset in comp, payload bytes, offset in unc, bytes out)
 void mdx_k_gbam_inflate(const uint8_t *comp, const uint4 *blk, int n_blocks, uint8_t *unc, int *status, hipStream_t s);
+// want[b] = CRC32 of block b's inflated bytes (gzip trailer); tables: a device copy of mdx_crc32::Tables; *bad = min failing block
+void mdx_k_gbam_crc(const uint8_t *unc, const uint4 *blk, const uint32_t *want, const void *tables, int n_blocks, int *bad, hipStream_t s);
 void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, uint4 *cnt, uint4 *pre,
                      unsigned long long *tot, int *bad, hipStream_t s);
 void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *blk, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec,

@@ -277,3 +277,31 @@ def test_rescaling_from_device_decoded_columns(tmp_path):
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
     np.testing.assert_array_equal(tables.mis, want_tables["mis"])
     np.testing.assert_array_equal(tables.comp, want_tables["comp"])
+
+
+def test_block_crc_is_checked_on_the_device(tmp_path):
+    """A block whose DEFLATE stream and ISIZE are intact but whose CRC32 field is not: an error, as on the host."""
+    import struct
+
+    from mapdamage_amd.engine import DamageEngine
+    ref, b, rg, path = _write(tmp_path, n=6000)
+    raw = bytearray(path.read_bytes())
+    off = 0
+    for _ in range(3):
+        off += struct.unpack_from("<H", raw, off + 16)[0] + 1
+    bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+    raw[off + bsize - 7] ^= 0x40
+    bad = tmp_path / "badcrc.bam"
+    bad.write_bytes(bytes(raw))
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        with pytest.raises(ValueError, match="CRC32"):
+            with sam.GpuBamStream(eng, str(bad), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)]) as g:
+                while g.next_view() is not None:
+                    pass
+        # (and the intact file passes the same check)
+        with sam.GpuBamStream(eng, str(path), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)], chunk_bytes=1 << 17) as g:
+            n = 0
+            while (v := g.next_view()) is not None:
+                n += int(v.n_reads)
+        assert n == b.n

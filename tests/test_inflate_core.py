@@ -49,3 +49,13 @@ def test_inflate_core_agrees_with_zlib(tmp_path):
     out = subprocess.run([str(exe)], input=bytes(blob), capture_output=True, timeout=120)
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     assert out.stdout.decode().strip().endswith("%d streams, 0 bad" % n)
+
+
+def test_crc32_pieces_join_to_zlibs_value(tmp_path):
+    """mapdamage_amd/csrc/mdx_crc32.h (the GPU decode path's block check): CRCs of 1 KiB pieces joined with the
+    append-zeros operator equal zlib's crc32 of the whole, for every length class of a BGZF block."""
+    exe = tmp_path / "crc_check"
+    subprocess.check_call(["g++", "-O2", "-I", str(ROOT / "mapdamage_amd" / "csrc"), str(ROOT / "tests" / "native" / "crc_check.cpp"),
+                           "-lz", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.decode().strip().endswith("0 bad"), out.stdout.decode()
