@@ -760,7 +760,23 @@ struct mdx_gbam {
     hipStream_t stream = nullptr;
     int device = 0;
     mdx_bam_stream *hs = nullptr;        // header (parsed on the host) and the mapped file
-    std::vector<Block> blocks;           // every BGZF block of the file
+    std::vector<Block> blocks;           // the BGZF blocks found so far (the file is scanned as the slabs need it:
+                                         // walking the block headers of a large file touches every page of it once)
+    size_t scanned = 0, scanned_out = 0; // compressed offset behind the last block found, inflated bytes in front of it
+    // blocks up to compressed offset `upto` (or the end of the file); false: a corrupt block header
+    bool scan_to(size_t upto) {
+        const MappedFile &f = *hs->file;
+        while (scanned < f.size() && scanned < upto) {
+            std::vector<Block> more;
+            size_t total = 0, consumed = scanned;
+            if (!scan_blocks(f, more, total, error, scanned, std::max<size_t>(upto - scanned, (size_t)1 << 20), &consumed)) return false;
+            if (consumed == scanned) break;
+            for (Block &b : more) { b.out_off += scanned_out; blocks.push_back(b); }
+            scanned = consumed; scanned_out += total;
+        }
+        return true;
+    }
+    bool whole_file_scanned() const { return scanned >= hs->file->size(); }
     size_t next_block = 0;               // first block not decoded yet
     std::string error;
     bool want_qual = false, want_mate = false;
@@ -798,12 +814,14 @@ int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out) {
         g->stream = (hipStream_t)st;
         int rc = mdx_bam_open(path, 4, &g->hs);
         if (rc != MDX_OK) { g->error = g->hs ? g->hs->head.error : "cannot open"; return rc; }
-        size_t total = 0;
-        if (!scan_blocks(*g->hs->file, g->blocks, total, g->error)) return MDX_ERR_ARG;
         // the records must start where a block starts (htslib flushes the header into blocks of its own)
         size_t k = 0;
-        while (k < g->blocks.size() && g->blocks[k].out_off < g->hs->header_bytes) k++;
-        if (k < g->blocks.size() ? g->blocks[k].out_off != g->hs->header_bytes : total != g->hs->header_bytes) {
+        for (;;) {
+            while (k < g->blocks.size() && g->blocks[k].out_off < g->hs->header_bytes) k++;
+            if (k < g->blocks.size() || g->whole_file_scanned()) break;
+            if (!g->scan_to(g->scanned + ((size_t)1 << 20))) return MDX_ERR_ARG;
+        }
+        if (k < g->blocks.size() ? g->blocks[k].out_off != g->hs->header_bytes : g->scanned_out != g->hs->header_bytes) {
             g->error = "the BAM header does not end at a BGZF block boundary";
             return MDX_ERR_UNSUPPORTED;
         }
@@ -862,6 +880,9 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         std::memset(view, 0, sizeof(*view));
         if (d_mtid) *d_mtid = nullptr;
         if (d_mpos) *d_mpos = nullptr;
+        const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
+        // (the block headers of this slab, unless the previous call has already walked them)
+        if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + want + 65536)) return MDX_ERR_ARG;
         if (g->next_block >= g->blocks.size()) return MDX_OK;             // end of file: an empty view
         if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
         // MDX_BAM_TIMING=1: stage times on stderr (each lap waits for the stream)
@@ -874,7 +895,6 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             std::fprintf(stderr, "mdx_gbam_next %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
             t_last = now;
         };
-        const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
         // the slab: blocks [b0, b1), about `want` compressed bytes, less than 4 GiB inflated
         const size_t b0 = g->next_block;
         size_t b1 = b0, unc_bytes = 0;
@@ -928,6 +948,8 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         (void)hipMemcpyAsync(d_bad_crc, &no_bad, 4, hipMemcpyHostToDevice, st);
         lap("upload");
         mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nb, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        // (the next slab's block headers, while the device inflates this one)
+        if (!timing && !g->scan_to(in1 + want + 65536)) return MDX_ERR_ARG;
         lap("inflate");
         mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nb, d_bad_crc, st);
         lap("crc32");
@@ -978,7 +1000,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
     }
 }
 
-int mdx_gbam_at_end(const mdx_gbam *g) { return (!g || g->next_block >= g->blocks.size()) ? 1 : 0; }
+int mdx_gbam_at_end(const mdx_gbam *g) { return (!g || (g->next_block >= g->blocks.size() && g->whole_file_scanned())) ? 1 : 0; }
 
 void mdx_gbam_close(mdx_gbam *g) {
     if (!g) return;
