@@ -2,8 +2,9 @@
 // leaving HBM — the device counterpart of mdx_bamio.cpp, which is the counterpart of pysam.AlignmentFile behind
 // mapdamage/reader.py:20-46.  Host orchestration: mdx_gbam_* in mdx_bamio.cpp.
 //
-//   gbam_inflate_kernel   one wavefront per BGZF block (mdx_inflate.h): 32 KiB window and tables in the LDS (~36 KB:
-//                         four blocks per CU, one per SIMD), output written to HBM 16 KiB at a time, 16 bytes per lane
+//   gbam_inflate_kernel   one wavefront per BGZF block (mdx_inflate.h): the last 4 KiB of the output and the tables in
+//                         the LDS (~10 KB: sixteen blocks per CU), output written to HBM 2 KiB at a time, 16 bytes per
+//                         lane; matches that reach further back read the output in HBM
 //   gbam_crc_kernel       one wavefront per BGZF block: CRC32 of the inflated bytes against the gzip trailer
 //   gbam_scan_kernel      one lane per BGZF block: follows the chain of block_size fields (htslib starts every BGZF
 //                         block at a record: bgzf_flush_try in bam_write1), counts records, CIGAR operations, bases
@@ -29,12 +30,12 @@ __device__ __forceinline__ u32 g32(const u8 *p) { return (u32)p[0] | ((u32)p[1] 
 __global__ __launch_bounds__(64) void gbam_inflate_kernel(const u8 *__restrict__ comp, const uint4 *__restrict__ blk,
                                                            u8 *__restrict__ unc, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    u8 *const win = lds;                                                       // the 32 KiB window
+    u8 *const win = lds;                                                       // the window (mdx_inflate::RING bytes)
     mdx_inflate::Tables &t = *(mdx_inflate::Tables *)(lds + mdx_inflate::RING);
     const uint4 b = blk[blockIdx.x];                                           // in_off, in_size, out_off, out_size
     int r = 0;
     if (b.w > 0) {
-        // (the output leaves the window for HBM 16 KiB at a time; b.w <= 65536 was checked on the host)
+        // (the output leaves the window for HBM half a ring at a time; b.w <= 65536 was checked on the host)
         r = mdx_inflate::inflate_block(comp + b.x, b.y, win, unc + b.z, b.w, t);
         if (r >= 0 && (u32)r != b.w) r = -4;                                   // ISIZE disagrees
     }

@@ -240,7 +240,15 @@ MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_
     return -1;
 }
 
-enum { RING = 32768, SEG = 16384 };   // the window (RFC 1951: distances up to 32 KiB) and the stretch written out at a time
+// The window the LDS holds and the stretch written out at a time.  RFC 1951 allows distances up to 32 KiB, but a
+// 32 KiB window per block is what kept the kernel at one wavefront per SIMD, and the decoder is bound by
+// instruction issue: the LDS holds the last MDX_RING bytes only, and a match that reaches further back reads its
+// source from the output already in memory (flushed at least half a ring ago).  Measured per 4 M BAM records:
+// 32 KiB 56 ms (4 blocks per CU), 16 KiB 39, 8 KiB 30, 4 KiB 24.4 (16 per CU: the register file's limit), 2 KiB 24.7.
+#ifndef MDX_RING
+#define MDX_RING 4096
+#endif
+enum { RING = MDX_RING, SEG = MDX_RING / 2 };
 
 // bytes [from, to) of the output, which the ring still holds, to `dst`
 MDX_HD void flush(const uint8_t *win, uint8_t *dst, uint32_t from, uint32_t to) {
@@ -416,7 +424,13 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 if (out + len > cap) return -2;
 #if MDX_ON_DEVICE
                 __builtin_amdgcn_wave_barrier();
-                if (len <= 64u && dist >= len) {
+                if (RING < 32768 && dist > (uint32_t)RING) {
+                    // the source has left the LDS: it is in `dst` (flushed at least SEG bytes ago; loaded past the
+                    // vector L1, which may hold an older copy of a line this wavefront has written since)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the flushes have arrived
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64u)
+                        win[(out + i) & (RING - 1)] = __hip_atomic_load(dst + (out - dist + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (len <= 64u && dist >= len) {
                     // the common case (a match is 15 bytes on average): one byte per lane, sources in front of the stretch
                     if ((uint32_t)lane < len) win[(out + (uint32_t)lane) & (RING - 1)] = win[(out - dist + (uint32_t)lane) & (RING - 1)];
                 } else if (dist >= 64u) {
@@ -431,7 +445,8 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 }
                 __builtin_amdgcn_wave_barrier();
 #else
-                for (uint32_t i = 0; i < len; i++) win[(out + i) & (RING - 1)] = win[(out - dist + i) & (RING - 1)];
+                if (RING < 32768 && dist > (uint32_t)RING) for (uint32_t i = 0; i < len; i++) win[(out + i) & (RING - 1)] = dst[out - dist + i];
+                else for (uint32_t i = 0; i < len; i++) win[(out + i) & (RING - 1)] = win[(out - dist + i) & (RING - 1)];
 #endif
                 out += len;
                 if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
