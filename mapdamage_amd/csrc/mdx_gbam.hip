@@ -27,7 +27,10 @@ typedef uint64_t u64;
 __device__ __forceinline__ u32 g16(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8); }
 __device__ __forceinline__ u32 g32(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 
-__global__ __launch_bounds__(64) void gbam_inflate_kernel(const u8 *__restrict__ comp, const uint4 *__restrict__ blk,
+#ifndef MDX_INFL_WPS
+#define MDX_INFL_WPS 4
+#endif
+__global__ __launch_bounds__(64, MDX_INFL_WPS) void gbam_inflate_kernel(const u8 *__restrict__ comp, const uint4 *__restrict__ blk,
                                                            u8 *__restrict__ unc, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     u8 *const win = lds;                                                       // the window (mdx_inflate::RING bytes)
