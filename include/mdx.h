@@ -282,6 +282,12 @@ const char *mdx_gbam_error(const mdx_gbam *g);
 int mdx_gbam_configure(mdx_gbam *g, int32_t n_rg, const char *const *rg_ids, const int32_t *lib_of_rg, int32_t lib_default,
                        int want_qual, int want_mate);
 int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *dev_view, const int32_t **d_mtid, const int32_t **d_mpos);
+/* --min-basequal on the device path (needs want_qual): records none of whose qualities is below the threshold get
+ * MDX_FLAG_QUAL_ABOVE_MIN in the flag column, a slab without a single maskable record is handed over without its
+ * quality column (the unmasked kernel), and mdx_gbam_missing_qualities says whether a record the kernel counts has
+ * come by without qualities so far (what main.py:185-192 warns about). */
+int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual);
+int mdx_gbam_missing_qualities(const mdx_gbam *g);
 int mdx_gbam_at_end(const mdx_gbam *g);
 void mdx_gbam_close(mdx_gbam *g);
 

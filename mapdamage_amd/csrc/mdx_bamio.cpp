@@ -809,6 +809,8 @@ struct mdx_gbam {
     size_t next_block = 0;               // first block not decoded yet
     std::string error;
     bool want_qual = false, want_mate = false;
+    int minqual = 0;                     // --min-basequal on the device path (mdx_gbam_set_min_basequal)
+    bool no_qual_seen = false;           // a counted record without qualities has come by
     // read groups
     std::vector<uint8_t> rg_names;
     std::vector<uint32_t> rg_off;
@@ -1010,6 +1012,9 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         c.seq = (uint8_t *)g->seq.p; c.qual = g->want_qual ? (uint8_t *)g->qual.p : nullptr;
         c.rg_names = (const uint8_t *)g->d_rg_names; c.rg_off = (const uint32_t *)g->d_rg_off; c.lib_of_rg = (const int32_t *)g->d_lib_of_rg;
         c.n_rg = (int)g->lib_of_rg.size(); c.lib_default = g->lib_default;
+        uint32_t *d_counters = (uint32_t *)((char *)g->small.p + 48);
+        c.minqual = g->want_qual ? g->minqual : 0; c.counters = d_counters;
+        if (c.minqual > 0 && hipMemsetAsync(d_counters, 0, 8, st) != hipSuccess) return MDX_ERR_HIP;
         mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
                           (uint32_t)tot[0], (uint32_t *)g->rec_off.p, c, st);
         if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
@@ -1017,6 +1022,12 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
         view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
         view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
+        if (c.minqual > 0) {
+            uint32_t counters[2] = {0, 0};
+            if (hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
+            if (counters[0]) g->no_qual_seen = true;
+            if (counters[1] == 0) view->qual = nullptr;       // nothing in this slab can be masked: the unmasked kernel
+        }
         if (d_mtid) *d_mtid = c.mtid;
         if (d_mpos) *d_mpos = c.mpos;
         g->next_block = b1;
@@ -1028,6 +1039,14 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         return MDX_ERR_ARG;
     }
 }
+
+int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual) {
+    if (!g || minqual < 0 || minqual > 93) return MDX_ERR_ARG;
+    g->minqual = minqual;
+    return MDX_OK;
+}
+
+int mdx_gbam_missing_qualities(const mdx_gbam *g) { return (g && g->no_qual_seen) ? 1 : 0; }
 
 int mdx_gbam_at_end(const mdx_gbam *g) { return (!g || (g->next_block >= g->blocks.size() && g->whole_file_scanned())) ? 1 : 0; }
 

@@ -182,13 +182,31 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
             s[k] = (u8)letter((k & 1u) ? (byte & 15u) : (byte >> 4));
         }
     q += (l_seq + 1u) / 2u;
+    u32 qmin = 0xFFu;                                  // lowest quality of the record (0xFF: none)
     if (c.qual) {
         u8 *__restrict__ ql = c.qual + so;
-        for (u32 k = j; k < n4; k += 8u) *(u32u *)(ql + 4 * k) = g32(q + 4 * k);
+        for (u32 k = j; k < n4; k += 8u) {
+            const u32 w = g32(q + 4 * k);
+            *(u32u *)(ql + 4 * k) = w;
+            const u32 a = w & 0xFFu, b = (w >> 8) & 0xFFu, cc = (w >> 16) & 0xFFu, d = w >> 24;
+            const u32 m = min(min(a, b), min(cc, d));
+            qmin = m < qmin ? m : qmin;
+        }
         if (j == 0)
-            for (u32 k = 4 * n4; k < l_seq; k++) ql[k] = q[k];
+            for (u32 k = 4 * n4; k < l_seq; k++) { ql[k] = q[k]; qmin = q[k] < qmin ? q[k] : qmin; }
+        if (c.minqual > 0)
+            for (int o = 1; o < 8; o <<= 1) { const u32 other = (u32)__shfl_xor((int)qmin, o); qmin = other < qmin ? other : qmin; }
     }
     if (j != 0) return;
+    if (c.qual && c.minqual > 0) {
+        // --min-basequal: a record none of whose qualities is below the threshold cannot be masked (flag bit
+        // MDX_FLAG_QUAL_ABOVE_MIN: the tabulation kernel skips its quality windows); a counted record without
+        // qualities is what main.py:185-192 warns about
+        const u32 fl = g16(p + 14);
+        if (qmin >= (u32)c.minqual) c.flag[r] = (uint16_t)(fl | 0x8000u);
+        else atomicAdd(c.counters + 1, 1u);
+        if ((fl & 0xF04u) == 0 && (l_seq == 0 || q[0] == 0xFFu)) atomicOr(c.counters, 1u);
+    }
     q += l_seq;
     // library: the RG:Z tag against the header's read groups
     int lib = c.lib_default;

@@ -197,6 +197,10 @@ struct MdxGbamCols {
     const uint32_t *rg_off;
     const int32_t *lib_of_rg;
     int n_rg, lib_default;
+    // --min-basequal (0: off; needs qual): counters[0] |= 1 when a counted record has no qualities, counters[1] += the
+    // records that hold a quality below the threshold
+    int minqual;
+    uint32_t *counters;
 };
 size_t mdx_k_gbam_inflate_lds();
 hipError_t mdx_k_gbam_prepare();

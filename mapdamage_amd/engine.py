@@ -32,7 +32,7 @@ EXPORTS = (
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
     "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled", "mdx_bam_qmin",
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
-    "mdx_gbam_at_end", "mdx_gbam_close",
+    "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
 )
 
 
@@ -121,6 +121,8 @@ def load_library(path=None):
                                        ctypes.c_int, ctypes.c_int]
     lib.mdx_gbam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mdx_gbam_at_end.argtypes = [ctypes.c_void_p]
+    lib.mdx_gbam_set_min_basequal.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mdx_gbam_missing_qualities.argtypes = [ctypes.c_void_p]
     lib.mdx_gbam_close.restype = None
     lib.mdx_gbam_close.argtypes = [ctypes.c_void_p]
     if path is None:

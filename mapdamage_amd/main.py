@@ -82,7 +82,7 @@ def build_parser():
     g.add_argument("--gpu-decode", action="store_true",
                    help="inflate and unpack a BAM file on the GPU (include/mdx.h mdx_gbam_*): the compressed file goes "
                         "to HBM, the batch columns never exist on the host.  Falls back to the host decoder for SAM "
-                        "input, --downsample, --min-basequal and files whose BGZF blocks do not start at records")
+                        "input, --downsample and files whose BGZF blocks do not start at records")
     g.add_argument("--chunk-mb", type=_ranged(float, 0), default=1024,
                    help="decode a BAM file in chunks of this many MiB of uncompressed records, overlapped with "
                         "the tabulation of the previous chunk (0: decode the whole file first)")
@@ -201,8 +201,7 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
     """--gpu-decode: the file inflated, unpacked and counted on the GPU.  None: not a case for it (the caller decodes
     on the host, which also words the errors the way the reference does)."""
     from .sam import GpuBamStream, GpuDecodeUnsupported, is_bam
-    if (str(options.filename) == "-" or not is_bam(options.filename) or options.downsample is not None
-            or options.minqual != 0):
+    if str(options.filename) == "-" or not is_bam(options.filename) or options.downsample is not None:
         logger.info("--gpu-decode does not apply to this run; decoding on the host")
         return None
     if options.merge_libraries:
@@ -211,16 +210,20 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
         readgroups = [(rg, libraries.index(lib)) for rg, lib in reader._readgroups.items()]
         lib_default = None
     try:
-        with DamageEngine(libraries, options.length, options.around, 0, device=options.device) as engine:
+        with DamageEngine(libraries, options.length, options.around, options.minqual, device=options.device) as engine:
             engine.set_reference(ref)
+            warned_about_quals = False
             # (a slab of compressed bytes inflates to about four times its size)
             slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
             with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
-                              chunk_bytes=slab) as stream:
+                              chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
                 while True:
                     view = stream.next_view()
                     if view is None:
                         break
+                    if options.minqual and not warned_about_quals and stream.missing_qualities():
+                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                        warned_about_quals = True
                     engine.tabulate_view(view)
                 return engine.finish()
     except GpuDecodeUnsupported as error:

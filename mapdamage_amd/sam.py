@@ -373,7 +373,7 @@ class GpuBamStream:
     do not start at records — the caller then decodes on the host (``BamStream``)."""
 
     def __init__(self, engine, path, readgroups=(), lib_default=None, chunk_bytes=256 << 20, want_qual=False,
-                 want_mate=False):
+                 want_mate=False, min_basequal=0):
         import ctypes
         self._lib = engine._lib
         self._engine = engine
@@ -394,6 +394,13 @@ class GpuBamStream:
                                           int(bool(want_qual)), int(bool(want_mate)))
         if rc != 0:
             raise ValueError("%r: %s" % (str(path), self._error()))
+        if min_basequal:
+            # --min-basequal: unmaskable records are flagged on the device, see ``missing_qualities``
+            self._lib.mdx_gbam_set_min_basequal(self._g, int(min_basequal))
+
+    def missing_qualities(self):
+        """A record the kernel counts has come by without qualities (main.py:185-192 warns once)."""
+        return bool(self._lib.mdx_gbam_missing_qualities(self._g))
 
     def _error(self):
         return self._lib.mdx_gbam_error(self._g).decode() if self._g else "GPU BAM decode failed"

@@ -95,6 +95,7 @@ def test_tables_from_device_decode_equal_oracle(tmp_path):
 
 
 @pytest.mark.parametrize("golden,extra", [("config1_L70_A10_Q0", []), ("config1_merged_L70_A10_Q0", ["--merge-libraries"]),
+                                          ("config1_L70_A10_Q20", ["-Q", "20"]), ("indelshapes_L70_A10_Q20", ["-Q", "20"]),
                                           ("indelshapes_L70_A10_Q0", []), ("edge_L70_A10_Q0", []), ("config4s_L70_A10", [])])
 def test_cli_gpu_decode_writes_the_reference_tables(tmp_path, golden, extra):
     """`python -m mapdamage_amd --gpu-decode`: the three tables of the reference, byte for byte, from a file that was
@@ -107,7 +108,7 @@ def test_cli_gpu_decode_writes_the_reference_tables(tmp_path, golden, extra):
     g = Golden(golden)
     rgs = [{"ID": "rg%d" % i, "SM": s, "LB": l} for i, (s, l) in enumerate(g.meta["libraries"])]
     raw_lib = np.load(str(pathlib.Path(__file__).parent / "golden" / (golden + ".npz")))["lib"]
-    if extra:
+    if "--merge-libraries" in extra:
         rgs = [{"ID": "rg0", "SM": "a", "LB": "b"}, {"ID": "rg1", "SM": "c", "LB": "d"}]
         rg_of = ["rg%d" % (i % 2) for i in range(g.batch.n)]
     else:
@@ -305,3 +306,36 @@ def test_block_crc_is_checked_on_the_device(tmp_path):
             while (v := g.next_view()) is not None:
                 n += int(v.n_reads)
         assert n == b.n
+
+
+def test_min_basequal_on_the_device_path(tmp_path):
+    """-Q on the GPU decode path: the tables of the host path; the warning about reads without qualities; a file
+    whose qualities are all above the threshold goes through the unmasked kernel and still gives the -Q 0 tables."""
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    ref, b, rg, path = _write(tmp_path, n=20_000, seed=8)
+    # a few records without qualities
+    b2 = b
+    rng = np.random.default_rng(3)
+    for i in rng.choice(b2.n, 40, replace=False):
+        b2.qual[b2.seq_off[i]:b2.seq_off[i + 1]] = 0xFF
+    p2 = tmp_path / "noq.bam"
+    sam.write_bam(str(p2), b2, ref.names, ref.lengths, RGS, rg_of_record=rg)
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    outs = {}
+    for name, flags in (("host", []), ("dev", ["--gpu-decode", "--chunk-mb", "2"])):
+        out = tmp_path / name
+        assert main(["-i", str(p2), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "-Q", "25"] + flags) == 0
+        outs[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
+        log = (out / "Runtime_log.txt").read_text()
+        assert log.count("Reads without PHRED scores found") == 1, name
+    assert outs["host"] == outs["dev"]
+    assert "decoding on the host" not in (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    # threshold below every quality: nothing to mask
+    lo = int(b.qual[b.qual != 0xFF].min())
+    res = {}
+    for name, flags in (("q0", []), ("qlow", ["-Q", str(max(lo, 1)), "--gpu-decode"])):
+        out = tmp_path / name
+        assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
+        res[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
+    assert res["q0"] == res["qlow"]
