@@ -249,6 +249,7 @@ MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_
 #define MDX_RING 4096
 #endif
 enum { RING = MDX_RING, SEG = MDX_RING / 2 };
+static_assert(RING >= 2048 && RING <= 32768 && (RING & (RING - 1)) == 0, "the ring holds a stretch being flushed plus one step of the decoder (258 + 8 bytes)");
 
 // bytes [from, to) of the output, which the ring still holds, to `dst`
 MDX_HD void flush(const uint8_t *win, uint8_t *dst, uint32_t from, uint32_t to) {
@@ -365,6 +366,9 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #endif
             const Counts kll = counts_of(t.count_ll), kd = counts_of(t.count_d);
             for (;;) {
+                // the one place a finished stretch leaves the ring (a step of the loop adds at most 258 bytes: the
+                // stretch is still whole in the ring, and still older than anything a far match may ask for)
+                if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                 in.refill();               // 56 bits: the whole symbol pair below needs at most 48
                 int s;
 #if MDX_ON_DEVICE
@@ -389,7 +393,6 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                         if ((uint32_t)lane < nlit) win[(out + (uint32_t)lane) & (RING - 1)] = (uint8_t)(lits >> (8u * (uint32_t)lane));
                         out += nlit;
                         in.drop(pbit);
-                        if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                         continue;
                     }
                     // the symbol at bit 0 is no literal with a short code
@@ -404,7 +407,6 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                     if (out >= cap) return -2;
                     win[out & (RING - 1)] = (uint8_t)s;  // (every lane stores the same byte: cheaper than masking 63 off)
                     out++;
-                    if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                     continue;
                 }
                 if (s == 256) break;
@@ -449,7 +451,6 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 else for (uint32_t i = 0; i < len; i++) win[(out + i) & (RING - 1)] = win[(out - dist + i) & (RING - 1)];
 #endif
                 out += len;
-                if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                 // (input that ends early decodes as zeros: caught at the end of the block, the output is bounded by cap)
             }
         } else {
