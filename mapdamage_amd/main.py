@@ -79,10 +79,12 @@ def build_parser():
                    help="EXPERIMENTAL: also write 5pCtoT_freq.txt / 3pGtoA_freq.txt (mapDamage 2.0-2.2 outputs that "
                         "this reference snapshot no longer produces; format unpinned)")
     g.add_argument("--batch-reads", type=int, default=4_000_000, help="records per device batch")
-    g.add_argument("--gpu-decode", action="store_true",
+    g.add_argument("--gpu-decode", dest="gpu_decode", action="store_true", default=True,
                    help="inflate and unpack a BAM file on the GPU (include/mdx.h mdx_gbam_*): the compressed file goes "
-                        "to HBM, the batch columns never exist on the host.  Falls back to the host decoder for SAM "
-                        "input, --downsample and files whose BGZF blocks do not start at records")
+                        "to HBM, the batch columns never exist on the host (the default; SAM input, --downsample and "
+                        "files whose BGZF blocks do not start at records are decoded on the host)")
+    g.add_argument("--host-decode", dest="gpu_decode", action="store_false",
+                   help="decode on the host (multi-threaded BGZF/BAM decoder) even where the GPU path applies")
     g.add_argument("--chunk-mb", type=_ranged(float, 0), default=1024,
                    help="decode a BAM file in chunks of this many MiB of uncompressed records, overlapped with "
                         "the tabulation of the previous chunk (0: decode the whole file first)")
@@ -202,7 +204,7 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
     on the host, which also words the errors the way the reference does)."""
     from .sam import GpuBamStream, GpuDecodeUnsupported, is_bam
     if str(options.filename) == "-" or not is_bam(options.filename) or options.downsample is not None:
-        logger.info("--gpu-decode does not apply to this run; decoding on the host")
+        logger.debug("the GPU decode path does not apply to this run; decoding on the host")
         return None
     if options.merge_libraries:
         readgroups, lib_default = [], 0

@@ -152,7 +152,7 @@ def test_layouts_the_device_path_does_not_take(tmp_path):
                 eng.sync()
     fasta.write_fasta(tmp_path / "ref.fa", ref)
     outs = []
-    for name, flags in (("host", []), ("dev", ["--gpu-decode"])):
+    for name, flags in (("host", ["--host-decode"]), ("dev", ["--gpu-decode"])):
         out = tmp_path / name
         assert main(["-i", str(odd), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
         outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
@@ -188,7 +188,7 @@ def test_empty_file_and_records_without_read_group(tmp_path):
     sam.write_bam(str(p1), b, ref.names, ref.lengths, RGS, rg_of_record=None)
     fasta.write_fasta(tmp_path / "ref.fa", ref)
     outs = []
-    for name, flags in (("host", []), ("dev", ["--gpu-decode"])):
+    for name, flags in (("host", ["--host-decode"]), ("dev", ["--gpu-decode"])):
         out = tmp_path / name
         assert main(["-i", str(p1), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "--merge-libraries"] + flags) == 0
         outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
@@ -323,7 +323,7 @@ def test_min_basequal_on_the_device_path(tmp_path):
     sam.write_bam(str(p2), b2, ref.names, ref.lengths, RGS, rg_of_record=rg)
     fasta.write_fasta(tmp_path / "ref.fa", ref)
     outs = {}
-    for name, flags in (("host", []), ("dev", ["--gpu-decode", "--chunk-mb", "2"])):
+    for name, flags in (("host", ["--host-decode"]), ("dev", ["--gpu-decode", "--chunk-mb", "2"])):
         out = tmp_path / name
         assert main(["-i", str(p2), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "-Q", "25"] + flags) == 0
         outs[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
@@ -334,7 +334,7 @@ def test_min_basequal_on_the_device_path(tmp_path):
     # threshold below every quality: nothing to mask
     lo = int(b.qual[b.qual != 0xFF].min())
     res = {}
-    for name, flags in (("q0", []), ("qlow", ["-Q", str(max(lo, 1)), "--gpu-decode"])):
+    for name, flags in (("q0", ["--host-decode"]), ("qlow", ["-Q", str(max(lo, 1)), "--gpu-decode"])):
         out = tmp_path / name
         assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
         res[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
