@@ -15,7 +15,7 @@ import numpy as np
 
 from . import __version__
 from .batch import mark_unmaskable
-from .engine import BadReadError, DamageEngine
+from .engine import BadReadError, DamageEngine, MdxError
 from .fasta import compare_sequence_dicts, read_fasta_index, reference_for_bam
 from .reader import BAMReader
 from .sam import BAMError
@@ -233,6 +233,10 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
     except BadReadError:
         # a record the reference cannot process, or one without a usable read group: the host path names it
         logger.info("the GPU decode path met a record it cannot count; decoding on the host")
+    except (ValueError, MdxError) as error:
+        # a damaged file (the host decoder finds the same damage and words the error), or the device path out of
+        # memory: either way the host path has the last word
+        logger.info("GPU decode path: %s; decoding on the host", error)
     return None
 
 

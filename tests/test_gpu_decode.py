@@ -285,10 +285,10 @@ def test_block_crc_is_checked_on_the_device(tmp_path):
     import struct
 
     from mapdamage_amd.engine import DamageEngine
-    ref, b, rg, path = _write(tmp_path, n=6000)
+    ref, b, rg, path = _write(tmp_path, n=12000)
     raw = bytearray(path.read_bytes())
     off = 0
-    for _ in range(3):
+    for _ in range(30):          # (a block behind the first megabyte, which the header parse on the host inflates)
         off += struct.unpack_from("<H", raw, off + 16)[0] + 1
     bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
     raw[off + bsize - 7] ^= 0x40
@@ -306,6 +306,13 @@ def test_block_crc_is_checked_on_the_device(tmp_path):
             while (v := g.next_view()) is not None:
                 n += int(v.n_reads)
         assert n == b.n
+    # the command line: the device path reports the damage, the host decoder has the last word
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    with pytest.raises(ValueError, match="CRC32"):
+        main(["-i", str(bad), "-r", str(tmp_path / "ref.fa"), "-d", str(tmp_path / "out"), "--no-stats"])
+    assert "GPU decode path" in (tmp_path / "out" / "Runtime_log.txt").read_text()
 
 
 def test_min_basequal_on_the_device_path(tmp_path):
