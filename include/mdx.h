@@ -272,7 +272,8 @@ int mdx_table_mode(const mdx_ctx *ctx);
  * counts, as is a read group the header does not list), and whether the quality and mate columns are wanted.
  * Every BGZF block must start at a record (htslib writes them so: bgzf_flush_try in bam_write1) and the header must
  * fill blocks of its own: any other layout is MDX_ERR_UNSUPPORTED, and the caller decodes on the host instead.  The
- * CRC32 of every block is checked on the device, like its ISIZE (MDX_ERR_ARG, as in the host decoder).  mdx_gbam_next at the end of the file: MDX_OK, n_reads 0,
+ * CRC32 of every block is checked on the device, like its ISIZE (MDX_ERR_ARG, as in the host decoder).
+ * chunk_bytes: compressed bytes per slab.  mdx_gbam_next at the end of the file: MDX_OK, n_reads 0,
  * mdx_gbam_at_end 1.  mdx_ctx_stream: the HIP stream (hipStream_t) and device the context works on. */
 typedef struct mdx_gbam mdx_gbam;
 int mdx_ctx_stream(mdx_ctx *ctx, void **stream, int *device);
