@@ -393,7 +393,9 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                         if ((uint32_t)lane < nlit) win[(out + (uint32_t)lane) & (RING - 1)] = (uint8_t)(lits >> (8u * (uint32_t)lane));
                         out += nlit;
                         in.drop(pbit);
-                        continue;
+                        // the match behind the run in the same step when the buffer still holds all of it (its length
+                        // code is known already: what follows needs up to 5 + 15 + 13 bits)
+                        if (!(nlit < 8u && ep && (ep >> 4) > 256u && in.nbits >= (int)(ep & 15u) + 33)) continue;
                     }
                     // the symbol at bit 0 is no literal with a short code
                     if (ep) { s = (int)(ep >> 4); in.drop((int)(ep & 15u)); }
