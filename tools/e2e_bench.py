@@ -1,7 +1,9 @@
 """End-to-end rate from a BAM file on disk to the three tables (N1 row): synthetic config-3 records with one read
 group are written as a BAM, then timed stage by stage — native multi-threaded BGZF/BAM decode (mdx_bam_*), flag
-filter + library column (reader.py), tabulation from host buffers (mdx_tabulate_host: H2D + kernel), finish.
-The tables are checked against the C oracle.  Run on the GPU box: python tools/e2e_bench.py [reads]"""
+filter + library column (reader.py), tabulation from host buffers (mdx_tabulate_host: H2D + kernel), finish; then the
+same file through the chunked host decoder (the command line's --host-decode path) and through the GPU decode path
+(mdx_gbam_*: compressed bytes to HBM, inflate + CRC32 + unpack + tabulation on the device; the command line's default).
+The tables of every variant are checked against the C oracle.  Run on the GPU box: python tools/e2e_bench.py [reads]"""
 import json
 import os
 import pathlib
