@@ -15,7 +15,7 @@ namespace mdx_crc32 {
 enum { N_MATS = 17 };   // operators for 2^0 .. 2^16 zero bytes (a BGZF block holds at most 2^16)
 
 struct Tables {
-    uint32_t tab[256];
+    uint32_t tab[4][256];        // slicing-by-4: tab[0] is the byte table, tab[k][i] = tab[0] applied k more times
     uint32_t mat[N_MATS][32];
 };
 
@@ -30,8 +30,10 @@ inline void make_tables(Tables &t) {
     for (uint32_t i = 0; i < 256; i++) {
         uint32_t c = i;
         for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        t.tab[i] = c;
+        t.tab[0][i] = c;
     }
+    for (uint32_t i = 0; i < 256; i++)
+        for (int k = 1; k < 4; k++) t.tab[k][i] = t.tab[0][t.tab[k - 1][i] & 0xFFu] ^ (t.tab[k - 1][i] >> 8);
     uint32_t a[32], b[32];
     a[0] = 0xEDB88320u;                                   // one zero bit
     for (int n = 1; n < 32; n++) a[n] = 1u << (n - 1);
@@ -41,9 +43,16 @@ inline void make_tables(Tables &t) {
     for (int k = 1; k < N_MATS; k++) gf2_square(t.mat[k], t.mat[k - 1]);
 }
 
+// tab: the four 256-entry tables, one after the other
 MDX_CRC_HD uint32_t crc_bytes(const uint32_t *tab, const uint8_t *p, uint32_t n) {
     uint32_t c = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < n; i++) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    uint32_t i = 0;
+    for (; i + 4u <= n; i += 4u) {
+        typedef uint32_t u32u __attribute__((aligned(1)));
+        c ^= *(const u32u *)(p + i);
+        c = tab[768 + (c & 0xFFu)] ^ tab[512 + ((c >> 8) & 0xFFu)] ^ tab[256 + ((c >> 16) & 0xFFu)] ^ tab[c >> 24];
+    }
+    for (; i < n; i++) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
     return c ^ 0xFFFFFFFFu;
 }
 

@@ -46,14 +46,14 @@ __global__ __launch_bounds__(64, MDX_INFL_WPS) void gbam_inflate_kernel(const u8
 }
 
 // The CRC32 of every block's inflated bytes against the one in its gzip trailer (htslib, behind the reference's pysam,
-// refuses a block that fails it): one wavefront per block, 1 KiB per lane through the byte table (in the LDS), the 64
+// refuses a block that fails it): one wavefront per block, 1 KiB per lane, four bytes per step (tables in the LDS), the 64
 // partial values joined by lane 0 with the "append n zero bytes" matrices.  bad = the lowest failing block.
 __global__ __launch_bounds__(64) void gbam_crc_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk,
                                                        const u32 *__restrict__ want, const mdx_crc32::Tables *__restrict__ tb,
                                                        int *__restrict__ bad) {
-    __shared__ u32 tab[256];
+    __shared__ u32 tab[1024];
     const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) tab[i] = tb->tab[i];
+    for (int i = lane; i < 1024; i += 64) tab[i] = (&tb->tab[0][0])[i];
     __syncthreads();
     const uint4 e = blk[blockIdx.x];
     const u32 n = e.w;

@@ -20,7 +20,7 @@ int main() {
             bool first = true;
             for (unsigned o = 0; o < len || first; o += 1024) {
                 const unsigned m = len - o < 1024 ? len - o : 1024;
-                const uint32_t c = mdx_crc32::crc_bytes(t.tab, d.data() + o, m);
+                const uint32_t c = mdx_crc32::crc_bytes(&t.tab[0][0], d.data() + o, m);
                 total = first ? c : (mdx_crc32::shift(t.mat, total, m) ^ c);
                 first = false;
                 if (len == 0) break;
