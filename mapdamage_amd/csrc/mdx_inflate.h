@@ -70,7 +70,7 @@ MDX_HD int lane_count() { return MDX_ON_DEVICE ? 64 : 1; }
 
 // eight bytes at byte offset `at` of the n input bytes, zero beyond the end
 MDX_HD uint64_t load8(const uint8_t *p, uint32_t n, uint32_t at) {
-    if (at + 8u <= n) {
+    if (__builtin_expect(at + 8u <= n, 1)) {
         // (a block's payload starts at an arbitrary byte of the file: an unaligned 8-byte load is one instruction)
         typedef uint64_t u64u __attribute__((aligned(1)));
         return *(const u64u *)(p + at);
@@ -135,7 +135,7 @@ struct BitIn {
     MDX_HD void refill() {
         if (nbits >= 48) return;                  // (still enough for a whole symbol pair)
 #if MDX_ON_DEVICE
-        if ((pos & ~511u) != held_at) reload(pos);
+        if (__builtin_expect((pos & ~511u) != held_at, 0)) reload(pos);
 #endif
         const uint32_t at = pos & ~7u, sh = (pos & 7u) * 8u;
         uint64_t w = word_at(at) >> sh;
@@ -226,7 +226,7 @@ MDX_HD Counts counts_of(const uint16_t *count) {
 // one symbol; -1: invalid code
 MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
     const uint32_t e = uni(fast[in.peek(fast_bits)]);
-    if (e) { in.drop((int)(e & 15u)); return (int)(e >> 4); }
+    if (__builtin_expect(e != 0u, 1)) { in.drop((int)(e & 15u)); return (int)(e >> 4); }
     // canonical walk, one bit at a time (codes longer than fast_bits)
     int code = 0, first = 0, index = 0;
     uint64_t b = in.bits;
@@ -368,7 +368,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
             for (;;) {
                 // the one place a finished stretch leaves the ring (a step of the loop adds at most 258 bytes: the
                 // stretch is still whole in the ring, and still older than anything a far match may ask for)
-                if (out - flushed >= SEG) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
+                if (__builtin_expect(out - flushed >= SEG, 0)) { flush(win, dst, flushed, flushed + SEG); flushed += SEG; }
                 in.refill();               // 56 bits: the whole symbol pair below needs at most 48
                 int s;
 #if MDX_ON_DEVICE
@@ -428,7 +428,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 if (out + len > cap) return -2;
 #if MDX_ON_DEVICE
                 __builtin_amdgcn_wave_barrier();
-                if (RING < 32768 && dist > (uint32_t)RING) {
+                if (RING < 32768 && __builtin_expect(dist > (uint32_t)RING, 0)) {
                     // the source has left the LDS: it is in `dst` (flushed at least SEG bytes ago; loaded past the
                     // vector L1, which may hold an older copy of a line this wavefront has written since)
                     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the flushes have arrived
