@@ -42,7 +42,10 @@ extern "C" {
 /* Optional hint in the `flag` column (a bit SAM does not define): every base quality of the record is at least
  * --min-basequal, so nothing of it can be masked (align.py:65-71 masks only qualities below the threshold).  The
  * kernel then skips the record's quality window loads.  The caller vouches for it (mdx_bam_qmin gives the lowest
- * quality of each record; mapdamage_amd.batch.mark_unmaskable sets the bit); without the bit nothing changes. */
+ * quality of each record; mapdamage_amd.batch.mark_unmaskable sets the bit); without the bit nothing changes.
+ * SAM defines FLAG bits 0..11 only, but a file may carry anything in its 16 bits: the decoders of this library
+ * (mdx_bam_*, mdx_gbam_*, the SAM text parser) clear bit 15 of what they read, and a caller that packs its own flag
+ * column must do the same unless it vouches for the record. */
 #define MDX_FLAG_QUAL_ABOVE_MIN 0x8000
 
 #define MDX_N_MIS_COLS 25         /* mapdamage/seq.py:6-30 without the derived "Total" */
@@ -133,7 +136,9 @@ int mdx_finish_device(mdx_ctx *ctx, uint64_t *d_tables);
  * copies the canonical tables to host memory.  lgd_over receives (lib, kind, strand, length)
  * quadruples for lengths >= lgd_max (at most lgd_over_cap); any pointer may be NULL.
  * With a communicator attached (mdx_comm_init / mdx_comm_adopt) the call is collective and returns the
- * totals over all ranks on every rank. */
+ * totals over all ranks on every rank; lgd_over then receives the lists of all ranks in rank order (every rank is
+ * bounded by the context's lgd_over_cap, so mdx_comm_size() x that many entries always suffice) and a buffer too
+ * small for them is MDX_ERR_LGD_OVERFLOW, never a shortened list. */
 int mdx_finish(mdx_ctx *ctx, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t *lgd_over,
                int64_t lgd_over_cap, int64_t *n_lgd_over, int64_t *n_kept);
 

@@ -193,7 +193,9 @@ def mark_unmaskable(batch, minqual, qmin=None):
         return batch, True
     qmin = record_min_quality(batch) if qmin is None else np.asarray(qmin)
     fine = qmin >= minqual            # (0xFF: no qualities at all — never masked either)
-    batch.flag = np.where(fine, batch.flag | np.uint16(FLAG_QUAL_ABOVE_MIN), batch.flag).astype(np.uint16)
+    # the bit is this function's to set: whatever the column held there before (a FLAG with bit 15 set in a file) is not a hint
+    base = batch.flag & np.uint16(0x7FFF)
+    batch.flag = np.where(fine, base | np.uint16(FLAG_QUAL_ABOVE_MIN), base).astype(np.uint16)
     return batch, bool(fine.all())
 
 
@@ -230,9 +232,14 @@ class Reference:
         return [len(s) for s in self.seqs]
 
     def concat(self):
-        """(bases u8[total], contig_off i64[n+1])."""
-        offs = np.zeros(len(self.seqs) + 1, np.int64)
-        for i, s in enumerate(self.seqs):
-            offs[i + 1] = offs[i] + len(s)
-        bases = np.frombuffer(b"".join(self.seqs), dtype=np.uint8).copy()
-        return bases, offs
+        """(bases u8[total], contig_off i64[n+1]); built once per object (a genome of human size is not joined again
+        for every caller), read-only."""
+        cat = self.__dict__.get("_cat")
+        if cat is None or cat[2] != [id(s) for s in self.seqs]:
+            offs = np.zeros(len(self.seqs) + 1, np.int64)
+            for i, s in enumerate(self.seqs):
+                offs[i + 1] = offs[i] + len(s)
+            bases = np.frombuffer(b"".join(self.seqs), dtype=np.uint8)
+            offs.setflags(write=False)
+            cat = self.__dict__["_cat"] = (bases, offs, [id(s) for s in self.seqs])
+        return cat[0], cat[1]

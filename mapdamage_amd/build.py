@@ -41,6 +41,20 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+def build_lib_locked():
+    """build_lib() under an exclusive file lock: of several processes started together (one rank per GPU) one compiles,
+    the others wait for it and find the library built."""
+    import fcntl
+    if not needs_build():
+        return LIB
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return build_lib()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 if __name__ == "__main__":
     import sys
     build_lib(force=True, verbose=True, extra_flags=sys.argv[1:])

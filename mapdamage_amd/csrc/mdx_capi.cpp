@@ -614,11 +614,19 @@ int mdx_finish(mdx_ctx *c, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t
             int64_t nov = (int64_t)tail[1];
             if (n_lgd_over) *n_lgd_over = nov;
             if (lgd_over && nov > 0) {
-                if (nov > lgd_over_cap) nov = lgd_over_cap;
                 if (r) {
-                    if (nov > (int64_t)gathered.size() / 4) nov = (int64_t)gathered.size() / 4;
+                    // the gathered list of all ranks: every rank stays within lgd_over_cap (mdx_sync), their sum need not
+                    // stay within the caller's buffer — an error, not a silently shortened list
+                    nov = (int64_t)gathered.size() / 4;
+                    if (nov > lgd_over_cap) {
+                        (void)hipFree(d);
+                        return fail(c, MDX_ERR_LGD_OVERFLOW, "the out-of-range fragment lengths of all ranks exceed the "
+                                    "caller's lgd_over buffer (give it comm_size x lgd_over_cap entries)");
+                    }
+                    if (n_lgd_over) *n_lgd_over = nov;
                     std::memcpy(lgd_over, gathered.data(), (size_t)nov * 32);
                 } else {
+                    if (nov > lgd_over_cap) nov = lgd_over_cap;
                     e = hipMemcpy(lgd_over, c->d_lgd_over, (size_t)nov * 32, hipMemcpyDeviceToHost);
                 }
             }

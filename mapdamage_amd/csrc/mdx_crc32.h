@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MDX_CRC_HD __host__ __device__ __forceinline__
 #else
 #define MDX_CRC_HD inline

@@ -156,7 +156,7 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
     const u32 bs = g32(p - 4);
     const u32 l_name = p[8], n_cig = g16(p + 12), l_seq = g32(p + 16);
     if (j == 0) {
-        c.flag[r] = (uint16_t)g16(p + 14);
+        c.flag[r] = (uint16_t)(g16(p + 14) & 0x7FFFu);     // bit 15 is the hint MDX_FLAG_QUAL_ABOVE_MIN, never the file's
         c.tid[r] = (int32_t)g32(p); c.pos[r] = (int32_t)g32(p + 4);
         c.tlen[r] = (int32_t)g32(p + 28);
         if (c.mtid) { c.mtid[r] = (int32_t)g32(p + 20); c.mpos[r] = (int32_t)g32(p + 24); }
@@ -202,7 +202,7 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
         // --min-basequal: a record none of whose qualities is below the threshold cannot be masked (flag bit
         // MDX_FLAG_QUAL_ABOVE_MIN: the tabulation kernel skips its quality windows); a counted record without
         // qualities is what main.py:185-192 warns about
-        const u32 fl = g16(p + 14);
+        const u32 fl = g16(p + 14) & 0x7FFFu;
         if (qmin >= (u32)c.minqual) c.flag[r] = (uint16_t)(fl | 0x8000u);
         else atomicAdd(c.counters + 1, 1u);
         if ((fl & 0xF04u) == 0 && (l_seq == 0 || q[0] == 0xFFu)) atomicOr(c.counters, 1u);

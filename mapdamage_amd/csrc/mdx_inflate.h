@@ -10,13 +10,13 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MDX_HD __host__ __device__ __forceinline__
 #else
 #define MDX_HD inline
 #endif
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MDX_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define MDX_NOINLINE __attribute__((noinline))
@@ -24,6 +24,9 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MDX_ON_DEVICE 1
+#if !defined(__gfx950__)
+#error "the s_waitcnt immediates of this file are gfx9 encodings (vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]); the tree targets gfx950 only"
+#endif
 #else
 #define MDX_ON_DEVICE 0
 #endif

@@ -8,7 +8,7 @@
 //   * phase 2, plain records: one lane owns eight consecutive bytes of a record's window (flank and
 //     columns merged), so a wavefront step counts R = 64 / G records at once (3 at --length 70
 //     --around 10); the per-record scalars are staged in the LDS by phase 1 and read back per slot.
-//     The loads of step k+4 are issued before step k is counted (four register sets) so that the
+//     The loads of step k+3 are issued before step k is counted (PIPE_DEPTH = 3 register sets) so that the
 //     gather latency of the resident genome is hidden;
 //   * the common outcome (read base == reference base, or an A/C/G/T flank base) is one
 //     conflict-free ds_add_u32 per byte into a (lane, byte)-indexed LDS table; everything else
@@ -23,6 +23,10 @@
 #include "mdx_internal.h"
 
 #include <type_traits>
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gfx950 only: the s_waitcnt immediates (0xC07F = lgkmcnt(0), 0x0F70 = vmcnt(0)) and the inline assembly below are gfx9 encodings"
+#endif
 
 typedef uint8_t u8;
 typedef int8_t i8;

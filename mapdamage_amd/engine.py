@@ -309,7 +309,8 @@ class DamageEngine:
         mis = np.zeros((nlib, 2, 2, Ln, L.N_MIS_COLS), np.uint64)
         comp = np.zeros((nlib, 2, 2, Ln + A, 4), np.uint64)
         lgd = np.zeros((nlib, 2, 2, self.lgd_max), np.uint64)
-        cap = max(1, self.lgd_over_cap)
+        # (with a communicator the list holds every rank's entries: each rank is bounded by lgd_over_cap)
+        cap = max(1, self.lgd_over_cap) * max(1, self.comm_size)
         over = np.zeros((cap, 4), np.int64)
         n_over = ctypes.c_int64(0)
         n_kept = ctypes.c_int64(0)

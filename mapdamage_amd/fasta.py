@@ -106,9 +106,10 @@ def compare_sequence_dicts(fasta_dict, bam_dict):
     return not (problems["mismatched"] or problems["missing"])
 
 
-def reference_for_bam(fasta_path, bam_names):
+def reference_for_bam(fasta_path, bam_names, missing_ok=False):
     """Contigs of the FASTA reordered to BAM ``tid`` order (chrom lookup is by name,
-    main.py:175-180)."""
+    main.py:175-180).  ``missing_ok``: a sequence the FASTA lacks becomes an empty contig — a record that maps to it
+    is then a bad record when it is met (the reference fails in ``fetch`` at that read, not before)."""
     names, seqs = read_fasta(fasta_path)
     by_name = dict(zip(names, seqs))
-    return Reference(list(bam_names), [by_name[n] for n in bam_names])
+    return Reference(list(bam_names), [by_name.get(n, b"") if missing_ok else by_name[n] for n in bam_names])

@@ -142,13 +142,17 @@ def rescale_qual(options):
     try:
         model = RescaleModel.from_csv(options.folder / "Stats_out_MCMC_correct_prob.csv",
                                       options.rescale_length_5p, options.rescale_length_3p)
-        # the header only (the records are streamed by rescale_bam); the FASTA must provide the BAM's sequences
+        # the header only (the records are streamed by rescale_bam).  The reference's --rescale-only branch
+        # (main.py:121-124) goes straight to rescale_qual without the .fai / dictionary checks of the tabulation
+        # pass: a sequence the FASTA lacks, or holds at another length, only matters when a record maps there
+        # (fetch fails at that read) — here such a record is a bad record when the kernel meets it.
         with BamStream(options.filename) as probe:
             header = probe.header
-        fai_lengths = read_fasta_index(str(options.ref) + ".fai")
-        if not fai_lengths or not compare_sequence_dicts(fai_lengths, dict(zip(header.references, header.lengths))):
-            return 1
-        ref = reference_for_bam(options.ref, header.references)
+        ref = reference_for_bam(options.ref, header.references, missing_ok=True)
+        for name, length, have in zip(header.references, header.lengths, ref.lengths):
+            if have != length:
+                logger.warning("FASTA sequence %r is %s; the BAM header says %i bp — records mapped to it may fail",
+                               name, "missing" if not have else "%i bp" % have, length)
         with DamageEngine([("*", "*")], options.length, options.around, 0, device=options.device) as engine:
             summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model)
     except RescaleError as error:
@@ -199,11 +203,17 @@ def _tabulate_on_host(options, reader, ref, libraries, logger):
     return tables
 
 
+def _device_path_applies(options):
+    """BAM files on disk, every record wanted (--downsample draws from Python's RNG on the host)."""
+    from .sam import is_bam
+    return str(options.filename) != "-" and is_bam(options.filename) and options.downsample is None
+
+
 def _tabulate_on_device(options, reader, ref, libraries, logger):
     """--gpu-decode: the file inflated, unpacked and counted on the GPU.  None: not a case for it (the caller decodes
     on the host, which also words the errors the way the reference does)."""
-    from .sam import GpuBamStream, GpuDecodeUnsupported, is_bam
-    if str(options.filename) == "-" or not is_bam(options.filename) or options.downsample is not None:
+    from .sam import GpuBamStream, GpuDecodeUnsupported
+    if not _device_path_applies(options):
         logger.debug("the GPU decode path does not apply to this run; decoding on the host")
         return None
     if options.merge_libraries:
@@ -229,14 +239,17 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
                     engine.tabulate_view(view)
                 return engine.finish()
     except GpuDecodeUnsupported as error:
-        logger.info("%s; decoding on the host", error)
-    except BadReadError:
+        reason = "file layout the device path does not take (MDX_ERR_UNSUPPORTED): %s" % error
+    except BadReadError as error:
         # a record the reference cannot process, or one without a usable read group: the host path names it
-        logger.info("the GPU decode path met a record it cannot count; decoding on the host")
+        reason = "a record the device path cannot count (MDX_ERR_BAD_READ, record %d of its slab)" % error.read_index
     except (ValueError, MdxError) as error:
         # a damaged file (the host decoder finds the same damage and words the error), or the device path out of
         # memory: either way the host path has the last word
-        logger.info("GPU decode path: %s; decoding on the host", error)
+        reason = "%s (libmdx code %s)" % (error, getattr(error, "code", "n/a"))
+    # never silent: a regression of the device path must not show up as nothing but a slow run
+    options.gpu_decode_fallbacks = getattr(options, "gpu_decode_fallbacks", 0) + 1
+    logger.warning("GPU decode path gave up: %s; decoding on the host (the whole file again)", reason)
     return None
 
 
@@ -278,6 +291,10 @@ def main(argv):
         tables = _tabulate_on_device(options, reader, ref, libraries, logger) if options.gpu_decode else None
         if tables is None:
             tables = _tabulate_on_host(options, reader, ref, libraries, logger)
+        fallbacks = getattr(options, "gpu_decode_fallbacks", 0)
+        if options.gpu_decode:
+            logger.log(logging.WARNING if fallbacks else logging.DEBUG, "Decode path: %s; fallbacks from the device path: %d",
+                       "host decoder" if (fallbacks or not _device_path_applies(options)) else "device", fallbacks)
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)
 

@@ -157,7 +157,10 @@ def test_layouts_the_device_path_does_not_take(tmp_path):
         assert main(["-i", str(odd), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
         outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
     assert outs[0] == outs[1]
-    assert "decoding on the host" in (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    log = (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    # the fallback is loud: a WARNING that names the library's code, and the count in the run's log
+    assert "WARNING GPU decode path gave up" in log and "MDX_ERR_UNSUPPORTED" in log and "decoding on the host" in log
+    assert "WARNING Decode path: host decoder; fallbacks from the device path: 1" in log
 
 
 def test_empty_file_and_records_without_read_group(tmp_path):
@@ -346,3 +349,33 @@ def test_min_basequal_on_the_device_path(tmp_path):
         assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
         res[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
     assert res["q0"] == res["qlow"]
+
+
+def test_flag_bit_15_of_a_file_is_not_the_kernels_hint(tmp_path):
+    """MDX_FLAG_QUAL_ABOVE_MIN (0x8000) is a hint the library sets itself; a file whose FLAG field carries that bit
+    (htslib does not reject it) must still be masked by its qualities alone (align.py:53-73): every decoder clears it."""
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    from tests.util import oracle_tableset
+    ref, b, rg, _ = _write(tmp_path, n=8_000, seed=21)
+    b.qual[:] = np.random.default_rng(1).integers(2, 20, size=b.qual.shape[0]).astype(np.uint8)   # everything maskable
+    clean = b.flag.copy()
+    b.flag = (b.flag | np.uint16(0x8000)).astype(np.uint16)
+    path = tmp_path / "bit15.bam"
+    sam.write_bam(str(path), b, ref.names, ref.lengths, RGS, rg_of_record=rg)
+    assert (sam.read_bam(str(path)).batch.flag == clean).all()
+    assert (sam.read_bam_native(str(path)).batch.flag == clean).all()
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    outs = {}
+    for name, flags in (("host", ["--host-decode"]), ("dev", ["--gpu-decode"])):
+        out = tmp_path / name
+        assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "-Q", "25"] + flags) == 0
+        outs[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
+    assert outs["host"] == outs["dev"]
+    assert "decoding on the host" not in (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    # the oracle masks by the qualities alone
+    libs = [("s", "lib1"), ("s", "lib2")]
+    b.flag = clean
+    b.lib = np.asarray([0 if r in ("rgA", "x") else 1 for r in rg], np.uint16)
+    want = oracle_tableset(ref, b, libs, 70, 10, 25)
+    assert outs["host"][0] == want.misincorporation_text() and outs["host"][1] == want.dnacomp_text()

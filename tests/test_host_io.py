@@ -396,3 +396,21 @@ def test_bgzf_block_crc_is_checked(tmp_path):
         with sam.BamStream(str(bad), chunk_bytes=1 << 16) as stream:
             for _ in stream:
                 pass
+
+
+def test_decoders_clear_flag_bit_15(files, tmp_path):
+    """Bit 15 of a FLAG field is the kernel's MDX_FLAG_QUAL_ABOVE_MIN hint (include/mdx.h), never the file's: the SAM
+    text parser and both BAM decoders clear it; mark_unmaskable decides it from the qualities alone."""
+    from mapdamage_amd.batch import mark_unmaskable
+    d, ref, batch, rg_of = files
+    dirty = batch.slice(0, batch.n)
+    dirty.flag = (dirty.flag | np.uint16(0x8000)).astype(np.uint16)
+    sam.write_sam(tmp_path / "d.sam", dirty, ref.names, ref.lengths, RGS, rg_of)
+    sam.write_bam(tmp_path / "d.bam", dirty, ref.names, ref.lengths, RGS, rg_of)
+    assert (sam.read_sam(tmp_path / "d.sam").batch.flag == batch.flag).all()
+    assert (sam.read_bam(tmp_path / "d.bam").batch.flag == batch.flag).all()
+    assert (sam.read_bam_native(tmp_path / "d.bam").batch.flag == batch.flag).all()
+    marked, nothing = mark_unmaskable(dirty, 94)          # every quality is below 94: nothing may keep the bit
+    has_q = np.asarray([batch.qual[batch.seq_off[i]] != 0xFF if batch.seq_off[i + 1] > batch.seq_off[i] else False
+                        for i in range(batch.n)])
+    assert not (marked.flag[has_q] & 0x8000).any() and not nothing

@@ -442,3 +442,31 @@ def test_cli_rescale_only_rewrites_bam(tmp_path):
         else:
             assert out.has_mr[i] and body[-7:-4] == b"MRf"
             assert struct.unpack("<f", body[-4:])[0] == np.float32(want_mr[i])
+
+
+@pytest.mark.gpu
+def test_cli_rescale_only_tolerates_a_fasta_without_an_unused_contig(tmp_path):
+    """The reference's --rescale-only branch (main.py:121-124) makes no .fai / dictionary check: a FASTA that lacks a
+    header sequence no record maps to (and has no .fai) still rescales the file."""
+    from mapdamage_amd import fasta, sam
+    from mapdamage_amd.batch import Reference
+    from mapdamage_amd.main import main
+    ref, batch, model, corr_prob, want_qual, want_mr = load(tmp_path)
+    used = sorted(set(int(t) for t in batch.tid if t >= 0))
+    spare = [t for t in range(len(ref.names)) if t not in used]
+    names = list(ref.names) + ["unused_extra"]
+    lengths = list(ref.lengths) + [1234]
+    sam.write_bam(tmp_path / "in.bam", batch, names, lengths, [], None)
+    keep = [t for t in range(len(ref.names)) if t not in spare[:1]]
+    fasta.write_fasta(tmp_path / "ref.fa", Reference([ref.names[t] for t in keep], [ref.seqs[t] for t in keep]))
+    fai = tmp_path / "ref.fa.fai"
+    if fai.exists():
+        fai.unlink()
+    folder = tmp_path / "res"
+    folder.mkdir()
+    (folder / "Stats_out_MCMC_correct_prob.csv").write_bytes((tmp_path / "Stats_out_MCMC_correct_prob.csv").read_bytes())
+    rc = main(["-i", str(tmp_path / "in.bam"), "-r", str(tmp_path / "ref.fa"), "-d", str(folder), "--rescale-only",
+               "--rescale-length-5p", "12", "--rescale-length-3p", "10"])
+    assert rc == 0
+    out = sam.read_bam(folder / "in.rescaled.bam", keep_raw=True)
+    np.testing.assert_array_equal(out.batch.qual, want_qual)
