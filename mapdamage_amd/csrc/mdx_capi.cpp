@@ -196,7 +196,12 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
 
-    const int lgd_lds = cfg->lgd_max < kLgdLds ? cfg->lgd_max : kLgdLds;
+    int lgd_lds = cfg->lgd_max < kLgdLds ? cfg->lgd_max : kLgdLds;
+    // two blocks per CU need half of the LDS each: the short-fragment histogram gives way first (lengths beyond it
+    // take the dense histogram's global atomics) — at --length 70 --around 10 it ends up at 226 entries instead of 256
+    while (lgd_lds > 128 && mdx_k_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds)) > kLdsLimit / 2 &&
+           mdx_k_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, 128)) <= kLdsLimit / 2)
+        lgd_lds -= 2;
     if ((int64_t)cfg->nlib * (4LL * cfg->length * 29 + 8LL * (2LL * cfg->around + 512) +
                               4LL * lgd_lds + 128) > 0x7FFFFFF0LL || cfg->length > (1 << 24) || cfg->around > (1 << 24))
         return fail(c, MDX_ERR_ARG, "table too large (nlib * length)");

@@ -24,6 +24,13 @@
 //                                    records (slot g = lane / G); the table index of (lane, byte j) is
 //                                    tau = 64 j + lane: the 64 increments of one ds_add_u32 fall in 64
 //                                    consecutive words, and every slot has its own words.
+//   DMP [strand 2][side 2][A + L]   fast path only: difference-encoded count, by window byte (left side: b = p + A;
+//                                    right side: e, as above), of the bytes that steps of partial and single-indel
+//                                    records put into plane A of TC although they are not tasks (or are counted
+//                                    elsewhere): such a step zeroes the reference bytes outside its tasks and counts
+//                                    all eight bytes of a lane with one increment, like a complete record's step;
+//                                    a record adds +1 where such a stretch of its window begins and -1 where it ends
+//                                    (phase 1), finalize_kernel subtracts the prefix sums from the A counts.
 //   LGD [kind 2][strand 2][lgd_lds] short fragment lengths
 // followed, after the last library, by one word: number of kept reads.
 // side 0 = left-anchored (columns counted from the leftmost reference coordinate),
@@ -35,7 +42,7 @@ struct MdxDims {
     int nl8;              // 8-byte lanes per side (0: no fast path)
     int G, R;             // lanes per record, records per wavefront step
     int t_pad;            // words per TC plane: 512 with the fast path
-    int w_mis, w_cmp, w_mc, w_tc, w_lgd, w_lib;
+    int w_mis, w_cmp, w_mc, w_tc, w_dmp, w_lgd, w_lib;
     int64_t w_total;      // nlib * w_lib + 1
     // word offsets within a library: TC first (256-byte aligned planes; the optimistic increments of a gapped record
     // behind a deletion address MIS / CMP rows by position — for bytes that are not tasks the position can be a few
@@ -43,7 +50,8 @@ struct MdxDims {
     __host__ __device__ int off_tc() const { return 0; }
     __host__ __device__ int off_mis() const { return w_tc; }
     __host__ __device__ int off_cmp() const { return w_tc + w_mis; }
-    __host__ __device__ int off_lgd() const { return w_tc + w_mc; }
+    __host__ __device__ int off_dmp() const { return w_tc + w_mc; }
+    __host__ __device__ int off_lgd() const { return w_tc + w_mc + w_dmp; }
     // task -> TC index of slot 0 (slot g adds g * G)
     __host__ __device__ int tau_left(int p) const { const int b = p + A; return 64 * (b & 7) + (b >> 3); }
     __host__ __device__ int tau_right(int p) const { const int e = p + A; return 64 * (7 - (e & 7)) + nl8 + (e >> 3); }
@@ -62,6 +70,10 @@ struct MdxDims {
 };
 
 #define MDX_MAX_R 4       // records per wavefront step (staging pad = R - 1 entries)
+// staging entries (16 B) per wavefront: a tile of 64 - 64 % R records and the R - 1 entries that pad its last step
+static inline __host__ __device__ int mdx_stage_entries(const MdxDims &d) {
+    return d.R > 0 ? 64 - 64 % d.R + d.R - 1 : 64;
+}
 // copies of the dense fragment-length histogram (lengths >= lgd_lds take global atomics: a block adds to copy
 // blockIdx & (copies - 1), finalize_kernel sums them) — a paired-end library with 350 bp inserts put every
 // second record on a few hundred words of a single copy: 0.73 ms instead of 0.13 ms per 2 M records
@@ -84,8 +96,9 @@ static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd
     d.w_cmp = 2 * 2 * L * 4;
     d.w_mc = d.w_mis + d.w_cmp;
     d.w_tc = 2 * 4 * d.t_pad;
+    d.w_dmp = d.nl8 > 0 ? 2 * 2 * (A + L) : 0;
     d.w_lgd = 2 * 2 * lgd_lds;
-    d.w_lib = (d.w_tc + d.w_mc + d.w_lgd + 63) / 64 * 64;
+    d.w_lib = (d.w_tc + d.w_mc + d.w_dmp + d.w_lgd + 63) / 64 * 64;
     d.w_total = (int64_t)nlib * d.w_lib + 1;
     return d;
 }

@@ -56,7 +56,6 @@ typedef long long i64;
 #endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
-#define STG_ENT (64 + MDX_MAX_R)        // staging entries (16 B) per wavefront: 64 records + pad
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -82,9 +81,9 @@ __constant__ u8 c_comp_col[25] = {3, 2, 1, 0, 5, 4, 7, 6, 12, 13, 14, 15, 8,
                                   9, 10, 11, 17, 16, 19, 18, 21, 20, 23, 22, 24};
 
 int mdx_k_block_threads() { return MDX_BLOCK; }
-// LDS image: [tables w_total words, padded to 16 B][staging, 12 x STG_ENT x 16 B][event queues, 12 x EVQ_BYTES]
+// LDS image: [tables w_total words, padded to 16 B][staging, 12 x mdx_stage_entries x 16 B][event queues, 12 x EVQ_BYTES]
 int mdx_k_stage_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
-int mdx_k_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_BLOCK / 64) * STG_ENT * 4; }
+int mdx_k_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_BLOCK / 64) * mdx_stage_entries(d) * 4; }
 // ... [byte-mask table: 9 x u64, entry n = the low n bytes set]
 #define LT_BYTES 72
 size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4 + (size_t)(MDX_BLOCK / 64) * EVQ_BYTES + LT_BYTES; }
@@ -129,44 +128,9 @@ __device__ __forceinline__ void bump(u32 *lds, u64 *raw, int idx) {
 // compiler's own sequence is shift + and + add3 per byte.  The ds_adds are invisible to the compiler's
 // lgkmcnt bookkeeping, which only makes its waits more conservative (LDS operations complete in order);
 // nothing reads TC before the final barrier, which is preceded by an explicit s_waitcnt.
-__device__ __forceinline__ void tc_bump8(u32 r_lo, u32 r_hi, u32 base_bytes, u32 d0, u32 d1, u32 d2, u32 d3,
-                                         u32 d4, u32 d5, u32 d6, u32 d7) {
-    u32 t0, t1, t2, t3;
-    asm volatile(
-        "v_bfe_u32 %0, %4, 1, 2\n\t"
-        "v_bfe_u32 %1, %4, 9, 2\n\t"
-        "v_bfe_u32 %2, %4, 17, 2\n\t"
-        "v_bfe_u32 %3, %4, 25, 2\n\t"
-        "v_lshl_add_u32 %0, %0, 11, %5\n\t"
-        "v_lshl_add_u32 %1, %1, 11, %5\n\t"
-        "v_lshl_add_u32 %2, %2, 11, %5\n\t"
-        "v_lshl_add_u32 %3, %3, 11, %5\n\t"
-        "ds_add_u32 %0, %6\n\t"
-        "ds_add_u32 %1, %7 offset:256\n\t"
-        "ds_add_u32 %2, %8 offset:512\n\t"
-        "ds_add_u32 %3, %9 offset:768"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(r_lo), "v"(base_bytes), "v"(d0), "v"(d1), "v"(d2), "v"(d3)
-        : "memory");
-    asm volatile(
-        "v_bfe_u32 %0, %4, 1, 2\n\t"
-        "v_bfe_u32 %1, %4, 9, 2\n\t"
-        "v_bfe_u32 %2, %4, 17, 2\n\t"
-        "v_bfe_u32 %3, %4, 25, 2\n\t"
-        "v_lshl_add_u32 %0, %0, 11, %5\n\t"
-        "v_lshl_add_u32 %1, %1, 11, %5\n\t"
-        "v_lshl_add_u32 %2, %2, 11, %5\n\t"
-        "v_lshl_add_u32 %3, %3, 11, %5\n\t"
-        "ds_add_u32 %0, %6 offset:1024\n\t"
-        "ds_add_u32 %1, %7 offset:1280\n\t"
-        "ds_add_u32 %2, %8 offset:1536\n\t"
-        "ds_add_u32 %3, %9 offset:1792"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(r_hi), "v"(base_bytes), "v"(d4), "v"(d5), "v"(d6), "v"(d7)
-        : "memory");
-}
-// The same with one increment for all eight bytes (complete records: a byte that is not a task has a
-// table word of its own that no task maps to, so counting it is harmless and saves the data registers)
+// One increment for all eight bytes: a byte of a complete record that is not a task has a table word of its
+// own that no task maps to, so counting it is harmless; the steps of the other records zero such bytes (plane A)
+// and account for them in DMP
 __device__ __forceinline__ void tc_bump8_all(u32 r_lo, u32 r_hi, u32 base_bytes, u32 dd) {
     u32 t0, t1, t2, t3, t4, t5, t6, t7;
     asm volatile(
@@ -321,7 +285,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (wave-uniform, and told so: the staging and queue addresses derived from it live in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int waves_per_block = MDX_BLOCK / 64;
     const u32 gwave = blockIdx.x * waves_per_block + wave;
     const u32 nwaves = gridDim.x * waves_per_block;
@@ -375,15 +340,18 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     c_ro += ph_ref;   // the phases of the aligned-down bases
     const u32 c_qo = c_so + ph_qual;
     c_so += ph_seq;
-    const u32 c_hivm_lo = c_vm_lo & 0x80808080u, c_hivm_hi = c_vm_hi & 0x80808080u;
-    const u32 c_lane18 = (u32)lane << 18;   // lane field of an event word
+    // (bit 7 of the task bytes is c_vm & 0x80808080 with the constant in a scalar register — one three-input
+    // operation either way — and the lane field of an event word is c_lane4 << 16: two vector registers less across the
+    // hot loop, which has none to spare)
+    u32 k_hi7 = 0x80808080u;
+    asm volatile("" : "+s"(k_hi7));
     const u32 c_lane4 = (u32)lane << 2;     // byte offset of word `lane` (the dynamic LDS starts at address 0)
 
     // Record staging of the fast path (wave-private, LDS): phase 1 writes one 16-byte entry per plain record,
     // complete records first, {rfL, sq, nq | nbefore << 16 | nafter << 24,
     //                          TC base bytes [17:8] | library [29:24] | has qualities [30] | reverse strand [31]};
     // phase 2 reads the entry of its slot with one ds_read_b128 (no v_readlane broadcast).
-    uint4 *const stg = (uint4 *)(lds + a.stage_off) + wave * STG_ENT;
+    uint4 *const stg = (uint4 *)(lds + a.stage_off) + wave * mdx_stage_entries(d);
     // Rare-event queue (wave-private, LDS): the lanes holding a byte that is not a plain match append
     // {read 8 bytes, reference 8 bytes, record word | lane << 18 | masked-quality flags [7:0]}; the queue is
     // drained completely, 64 events in parallel, whenever the next step might not fit.
@@ -472,7 +440,6 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
         u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
         u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi;
-        const u32 hivm_lo = c_hivm_lo, hivm_hi = c_hivm_hi;
         const u32 base_b = tc_base(st.pk, c_lane4);
         u32 q_lo = 0, q_hi = 0, qo_ = 0;
         u32x3 q12_ = {0u, 0u, 0u};
@@ -506,7 +473,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // tasks = bytes [lo, hi)
                 const u64 Lo = *(const u64 *)((const u8 *)ltab + (aux & 0x7Fu)), Hi = *(const u64 *)((const u8 *)ltab + ((aux >> 7) & 0x7Fu));
                 dyn_lo = (u32)Hi & ~(u32)Lo & c_vm_lo; dyn_hi = (u32)(Hi >> 32) & ~(u32)(Lo >> 32) & c_vm_hi;
-                tcd_lo = dyn_lo; tcd_hi = dyn_hi;
+                tcd_lo = tcd_hi = 0u;
             } else {
                 // [ta, tb) = the gap, tasks end at byte tl (left side; on the right side they start there)
                 const u64 X = *(const u64 *)((const u8 *)ltab + (aux & 0x7Fu)), Y = *(const u64 *)((const u8 *)ltab + ((aux >> 7) & 0x7Fu)),
@@ -523,7 +490,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const u32 X_lo = (u32)X, X_hi = (u32)(X >> 32), Y_lo = (u32)Y, Y_hi = (u32)(Y >> 32);
                 u32 m_lo = (X_lo & (u32)low) | (~X_lo & gapc), m_hi = (X_hi & (u32)(low >> 32)) | (~X_hi & gapc);
                 m_lo = (Y_lo & m_lo) | (~Y_lo & (u32)high); m_hi = (Y_hi & m_hi) | (~Y_hi & (u32)(high >> 32));
-                tcd_lo = dyn_lo; tcd_hi = dyn_hi;
+                tcd_lo = tcd_hi = 0u;
                 if (KIND == STEP_GD) {
                     s_lo = m_lo; s_hi = m_hi;
                     if (MASK) {
@@ -538,7 +505,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     // right side), instead of TC
                     const u32 beh_lo = (X_lo & sm) | (~Y_lo & ~sm), beh_hi = (X_hi & sm) | (~Y_hi & ~sm);
                     const u32 dm_lo = dyn_lo & beh_lo, dm_hi = dyn_hi & beh_hi;
-                    tcd_lo &= ~beh_lo; tcd_hi &= ~beh_hi;
+                    tcd_lo = ~beh_lo; tcd_hi = ~beh_hi;      // the bytes TC counts (the others: by position, below)
                     evw = (st.pk & 0xBF000000u) | 0x40000000u | (((aux >> 24) & 0x7Fu) << 8);
                     if (__ballot((dm_lo | dm_hi) != 0u)) {
                         const int g = (int)((aux >> 24) & 7u);
@@ -558,8 +525,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // drain_all passes over)
             s_lo &= dyn_lo; s_hi &= dyn_hi; r_lo &= dyn_lo; r_hi &= dyn_hi;
             if (MASK) { emvm_lo &= dyn_lo; emvm_hi &= dyn_hi; }   // (the quality bytes are not zeroed)
-            tc_bump8(r_lo, r_hi, base_b, tcd_lo & 1u, (tcd_lo >> 8) & 1u, (tcd_lo >> 16) & 1u, (tcd_lo >> 24) & 1u,
-                     tcd_hi & 1u, (tcd_hi >> 8) & 1u, (tcd_hi >> 16) & 1u, (tcd_hi >> 24) & 1u);
+            // all eight bytes with one increment, like a complete record's: a zeroed byte lands in plane A, and DMP knows
+            // how many of those there are per window byte (phase 1)
+            if (KIND == STEP_GD) tc_bump8_all(r_lo & tcd_lo, r_hi & tcd_hi, base_b, act ? 1u : 0u);
+            else tc_bump8_all(r_lo, r_hi, base_b, act ? 1u : 0u);
         }
         // MASK: bit 7 of the bytes whose quality is below --min-basequal (align.py:65-71)
         u32 lowq_lo = 0, lowq_hi = 0;
@@ -571,8 +540,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
         // x: per byte, zero iff the byte is a plain match (read == reference, reference is
         // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
-        u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & hivm_lo);
-        u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & hivm_hi);
+        u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & c_vm_lo & k_hi7);
+        u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & c_vm_hi & k_hi7);
         u32 mq_lo = 0, mq_hi = 0;
         if (MASK) {
             // the masked columns of this lane: bit 7 of the byte
@@ -623,7 +592,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 es.x = s_lo; es.y = s_hi; er.x = r_lo; er.y = r_hi;
                 qS[slot] = es;
                 qR[slot] = er;
-                u32 w = evw | c_lane18;
+                u32 w = evw | (c_lane4 << 16);
                 if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
                 qW[slot] = w;
             }
@@ -1038,9 +1007,35 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 if (lane < d.R - 1) stg[nF + lane] = pad;
             }
             if (mP | mS) {
-                // partial and single-indel records: appended to the wavefront's lists (counted behind the tile loop, in
-                // full steps): partial ones upwards from 0, insertions upwards from list_cap, deletions downwards
-                // from 2 list_cap - 1
+                // The steps of these records zero the reference bytes that are not their tasks (or, behind a deletion,
+                // are counted by position) and count all eight bytes of a lane into TC with one increment: those bytes
+                // land in plane A.  DMP says, as differences over the window bytes of a side, how many such bytes
+                // there are (finalize_kernel takes the prefix sums off the A counts): +1 where a stretch begins, -1
+                // where it ends before the window does.
+                if (USE_LDS) {
+                    const int dl = libid * d.w_lib + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
+                    const int nbf = (w1 >> D_NB_SHIFT) & 0xFF, naf = (w1 >> D_NA_SHIFT) & 0xFF;
+                    if (plain && !isF) {
+                        // tasks [-flank, min(nq, L)) per side
+                        const int k1 = nq < L ? nq : L;
+                        if (nbf < A) { atomicAdd(&lds[dl], 1u); atomicAdd(&lds[dl + A - nbf], 0xFFFFFFFFu); }
+                        if (naf < A) { atomicAdd(&lds[dr], 1u); atomicAdd(&lds[dr + A - naf], 0xFFFFFFFFu); }
+                        if (k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
+                    } else if (gpre && !isS) {
+                        // tasks [-A, first / last match run)
+                        const int vl = vlr & 0xFF, vr = vlr >> 8;
+                        if (vl < L) atomicAdd(&lds[dl + A + vl], 1u);
+                        if (vr < L) atomicAdd(&lds[dr + A + vr], 1u);
+                    } else if (isS) {
+                        // an insertion counts its columns up to min(ncols, L) through TC; a deletion those in front
+                        // of and in the gap — the columns behind it go to MIS / CMP by position
+                        const int g = n0 - nq, u = vlr & 0xFF, v = vlr >> 8;
+                        const int Lm = ncols < L ? ncols : L;
+                        const int el = g > 0 ? (u + g < Lm ? u + g : Lm) : Lm, er = g > 0 ? (v + g < Lm ? v + g : Lm) : Lm;
+                        if (el < L) atomicAdd(&lds[dl + A + el], 1u);
+                        if (er < L) atomicAdd(&lds[dr + A + er], 1u);
+                    }
+                }
                 i64 at = -1;
                 if ((plain && !isF) || (gpre && !isS)) at = lP + mbcnt64(mP, 0);
                 else if (isS) at = isD ? 2 * a.list_cap - 1 - (lD + mbcnt64(mS & ~mSI, 0)) : a.list_cap + lI + mbcnt64(mSI, 0);
@@ -1298,6 +1293,13 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
     const i64 n_comp = (i64)d.nlib * 2 * 2 * (L + A) * 4;
     const i64 n_lgd = (i64)d.nlib * 2 * 2 * d.lgd_max;
     const i64 total = n_mis + n_comp + n_lgd + 2;
+    // bytes counted into plane A of TC at window byte w of (strand, side) without being A tasks (DMP: differences)
+    auto dumped = [&](i64 lb, int strand, int side, int w) -> u64 {
+        u64 sum = 0;
+        if (d.w_dmp)
+            for (int q = 0; q <= w; q++) sum += raw[lb + d.off_dmp() + (strand * 2 + side) * (A + L) + q];
+        return sum;
+    };
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
         u64 v;
         if (i < n_mis) {
@@ -1318,6 +1320,7 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
                 for (int g = 0; g < d.R; g++)  // plain records: one copy per slot of the wavefront step
                     v += raw[lb + d.off_tc() + (strand * 4 + k) * d.t_pad + (side ? d.tau_right(p) : d.tau_left(p)) + g * d.G];
                 for (int x = 0; x < 4; x++) v += raw[row + c_refcols[k * 4 + x]];
+                if (k == 0) v -= dumped(lb, strand, side, p + A);
             } else {
                 const int rc = strand ? c_comp_col[col] : col;
                 if (col == COL_S) {   // soft clips are stored as differences over the positions
@@ -1346,10 +1349,12 @@ __global__ void finalize_kernel(const u64 *__restrict__ raw, const u64 *__restri
             if (slot >= 0) {
                 v = raw[lb + d.off_cmp() + ((strand * 2 + side) * L + slot) * 4 + k];
                 for (int g = 0; g < d.R; g++) v += raw[tc + (side ? d.tau_right(slot) : d.tau_left(slot)) + g * d.G];
+                if (k == 0) v -= dumped(lb, strand, side, slot + A);
             } else {
                 v = 0;
                 const int t = side ? d.tau_rflank(dist) : d.tau_lflank(dist);
                 for (int g = 0; g < (d.R > 0 ? d.R : 1); g++) v += raw[tc + t + g * d.G];
+                if (k == 0) v -= dumped(lb, strand, side, A - dist);
             }
         } else if (i < n_mis + n_comp + n_lgd) {
             i64 x = i - n_mis - n_comp;
