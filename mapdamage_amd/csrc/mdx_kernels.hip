@@ -340,11 +340,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     c_ro += ph_ref;   // the phases of the aligned-down bases
     const u32 c_qo = c_so + ph_qual;
     c_so += ph_seq;
-    // (bit 7 of the task bytes is c_vm & 0x80808080 with the constant in a scalar register — one three-input
-    // operation either way — and the lane field of an event word is c_lane4 << 16: two vector registers less across the
-    // hot loop, which has none to spare)
-    u32 k_hi7 = 0x80808080u;
-    asm volatile("" : "+s"(k_hi7));
+    const u32 c_hivm_lo = c_vm_lo & 0x80808080u, c_hivm_hi = c_vm_hi & 0x80808080u;
+    // (the lane field of an event word is c_lane4 << 16: no register of its own across the hot loop)
     const u32 c_lane4 = (u32)lane << 2;     // byte offset of word `lane` (the dynamic LDS starts at address 0)
 
     // Record staging of the fast path (wave-private, LDS): phase 1 writes one 16-byte entry per plain record,
@@ -433,10 +430,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     //           deletion the composition position (query index) is g less than the misincorporation position
     //           (column): those bytes are counted, still optimistically, straight into MIS[c][base] and CMP[c - g][base]
     //           (direct8) instead of TC, and their events say so (drain_all).
-    auto count = [&](const Stage &st, auto kind_tag) {
+    // (full_tag: every slot of the step holds a record — all steps of a run but its last one)
+    auto count = [&](const Stage &st, auto kind_tag, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         constexpr int KIND = decltype(kind_tag)::value;
         // slots past the last record of the tile: no increments, no events
-        const bool act = lane < st.lim;
+        const bool act = FULL || lane < st.lim;
         u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
         u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
         u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi;
@@ -540,8 +539,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
         // x: per byte, zero iff the byte is a plain match (read == reference, reference is
         // A/C/G/T); flank bytes only test the reference byte; bytes that are not tasks are zero
-        u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & c_vm_lo & k_hi7);
-        u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & c_vm_hi & k_hi7);
+        u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & c_hivm_lo);
+        u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & c_hivm_hi);
         u32 mq_lo = 0, mq_hi = 0;
         if (MASK) {
             // the masked columns of this lane: bit 7 of the byte
@@ -580,7 +579,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
         // ... and queue the lanes holding a byte that is not one (drain_all corrects them)
         u32 xx = x_lo | x_hi;
-        if (KIND == STEP_C) xx = act ? xx : 0u;   // (the other kinds mask by dyn already)
+        if (KIND == STEP_C && !FULL) xx = act ? xx : 0u;   // (the other kinds mask by dyn already)
         const bool ev = xx != 0;
         const u64 mm = __ballot(ev);
         if (mm) {
@@ -679,13 +678,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             for (int k = PD; k < nsteps; k += PD) {
     #pragma unroll
                 for (int dd = 0; dd < PD; dd++) {
-                    count(st[dd], kind_tag);
+                    count(st[dd], kind_tag, std::true_type{});      // (never the last step of the run)
                     fill(st[dd]);
                 }
             }
     #pragma unroll
             for (int dd = 0; dd < PD; dd++)
-                if (dd == 0 || st[dd].valid) count(st[dd], kind_tag);
+                if (dd == 0 || st[dd].valid) count(st[dd], kind_tag, std::false_type{});
         };
 
     // Tiles of (up to) 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
@@ -703,23 +702,30 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
     // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
     const MdxTabArgs *const ka = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    uint4 *const lists = a.lists + (i64)gwave * 2 * a.list_cap;
-    int lP = 0, lI = 0, lD = 0;
-    for (u32 it = 0; it < n_it; it++) {
+    // Regions of the wavefront's part of MdxTabArgs::lists (16-byte entries; `cap` = list_cap):
+    //   [0, cap)        partial records, upwards            [cap, 2 cap)  single insertions upwards / deletions downwards
+    //   [2 cap, 3 cap)  complete records found by the general pass, upwards
+    //   [3 cap, ...)    the indices (u32) of the records the tile loop leaves to the general pass
+    uint4 *const lists = a.lists + (i64)gwave * (3 * a.list_cap + a.list_cap / 4 + 1);
+    u32 *const dlist = (u32 *)(lists + 3 * a.list_cap);
+    int lP = 0, lI = 0, lD = 0, lC = 0;
+
+    // ------------------------------------------------------------ the general pass: any record, lane per record
+    // Everything the reference's loop body does to a record up to the columns the steps count: flag filter, CIGAR scan,
+    // fragment length, soft clips, error checks, classification.  FAST: fed 64 at a time with the records the tile loop
+    // cannot take (anything but a single match operation) — their entries go to the wavefront's lists; otherwise it is
+    // the whole tile loop.
+    auto general = [&](const u32 ri, const bool valid) {
         // the arguments phase 1 needs are read from the kernel-argument segment when they are used (scalar loads through
         // the constant cache) instead of living in SGPRs across the whole kernel: the kernel wants far more scalar
         // registers than there are, and every spilled one costs a v_readlane per use
         const MdxTabArgs *kp = ka;
         asm volatile("" : "+s"(kp));
         const MdxTabArgs &p = *kp;
-        const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
-        const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
         // ------------------------------------------------------------ phase 1: lane per record
-        const u32 ri = tbase + lane;
-        const bool valid = ri < r_hi;
         // the per-record columns are requested together, before the flag is known (one memory round
-        // trip for the tile instead of two)
-        const u32 rj = valid ? ri : r_hi - 1;
+        // trip for the batch instead of two)
+        const u32 rj = valid ? ri : 0u;
         const u32 fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
         const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
         const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
@@ -998,13 +1004,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS); nSI = __popcll(mSI);
             todo_g = todo_all & ~(mF | mPp | mS | __ballot(covered));
             if (mF) {
-                if (isF) stg[mbcnt64(mF, 0)] = ent;
-                // the slots past the last record of a step shadow a real record (and are masked out)
-                const int first = __ffsll((long long)mF) - 1;
-                uint4 pad;
-                pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
-                pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
-                if (lane < d.R - 1) stg[nF + lane] = pad;
+                // complete records (soft-clipped ones, mostly): counted behind the tile loop like the other lists
+                if (isF) lists[2 * a.list_cap + lC + mbcnt64(mF, 0)] = ent;
+                lC += nF;
             }
             if (mP | mS) {
                 // The steps of these records zero the reference bytes that are not their tasks (or, behind a deletion,
@@ -1073,8 +1075,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // flank lengths: from the packed descriptor (A < 248 with the fast path), else recomputed
             int s_nb = (s_w1 >> D_NB_SHIFT) & 0xFF, s_na = (s_w1 >> D_NA_SHIFT) & 0xFF;
             if (!FAST) {
-                const i64 pos = a.pos[tbase + j];
-                const int tid = a.tid[tbase + j];
+                const u32 rk = (u32)rl((int)ri, j);
+                const i64 pos = a.pos[rk];
+                const int tid = a.tid[rk];
                 const i64 clen = a.contig_off[tid + 1] - a.contig_off[tid];
                 s_nb = pos < A ? (int)pos : A;
                 s_na = clen - (pos + s_n0) < A ? (int)(clen - (pos + s_n0)) : A;
@@ -1179,20 +1182,179 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             }
         }
 
-        // ------------------------------------------------------------ phase 2a: plain records
-        // One lane = eight consecutive bytes of a record's window; one wavefront step = R records.
-        // Bytes that are not plain matches are not handled here: they are appended as events to a
-        // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
-        // classification code runs once per 64 events instead of once per record.
-        if (FAST) {
+    };   // general
+
+    if (!FAST) {
+        for (u32 it = 0; it < n_it; it++) {
+            const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
+            const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
+            general(tbase + lane, tbase + lane < r_hi);
+        }
+    } else {
+        // The tile loop proper takes the records whose CIGAR is a single match operation (aDNA: most of them) with
+        // a short phase 1 of its own — no CIGAR scan, no clips, no gaps — counts the complete ones of the tile at
+        // once, and leaves every other kept record to the general pass: its index goes to a list, and as soon as 64
+        // of them wait they are classified together, every lane busy (a tile of 63 records holds a dozen such records
+        // at most, which used to drag the whole wavefront through the general code once per tile).  Wavefronts reach
+        // their general passes at different moments, under the counting of the others.
+        // The wavefronts of a CU start together and do the same work: left alone they would all sit in phase 1 (two
+        // memory round trips, nothing to count) at the same moments.  Each takes its first tile in two parts, the first
+        // of 9 .. 54 records by its place in the SIMD, so that the phases of the six wavefronts of a SIMD interleave.
+        const u32 skew = (u32)d.R * 3u * (1u + (u32)(((wave >> 2) * 2 + ((blockIdx.x ^ (blockIdx.x >> 8)) & 1)) % 6));
+        int nDef = 0, dDone = 0;
+        for (u32 it = 0;; it++) {
+            const bool past = it > n_it || n_it == 0;
+            int nF = 0;
+            if (!past) {
+                const MdxTabArgs *kp = ka;
+                asm volatile("" : "+s"(kp));
+                const MdxTabArgs &p = *kp;
+                const u32 ti = it ? it - 1 : 0;      // iterations 0 and 1: the two parts of tile 0
+                const u32 tbase = ti < rounds ? (ti * nwaves + gwave) * T : t_lo + (ti - rounds) * T;
+                const u32 t_end = ti < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
+                const u32 r_lo = it == 1 ? (tbase + skew < t_end ? tbase + skew : t_end) : tbase;
+                const u32 r_hi = it == 0 ? (tbase + skew < t_end ? tbase + skew : t_end) : t_end;
+                // ---------------------------------------------------- phase 1 of the single-match records
+                const u32 ri = r_lo + lane;
+                const bool valid = ri < r_hi;
+                const u32 rj = valid ? ri : tbase;
+                const u32 fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
+                const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
+                const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
+                bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
+                if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
+                // second round trip of the tile: the operation, the contig bounds and (MASK) the first quality together
+                const bool cand = kept && c_co1 - c_co0 == 1u && c_tid >= 0 && c_tid < a.n_contig && c_lib < a.nlib_total;
+                u32 cg0 = 0xFu;                  // (an operation code that is not a match)
+                i64 c0 = 0, clen = 0;
+                u32 q0 = 0xFFu;
+                if (cand) {
+                    cg0 = a.cigar[c_co0];
+                    c0 = a.contig_off[c_tid];
+                    clen = a.contig_off[c_tid + 1] - c0;
+                    if (MASK && a.qual != nullptr) q0 = a.qual[c_so0];
+                }
+                const u32 op = cg0 & 0xFu, len = cg0 >> 4;
+                const i64 aend = (i64)c_pos + (i64)len;
+                // M, = or X over the whole of SEQ, inside the contig, and the speculative window loads inside the SEQ
+                // buffer; anything else (and anything wrong) is the general pass's
+                const bool triv = cand && ((0x181u >> op) & 1u) != 0 && len == c_so1 - c_so0 && len - 1u < 32767u && c_pos >= 0 &&
+                                  aend <= clen && c_so0 >= (u32)(8 * d.nl8) && (i64)c_so0 + (i64)len + 8 * d.nl8 <= a.n_bases;
+                const u64 mDef = __ballot(kept && !triv);
+                if (mDef) {
+                    if (kept && !triv) dlist[nDef + mbcnt64(mDef, 0)] = ri;
+                    nDef += __popcll(mDef);
+                }
+                const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
+                const int lbase = libid * d.w_lib;
+                const int nbefore = c_pos < A ? c_pos : A;
+                const int nafter = clen - aend < A ? (int)(clen - aend) : A;
+                const bool isF = triv && nq >= L && nbefore == A && nafter == A;
+                // statistics.py:117-126
+                int lkey = -1;
+                if (triv) {
+                    int kind = -1;
+                    i64 flen = 0;
+                    if (fl & 0x1) {
+                        if ((fl & 0x40) && (fl & 0x2)) {
+                            kind = 0;
+                            const i64 t = c_tlen;
+                            flen = t < 0 ? -t : t;
+                        }
+                    } else {
+                        kind = 1;
+                        flen = (i64)len;
+                    }
+                    if (kind >= 0) {
+                        if (flen < d.lgd_lds) {
+                            lkey = lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen;
+                        } else if (flen < d.lgd_max) {
+                            atomicAdd(&p.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
+                                                   (((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
+                        } else {
+                            const u64 slot = atomicAdd(p.n_lgd_over, 1ull);
+                            if ((i64)slot < p.lgd_over_cap) {
+                                p.lgd_over[4 * slot + 0] = libid + a.lib_lo;
+                                p.lgd_over[4 * slot + 1] = kind;
+                                p.lgd_over[4 * slot + 2] = rev;
+                                p.lgd_over[4 * slot + 3] = flen;
+                            }
+                        }
+                    }
+                }
+                // fragment lengths: two rounds of wave-level aggregation (uniform read lengths give one
+                // or two distinct keys per tile), the remainder as individual adds
+                {
+                    u64 pend = __ballot(lkey >= 0);
+#pragma unroll 1
+                    for (int round = 0; round < 2 && pend; round++) {
+                        const int leader = __ffsll((long long)pend) - 1;
+                        const int key = rl(lkey, leader);
+                        const u64 same = __ballot(lkey == key);
+                        if (lane == leader) bump_n<USE_LDS>(lds, raw, key, (u32)__popcll(same));
+                        if (lkey == key) lkey = -1;
+                        pend &= ~same;
+                    }
+                    if (lkey >= 0) bump<USE_LDS>(lds, raw, lkey);
+                }
+                const u64 mT = __ballot(triv);
+                if (lane == 0 && mT) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), (u32)__popcll(mT));
+                // staging entry (as in the general pass)
+                uint4 ent;
+                ent.x = (u32)(c0 + c_pos - A + 256);
+                ent.y = c_so0;
+                ent.z = (u32)nq | ((u32)(nbefore | (nafter << 8)) << 16);
+                ent.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
+                        ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
+                const u64 mF = __ballot(isF), mP = mT & ~mF;
+                nF = __popcll(mF);
+                if (mF) {
+                    if (isF) stg[mbcnt64(mF, 0)] = ent;
+                    // the slots past the last record of a step shadow a real record (and are masked out)
+                    const int first = __ffsll((long long)mF) - 1;
+                    uint4 pad;
+                    pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
+                    pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
+                    if (lane < d.R - 1) stg[nF + lane] = pad;
+                }
+                if (mP) {
+                    // short records and contig edges: tasks [-flank, min(nq, L)) per side (the list of partial records; DMP)
+                    if (triv && !isF) {
+                        const int dl = lbase + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
+                        const int k1 = nq < L ? nq : L;
+                        if (nbefore < A) { atomicAdd(&lds[dl], 1u); atomicAdd(&lds[dl + A - nbefore], 0xFFFFFFFFu); }
+                        if (nafter < A) { atomicAdd(&lds[dr], 1u); atomicAdd(&lds[dr + A - nafter], 0xFFFFFFFFu); }
+                        if (k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
+                        lists[lP + mbcnt64(mP, 0)] = ent;
+                    }
+                    lP += __popcll(mP);
+                }
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
-            if (nF) run(0, nF, std::integral_constant<int, STEP_C>{});
+                // ---------------------------------------------------- phase 2a: the complete records of the tile
+                // One lane = eight consecutive bytes of a record's window; one wavefront step = R records.
+                // Bytes that are not plain matches are not handled here: they are appended as events to a
+                // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
+                // classification code runs once per 64 events instead of once per record.
+                if (nF) run(0, nF, std::integral_constant<int, STEP_C>{});
 #endif
+            }
+            // ---------------------------------------------------- the general pass over the records left to it
+            const int pend = nDef - dDone;
+            if (pend >= 64 || (past && pend > 0)) {
+                const int m = pend < 64 ? pend : 64;
+                // (the wavefront's own stores: complete before they are read back)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const u32 rk = dlist[dDone + (lane < m ? lane : 0)];
+                general(rk, lane < m);
+                dDone += m;
+            }
+            if (past && dDone >= nDef) break;
         }
     }
 
 #ifndef MDX_ONLY_PHASE1
-    if (FAST && (lP | lI | lD)) {
+    if (FAST && (lP | lI | lD | lC)) {
         // the entries this wavefront appended (its own stores: complete before they are read back)
         // (workgroup scope: the stores have reached the L2 and no line of the lists was read before, so nothing
         // stale can sit in this CU's L1; an agent-scope release would write the whole L2 back, once per wavefront)
@@ -1208,9 +1370,14 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 run(0, m, kind_tag);
             }
         };
+        list_runs(2 * a.list_cap, 1, lC, std::integral_constant<int, STEP_C>{});
+#ifndef MDX_ABL_NO_PRUN      // (ablation builds, tools/ablate.sh: wrong tables, instruction counts by part)
         list_runs(0, 1, lP, std::integral_constant<int, STEP_P>{});
+#endif
+#ifndef MDX_ABL_NO_GRUN
         list_runs(a.list_cap, 1, lI, std::integral_constant<int, STEP_GI>{});
         list_runs(2 * a.list_cap - 1, -1, lD, std::integral_constant<int, STEP_GD>{});
+#endif
     }
 #endif
     if (FAST) {

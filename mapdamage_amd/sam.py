@@ -578,12 +578,80 @@ def write_sam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
             out.write("\t".join(fields) + "\n")
 
 
-def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None, htslib_blocks=True):
+_WB_JOB = None
+
+
+def _wb_slice(span):
+    """Worker of write_bam(workers=N): records [lo, hi) as finished BGZF blocks, each starting at a record."""
+    lo, hi = span
+    batch, rg_of_record = _WB_JOB
+    out = io.BytesIO()
+    room = 0xFF00
+    piece = bytearray()
+    for i in range(lo, hi):
+        record = _bam_record(batch, i, None if rg_of_record is None else rg_of_record[i])
+        if piece and len(piece) + len(record) > room:
+            out.write(_bgzf_block(bytes(piece)))
+            piece = bytearray()
+        piece += record
+        while len(piece) > room:                 # a record larger than a block spills over
+            out.write(_bgzf_block(bytes(piece[:room])))
+            del piece[:room]
+    if piece:
+        out.write(_bgzf_block(bytes(piece)))
+    return out.getvalue()
+
+
+def _bam_record(batch, i, rg):
+    c0, c1 = int(batch.cigar_off[i]), int(batch.cigar_off[i + 1])
+    s0, s1 = int(batch.seq_off[i]), int(batch.seq_off[i + 1])
+    name = ("r%d" % i).encode() + b"\x00"
+    l_seq = s1 - s0
+    codes = _SEQ_ENCODE[batch.seq[s0:s1]]
+    if l_seq % 2:
+        codes = np.concatenate([codes, np.zeros(1, np.uint8)])
+    packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
+    qual = batch.qual[s0:s1].tobytes() if batch.qual is not None else b"\xff" * l_seq
+    aux = b"" if rg is None else b"RGZ" + rg.encode() + b"\x00"
+    ntid = -1 if batch.mtid is None else int(batch.mtid[i])
+    npos = -1 if batch.mpos is None else int(batch.mpos[i])
+    body = struct.pack("<iiBBHHHiiii", int(batch.tid[i]), int(batch.pos[i]), len(name), 30, 4680,
+                       c1 - c0, int(batch.flag[i]), l_seq, ntid, npos, int(batch.tlen[i]))
+    body += name + batch.cigar[c0:c1].astype("<u4").tobytes() + packed + qual + aux
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None, htslib_blocks=True,
+              workers=1):
     """``htslib_blocks``: lay the BGZF blocks out as htslib does (the header flushed on its own, and a block closed
     early when the next record would not fit, ``bgzf_flush_try`` in ``bam_write1``), so that every block starts
     at a record — what the files mapDamage sees in practice look like, and what the native decoder's parallel
-    record scan speculates on.  False: blocks of 0xFF00 bytes cut anywhere (records straddle them)."""
+    record scan speculates on.  False: blocks of 0xFF00 bytes cut anywhere (records straddle them).
+    ``workers`` > 1 (htslib layout only): the records are encoded and deflated by forked worker processes, a slice
+    each (call it before the process touches the GPU); a slice starts a block of its own, otherwise the same file."""
     text = header_text(ref_names, ref_lengths, read_groups).encode()
+    if htslib_blocks and workers > 1 and batch.n > 4 * workers:
+        import multiprocessing as mp
+        global _WB_JOB
+        head = io.BytesIO()
+        head.write(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names)))
+        for name, ln in zip(ref_names, ref_lengths):
+            nb = name.encode() + b"\x00"
+            head.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln))
+        hv = head.getvalue()
+        n_jobs = workers * 4
+        spans = [(batch.n * k // n_jobs, batch.n * (k + 1) // n_jobs) for k in range(n_jobs)]
+        _WB_JOB = (batch, rg_of_record)
+        try:
+            with mp.get_context("fork").Pool(workers) as pool, open(path, "wb") as out:
+                for lo in range(0, len(hv), 0xFF00):
+                    out.write(_bgzf_block(hv[lo:lo + 0xFF00]))
+                for blob in pool.imap(_wb_slice, spans, chunksize=1):
+                    out.write(blob)
+                out.write(_bgzf_block(b""))
+        finally:
+            _WB_JOB = None
+        return
     raw = io.BytesIO()
     pieces = []                      # htslib layout: uncompressed payload of each block
     room = 0xFF00
@@ -595,25 +663,7 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
         head = raw.getvalue()
         pieces = [bytearray(head[lo:lo + room]) for lo in range(0, len(head), room)] + [bytearray()]
     for i in range(batch.n):
-        c0, c1 = int(batch.cigar_off[i]), int(batch.cigar_off[i + 1])
-        s0, s1 = int(batch.seq_off[i]), int(batch.seq_off[i + 1])
-        name = ("r%d" % i).encode() + b"\x00"
-        l_seq = s1 - s0
-        codes = _SEQ_ENCODE[batch.seq[s0:s1]]
-        if l_seq % 2:
-            codes = np.concatenate([codes, np.zeros(1, np.uint8)])
-        packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
-        qual = batch.qual[s0:s1].tobytes() if batch.qual is not None else b"\xff" * l_seq
-        aux = b""
-        rg = None if rg_of_record is None else rg_of_record[i]
-        if rg is not None:
-            aux = b"RGZ" + rg.encode() + b"\x00"
-        ntid = -1 if batch.mtid is None else int(batch.mtid[i])
-        npos = -1 if batch.mpos is None else int(batch.mpos[i])
-        body = struct.pack("<iiBBHHHiiii", int(batch.tid[i]), int(batch.pos[i]), len(name), 30, 4680,
-                           c1 - c0, int(batch.flag[i]), l_seq, ntid, npos, int(batch.tlen[i]))
-        body += name + batch.cigar[c0:c1].astype("<u4").tobytes() + packed + qual + aux
-        record = struct.pack("<i", len(body)) + body
+        record = _bam_record(batch, i, None if rg_of_record is None else rg_of_record[i])
         if not htslib_blocks:
             raw.write(record)
             continue
