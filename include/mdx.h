@@ -296,6 +296,14 @@ int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual);
 int mdx_gbam_missing_qualities(const mdx_gbam *g);
 int mdx_gbam_at_end(const mdx_gbam *g);
 void mdx_gbam_close(mdx_gbam *g);
+/* Introspection for tests: the device inflate and CRC32 stages of the decode path alone, on BGZF payloads the caller
+ * supplies (host buffers).  blk holds four words per block — payload offset in comp, payload bytes, offset in out,
+ * bytes out (ISIZE, at most 65536) — and want_crc the CRC32 of each block's inflated bytes (may be NULL: no check).
+ * status[b] = bytes produced, or a negative inflate code (-4: ISIZE disagrees); crc_ok[b] = 1 when the check passed.
+ * tests/test_gpu_decode.py feeds it every deflate block type, window distances across the LDS ring and damaged
+ * streams, against zlib. */
+int mdx_gbam_inflate_blocks(mdx_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const uint32_t *blk, int32_t n_blocks,
+                            uint8_t *out, int64_t out_bytes, int32_t *status, const uint32_t *want_crc, uint8_t *crc_ok);
 
 #ifdef __cplusplus
 }

@@ -1040,6 +1040,60 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
     }
 }
 
+int mdx_gbam_inflate_blocks(mdx_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const uint32_t *blk, int32_t n_blocks,
+                            uint8_t *out, int64_t out_bytes, int32_t *status, const uint32_t *want_crc, uint8_t *crc_ok) {
+    if (!ctx || !comp || !blk || !out || !status || n_blocks < 0 || comp_bytes < 0 || out_bytes < 0) return MDX_ERR_ARG;
+    if (n_blocks == 0) return MDX_OK;
+    for (int32_t b = 0; b < n_blocks; b++) {
+        const uint32_t *e = blk + 4 * (size_t)b;
+        if ((int64_t)e[0] + e[1] > comp_bytes || e[3] > 65536u || (int64_t)e[2] + e[3] > out_bytes) return MDX_ERR_ARG;
+    }
+    void *st_ = nullptr;
+    int device = 0;
+    if (mdx_ctx_stream(ctx, &st_, &device) != MDX_OK) return MDX_ERR_ARG;
+    hipStream_t st = (hipStream_t)st_;
+    if (hipSetDevice(device) != hipSuccess || mdx_k_gbam_prepare() != hipSuccess) return MDX_ERR_HIP;
+    static mdx_crc32::Tables tables;
+    static std::once_flag once;
+    std::call_once(once, [] { mdx_crc32::make_tables(tables); });
+    uint8_t *d_comp = nullptr, *d_out = nullptr;
+    uint32_t *d_blk = nullptr, *d_crc = nullptr;
+    int *d_status = nullptr, *d_bad = nullptr;
+    void *d_tab = nullptr;
+    int rc = MDX_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess) rc = MDX_ERR_HIP; return e == hipSuccess; };
+    // (one block per launch of the CRC kernel would be simplest to read back; instead every block is checked on its own
+    // by giving the kernel one block at a time only when a check fails — the common case is one launch)
+    if (ok(hipMalloc((void **)&d_comp, (size_t)comp_bytes + 64)) && ok(hipMalloc((void **)&d_out, (size_t)out_bytes + 64)) &&
+        ok(hipMalloc((void **)&d_blk, (size_t)n_blocks * 16)) && ok(hipMalloc((void **)&d_status, (size_t)n_blocks * 4)) &&
+        ok(hipMalloc((void **)&d_crc, (size_t)n_blocks * 4)) && ok(hipMalloc((void **)&d_bad, 4)) && ok(hipMalloc(&d_tab, sizeof(tables))) &&
+        ok(hipMemcpyAsync(d_comp, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st)) &&
+        ok(hipMemcpyAsync(d_blk, blk, (size_t)n_blocks * 16, hipMemcpyHostToDevice, st)) &&
+        ok(hipMemcpyAsync(d_tab, &tables, sizeof(tables), hipMemcpyHostToDevice, st)) &&
+        ok(hipMemsetAsync(d_out, 0xEE, (size_t)out_bytes + 64, st))) {
+        mdx_k_gbam_inflate(d_comp, (const uint4 *)d_blk, n_blocks, d_out, d_status, st);
+        if (ok(hipGetLastError()) && ok(hipMemcpyAsync(status, d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, st)) &&
+            ok(hipMemcpyAsync(out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st)) && want_crc && crc_ok) {
+            // the CRC kernel reports the lowest failing block of a launch: launch it over the blocks behind each failure
+            ok(hipMemcpyAsync(d_crc, want_crc, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+            int32_t from = 0;
+            for (int32_t b = 0; b < n_blocks; b++) crc_ok[b] = 1;
+            while (rc == MDX_OK && from < n_blocks) {
+                const int no_bad = 0x7FFFFFFF;
+                int bad = no_bad;
+                if (!ok(hipMemcpyAsync(d_bad, &no_bad, 4, hipMemcpyHostToDevice, st))) break;
+                mdx_k_gbam_crc(d_out, (const uint4 *)d_blk + from, d_crc + from, d_tab, n_blocks - from, d_bad, st);
+                if (!ok(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) break;
+                if (bad == no_bad) break;
+                crc_ok[from + bad] = 0;
+                from += bad + 1;
+            }
+        }
+    }
+    for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_blk, (void *)d_status, (void *)d_crc, (void *)d_bad, d_tab}) if (p) (void)hipFree(p);
+    return rc;
+}
+
 int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual) {
     if (!g || minqual < 0 || minqual > 93) return MDX_ERR_ARG;
     g->minqual = minqual;

@@ -51,6 +51,9 @@ typedef long long i64;
 #ifndef PIPE_DEPTH
 #define PIPE_DEPTH 3                    // wavefront steps in flight (register sets of the load pipeline)
 #endif
+#ifndef MDX_QPREFETCH
+#define MDX_QPREFETCH 1                 // MASK: the quality windows requested with the other two, PIPE_DEPTH steps ahead
+#endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
 #endif
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
 
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
-    struct Stage { u32x3 s12, r12; u32 ro, so, pk, aux; int lim; bool valid; };
+    struct Stage { u32x3 s12, r12, q12; u32 ro, so, pk, aux; int lim; bool valid; };
     // Three kinds of steps (one instantiation each):
     //   STEP_C  complete records: every task present, static byte masks;
     //   STEP_P  a column range per side: short records and contig edges ([-flank, min(nq, L))), gapped records whose
@@ -451,6 +454,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             }
         };
         if (MASK) {
+#if MDX_QPREFETCH
+            // (requested by fill(), with the other two windows)
+            q12_ = st.q12; qo_ = st.so - c_so + c_qo;
+#else
             // the quality window is requested here, at the start of the step that uses it, not a step or two ahead like
             // the other two: three more registers per step in flight are more than the kernel has (the hot loop
             // spilled), and what a step does before it needs the qualities covers part of the latency.  Records that
@@ -458,6 +465,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const u32 qo = st.so - c_so + c_qo;
             const u32x3 q12 = *(const u32x3 *)(qualW + ((st.pk & 0x40000000u) ? (qo & ~3u) : 0u));
             q12_ = q12; qo_ = qo;       // (funnelled out where the qualities are first needed: the wait sits there)
+#endif
         }
         u32 evw = st.pk & 0xBF03FF00u;    // event word of this lane (without lane and quality bits)
         if (KIND == STEP_C) {
@@ -665,6 +673,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                 st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
                 st.pk = ent.w;
+#if MDX_QPREFETCH
+                if (MASK) {
+                    // records that cannot be masked — no qualities, or the caller's hint — read one fixed line instead
+                    const u32 qo = so - c_so + c_qo;
+                    st.q12 = *(const u32x3 *)(qualW + ((ent.w & 0x40000000u) ? (qo & ~3u) : 0u));
+                }
+#endif
             };
             // software pipeline: PIPE_DEPTH steps in flight, each in its own register set (no register
             // rotation: a copy of an in-flight destination would wait for its load).  Every point of

@@ -379,3 +379,129 @@ def test_flag_bit_15_of_a_file_is_not_the_kernels_hint(tmp_path):
     b.lib = np.asarray([0 if r in ("rgA", "x") else 1 for r in rg], np.uint16)
     want = oracle_tableset(ref, b, libs, 70, 10, 25)
     assert outs["host"][0] == want.misincorporation_text() and outs["host"][1] == want.dnacomp_text()
+
+
+def _inflate_on_device(eng, cases):
+    """cases: [(deflate payload, ISIZE, CRC32)] -> [(status, bytes out, crc ok)] through mdx_gbam_inflate_blocks."""
+    lib = eng._lib
+    lib.mdx_gbam_inflate_blocks.restype = ctypes.c_int
+    lib.mdx_gbam_inflate_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    comp = np.frombuffer(b"".join(c for c, _, _ in cases) + b"\0" * 8, np.uint8).copy()
+    blk = np.zeros((len(cases), 4), np.uint32)
+    cin = cout = 0
+    for i, (c, isize, _) in enumerate(cases):
+        blk[i] = (cin, len(c), cout, isize)
+        cin += len(c)
+        cout += (isize + 15) & ~15
+    out = np.zeros(cout + 16, np.uint8)
+    status = np.zeros(len(cases), np.int32)
+    crc = np.asarray([k for _, _, k in cases], np.uint32)
+    crc_ok = np.zeros(len(cases), np.uint8)
+    rc = lib.mdx_gbam_inflate_blocks(eng._ctx, comp.ctypes.data, cin, blk.ctypes.data, len(cases), out.ctypes.data, cout,
+                                     status.ctypes.data, crc.ctypes.data, crc_ok.ctypes.data)
+    assert rc == 0, rc
+    return [(int(status[i]), out[int(blk[i, 2]):int(blk[i, 2]) + int(blk[i, 3])].tobytes(), bool(crc_ok[i])) for i in range(len(cases))]
+
+
+def test_device_inflate_against_zlib_every_block_type_and_damage():
+    """gbam_inflate_kernel on streams htslib never writes but DEFLATE allows: levels 0/1/6/9 x default / Z_FIXED /
+    Z_HUFFMAN_ONLY / Z_RLE, several deflate blocks per member (stored ones among them), matches at distances that
+    cross the 4 KiB LDS ring and reach the output already flushed to HBM (4097 .. 32768), 64 KiB of one byte; then
+    damaged streams: whatever zlib decodes the device decodes to the same bytes, what zlib refuses is refused or
+    caught by the CRC — never accepted with other bytes, never a hang."""
+    import random
+    import zlib
+    from mapdamage_amd.engine import DamageEngine
+
+    def raw(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        if not flush_every:
+            return c.compress(data) + c.flush()
+        out = b""
+        for lo in range(0, len(data), flush_every):
+            out += c.compress(data[lo:lo + flush_every]) + c.flush(zlib.Z_FULL_FLUSH if (lo // flush_every) % 2 else zlib.Z_SYNC_FLUSH)
+        return out + c.flush()
+
+    rnd = random.Random(5)
+    nprng = np.random.default_rng(5)
+    rb = lambda n: nprng.integers(0, 256, n, dtype=np.uint8).tobytes()      # noqa: E731
+    dna = lambda n: bytes(nprng.choice(np.frombuffer(b"ACGT", np.uint8), n))   # noqa: E731
+    datas = [b"", b"a", b"abc" * 1000, rb(60000), dna(65536), b"\x00" * 65536, b"G" * 65536, rb(100),
+             bytes(nprng.choice(np.frombuffer(b"ACGTN!#$%&'()*+,-./0123456789", np.uint8), 30000)),
+             b"ACGT" * 3000 + rb(30000) + b"TTTTGGGG" * 2000, rb(20000) + dna(40000)]
+    # matches that reach back across the ring into flushed output: a seed repeated at chosen distances
+    for dist in (4095, 4096, 4097, 4098, 4350, 6143, 8191, 8192, 8193, 12000, 16384, 20000, 32767, 32768):
+        seed = rb(700)
+        body = bytearray(rb(dist - 700) if dist > 700 else b"")
+        data = seed + bytes(body) + seed + dna(300) + seed[:258] + rb(50)
+        datas.append(data[:65536])
+        # the same right behind a stored block (level 0 first half, compressed second half in one member)
+        datas.append((rb(dist) + data)[:65536])
+    valid = []
+    for d in datas:
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                valid.append((raw(d, level, strategy), d))
+        for every in (1000, 5000, 33000):
+            valid.append((raw(d, 6, flush_every=every), d))
+            valid.append((raw(d, 9, zlib.Z_FIXED, flush_every=every), d))
+    # a stored block right in front of a far match (distance > ring directly behind a stored block)
+    for dist in (4097, 9000, 32768):
+        a = rb(dist)
+        c = zlib.compressobj(0, zlib.DEFLATED, -15)
+        part1 = c.compress(a) + c.flush(zlib.Z_FULL_FLUSH)
+        d2 = a[:300] + b"xyz"
+        # second part compressed with the first as dictionary-less history: decoders see one stream
+        c2 = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, a[-32768:])
+        part2 = c2.compress(d2) + c2.flush()
+        valid.append((part1 + part2, a + d2))
+
+    def zlib_says(comp):
+        try:
+            z = zlib.decompressobj(-15)
+            out = z.decompress(comp, 65537)
+            if z.eof and len(out) <= 65536:
+                return out
+        except zlib.error:
+            pass
+        return None
+
+    cases, expect = [], []
+    for comp, d in valid:
+        assert zlib_says(comp) == d
+        cases.append((comp, len(d), zlib.crc32(d) & 0xFFFFFFFF))
+        expect.append(("valid", d))
+    for _ in range(200):                                   # random bytes
+        g = rb(rnd.randint(1, 400))
+        z = zlib_says(g)
+        ref = z if z is not None else b"?" * rnd.randint(1, 500)
+        cases.append((g, len(ref), zlib.crc32(ref) & 0xFFFFFFFF))
+        expect.append(("ok" if z is not None else "refused", ref))
+    for _ in range(1500):                                  # valid streams with a few bits flipped
+        d = bytes(rnd.choice(b"ACGTACGTACGTNIIIIII#####") for _ in range(rnd.randint(1, 3000))) if rnd.random() < 0.7 else \
+            (rb(rnd.randint(1, 9000)) + dna(rnd.randint(1, 9000))) * rnd.randint(1, 3)
+        d = d[:65536]
+        comp = bytearray(raw(d, rnd.choice([1, 6, 9]), rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE])))
+        for _ in range(rnd.randint(1, 3)):
+            comp[rnd.randrange(len(comp))] ^= 1 << rnd.randrange(8)
+        comp = bytes(comp)
+        if rnd.random() < 0.2:
+            comp = comp[:rnd.randrange(1, len(comp) + 1)]                      # truncated
+        z = zlib_says(comp)
+        ref = z if z is not None else d
+        cases.append((comp, len(ref), zlib.crc32(ref) & 0xFFFFFFFF))
+        expect.append(("ok" if z is not None else "refused", ref))
+    with DamageEngine([("s", "l")]) as eng:
+        got = []
+        for lo in range(0, len(cases), 512):
+            got += _inflate_on_device(eng, cases[lo:lo + 512])
+    bad = []
+    for i, ((kind, ref), (status, out, crc_ok)) in enumerate(zip(expect, got)):
+        if kind in ("valid", "ok"):
+            if status != len(ref) or out != ref or not crc_ok:
+                bad.append((i, kind, status, len(ref), crc_ok))
+        elif status == len(ref) and crc_ok and out != ref:
+            bad.append((i, kind, status, len(ref), crc_ok))
+    assert not bad, bad[:10]
+    assert sum(1 for k, _ in expect if k == "refused") > 300 and sum(1 for k, _ in expect if k == "ok") > 20
