@@ -402,7 +402,7 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
             // a wavefront classifies at most ceil(n / wavefronts) records, rounded up to whole tiles
             const int64_t nwaves = (int64_t)grid * wpb;
             a.list_cap = (b->n_reads + nwaves - 1) / nwaves + 128;
-            HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(3 * a.list_cap + a.list_cap / 4 + 1) * 16));
+            HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 4 + 1) * 16));
             a.lists = (uint4 *)c->lists.p;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -135,11 +135,11 @@ struct MdxTabArgs {
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
-    // Per-wavefront lists (16-byte staging entries): wavefront w owns 3 list_cap + list_cap / 4 + 1 entries — partial
+    // Per-wavefront lists (16-byte staging entries): wavefront w owns 5 list_cap + list_cap / 4 + 1 entries — partial
     // records upwards from 0, single insertions upwards from list_cap, single deletions downwards from 2 list_cap - 1,
-    // the complete records the general pass finds upwards from 2 list_cap, and from 3 list_cap on the indices (u32) of
-    // the records the tile loop leaves to the general pass; list_cap >= the records a wavefront classifies.  Written
-    // in the tile loop, read back by the same wavefront.
+    // the complete records the general pass finds upwards from 2 list_cap, from 3 list_cap on the columns (two entries
+    // per record) and from 5 list_cap on the indices (u32) of the records the tile loop leaves to the general pass;
+    // list_cap >= the records a wavefront classifies.  Written in the tile loop, read back by the same wavefront.
     uint4 *lists;
     int64_t list_cap;
 };

@@ -39,6 +39,24 @@ typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 typedef u32 __attribute__((aligned(1))) u32_u;
 typedef u16 __attribute__((aligned(1))) u16_u;
 struct __attribute__((packed, aligned(4))) u32x3 { u32 x, y, z; };   // global_load_dwordx3
+typedef u32 u32v3 __attribute__((ext_vector_type(3)));
+typedef u32v3 __attribute__((aligned(4))) u32v3_u;
+// Streamed once (SEQ, qualities, the per-record columns): loaded non-temporal, so that these lines are the first to leave
+// the XCD's L2 — which then keeps more of the reference, the one operand that is re-read (two random windows per
+// record: 58 % of what crosses the fabric for the survey's genome)
+#ifndef MDX_NT
+#define MDX_NT 1
+#endif
+__device__ __forceinline__ u32x3 ld12_stream(const u8 *p) {
+    u32x3 r;
+#if MDX_NT
+    const u32v3 t = __builtin_nontemporal_load((const u32v3_u *)p);
+    r.x = t.x; r.y = t.y; r.z = t.z;
+#else
+    r = *(const u32x3 *)p;
+#endif
+    return r;
+}
 typedef unsigned long long u64;
 typedef long long i64;
 
@@ -277,7 +295,11 @@ __device__ __forceinline__ void direct8(u32 *lds, u32 r_lo, u32 r_hi, u32 base_b
 // element idx of a column, the byte offset computed in 32 bits (batches hold fewer than 2^30 records)
 template <class T>
 __device__ __forceinline__ T ld32(const T *base, u32 idx) {
+#if MDX_NT
+    return __builtin_nontemporal_load((const T *)((const char *)base + (size_t)(idx * (u32)sizeof(T))));
+#else
     return *(const T *)((const char *)base + (size_t)(idx * (u32)sizeof(T)));
+#endif
 }
 
 // FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
@@ -671,13 +693,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 }
                 st.ro = ro; st.so = so;
                 st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
-                st.s12 = *(const u32x3 *)(seqW + (so & ~3u));
+                st.s12 = ld12_stream(seqW + (so & ~3u));
                 st.pk = ent.w;
 #if MDX_QPREFETCH
                 if (MASK) {
                     // records that cannot be masked — no qualities, or the caller's hint — read one fixed line instead
                     const u32 qo = so - c_so + c_qo;
-                    st.q12 = *(const u32x3 *)(qualW + ((ent.w & 0x40000000u) ? (qo & ~3u) : 0u));
+                    st.q12 = ld12_stream(qualW + ((ent.w & 0x40000000u) ? (qo & ~3u) : 0u));
                 }
 #endif
             };
@@ -720,9 +742,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     // Regions of the wavefront's part of MdxTabArgs::lists (16-byte entries; `cap` = list_cap):
     //   [0, cap)        partial records, upwards            [cap, 2 cap)  single insertions upwards / deletions downwards
     //   [2 cap, 3 cap)  complete records found by the general pass, upwards
-    //   [3 cap, ...)    the indices (u32) of the records the tile loop leaves to the general pass
-    uint4 *const lists = a.lists + (i64)gwave * (3 * a.list_cap + a.list_cap / 4 + 1);
-    u32 *const dlist = (u32 *)(lists + 3 * a.list_cap);
+    //   [3 cap, 5 cap)  the columns (two entries each) of the records the tile loop leaves to the general pass,
+    //   [5 cap, ...)    and their indices (u32)
+    uint4 *const lists = a.lists + (i64)gwave * (5 * a.list_cap + a.list_cap / 4 + 1);
+    uint4 *const dcols = lists + 3 * a.list_cap;
+    u32 *const dlist = (u32 *)(lists + 5 * a.list_cap);
     int lP = 0, lI = 0, lD = 0, lC = 0;
 
     // ------------------------------------------------------------ the general pass: any record, lane per record
@@ -730,7 +754,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     // fragment length, soft clips, error checks, classification.  FAST: fed 64 at a time with the records the tile loop
     // cannot take (anything but a single match operation) — their entries go to the wavefront's lists; otherwise it is
     // the whole tile loop.
-    auto general = [&](const u32 ri, const bool valid) {
+    // (the record's columns come with it: the tile loop has read them once already and hands them over through the list)
+    auto general = [&](const u32 ri, const bool valid, const u32 fl, const int c_lib, const int c_tid, const int c_pos,
+                       const int c_tlen, const u32 c_co0, const u32 c_co1, const u32 c_so0, const u32 c_so1) {
         // the arguments phase 1 needs are read from the kernel-argument segment when they are used (scalar loads through
         // the constant cache) instead of living in SGPRs across the whole kernel: the kernel wants far more scalar
         // registers than there are, and every spilled one costs a v_readlane per use
@@ -738,13 +764,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         asm volatile("" : "+s"(kp));
         const MdxTabArgs &p = *kp;
         // ------------------------------------------------------------ phase 1: lane per record
-        // the per-record columns are requested together, before the flag is known (one memory round
-        // trip for the batch instead of two)
-        const u32 rj = valid ? ri : 0u;
-        const u32 fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
-        const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
-        const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
-        bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
+        bool kept = valid && (fl & 0xF04u) == 0;  // reader.py:121-132
         // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
         // the others are left to their own launch (a library id beyond the last one is an error in every launch)
         if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
@@ -1203,7 +1223,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         for (u32 it = 0; it < n_it; it++) {
             const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
             const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
-            general(tbase + lane, tbase + lane < r_hi);
+            // the per-record columns are requested together, before the flag is known (one memory round
+            // trip for the tile instead of two)
+            const u32 ri = tbase + lane;
+            const bool valid = ri < r_hi;
+            const u32 rj = valid ? ri : r_hi - 1;
+            general(ri, valid, (u32)ld32(a.flag, rj), ld32(a.lib, rj), ld32(a.tid, rj), ld32(a.pos, rj), ld32(a.tlen, rj),
+                    ld32(a.cigar_off, rj), ld32(a.cigar_off, rj + 1), ld32(a.seq_off, rj), ld32(a.seq_off, rj + 1));
         }
     } else {
         // The tile loop proper takes the records whose CIGAR is a single match operation (aDNA: most of them) with
@@ -1257,7 +1283,16 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                                   aend <= clen && c_so0 >= (u32)(8 * d.nl8) && (i64)c_so0 + (i64)len + 8 * d.nl8 <= a.n_bases;
                 const u64 mDef = __ballot(kept && !triv);
                 if (mDef) {
-                    if (kept && !triv) dlist[nDef + mbcnt64(mDef, 0)] = ri;
+                    if (kept && !triv) {
+                        // the record's index and the columns just read (36 bytes): the general pass does not gather them again
+                        const int at = nDef + mbcnt64(mDef, 0);
+                        uint4 c0_, c1_;
+                        c0_.x = fl | ((u32)c_lib << 16); c0_.y = (u32)c_tid; c0_.z = (u32)c_pos; c0_.w = (u32)c_tlen;
+                        c1_.x = c_co0; c1_.y = c_co1; c1_.z = c_so0; c1_.w = c_so1;
+                        dlist[at] = ri;
+                        dcols[2 * at] = c0_;
+                        dcols[2 * at + 1] = c1_;
+                    }
                     nDef += __popcll(mDef);
                 }
                 const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
@@ -1360,8 +1395,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // (the wavefront's own stores: complete before they are read back)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const u32 rk = dlist[dDone + (lane < m ? lane : 0)];
-                general(rk, lane < m);
+                const int at = dDone + (lane < m ? lane : 0);
+                const u32 rk = dlist[at];
+                const uint4 c0_ = dcols[2 * at], c1_ = dcols[2 * at + 1];
+                general(rk, lane < m, c0_.x & 0xFFFFu, (int)(c0_.x >> 16), (int)c0_.y, (int)c0_.z, (int)c0_.w, c1_.x, c1_.y, c1_.z, c1_.w);
                 dDone += m;
             }
             if (past && dDone >= nDef) break;
