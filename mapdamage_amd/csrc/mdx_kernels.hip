@@ -41,11 +41,12 @@ typedef u16 __attribute__((aligned(1))) u16_u;
 struct __attribute__((packed, aligned(4))) u32x3 { u32 x, y, z; };   // global_load_dwordx3
 typedef u32 u32v3 __attribute__((ext_vector_type(3)));
 typedef u32v3 __attribute__((aligned(4))) u32v3_u;
-// Streamed once (SEQ, qualities, the per-record columns): loaded non-temporal, so that these lines are the first to leave
-// the XCD's L2 — which then keeps more of the reference, the one operand that is re-read (two random windows per
-// record: 58 % of what crosses the fabric for the survey's genome)
+// MDX_NT=1: the operands streamed once (SEQ, qualities, the per-record columns) loaded non-temporal, so that their lines
+// are the first to leave the XCD's L2 in favour of the reference (two random windows per record: 58 % of what crosses
+// the fabric for the survey's genome).  Measured (r03c): L2 misses -2 %, kernel time unchanged on the 10 Mb genome and
+// 7 % worse on a 3 Gb one (the loads skip the vector L1) — off.
 #ifndef MDX_NT
-#define MDX_NT 1
+#define MDX_NT 0
 #endif
 __device__ __forceinline__ u32x3 ld12_stream(const u8 *p) {
     u32x3 r;
