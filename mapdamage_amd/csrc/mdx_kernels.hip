@@ -457,8 +457,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     //           (column): those bytes are counted, still optimistically, straight into MIS[c][base] and CMP[c - g][base]
     //           (direct8) instead of TC, and their events say so (drain_all).
     // (full_tag: every slot of the step holds a record — all steps of a run but its last one)
-    auto count = [&](const Stage &st, auto kind_tag, auto full_tag) {
+    // (qm_tag: the step looks at the qualities — QM kernels only; the run of the records that cannot be masked does not)
+    auto count = [&](const Stage &st, auto kind_tag, auto full_tag, auto qm_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool QM = MASK && decltype(qm_tag)::value;
         constexpr int KIND = decltype(kind_tag)::value;
         // slots past the last record of the tile: no increments, no events
         const bool act = FULL || lane < st.lim;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 q_ready = true;
             }
         };
-        if (MASK) {
+        if (QM) {
 #if MDX_QPREFETCH
             // (requested by fill(), with the other two windows)
             q12_ = st.q12; qo_ = st.so - c_so + c_qo;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 tcd_lo = tcd_hi = 0u;
                 if (KIND == STEP_GD) {
                     s_lo = m_lo; s_hi = m_hi;
-                    if (MASK) {
+                    if (QM) {
                         // the qualities travel with the read; a deleted column has none (never masked, align.py:67)
                         qwin();
                         const u64 q64 = (u64)q_lo | ((u64)q_hi << 32), ql = q64 >> shr, qh = q64 << shl;
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // bytes that are not tasks of this record: zero in both strings (a pair that raises no event and that
             // drain_all passes over)
             s_lo &= dyn_lo; s_hi &= dyn_hi; r_lo &= dyn_lo; r_hi &= dyn_hi;
-            if (MASK) { emvm_lo &= dyn_lo; emvm_hi &= dyn_hi; }   // (the quality bytes are not zeroed)
+            if (QM) { emvm_lo &= dyn_lo; emvm_hi &= dyn_hi; }   // (the quality bytes are not zeroed)
             // all eight bytes with one increment, like a complete record's: a zeroed byte lands in plane A, and DMP knows
             // how many of those there are per window byte (phase 1)
             if (KIND == STEP_GD) tc_bump8_all(r_lo & tcd_lo, r_hi & tcd_hi, base_b, act ? 1u : 0u);
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         }
         // MASK: bit 7 of the bytes whose quality is below --min-basequal (align.py:65-71)
         u32 lowq_lo = 0, lowq_hi = 0;
-        if (MASK) {
+        if (QM) {
             qwin();
             const u32 minq4 = (st.pk & 0x40000000u) ? (u32)a.minqual * 0x01010101u : 0u;
             lowq_lo = ~((q_lo | 0x80808080u) - minq4) & 0x80808080u;
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         u32 x_lo = ((s_lo ^ r_lo) & emvm_lo) | (r_lo & c_hivm_lo);
         u32 x_hi = ((s_hi ^ r_hi) & emvm_hi) | (r_hi & c_hivm_hi);
         u32 mq_lo = 0, mq_hi = 0;
-        if (MASK) {
+        if (QM) {
             // the masked columns of this lane: bit 7 of the byte
             mq_lo = lowq_lo & emvm_lo;
             mq_hi = lowq_hi & emvm_hi;
@@ -588,17 +590,25 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 if (m) {
                     const u32 t_lo = mq_lo >> 7, t_hi = mq_hi >> 7;
                     x_lo &= ~((t_lo << 8) - t_lo); x_hi &= ~((t_hi << 8) - t_hi);
-                    const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
-                    const int b_cmp = lbw + d.off_cmp() + (rev * 2 + c_side) * L * 4;
+                    // (all in 32 bits, and the lane's first position derived here from the SEQ offset it holds anyway: as a
+                    // loop invariant of its own it was a 64-bit register pair spilled across the hot loop)
+                    u32 so_l = c_so;
+                    asm volatile("" : "+v"(so_l));
+                    const u32 right = c_cm != 0u ? 1u : 0u;
+                    // position of byte 0 (left side: c_m8 - A, rising) or of byte 7 (right side: c_m8 - A, byte 7 - j rising)
+                    const u32 p0 = right ? ph_seq - 8u - so_l : so_l - ph_seq;        // c_m8 - A on either side
+                    const u32 lbw = ((st.pk >> 24) & 0x3Fu) * (u32)d.w_lib, rev = st.pk >> 31;
+                    const u32 b_cmp = lbw + (u32)d.off_cmp() + (rev * 2u + right) * (u32)(L * 4);
                     const u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32);
 #pragma unroll 1
                     while (m) {
-                        const int sh = (__ffsll((long long)m) - 1) & ~7, jb = sh >> 3;
+                        const u32 sh = (u32)(__ffsll((long long)m) - 1) & ~7u, jb = sh >> 3;
                         m &= m - 1;
                         const u32 sb = (u32)(s64 >> sh) & 0xFFu, rb = (u32)(r64 >> sh) & 0xFFu;
-                        atomicAdd(&lds[(base_b >> 2) + (((rb >> 1) & 3u) << 9) + 64 * jb], 0xFFFFFFFFu);   // -1
+                        atomicAdd(&lds[(base_b >> 2) + (((rb >> 1) & 3u) << 9) + 64u * jb], 0xFFFFFFFFu);   // -1
                         const int sc = classify_read(sb);
-                        if (sc < 4) atomicAdd(&lds[b_cmp + ((c_side ? c_m8 + 7 - jb : c_m8 + jb) - A) * 4 + sc], 1u);
+                        const u32 pos = right ? p0 + 7u - jb : p0 + jb;      // = (c_side ? c_m8 + 7 - jb : c_m8 + jb) - A
+                        if (sc < 4) atomicAdd(&lds[b_cmp + pos * 4u + (u32)sc], 1u);
                     }
                     // (a matching pair in the event copy: drain_all must not look at these bytes again)
                     const u32 mb_lo = (t_lo << 8) - t_lo, mb_hi = (t_hi << 8) - t_hi;
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 qS[slot] = es;
                 qR[slot] = er;
                 u32 w = evw | (c_lane4 << 16);
-                if (MASK) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
+                if (QM) w |= gather_bits(mq_lo) | (gather_bits(mq_hi) << 4);
                 qW[slot] = w;
             }
             qcount += n;
@@ -633,8 +643,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     // ---- the fast path's runs (used by the tile loop for the complete records and, behind it, for the lists)
         const int R = d.R, G = d.G;
         // A run = the steps of the nrec staged records from entry e0 on, all of one kind (count())
-        auto run = [&](const int e0, const int nrec, auto kind_tag) {
+        auto run = [&](const int e0, const int nrec, auto kind_tag, auto qm_tag) {
             constexpr int KIND = decltype(kind_tag)::value;
+            constexpr bool QM = MASK && decltype(qm_tag)::value;
             const int nsteps = (nrec + R - 1) / R;
             int kf = 0;
             // fill() always issues its loads (past the last step it re-reads it), so the number of
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 st.s12 = ld12_stream(seqW + (so & ~3u));
                 st.pk = ent.w;
 #if MDX_QPREFETCH
-                if (MASK) {
+                if (QM) {
                     // records that cannot be masked — no qualities, or the caller's hint — read one fixed line instead
                     const u32 qo = so - c_so + c_qo;
                     st.q12 = ld12_stream(qualW + ((ent.w & 0x40000000u) ? (qo & ~3u) : 0u));
@@ -716,13 +727,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             for (int k = PD; k < nsteps; k += PD) {
     #pragma unroll
                 for (int dd = 0; dd < PD; dd++) {
-                    count(st[dd], kind_tag, std::true_type{});      // (never the last step of the run)
+                    count(st[dd], kind_tag, std::true_type{}, qm_tag);      // (never the last step of the run)
                     fill(st[dd]);
                 }
             }
     #pragma unroll
             for (int dd = 0; dd < PD; dd++)
-                if (dd == 0 || st[dd].valid) count(st[dd], kind_tag, std::false_type{});
+                if (dd == 0 || st[dd].valid) count(st[dd], kind_tag, std::false_type{}, qm_tag);
         };
 
     // Tiles of (up to) 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
@@ -1246,7 +1257,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         int nDef = 0, dDone = 0;
         for (u32 it = 0;; it++) {
             const bool past = it > n_it || n_it == 0;
-            int nF = 0;
+            int nF = 0, nF0 = 0;
             if (!past) {
                 const MdxTabArgs *kp = ka;
                 asm volatile("" : "+s"(kp));
@@ -1359,8 +1370,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
                 const u64 mF = __ballot(isF), mP = mT & ~mF;
                 nF = __popcll(mF);
+                // MASK: the complete records that cannot be masked (no qualities, or the caller's hint) are staged first and
+                // counted by a run of their own that does not look at qualities — the unmasked step
+                const u64 mF0 = MASK ? __ballot(isF && !(ent.w & 0x40000000u)) : 0ull;
+                nF0 = MASK ? __popcll(mF0) : 0;
                 if (mF) {
-                    if (isF) stg[mbcnt64(mF, 0)] = ent;
+                    if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
                     // the slots past the last record of a step shadow a real record (and are masked out)
                     const int first = __ffsll((long long)mF) - 1;
                     uint4 pad;
@@ -1386,7 +1401,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // Bytes that are not plain matches are not handled here: they are appended as events to a
                 // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
                 // classification code runs once per 64 events instead of once per record.
-                if (nF) run(0, nF, std::integral_constant<int, STEP_C>{});
+                if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
+                if (nF - nF0) run(nF0, nF - nF0, std::integral_constant<int, STEP_C>{}, std::true_type{});
 #endif
             }
             // ---------------------------------------------------- the general pass over the records left to it
@@ -1420,7 +1436,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const uint4 ent = lists[first + (i64)dir * (e + (lane < m ? lane : 0))];
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
-                run(0, m, kind_tag);
+                run(0, m, kind_tag, std::true_type{});
             }
         };
         list_runs(2 * a.list_cap, 1, lC, std::integral_constant<int, STEP_C>{});

@@ -1,4 +1,4 @@
-for t in noqp cur; do
+for t in r03d cur; do
   if [ $t != cur ]; then cp mapdamage_amd/libmdx.so /tmp/keep.so; cp tools/bin/libmdx_$t.so mapdamage_amd/libmdx.so; fi
   echo "== $t"; python tools/minqual_cost.py 4000000 2>&1 | grep "config 2" | python -c "
 import sys, json
