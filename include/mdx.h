@@ -119,6 +119,13 @@ int mdx_batch_free(mdx_ctx *ctx, mdx_batch *dev);
 int mdx_tabulate_host(mdx_ctx *ctx, const mdx_batch *batch);
 int mdx_tabulate_device(mdx_ctx *ctx, const mdx_batch *batch);
 
+/* The index mdx_sync reports for a bad record is its index within its batch plus this base (default 0): a caller
+ * that enqueues several batches before it synchronises (mdx_tabulate_host returns as soon as the host columns are
+ * staged; copies and kernels of consecutive batches overlap) sets the base to the number of records in front of each
+ * batch and gets back an index in its own numbering.  The lowest such index of all batches since the last
+ * mdx_sync / mdx_reset is reported. */
+int mdx_set_record_base(mdx_ctx *ctx, int64_t base);
+
 /* Waits for the stream and reports deferred per-read errors (MDX_ERR_BAD_READ ...);
  * *bad_read (may be NULL) receives the index of the first offending record of its batch. */
 int mdx_sync(mdx_ctx *ctx, int64_t *bad_read);

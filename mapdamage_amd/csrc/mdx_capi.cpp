@@ -100,7 +100,12 @@ struct mdx_ctx {
     uint32_t *d_partials = nullptr;
     // staging for mdx_tabulate_host: device columns, and two pinned bounce buffers the host columns go through
     // (the CPU fills one while the DMA engine drains the other)
-    DevBuf st[10];
+    DevBuf st[2][10];      // two sets: the columns of batch k+1 are copied while the kernel of batch k reads its own
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t st_copied[2] = {nullptr, nullptr}, st_done[2] = {nullptr, nullptr};
+    bool st_busy[2] = {false, false};
+    int st_turn = 0;
+    int64_t record_base = 0;   // added to the batch index of a record in the error word (mdx_set_record_base)
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
     DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
@@ -241,7 +246,12 @@ void mdx_destroy(mdx_ctx *c) {
     if (c->comm && c->comm_owned && rccl()) (void)rccl()->CommDestroy(c->comm);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &ev : c->rs_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (auto &b : c->st) b.release();
+    for (auto &set : c->st) for (auto &b : set) b.release();
+    for (int i = 0; i < 2; i++) {
+        if (c->st_copied[i]) (void)hipEventDestroy(c->st_copied[i]);
+        if (c->st_done[i]) (void)hipEventDestroy(c->st_done[i]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->lists.release();
     c->rs_part.release();
     c->rs_lists.release();
@@ -367,6 +377,7 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     a.lgd_over_cap = c->cfg.lgd_over_cap;
     a.n_lgd_over = c->d_n_lgd_over;
     a.err = c->d_err;
+    a.record_base = c->record_base;
     a.stage_off = mdx_k_stage_off(c->dims);
     a.queue_off = mdx_k_queue_off(c->dims);
     a.n_bases = b->n_bases;
@@ -435,36 +446,64 @@ int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
     const size_t bytes[10] = {(size_t)n * 2, (size_t)n * 2, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4,
                               (size_t)(n + 1) * 4, (size_t)h->n_cigar * 4, (size_t)(n + 1) * 4,
                               (size_t)h->n_bases, h->qual ? (size_t)h->n_bases : 0};
-    // the staging buffers may still be read by the previous batch's kernel
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // Two sets of staging buffers and a copy stream of the context's own: the columns of this batch are copied (set s)
+    // while the kernel of the previous one still reads the other set; the kernel waits for its copies (an event), and
+    // the copies into a set wait for the kernel that read it last (another one).  The call returns once the host
+    // columns sit in the pinned bounce buffers — the caller may release them — without waiting for the device.
     constexpr size_t PIN_BYTES = (size_t)16 << 20;
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) {
         if (!c->pin[i]) HIP_TRY(c, hipHostMalloc(&c->pin[i], PIN_BYTES, hipHostMallocDefault));
         if (!c->pin_done[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->pin_done[i], hipEventDisableTiming));
+        if (!c->st_copied[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->st_copied[i], hipEventDisableTiming));
+        if (!c->st_done[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->st_done[i], hipEventDisableTiming));
+    }
+    const int s = c->st_turn;
+    DevBuf *const st = c->st[s];
+    // (a buffer that has to grow is freed first: the kernel that read it must be done — rare, the sets settle at the
+    // size of the largest batch)
+    bool grow = false;
+    for (int i = 0; i < 10; i++) grow = grow || (src[i] && bytes[i] + 64 > st[i].cap);
+    if (c->st_busy[s]) {
+        if (grow) HIP_TRY(c, hipEventSynchronize(c->st_done[s]));
+        else HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->st_done[s], 0));
     }
     int turn = 0;
     for (int i = 0; i < 10; i++) {
         if (!src[i] || bytes[i] == 0) continue;
-        HIP_TRY(c, c->st[i].reserve(bytes[i] + 64));
+        HIP_TRY(c, st[i].reserve(bytes[i] + 64));
         // pageable host memory -> pinned bounce buffer (CPU) -> device (DMA), 16 MiB at a time: a pageable
         // hipMemcpy moves ~3.5 GB/s on this platform, this pipeline what one core copies
         for (size_t off = 0; off < bytes[i]; off += PIN_BYTES) {
             const size_t len = bytes[i] - off < PIN_BYTES ? bytes[i] - off : PIN_BYTES;
             if (c->pin_busy[turn]) HIP_TRY(c, hipEventSynchronize(c->pin_done[turn]));
             std::memcpy(c->pin[turn], (const uint8_t *)src[i] + off, len);
-            HIP_TRY(c, hipMemcpyAsync((uint8_t *)c->st[i].p + off, c->pin[turn], len, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipEventRecord(c->pin_done[turn], c->stream));
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)st[i].p + off, c->pin[turn], len, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipEventRecord(c->pin_done[turn], c->copy_stream));
             c->pin_busy[turn] = true;
             turn ^= 1;
         }
     }
+    HIP_TRY(c, hipEventRecord(c->st_copied[s], c->copy_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->st_copied[s], 0));
     mdx_batch dv = *h;
-    dv.flag = (const uint16_t *)c->st[0].p; dv.lib = (const uint16_t *)c->st[1].p;
-    dv.tid = (const int32_t *)c->st[2].p; dv.pos = (const int32_t *)c->st[3].p;
-    dv.tlen = (const int32_t *)c->st[4].p; dv.cigar_off = (const uint32_t *)c->st[5].p;
-    dv.cigar = (const uint32_t *)c->st[6].p; dv.seq_off = (const uint32_t *)c->st[7].p;
-    dv.seq = (const uint8_t *)c->st[8].p; dv.qual = h->qual ? (const uint8_t *)c->st[9].p : nullptr;
-    return mdx_tabulate_device(c, &dv);
+    dv.flag = (const uint16_t *)st[0].p; dv.lib = (const uint16_t *)st[1].p;
+    dv.tid = (const int32_t *)st[2].p; dv.pos = (const int32_t *)st[3].p;
+    dv.tlen = (const int32_t *)st[4].p; dv.cigar_off = (const uint32_t *)st[5].p;
+    dv.cigar = (const uint32_t *)st[6].p; dv.seq_off = (const uint32_t *)st[7].p;
+    dv.seq = (const uint8_t *)st[8].p; dv.qual = h->qual ? (const uint8_t *)st[9].p : nullptr;
+    rc = mdx_tabulate_device(c, &dv);
+    // (recorded whatever the outcome: the set is in use until what was enqueued on the stream has run)
+    HIP_TRY(c, hipEventRecord(c->st_done[s], c->stream));
+    c->st_busy[s] = true;
+    c->st_turn = s ^ 1;
+    return rc;
+}
+
+int mdx_set_record_base(mdx_ctx *c, int64_t base) {
+    if (!c || base < 0) return MDX_ERR_ARG;
+    c->record_base = base;
+    return MDX_OK;
 }
 
 int mdx_sync(mdx_ctx *c, int64_t *bad_read) {
@@ -478,7 +517,7 @@ int mdx_sync(mdx_ctx *c, int64_t *bad_read) {
         if (bad_read) *bad_read = (int64_t)(err >> 8);
         const int code = -(int)(err & 0xFF);
         char msg[160];
-        std::snprintf(msg, sizeof msg, "record %lld of its batch: %s", (long long)(err >> 8), mdx_strerror(code));
+        std::snprintf(msg, sizeof msg, "record %lld (index within its batch + the record base): %s", (long long)(err >> 8), mdx_strerror(code));
         return fail(c, code, msg);
     }
     if ((int64_t)nover > c->cfg.lgd_over_cap) return fail(c, MDX_ERR_LGD_OVERFLOW, mdx_strerror(MDX_ERR_LGD_OVERFLOW));

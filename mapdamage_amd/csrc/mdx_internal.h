@@ -129,7 +129,8 @@ struct MdxTabArgs {
     long long *lgd_over;             // [cap][4]
     long long lgd_over_cap;
     unsigned long long *n_lgd_over;
-    unsigned long long *err;         // min over (read_index << 8 | -code); ~0 = no error
+    unsigned long long *err;         // min over ((record_base + read_index) << 8 | -code); ~0 = no error
+    long long record_base;           // index of the batch's first record in the caller's numbering (mdx_set_record_base)
     int stage_off;                   // word offset of the per-wave record staging areas in the LDS
     int queue_off;                   // word offset of the per-wave rare-event queues in the LDS
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets

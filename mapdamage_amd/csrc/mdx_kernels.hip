@@ -907,7 +907,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // a CIGAR that disagrees with SEQ cannot come out of htslib
             bad = bad || over || cig_n == 0 || aend > clen || nq64 != (i64)sQ || sC > 0x3FFFFFFFu || n0u + sI > 0x3FFFFFFFu;
             if (bad) {
-                flag_error(p.err, (i64)ri, ERR_BAD_READ);
+                flag_error(p.err, (i64)ri + p.record_base, ERR_BAD_READ);
                 kept = false;
             } else {
                 const int n_gap = nID + 4 * (nE - nID);

@@ -33,7 +33,7 @@ EXPORTS = (
     "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled", "mdx_bam_qmin",
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
-    "mdx_gbam_inflate_blocks",
+    "mdx_gbam_inflate_blocks", "mdx_set_record_base",
 )
 
 
@@ -92,7 +92,8 @@ def load_library(path=None):
                  "mdx_finish", "mdx_reset", "mdx_timing_enable", "mdx_timing_read",
                  "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
                  "mdx_rescale_summary", "mdx_comm_unique_id", "mdx_comm_init", "mdx_comm_adopt", "mdx_comm_size",
-                 "mdx_finish_allreduce", "mdx_rescale_device", "mdx_tabulate_rescale_device", "mdx_rescale_timing_read"):
+                 "mdx_finish_allreduce", "mdx_rescale_device", "mdx_tabulate_rescale_device", "mdx_rescale_timing_read",
+                 "mdx_set_record_base"):
         getattr(lib, name).restype = ctypes.c_int
     lib.mdx_comm_size.argtypes = [ctypes.c_void_p]
     lib.mdx_rescale_summary_words.restype = ctypes.c_int64
@@ -235,16 +236,23 @@ class DamageEngine:
         self._check(self._lib.mdx_batch_upload(self._ctx, ctypes.byref(hb), ctypes.byref(dev)))
         return DeviceBatch(self, dev, batch.n, int(batch.seq.shape[0]), int(batch.cigar.shape[0]))
 
-    def tabulate(self, batch):
-        """Accumulate one batch (host ``ReadBatch`` or resident ``DeviceBatch``)."""
+    def tabulate(self, batch, sync=True, record_base=None):
+        """Accumulate one batch (host ``ReadBatch`` or resident ``DeviceBatch``).  A host batch is staged through the
+        library's pinned buffers: when the call returns its columns may be released.  ``sync=False`` leaves copies and
+        kernel in flight (the next host batch is copied meanwhile); a record the reference cannot process then
+        surfaces at the next ``sync()`` / ``finish()`` with index ``record_base`` + its index within its batch."""
+        base = 0 if record_base is None else int(record_base)
+        if base != getattr(self, "_record_base", 0):
+            self._check(self._lib.mdx_set_record_base(self._ctx, ctypes.c_int64(base)))
+            self._record_base = base
         if isinstance(batch, DeviceBatch):
             self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(batch.dev)))
         else:
             hb = _host_batch(batch)
             self._check(self._lib.mdx_tabulate_host(self._ctx, ctypes.byref(hb)))
-            # host columns may be released once the staged copies are enqueued and done; a record the
-            # reference cannot process surfaces here, with its index within this batch
-            self.sync()
+            if sync:
+                # a record the reference cannot process surfaces here, with its index within this batch
+                self.sync()
 
     def tabulate_view(self, view):
         """An ``MdxBatch`` of device pointers (``sam.GpuBamStream.next_view``): enqueued, errors at ``sync``."""

@@ -192,12 +192,12 @@ def _tabulate_on_host(options, reader, ref, libraries, logger):
                 batch, nothing_to_mask = mark_unmaskable(batch, options.minqual)
                 if nothing_to_mask:
                     batch = dataclasses.replace(batch, qual=None)
+            # the slices of a chunk are enqueued one behind the other — the copy of slice k+1 runs under the kernel of
+            # slice k — and the chunk is waited for once; a bad record comes back with its index among all records
+            # iterated so far (the reference would name the read)
             for lo in range(0, batch.n, options.batch_reads):
-                try:
-                    engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False))
-                except BadReadError as error:
-                    # index within the records iterated so far (the reference would name the read)
-                    raise BadReadError(n_reads + lo + error.read_index, str(error)) from None
+                engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False), sync=False, record_base=n_reads + lo)
+            engine.sync()
             n_reads += batch.n
         tables = engine.finish()
     return tables

@@ -440,3 +440,39 @@ def test_hip_quality_hint_skips_nothing_that_matters(mid_genome):
         eng.tabulate(hinted)
         got = eng.finish()
     assert_tables_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_host_batches_in_flight_and_record_base():
+    """mdx_tabulate_host returns once the host columns are staged: several slices are enqueued before the one sync (the
+    copy of slice k+1 runs under the kernel of slice k, two staging sets), the tables equal the oracle's, and a bad
+    record in a later slice is reported with its index among all records (mdx_set_record_base)."""
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    ref = synth.small_genome()
+    batch = synth.make_reads(ref, 30_000, 5, len_range=(25, 140), nlib=2, paired=True, frac_softclip=0.1, frac_ins=0.05,
+                             frac_del=0.05, frac_skip=0.01, frac_filtered=0.03)
+    libs = [("a", "x"), ("b", "y")]
+    want = oracle_tableset(ref, batch, libs, 70, 10, 0)
+    cuts = [0, 7_000, 7_001, 16_000, 16_500, 29_999, 30_000]          # slices of very different sizes: the sets grow
+    with DamageEngine(libs, 70, 10, 0) as eng:
+        eng.set_reference(ref)
+        for rep in range(3):
+            eng.reset()
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                eng.tabulate(batch.slice(lo, hi), sync=False, record_base=lo)
+            assert_tables_equal(eng.finish(), want)
+        # a record past its contig end in the fourth slice
+        eng.reset()
+        bad_at = int(np.flatnonzero((batch.flag[16_000:16_500] & 0xF04) == 0)[7]) + 16_000
+        broken = batch.slice(0, batch.n)
+        broken.pos[bad_at] = 10_000_000
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            eng.tabulate(broken.slice(lo, hi), sync=False, record_base=lo)
+        with pytest.raises(BadReadError) as err:
+            eng.sync()
+        assert err.value.read_index == bad_at
+        # and the default call still synchronises and numbers within the batch
+        eng.reset()
+        with pytest.raises(BadReadError) as err:
+            eng.tabulate(broken.slice(16_000, 16_500))
+        assert err.value.read_index == bad_at - 16_000
