@@ -268,12 +268,12 @@ __device__ __forceinline__ void rare_column(u32 *lds, u64 *raw, int b_mis, int b
                                             int p, int pc, u32 ch, int rch, bool masked) {
     // p: misincorporation position (column), pc: composition position (query index; differs behind a deletion)
     const int s = classify_read(ch);
-    const int sp = side * L + p;
-    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + pc) * 4 + s);
+    const int sp = (side ? L : 0) + p;      // (no 32-bit multiplies on this path: they run at a quarter of the rate)
+    if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + ((side ? L : 0) + pc) * 4 + s);
     if (!masked && s <= SYM_GAP) {
         const int r = classify_ref(rch);
         if (r <= SYM_GAP && r != s) {  // statistics.py:26-35
-            bump<USE_LDS>(lds, raw, b_mis + sp * 25 + mis_col(r, s));
+            bump<USE_LDS>(lds, raw, b_mis + __mul24(sp, 25) + mis_col(r, s));
         }
     }
 }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const u32 w = qW[lane];
             const int ln = (int)(w >> 18) & 63;
             const int rev = (int)(w >> 31);
-            const int lb = (int)((w >> 24) & 0x3Fu) * d.w_lib;
+            const int lb = __mul24((int)((w >> 24) & 0x3Fu), d.w_lib);
             const bool del = (w >> 30) & 1u;
             const int g = del ? (int)(w >> 8) & 7 : 0, bnd = (int)(w >> 11) & 15;
             const int tcw = del ? lb + d.off_tc() + rev * 4 * 512 : (int)((w & 0x3FF00u) >> 2);   // first word of TC[library][strand]
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const u64 s64 = (u64)es.x | ((u64)es.y << 32), r64 = (u64)er.x | ((u64)er.y << 32);
             u64 x = (((s64 ^ r64) & em) | (r64 & 0x8080808080808080ull)) & vm;
             if (MASK) x |= spread_bits(w & 0xFFu);
-            const int b_mis = lb + d.off_mis() + rev * 2 * L * 25, b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
+            const int b_mis = lb + d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = lb + d.off_cmp() + (rev ? 2 * L * 4 : 0);
             // usually exactly one byte of the lane differs: handle the lowest such byte (all lanes busy),
             // repeat only while some lane has another
             while (x) {
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const bool direct = del && (side ? jb < bnd : jb >= bnd);
                 const int pc = direct ? p - g : p;
                 if (direct) {
-                    bump_n<USE_LDS>(lds, raw, b_mis + (side * L + p) * 25 + (int)((rb >> 1) & 3u), 0xFFFFFFFFu);
-                    bump_n<USE_LDS>(lds, raw, b_cmp + (side * L + pc) * 4 + (int)((rb >> 1) & 3u), 0xFFFFFFFFu);
+                    bump_n<USE_LDS>(lds, raw, b_mis + __mul24((side ? L : 0) + p, 25) + (int)((rb >> 1) & 3u), 0xFFFFFFFFu);
+                    bump_n<USE_LDS>(lds, raw, b_cmp + ((side ? L : 0) + pc) * 4 + (int)((rb >> 1) & 3u), 0xFFFFFFFFu);
                 } else {
                     bump_n<USE_LDS>(lds, raw, tcw + (int)(((rb >> 1) & 3u) << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
                 }
@@ -541,12 +541,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     evw = (st.pk & 0xBF000000u) | 0x40000000u | (((aux >> 24) & 0x7Fu) << 8);
                     if (__ballot((dm_lo | dm_hi) != 0u)) {
                         const int g = (int)((aux >> 24) & 7u);
-                        const int lbw = (int)((st.pk >> 24) & 0x3Fu) * d.w_lib, rev = (int)(st.pk >> 31);
-                        const int row = (rev * 2 + c_side) * L + c_m8 - A;        // row of the lane's lowest position
+                        const int lbw = __mul24((int)((st.pk >> 24) & 0x3Fu), d.w_lib), rev = (int)(st.pk >> 31);
+                        const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
                         const u32 p_lo = c_side ? 0x04050607u : 0x03020100u, p_hi = c_side ? 0x00010203u : 0x07060504u;
                         const u32 rr_lo = __builtin_amdgcn_perm(r_hi, r_lo, p_lo), rr_hi = __builtin_amdgcn_perm(r_hi, r_lo, p_hi);
                         const u32 mm_lo = __builtin_amdgcn_perm(dm_hi, dm_lo, p_lo), mm_hi = __builtin_amdgcn_perm(dm_hi, dm_lo, p_hi);
-                        direct8<100>(lds, rr_lo, rr_hi, (u32)(4 * (lbw + d.off_mis() + row * 25)), mm_lo, mm_hi);
+                        direct8<100>(lds, rr_lo, rr_hi, (u32)(4 * (lbw + d.off_mis() + __mul24(row, 25))), mm_lo, mm_hi);
                         direct8<16>(lds, rr_lo, rr_hi, (u32)(4 * (lbw + d.off_cmp() + (row - g) * 4)), mm_lo, mm_hi);
                     }
                 } else {
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const u32 right = c_cm != 0u ? 1u : 0u;
                     // position of byte 0 (left side: c_m8 - A, rising) or of byte 7 (right side: c_m8 - A, byte 7 - j rising)
                     const u32 p0 = right ? ph_seq - 8u - so_l : so_l - ph_seq;        // c_m8 - A on either side
-                    const u32 lbw = ((st.pk >> 24) & 0x3Fu) * (u32)d.w_lib, rev = st.pk >> 31;
-                    const u32 b_cmp = lbw + (u32)d.off_cmp() + (rev * 2u + right) * (u32)(L * 4);
+                    const u32 lbw = __umul24((st.pk >> 24) & 0x3Fu, (u32)d.w_lib), rev = st.pk >> 31;
+                    const u32 b_cmp = lbw + (u32)d.off_cmp() + __umul24(rev * 2u + right, (u32)(L * 4));
                     const u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32);
 #pragma unroll 1
                     while (m) {
@@ -1250,23 +1250,17 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // of them wait they are classified together, every lane busy (a tile of 63 records holds a dozen such records
         // at most, which used to drag the whole wavefront through the general code once per tile).  Wavefronts reach
         // their general passes at different moments, under the counting of the others.
-        // The wavefronts of a CU start together and do the same work: left alone they would all sit in phase 1 (two
-        // memory round trips, nothing to count) at the same moments.  Each takes its first tile in two parts, the first
-        // of 9 .. 54 records by its place in the SIMD, so that the phases of the six wavefronts of a SIMD interleave.
-        const u32 skew = (u32)d.R * 3u * (1u + (u32)(((wave >> 2) * 2 + ((blockIdx.x ^ (blockIdx.x >> 8)) & 1)) % 6));
         int nDef = 0, dDone = 0;
         for (u32 it = 0;; it++) {
-            const bool past = it > n_it || n_it == 0;
+            const bool past = it >= n_it;
             int nF = 0, nF0 = 0;
             if (!past) {
                 const MdxTabArgs *kp = ka;
                 asm volatile("" : "+s"(kp));
                 const MdxTabArgs &p = *kp;
-                const u32 ti = it ? it - 1 : 0;      // iterations 0 and 1: the two parts of tile 0
-                const u32 tbase = ti < rounds ? (ti * nwaves + gwave) * T : t_lo + (ti - rounds) * T;
-                const u32 t_end = ti < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
-                const u32 r_lo = it == 1 ? (tbase + skew < t_end ? tbase + skew : t_end) : tbase;
-                const u32 r_hi = it == 0 ? (tbase + skew < t_end ? tbase + skew : t_end) : t_end;
+                const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
+                const u32 r_lo = tbase;
+                const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
                 // ---------------------------------------------------- phase 1 of the single-match records
                 const u32 ri = r_lo + lane;
                 const bool valid = ri < r_hi;
@@ -1308,7 +1302,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     nDef += __popcll(mDef);
                 }
                 const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
-                const int lbase = libid * d.w_lib;
+                const int lbase = __mul24(libid, d.w_lib);
                 const int nbefore = c_pos < A ? c_pos : A;
                 const int nafter = clen - aend < A ? (int)(clen - aend) : A;
                 const bool isF = triv && nq >= L && nbefore == A && nafter == A;
