@@ -502,9 +502,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const u32 aux = st.aux;
             u32 dyn_lo, dyn_hi, tcd_lo, tcd_hi;
             if (KIND == STEP_P) {
-                // tasks = bytes [lo, hi)
-                const u64 Lo = *(const u64 *)((const u8 *)ltab + (aux & 0x7Fu)), Hi = *(const u64 *)((const u8 *)ltab + ((aux >> 7) & 0x7Fu));
-                dyn_lo = (u32)Hi & ~(u32)Lo & c_vm_lo; dyn_hi = (u32)(Hi >> 32) & ~(u32)(Lo >> 32) & c_vm_hi;
+                // tasks = the bytes below the boundary (left side) / from it on (right side)
+                const u64 M = *(const u64 *)((const u8 *)ltab + aux);
+                const u32 sm = 0u - (u32)c_side;                         // all ones on the right side
+                dyn_lo = ((u32)M ^ sm) & c_vm_lo; dyn_hi = ((u32)(M >> 32) ^ sm) & c_vm_hi;
                 tcd_lo = tcd_hi = 0u;
             } else {
                 // [ta, tb) = the gap, tasks end at byte tl (left side; on the right side they start there)
@@ -675,14 +676,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     const bool act = lane < st.lim;
                     auto c8 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 8 ? 8 : v)) << 3; };
                     if (KIND == STEP_P) {
-                        // tasks = columns [k0, k1): entries of gapped records ([15] of z set) carry their run lengths,
-                        // plain ones their flank lengths
-                        const bool pre = (z & 0x8000u) != 0;
-                        const int k0 = pre ? -A : -t8;
-                        const int k1 = pre ? t8 : (nq_ < L ? nq_ : L);
-                        const int m0 = jo + sgn * k0, m1 = jo + sgn * k1;
-                        const int lo = m0 < m1 ? m0 : m1, hi = act ? (m0 < m1 ? m1 : m0) : 0;
-                        st.aux = c8(lo) | (c8(hi) << 7);
+                        // t8 = the task bytes of this side's window, counted from its outer end (the flank is complete:
+                        // records at a contig edge walk): the lane's tasks are its bytes [0, t8 - c_m8) on the left
+                        // side, [8 - (t8 - c_m8), 8) on the right side
+                        // (aux = eight times the number of bytes below the boundary; a slot without a record: no tasks)
+                        const int dm = t8 - c_m8;
+                        st.aux = act ? c8(c_side ? 8 - dm : dm) : (c_side ? 64u : 0u);
                     } else {
                         // one indel of g bases behind the first (left) / last (right) match run of t8 columns: the gap
                         // is bytes [ta, tb), the tasks end (left) / start (right) at byte tl.  A lane whose first
@@ -989,8 +988,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         u64 todo_g = todo_all;
         int nF = 0, nP = 0, nS = 0, nSI = 0;
         if (FAST) {
+            // (a record at a contig edge — a flank cut short — walks: the entries of the partial list have complete flanks,
+            // so that a partial step's tasks are a prefix of each window)
             const bool plain = kept && (w1 & D_SIMPLE) && sq >= (u32)(8 * d.nl8) &&
-                               (i64)sq + nq + 8 * d.nl8 <= a.n_bases;
+                               (i64)sq + nq + 8 * d.nl8 <= a.n_bases &&
+                               ((w1 >> D_NB_SHIFT) & 0xFF) == A && ((w1 >> D_NA_SHIFT) & 0xFF) == A;
             const bool isF = plain && (w1 & D_FULL);
             const u64 mF = __ballot(isF), mPp = __ballot(plain && !isF);
             u64 mP = mPp, mS = 0, mSI = 0;
@@ -999,7 +1001,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             uint4 ent;
             ent.x = (u32)(rbase - A + 256);
             ent.y = sq;
-            ent.z = (u32)nq | ((u32)(w1 >> D_NB_SHIFT) << 16);
+            // (partial entries: the task bytes of each window, A + min(nq, L); complete ones do not look at them)
+            ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
             ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                     ((w1 & D_HASQ) ? 0x40000000u : 0u) | ((u32)rev << 31);
             bool gpre = false, isS = false, covered = false;
@@ -1019,7 +1022,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 isS = gpre && one && dnq >= -7 && dnq <= 7;
                 if (gpre) {
                     w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
-                    ent.z = (u32)nq | 0x8000u | ((u32)vlr << 16);
+                    // (single-indel entries carry the two run lengths, the others the task bytes of each window)
+                    ent.z = (u32)nq | 0x8000u | ((u32)(isS ? vlr : vlr + A * 0x101) << 16);
                     // n0 - nq: 11 bits, the low eight in the low byte (all a D_ONE entry needs), the rest in [23:21]
                     ent.w |= ((u32)dnq & 0xFFu) | ((((u32)dnq >> 8) & 7u) << 21) | (isS ? PK_ONE : 0u);
                     // both runs reach --length: the entry covers every task of the record, nothing is left to walk
@@ -1063,12 +1067,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // where it ends before the window does.
                 if (USE_LDS) {
                     const int dl = libid * d.w_lib + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
-                    const int nbf = (w1 >> D_NB_SHIFT) & 0xFF, naf = (w1 >> D_NA_SHIFT) & 0xFF;
                     if (plain && !isF) {
-                        // tasks [-flank, min(nq, L)) per side
+                        // tasks [-A, min(nq, L)) per side
                         const int k1 = nq < L ? nq : L;
-                        if (nbf < A) { atomicAdd(&lds[dl], 1u); atomicAdd(&lds[dl + A - nbf], 0xFFFFFFFFu); }
-                        if (naf < A) { atomicAdd(&lds[dr], 1u); atomicAdd(&lds[dr + A - naf], 0xFFFFFFFFu); }
                         if (k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
                     } else if (gpre && !isS) {
                         // tasks [-A, first / last match run)
@@ -1285,8 +1286,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const i64 aend = (i64)c_pos + (i64)len;
                 // M, = or X over the whole of SEQ, inside the contig, and the speculative window loads inside the SEQ
                 // buffer; anything else (and anything wrong) is the general pass's
-                const bool triv = cand && ((0x181u >> op) & 1u) != 0 && len == c_so1 - c_so0 && len - 1u < 32767u && c_pos >= 0 &&
-                                  aend <= clen && c_so0 >= (u32)(8 * d.nl8) && (i64)c_so0 + (i64)len + 8 * d.nl8 <= a.n_bases;
+                // (and both flanks complete: a record at a contig edge walks)
+                const bool triv = cand && ((0x181u >> op) & 1u) != 0 && len == c_so1 - c_so0 && len - 1u < 32767u && c_pos >= A &&
+                                  aend + A <= clen && c_so0 >= (u32)(8 * d.nl8) && (i64)c_so0 + (i64)len + 8 * d.nl8 <= a.n_bases;
                 const u64 mDef = __ballot(kept && !triv);
                 if (mDef) {
                     if (kept && !triv) {
@@ -1303,9 +1305,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 }
                 const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
                 const int lbase = __mul24(libid, d.w_lib);
-                const int nbefore = c_pos < A ? c_pos : A;
-                const int nafter = clen - aend < A ? (int)(clen - aend) : A;
-                const bool isF = triv && nq >= L && nbefore == A && nafter == A;
+                const bool isF = triv && nq >= L;
                 // statistics.py:117-126
                 int lkey = -1;
                 if (triv) {
@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 uint4 ent;
                 ent.x = (u32)(c0 + c_pos - A + 256);
                 ent.y = c_so0;
-                ent.z = (u32)nq | ((u32)(nbefore | (nafter << 8)) << 16);
+                ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
                 ent.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                         ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
                 const u64 mF = __ballot(isF), mP = mT & ~mF;
@@ -1382,8 +1382,6 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     if (triv && !isF) {
                         const int dl = lbase + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
                         const int k1 = nq < L ? nq : L;
-                        if (nbefore < A) { atomicAdd(&lds[dl], 1u); atomicAdd(&lds[dl + A - nbefore], 0xFFFFFFFFu); }
-                        if (nafter < A) { atomicAdd(&lds[dr], 1u); atomicAdd(&lds[dr + A - nafter], 0xFFFFFFFFu); }
                         if (k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
                         lists[lP + mbcnt64(mP, 0)] = ent;
                     }
