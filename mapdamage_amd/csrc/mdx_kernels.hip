@@ -1271,24 +1271,36 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
                 bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
                 if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
-                // second round trip of the tile: the operation, the contig bounds and (MASK) the first quality together
-                const bool cand = kept && c_co1 - c_co0 == 1u && c_tid >= 0 && c_tid < a.n_contig && c_lib < a.nlib_total;
-                u32 cg0 = 0xFu;                  // (an operation code that is not a match)
+                // second round trip of the tile: the (up to three) operations, the contig bounds and (MASK) the first quality
+                // together.  The tile loop's own records: one match operation (M, = or X), alone or between soft clips —
+                // [S] M [S] — over the whole of SEQ.
+                const u32 cn = c_co1 - c_co0;
+                const bool cand = kept && cn - 1u < 3u && c_tid >= 0 && c_tid < a.n_contig && c_lib < a.nlib_total;
+                u32 g0 = 0xFu, g1 = 0xFu, g2 = 0xFu;                  // (an operation code that is neither)
                 i64 c0 = 0, clen = 0;
                 u32 q0 = 0xFFu;
                 if (cand) {
-                    cg0 = a.cigar[c_co0];
+                    g0 = a.cigar[c_co0];
+                    if (cn >= 2u) g1 = a.cigar[c_co0 + 1];
+                    if (cn >= 3u) g2 = a.cigar[c_co0 + 2];
                     c0 = a.contig_off[c_tid];
                     clen = a.contig_off[c_tid + 1] - c0;
                     if (MASK && a.qual != nullptr) q0 = a.qual[c_so0];
                 }
-                const u32 op = cg0 & 0xFu, len = cg0 >> 4;
+                const bool m0 = ((0x181u >> (g0 & 0xFu)) & 1u) != 0, m1 = ((0x181u >> (g1 & 0xFu)) & 1u) != 0;
+                const bool s0 = (g0 & 0xFu) == 4u, s1 = (g1 & 0xFu) == 4u, s2 = (g2 & 0xFu) == 4u;
+                // S M / S M S: the match is the second operation; M / M S: the first
+                const bool lead = s0 && m1 && (cn == 2u || (cn == 3u && s2));
+                const bool shape = lead || (m0 && (cn == 1u || (cn == 2u && s1)));
+                const u32 qs = lead ? g0 >> 4 : 0u;                                  // leading clip
+                const u32 tr = cn == 3u ? g2 >> 4 : ((cn == 2u && !lead) ? g1 >> 4 : 0u);   // trailing clip
+                const u32 len = (lead ? g1 : g0) >> 4;                               // the match
+                const u32 sq = c_so0 + qs;                                           // first aligned base (pysam's query)
                 const i64 aend = (i64)c_pos + (i64)len;
-                // M, = or X over the whole of SEQ, inside the contig, and the speculative window loads inside the SEQ
-                // buffer; anything else (and anything wrong) is the general pass's
-                // (and both flanks complete: a record at a contig edge walks)
-                const bool triv = cand && ((0x181u >> op) & 1u) != 0 && len == c_so1 - c_so0 && len - 1u < 32767u && c_pos >= A &&
-                                  aend + A <= clen && c_so0 >= (u32)(8 * d.nl8) && (i64)c_so0 + (i64)len + 8 * d.nl8 <= a.n_bases;
+                // ... inside the contig with both flanks complete (a record at a contig edge walks), and the speculative
+                // window loads inside the SEQ buffer; anything else (and anything wrong) is the general pass's
+                const bool triv = cand && shape && (u64)qs + len + tr == (u64)(c_so1 - c_so0) && len - 1u < 32767u && c_pos >= A &&
+                                  aend + A <= clen && sq >= (u32)(8 * d.nl8) && (i64)sq + (i64)len + 8 * d.nl8 <= a.n_bases;
                 const u64 mDef = __ballot(kept && !triv);
                 if (mDef) {
                     if (kept && !triv) {
@@ -1306,6 +1318,20 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
                 const int lbase = __mul24(libid, d.w_lib);
                 const bool isF = triv && nq >= L;
+                // statistics.py:37-51: positions [0, min(len, L)) of a soft clip, the left side's table iff no alignment
+                // column precedes it — as a difference (+1 at 0, -1 at the end), like the general pass
+                if (__ballot(triv && (qs | tr) != 0u)) {
+                    if (triv && qs) {
+                        const int m = qs < (u32)L ? (int)qs : L, base = lbase + d.off_mis() + __mul24(__mul24(rev * 2, L), 25) + COL_S;
+                        atomicAdd(&lds[base], 1u);
+                        if (m < L) atomicAdd(&lds[base + __mul24(m, 25)], 0xFFFFFFFFu);
+                    }
+                    if (triv && tr) {
+                        const int m = tr < (u32)L ? (int)tr : L, base = lbase + d.off_mis() + __mul24(__mul24(rev * 2 + 1, L), 25) + COL_S;
+                        atomicAdd(&lds[base], 1u);
+                        if (m < L) atomicAdd(&lds[base + __mul24(m, 25)], 0xFFFFFFFFu);
+                    }
+                }
                 // statistics.py:117-126
                 int lkey = -1;
                 if (triv) {
@@ -1358,7 +1384,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // staging entry (as in the general pass)
                 uint4 ent;
                 ent.x = (u32)(c0 + c_pos - A + 256);
-                ent.y = c_so0;
+                ent.y = sq;
                 ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
                 ent.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                         ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
