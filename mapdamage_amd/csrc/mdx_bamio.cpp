@@ -3,7 +3,9 @@
 // mdx_batch — the counterpart of iterating a pysam.AlignmentFile (mapdamage/reader.py:38,83-96,
 // 121-132) without pysam.  Pure host code (zlib); no HIP calls.
 #include "../../include/mdx.h"
+#ifndef MDX_HOST_ONLY      // (tools/sanitize/run_bamio.sh builds the host decoder alone, without the HIP runtime)
 #include "mdx_internal.h"
+#endif
 #include "mdx_crc32.h"
 
 #include <fcntl.h>
@@ -781,6 +783,7 @@ void mdx_bam_close(mdx_bam_stream *s) {
 }
 
 
+#ifndef MDX_HOST_ONLY
 // ------------------------------------------------------------------------------------------------
 // GPU-side decode (mdx_gbam.hip): the compressed file goes to HBM a slab of BGZF blocks at a time, is inflated and
 // unpacked there, and the batch columns never exist on the host.
@@ -1113,5 +1116,7 @@ void mdx_gbam_close(mdx_gbam *g) {
     if (g->hs) mdx_bam_close(g->hs);
     delete g;
 }
+
+#endif  // MDX_HOST_ONLY
 
 }  // extern "C"

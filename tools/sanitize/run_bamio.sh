@@ -1,12 +1,12 @@
 #!/bin/bash
-# ASan + UBSan over the native BAM decoder (mapdamage_amd/csrc/mdx_bamio.cpp is host-only code): one-piece and
+# ASan + UBSan over the native BAM decoder (the host part of mapdamage_amd/csrc/mdx_bamio.cpp, -DMDX_HOST_ONLY): one-piece and
 # chunked decode of BAM files in both block layouts, with the parallel record scan forced on and off, plus a
 # truncated and a garbage file.  CPU only.  Usage: tools/sanitize/run_bamio.sh
 set -eu
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT
-g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined \
+g++ -std=c++17 -O1 -g -DMDX_HOST_ONLY -fsanitize=address,undefined -fno-sanitize-recover=undefined \
     "$ROOT/mapdamage_amd/csrc/mdx_bamio.cpp" "$ROOT/tools/sanitize/bamio_driver.cpp" -lz -lpthread -o "$TMP/driver"
 cd "$ROOT"
 python - "$TMP" <<'PY'
