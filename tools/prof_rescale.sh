@@ -12,5 +12,8 @@ pmc() { local name=$1; shift
 pmc inst SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 pmc wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE
 pmc tcc TCC_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc ta TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum
 rm -rf $OUT/trace $OUT/pmc_*/
 head -4 $OUT/kernel_stats.csv; cat $OUT/pmc_*.txt
