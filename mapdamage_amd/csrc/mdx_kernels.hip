@@ -1332,40 +1332,35 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         if (m < L) atomicAdd(&lds[base + __mul24(m, 25)], 0xFFFFFFFFu);
                     }
                 }
-                // statistics.py:117-126
+                // statistics.py:117-126 — in 32 bits (|tlen| of INT_MIN is 2^31 as unsigned): a paired record counts as
+                // read 1 of a proper pair, by |tlen|; an unpaired one by its reference length
                 int lkey = -1;
-                if (triv) {
-                    int kind = -1;
-                    i64 flen = 0;
-                    if (fl & 0x1) {
-                        if ((fl & 0x40) && (fl & 0x2)) {
-                            kind = 0;
-                            const i64 t = c_tlen;
-                            flen = t < 0 ? -t : t;
-                        }
-                    } else {
-                        kind = 1;
-                        flen = (i64)len;
-                    }
-                    if (kind >= 0) {
-                        if (flen < d.lgd_lds) {
-                            lkey = lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen;
-                        } else if (flen < d.lgd_max) {
-                            atomicAdd(&p.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
-                                                   (((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
-                        } else {
-                            const u64 slot = atomicAdd(p.n_lgd_over, 1ull);
-                            if ((i64)slot < p.lgd_over_cap) {
-                                p.lgd_over[4 * slot + 0] = libid + a.lib_lo;
-                                p.lgd_over[4 * slot + 1] = kind;
-                                p.lgd_over[4 * slot + 2] = rev;
-                                p.lgd_over[4 * slot + 3] = flen;
+                {
+                    const u32 paired = fl & 1u;
+                    const bool counts = triv && (!paired || (fl & 0x42u) == 0x42u);
+                    const u32 flen = paired ? (c_tlen < 0 ? 0u - (u32)c_tlen : (u32)c_tlen) : len;
+                    const int krow = (paired ? 0 : 2) + rev;                 // kind * 2 + strand
+                    if (counts && flen < (u32)d.lgd_lds) lkey = lbase + d.off_lgd() + __mul24(krow, d.lgd_lds) + (int)flen;
+                    if (__ballot(counts && flen >= (u32)d.lgd_lds)) {          // (a tile in five at the survey's insert sizes)
+                        if (counts && flen >= (u32)d.lgd_lds) {
+                            if (flen < (u32)d.lgd_max) {
+                                atomicAdd(&p.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
+                                                       ((i64)libid * 4 + krow) * d.lgd_max + flen], 1ull);
+                            } else {
+                                const u64 slot = atomicAdd(p.n_lgd_over, 1ull);
+                                if ((i64)slot < p.lgd_over_cap) {
+                                    p.lgd_over[4 * slot + 0] = libid + a.lib_lo;
+                                    p.lgd_over[4 * slot + 1] = paired ? 0 : 1;
+                                    p.lgd_over[4 * slot + 2] = rev;
+                                    p.lgd_over[4 * slot + 3] = (i64)flen;
+                                }
                             }
                         }
                     }
                 }
-                // fragment lengths: two rounds of wave-level aggregation (uniform read lengths give one
-                // or two distinct keys per tile), the remainder as individual adds
+                // fragment lengths: wave-level aggregation while it pays (uniform read lengths give one or two distinct keys
+                // per tile; insert sizes give fifty, and a round that gathers fewer than four lanes is the last), the
+                // remainder as individual adds
                 {
                     u64 pend = __ballot(lkey >= 0);
 #pragma unroll 1
@@ -1373,7 +1368,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         const int leader = __ffsll((long long)pend) - 1;
                         const int key = rl(lkey, leader);
                         const u64 same = __ballot(lkey == key);
-                        if (lane == leader) bump_n<USE_LDS>(lds, raw, key, (u32)__popcll(same));
+                        const int n_same = __popcll(same);
+                        if (n_same < 4) break;
+                        if (lane == leader) bump_n<USE_LDS>(lds, raw, key, (u32)n_same);
                         if (lkey == key) lkey = -1;
                         pend &= ~same;
                     }
