@@ -54,3 +54,34 @@ def test_bench_gpus_n_relaunches_itself_under_torchrun():
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "7"] or ("--gpus" in cmd and "--steps" in cmd)
     assert any(part.endswith("bench.py") for part in cmd)
+
+
+def test_bench_tiled_genome_keeps_the_records_matching():
+    """bench.py's 3 Gb-genome workload: the genome repeated as contigs of their own and the records moved to random
+    copies (and coordinate-sorted) must count to the same tables as the original records over the original genome —
+    only the addresses of the reference windows change."""
+    import importlib.util
+    from mapdamage_amd import synth
+    from tests.util import assert_tables_equal, oracle_tableset
+    spec = importlib.util.spec_from_file_location("bench_mod", str(ROOT / "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ref = synth.small_genome()
+    batch = synth.make_reads(ref, 4000, 9, len_range=(30, 120), paired=True, frac_softclip=0.1, frac_ins=0.05, frac_del=0.05,
+                             frac_skip=0.01)
+    libs = [("s", "l")]
+    want = oracle_tableset(ref, batch, libs, 70, 10, 0)
+    big = bench.tiled_genome(ref, 7)
+    assert len(big.names) == 7 * len(ref.names) and sum(big.lengths) == 7 * sum(ref.lengths)
+    for srt in (False, True):
+        moved = bench.retile(batch, len(ref.names), 7, 123, srt)
+        assert moved.n == batch.n and int(moved.tid.max()) >= len(ref.names)
+        if srt:
+            key = moved.tid.astype(np.int64) * (1 << 32) + moved.pos
+            assert (np.diff(key) >= 0).all()
+        assert_tables_equal(oracle_tableset(big, moved, libs, 70, 10, 0), want)
+    # the traffic look-up never goes silently null
+    val, note = bench.traffic_entry("config3", 1000)
+    assert val and val > 0 and "per record" in note
+    val, note = bench.traffic_entry("no such workload", 1000)
+    assert val is None and "no PMC pass committed" in note
