@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
     const u8 *const l_lut = rs_lds;
     const double *const l_term = (const double *)(rs_lds + lut_bytes);
     u32 *const l_cnt = (u32 *)(rs_lds + lut_bytes + 2 * npos * 8);
-    uint4 *const stg = (uint4 *)(rs_lds + lut_bytes + 2 * npos * 8 + ((n_cnt * 4 + 15) & ~15)) + (threadIdx.x >> 6) * RS_STG;
+    uint4 *const stg = (uint4 *)(rs_lds + lut_bytes + 2 * npos * 8 + ((n_cnt * 4 + 15) & ~15)) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * RS_STG;
     {
         for (int i = threadIdx.x; i < 2 * npos * 94; i += blockDim.x) rs_lds[i] = a.lut[i];
         for (int i = threadIdx.x; i < 2 * npos; i += blockDim.x) ((double *)(rs_lds + lut_bytes))[i] = a.term[i];
