@@ -1,19 +1,25 @@
 // gfx950 (MI355X / CDNA4) kernels of the damage-tabulation engine.
 //
 // Work decomposition (integer/byte histogram work — HBM/LDS bound, no MFMA):
-//   * a wavefront (64 lanes) owns a tile of 64 consecutive records;
-//   * phase 1, lane-per-record: coalesced SoA loads of the per-record columns, flag filter
-//     (reader.py:121-132), CIGAR scan (clips, reference span, column count), fragment-length
-//     update (statistics.py:117-126), soft-clip update (statistics.py:37-51), error checks;
-//   * phase 2, plain records: one lane owns eight consecutive bytes of a record's window (flank and
-//     columns merged), so a wavefront step counts R = 64 / G records at once (3 at --length 70
-//     --around 10); the per-record scalars are staged in the LDS by phase 1 and read back per slot.
-//     The loads of step k+3 are issued before step k is counted (PIPE_DEPTH = 3 register sets) so that the
-//     gather latency of the resident genome is hidden;
+//   * a wavefront (64 lanes) takes tiles of 63 consecutive records, dealt round-robin;
+//   * phase 1 of the tile loop, lane per record: coalesced SoA loads of the per-record columns, flag filter
+//     (reader.py:121-132), and everything a record needs whose CIGAR is one match operation, alone or between soft
+//     clips ([S] M [S]: nine records in ten of an aDNA library): soft-clip update (statistics.py:37-51),
+//     fragment-length update (statistics.py:117-126), the 16-byte staging entry of the record;
+//   * every other kept record — indels, N / P operations, hard clips, contig edges, anything odd or wrong — is handed,
+//     index and columns, to the *general pass*: 64 such records at a time, lane per record, the full CIGAR scan
+//     (pysam's query_alignment_start / _end, htslib's bam_endpos, align.parse_cigar), error checks and
+//     classification into complete / partial / single-insertion / single-deletion entries (appended to the
+//     wavefront's lists in global memory) and the few that walk their CIGAR column by column;
+//   * phase 2, the steps: one lane owns eight consecutive bytes of a record's window (flank and columns merged), so
+//     a wavefront step counts R = 64 / G records at once (3 at --length 70 --around 10); the entry of a record is
+//     read back per slot.  The loads of step k+3 are issued before step k is counted (PIPE_DEPTH = 3 register sets)
+//     so that the gather latency of the resident genome is hidden.  The complete records of a tile are counted at
+//     once; the entries of the lists behind the tile loop, in dense runs of one kind each;
 //   * the common outcome (read base == reference base, or an A/C/G/T flank base) is one
 //     conflict-free ds_add_u32 per byte into a (lane, byte)-indexed LDS table; everything else
 //     (substitutions, N, masked columns) is queued and counted 64 events at a time into the MIS/CMP
-//     tables; gapped records (I/D/N) walk their CIGAR per column;
+//     tables;
 //   * at block end the LDS image is stored to a per-block slot and a second kernel sums the
 //     slots into the u64 accumulators (no global atomics on the hot path).
 // Counting is done in *reference orientation* (left-/right-anchored, no complementing); the
