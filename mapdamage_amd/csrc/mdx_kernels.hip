@@ -76,6 +76,9 @@ typedef long long i64;
 #ifndef PIPE_DEPTH
 #define PIPE_DEPTH 3                    // wavefront steps in flight (register sets of the load pipeline)
 #endif
+#ifndef MDX_PD_G
+#define MDX_PD_G 2                      // steps in flight of the single-indel runs
+#endif
 #ifndef MDX_QPREFETCH
 #define MDX_QPREFETCH 1                 // MASK: the quality windows requested with the other two, PIPE_DEPTH steps ahead
 #endif
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
             // PIPE_DEPTH - 1 fills per run go past the last step.
             // (the runs of gapped records are a step or two long: two register sets)
-            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? 2 : PIPE_DEPTH;
+            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : PIPE_DEPTH;
             Stage st[PD];
     #pragma unroll
             for (int dd = 0; dd < PD; dd++) fill(st[dd]);
