@@ -13,7 +13,7 @@
 //     wavefront's lists in global memory) and the few that walk their CIGAR column by column;
 //   * phase 2, the steps: one lane owns eight consecutive bytes of a record's window (flank and columns merged), so
 //     a wavefront step counts R = 64 / G records at once (3 at --length 70 --around 10); the entry of a record is
-//     read back per slot.  The loads of step k+3 are issued before step k is counted (PIPE_DEPTH = 3 register sets)
+//     read back per slot.  The loads of step k+4 are issued before step k is counted (PIPE_DEPTH = 4 register sets; 3 with --min-basequal)
 //     so that the gather latency of the resident genome is hidden.  The complete records of a tile are counted at
 //     once; the entries of the lists behind the tile loop, in dense runs of one kind each;
 //   * the common outcome (read base == reference base, or an A/C/G/T flank base) is one
@@ -74,10 +74,13 @@ typedef long long i64;
 #define MDX_WPS 6                       // wavefronts per SIMD the register budget is sized for
 #endif
 #ifndef PIPE_DEPTH
-#define PIPE_DEPTH 3                    // wavefront steps in flight (register sets of the load pipeline)
+#define PIPE_DEPTH 4                    // wavefront steps in flight of the complete runs (register sets of the load pipeline)
 #endif
 #ifndef MDX_PD_G
 #define MDX_PD_G 2                      // steps in flight of the single-indel runs
+#endif
+#ifndef MDX_PD_P
+#define MDX_PD_P 3                      // ... and of the runs of partial entries
 #endif
 #ifndef MDX_QPREFETCH
 #define MDX_QPREFETCH 1                 // MASK: the quality windows requested with the other two, PIPE_DEPTH steps ahead
@@ -728,7 +731,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // the loop has the same number of loads in flight (counted s_waitcnt vmcnt), and at most
             // PIPE_DEPTH - 1 fills per run go past the last step.
             // (the runs of gapped records are a step or two long: two register sets)
-            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : PIPE_DEPTH;
+            // (complete runs: four steps in flight in the unmasked kernel, which has the registers since round 3 — plain
+            // records 2 %, config 3 1.8 % faster than with three; the masked kernel, with its third window, would spill)
+            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : ((KIND == STEP_P || MASK) ? MDX_PD_P : PIPE_DEPTH);
             Stage st[PD];
     #pragma unroll
             for (int dd = 0; dd < PD; dd++) fill(st[dd]);
