@@ -76,6 +76,9 @@ typedef long long i64;
 #ifndef PIPE_DEPTH
 #define PIPE_DEPTH 4                    // wavefront steps in flight of the complete runs (register sets of the load pipeline)
 #endif
+#ifndef MDX_ENT_AHEAD
+#define MDX_ENT_AHEAD 0                 // staging entries read one fill ahead
+#endif
 #ifndef MDX_PD_G
 #define MDX_PD_G 2                      // steps in flight of the single-indel runs
 #endif
@@ -661,6 +664,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             constexpr bool QM = MASK && decltype(qm_tag)::value;
             const int nsteps = (nrec + R - 1) / R;
             int kf = 0;
+#if MDX_ENT_AHEAD
+            // (the staging entry of a step is read from the LDS one fill ahead: its latency — behind the eight table
+            // updates of the step just counted — is off the path to the window loads)
+            uint4 ent_next = stg[e0 + c_slot];
+#endif
             // fill() always issues its loads (past the last step it re-reads it), so the number of
             // loads in flight is static and the waits before count() are counted ones
             auto fill = [&](Stage &st) {
@@ -670,7 +678,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 int nv = nrec - k * R;
                 nv = nv > R ? R : nv;
                 st.lim = nv * G;
+#if MDX_ENT_AHEAD
+                const uint4 ent = ent_next;
+                {
+                    const int kn = kf < nsteps ? kf : nsteps - 1;
+                    ent_next = stg[e0 + kn * R + c_slot];
+                }
+#else
                 const uint4 ent = stg[e0 + k * R + c_slot];
+#endif
                 const u32 t = ent.z & c_cm;
                 u32 ro = ent.x + c_ro + t;
                 u32 so = ent.y + c_so + t;
@@ -1266,6 +1282,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // at most, which used to drag the whole wavefront through the general code once per tile).  Wavefronts reach
         // their general passes at different moments, under the counting of the others.
         int nDef = 0, dDone = 0;
+        u32 n_kept_lite = 0;
         for (u32 it = 0;; it++) {
             const bool past = it >= n_it;
             int nF = 0, nF0 = 0;
@@ -1291,14 +1308,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const u32 cn = c_co1 - c_co0;
                 const bool cand = kept && cn - 1u < 3u && c_tid >= 0 && c_tid < a.n_contig && c_lib < a.nlib_total;
                 u32 g0 = 0xFu, g1 = 0xFu, g2 = 0xFu;                  // (an operation code that is neither)
-                i64 c0 = 0, clen = 0;
+                // (32-bit reference coordinates: the fast path runs on references shorter than 4 GiB, MdxTabArgs::ref32)
+                u32 c0 = 0, clen = 0;
                 u32 q0 = 0xFFu;
                 if (cand) {
                     g0 = a.cigar[c_co0];
                     if (cn >= 2u) g1 = a.cigar[c_co0 + 1];
                     if (cn >= 3u) g2 = a.cigar[c_co0 + 2];
-                    c0 = a.contig_off[c_tid];
-                    clen = a.contig_off[c_tid + 1] - c0;
+                    c0 = (u32)a.contig_off[c_tid];
+                    clen = (u32)a.contig_off[c_tid + 1] - c0;
                     if (MASK && a.qual != nullptr) q0 = a.qual[c_so0];
                 }
                 const bool m0 = ((0x181u >> (g0 & 0xFu)) & 1u) != 0, m1 = ((0x181u >> (g1 & 0xFu)) & 1u) != 0;
@@ -1310,11 +1328,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const u32 tr = cn == 3u ? g2 >> 4 : ((cn == 2u && !lead) ? g1 >> 4 : 0u);   // trailing clip
                 const u32 len = (lead ? g1 : g0) >> 4;                               // the match
                 const u32 sq = c_so0 + qs;                                           // first aligned base (pysam's query)
-                const i64 aend = (i64)c_pos + (i64)len;
                 // ... inside the contig with both flanks complete (a record at a contig edge walks), and the speculative
                 // window loads inside the SEQ buffer; anything else (and anything wrong) is the general pass's
-                const bool triv = cand && shape && (u64)qs + len + tr == (u64)(c_so1 - c_so0) && len - 1u < 32767u && c_pos >= A &&
-                                  aend + A <= clen && sq >= (u32)(8 * d.nl8) && (i64)sq + (i64)len + 8 * d.nl8 <= a.n_bases;
+                // (all in 32 bits: a clip of 2^28 bases and more is not this loop's, the match is shorter than 2^15, pos is
+                // below 2^31, and n_bases is what a 32-bit seq_off column can address)
+                const u32 lseq = c_so1 - c_so0, nb32 = (u32)a.n_bases, pad8 = (u32)(8 * d.nl8);
+                const bool triv = cand && shape && ((qs | tr) >> 28) == 0u && qs + len + tr == lseq && len - 1u < 32767u && c_pos >= A &&
+                                  (u32)c_pos + len + (u32)A <= clen && sq >= pad8 && len + pad8 <= nb32 && sq <= nb32 - len - pad8;
                 const u64 mDef = __ballot(kept && !triv);
                 if (mDef) {
                     if (kept && !triv) {
@@ -1391,10 +1411,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     if (lkey >= 0) bump<USE_LDS>(lds, raw, lkey);
                 }
                 const u64 mT = __ballot(triv);
-                if (lane == 0 && mT) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), (u32)__popcll(mT));
+                n_kept_lite += (u32)__popcll(mT);        // (added to the table once, behind the loop)
                 // staging entry (as in the general pass)
                 uint4 ent;
-                ent.x = (u32)(c0 + c_pos - A + 256);
+                ent.x = c0 + (u32)c_pos - (u32)A + 256u;
                 ent.y = sq;
                 ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
                 ent.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
@@ -1407,12 +1427,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 nF0 = MASK ? __popcll(mF0) : 0;
                 if (mF) {
                     if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
-                    // the slots past the last record of a step shadow a real record (and are masked out)
-                    const int first = __ffsll((long long)mF) - 1;
-                    uint4 pad;
-                    pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
-                    pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
-                    if (lane < d.R - 1) stg[nF + lane] = pad;
+                    // the slots past the last record of a step shadow a real record (and are masked out); a run of the
+                    // clean records in front (MASK) reads its own last slots from the maskable records' entries
+                    if (MASK || nF % R) {
+                        const int first = __ffsll((long long)mF) - 1;
+                        uint4 pad;
+                        pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
+                        pad.z = (u32)rl((int)ent.z, first); pad.w = (u32)rl((int)ent.w, first);
+                        if (lane < d.R - 1) stg[nF + lane] = pad;
+                    }
                 }
                 if (mP) {
                     // short records and contig edges: tasks [-flank, min(nq, L)) per side (the list of partial records; DMP)
@@ -1449,6 +1472,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             }
             if (past && dDone >= nDef) break;
         }
+        if (lane == 0 && n_kept_lite) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), n_kept_lite);
     }
 
 #ifndef MDX_ONLY_PHASE1
