@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -109,6 +110,9 @@ struct mdx_ctx {
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
     DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
+    DevBuf rs_in;          // fused launch: per-wavefront lists of the records left to the rescale kernels (MdxFuse::gen_list)
+    size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
+    int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_done[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
@@ -255,6 +259,7 @@ void mdx_destroy(mdx_ctx *c) {
     c->lists.release();
     c->rs_part.release();
     c->rs_lists.release();
+    c->rs_in.release();
     for (int i = 0; i < 2; i++) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
@@ -355,7 +360,8 @@ int mdx_batch_free(mdx_ctx *c, mdx_batch *dv) {
     return MDX_OK;
 }
 
-int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
+// fuse: the rescale side of the fused launch (mdx_tabulate_rescale_device), or null
+static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, int *fused_grid) {
     int rc = check_batch(c, b);
     if (rc != MDX_OK) return rc;
     if (!c->d_ref) return fail(c, MDX_ERR_STATE, "mdx_set_reference has not been called");
@@ -408,12 +414,28 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
         }
         a.stage_off = mdx_k_stage_off(a.dims);
         a.queue_off = mdx_k_queue_off(a.dims);
-        const int grid = (int)(want < max_grid ? want : max_grid);
+        int grid = (int)(want < max_grid ? want : max_grid);
+        int wpb_l = wpb;
+        if (fuse) {
+            // one 1024-thread block per CU (mdx_k_fuse_*): the whole batch in one launch, all libraries
+            const int npos = 1 + fuse->len5p + fuse->len3p;
+            a.rs = *fuse;
+            a.queue_off = mdx_k_fuse_queue_off(a.dims);
+            a.rs.tcb_off = mdx_k_fuse_tcb_off(a.dims);
+            lds = mdx_k_fuse_lds_bytes(a.dims, npos);
+            wpb_l = mdx_k_fuse_block_threads() / 64;
+            const int64_t want_f = (ntiles + wpb_l - 1) / wpb_l;
+            grid = (int)(want_f < c->n_cu ? want_f : c->n_cu);
+            if (!c->fuse_prepared || c->fuse_prepared < lds) {
+                HIP_TRY(c, mdx_k_fuse_prepare(lds));
+                c->fuse_prepared = lds;
+            }
+        }
         {
             // a wavefront classifies at most ceil(n / wavefronts) records, rounded up to whole tiles
-            const int64_t nwaves = (int64_t)grid * wpb;
+            const int64_t nwaves = (int64_t)grid * wpb_l;
             a.list_cap = (b->n_reads + nwaves - 1) / nwaves + 128;
-            HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 4 + 1) * 16));
+            HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16));
             a.lists = (uint4 *)c->lists.p;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -422,7 +444,18 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
             HIP_TRY(c, hipEventCreate(&e1));
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         }
-        mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);
+        if (fuse) {
+            // the wavefronts' lists of records left to the rescale kernels: list_cap indices each, then the counts
+            const int64_t nwaves = (int64_t)grid * wpb_l;
+            HIP_TRY(c, c->rs_in.reserve((size_t)nwaves * (size_t)(a.list_cap + 1) * 4));
+            a.rs.gen_count = (uint32_t *)c->rs_in.p;
+            a.rs.gen_list = a.rs.gen_count + nwaves;
+            mdx_k_tabulate_fused(a, grid, lds, c->stream);
+            c->fuse_list_cap = a.list_cap;
+            if (fused_grid) *fused_grid = grid;
+        } else {
+            mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);
+        }
         if (c->timing) {
             HIP_TRY(c, hipEventRecord(e1, c->stream));
             c->events.emplace_back(e0, e1);
@@ -435,6 +468,8 @@ int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) {
     }
     return MDX_OK;
 }
+
+int mdx_tabulate_device(mdx_ctx *c, const mdx_batch *b) { return tabulate_impl(c, b, nullptr, nullptr); }
 
 int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
     int rc = check_batch(c, h);
@@ -826,12 +861,78 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, co
     return MDX_OK;
 }
 
+// The fused launch applies when the tabulation is the plain fast kernel in one launch (tables in the LDS, all libraries
+// at once, no --min-basequal, 32-bit reference offsets) and the model is one the end-window walk can take (key 0 the
+// identity) whose tables fit the image next to a second TC table.  MDX_NO_FUSE=1 in the environment: never (A/B).
+static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b) {
+    const char *env = getenv("MDX_NO_FUSE");
+    const bool off = env && *env && *env != '0';
+    if (off || c->mode != MDX_MODE_LDS || c->lib_group != c->cfg.nlib || !c->dims.fast_ok()) return false;
+    if (c->cfg.minqual > 0 || !(c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL)) return false;
+    const int npos = 1 + c->len5p + c->len3p;
+    // (the MR terms of a record are noted as bits sub * npos + key of one 64-bit word)
+    if (!c->key0_plain || npos > 32 || !c->d_subs) return false;
+    if (mdx_k_fuse_lds_bytes(c->dims, npos) > kLdsLimit) return false;
+    // (the second TC table's byte offset travels in 10 bits of a staging entry, in units of 256 bytes)
+    if ((size_t)mdx_k_fuse_tcb_off(c->dims) * 4 + (size_t)c->dims.nlib * c->dims.w_tc * 4 > ((size_t)1 << 18)) return false;
+    return b->n_reads > 0 && b->n_bases <= 0xFFFF0000LL;
+}
+
 int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, const int32_t *d_mpos,
                                 uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status) {
     // one pass over one resident batch: the tables and, from the same columns in HBM, the rescaled qualities
-    int rc = mdx_tabulate_device(c, b);
+    int rc = check_batch(c, b);
     if (rc != MDX_OK) return rc;
-    return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);
+    if (!c->d_ref || !c->d_lut || !b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status || d_qual_out == b->qual ||
+        !fuse_applies(c, b)) {
+        rc = mdx_tabulate_device(c, b);
+        if (rc != MDX_OK) return rc;
+        return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // The tabulation kernel rescales the records of its own tile loop as it counts them ([S] M [S] of at most 2 L
+    // aligned bases: qualities, MR, status, their part of the summary) and copies the quality column on the way; the
+    // records it lists — gapped ones, longer ones, records the tabulation does not count — go through rescale_kernel and
+    // rescale_walk_kernel as in mdx_rescale_device.
+    const int npos = 1 + c->len5p + c->len3p, n_cnt = 752 + 2 * npos * 94;
+    MdxFuse f{};
+    f.mtid = d_mtid; f.mpos = d_mpos; f.qual_out = d_qual_out; f.mr_raw = d_mr_raw; f.status = d_status;
+    f.lut = c->d_lut; f.term = c->d_term; f.len5p = c->len5p; f.len3p = c->len3p;
+    HIP_TRY(c, c->rs_part.reserve(mdx_k_rescale_part_bytes(c->len5p, c->len3p, c->n_cu) + (size_t)c->n_cu * n_cnt * 4));
+    f.subs_part = (uint32_t *)c->rs_part.p;
+    int fgrid = 0;
+    rc = tabulate_impl(c, b, &f, &fgrid);
+    if (rc != MDX_OK) return rc;
+    MdxRescaleArgs a{};
+    a.n_reads = b->n_reads; a.n_bases = b->n_bases; a.flag = b->flag; a.tid = b->tid; a.pos = b->pos; a.mtid = d_mtid; a.mpos = d_mpos;
+    a.cigar_off = b->cigar_off; a.cigar = b->cigar; a.seq_off = b->seq_off; a.seq = b->seq; a.qual = b->qual;
+    a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
+    a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p; a.key0_plain = 1;
+    a.qual_out = d_qual_out; a.mr_raw = d_mr_raw; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
+    a.subs_part = (uint32_t *)c->rs_part.p;
+    const int64_t n_in = (int64_t)fgrid * (mdx_k_fuse_block_threads() / 64);
+    a.in_count = (const uint32_t *)c->rs_in.p;
+    a.in_list = a.in_count + n_in;
+    a.in_cap = c->fuse_list_cap;
+    a.n_in = (int)n_in;
+    // (a wavefront of rescale_kernel takes one list — there are at least as many wavefronts as lists — and leaves at
+    // most that many records to the walk kernel)
+    int64_t cons_waves = 0, cons_cap = 0;
+    mdx_k_rescale_lists((int64_t)1 << 40, c->n_cu, &cons_waves, &cons_cap);     // (the wavefronts of a full grid)
+    HIP_TRY(c, c->rs_lists.reserve((size_t)cons_waves * (size_t)(a.in_cap + 1) * 4));
+    a.gen_count = (uint32_t *)c->rs_lists.p;
+    a.gen_list = a.gen_count + cons_waves;
+    a.gen_cap = a.in_cap;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+        (void)hipEventRecord(e0, c->stream);
+    mdx_k_rescale_lists_pass(a, fgrid, c->n_cu, c->stream);
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, c->stream);
+        c->rs_events.emplace_back(e0, e1);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return MDX_OK;
 }
 
 int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const int32_t *mpos, uint8_t *qual_out,

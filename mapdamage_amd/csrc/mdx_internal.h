@@ -103,6 +103,25 @@ static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd
     return d;
 }
 
+// The fused tabulate + rescale launch (mdx_tabulate_rescale_device, BASELINE configs[4]): what the tabulation kernel
+// needs to rescale the records of its own tile loop — [S] M [S] records of at most 2 L aligned bases that
+// mapdamage/rescale.py:300-342 routes to _rescale_qual_read — while it counts them.  Every other record that wants
+// rescaling is appended to the wavefront's list (gen_list / gen_count, list_cap entries per wavefront) for
+// rescale_kernel and rescale_walk_kernel behind it.
+struct MdxFuse {
+    const int32_t *mtid, *mpos;
+    uint8_t *qual_out;          // becomes a copy of the batch's quality column, tile by tile, then takes the rescaled bytes
+    double *mr_raw;
+    uint8_t *status;
+    const uint8_t *lut;         // [2][npos][94]
+    const double *term;         // [2][npos]
+    int len5p, len3p;
+    uint32_t *subs_part;        // [grid][752 + 2 npos 94]: the block's own summary row (zeroed by the block itself)
+    uint32_t *gen_list, *gen_count;
+    int tcb_off;                // word offset in the LDS of the second TC table (the fused records' own), then 4 words of
+                                // reference-base counts, the lookup table and the terms (mdx_k_fuse_lds_bytes)
+};
+
 struct MdxTabArgs {
     // batch (device pointers)
     int64_t n_reads;
@@ -136,13 +155,15 @@ struct MdxTabArgs {
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
-    // Per-wavefront lists (16-byte staging entries): wavefront w owns 5 list_cap + list_cap / 4 + 1 entries — partial
+    // Per-wavefront lists (16-byte staging entries): wavefront w owns 5 list_cap + list_cap / 2 + 2 entries (the last
+    // list_cap / 4 + 1: the fused kernel's record indices of the partial list) — partial
     // records upwards from 0, single insertions upwards from list_cap, single deletions downwards from 2 list_cap - 1,
     // the complete records the general pass finds upwards from 2 list_cap, from 3 list_cap on the columns (two entries
     // per record) and from 5 list_cap on the indices (u32) of the records the tile loop leaves to the general pass;
     // list_cap >= the records a wavefront classifies.  Written in the tile loop, read back by the same wavefront.
     uint4 *lists;
     int64_t list_cap;
+    MdxFuse rs;                      // used by the fused kernel only
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };
@@ -152,8 +173,16 @@ size_t mdx_k_lds_bytes(const MdxDims &d);
 int mdx_k_stage_off(const MdxDims &d);
 int mdx_k_queue_off(const MdxDims &d);
 hipError_t mdx_k_prepare(size_t lds_bytes);
+// the fused tabulate + rescale kernel: one 1024-thread block per CU (its LDS image holds a second TC table and the
+// rescale model), queue offset and size of its image, the word offset of the second TC table in it
+int mdx_k_fuse_block_threads();
+int mdx_k_fuse_queue_off(const MdxDims &d);
+int mdx_k_fuse_tcb_off(const MdxDims &d);
+size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos);
+hipError_t mdx_k_fuse_prepare(size_t lds_bytes);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
+void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
                            int64_t w_total, int grid, hipStream_t s);
 void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
@@ -193,10 +222,18 @@ struct MdxRescaleArgs {
     uint32_t *gen_list;
     uint32_t *gen_count;
     int64_t gen_cap;
+    // list mode (behind the fused kernel): the records to take are those of n_in lists of up to in_cap indices each
+    // (in_list[l * in_cap ..], in_count[l]) instead of every record of the batch; qual_out is complete already
+    const uint32_t *in_list, *in_count;
+    int64_t in_cap;
+    int n_in;
     int row_base;               // first row of subs_part the walk kernel's blocks write (set by mdx_k_rescale)
     int copy_qual;              // set by mdx_k_rescale: rescale_kernel copies qual to qual_out tile by tile
 };
 void mdx_k_rescale(const MdxRescaleArgs &a, int n_cu, hipStream_t s);
+// behind the fused kernel: rescale_kernel over a.in_list, the walk kernel over what that leaves, and the reduction of the
+// summary rows of all three kernels (the fused kernel's `fused_rows` rows come first in subs_part)
+void mdx_k_rescale_lists_pass(const MdxRescaleArgs &a, int fused_rows, int n_cu, hipStream_t s);
 size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu);
 void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *cap);
 

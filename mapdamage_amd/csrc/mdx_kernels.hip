@@ -124,6 +124,28 @@ int mdx_k_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_BLOCK /
 // ... [byte-mask table: 9 x u64, entry n = the low n bytes set]
 #define LT_BYTES 72
 size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4 + (size_t)(MDX_BLOCK / 64) * EVQ_BYTES + LT_BYTES; }
+// The fused tabulate + rescale kernel (tabulate_kernel<.., RS>): one block of 1024 threads per CU — 16 wavefronts with
+// 128 registers each instead of 24 with 80 (measured with the plain kernel: +3 % on config 3) — because its image does
+// not fit twice: behind the plain image [second TC table, 256-byte aligned][4 words][lookup table][terms]
+#define MDX_FUSE_BLOCK 1024
+#define MDX_FUSE_WPS 4
+#ifndef MDX_FUSE_CPU
+#define MDX_FUSE_CPU 2                  // 16-byte units per lane of the first pass of a tile's quality copy (measured: 2 3.64 ms, 4 3.74, 7 4.18 — the registers)
+#endif
+#ifndef MDX_FUSE_PD
+#define MDX_FUSE_PD 4                   // steps in flight of the complete runs in the fused kernel
+#endif
+#define MDX_FUSE_MRM 72                 // per wavefront: one 64-bit word per staging entry (the MR terms of its record)
+int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
+int mdx_k_fuse_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_FUSE_BLOCK / 64) * mdx_stage_entries(d) * 4; }
+int mdx_k_fuse_tcb_off(const MdxDims &d) {
+    const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * EVQ_BYTES + LT_BYTES;
+    return (int)(((end + 255) & ~(size_t)255) / 4);
+}
+size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos) {
+    return (size_t)mdx_k_fuse_tcb_off(d) * 4 + (size_t)d.nlib * d.w_tc * 4 + 16 + (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 +
+           (size_t)(MDX_FUSE_BLOCK / 64) * MDX_FUSE_MRM * 8;
+}
 
 // read byte -> class; accepted only if it is exactly the upper-case letter
 // ("nt in 'ACGT-'", statistics.py:27)
@@ -320,25 +342,49 @@ __device__ __forceinline__ T ld32(const T *base, u32 idx) {
 
 // FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
 // otherwise every record takes the generic CIGAR walk.
-template <bool USE_LDS, bool MASK, bool FAST>
-__global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs a) {
+// RS: the fused tabulate + rescale launch (MdxFuse; mapdamage/rescale.py:195-365 for the records of the tile loop)
+template <bool USE_LDS, bool MASK, bool FAST, bool RS = false>
+__global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS : MDX_WPS) void tabulate_kernel(MdxTabArgs a) {
+    static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
+    constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : MDX_BLOCK;
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
     const int lane = threadIdx.x & 63;
     // (wave-uniform, and told so: the staging and queue addresses derived from it live in scalar registers)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int waves_per_block = MDX_BLOCK / 64;
+    const int waves_per_block = BLOCK / 64;
     const u32 gwave = blockIdx.x * waves_per_block + wave;
     const u32 nwaves = gridDim.x * waves_per_block;
     u64 *raw = a.raw;
 
     // nine-entry LDS table of byte masks (entry n = the low n bytes of a 64-bit word set): the per-record byte masks
     // of the partial steps are two or three lookups instead of 64-bit shifts
-    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (MDX_BLOCK / 64) * EVQ_BYTES);
+    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (BLOCK / 64) * EVQ_BYTES);
+    // RS: the fused records count into a TC table of their own (the reference bases of their columns are part of the
+    // rescale summary, rescale.py:142-143), added to the first one at block end; behind it four words for those counts,
+    // the lookup table and the terms of the model
+    const int rs_npos = RS ? 1 + a.rs.len5p + a.rs.len3p : 0;
+    const int rs_ncnt = 752 + 2 * rs_npos * 94;
+    u32 *const rs_cnt = lds + (RS ? a.rs.tcb_off + d.nlib * d.w_tc : 0);
+    const u8 *const l_lut = (const u8 *)(rs_cnt + 4);
+    const double *const l_term = (const double *)(l_lut + ((2 * rs_npos * 94 + 15) & ~15));
+    // ... and per wavefront one 64-bit word per staging entry: bit sub * npos + key = the record has a rescaled column of
+    // that kind (drain_all sets them; the MR sum is formed from them, in the reference's order, when the run is over)
+    u64 *const mrm = (u64 *)(l_term + 2 * rs_npos) + (RS ? wave * MDX_FUSE_MRM : 0);
+    int bcA = 0, bcC = 0, bcG = 0, bcT = 0;   // RS: reference bases (read orientation) this lane has counted itself
     if (USE_LDS) {
-        for (i64 i = threadIdx.x; i < d.w_total; i += MDX_BLOCK) lds[i] = 0;
+        for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) lds[i] = 0;
         if (FAST && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
+        if (RS) {
+            for (int i = threadIdx.x; i < d.nlib * d.w_tc + 4; i += BLOCK) lds[a.rs.tcb_off + i] = 0;
+            for (int i = threadIdx.x; i < 2 * rs_npos * 94; i += BLOCK) ((u8 *)(rs_cnt + 4))[i] = a.rs.lut[i];
+            for (int i = threadIdx.x; i < 2 * rs_npos; i += BLOCK) ((double *)(l_lut + ((2 * rs_npos * 94 + 15) & ~15)))[i] = a.rs.term[i];
+            // the block's summary row: zeroed here, counted into with global atomics by this block alone
+            u32 *const row = a.rs.subs_part + (size_t)blockIdx.x * rs_ncnt;
+            for (int i = threadIdx.x; i < rs_ncnt; i += BLOCK) row[i] = 0;
+            __threadfence();
+        }
         __syncthreads();
     }
 
@@ -404,10 +450,78 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     // [29:24] library | [30] the entry is a single deletion (then [10:8] = deleted bases g, [14:11] = first byte of
     // the lane that lies behind the deletion — on the right side: the bytes below it — and the TC base is recomputed)
     // | [31] reverse strand.
+    // RS: an event byte of a fused record (its staging entry `e`, number `ix`, is still in place: the runs of the fused
+    // kernel drain the queue before they return).  The byte is read column p of its side.  A reference base in a left
+    // column is counted here (the plain matches: the second TC table).  A transition — each column once: the left
+    // side's [0, min(nq, L)), the right side's columns beyond — goes into the summary (rescale.py:108-143) by its old
+    // quality (q8: the qualities of the lane's eight bytes), and a C>T / G>A one with a position key is rescaled
+    // (_rescale_qual_read, rescale.py:228-246): new quality from the lookup table, its MR term noted in mrm.
+    auto rs_event = [&](const uint4 &e, const u64 q8, const int ix, const int rev, const int side, const int p, const int jb,
+                        const u32 sb, const u32 rb) {
+        const int nq = (int)(e.z & 0x7FFFu);
+        if (!side && rb < 0x80u) {
+            const u32 k = (rb >> 1) & 3u;           // A,C,T,G
+            u32 b = k ^ (k >> 1);                   // A,C,G,T
+            if (rev) b = 3u - b;
+            bcA += b == 0u; bcC += b == 1u; bcG += b == 2u; bcT += b == 3u;
+        }
+        if (side && p >= nq - L) return;
+        const u32 pr = sb | (rb << 8);
+        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
+        const int kind = (int)(pr == ('T' | 'C' << 8)) * (1 + rev) + (int)(pr == ('A' | 'G' << 8)) * (2 - rev) +
+                         (int)(pr == ('C' | 'T' << 8)) * (3 + rev) + (int)(pr == ('G' | 'A' << 8)) * (4 - rev) - 1;
+        if (kind < 0) return;
+        const MdxTabArgs *kp = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const int qi = side ? nq - 1 - p : p;
+        const u32 q = (u32)(q8 >> (8 * jb)) & 0xFFu;
+        const int len5p = kp->rs.len5p, len3p = kp->rs.len3p;
+        int pp = (rev ? nq - 1 - qi : qi) + 1;                         // _corr_this_base, rescale.py:49-79
+        const int back = pp - nq - 1;
+        pp = (!((e.w >> 20) & 1u) && pp >= -back) ? back : pp;
+        const int k5 = pp <= len5p ? pp : 0, k3 = -pp <= len3p ? len5p - pp : 0;
+        const int key = pp > 0 ? k5 : k3;
+        if (kind < 2 && key) {
+            const int ti = kind * rs_npos + key;
+            atomicOr(&mrm[ix], 1ull << ti);
+            if (q <= 93u) {
+                const u32 newq = l_lut[ti * 94 + (int)q];
+                if (newq != q) kp->rs.qual_out[e.y + (u32)qi] = (u8)newq;
+            }
+        }
+        // "before" words of T>C / A>G, or the occurrences of (substitution, key, old quality)
+        const int idx = kind >= 2 ? (kind == 2 ? 2 : 6) * 94 : 752 + (kind * rs_npos + key) * 94;
+        if (q <= 93u) atomicAdd(&kp->rs.subs_part[(size_t)blockIdx.x * rs_ncnt + idx + (int)q], 1u);
+    };
+    // the MR sum of a record from its word of mrm: the terms in column order — 5' keys upwards, then 3' keys downwards
+    auto mr_of = [&](const u64 m) -> double {
+        double mr = 0.0;
+        const u32 m0 = (u32)(m & ((1ull << rs_npos) - 1ull)), m1 = (u32)(m >> rs_npos);
+        const u32 c = m0 | m1;
+        u32 c5 = c & (u32)((2ull << a.rs.len5p) - 2ull);
+        while (c5) {
+            const int k = __ffs((int)c5) - 1;
+            c5 &= c5 - 1;
+            mr += l_term[((m0 >> k) & 1u) ? k : rs_npos + k];
+        }
+        u32 c3 = (u32)((u64)c >> (a.rs.len5p + 1));
+        while (c3) {
+            const int j = 31 - __clz((int)c3);
+            c3 &= ~(1u << j);
+            const int k = a.rs.len5p + 1 + j;
+            mr += l_term[((m0 >> k) & 1u) ? k : rs_npos + k];
+        }
+        return mr;
+    };
     auto drain_all = [&]() {
         if (lane < qcount) {
             const u32x2 es = qS[lane], er = qR[lane];
             const u32 w = qW[lane];
+            // (RS: an event of a fused record is known by its TC table — the second one)
+            const bool rsev = RS && !((w >> 30) & 1u) && ((w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off;
+            uint4 rent = make_uint4(0u, 0u, 0u, 0u);
+            u64 rq8 = 0;
+            if (RS && rsev) rent = stg[w & 0x7Fu];
             const int ln = (int)(w >> 18) & 63;
             const int rev = (int)(w >> 31);
             const int lb = __mul24((int)((w >> 24) & 0x3Fu), d.w_lib);
@@ -422,6 +536,15 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             const int m8 = 8 * (ll - side * d.nl8);
             u64 vm, em;
             lane_masks(d, side, m8, vm, em);
+            if (RS && rsev) {
+                // the qualities of the lane's eight bytes (they sit where its read bytes sit): requested here, looked at
+                // behind the table work of the event
+                const MdxTabArgs *kp = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kp));
+                const u32 qo = rent.y + (u32)(side ? (int)(rent.z & 0x7FFFu) + A - 8 - m8 : m8 - A);
+                const u32x2 v = *(const u32x2_u *)(kp->qual + qo);
+                rq8 = (u64)v.x | ((u64)v.y << 32);
+            }
             const u64 s64 = (u64)es.x | ((u64)es.y << 32), r64 = (u64)er.x | ((u64)er.y << 32);
             u64 x = (((s64 ^ r64) & em) | (r64 & 0x8080808080808080ull)) & vm;
             if (MASK) x |= spread_bits(w & 0xFFu);
@@ -444,8 +567,12 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 } else {
                     bump_n<USE_LDS>(lds, raw, tcw + (int)(((rb >> 1) & 3u) << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
                 }
-                if ((em >> sh) & 1ull)
+                if ((em >> sh) & 1ull) {
                     rare_column<USE_LDS>(lds, raw, b_mis, b_cmp, L, side, p, pc, sb, (int)(i8)rb, MASK && ((w >> jb) & 1u));
+#ifndef MDX_RSABL_NOEV
+                    if (RS && rsev) rs_event(rent, rq8, (int)(w & 0x7Fu), rev, side, p, jb, sb, rb);
+#endif
+                }
             }
         }
         qcount = 0;
@@ -507,7 +634,8 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             q12_ = q12; qo_ = qo;       // (funnelled out where the qualities are first needed: the wait sits there)
 #endif
         }
-        u32 evw = st.pk & 0xBF03FF00u;    // event word of this lane (without lane and quality bits)
+        // event word of this lane (without lane and quality bits; RS: with the staging index)
+        u32 evw = st.pk & (RS ? 0xBF03FF7Fu : 0xBF03FF00u);
         if (KIND == STEP_C) {
             // optimistic: count every byte as a plain match (the base class of the reference
             // byte selects the plane of TC) ...
@@ -733,7 +861,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 st.ro = ro; st.so = so;
                 st.r12 = *(const u32x3 *)(refW + (ro & ~3u));
                 st.s12 = ld12_stream(seqW + (so & ~3u));
-                st.pk = ent.w;
+                // (RS: the low byte — n0 - nq of a gapped entry, read above — makes room for the entry's place in the
+                // staging area, which an event of a fused record hands to drain_all)
+                st.pk = RS ? ((ent.w & 0xFFFFFF00u) | (u32)(e0 + k * R + c_slot)) : ent.w;
 #if MDX_QPREFETCH
                 if (QM) {
                     // records that cannot be masked — no qualities, or the caller's hint — read one fixed line instead
@@ -749,7 +879,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             // (the runs of gapped records are a step or two long: two register sets)
             // (complete runs: four steps in flight in the unmasked kernel, which has the registers since round 3 — plain
             // records 2 %, config 3 1.8 % faster than with three; the masked kernel, with its third window, would spill)
-            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : ((KIND == STEP_P || MASK) ? MDX_PD_P : PIPE_DEPTH);
+            constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : ((KIND == STEP_P || MASK) ? MDX_PD_P : (RS ? MDX_FUSE_PD : PIPE_DEPTH));
             Stage st[PD];
     #pragma unroll
             for (int dd = 0; dd < PD; dd++) fill(st[dd]);
@@ -763,6 +893,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     #pragma unroll
             for (int dd = 0; dd < PD; dd++)
                 if (dd == 0 || st[dd].valid) count(st[dd], kind_tag, std::false_type{}, qm_tag);
+            // (RS: the events of fused records look their staging entries up: drained before those are overwritten)
+#ifndef MDX_RSABL_NOFD
+            if (RS && qcount > 0) drain_all();
+#endif
         };
 
     // Tiles of (up to) 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
@@ -785,9 +919,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     //   [2 cap, 3 cap)  complete records found by the general pass, upwards
     //   [3 cap, 5 cap)  the columns (two entries each) of the records the tile loop leaves to the general pass,
     //   [5 cap, ...)    and their indices (u32)
-    uint4 *const lists = a.lists + (i64)gwave * (5 * a.list_cap + a.list_cap / 4 + 1);
+    //   [5 cap + cap / 4 + 1, ...)  RS: the record index of every entry of the partial list (u32)
+    uint4 *const lists = a.lists + (i64)gwave * (5 * a.list_cap + a.list_cap / 2 + 2);
     uint4 *const dcols = lists + 3 * a.list_cap;
     u32 *const dlist = (u32 *)(lists + 5 * a.list_cap);
+    u32 *const lri = (u32 *)(lists + 5 * a.list_cap + a.list_cap / 4 + 1);
     int lP = 0, lI = 0, lD = 0, lC = 0;
 
     // ------------------------------------------------------------ the general pass: any record, lane per record
@@ -1283,6 +1419,13 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
         // their general passes at different moments, under the counting of the others.
         int nDef = 0, dDone = 0;
         u32 n_kept_lite = 0;
+        u32 n_rs = 0;       // RS: records left to the rescale kernels behind this one
+        u32 nb0 = 0, nb1 = 0;   // RS: byte range of the next tile's qualities (requested a tile ahead)
+        if (RS && n_it > 0) {
+            const u32 tb0 = 0 < rounds ? gwave * T : t_lo;
+            const u32 rh0 = 0 < rounds ? tb0 + T : (tb0 + T < t_hi ? tb0 + T : t_hi);
+            nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
+        }
         for (u32 it = 0;; it++) {
             const bool past = it >= n_it;
             int nF = 0, nF0 = 0;
@@ -1293,6 +1436,34 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
                 const u32 r_lo = tbase;
                 const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
+                u32x4 cpv[MDX_FUSE_CPU];
+                u32 cp_a0 = 0, cp_nu = 0, cp_b0 = 0, cp_b1 = 0;
+                if (RS) {
+                    // qual_out starts as a copy of the quality column: the tile's own stretch (its bounds were requested a
+                    // tile ahead), 16 bytes per lane, before any lane of this wavefront stores a rescaled byte into it (the
+                    // up to 15 bytes in front of and behind the 16-byte units are moved byte by byte: the stretch belongs
+                    // to this tile alone).  The loads of the first pass go out in front of the tile's column loads, its
+                    // stores behind them: one round trip for both.
+                    cp_b0 = nb0; cp_b1 = nb1;
+                    // (units at the same 16-byte phase as the source column: both columns are 16-byte aligned in any
+                    // allocation this library is handed)
+                    const u32 head = (0u - (cp_b0 + (u32)((size_t)p.qual & 15))) & 15u;
+                    cp_a0 = cp_b0 + head < cp_b1 ? cp_b0 + head : cp_b1;
+#ifndef MDX_RSABL_NOCOPY
+                    cp_nu = (cp_b1 - cp_a0) >> 4;
+#endif
+                    const u8 *__restrict__ qin = p.qual;
+#pragma unroll
+                    for (int k = 0; k < MDX_FUSE_CPU; k++) {
+                        const u32 u = (u32)lane + 64u * k;
+                        if (u < cp_nu) cpv[k] = *(const u32x4_u *)(qin + (cp_a0 + 16u * u));
+                    }
+                    if (it + 1 < n_it) {
+                        const u32 tb2 = it + 1 < rounds ? ((it + 1) * nwaves + gwave) * T : t_lo + (it + 1 - rounds) * T;
+                        const u32 rh2 = it + 1 < rounds ? tb2 + T : (tb2 + T < t_hi ? tb2 + T : t_hi);
+                        nb0 = ld32(a.seq_off, tb2); nb1 = ld32(a.seq_off, rh2);
+                    }
+                }
                 // ---------------------------------------------------- phase 1 of the single-match records
                 const u32 ri = r_lo + lane;
                 const bool valid = ri < r_hi;
@@ -1300,6 +1471,23 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const u32 fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
                 const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
                 const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
+                int c_mtid = 0, c_mpos = 0;
+                if (RS) {
+                    c_mtid = ld32(p.rs.mtid, rj); c_mpos = ld32(p.rs.mpos, rj);
+                    // (the stores of the copy's first pass; then the passes a tile of long records needs beyond it)
+                    const u8 *__restrict__ qin = p.qual;
+                    u8 *__restrict__ qout = p.rs.qual_out;
+#pragma unroll
+                    for (int k = 0; k < MDX_FUSE_CPU; k++) {
+                        const u32 u = (u32)lane + 64u * k;
+                        if (u < cp_nu) *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = cpv[k];
+                    }
+                    for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 64u)
+                        *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = *(const u32x4_u *)(qin + (cp_a0 + 16u * u));
+                    if (cp_b0 + (u32)lane < cp_a0) qout[cp_b0 + (u32)lane] = qin[cp_b0 + (u32)lane];
+                    const u32 t0 = cp_a0 + 16u * cp_nu + (u32)lane;
+                    if (t0 < cp_b1) qout[t0] = qin[t0];
+                }
                 bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
                 if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
                 // second round trip of the tile: the (up to three) operations, the contig bounds and (MASK) the first quality
@@ -1318,6 +1506,10 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                     c0 = (u32)a.contig_off[c_tid];
                     clen = (u32)a.contig_off[c_tid + 1] - c0;
                     if (MASK && a.qual != nullptr) q0 = a.qual[c_so0];
+                }
+                u32 rs_qf = 0xFFu;          // RS: the record's first quality (0xFF: none, rescale.py:306)
+                if (RS) {
+                    if (valid && c_so1 != c_so0) rs_qf = p.qual[c_so0];
                 }
                 const bool m0 = ((0x181u >> (g0 & 0xFu)) & 1u) != 0, m1 = ((0x181u >> (g1 & 0xFu)) & 1u) != 0;
                 const bool s0 = (g0 & 0xFu) == 4u, s1 = (g1 & 0xFu) == 4u, s2 = (g2 & 0xFu) == 4u;
@@ -1352,6 +1544,34 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
                 const int lbase = __mul24(libid, d.w_lib);
                 const bool isF = triv && nq >= L;
+                // RS: record routing (rescale.py:300-342).  Rescaled here, while it is counted: a record of this loop with
+                // at most 2 L aligned bases (every column is then a task of one of its windows) whose end windows can be
+                // fetched eight bytes at a time; any other record that wants rescaling goes to the list of the kernels
+                // behind this one.
+                bool rs_fused = false;
+                int rs_st = 0, rs_fwd = 0;
+                if (RS) {
+                    const int mate_rev = (fl >> 5) & 1;
+                    if (fl & 0x4u) rs_st = 0;
+                    else if (c_so1 == c_so0 || rs_qf == 0xFFu) rs_st = 1;
+                    else if (fl & 0x1u) {
+                        const bool same = c_tid == c_mtid;
+                        if ((!rev && mate_rev && c_mpos > c_pos && same) || (rev && !mate_rev && c_mpos < c_pos && same)) { rs_st = 3; rs_fwd = 1; }
+                        else rs_st = 4;
+                    } else rs_st = 2;
+                    const bool want = valid && (rs_st == 2 || rs_st == 3);
+                    rs_fused = want && triv && nq <= 2 * L && (u64)c_so0 + lseq + 16u <= (u64)a.n_bases;
+                    if (valid && !want) {
+                        // written back unchanged (the copy above), only the status and the MR marker are left to set
+                        p.rs.status[ri] = (u8)rs_st;
+                        p.rs.mr_raw[ri] = __builtin_nan("");
+                    }
+                    const u64 mW = __ballot(want && !rs_fused);
+                    if (mW) {
+                        if (want && !rs_fused) (p.rs.gen_list + (size_t)gwave * (size_t)p.list_cap)[n_rs + (u32)mbcnt64(mW, 0)] = ri;
+                        n_rs += (u32)__popcll(mW);
+                    }
+                }
                 // statistics.py:37-51: positions [0, min(len, L)) of a soft clip, the left side's table iff no alignment
                 // column precedes it — as a difference (+1 at 0, -1 at the end), like the general pass
                 if (__ballot(triv && (qs | tr) != 0u)) {
@@ -1419,6 +1639,11 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
                 ent.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                         ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
+                // (RS: a fused record counts into the second TC table — which is what marks its entry and events; bit 20 =
+                // rescaled from the 5' end only)
+                if (RS && rs_fused)
+                    ent.w = ((u32)(p.rs.tcb_off + __mul24(libid, d.w_tc) + rev * 4 * 512) << 2) | ((u32)libid << 24) | ((u32)rev << 31) |
+                            ((u32)rs_fwd << 20);
                 const u64 mF = __ballot(isF), mP = mT & ~mF;
                 nF = __popcll(mF);
                 // MASK: the complete records that cannot be masked (no qualities, or the caller's hint) are staged first and
@@ -1444,8 +1669,38 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                         const int k1 = nq < L ? nq : L;
                         if (k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
                         lists[lP + mbcnt64(mP, 0)] = ent;
+                        if (RS) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
                     }
                     lP += __popcll(mP);
+                }
+                if (RS) {
+#ifdef MDX_RSABL_NOE
+                    if (false) {
+#else
+                    if (rs_fused) {
+#endif
+                        p.rs.status[ri] = (u8)rs_st;
+                        // subs[nt_ref] (rescale.py:142-143) of the columns the left windows do not hold, [L, nq); a
+                        // record shorter than L leaves L - nq zeroed bytes in plane A of its left columns
+                        const u8 *__restrict__ g_ref = p.ref + (size_t)(c0 + (u32)c_pos);
+                        int nA = 0, nC = 0, nG = 0, nT = 0;
+                        for (int qi = L; qi < nq; qi += 16) {
+                            const u32x4 rv = *(const u32x4_u *)(g_ref + qi);
+                            const u64 r64[2] = {(u64)rv.x | ((u64)rv.y << 32), (u64)rv.z | ((u64)rv.w << 32)};
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                const u64 ok7 = ~r64[h] & 0x8080808080808080ull & byte_range(0, nq - qi - 8 * h);   // bit 7 clear: a base
+                                const u64 b1 = (r64[h] << 6) & ok7, b2 = (r64[h] << 5) & ok7;                      // bit 1, bit 2 of the byte
+                                nA += __popcll(ok7 & ~b1 & ~b2); nC += __popcll(b1 & ~b2); nT += __popcll(~b1 & b2); nG += __popcll(b1 & b2);
+                            }
+                        }
+                        if (nq < L) nA -= L - nq;
+                        if (rev) { bcA += nT; bcC += nG; bcG += nC; bcT += nA; }
+                        else { bcA += nA; bcC += nC; bcG += nG; bcT += nT; }
+                    }
+                    // (the MR words of the tile's staging entries)
+                    mrm[lane] = 0ull;
+                    if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
                 }
 #ifndef MDX_ONLY_PHASE1   // probe build (tools/p1_probe.sh): phase 1 and the gapped walk only
                 // ---------------------------------------------------- phase 2a: the complete records of the tile
@@ -1455,6 +1710,9 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 // classification code runs once per 64 events instead of once per record.
                 if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
                 if (nF - nF0) run(nF0, nF - nF0, std::integral_constant<int, STEP_C>{}, std::true_type{});
+                // RS: the run has drained its events: the MR sum of a fused complete record from its word (a record that
+                // is not complete: behind the run of the partial list)
+                if (RS && rs_fused && isF) p.rs.mr_raw[ri] = mr_of(mrm[mbcnt64(mF, 0)]);
 #endif
             }
             // ---------------------------------------------------- the general pass over the records left to it
@@ -1473,6 +1731,7 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
             if (past && dDone >= nDef) break;
         }
         if (lane == 0 && n_kept_lite) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), n_kept_lite);
+        if (RS && lane == 0) a.rs.gen_count[gwave] = n_rs;
     }
 
 #ifndef MDX_ONLY_PHASE1
@@ -1489,7 +1748,16 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
                 const uint4 ent = lists[first + (i64)dir * (e + (lane < m ? lane : 0))];
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
+                constexpr bool RSP = RS && decltype(kind_tag)::value == STEP_P;
+                u32 ri_l = 0;
+                if (RSP) {
+                    ri_l = lri[e + (lane < m ? lane : 0)];
+                    mrm[lane] = 0ull;
+                    if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
+                }
                 run(0, m, kind_tag, std::true_type{});
+                // RS: the MR sums of the fused records among them (known by their TC table)
+                if (RSP && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
             }
         };
         list_runs(2 * a.list_cap, 1, lC, std::integral_constant<int, STEP_C>{});
@@ -1508,8 +1776,40 @@ __global__ __launch_bounds__(MDX_BLOCK, MDX_WPS) void tabulate_kernel(MdxTabArgs
     if (USE_LDS) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // the hand-written ds_adds of this wavefront
         __syncthreads();
+        if (RS) {
+            // The reference bases of the fused records' columns (subs["A"] ... ["T"], read orientation): the plain matches
+            // of the left columns from the second TC table (lane (slot, left side, m), byte j = window byte 8 m + j, a
+            // column iff A <= 8 m + j < A + L), everything else from the lanes' own counts; words 0..3 of the block's
+            // summary row.  Then the second table is added to the first.
+            int tA = 0, tC = 0, tG = 0, tT = 0;
+            const int n_tcb = d.nlib * d.w_tc;
+            for (int i = threadIdx.x; i < n_tcb; i += BLOCK) {
+                const int w = i & 511, k = (i >> 9) & 3, strand = (i >> 11) & 1;
+                const int ln = w & 63, jb = w >> 6;
+                const int g = ln / d.G, ll = ln - g * d.G, b = 8 * ll + jb;
+                if (g < d.R && ll < d.nl8 && b >= A && b < A + L) {
+                    const int v = (int)lds[a.rs.tcb_off + i];
+                    int bb = k ^ (k >> 1);                  // A,C,T,G -> A,C,G,T
+                    if (strand) bb = 3 - bb;
+                    tA += bb == 0 ? v : 0; tC += bb == 1 ? v : 0; tG += bb == 2 ? v : 0; tT += bb == 3 ? v : 0;
+                }
+            }
+            int v4[4] = {tA + bcA, tC + bcC, tG + bcG, tT + bcT};
+            for (int b = 0; b < 4; b++) {
+                int v = v4[b];
+                for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0 && v) atomicAdd(&rs_cnt[b], (u32)v);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < n_tcb; i += BLOCK) {
+                const int lib = i / d.w_tc, j = i - lib * d.w_tc;
+                lds[lib * d.w_lib + d.off_tc() + j] += lds[a.rs.tcb_off + i];
+            }
+            if (threadIdx.x < 4) a.rs.subs_part[(size_t)blockIdx.x * rs_ncnt + threadIdx.x] = rs_cnt[threadIdx.x];
+            __syncthreads();
+        }
         u32 *out = a.partials + (i64)blockIdx.x * d.w_total;
-        for (i64 i = threadIdx.x; i < d.w_total; i += MDX_BLOCK) out[i] = lds[i];
+        for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) out[i] = lds[i];
     }
 }
 
@@ -1517,6 +1817,16 @@ template <bool MASK, bool FAST>
 static hipError_t prep_one(size_t lds_bytes) {
     return hipFuncSetAttribute((const void *)tabulate_kernel<true, MASK, FAST>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+hipError_t mdx_k_fuse_prepare(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, false, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    if (a.n_reads <= 0) return;
+    hipLaunchKernelGGL((tabulate_kernel<true, false, true, true>), dim3(grid), dim3(MDX_FUSE_BLOCK), lds_bytes, s, a);
 }
 
 hipError_t mdx_k_prepare(size_t lds_bytes) {
@@ -1770,7 +2080,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
         const u32x2 v = *(const u32x2_u *)ptr;
         return (u64)v.x | ((u64)v.y << 32);
     };
-    for (i64 tile = gwave; tile < ntiles; tile += nwaves) {
+    auto do_tile = [&](const i64 tile, const i64 ri, const bool valid) __attribute__((always_inline)) {
         if (a.copy_qual) {
             // qual_out starts as a copy of qual: the tile's own stretch of the column, 16 bytes per lane, before any
             // lane of this wavefront stores a rescaled byte into it (the stretch belongs to this tile alone: its first
@@ -1791,8 +2101,6 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
             const u32 t0 = b0 + 16u * nu + (u32)lane;
             if (t0 < b1) a.qual_out[t0] = a.qual[t0];
         }
-        const i64 ri = tile * 64 + lane;
-        const bool valid = ri < a.n_reads;
         u32 so = 0;
         int lseq = 0, qs = 0, nq = 0, st = 0, fwd_only = 0, rev = 0;
         int m1 = 0, gi = 0, gd = 0;   // a fast record is M(m1) [I(gi) | D(gd)] M(nq - m1 - gi) between its soft clips
@@ -2040,6 +2348,16 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
             if (walk) my_list[n_list + (u32)mbcnt64(m_gen, 0)] = (u32)ri;
             n_list += (u32)__popcll(m_gen);
         }
+    };
+    if (a.in_list) {
+        // behind the fused kernel: the records its wavefronts listed, 64 at a time (qual_out is complete: no copy)
+        for (i64 l = gwave; l < a.n_in; l += nwaves) {
+            const u32 *__restrict__ in = a.in_list + l * a.in_cap;
+            const u32 n = a.in_count[l];
+            for (u32 k0 = 0; k0 < n; k0 += 64) do_tile(0, k0 + lane < n ? (i64)in[k0 + lane] : 0, k0 + lane < n);
+        }
+    } else {
+        for (i64 tile = gwave; tile < ntiles; tile += nwaves) do_tile(tile, tile * 64 + lane, tile * 64 + lane < a.n_reads);
     }
     if (lane == 0) a.gen_count[gwave] = n_list;
     if (a.subs) {
@@ -2547,6 +2865,30 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
         if (a.subs && a.lds_tables)
             hipLaunchKernelGGL(rescale_reduce_kernel, dim3((n_cnt + 255) / 256, RS_RED_Y), dim3(256), 0, s, a.subs_part, grid, n_cnt, a.subs);
     }
+}
+
+void mdx_k_rescale_lists_pass(const MdxRescaleArgs &a0, int fused_rows, int n_cu, hipStream_t s) {
+    MdxRescaleArgs a = a0;
+    const int npos = 1 + a.len5p + a.len3p, n_cnt = 752 + 2 * npos * 94;
+    const size_t need = rs_lds_bytes(npos, true);
+    static_assert(RS_BPC * RS_BLOCK >= MDX_FUSE_BLOCK, "a wavefront of rescale_kernel per list of the fused kernel");
+    a.lds_tables = 1;
+    a.copy_qual = 0;
+    // every wavefront of the fused kernel has a list: as many wavefronts here, at least (a wavefront takes the lists
+    // l = its index, + the number of wavefronts, ...; its own list for the walk kernel holds what it leaves out)
+    int64_t want = ((int64_t)a.n_in * 64 + RS_BLOCK - 1) / RS_BLOCK;
+    if (want < 1) want = 1;
+    const int grid = (int)(want < (int64_t)n_cu * RS_BPC ? want : (int64_t)n_cu * RS_BPC);
+    if (need > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+    a.subs_part = a0.subs_part + (size_t)fused_rows * n_cnt;
+    hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(RS_BLOCK), need, s, a);
+    a.in_list = nullptr; a.in_count = nullptr; a.n_in = 0;
+    a.row_base = grid;
+    hipLaunchKernelGGL(rescale_walk_kernel, dim3(grid), dim3(RS_BLOCK), rs_lds_bytes(npos, false), s, a);
+    if (a.subs)
+        hipLaunchKernelGGL(rescale_reduce_kernel, dim3((n_cnt + 255) / 256, RS_RED_Y), dim3(256), 0, s, a0.subs_part,
+                           fused_rows + 2 * grid, n_cnt, a.subs);
 }
 
 // wavefronts of a launch over n_reads records, and the list entries each may need (its tiles x 64)

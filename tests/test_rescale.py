@@ -394,6 +394,73 @@ def test_hip_tabulate_and_rescale_in_one_pass(tmp_path):
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
 
 
+def one_pass(eng, b):
+    """mdx_tabulate_rescale_device on the uploaded batch -> (qualities, MR, status) as host arrays; the tables stay in the
+    engine."""
+    import torch
+    dev = torch.device("cuda", 0)
+    db = eng.upload(b)
+    mtid, mpos = torch.from_numpy(b.mtid).to(dev), torch.from_numpy(b.mpos).to(dev)
+    qout = torch.zeros(b.seq.shape[0] + 64, dtype=torch.uint8, device=dev)
+    mr = torch.zeros(b.n, dtype=torch.float64, device=dev)
+    st = torch.zeros(b.n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.rescale_device(db, mtid.data_ptr(), mpos.data_ptr(), qout.data_ptr(), mr.data_ptr(), st.data_ptr(), with_tables=True)
+    eng.sync()
+    out = qout.cpu().numpy()[:b.seq.shape[0]], mr.cpu().numpy(), st.cpu().numpy()
+    db.free()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length,l5,l3,lens", [(70, 12, 12, (25, 160)), (25, 12, 12, (20, 120)), (70, 20, 3, (15, 90)),
+                                               (12, 0, 30, (15, 60))])
+def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, monkeypatch, length, l5, l3, lens):
+    """The fused launch (the tabulation kernel rescales the records of its own tile loop and lists the others for the
+    rescale kernels): tables, qualities, MR, routing and every summary word — against the oracle, and the summary
+    word for word against the two-kernel path on the same batch.  Record lengths on both sides of --length and of
+    2 x --length (longer records are listed), records the tabulation drops but the rescaling takes, models with
+    uneven windows."""
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.rescale import RescaleModel
+    from oracle import oracle
+    from tests.util import assert_tables_equal, oracle_tableset
+    rng = np.random.default_rng(100 + length)
+    corr_prob = {}
+    for p in list(range(1, l5 + 1)) + list(range(-l3, 0)):
+        corr_prob[("C", "T", p)] = float(rng.random() * 0.7)
+        corr_prob[("G", "A", p)] = float(rng.random() * 0.7)
+    model = RescaleModel(corr_prob, l5, l3)
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500,
+                            lower_run=3000)
+    b = synth.make_reads(ref, 70_000, 40 + length, len_range=lens, paired=True, frac_softclip=0.2, frac_ins=0.05,
+                         frac_del=0.05, frac_skip=0.01, with_qual=True, frac_filtered=0.03)
+    b.mtid = np.where(rng.random(b.n) < 0.9, b.tid, (b.tid + 1) % 2).astype(np.int32)
+    b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
+    b.flag = np.where(rng.random(b.n) < 0.4, b.flag & 0xF14, b.flag).astype(np.uint16)      # unpaired: rescaled from both ends
+    b.flag = np.where(rng.random(b.n) < 0.05, b.flag | 0x400, b.flag).astype(np.uint16)     # duplicates: rescaled, not counted
+    libs = [("s", "l")]
+    want_tables = oracle_tableset(ref, b, libs, length, 10, 0)
+    want_q, want_mr, want_st, want_counts, _ = oracle.rescale_with_subs(ref, b, corr_table(corr_prob, model), l5, l3)
+    got = {}
+    for fuse in (True, False):
+        monkeypatch.setenv("MDX_NO_FUSE", "0" if fuse else "1")
+        with DamageEngine(libs, length, 10, 0) as eng:
+            eng.set_reference(ref)
+            eng.set_rescale_model(model)
+            q, mr, st = one_pass(eng, b)
+            words = eng.rescale_summary()
+            tables = eng.finish()
+        assert_tables_equal(tables, want_tables)
+        np.testing.assert_array_equal(q, want_q)
+        np.testing.assert_array_equal(st, want_st)
+        assert np.array_equal(np.isnan(mr), np.isnan(want_mr))
+        np.testing.assert_array_equal(mr[~np.isnan(mr)], want_mr[~np.isnan(want_mr)])
+        np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))
+        got[fuse] = words
+    np.testing.assert_array_equal(got[True], got[False])
+
+
 @pytest.mark.gpu
 def test_hip_rescale_names_the_record_it_cannot_process(tmp_path):
     """A record running past its contig end (the reference's fetch raises there) is reported with its index."""

@@ -15,11 +15,14 @@ from mapdamage_amd.batch import batch_from_records  # noqa: E402
 from mapdamage_amd.engine import DamageEngine  # noqa: E402
 from mapdamage_amd.rescale import RescaleModel  # noqa: E402
 from oracle import oracle  # noqa: E402
-from tests.test_rescale import corr_table, short_records, summary_ints_from_oracle  # noqa: E402
+from tests.test_rescale import corr_table, one_pass, short_records, summary_ints_from_oracle  # noqa: E402
+from tests.util import assert_tables_equal, oracle_tableset  # noqa: E402
 from tools.fuzz_vs_reference import fuzz_records, rescale_writable  # noqa: E402
 
 
 def main():
+    import torch
+    torch.cuda.init()      # (before the engine: the two share the device)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500, lower_run=3000)
     bad = 0
@@ -47,6 +50,31 @@ def main():
         ok = (np.array_equal(got_q, want_q) and np.array_equal(got_st, want_st) and np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
               and np.array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
               and np.array_equal(words[:756], summary_ints_from_oracle(want_counts)))
+        # the same batch through the fused launch (mdx_tabulate_rescale_device) at a random --length: tables too
+        length = int(rng.integers(8, 90))
+        libs = [("s", "l")]
+        try:
+            want_tables = oracle_tableset(ref, b, libs, length, 10, 0)
+        except Exception as e:      # (fuzzed batches hold records the tabulation rejects: then only the rescaling is compared)
+            want_tables = None
+        with DamageEngine(libs, length, 10, 0) as eng:
+            eng.set_reference(ref)
+            eng.set_rescale_model(model)
+            try:
+                fq, fmr, fst = one_pass(eng, b)
+                fwords = eng.rescale_summary()
+                ftables = eng.finish() if want_tables is not None else None
+                okf = (np.array_equal(fq, want_q) and np.array_equal(fst, want_st) and np.array_equal(np.isnan(fmr), np.isnan(want_mr))
+                       and np.array_equal(fmr[~np.isnan(fmr)], want_mr[~np.isnan(want_mr)]) and np.array_equal(fwords, words))
+                if ftables is not None:
+                    try:
+                        assert_tables_equal(ftables, want_tables)
+                    except AssertionError:
+                        okf = False
+            except Exception as e:
+                okf = want_tables is None
+                print("   fused pass raised:", type(e).__name__, str(e)[:100])
+        ok = ok and okf
         print("round %d (%s, model %d+%d, %d records): %s" % (k, "fuzzed CIGARs" if k % 2 == 0 else "short records", l5, l3, b.n,
                                                               "equal" if ok else "MISMATCH"), flush=True)
         bad += not ok
