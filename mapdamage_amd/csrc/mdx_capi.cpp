@@ -445,7 +445,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         }
         if (fuse) {
-            // the wavefronts' lists of records left to the rescale kernels: list_cap indices each, then the counts
+            // (a record written back unchanged keeps this NaN — all ones; inside the timed region)
+            HIP_TRY(c, hipMemsetAsync(fuse->mr_raw, 0xFF, (size_t)b->n_reads * 8, c->stream));
+            // the wavefronts' lists of records left to the rescale kernels: list_cap indices each, in front the counts
             const int64_t nwaves = (int64_t)grid * wpb_l;
             HIP_TRY(c, c->rs_in.reserve((size_t)nwaves * (size_t)(a.list_cap + 1) * 4));
             a.rs.gen_count = (uint32_t *)c->rs_in.p;
