@@ -1503,21 +1503,30 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
                 const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
                 int c_mtid = 0, c_mpos = 0;
+                bool rs_anyhi = false;       // RS: some quality byte of the tile has bit 7 set (0xFF: a record without qualities)
                 if (RS) {
                     c_mtid = ld32(p.rs.mtid, rj); c_mpos = ld32(p.rs.mpos, rj);
                     // (the stores of the copy's first pass; then the passes a tile of long records needs beyond it)
                     const u8 *__restrict__ qin = p.qual;
                     u8 *__restrict__ qout = p.rs.qual_out;
+                    u32 hi = 0;
 #pragma unroll
                     for (int k = 0; k < MDX_FUSE_CPU; k++) {
                         const u32 u = (u32)lane + 64u * k;
-                        if (u < cp_nu) *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = cpv[k];
+                        if (u < cp_nu) {
+                            *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = cpv[k];
+                            hi |= cpv[k].x | cpv[k].y | cpv[k].z | cpv[k].w;
+                        }
                     }
-                    for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 64u)
-                        *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = *(const u32x4_u *)(qin + (cp_a0 + 16u * u));
-                    if (cp_b0 + (u32)lane < cp_a0) qout[cp_b0 + (u32)lane] = qin[cp_b0 + (u32)lane];
+                    for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 64u) {
+                        const u32x4 v = *(const u32x4_u *)(qin + (cp_a0 + 16u * u));
+                        *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = v;
+                        hi |= v.x | v.y | v.z | v.w;
+                    }
+                    if (cp_b0 + (u32)lane < cp_a0) { const u8 b = qin[cp_b0 + (u32)lane]; qout[cp_b0 + (u32)lane] = b; hi |= b; }
                     const u32 t0 = cp_a0 + 16u * cp_nu + (u32)lane;
-                    if (t0 < cp_b1) qout[t0] = qin[t0];
+                    if (t0 < cp_b1) { const u8 b = qin[t0]; qout[t0] = b; hi |= b; }
+                    rs_anyhi = __ballot((hi & 0x80808080u) != 0u) != 0ull;
                 }
                 bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
                 if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
@@ -1540,11 +1549,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 }
                 u32 rs_qf = 0xFFu;          // RS: the record's first quality (0xFF: none, rescale.py:306)
                 if (RS) {
-#ifdef MDX_RSABL_NOQF
-                    rs_qf = 30u;
-#else
-                    if (valid && c_so1 != c_so0) rs_qf = p.qual[c_so0];
-#endif
+                    // (the copy has seen every quality byte of the tile: without a byte above 127 among them every record
+                    // has qualities, and the 63 scattered loads are not needed)
+                    rs_qf = 0u;
+                    if (rs_anyhi && valid && c_so1 != c_so0) rs_qf = p.qual[c_so0];
                 }
                 const bool m0 = ((0x181u >> (g0 & 0xFu)) & 1u) != 0, m1 = ((0x181u >> (g1 & 0xFu)) & 1u) != 0;
                 const bool s0 = (g0 & 0xFu) == 4u, s1 = (g1 & 0xFu) == 4u, s2 = (g2 & 0xFu) == 4u;

@@ -439,6 +439,8 @@ def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, mon
     b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
     b.flag = np.where(rng.random(b.n) < 0.4, b.flag & 0xF14, b.flag).astype(np.uint16)      # unpaired: rescaled from both ends
     b.flag = np.where(rng.random(b.n) < 0.05, b.flag | 0x400, b.flag).astype(np.uint16)     # duplicates: rescaled, not counted
+    for i in np.flatnonzero(rng.random(b.n) < 0.01):                                        # records without qualities
+        b.qual[b.seq_off[i]:b.seq_off[i + 1]] = 0xFF
     libs = [("s", "l")]
     want_tables = oracle_tableset(ref, b, libs, length, 10, 0)
     want_q, want_mr, want_st, want_counts, _ = oracle.rescale_with_subs(ref, b, corr_table(corr_prob, model), l5, l3)
