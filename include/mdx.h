@@ -206,8 +206,15 @@ int mdx_rescale_host(mdx_ctx *ctx, const mdx_batch *batch, const int32_t *mtid, 
  * batch in one call: the count tables (main.py:165-217) and the rescaled qualities (rescale.py:300-344) from the
  * same columns, uploaded once.  d_qual_out is a column of its own (n_bases bytes; it must not be the batch's quality
  * column: MDX_ERR_ARG), filled completely — the qualities of records written back unchanged included.
+ * mdx_tabulate_rescale_device is one fused launch when the tabulation runs as the plain fast kernel (tables in the LDS,
+ * all libraries in one launch, no --min-basequal, reference below 4 GiB) and the model has at most 31 window positions:
+ * the tabulation kernel rescales the [S] M [S] records of at most 2 x --length aligned bases while it counts them and
+ * lists the others for the rescale kernels behind it; otherwise — and with MDX_NO_FUSE=1 in the environment — it is
+ * mdx_tabulate_device followed by mdx_rescale_device.  Either way the results are the same bytes.  A NaN in mr_raw
+ * (record written back unchanged) is any NaN.
  * mdx_rescale_timing_read: time of the rescale launches (the rescale kernels with the copy of the quality column
- * they contain; HIP events, like mdx_timing_read for the tabulation kernel; enabled by mdx_timing_enable). */
+ * they contain — after a fused launch: of the kernels that take the records it has listed; HIP events, like
+ * mdx_timing_read for the tabulation kernel, which then times the fused kernel; enabled by mdx_timing_enable). */
 int mdx_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
                        uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
 int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
