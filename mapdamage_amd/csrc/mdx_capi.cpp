@@ -885,8 +885,10 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d
     // one pass over one resident batch: the tables and, from the same columns in HBM, the rescaled qualities
     int rc = check_batch(c, b);
     if (rc != MDX_OK) return rc;
+    // (the fused kernel copies the quality column in 16-byte units: both columns at the same 16-byte phase — true of any two
+    // device allocations)
     if (!c->d_ref || !c->d_lut || !b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status || d_qual_out == b->qual ||
-        !fuse_applies(c, b)) {
+        (((uintptr_t)d_qual_out ^ (uintptr_t)b->qual) & 15) != 0 || !fuse_applies(c, b)) {
         rc = mdx_tabulate_device(c, b);
         if (rc != MDX_OK) return rc;
         return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);

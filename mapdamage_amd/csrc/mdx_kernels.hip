@@ -54,6 +54,27 @@ typedef u32v3 __attribute__((aligned(4))) u32v3_u;
 #ifndef MDX_NT
 #define MDX_NT 0
 #endif
+// The quality copy of the fused kernel (16-byte units at 16-byte-aligned addresses): the copy is written once and not
+// read again by this kernel: MDX_CP_NT & 1 stores it non-temporal, so that it does not take the reference's place in the
+// L2, MDX_CP_NT & 2 loads the source likewise — measured: 3.43 ms either way against 3.44 (off).
+#ifndef MDX_CP_NT
+#define MDX_CP_NT 0
+#endif
+typedef u32x4 __attribute__((aligned(16))) u32x4_a;
+__device__ __forceinline__ void cp_store(u8 *p, const u32x4 v) {
+#if MDX_CP_NT & 1
+    __builtin_nontemporal_store(v, (u32x4_a *)p);
+#else
+    *(u32x4_a *)p = v;
+#endif
+}
+__device__ __forceinline__ u32x4 cp_load(const u8 *p) {
+#if MDX_CP_NT & 2
+    return __builtin_nontemporal_load((const u32x4_a *)p);
+#else
+    return *(const u32x4_a *)p;
+#endif
+}
 __device__ __forceinline__ u32x3 ld12_stream(const u8 *p) {
     u32x3 r;
 #if MDX_NT
@@ -1487,7 +1508,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
 #pragma unroll
                     for (int k = 0; k < MDX_FUSE_CPU; k++) {
                         const u32 u = (u32)lane + 64u * k;
-                        if (u < cp_nu) cpv[k] = *(const u32x4_u *)(qin + (cp_a0 + 16u * u));
+                        if (u < cp_nu) cpv[k] = cp_load(qin + (cp_a0 + 16u * u));
                     }
                     if (it + 1 < n_it) {
                         const u32 tb2 = it + 1 < rounds ? ((it + 1) * nwaves + gwave) * T : t_lo + (it + 1 - rounds) * T;
@@ -1514,13 +1535,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     for (int k = 0; k < MDX_FUSE_CPU; k++) {
                         const u32 u = (u32)lane + 64u * k;
                         if (u < cp_nu) {
-                            *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = cpv[k];
+                            cp_store(qout + (cp_a0 + 16u * u), cpv[k]);
                             hi |= cpv[k].x | cpv[k].y | cpv[k].z | cpv[k].w;
                         }
                     }
                     for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 64u) {
-                        const u32x4 v = *(const u32x4_u *)(qin + (cp_a0 + 16u * u));
-                        *(u32x4_u *)(qout + (cp_a0 + 16u * u)) = v;
+                        const u32x4 v = cp_load(qin + (cp_a0 + 16u * u));
+                        cp_store(qout + (cp_a0 + 16u * u), v);
                         hi |= v.x | v.y | v.z | v.w;
                     }
                     if (cp_b0 + (u32)lane < cp_a0) { const u8 b = qin[cp_b0 + (u32)lane]; qout[cp_b0 + (u32)lane] = b; hi |= b; }

@@ -9,7 +9,7 @@ disp = defaultdict(set)
 with open(path) as fh:
     for row in csv.DictReader(fh):
         k = row.get("Kernel_Name", "")
-        if pat and pat not in k:
+        if pat and not any(x in k for x in pat.split("|")):      # (alternatives: a|b)
             continue
         k = k.split("(")[0][:60]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])

@@ -16,6 +16,8 @@ mkdir -p $OUT
 COMMON="--reads 25000000 --no-cpu --no-secondary --batch-cache /tmp/mdx_bc $*"
 BENCH="python $R/bench.py --steps 50 --warmup 5 $COMMON"
 SHORT="python $R/bench.py --steps 6 --warmup 2 $COMMON"
+# (config 5: the rescale kernels behind the fused tabulation kernel belong to the launch)
+case "$*" in *"--config 5"*) KPAT="tabulate_kernel|rescale_kernel|rescale_walk_kernel|rescale_reduce_kernel";; *) KPAT=tabulate_kernel;; esac
 echo "$BENCH" > $OUT/command.txt
 $BENCH > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
@@ -25,7 +27,7 @@ pmc() { # name counters...
   local name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- $SHORT > $OUT/pmc_$name.log 2>&1
   for f in $(find $OUT/pmc_$name -name '*counter_collection.csv'); do
-    python3 $R/tools/pmc_summary.py $f tabulate_kernel > $OUT/pmc_$name.txt 2>&1
+    python3 $R/tools/pmc_summary.py $f "$KPAT" > $OUT/pmc_$name.txt 2>&1
   done
 }
 pmc inst SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM

@@ -18,10 +18,24 @@ except OSError:
     pass
 warm = 5
 durs = []
+# config 5 (tabulation + rescaling in one call): a launch is the fused tabulation kernel and the rescale kernels behind it
+# (rescale_kernel over the records it lists, the walk kernel, the reduction of the summary rows) — their durations summed
+config5 = "--config 5" in res["command"]
+extra = ("rescale_kernel", "rescale_walk_kernel", "rescale_reduce_kernel") if config5 else ()
 try:
-    rows = [r for r in csv.DictReader(open(os.path.join(out, "kernel_trace_full.csv"))) if "tabulate_kernel" in r["Kernel_Name"]]
+    allrows = list(csv.DictReader(open(os.path.join(out, "kernel_trace_full.csv"))))
+    rows = [r for r in allrows if "tabulate_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    if extra:
+        starts = [int(r["Start_Timestamp"]) for r in rows]
+        import bisect
+        for r in allrows:
+            if any(r["Kernel_Name"].startswith(x) for x in extra):
+                j = bisect.bisect_right(starts, int(r["Start_Timestamp"])) - 1     # the tabulation launch in front of it
+                if j >= 0:
+                    durs[j] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        res["kernels"] = ["tabulate_kernel (rescaling fused in)"] + list(extra)
 except (OSError, KeyError):
     pass
 if durs:
@@ -42,12 +56,20 @@ if line:
 
 
 def counter(name, key):
+    """Per launch: the tabulation kernel's value per dispatch (config 5: plus the rescale kernels' — each runs once per
+    launch, so their per-dispatch values add)."""
     try:
         txt = open(os.path.join(out, "pmc_%s.txt" % name)).read()
     except OSError:
         return None
-    m = re.search(r"%s\s+([0-9.e+]+) per dispatch" % key, txt)
-    return float(m.group(1)) if m else None
+    tot, found = 0.0, False
+    for block in re.split(r"\n(?=\S)", txt):
+        head = block.split("\n", 1)[0]
+        if "tabulate_kernel" in head or any(head.startswith(x + " ") or head.startswith(x + "(") for x in extra):
+            m = re.search(r"%s\s+([0-9.e+]+) per dispatch" % key, block)
+            if m:
+                tot += float(m.group(1)); found = True
+    return tot if found else None
 
 
 fetch_kb, write_kb = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
