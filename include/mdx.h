@@ -220,6 +220,8 @@ int mdx_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *
 int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
                                 uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
 int mdx_rescale_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
+/* Calls of mdx_tabulate_rescale_device so far that ran as the fused launch (the others: two kernels). */
+int64_t mdx_fused_launches(const mdx_ctx *ctx);
 /* The integer content of the `subs` dictionary that _rescale_qual_read fills through _record_subs
  * (rescale.py:82-143) and _print_subs logs (:159-192), accumulated over every mdx_rescale_host call
  * since mdx_rescale_set_model.  words (uint64), npos = 1 + len5p + len3p:

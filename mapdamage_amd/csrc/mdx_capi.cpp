@@ -112,6 +112,7 @@ struct mdx_ctx {
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
     DevBuf rs_in;          // fused launch: per-wavefront lists of the records left to the rescale kernels (MdxFuse::gen_list)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
+    int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
     int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_done[2] = {nullptr, nullptr};
@@ -931,6 +932,7 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d
     if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
         (void)hipEventRecord(e0, c->stream);
     mdx_k_rescale_lists_pass(a, fgrid, c->n_cu, c->stream);
+    c->n_fused++;
     if (e0 && e1) {
         (void)hipEventRecord(e1, c->stream);
         c->rs_events.emplace_back(e0, e1);
@@ -976,6 +978,8 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
     if (e != hipSuccess) return fail(c, MDX_ERR_HIP, hipGetErrorString(e));
     return mdx_sync(c, nullptr);
 }
+
+int64_t mdx_fused_launches(const mdx_ctx *c) { return c ? c->n_fused : -1; }
 
 int mdx_rescale_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
     if (!c) return MDX_ERR_ARG;

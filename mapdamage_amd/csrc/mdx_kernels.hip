@@ -512,6 +512,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             if (i < n) { t[k] = rsq[i]; q[k] = qin[t[k].x]; }
 #endif
         }
+        // (every vector-memory operation of the wavefront so far is complete — the qualities just requested, and the stores
+        // of the tile's quality copy, which the new qualities must not overtake)
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
 #pragma unroll
         for (int k = 0; k < MDX_FUSE_RSQ / 64; k++)
             if ((u32)lane + 64u * k < n) rs_apply(t[k], q[k]);
@@ -553,7 +556,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         u32x2 ent2;
         ent2.x = e.y + (u32)qi; ent2.y = (u32)idx | (resc ? 0x8000u : 0u);
         if (slot < (u32)MDX_FUSE_RSQ) rsq[slot] = ent2;
-        else rs_apply(ent2, (u32)kp->qual[ent2.x]);     // (a tile with more transitions than the list holds)
+        else {
+            // (a tile with more transitions than the list holds: at once — behind the stores of the tile's quality copy)
+            const u32 q = (u32)kp->qual[ent2.x];
+            __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+            rs_apply(ent2, q);
+        }
     };
     // the MR sum of a record from its word of mrm: the terms in column order — 5' keys upwards, then 3' keys downwards
     auto mr_of = [&](const u64 m) -> double {

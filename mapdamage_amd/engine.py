@@ -26,7 +26,7 @@ EXPORTS = (
     "mdx_table_mode", "mdx_genome_composition", "mdx_rescale_set_model", "mdx_rescale_host",
     "mdx_rescale_summary_words", "mdx_rescale_summary",
     "mdx_comm_unique_id", "mdx_comm_init", "mdx_comm_adopt", "mdx_comm_size", "mdx_finish_allreduce",
-    "mdx_rescale_device", "mdx_tabulate_rescale_device", "mdx_rescale_timing_read",
+    "mdx_rescale_device", "mdx_tabulate_rescale_device", "mdx_rescale_timing_read", "mdx_fused_launches",
     "mdx_bam_read", "mdx_bam_free", "mdx_bam_error", "mdx_bam_header_text", "mdx_bam_n_ref", "mdx_bam_ref_name",
     "mdx_bam_ref_length", "mdx_bam_batch", "mdx_bam_n_rg", "mdx_bam_rg_name", "mdx_bam_qnames",
     "mdx_bam_open", "mdx_bam_stream_header", "mdx_bam_next", "mdx_bam_close",
@@ -98,6 +98,8 @@ def load_library(path=None):
     lib.mdx_comm_size.argtypes = [ctypes.c_void_p]
     lib.mdx_rescale_summary_words.restype = ctypes.c_int64
     lib.mdx_rescale_summary_words.argtypes = [ctypes.c_void_p]
+    lib.mdx_fused_launches.restype = ctypes.c_int64
+    lib.mdx_fused_launches.argtypes = [ctypes.c_void_p]
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
         getattr(lib, name).restype = ctypes.c_char_p
     lib.mdx_bam_qnames.restype = ctypes.c_void_p
@@ -378,6 +380,10 @@ class DamageEngine:
         fn = self._lib.mdx_tabulate_rescale_device if with_tables else self._lib.mdx_rescale_device
         self._check(fn(self._ctx, ctypes.byref(dbatch.dev), ctypes.c_void_p(d_mtid), ctypes.c_void_p(d_mpos),
                        ctypes.c_void_p(d_qual_out), ctypes.c_void_p(d_mr), ctypes.c_void_p(d_status)))
+
+    def fused_launches(self):
+        """Calls of rescale_device(with_tables=True) so far that ran as one fused launch."""
+        return int(self._lib.mdx_fused_launches(self._ctx))
 
     def rescale_timing_read(self):
         n = ctypes.c_int64(0)

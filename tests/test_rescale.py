@@ -451,6 +451,7 @@ def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, mon
             eng.set_reference(ref)
             eng.set_rescale_model(model)
             q, mr, st = one_pass(eng, b)
+            assert eng.fused_launches() == (1 if fuse else 0)
             words = eng.rescale_summary()
             tables = eng.finish()
         assert_tables_equal(tables, want_tables)
@@ -461,6 +462,37 @@ def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, mon
         np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))
         got[fuse] = words
     np.testing.assert_array_equal(got[True], got[False])
+
+
+@pytest.mark.gpu
+def test_hip_fused_pass_with_two_libraries(tmp_path, monkeypatch):
+    """Two libraries in one fused launch (--length 12, fragment lengths up to 128: both images fit next to the fused
+    kernel's own tables): a second TC table per library."""
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    from tests.util import assert_tables_equal, oracle_tableset
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000)), n_run=500, lower_run=3000)
+    b = synth.make_reads(ref, 50_000, 77, len_range=(20, 60), nlib=2, paired=False, frac_softclip=0.2, frac_ins=0.04,
+                         frac_del=0.04, with_qual=True, frac_filtered=0.02)
+    b.mtid = b.tid.copy(); b.mpos = b.pos.copy()
+    libs = [("s", "l0"), ("s", "l1")]
+    want_tables = oracle_tableset(ref, b, libs, 12, 10, 0, lgd_max=128)
+    want_q, want_mr, want_st, want_counts, _ = oracle.rescale_with_subs(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    monkeypatch.setenv("MDX_NO_FUSE", "0")
+    with DamageEngine(libs, 12, 10, 0, lgd_max=128) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        q, mr, st = one_pass(eng, b)
+        assert eng.fused_launches() == 1
+        words = eng.rescale_summary()
+        tables = eng.finish()
+    assert_tables_equal(tables, want_tables)
+    np.testing.assert_array_equal(q, want_q)
+    np.testing.assert_array_equal(st, want_st)
+    assert np.array_equal(np.isnan(mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(mr[~np.isnan(mr)], want_mr[~np.isnan(want_mr)])
+    np.testing.assert_array_equal(words[:756], summary_ints_from_oracle(want_counts))
 
 
 @pytest.mark.gpu
