@@ -22,6 +22,10 @@
 //     tables;
 //   * at block end the LDS image is stored to a per-block slot and a second kernel sums the
 //     slots into the u64 accumulators (no global atomics on the hot path).
+//   * tabulate_kernel<.., RS> is the same kernel with the quality rescaling of mapdamage/rescale.py fused in for the
+//     records of its own tile loop (mdx_tabulate_rescale_device, BASELINE configs[4]): routing and the quality copy in
+//     phase 1, the rescaled columns — they are mismatches, hence events — through drain_all, one 1024-thread block per
+//     CU (see MdxFuse in mdx_internal.h and the RS blocks below).
 // Counting is done in *reference orientation* (left-/right-anchored, no complementing); the
 // strand step of main.py:200-205 (reverse-complement + flank swap) becomes a fixed permutation
 // applied once by finalize_kernel.  The oracle (oracle/mdx_oracle.c) builds and reverses the
