@@ -490,7 +490,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         const MdxTabArgs *kp = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const u32 idx = t.y & 0x7FFFu;
+#ifndef MDX_RSABL_NOATOM
         atomicAdd(&kp->rs.subs_part[(size_t)blockIdx.x * rs_ncnt + idx + q], 1u);
+#endif
         if (t.y & 0x8000u) {
             const u32 newq = l_lut[idx - 752u + q];
             if (newq != q) kp->rs.qual_out[t.x] = (u8)newq;
