@@ -111,6 +111,7 @@ struct mdx_ctx {
     DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
     DevBuf rs_in;          // fused launch: per-wavefront lists of the records left to the rescale kernels (MdxFuse::gen_list)
+    uint32_t *d_tile_ctr = nullptr; // tile counters of the fast kernels' pools (MdxTabArgs::tile_ctr)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
     int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
@@ -266,7 +267,7 @@ void mdx_destroy(mdx_ctx *c) {
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
     }
     void *ptrs[] = {c->d_ref, c->d_contig_off, c->d_raw, c->d_lgd_dense, c->d_lgd_over,
-                    c->d_n_lgd_over, c->d_err, c->d_partials, c->d_lut, c->d_term, c->d_subs};
+                    c->d_n_lgd_over, c->d_err, c->d_partials, c->d_lut, c->d_term, c->d_subs, c->d_tile_ctr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -433,9 +434,18 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
             }
         }
         {
-            // a wavefront classifies at most ceil(n / wavefronts) records, rounded up to whole tiles
+            // Tiles are handed out on demand within pools of two blocks (mdx_kernels.hip): a wavefront takes at most twice
+            // its even share of its pool's tiles, and its lists hold the records of that many
             const int64_t nwaves = (int64_t)grid * wpb_l;
-            a.list_cap = (b->n_reads + nwaves - 1) / nwaves + 128;
+            const int64_t T = a.dims.R > 0 ? 64 - 64 % a.dims.R : 64;
+            const int64_t n_tiles = (b->n_reads + T - 1) / T;
+            const int64_t n_pools = (grid >= 2 && !(grid & 1)) ? grid / 2 : grid;
+            const int64_t pool_tiles = (n_tiles + n_pools - 1) / n_pools, pool_waves = (grid / n_pools) * wpb_l;
+            a.tile_quota = (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2);
+            a.list_cap = (int64_t)a.tile_quota * T + 128;
+            if (!c->d_tile_ctr) HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)4096 * 4));
+            if (n_pools > 4096) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
+            a.tile_ctr = c->d_tile_ctr;
             HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16));
             a.lists = (uint4 *)c->lists.p;
         }
@@ -445,6 +455,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
             HIP_TRY(c, hipEventCreate(&e1));
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         }
+        // (the pools' tile counters: inside the timed region)
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)4096 * 4, c->stream));
         if (fuse) {
             // (a record written back unchanged keeps this NaN — all ones; inside the timed region)
             HIP_TRY(c, hipMemsetAsync(fuse->mr_raw, 0xFF, (size_t)b->n_reads * 8, c->stream));

@@ -164,6 +164,10 @@ struct MdxTabArgs {
     uint4 *lists;
     int64_t list_cap;
     MdxFuse rs;                      // used by the fused kernel only
+    // Fast kernels: tiles are handed out on demand within pools of two blocks (the two that share a CU): one counter per
+    // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
+    uint32_t *tile_ctr;
+    int tile_quota;
 };
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };

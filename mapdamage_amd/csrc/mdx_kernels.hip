@@ -1487,21 +1487,47 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         u32 n_kept_lite = 0;
         u32 n_rs = 0;           // RS: records left to the rescale kernels behind this one
         u32 nb0 = 0, nb1 = 0;   // RS: byte range of the next tile's qualities (requested a tile ahead)
-        if (RS && n_it > 0) {
-            const u32 tb0 = 0 < rounds ? gwave * T : t_lo;
-            const u32 rh0 = 0 < rounds ? tb0 + T : (tb0 + T < t_hi ? tb0 + T : t_hi);
+        // Tiles are handed out on demand within a *pool*: the two blocks that share a CU (blocks p and p + gridDim / 2: the
+        // dispatcher places the first gridDim / 2 blocks one per CU, then the second half) own a contiguous stretch of the
+        // tiles and one counter (MdxTabArgs::tile_ctr).  A CU's arbiters favour its older wavefronts: with the tiles dealt
+        // out in advance the block dispatched first ran 30 % ahead of the other, and within a block the older wavefronts
+        // ahead of the younger — the launch ended with a third of its time spent on half-empty CUs
+        // (tools/experiments/wave_clk.py).  A wavefront asks for a tile two tiles before it starts it (the answer comes
+        // back under a tile's work) and takes at most tile_quota of them: its lists are sized for that many, and the
+        // quotas of a pool's wavefronts add up to twice its tiles.
+        const u32 n_tiles = (n_rec + T - 1) / T;
+        const u32 n_pools = (gridDim.x >= 2u && !(gridDim.x & 1u)) ? gridDim.x / 2u : gridDim.x;
+        const u32 pool = blockIdx.x % n_pools;
+        const u32 p_lo = (u32)((u64)n_tiles * pool / n_pools), p_hi = (u32)((u64)n_tiles * (pool + 1) / n_pools);
+        u32 grabs = 0;
+        auto grab = [&]() -> u32 {
+            // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
+            u32 v = 0xFFFFFFFFu;
+            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + pool, 1u); grabs++; }
+            return v;
+        };
+        auto tile_of = [&](const u32 raw) -> u32 {
+            const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)raw);
+            return v == 0xFFFFFFFFu || v >= p_hi - p_lo ? 0xFFFFFFFFu : p_lo + v;
+        };
+        u32 cur = tile_of(grab());
+        u32 nxt = cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
+        if (RS && cur != 0xFFFFFFFFu) {
+            const u32 tb0 = cur * T, rh0 = tb0 + T < n_rec ? tb0 + T : n_rec;
             nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
         }
-        for (u32 it = 0;; it++) {
-            const bool past = it >= n_it;
+        for (;;) {
+            const bool past = cur == 0xFFFFFFFFu;
             int nF = 0, nF0 = 0;
+            u32 nxt2_raw = 0xFFFFFFFFu;
             if (!past) {
+                if (nxt != 0xFFFFFFFFu) nxt2_raw = grab();
                 const MdxTabArgs *kp = ka;
                 asm volatile("" : "+s"(kp));
                 const MdxTabArgs &p = *kp;
-                const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
+                const u32 tbase = cur * T;
                 const u32 r_lo = tbase;
-                const u32 r_hi = it < rounds ? tbase + T : (tbase + T < t_hi ? tbase + T : t_hi);
+                const u32 r_hi = tbase + T < n_rec ? tbase + T : n_rec;
                 u32x4 cpv[MDX_FUSE_CPU];
                 u32 cp_a0 = 0, cp_nu = 0, cp_b0 = 0, cp_b1 = 0;
                 if (RS) {
@@ -1524,9 +1550,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                         const u32 u = (u32)lane + 64u * k;
                         if (u < cp_nu) cpv[k] = cp_load(qin + (cp_a0 + 16u * u));
                     }
-                    if (it + 1 < n_it) {
-                        const u32 tb2 = it + 1 < rounds ? ((it + 1) * nwaves + gwave) * T : t_lo + (it + 1 - rounds) * T;
-                        const u32 rh2 = it + 1 < rounds ? tb2 + T : (tb2 + T < t_hi ? tb2 + T : t_hi);
+                    if (nxt != 0xFFFFFFFFu) {
+                        const u32 tb2 = nxt * T, rh2 = tb2 + T < n_rec ? tb2 + T : n_rec;
                         nb0 = ld32(a.seq_off, tb2); nb1 = ld32(a.seq_off, rh2);
                     }
                 }
@@ -1823,6 +1848,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 dDone += m;
             }
             if (past && dDone >= nDef) break;
+            if (!past) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
         }
         if (lane == 0 && n_kept_lite) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), n_kept_lite);
         if (RS && lane == 0) a.rs.gen_count[gwave] = n_rs;

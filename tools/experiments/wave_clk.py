@@ -1,0 +1,42 @@
+"""Per-wavefront start / end-of-tile-loop / end clocks of the tabulation kernel (experiment build with dbg_clk):
+how much of a launch is the tail of its slowest wavefronts."""
+import ctypes, os, sys, pathlib
+import numpy as np
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ["MDX_DBG_CLK"] = "1"
+from mapdamage_amd import engine, synth
+from tools.split_cost import VARIANTS
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
+kw = dict(VARIANTS)["config 3"]
+ref = synth.make_genome()
+b = synth.parallel_batch(dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw), ref, n, 3, workers=64)
+with engine.DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
+    eng.set_reference(ref)
+    db = eng.upload(b)
+    for _ in range(3):
+        eng.tabulate(db)
+    eng.sync()
+    nw = 512 * 12
+    out = np.zeros(nw * 3, np.uint64)
+    lib = engine._lib
+    rc = lib.mdx_dbg_clk_read(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(nw))
+    t = out.reshape(nw, 3).astype(np.int64)
+    t0 = t[:, 0].min()
+    s, m, e = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0     # microseconds
+    print("rc", rc, "waves", nw)
+    for name, v in (("start", s), ("end of tile loop", m), ("end", e), ("tile loop duration", m - s), ("lists duration", e - m), ("total duration", e - s)):
+        print("%-20s min %8.1f  p50 %8.1f  p90 %8.1f  p99 %8.1f  max %8.1f  mean %8.1f us" % (name, v.min(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(), v.mean()))
+    eb = e.reshape(512, 12).max(axis=1)
+    print("block end           min %8.1f  p50 %8.1f  max %8.1f" % (eb.min(), np.percentile(eb, 50), eb.max()))
+    db.free()
+    d = (e - s).reshape(512, 12)
+    bm = d.mean(axis=1)
+    print("by XCD (block % 8):", " ".join("%.0f" % bm[x::8].mean() for x in range(8)))
+    print("by XCD spread (std of block means within XCD):", " ".join("%.0f" % bm[x::8].std() for x in range(8)))
+    print("within-block std of wave durations: mean %.1f" % d.std(axis=1).mean())
+    print("block means: min %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f" % (bm.min(), np.percentile(bm, 10), np.percentile(bm, 50), np.percentile(bm, 90), bm.max()))
+    order = np.argsort(bm)
+    print("slowest blocks:", order[-16:], "fastest:", order[:16])
+    print("block mean by block index / 64:", " ".join("%.0f" % bm[k * 64:(k + 1) * 64].mean() for k in range(8)))
+    print("first 32 block means:", " ".join("%.0f" % v for v in bm[:32]))
