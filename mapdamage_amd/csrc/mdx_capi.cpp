@@ -440,7 +440,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
             const int64_t T = a.dims.R > 0 ? 64 - 64 % a.dims.R : 64;
             const int64_t n_tiles = (b->n_reads + T - 1) / T;
             const int64_t n_pools = (grid >= 2 && !(grid & 1)) ? grid / 2 : grid;
-            const int64_t pool_tiles = (n_tiles + n_pools - 1) / n_pools, pool_waves = (grid / n_pools) * wpb_l;
+            // (a pool takes chunks of MDX_POOL_CHUNK tiles, the pools' chunks interleaved: at most one chunk more than its share)
+            const int64_t chunk = MDX_POOL_CHUNK;
+            const int64_t pool_tiles = ((n_tiles + n_pools * chunk - 1) / (n_pools * chunk)) * chunk, pool_waves = (grid / n_pools) * wpb_l;
             a.tile_quota = (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2);
             a.list_cap = (int64_t)a.tile_quota * T + 128;
             if (!c->d_tile_ctr) HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)4096 * 4));

@@ -70,6 +70,9 @@ struct MdxDims {
 };
 
 #define MDX_MAX_R 4       // records per wavefront step (staging pad = R - 1 entries)
+#ifndef MDX_POOL_CHUNK
+#define MDX_POOL_CHUNK 24  // consecutive tiles a pool of two blocks takes at a time (the fast kernels' hand-out of tiles)
+#endif
 // staging entries (16 B) per wavefront: a tile of 64 - 64 % R records and the R - 1 entries that pad its last step
 static inline __host__ __device__ int mdx_stage_entries(const MdxDims &d) {
     return d.R > 0 ? 64 - 64 % d.R + d.R - 1 : 64;

@@ -58,6 +58,7 @@ typedef u32v3 __attribute__((aligned(4))) u32v3_u;
 #ifndef MDX_NT
 #define MDX_NT 0
 #endif
+
 // The quality copy of the fused kernel (16-byte units at 16-byte-aligned addresses): the copy is written once and not
 // read again by this kernel: MDX_CP_NT & 1 stores it non-temporal, so that it does not take the reference's place in the
 // L2, MDX_CP_NT & 2 loads the source likewise — measured: 3.43 ms either way against 3.44 (off).
@@ -1498,7 +1499,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         const u32 n_tiles = (n_rec + T - 1) / T;
         const u32 n_pools = (gridDim.x >= 2u && !(gridDim.x & 1u)) ? gridDim.x / 2u : gridDim.x;
         const u32 pool = blockIdx.x % n_pools;
-        const u32 p_lo = (u32)((u64)n_tiles * pool / n_pools), p_hi = (u32)((u64)n_tiles * (pool + 1) / n_pools);
+        // (a pool's tiles: chunks of MDX_POOL_CHUNK consecutive tiles, the pools' chunks interleaved — the whole chip works
+        // on one neighbourhood of a coordinate-sorted batch at a time and shares its reference lines in the L2s, as it did
+        // when the tiles were dealt round-robin; a stretch of its own per pool cost such a batch 5 %)
         u32 grabs = 0;
         auto grab = [&]() -> u32 {
             // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
@@ -1508,7 +1511,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         };
         auto tile_of = [&](const u32 raw) -> u32 {
             const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)raw);
-            return v == 0xFFFFFFFFu || v >= p_hi - p_lo ? 0xFFFFFFFFu : p_lo + v;
+            if (v == 0xFFFFFFFFu) return v;
+            const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * n_pools + pool) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
+            return tile < n_tiles ? tile : 0xFFFFFFFFu;
         };
         u32 cur = tile_of(grab());
         u32 nxt = cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
