@@ -1,7 +1,7 @@
 // gfx950 (MI355X / CDNA4) kernels of the damage-tabulation engine.
 //
 // Work decomposition (integer/byte histogram work — HBM/LDS bound, no MFMA):
-//   * a wavefront (64 lanes) takes tiles of 63 consecutive records, dealt round-robin;
+//   * a wavefront (64 lanes) takes tiles of 63 consecutive records, handed out on demand within the two blocks of a CU;
 //   * phase 1 of the tile loop, lane per record: coalesced SoA loads of the per-record columns, flag filter
 //     (reader.py:121-132), and everything a record needs whose CIGAR is one match operation, alone or between soft
 //     clips ([S] M [S]: nine records in ten of an aDNA library): soft-clip update (statistics.py:37-51),
@@ -966,10 +966,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
 #endif
         };
 
-    // Tiles of (up to) 64 records are dealt round-robin to the wavefronts (a run of expensive records — reads over
-    // an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one); the
-    // records left after the last complete round are split evenly, so every wavefront counts the same
-    // number of records to within one.
+    // Without the fast path, tiles of 64 records are dealt round-robin to the wavefronts (a run of expensive records —
+    // reads over an assembly gap in a coordinate-sorted batch — is spread over many wavefronts instead of one) and the
+    // records left after the last complete round are split evenly; the fast kernels hand their tiles out on demand
+    // (see the tile loop).
     // (record indices fit 32 bits: mdx_tabulate_device rejects batches of 2^30 records and more)
     // A tile holds a multiple of R records (63 at three per step): the fast run of a tile of complete
     // records ends on a full step.
