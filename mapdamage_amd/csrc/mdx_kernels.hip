@@ -1515,8 +1515,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * n_pools + pool) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
             return tile < n_tiles ? tile : 0xFFFFFFFFu;
         };
+        // (the fused kernel knows its next tile while it works on one — the bounds of that tile's quality copy are requested
+        // a tile ahead — and asks for the one after; the others ask for the next one: a wavefront that finds its pool
+        // empty has one tile less left to do)
         u32 cur = tile_of(grab());
-        u32 nxt = cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
+        u32 nxt = RS && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
         if (RS && cur != 0xFFFFFFFFu) {
             const u32 tb0 = cur * T, rh0 = tb0 + T < n_rec ? tb0 + T : n_rec;
             nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
@@ -1526,7 +1529,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             int nF = 0, nF0 = 0;
             u32 nxt2_raw = 0xFFFFFFFFu;
             if (!past) {
-                if (nxt != 0xFFFFFFFFu) nxt2_raw = grab();
+                if (!RS || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
                 const MdxTabArgs *kp = ka;
                 asm volatile("" : "+s"(kp));
                 const MdxTabArgs &p = *kp;
@@ -1853,7 +1856,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 dDone += m;
             }
             if (past && dDone >= nDef) break;
-            if (!past) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
+            if (!past) {
+                if (RS) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
+                else cur = tile_of(nxt2_raw);
+            }
         }
         if (lane == 0 && n_kept_lite) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), n_kept_lite);
         if (RS && lane == 0) a.rs.gen_count[gwave] = n_rs;
