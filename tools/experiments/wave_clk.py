@@ -1,5 +1,9 @@
-"""Per-wavefront start / end-of-tile-loop / end clocks of the tabulation kernel (experiment build with dbg_clk):
-how much of a launch is the tail of its slowest wavefronts."""
+"""Per-wavefront start / end-of-tile-loop / end clocks of the tabulation kernel: how much of a launch is the tail of its
+slowest wavefronts, and who they are ("The hand-out of tiles").  Needs the instrumented build:
+    git apply tools/experiments/wave_clk.patch && python -m mapdamage_amd.build
+    gpurun -- python tools/experiments/wave_clk.py 25000000 ["config 3" | "config 4" | ...]      (tools/split_cost.py VARIANTS)
+    git checkout mapdamage_amd/csrc
+(three stores of the 100 MHz clock per wavefront; the library of the tree does not carry them)."""
 import ctypes, os, sys, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
@@ -8,7 +12,7 @@ os.environ["MDX_DBG_CLK"] = "1"
 from mapdamage_amd import engine, synth
 from tools.split_cost import VARIANTS
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
-kw = dict(VARIANTS)["config 3"]
+kw = dict(VARIANTS)[sys.argv[2] if len(sys.argv) > 2 else "config 3"]
 ref = synth.make_genome()
 b = synth.parallel_batch(dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw), ref, n, 3, workers=64)
 with engine.DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
