@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 1
+#define MDX_ABI_VERSION 2   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -64,6 +64,21 @@ typedef struct {
     int64_t lgd_over_cap;  /* capacity (records) of the out-of-range length list */
 } mdx_config;
 
+/* The two forms of the `seq` column ("seq:u8[] (ASCII or 4-bit)").
+ *   MDX_SEQ_ASCII  one byte per base, the characters pysam's read.query holds.
+ *   MDX_SEQ_4BIT   two bases per byte, base i of the column in bits [4 (i & 1), 4 (i & 1) + 4) of byte i / 2 (the
+ *                  low nibble first — BAM stores the high nibble first), code 1 = 'A', 2 = 'C', 4 = 'T', 8 = 'G' and 0 for
+ *                  every other symbol.  Nothing is lost: the reference counts a read symbol only when it is exactly one
+ *                  of "ACGT" (statistics.py:27, 101; rescale.py:228-246), every other one behaves alike.  seq_off and
+ *                  n_bases keep counting bases; the column holds (n_bases + 1) / 2 bytes.  mdx_pack_seq converts;
+ *                  mdx_gbam_set_seq_format makes the device decode path write this form straight from BAM's nibbles.
+ *                  Such a batch runs through the packed kernel (half the SEQ and reference bytes, no LDS update per
+ *                  plain match) whenever the launch is the plain tabulation — no --min-basequal, no rescaling, tables
+ *                  in the LDS, reference below 4 Gbases; for anything else the library unpacks it into a scratch column
+ *                  first and the results are the same bytes. */
+#define MDX_SEQ_ASCII 0
+#define MDX_SEQ_4BIT 1
+
 /* One batch of alignment records as SoA columns: exactly what main.py:165-217 reads from each
  * pysam.AlignedSegment.  `seq` is the full SEQ (soft clips included); `qual`
  * raw Phred (BAM convention, first byte 0xFF = absent) or NULL; `cigar` BAM-encoded len<<4|op.
@@ -84,7 +99,14 @@ typedef struct {
     const uint32_t *seq_off;   /* n_reads + 1 */
     const uint8_t *seq;
     const uint8_t *qual;       /* may be NULL */
+    int32_t seq_format;        /* MDX_SEQ_ASCII (0) or MDX_SEQ_4BIT */
+    int32_t reserved;          /* 0 */
 } mdx_batch;
+
+/* ASCII SEQ bytes -> the MDX_SEQ_4BIT column (host buffers; `packed` holds (n_bases + 1) / 2 bytes; `threads` host
+ * threads, 0 = all).  What main.py:180-205 and statistics.py:22-35 do with a read symbol depends only on which of
+ * "ACGT" it is, if any. */
+int mdx_pack_seq(const uint8_t *ascii, int64_t n_bases, uint8_t *packed, int32_t threads);
 
 int mdx_abi_version(void);
 const char *mdx_strerror(int code);
@@ -309,6 +331,9 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *dev_view, const i
  * quality column (the unmasked kernel), and mdx_gbam_missing_qualities says whether a record the kernel counts has
  * come by without qualities so far (what main.py:185-192 warns about). */
 int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual);
+/* MDX_SEQ_4BIT: the unpack kernel keeps BAM's nibbles (recoded, low nibble first) instead of expanding them to ASCII;
+ * the views of mdx_gbam_next then carry seq_format = MDX_SEQ_4BIT.  Default MDX_SEQ_ASCII. */
+int mdx_gbam_set_seq_format(mdx_gbam *g, int32_t seq_format);
 int mdx_gbam_missing_qualities(const mdx_gbam *g);
 int mdx_gbam_at_end(const mdx_gbam *g);
 void mdx_gbam_close(mdx_gbam *g);

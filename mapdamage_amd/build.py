@@ -34,10 +34,17 @@ def build_lib(force=False, verbose=False, extra_flags=()):
            "-x", "hip", "-Wall", "-Wno-unused-function"]
     cmd += list(extra_flags)
     cmd += [str(CSRC / s) for s in SOURCES]
-    cmd += ["-lz", "-lpthread", "-ldl", "-o", str(LIB)]
+    # linked under another name and moved into place: a process that finds libmdx.so finds a complete one
+    tmp = LIB.with_name("libmdx.so.%d.tmp" % os.getpid())
+    cmd += ["-lz", "-lpthread", "-ldl", "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
     return LIB
 
 
@@ -45,8 +52,7 @@ def build_lib_locked():
     """build_lib() under an exclusive file lock: of several processes started together (one rank per GPU) one compiles,
     the others wait for it and find the library built."""
     import fcntl
-    if not needs_build():
-        return LIB
+    # (the check is made under the lock: a rank that arrives while another one links must wait for it, not load half a file)
     with open(HERE / ".build.lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:

@@ -622,6 +622,7 @@ int mdx_bam_batch(const mdx_bam *b, mdx_batch *view, const int32_t **mtid, const
     view->flag = b->flag.data(); view->lib = b->lib.data(); view->tid = b->tid.data(); view->pos = b->pos.data();
     view->tlen = b->tlen.data(); view->cigar_off = b->cigar_off.data(); view->cigar = b->cigar.data();
     view->seq_off = b->seq_off.data(); view->seq = b->seq.data(); view->qual = b->qual.data();
+    view->seq_format = MDX_SEQ_ASCII; view->reserved = 0;
     if (mtid) *mtid = b->mtid.data();
     if (mpos) *mpos = b->mpos.data();
     if (rg_index) *rg_index = b->rg_index.data();
@@ -813,6 +814,7 @@ struct mdx_gbam {
     std::string error;
     bool want_qual = false, want_mate = false;
     int minqual = 0;                     // --min-basequal on the device path (mdx_gbam_set_min_basequal)
+    int seq_format = MDX_SEQ_ASCII;      // form of the seq column handed out (mdx_gbam_set_seq_format)
     bool no_qual_seen = false;           // a counted record without qualities has come by
     // read groups
     std::vector<uint8_t> rg_names;
@@ -1018,6 +1020,9 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         uint32_t *d_counters = (uint32_t *)((char *)g->small.p + 48);
         c.minqual = g->want_qual ? g->minqual : 0; c.counters = d_counters;
         if (c.minqual > 0 && hipMemsetAsync(d_counters, 0, 8, st) != hipSuccess) return MDX_ERR_HIP;
+        c.seq_packed = g->seq_format == MDX_SEQ_4BIT ? 1 : 0;
+        // (the unpack kernel ORs the nibbles of a record into the column: zeroed first, with the dword behind the last base)
+        if (c.seq_packed && hipMemsetAsync(c.seq, 0, (size_t)(tot[2] + 1) / 2 + 8, st) != hipSuccess) return MDX_ERR_HIP;
         mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
                           (uint32_t)tot[0], (uint32_t *)g->rec_off.p, c, st);
         if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
@@ -1025,6 +1030,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
         view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
         view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
+        view->seq_format = g->seq_format;
         if (c.minqual > 0) {
             uint32_t counters[2] = {0, 0};
             if (hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
@@ -1100,6 +1106,12 @@ int mdx_gbam_inflate_blocks(mdx_ctx *ctx, const uint8_t *comp, int64_t comp_byte
 int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual) {
     if (!g || minqual < 0 || minqual > 93) return MDX_ERR_ARG;
     g->minqual = minqual;
+    return MDX_OK;
+}
+
+int mdx_gbam_set_seq_format(mdx_gbam *g, int32_t seq_format) {
+    if (!g || (seq_format != MDX_SEQ_ASCII && seq_format != MDX_SEQ_4BIT)) return MDX_ERR_ARG;
+    g->seq_format = seq_format;
     return MDX_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -89,6 +90,7 @@ struct mdx_ctx {
     hipStream_t stream = nullptr;
     // reference
     uint8_t *d_ref = nullptr;
+    uint8_t *d_ref4 = nullptr;     // the same bases as 4-bit codes, guard bands included (the packed kernel's)
     int64_t *d_contig_off = nullptr;
     int n_contig = 0;
     int64_t ref_len = 0;
@@ -107,6 +109,7 @@ struct mdx_ctx {
     bool st_busy[2] = {false, false};
     int st_turn = 0;
     int64_t record_base = 0;   // added to the batch index of a record in the error word (mdx_set_record_base)
+    DevBuf unpacked;       // ASCII copy of a 4-bit SEQ column, for the launches the packed kernel does not take
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
     DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
@@ -171,6 +174,29 @@ extern "C" {
 
 int mdx_abi_version(void) { return MDX_ABI_VERSION; }
 
+int mdx_pack_seq(const uint8_t *ascii, int64_t n_bases, uint8_t *packed, int32_t threads) {
+    if (n_bases < 0 || (n_bases > 0 && (!ascii || !packed))) return MDX_ERR_ARG;
+    // exactly 'A', 'C', 'T', 'G' -> 1, 2, 4, 8 (bit k = symbol class k, the order of (ascii >> 1) & 3); anything else 0
+    uint8_t lut[256];
+    std::memset(lut, 0, sizeof lut);
+    lut['A'] = 1; lut['C'] = 2; lut['T'] = 4; lut['G'] = 8;
+    const int64_t nb = (n_bases + 1) / 2;
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nb < (int64_t)1 << 20) nt = 1;
+    auto work = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            const uint8_t a = lut[ascii[2 * i]], b = 2 * i + 1 < n_bases ? lut[ascii[2 * i + 1]] : 0;
+            packed[i] = (uint8_t)(a | (b << 4));
+        }
+    };
+    if (nt == 1) { work(0, nb); return MDX_OK; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back(work, nb * t / nt, nb * (t + 1) / nt);
+    for (auto &th : pool) th.join();
+    return MDX_OK;
+}
+
 const char *mdx_strerror(int code) {
     switch (code) {
         case MDX_OK: return "ok";
@@ -229,6 +255,8 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
         c->lib_group = group;
         c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
         HIP_TRY(c, mdx_k_prepare(c->lds_bytes));
+        // (the packed kernel counts one library per launch)
+        HIP_TRY(c, mdx_k_prepare_packed(mdx_k_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds))));
         HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * gdims.w_total * 4));
     } else {
         c->mode = MDX_MODE_GLOBAL;  // tables do not fit the LDS: global-atomic fallback
@@ -259,6 +287,7 @@ void mdx_destroy(mdx_ctx *c) {
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->lists.release();
+    c->unpacked.release();
     c->rs_part.release();
     c->rs_lists.release();
     c->rs_in.release();
@@ -266,7 +295,7 @@ void mdx_destroy(mdx_ctx *c) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
     }
-    void *ptrs[] = {c->d_ref, c->d_contig_off, c->d_raw, c->d_lgd_dense, c->d_lgd_over,
+    void *ptrs[] = {c->d_ref, c->d_ref4, c->d_contig_off, c->d_raw, c->d_lgd_dense, c->d_lgd_over,
                     c->d_n_lgd_over, c->d_err, c->d_partials, c->d_lut, c->d_term, c->d_subs, c->d_tile_ctr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -291,17 +320,24 @@ int mdx_set_reference(mdx_ctx *c, const uint8_t *bases, const int64_t *contig_of
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_ref) { (void)hipFree(c->d_ref); c->d_ref = nullptr; }
+    if (c->d_ref4) { (void)hipFree(c->d_ref4); c->d_ref4 = nullptr; }
     if (c->d_contig_off) { (void)hipFree(c->d_contig_off); c->d_contig_off = nullptr; }
     // a guard band on both sides keeps speculative flank addresses inside the allocation
     const size_t pad = 256;
     uint8_t *tmp = nullptr;
     HIP_TRY(c, hipMalloc((void **)&tmp, (size_t)n + 1));
-    HIP_TRY(c, hipMalloc((void **)&c->d_ref, (size_t)n + 2 * pad));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ref, (size_t)n + 2 * pad + 1));
     HIP_TRY(c, hipMalloc((void **)&c->d_contig_off, (size_t)(n_contig + 1) * 8));
-    HIP_TRY(c, hipMemsetAsync(c->d_ref, 0x85, (size_t)n + 2 * pad, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref, 0x85, (size_t)n + 2 * pad + 1, c->stream));
     if (n > 0) HIP_TRY(c, hipMemcpyAsync(tmp, bases, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_contig_off, contig_off, (size_t)(n_contig + 1) * 8, hipMemcpyHostToDevice, c->stream));
     mdx_k_encode_ref(tmp, c->d_ref + pad, n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    // the 4-bit form of the same bytes, guard bands included (an even number of them: one more guard byte behind an odd genome)
+    const size_t n4 = ((size_t)n + 2 * pad + 1) / 2;
+    HIP_TRY(c, hipMalloc((void **)&c->d_ref4, n4 + 64));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref4, 0, n4 + 64, c->stream));
+    mdx_k_encode_ref4(c->d_ref, c->d_ref4, (int64_t)(2 * n4), c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(tmp);
@@ -318,6 +354,26 @@ static int check_batch(mdx_ctx *c, const mdx_batch *b) {
     if (b->n_reads > 0 && (!b->flag || !b->lib || !b->tid || !b->pos || !b->tlen || !b->cigar_off || !b->seq_off))
         return fail(c, MDX_ERR_ARG, "null column");
     if ((b->n_cigar > 0 && !b->cigar) || (b->n_bases > 0 && !b->seq)) return fail(c, MDX_ERR_ARG, "null column");
+    if (b->seq_format != MDX_SEQ_ASCII && b->seq_format != MDX_SEQ_4BIT) return fail(c, MDX_ERR_ARG, "unknown seq_format");
+    return MDX_OK;
+}
+
+// bytes of the seq column in its form
+static size_t seq_bytes(const mdx_batch *b) {
+    return b->seq_format == MDX_SEQ_4BIT ? ((size_t)b->n_bases + 1) / 2 : (size_t)b->n_bases;
+}
+
+// For the launches that read ASCII: a batch whose SEQ column is 4-bit gets an ASCII copy in the context's scratch
+// column (enqueued on the stream; valid until the next such call).  *out = the batch to launch with.
+static int ascii_view(mdx_ctx *c, const mdx_batch *b, mdx_batch *out) {
+    *out = *b;
+    if (b->seq_format != MDX_SEQ_4BIT || b->n_bases == 0) { out->seq_format = MDX_SEQ_ASCII; return MDX_OK; }
+    // (launches are in stream order: the kernels of the previous call are done with the scratch column when this one writes it)
+    HIP_TRY(c, c->unpacked.reserve((size_t)b->n_bases + 64));
+    mdx_k_unpack_seq(b->seq, (uint8_t *)c->unpacked.p, b->n_bases, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    out->seq = (const uint8_t *)c->unpacked.p;
+    out->seq_format = MDX_SEQ_ASCII;
     return MDX_OK;
 }
 
@@ -328,6 +384,7 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     std::memset(dv, 0, sizeof(*dv));
     dv->n_reads = h->n_reads; dv->n_cigar = h->n_cigar; dv->n_bases = h->n_bases;
+    dv->seq_format = h->seq_format;
     const int64_t n = h->n_reads;
     struct Col { const void *src; const void **dst; size_t bytes; } cols[] = {
         {h->flag, (const void **)&dv->flag, (size_t)n * 2},
@@ -338,7 +395,7 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
         {h->cigar_off, (const void **)&dv->cigar_off, (size_t)(n + 1) * 4},
         {h->cigar, (const void **)&dv->cigar, (size_t)h->n_cigar * 4},
         {h->seq_off, (const void **)&dv->seq_off, (size_t)(n + 1) * 4},
-        {h->seq, (const void **)&dv->seq, (size_t)h->n_bases},
+        {h->seq, (const void **)&dv->seq, seq_bytes(h)},
         {h->qual, (const void **)&dv->qual, h->qual ? (size_t)h->n_bases : 0},
     };
     for (auto &col : cols) {
@@ -363,13 +420,29 @@ int mdx_batch_free(mdx_ctx *c, mdx_batch *dv) {
 }
 
 // fuse: the rescale side of the fused launch (mdx_tabulate_rescale_device), or null
-static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, int *fused_grid) {
-    int rc = check_batch(c, b);
+static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse, int *fused_grid) {
+    int rc = check_batch(c, b_in);
     if (rc != MDX_OK) return rc;
     if (!c->d_ref) return fail(c, MDX_ERR_STATE, "mdx_set_reference has not been called");
-    if (b->n_reads == 0) return MDX_OK;
+    if (b_in->n_reads == 0) return MDX_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // A 4-bit SEQ column runs through the packed kernel when the launch is the plain fast tabulation: tables in the
+    // LDS, 8-base lanes, 32-bit reference offsets, no quality masking, no fused rescaling.  Anything else reads an ASCII
+    // copy (MDX_NO_PACKED=1 in the environment: always, for A/B runs).
+    const bool ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL;
+    static const bool no_packed = [] { const char *e = getenv("MDX_NO_PACKED"); return e && *e && *e != '0'; }();
+    const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 && !fuse &&
+                        !(c->cfg.minqual > 0 && b_in->qual != nullptr) && !no_packed;
+    mdx_batch b_ascii;
+    const mdx_batch *b = b_in;
+    if (!packed) {
+        rc = ascii_view(c, b_in, &b_ascii);
+        if (rc != MDX_OK) return rc;
+        b = &b_ascii;
+    }
     MdxTabArgs a{};
+    a.ref4 = c->d_ref4;
+    a.seq_packed = packed ? 1 : 0;
     a.n_reads = b->n_reads;
     a.flag = b->flag; a.lib = b->lib; a.tid = b->tid; a.pos = b->pos; a.tlen = b->tlen;
     a.cigar_off = b->cigar_off; a.cigar = b->cigar; a.seq_off = b->seq_off; a.seq = b->seq; a.qual = b->qual;
@@ -389,7 +462,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
     a.stage_off = mdx_k_stage_off(c->dims);
     a.queue_off = mdx_k_queue_off(c->dims);
     a.n_bases = b->n_bases;
-    a.ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL ? 1 : 0;
+    a.ref32 = ref32 ? 1 : 0;
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
     const int wpb = mdx_k_block_threads() / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;
@@ -398,7 +471,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
     a.nlib_total = c->cfg.nlib;
     // LDS mode: one launch per group of libraries (usually a single one); every launch scans all records and
     // counts those of its group
-    const int group = c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib;
+    // (the packed kernel: one library per launch — its bit-sliced counters are one table's)
+    const int group = packed ? 1 : (c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib);
     for (int lo = 0; lo < c->cfg.nlib; lo += group) {
         const int gn = c->cfg.nlib - lo < group ? c->cfg.nlib - lo : group;
         a.lib_lo = lo;
@@ -470,6 +544,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b, const MdxFuse *fuse, in
             mdx_k_tabulate_fused(a, grid, lds, c->stream);
             c->fuse_list_cap = a.list_cap;
             if (fused_grid) *fused_grid = grid;
+        } else if (packed) {
+            mdx_k_tabulate_packed(a, grid, lds, c->stream);
         } else {
             mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);
         }
@@ -497,7 +573,7 @@ int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
     const void *src[10] = {h->flag, h->lib, h->tid, h->pos, h->tlen, h->cigar_off, h->cigar, h->seq_off, h->seq, h->qual};
     const size_t bytes[10] = {(size_t)n * 2, (size_t)n * 2, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4,
                               (size_t)(n + 1) * 4, (size_t)h->n_cigar * 4, (size_t)(n + 1) * 4,
-                              (size_t)h->n_bases, h->qual ? (size_t)h->n_bases : 0};
+                              seq_bytes(h), h->qual ? (size_t)h->n_bases : 0};
     // Two sets of staging buffers and a copy stream of the context's own: the columns of this batch are copied (set s)
     // while the kernel of the previous one still reads the other set; the kernel waits for its copies (an event), and
     // the copies into a set wait for the kernel that read it last (another one).  The call returns once the host
@@ -838,10 +914,15 @@ int mdx_rescale_summary(mdx_ctx *c, uint64_t *words) {
     return MDX_OK;
 }
 
-int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, const int32_t *d_mpos, uint8_t *d_qual_out,
+int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos, uint8_t *d_qual_out,
                        double *d_mr_raw, uint8_t *d_status) {
-    int rc = check_batch(c, b);
+    int rc = check_batch(c, b_in);
     if (rc != MDX_OK) return rc;
+    // (the rescale kernels read ASCII)
+    mdx_batch b_ascii;
+    rc = ascii_view(c, b_in, &b_ascii);
+    if (rc != MDX_OK) return rc;
+    const mdx_batch *b = &b_ascii;
     if (!c->d_ref || !c->d_lut) return fail(c, MDX_ERR_STATE, "set_reference and rescale_set_model first");
     if (!b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status) return fail(c, MDX_ERR_ARG, "null column");
     // (the kernels read the old qualities of a record after they have stored its new ones; offsets up to a few hundred
@@ -895,16 +976,20 @@ static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b) {
     return b->n_reads > 0 && b->n_bases <= 0xFFFF0000LL;
 }
 
-int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b, const int32_t *d_mtid, const int32_t *d_mpos,
+int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos,
                                 uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status) {
     // one pass over one resident batch: the tables and, from the same columns in HBM, the rescaled qualities
-    int rc = check_batch(c, b);
+    int rc = check_batch(c, b_in);
     if (rc != MDX_OK) return rc;
+    mdx_batch b_ascii;
+    rc = ascii_view(c, b_in, &b_ascii);
+    if (rc != MDX_OK) return rc;
+    const mdx_batch *b = &b_ascii;
     // (the fused kernel copies the quality column in 16-byte units: both columns at the same 16-byte phase — true of any two
     // device allocations)
     if (!c->d_ref || !c->d_lut || !b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status || d_qual_out == b->qual ||
         (((uintptr_t)d_qual_out ^ (uintptr_t)b->qual) & 15) != 0 || !fuse_applies(c, b)) {
-        rc = mdx_tabulate_device(c, b);
+        rc = mdx_tabulate_device(c, b_in);
         if (rc != MDX_OK) return rc;
         return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);
     }

@@ -172,6 +172,28 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
     const u64 hi8 = ((u64)'T') | ((u64)'W' << 8) | ((u64)'Y' << 16) | ((u64)'H' << 24) | ((u64)'K' << 32) | ((u64)'D' << 40) | ((u64)'B' << 48) | ((u64)'N' << 56);
     auto letter = [&](const u32 nib) -> u32 { return (u32)(((nib < 8u ? lo8 : hi8) >> (8u * (nib & 7u))) & 0xFFu); };
     const u32 n4 = l_seq >> 2;
+    if (c.seq_packed) {
+        // MDX_SEQ_4BIT (include/mdx.h): the nibbles stay nibbles — recoded (A C G T = 1 2 4 8 in BAM become 1 2 8 4: bit k =
+        // symbol class k of the tabulation kernel; every other code, '=' and the ambiguity letters, becomes 0: the
+        // reference counts a read symbol only when it is one of "ACGT", statistics.py:27, 101), low nibble first, the
+        // record's first base at nibble seq_off[r] of the column whatever its parity.  Eight bases per step: four bytes
+        // in, one dword out, OR-ed into the (zeroed) column across its dword boundary.
+        u32 *__restrict__ d32 = (u32 *)c.seq;
+        const u64 lut = 0x0000000400080210ull;      // code of BAM nibble n at bits [4 n, 4 n + 4)
+        auto code = [&](const u32 nib) -> u32 { return (u32)(lut >> (4u * nib)) & 15u; };
+        const u32 n8 = (l_seq + 7u) >> 3;
+        for (u32 k = j; k < n8; k += 8u) {
+            const u32 nb = l_seq - 8u * k < 8u ? l_seq - 8u * k : 8u;       // bases of this step
+            u32 v = 0;
+            for (u32 i = 0; i < nb; i++) {
+                const u32 byte = q[4u * k + (i >> 1)];
+                v |= code((i & 1u) ? (byte & 15u) : (byte >> 4)) << (4u * i);
+            }
+            const u32 n0 = so + 8u * k, sh = 4u * (n0 & 7u);
+            if (v << sh) atomicOr(&d32[n0 >> 3], v << sh);
+            if (sh && (v >> (32u - sh))) atomicOr(&d32[(n0 >> 3) + 1u], v >> (32u - sh));
+        }
+    } else {
     for (u32 k = j; k < n4; k += 8u) {
         const u32 b0 = q[2 * k], b1 = q[2 * k + 1];
         *(u32u *)(s + 4 * k) = letter(b0 >> 4) | (letter(b0 & 15u) << 8) | (letter(b1 >> 4) << 16) | (letter(b1 & 15u) << 24);
@@ -181,6 +203,7 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
             const u32 byte = q[k >> 1];
             s[k] = (u8)letter((k & 1u) ? (byte & 15u) : (byte >> 4));
         }
+    }
     q += (l_seq + 1u) / 2u;
     u32 qmin = 0xFFu;                                  // lowest quality of the record (0xFF: none)
     if (c.qual) {

@@ -140,6 +140,10 @@ struct MdxTabArgs {
     const uint8_t *qual;
     // resident reference: one symbol class per base (0..3 ACGT, 4 '-', 5 other)
     const uint8_t *ref;
+    // ... and its 4-bit form (MDX_SEQ_4BIT codes, two bases per byte, the 256-base guard bands included: nibble i is
+    // genome coordinate i - 256), read by the packed kernel (tabulate_kernel<.., PK>) together with a 4-bit SEQ column
+    const uint8_t *ref4;
+    int seq_packed;                  // the batch's seq column holds MDX_SEQ_4BIT codes (include/mdx.h)
     const int64_t *contig_off;
     int n_contig;
     int minqual;
@@ -188,6 +192,13 @@ int mdx_k_fuse_tcb_off(const MdxDims &d);
 size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos);
 hipError_t mdx_k_fuse_prepare(size_t lds_bytes);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
+// resident reference bytes (guard bands included, n even) -> 4-bit codes, n / 2 bytes
+void mdx_k_encode_ref4(const uint8_t *d_codes, uint8_t *d_ref4, int64_t n, hipStream_t s);
+// SEQ columns between the two forms of mdx_batch::seq (n bases; the packed column holds (n + 1) / 2 bytes)
+void mdx_k_pack_seq(const uint8_t *d_ascii, uint8_t *d_packed, int64_t n, hipStream_t s);
+void mdx_k_unpack_seq(const uint8_t *d_packed, uint8_t *d_ascii, int64_t n, hipStream_t s);
+hipError_t mdx_k_prepare_packed(size_t lds_bytes);
+void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
@@ -250,6 +261,7 @@ struct MdxGbamCols {
     int32_t *tid, *pos, *tlen, *mtid, *mpos;     // mtid / mpos may be null
     uint32_t *cigar_off, *cigar, *seq_off;
     uint8_t *seq, *qual;                         // qual may be null (not wanted)
+    int seq_packed;                              // seq in its 4-bit form (MDX_SEQ_4BIT; the column zeroed beforehand)
     // read groups of the header: names concatenated, rg_off[n_rg + 1], library of each; lib_default: library of a
     // record without RG tag (-1: none -> 0xFFFF, which the tabulation kernel reports if the record is counted)
     const uint8_t *rg_names;

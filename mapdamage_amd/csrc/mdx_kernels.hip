@@ -367,12 +367,142 @@ __device__ __forceinline__ T ld32(const T *base, u32 idx) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The packed form (tabulate_kernel<.., PK>): SEQ and the resident reference as 4-bit codes (MDX_SEQ_4BIT, include/mdx.h:
+// 1 = A, 2 = C, 4 = T, 8 = G — bit k = symbol class k — and 0 for anything else; 15 = the gap symbol, in registers and
+// events only), two bases per byte, low nibble first.  A lane still owns eight consecutive bases of a record's window —
+// one dword now: an aligned dwordx2 load and one v_alignbit_b32 per operand — and the geometry (MdxDims) is the ASCII
+// kernel's.  What changes is the counting: a code is one-hot, so the eight reference nibbles of a lane *are* the 32
+// increments of its step — bit 4 j + k set: base k at the lane's byte j — and they are added into bit-sliced counters
+// held in registers (eight planes: bit b of plane i = bit i of counter b; two sets, all records and reverse-strand
+// ones), three steps' worth with two v_bitop3_b32 per carry-save adder.  No LDS update per plain match; the planes are
+// folded into TC (same table, same indices) every 255 steps at most.  A nibble that is not a task is zeroed and counts
+// nothing (no DMP correction), an event undoes the count of its reference nibble in TC like the ASCII kernel's.
+#define SYM4_GAP 15u
+// 4-bit code -> symbol class (A, C, T, G = 0..3; '-' = 4; anything else 5)
+__device__ __forceinline__ int cls4(u32 nib) {
+    const bool one = nib != 0u && (nib & (nib - 1u)) == 0u;
+    return one ? __ffs((int)nib) - 1 : (nib == SYM4_GAP ? SYM_GAP : SYM_OTHER);
+}
+// nibbles [lo, hi) of a dword, the range clamped to [0, 8)
+__device__ __forceinline__ u32 nibble_range(int lo, int hi) {
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 8 ? 8 : hi;
+    if (hi <= lo) return 0u;
+    const u32 upto = hi >= 8 ? ~0u : ((1u << (4 * hi)) - 1u);
+    return upto & ~((1u << (4 * lo)) - 1u);
+}
+// lane_masks for nibbles: vm = the nibble is a task of a complete record, em = it is a read column
+__device__ __forceinline__ void lane_masks4(const MdxDims &d, int side, int m8, u32 &vm, u32 &em) {
+    if (!side) {
+        vm = nibble_range(0, d.A + d.L - m8);
+        em = vm & nibble_range(d.A - m8, 8);
+    } else {
+        vm = nibble_range(m8 + 8 - d.A - d.L, 8);
+        em = vm & nibble_range(0, m8 + 8 - d.A);
+    }
+}
+// carry-save adder over 32 one-bit columns: p + a + b = p' + 2 c
+__device__ __forceinline__ void bs_csa(u32 &p, const u32 a, const u32 b, u32 &c) {
+    const u32 sum = __builtin_amdgcn_bitop3_b32(p, a, b, 0x96);      // p ^ a ^ b
+    c = __builtin_amdgcn_bitop3_b32(p, a, b, 0xE8);                  // majority
+    p = sum;
+}
+// c, a word of weight 2^from, into the planes from `from` upwards
+template <int FROM>
+__device__ __forceinline__ void bs_ripple(u32 (&p)[8], u32 c) {
+#pragma unroll
+    for (int i = FROM; i < 8; i++) {
+        const u32 t = p[i] & c;
+        p[i] ^= c;
+        c = t;
+    }
+}
+// N words of weight 1 into the planes (N a compile-time count of 1..4)
+template <int N>
+__device__ __forceinline__ void bs_add(u32 (&p)[8], const u32 (&x)[4]) {
+    if (N == 1) bs_ripple<0>(p, x[0]);
+    else if (N == 2) { u32 c; bs_csa(p[0], x[0], x[1], c); bs_ripple<1>(p, c); }
+    else if (N == 3) { u32 c, e; bs_csa(p[0], x[0], x[1], c); e = p[0] & x[2]; p[0] ^= x[2]; bs_csa(p[1], c, e, c); bs_ripple<2>(p, c); }
+    else { u32 c0, c1, c2; bs_csa(p[0], x[0], x[1], c0); bs_csa(p[0], x[2], x[3], c1); bs_csa(p[1], c0, c1, c2); bs_ripple<2>(p, c2); }
+}
+// Eight optimistic increments by position of the packed kernel's single-deletion steps: word (base_bytes / 4) +
+// (STRIDE / 4) j + class of the reference nibble at position j of the lane (rising positions: nibble j on the left
+// side, nibble 7 - j on the right side), for the nibbles of the mask that hold a base
+template <int STRIDE>
+__device__ __forceinline__ void direct8n(u32 *lds, u32 r8, u32 base_bytes, u32 m8, bool reversed) {
+    u32 *const row = lds + (base_bytes >> 2);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int sh = 4 * (reversed ? 7 - j : j);
+        const u32 nib = (r8 >> sh) & 15u;
+        const bool on = ((m8 >> sh) & 1u) && nib != 0u && (nib & (nib - 1u)) == 0u;
+        const u32 k = on ? (u32)(__ffs((int)nib) - 1) : 0u;
+        atomicAdd(&row[j * (STRIDE / 4) + k], on ? 1u : 0u);
+    }
+}
+
+// resident reference bytes (encode_ref_kernel's, guard bands included) -> 4-bit codes, eight bases per thread and step
+__device__ __forceinline__ u32 code4_of_ref(u32 b) {
+    // 'A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47: class (b >> 1) & 3; 0x84 / 0x85: nothing
+    return (b & 0x80u) ? 0u : 1u << ((b >> 1) & 3u);
+}
+__global__ void encode_ref4_kernel(const u8 *__restrict__ in, u8 *__restrict__ out, i64 n2) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) out[i] = (u8)(code4_of_ref(in[2 * i]) | (code4_of_ref(in[2 * i + 1]) << 4));
+}
+void mdx_k_encode_ref4(const u8 *d_codes, u8 *d_ref4, int64_t n, hipStream_t s) {
+    const i64 n2 = n / 2;
+    if (n2 <= 0) return;
+    const int grid = (int)((n2 + 255) / 256 < 8192 ? (n2 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(encode_ref4_kernel, dim3(grid), dim3(256), 0, s, d_codes, d_ref4, n2);
+}
+// a read symbol -> its code: exactly 'A', 'C', 'G', 'T' (statistics.py:27, 101), anything else 0
+__device__ __forceinline__ u32 code4_of_read(u32 ch) {
+    const int c = classify_read(ch);
+    return c < 4 ? 1u << c : 0u;
+}
+__global__ void pack_seq_kernel(const u8 *__restrict__ in, u8 *__restrict__ out, i64 n) {
+    const i64 n2 = (n + 1) / 2;
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) {
+        const u32 lo = code4_of_read(in[2 * i]), hi = 2 * i + 1 < n ? code4_of_read(in[2 * i + 1]) : 0u;
+        out[i] = (u8)(lo | (hi << 4));
+    }
+}
+void mdx_k_pack_seq(const u8 *d_ascii, u8 *d_packed, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    const i64 n2 = (n + 1) / 2;
+    const int grid = (int)((n2 + 255) / 256 < 16384 ? (n2 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(pack_seq_kernel, dim3(grid), dim3(256), 0, s, d_ascii, d_packed, (i64)n);
+}
+// ... and back (for the kernels that read ASCII: --min-basequal, rescaling, the generic path): a code that is not a
+// base becomes 'N' — which is what every such symbol is to the reference
+__global__ void unpack_seq_kernel(const u8 *__restrict__ in, u8 *__restrict__ out, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const u32 nib = (in[i >> 1] >> (4 * (i & 1))) & 15u;
+        const int c = cls4(nib);
+        out[i] = c < 4 ? (u8)((0x47544341u >> (8 * c)) & 0xFFu) : (u8)'N';
+    }
+}
+void mdx_k_unpack_seq(const u8 *d_packed, u8 *d_ascii, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(unpack_seq_kernel, dim3(grid), dim3(256), 0, s, d_packed, d_ascii, (i64)n);
+}
+
 // FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
 // otherwise every record takes the generic CIGAR walk.
 // RS: the fused tabulate + rescale launch (MdxFuse; mapdamage/rescale.py:195-365 for the records of the tile loop)
-template <bool USE_LDS, bool MASK, bool FAST, bool RS = false>
+// PK: the packed form — 4-bit SEQ and reference, bit-sliced counting (see above); one library per launch
+template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false>
 __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS : MDX_WPS) void tabulate_kernel(MdxTabArgs a) {
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
+    static_assert(!PK || (USE_LDS && FAST && !MASK && !RS), "the packed kernel is the plain fast LDS kernel");
     constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : MDX_BLOCK;
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -408,7 +538,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     int bcA = 0, bcC = 0, bcG = 0, bcT = 0;   // RS: reference bases (read orientation) this lane has counted itself
     if (USE_LDS) {
         for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) lds[i] = 0;
-        if (FAST && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
+        if (FAST && !PK && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
+        // (PK: nine 32-bit masks, entry n = the low n nibbles set)
+        if (PK && threadIdx.x < 9) ((u32 *)ltab)[threadIdx.x] = threadIdx.x >= 8 ? ~0u : ((1u << (4 * threadIdx.x)) - 1u);
         if (RS) {
             for (int i = threadIdx.x; i < d.nlib * d.w_tc + 4; i += BLOCK) lds[a.rs.tcb_off + i] = 0;
             for (int i = threadIdx.x; i < 2 * rs_npos * 94; i += BLOCK) ((u8 *)(rs_cnt + 4))[i] = a.rs.lut[i];
@@ -426,10 +558,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     // load whose lane addresses are not dword-aligned costs the texture-address unit about twice as much
     // (14.1 vs 8.4 ns for the SEQ pattern, 16.2 vs 12.6 ns for the reference pattern), and that unit is
     // what bounds this kernel.  The bases are aligned down here, their phase goes into the lane offsets.
-    const u32 ph_ref = (u32)((size_t)(a.ref - 256) & 3), ph_seq = (u32)((size_t)a.seq & 3),
+    // (PK: offsets count bases — nibbles —, so the phase of the SEQ column's base address counts twice; the 4-bit
+    // reference is the library's own allocation, dword-aligned)
+    const u32 ph_ref = PK ? 0u : (u32)((size_t)(a.ref - 256) & 3), ph_seq = (PK ? 2u : 1u) * (u32)((size_t)a.seq & 3),
               ph_qual = MASK ? (u32)((size_t)a.qual & 3) : 0u;
-    const u8 *const refW = a.ref - 256 - ph_ref;  // start of the guard band (dword-aligned): window offsets are >= 0
-    const u8 *const seqW = a.seq - ph_seq;
+    const u8 *const refW = PK ? a.ref4 : a.ref - 256 - ph_ref;  // start of the guard band (dword-aligned): window offsets are >= 0
+    const u8 *const seqW = a.seq - ((size_t)a.seq & 3);
     const u8 *const qualW = MASK ? a.qual - ph_qual : nullptr;
 
     // Per-lane constants of the fast path (MdxDims): slot g = lane / G holds one record of the step; within
@@ -451,10 +585,15 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             } else {
                 c_ro = (u32)c_m8; c_so = (u32)(c_m8 - A);
             }
-            u64 vm, em;
-            lane_masks(d, c_side, c_m8, vm, em);
-            c_vm_lo = (u32)vm; c_vm_hi = (u32)(vm >> 32);
-            c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
+            if (PK) {
+                // (one dword of eight nibbles per lane: the masks live in the low halves)
+                lane_masks4(d, c_side, c_m8, c_vm_lo, c_em_lo);
+            } else {
+                u64 vm, em;
+                lane_masks(d, c_side, c_m8, vm, em);
+                c_vm_lo = (u32)vm; c_vm_hi = (u32)(vm >> 32);
+                c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
+            }
         }
     }
     c_ro += ph_ref;   // the phases of the aligned-down bases
@@ -476,6 +615,40 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     u32x2 *const qR = qS + EVQ_CAP;
     u32 *const qW = (u32 *)(qR + EVQ_CAP);
     int qcount = 0;
+    // PK: an event is {read dword, reference dword, word}: S[64] | R[64] | W[64] u32 at the start of the same area
+    u32 *const qS4 = (u32 *)qS, *const qR4 = qS4 + EVQ_CAP, *const qW4 = qR4 + EVQ_CAP;
+    // PK: the bit-sliced counters of this lane's eight window nibbles (bit 4 j + k of plane i = bit i of the count of
+    // base k at nibble j) — all records, and the reverse-strand ones — and the steps added since they were last folded
+    // into TC (at most 255: eight planes)
+    u32 bsT[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, bsM[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int bs_steps = 0;
+    // fold the planes into TC[strand][base][64 j + lane] of the launch's library (the ASCII kernel's table, which the
+    // events' undo and finalize_kernel address): per bit position s of the bytes, the four counters of bits s, s + 8,
+    // s + 16, s + 24 are gathered as the bytes of one word
+    auto bs_flush = [&]() {
+        if (PK) {
+            u32 *const tcp = lds + d.off_tc() + lane;
+#pragma unroll
+            for (int sft = 0; sft < 8; sft++) {
+                u32 accT = 0u, accM = 0u;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    accT |= ((bsT[i] >> sft) & 0x01010101u) << i;
+                    accM |= ((bsM[i] >> sft) & 0x01010101u) << i;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int b = sft + 8 * q, j = b >> 2, k = b & 3;
+                    const u32 t = (accT >> (8 * q)) & 0xFFu, m = (accM >> (8 * q)) & 0xFFu;
+                    atomicAdd(&tcp[k * 512 + 64 * j], t - m);
+                    atomicAdd(&tcp[(4 + k) * 512 + 64 * j], m);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) { bsT[i] = 0u; bsM[i] = 0u; }
+            bs_steps = 0;
+        }
+    };
 
     // Undo the optimistic increment of each queued byte that was not a plain match and, for read
     // columns, count what the byte really is (rare_column) — lane-parallel over the queued events.
@@ -591,6 +764,52 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         return mr;
     };
     auto drain_all = [&]() {
+        if (PK) {
+            // the packed kernel's events: nibbles instead of bytes; only a nibble that holds a base was counted
+            if (lane < qcount) {
+                const u32 s8 = qS4[lane], r8 = qR4[lane], w = qW4[lane];
+                const int ln = (int)(w >> 18) & 63;
+                const int rev = (int)(w >> 31);
+                const int lb = __mul24((int)((w >> 24) & 0x3Fu), d.w_lib);
+                const bool del = (w >> 30) & 1u;
+                const int g = del ? (int)(w >> 8) & 7 : 0, bnd = (int)(w >> 11) & 15;
+                const int tcw = del ? lb + d.off_tc() + rev * 4 * 512 : (int)((w & 0x3FF00u) >> 2);
+                int ll = ln;
+                if (ll >= d.G) ll -= d.G;
+                if (ll >= d.G) ll -= d.G;
+                if (ll >= d.G) ll -= d.G;
+                const int side = ll >= d.nl8;
+                const int m8 = 8 * (ll - side * d.nl8);
+                u32 vm, em;
+                lane_masks4(d, side, m8, vm, em);
+                u32 x = (s8 ^ r8) & em;
+                const int b_mis = lb + d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = lb + d.off_cmp() + (rev ? 2 * L * 4 : 0);
+                while (x) {
+                    const int jb = (__ffs((int)x) - 1) >> 2;
+                    const int sh = 4 * jb;
+                    x &= ~(0xFu << sh);
+                    const int rc = cls4((r8 >> sh) & 15u), sc = cls4((s8 >> sh) & 15u);
+                    const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
+                    const bool direct = del && (side ? jb < bnd : jb >= bnd);
+                    const int pc = direct ? p - g : p;
+                    const int sp = (side ? L : 0) + p;
+                    if (rc < 4) {
+                        if (direct) {
+                            bump_n<USE_LDS>(lds, raw, b_mis + __mul24(sp, 25) + rc, 0xFFFFFFFFu);
+                            bump_n<USE_LDS>(lds, raw, b_cmp + ((side ? L : 0) + pc) * 4 + rc, 0xFFFFFFFFu);
+                        } else {
+                            bump_n<USE_LDS>(lds, raw, tcw + (rc << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
+                        }
+                    }
+                    // what the column really is (rare_column): the read base, and a substitution / indel
+                    if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + ((side ? L : 0) + pc) * 4 + sc);
+                    if (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) bump<USE_LDS>(lds, raw, b_mis + __mul24(sp, 25) + mis_col(rc, sc));
+                }
+            }
+            qcount = 0;
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            return;
+        }
         if (lane < qcount) {
             const u32x2 es = qS[lane], er = qR[lane];
             const u32 w = qW[lane];
@@ -859,6 +1078,154 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             constexpr bool QM = MASK && decltype(qm_tag)::value;
             const int nsteps = (nrec + R - 1) / R;
             int kf = 0;
+            if constexpr (PK) {
+                // ---- the packed kernel's run: same entries, same lanes, nibbles instead of bytes (see "The packed form")
+                if (bs_steps + nsteps > 255) bs_flush();
+                bs_steps += nsteps;
+                struct St4 { u32x2 s, r; u32 sa, ra, pk, aux; int lim; bool valid; };
+                auto fill4 = [&](St4 &st) {
+                    st.valid = kf < nsteps;
+                    const int k = st.valid ? kf : nsteps - 1;
+                    kf++;
+                    int nv = nrec - k * R;
+                    nv = nv > R ? R : nv;
+                    st.lim = nv * G;
+                    const uint4 ent = stg[e0 + k * R + c_slot];
+                    const u32 t = ent.z & c_cm;
+                    u32 ro = ent.x + c_ro + t;
+                    u32 so = ent.y + c_so + t;
+                    st.aux = 0u;
+                    if (KIND != STEP_C) {
+                        const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
+                        ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
+                        const u32 z = ent.z;
+                        const int nq_ = (int)(z & 0x7FFFu);
+                        const int t8 = (int)((z >> (16 + 8 * c_side)) & 0xFFu);      // task nibbles / run length of this side
+                        const int jo = c_side ? c_m8 + 8 - A : A - c_m8, sgn = 1 - 2 * c_side;
+                        const bool act = lane < st.lim;
+                        auto c4 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 8 ? 8 : v)) << 2; };   // offset into the nibble-mask table
+                        if (KIND == STEP_P) {
+                            const int dm = t8 - c_m8;
+                            st.aux = act ? c4(c_side ? 8 - dm : dm) : (c_side ? 32u : 0u);
+                        } else {
+                            const int dd = (int)(i8)(ent.w & 0xFFu);
+                            const int g = KIND == STEP_GD ? dd : -dd;
+                            const int ncol = KIND == STEP_GD ? nq_ + g : nq_;
+                            const int Lm = ncol < L ? ncol : L;
+                            const int ta = jo + sgn * t8 - (c_side ? g : 0), tb = ta + g;
+                            const int tl = act ? jo + sgn * Lm : (c_side ? 8 : 0);
+                            const bool blane = c_side ? tb >= 8 : ta <= 0;
+                            const u32 off = blane ? (u32)(-sgn * g) : 0u;
+                            if (KIND == STEP_GD) so += off; else ro += off;
+                            const int bnd = c_side ? ta : tb;
+                            st.aux = c4(ta) | (c4(tb) << 7) | (c4(tl) << 14) | ((blane ? 0u : (u32)g) << 21) | ((u32)g << 24) |
+                                     ((c4(bnd) >> 2) << 27);
+                        }
+                    }
+                    // eight nibbles from bit 4 (offset & 7) of the aligned dword pair
+                    st.ra = ro << 2; st.sa = so << 2;
+                    st.r = *(const u32x2 *)(refW + ((ro >> 1) & ~3u));
+                    st.s = *(const u32x2 *)(seqW + ((so >> 1) & ~3u));
+                    st.pk = ent.w;
+                };
+                // one step: X = the nibbles this step counts (one-hot codes: the increments themselves), Xm = those of
+                // reverse-strand records
+                auto count4 = [&](const St4 &st, auto full_tag, u32 &Xo, u32 &Mo) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    const bool act = FULL || lane < st.lim;
+                    u32 s8 = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa);
+                    u32 r8 = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra);
+                    u32 X;
+                    u32 evw = st.pk & 0xBF03FF00u;
+                    if (KIND == STEP_C) {
+                        // (a nibble that is not a task has counters of its own, which nothing reads)
+                        X = act ? r8 : 0u;
+                    } else {
+                        const u32 aux = st.aux;
+                        const u32 sm = 0u - (u32)c_side;                         // all ones on the right side
+                        const u32 *const lt4 = (const u32 *)ltab;
+                        if (KIND == STEP_P) {
+                            const u32 Mk = *(const u32 *)((const u8 *)lt4 + aux);
+                            const u32 dyn = (Mk ^ sm) & c_vm_lo;
+                            s8 &= dyn; r8 &= dyn;
+                            X = r8;
+                        } else {
+                            const u32 Xk = *(const u32 *)((const u8 *)lt4 + (aux & 0x7Fu)), Yk = *(const u32 *)((const u8 *)lt4 + ((aux >> 7) & 0x7Fu)),
+                                      Tk = *(const u32 *)((const u8 *)lt4 + ((aux >> 14) & 0x7Fu));
+                            const u32 dyn = (Tk ^ sm) & c_vm_lo;
+                            // the string that carries the gap: its nibbles in front of the gap as loaded, the gap symbol,
+                            // its nibbles behind the gap moved by g within the lane that straddles it
+                            const u32 shb = ((aux >> 21) & 7u) << 2, shr = shb & sm, shl = shb & ~sm;
+                            const u32 star = KIND == STEP_GD ? s8 : r8;
+                            const u32 low = star >> shr, high = star << shl;
+                            u32 m = (Xk & low) | ~Xk;                            // (the gap symbol: 15)
+                            m = (Yk & m) | (~Yk & high);
+                            if (KIND == STEP_GD) {
+                                s8 = m;
+                                // nibbles behind the deletion (left: from tb on, right: below ta): MIS[column][base] and
+                                // CMP[column - g][base] by position instead of the counters
+                                const u32 beh = (Xk & sm) | (~Yk & ~sm);
+                                const u32 dmk = dyn & beh;
+                                evw = (st.pk & 0xBF000000u) | 0x40000000u | (((aux >> 24) & 0x7Fu) << 8);
+                                if (__ballot(dmk != 0u)) {
+                                    const int g = (int)((aux >> 24) & 7u);
+                                    const int lbw = __mul24((int)((st.pk >> 24) & 0x3Fu), d.w_lib), rev = (int)(st.pk >> 31);
+                                    const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
+                                    direct8n<100>(lds, r8, (u32)(4 * (lbw + d.off_mis() + __mul24(row, 25))), dmk, c_side != 0);
+                                    direct8n<16>(lds, r8, (u32)(4 * (lbw + d.off_cmp() + (row - g) * 4)), dmk, c_side != 0);
+                                }
+                                s8 &= dyn; r8 &= dyn;
+                                X = r8 & ~beh;
+                            } else {
+                                r8 = m;
+                                s8 &= dyn; r8 &= dyn;
+                                X = r8 & (Xk | ~Yk);                             // (not the gap symbols)
+                            }
+                        }
+                    }
+                    Xo = X;
+                    Mo = (int)st.pk < 0 ? X : 0u;
+                    u32 xx = (s8 ^ r8) & c_em_lo;
+                    if (KIND == STEP_C && !FULL) xx = act ? xx : 0u;   // (the other kinds: no tasks in a slot without a record)
+                    const bool ev = xx != 0;
+                    const u64 mm = __ballot(ev);
+                    if (mm) {
+                        const int n = __popcll(mm);
+                        if (qcount + n > EVQ_CAP) drain_all();
+                        if (ev) {
+                            const int slot = mbcnt64(mm, qcount);
+                            qS4[slot] = s8;
+                            qR4[slot] = r8;
+                            qW4[slot] = evw | (c_lane4 << 16);
+                        }
+                        qcount += n;
+                    }
+                };
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : PIPE_DEPTH);
+                static_assert(PD4 >= 1 && PD4 <= 4, "bs_add takes up to four steps");
+                St4 st[PD4];
+#pragma unroll
+                for (int dd = 0; dd < PD4; dd++) fill4(st[dd]);
+                for (int k = PD4; k < nsteps; k += PD4) {
+                    u32 xs[4] = {0u, 0u, 0u, 0u}, ms[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int dd = 0; dd < PD4; dd++) {
+                        count4(st[dd], std::true_type{}, xs[dd], ms[dd]);      // (never the last step of the run)
+                        fill4(st[dd]);
+                    }
+                    bs_add<PD4>(bsT, xs);
+                    bs_add<PD4>(bsM, ms);
+                }
+                {
+                    u32 xs[4] = {0u, 0u, 0u, 0u}, ms[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int dd = 0; dd < PD4; dd++)
+                        if (dd == 0 || st[dd].valid) count4(st[dd], std::false_type{}, xs[dd], ms[dd]);
+                    bs_add<PD4>(bsT, xs);
+                    bs_add<PD4>(bsM, ms);
+                }
+                return;
+            }
 #if MDX_ENT_AHEAD
             // (the staging entry of a step is read from the LDS one fill ahead: its latency — behind the eight table
             // updates of the step just counted — is off the path to the window loads)
@@ -993,6 +1360,16 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     u32 *const lri = (u32 *)(lists + 5 * a.list_cap + a.list_cap / 4 + 1);
     int lP = 0, lI = 0, lD = 0, lC = 0;
 
+    // class of the read symbol at index i of the SEQ column / of the reference symbol at (concatenated) genome coordinate i,
+    // which may lie in the guard bands — in either form of the two columns
+    auto seq_cls = [&](const u32 i) -> int {
+        if (PK) return cls4(((u32)a.seq[i >> 1] >> (4u * (i & 1u))) & 15u);
+        return classify_read(a.seq[i]);
+    };
+    auto ref_cls = [&](const i64 i) -> int {
+        if (PK) { const i64 n = i + 256; return cls4(((u32)a.ref4[n >> 1] >> (4 * (int)(n & 1))) & 15u); }
+        return classify_ref(((const i8 *)a.ref)[i]);
+    };
     // ------------------------------------------------------------ the general pass: any record, lane per record
     // Everything the reference's loop body does to a record up to the columns the steps count: flag filter, CIGAR scan,
     // fragment length, soft clips, error checks, classification.  FAST: fed 64 at a time with the records the tile loop
@@ -1275,11 +1652,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                         const int g = dnq, u = vlr & 0xFF, v = vlr >> 8, Lq = nq < L ? nq : L;
                         const int b_cmp = libid * d.w_lib + d.off_cmp() + rev * 2 * L * 4;
                         for (int q = u > L - g ? u : L - g; q < Lq; q++) {
-                            const int sc = classify_read(a.seq[sq + q]);
+                            const int sc = seq_cls(sq + (u32)q);
                             if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + q * 4 + sc);
                         }
                         for (int i = v > L - g ? v : L - g; i < Lq; i++) {
-                            const int sc = classify_read(a.seq[sq + nq - 1 - i]);
+                            const int sc = seq_cls(sq + (u32)(nq - 1 - i));
                             if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + (L + i) * 4 + sc);
                         }
                     }
@@ -1298,7 +1675,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // land in plane A.  DMP says, as differences over the window bytes of a side, how many such bytes
                 // there are (finalize_kernel takes the prefix sums off the A counts): +1 where a stretch begins, -1
                 // where it ends before the window does.
-                if (USE_LDS) {
+                // (PK: a nibble that is not a task is zero and counts nothing — no correction)
+                if (USE_LDS && !PK) {
                     const int dl = libid * d.w_lib + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
                     if (plain && !isF) {
                         // tasks [-A, min(nq, L)) per side
@@ -1350,8 +1728,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             const int b_mis = lb + d.off_mis() + rev * 2 * L * 25;
             const int b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
             const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad;
-            const i8 *__restrict__ rp = (const i8 *)a.ref + s_rbase;
-            const u8 *__restrict__ sp = a.seq + s_sq;
             const u8 *__restrict__ qp = MASK ? a.qual + s_sq : nullptr;
             // flank lengths: from the packed descriptor (A < 248 with the fast path), else recomputed
             int s_nb = (s_w1 >> D_NB_SHIFT) & 0xFF, s_na = (s_w1 >> D_NA_SHIFT) & 0xFF;
@@ -1408,8 +1784,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     }
                 }
                 if (rix == -2) rix = jr - shift;
-                int s = qi < 0 ? SYM_GAP : classify_read(sp[qi]);
-                int r = rix < 0 ? SYM_GAP : classify_ref(rp[rix]);
+                int s = qi < 0 ? SYM_GAP : seq_cls(s_sq + (u32)qi);
+                int r = rix < 0 ? SYM_GAP : ref_cls(s_rbase + rix);
                 if (hasq) {
                     const bool ms = qi >= 0 && (int)qp[qi] < a.minqual;
                     bool mr = ms;
@@ -1449,7 +1825,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             for (int t = lane; t < nql + nqr; t += 64) {
                 const int side = t >= nql;
                 const int k0 = side ? s_vr + (t - nql) : s_vl + t;
-                const int s = classify_read(sp[side ? s_nq - 1 - k0 : k0]);
+                const int s = seq_cls(s_sq + (u32)(side ? s_nq - 1 - k0 : k0));
                 if (s < 4) bump<USE_LDS>(lds, raw, b_cmp + (side * L + k0) * 4 + s);
             }
             // flanks (statistics.py:85-93) go to their task slots
@@ -1457,8 +1833,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 const int side = t >= A;
                 const int dist = (side ? t - A : t) + 1;
                 if (dist <= (side ? s_na : s_nb)) {
-                    const int r = side ? rp[s_n0 - 1 + dist] : rp[-dist];
-                    if (r >= 0) bump<USE_LDS>(lds, raw, b_tc + ((r >> 1) & 3) * d.t_pad + (side ? d.tau_rflank(dist) : d.tau_lflank(dist)));
+                    const int r = ref_cls(s_rbase + (side ? s_n0 - 1 + dist : -dist));
+                    if (r < 4) bump<USE_LDS>(lds, raw, b_tc + r * d.t_pad + (side ? d.tau_rflank(dist) : d.tau_lflank(dist)));
                 }
             }
         }
@@ -1783,7 +2159,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     if (triv && !isF) {
                         const int dl = lbase + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
                         const int k1 = nq < L ? nq : L;
-                        if (k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
+                        if (!PK && k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
                         lists[lP + mbcnt64(mP, 0)] = ent;
                         if (RS) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
                     }
@@ -1904,6 +2280,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
 #endif
     if (FAST) {
         if (qcount > 0) drain_all();
+        if (PK) bs_flush();
     }
     if (USE_LDS) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // the hand-written ds_adds of this wavefront
@@ -1959,6 +2336,17 @@ hipError_t mdx_k_fuse_prepare(size_t lds_bytes) {
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
     hipLaunchKernelGGL((tabulate_kernel<true, false, true, true>), dim3(grid), dim3(MDX_FUSE_BLOCK), lds_bytes, s, a);
+}
+
+hipError_t mdx_k_prepare_packed(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, false, true, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+// the packed kernel: 4-bit SEQ column and 4-bit reference, one library per launch
+void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    if (a.n_reads <= 0) return;
+    hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(MDX_BLOCK), lds_bytes, s, a);
 }
 
 hipError_t mdx_k_prepare(size_t lds_bytes) {

@@ -33,8 +33,10 @@ EXPORTS = (
     "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled", "mdx_bam_qmin",
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
-    "mdx_gbam_inflate_blocks", "mdx_set_record_base",
+    "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format",
 )
+
+SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
 
 
 class MdxConfig(ctypes.Structure):
@@ -51,7 +53,8 @@ class MdxBatch(ctypes.Structure):
                 ("pos", ctypes.c_void_p), ("tlen", ctypes.c_void_p),
                 ("cigar_off", ctypes.c_void_p), ("cigar", ctypes.c_void_p),
                 ("seq_off", ctypes.c_void_p), ("seq", ctypes.c_void_p),
-                ("qual", ctypes.c_void_p)]
+                ("qual", ctypes.c_void_p),
+                ("seq_format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class MdxError(RuntimeError):
@@ -126,6 +129,9 @@ def load_library(path=None):
     lib.mdx_gbam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mdx_gbam_at_end.argtypes = [ctypes.c_void_p]
     lib.mdx_gbam_set_min_basequal.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mdx_gbam_set_seq_format.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.mdx_pack_seq.restype = ctypes.c_int
+    lib.mdx_pack_seq.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32]
     lib.mdx_gbam_missing_qualities.argtypes = [ctypes.c_void_p]
     lib.mdx_gbam_close.restype = None
     lib.mdx_gbam_close.argtypes = [ctypes.c_void_p]
@@ -138,7 +144,18 @@ def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
-def _host_batch(batch: ReadBatch):
+def pack_seq(seq, threads=0):
+    """ASCII SEQ bytes -> the 4-bit column of ``MDX_SEQ_4BIT`` (include/mdx.h): two bases per byte, low nibble first,
+    1 = A, 2 = C, 4 = T, 8 = G, 0 = anything else — all the reference's loop distinguishes (statistics.py:27, 101)."""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    out = np.empty((seq.shape[0] + 1) // 2, np.uint8)
+    rc = load_library().mdx_pack_seq(_ptr(seq), ctypes.c_int64(seq.shape[0]), _ptr(out), ctypes.c_int32(threads))
+    if rc != 0:
+        raise MdxError(rc, "mdx_pack_seq")
+    return out
+
+
+def _host_batch(batch: ReadBatch, packed=False):
     b = MdxBatch()
     b.n_reads = batch.n
     b.n_cigar = int(batch.cigar.shape[0])
@@ -146,6 +163,9 @@ def _host_batch(batch: ReadBatch):
     keep = []
     for name in ("flag", "lib", "tid", "pos", "tlen", "cigar_off", "cigar", "seq_off", "seq"):
         arr = np.ascontiguousarray(getattr(batch, name))
+        if name == "seq" and packed:
+            arr = pack_seq(arr)
+            b.seq_format = SEQ_4BIT
         setattr(b, name, arr.ctypes.data)
         keep.append(arr)
     if batch.qual is not None:
@@ -177,6 +197,10 @@ class DamageEngine:
 
     ``libraries``: list of (sample, library) tuples indexed by the ``lib`` column (unique
     libraries in header order, or ``[("*", "*")]`` for --merge-libraries)."""
+
+    # the form in which ``upload`` / ``tabulate`` hand a host batch's SEQ column over when the caller does not say
+    # (False: ASCII as it stands, True: packed to 4 bits first); the tests run every parity case through both
+    default_packed = False
 
     def __init__(self, libraries, length=70, around=10, minqual=0, lgd_max=65536, device=0,
                  lgd_over_cap=1 << 20):
@@ -232,32 +256,40 @@ class DamageEngine:
         self._check(self._lib.mdx_set_reference(self._ctx, _ptr(bases), _ptr(offs),
                                                 ctypes.c_int32(len(ref.names))))
 
-    def upload(self, batch: ReadBatch) -> DeviceBatch:
-        hb = _host_batch(batch)
+    def upload(self, batch: ReadBatch, packed=None) -> DeviceBatch:
+        """Resident copy of a host batch; ``packed``: with the SEQ column in its 4-bit form (``pack_seq``), which the
+        plain tabulation then reads through the packed kernel."""
+        hb = _host_batch(batch, self.default_packed if packed is None else packed)
         dev = MdxBatch()
         self._check(self._lib.mdx_batch_upload(self._ctx, ctypes.byref(hb), ctypes.byref(dev)))
         return DeviceBatch(self, dev, batch.n, int(batch.seq.shape[0]), int(batch.cigar.shape[0]))
 
-    def tabulate(self, batch, sync=True, record_base=None):
-        """Accumulate one batch (host ``ReadBatch`` or resident ``DeviceBatch``).  A host batch is staged through the
-        library's pinned buffers: when the call returns its columns may be released.  ``sync=False`` leaves copies and
-        kernel in flight (the next host batch is copied meanwhile); a record the reference cannot process then
-        surfaces at the next ``sync()`` / ``finish()`` with index ``record_base`` + its index within its batch."""
-        base = 0 if record_base is None else int(record_base)
+    def _set_record_base(self, base):
+        # (context state: every entry point that launches sets it, so that a base given to one call does not shift the
+        # record numbers of the next)
         if base != getattr(self, "_record_base", 0):
             self._check(self._lib.mdx_set_record_base(self._ctx, ctypes.c_int64(base)))
             self._record_base = base
+
+    def tabulate(self, batch, sync=True, record_base=None, packed=None):
+        """Accumulate one batch (host ``ReadBatch`` or resident ``DeviceBatch``).  A host batch is staged through the
+        library's pinned buffers: when the call returns its columns may be released.  ``sync=False`` leaves copies and
+        kernel in flight (the next host batch is copied meanwhile); a record the reference cannot process then
+        surfaces at the next ``sync()`` / ``finish()`` with index ``record_base`` + its index within its batch.
+        ``packed`` (host batches): hand the SEQ column over in its 4-bit form (half the bytes across PCIe)."""
+        self._set_record_base(0 if record_base is None else int(record_base))
         if isinstance(batch, DeviceBatch):
             self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(batch.dev)))
         else:
-            hb = _host_batch(batch)
+            hb = _host_batch(batch, self.default_packed if packed is None else packed)
             self._check(self._lib.mdx_tabulate_host(self._ctx, ctypes.byref(hb)))
             if sync:
                 # a record the reference cannot process surfaces here, with its index within this batch
                 self.sync()
 
-    def tabulate_view(self, view):
+    def tabulate_view(self, view, record_base=None):
         """An ``MdxBatch`` of device pointers (``sam.GpuBamStream.next_view``): enqueued, errors at ``sync``."""
+        self._set_record_base(0 if record_base is None else int(record_base))
         self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(view)))
 
     def tabulate_pointers(self, n_reads, n_cigar, n_bases, **ptrs):
@@ -266,6 +298,7 @@ class DamageEngine:
         b.n_reads, b.n_cigar, b.n_bases = n_reads, n_cigar, n_bases
         for k, v in ptrs.items():
             setattr(b, k, v)
+        self._set_record_base(0)
         self._check(self._lib.mdx_tabulate_device(self._ctx, ctypes.byref(b)))
 
     def sync(self):
@@ -378,6 +411,7 @@ class DamageEngine:
         """Rescale a resident batch (``DeviceBatch`` with qualities; the other arguments are device pointers as
         integers); ``with_tables``: count the batch into the tables in the same call (BASELINE configs[4])."""
         fn = self._lib.mdx_tabulate_rescale_device if with_tables else self._lib.mdx_rescale_device
+        self._set_record_base(0)
         self._check(fn(self._ctx, ctypes.byref(dbatch.dev), ctypes.c_void_p(d_mtid), ctypes.c_void_p(d_mpos),
                        ctypes.c_void_p(d_qual_out), ctypes.c_void_p(d_mr), ctypes.c_void_p(d_status)))
 

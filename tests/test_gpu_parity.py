@@ -13,6 +13,18 @@ from tests.util import Golden, assert_tables_equal, golden_names, oracle_tablese
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["ascii", "4bit"])
+def seq_form(request):
+    """Every case of this module runs through both forms of the SEQ column (include/mdx.h MDX_SEQ_*): as ASCII, and
+    packed to 4 bits on the host — the packed kernel where the launch is a plain tabulation, an ASCII scratch copy made by
+    the library where it is not (--min-basequal, the generic path)."""
+    from mapdamage_amd.engine import DamageEngine
+    old = DamageEngine.default_packed
+    DamageEngine.default_packed = request.param == "4bit"
+    yield request.param
+    DamageEngine.default_packed = old
+
+
 def run_engine(ref, batch, libraries, length, around, minqual=0, lgd_max=65536, resident=False,
                splits=1):
     from mapdamage_amd.engine import DamageEngine
@@ -95,8 +107,9 @@ def test_hip_sorted_batch_with_gap_run(mid_genome):
     assert_tables_equal(got, want)
 
 
+@pytest.mark.parametrize("Q", [15, 0])
 @pytest.mark.parametrize("phase", [1, 2, 3])
-def test_hip_unaligned_column_pointers(phase, mid_genome):
+def test_hip_unaligned_column_pointers(phase, Q, mid_genome, seq_form):
     """SEQ / QUAL device pointers that are not dword-aligned (the kernel aligns its window loads down and
     folds the pointer phase into the lane offsets)."""
     import torch
@@ -104,14 +117,19 @@ def test_hip_unaligned_column_pointers(phase, mid_genome):
     batch = synth.make_reads(mid_genome, 30_000, 31, len_range=(30, 140), with_qual=True, frac_softclip=0.1,
                              frac_ins=0.03, frac_del=0.03)
     libs = [("s", "l")]
-    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 15)
-    with DamageEngine(libs, 70, 10, 15) as eng:
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, Q)
+    with DamageEngine(libs, 70, 10, Q) as eng:
         eng.set_reference(mid_genome)
         dev = eng.upload(batch)
         n = int(batch.seq.shape[0])
         tseq = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
         tqual = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
-        tseq[phase:phase + n] = torch.from_numpy(batch.seq).cuda()
+        if seq_form == "4bit":
+            from mapdamage_amd.engine import pack_seq
+            pk = pack_seq(batch.seq)
+            tseq[phase:phase + pk.shape[0]] = torch.from_numpy(pk).cuda()
+        else:
+            tseq[phase:phase + n] = torch.from_numpy(batch.seq).cuda()
         tqual[phase:phase + n] = torch.from_numpy(batch.qual).cuda()
         torch.cuda.synchronize()
         own = (dev.dev.seq, dev.dev.qual)
