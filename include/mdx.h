@@ -244,6 +244,8 @@ int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const 
 int mdx_rescale_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
 /* Calls of mdx_tabulate_rescale_device so far that ran as the fused launch (the others: two kernels). */
 int64_t mdx_fused_launches(const mdx_ctx *ctx);
+/* Kernel launches so far that ran as the packed kernel (a MDX_SEQ_4BIT batch in a plain tabulation; one per library). */
+int64_t mdx_packed_launches(const mdx_ctx *ctx);
 /* The integer content of the `subs` dictionary that _rescale_qual_read fills through _record_subs
  * (rescale.py:82-143) and _print_subs logs (:159-192), accumulated over every mdx_rescale_host call
  * since mdx_rescale_set_model.  words (uint64), npos = 1 + len5p + len3p:

@@ -110,6 +110,7 @@ struct mdx_ctx {
     int st_turn = 0;
     int64_t record_base = 0;   // added to the batch index of a record in the error word (mdx_set_record_base)
     DevBuf unpacked;       // ASCII copy of a 4-bit SEQ column, for the launches the packed kernel does not take
+    DevBuf ev_ovf;         // per-wavefront event overflow lists of the packed kernel (MdxTabArgs::ev_ovf)
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
     DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
@@ -117,6 +118,7 @@ struct mdx_ctx {
     uint32_t *d_tile_ctr = nullptr; // tile counters of the fast kernels' pools (MdxTabArgs::tile_ctr)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
+    int64_t n_packed = 0;          // launches of the packed kernel so far (mdx_packed_launches)
     int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_done[2] = {nullptr, nullptr};
@@ -288,6 +290,7 @@ void mdx_destroy(mdx_ctx *c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->lists.release();
     c->unpacked.release();
+    c->ev_ovf.release();
     c->rs_part.release();
     c->rs_lists.release();
     c->rs_in.release();
@@ -524,6 +527,11 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.tile_ctr = c->d_tile_ctr;
             HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16));
             a.lists = (uint4 *)c->lists.p;
+            if (packed) {
+                a.ev_ovf_cap = mdx_pk_ovf_cap(a.dims);
+                HIP_TRY(c, c->ev_ovf.reserve((size_t)nwaves * (size_t)a.ev_ovf_cap * 4));
+                a.ev_ovf = (uint32_t *)c->ev_ovf.p;
+            }
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {
@@ -546,6 +554,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             if (fused_grid) *fused_grid = grid;
         } else if (packed) {
             mdx_k_tabulate_packed(a, grid, lds, c->stream);
+            c->n_packed++;
         } else {
             mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);
         }
@@ -1079,6 +1088,7 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
 }
 
 int64_t mdx_fused_launches(const mdx_ctx *c) { return c ? c->n_fused : -1; }
+int64_t mdx_packed_launches(const mdx_ctx *c) { return c ? c->n_packed : -1; }
 
 int mdx_rescale_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
     if (!c) return MDX_ERR_ARG;

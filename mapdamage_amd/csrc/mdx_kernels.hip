@@ -114,6 +114,9 @@ typedef long long i64;
 #ifndef MDX_QPREFETCH
 #define MDX_QPREFETCH 1                 // MASK: the quality windows requested with the other two, PIPE_DEPTH steps ahead
 #endif
+#ifndef MDX_PK_PD
+#define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
+#endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
 #endif
@@ -599,6 +602,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     c_ro += ph_ref;   // the phases of the aligned-down bases
     const u32 c_qo = c_so + ph_qual;
     c_so += ph_seq;
+    // PK: c_so - c_ro, the same in every lane (the staging entries carry SEQ offset - reference offset + this)
+    const u32 pk_dso = ph_seq - (u32)A;
     const u32 c_hivm_lo = c_vm_lo & 0x80808080u, c_hivm_hi = c_vm_hi & 0x80808080u;
     // (the lane field of an event word is c_lane4 << 16: no register of its own across the hot loop)
     const u32 c_lane4 = (u32)lane << 2;     // byte offset of word `lane` (the dynamic LDS starts at address 0)
@@ -615,8 +620,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     u32x2 *const qR = qS + EVQ_CAP;
     u32 *const qW = (u32 *)(qR + EVQ_CAP);
     int qcount = 0;
-    // PK: an event is {read dword, reference dword, word}: S[64] | R[64] | W[64] u32 at the start of the same area
-    u32 *const qS4 = (u32 *)qS, *const qR4 = qS4 + EVQ_CAP, *const qW4 = qR4 + EVQ_CAP;
+    // PK: an event is one nibble that is not a plain match, four bytes: [3:0] read code | [7:4] reference code | [10:8] the
+    // lane's nibble | [16:11] lane | [17] reverse strand | [18] single-deletion entry, then [21:19] = deleted bases g and
+    // [25:22] = first nibble of the lane behind the deletion (right side: the nibbles below it).  MDX_PK_QCAP of them in
+    // the same area; what a run raises beyond that goes to the wavefront's stretch of MdxTabArgs::ev_ovf.  Nothing is
+    // drained inside a run: the drain's registers would be the hot loop's.
+    u32 *const qE = (u32 *)qS;
+    u32 *const ev_ovf_w = PK ? a.ev_ovf + (size_t)gwave * (size_t)a.ev_ovf_cap : nullptr;
+    static_assert(!PK || MDX_PK_QCAP * 4 <= EVQ_BYTES, "the LDS event queue");
     // PK: the bit-sliced counters of this lane's eight window nibbles (bit 4 j + k of plane i = bit i of the count of
     // base k at nibble j) — all records, and the reverse-strand ones — and the steps added since they were last folded
     // into TC (at most 255: eight planes)
@@ -765,45 +776,47 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     };
     auto drain_all = [&]() {
         if (PK) {
-            // the packed kernel's events: nibbles instead of bytes; only a nibble that holds a base was counted
-            if (lane < qcount) {
-                const u32 s8 = qS4[lane], r8 = qR4[lane], w = qW4[lane];
-                const int ln = (int)(w >> 18) & 63;
-                const int rev = (int)(w >> 31);
-                const int lb = __mul24((int)((w >> 24) & 0x3Fu), d.w_lib);
-                const bool del = (w >> 30) & 1u;
-                const int g = del ? (int)(w >> 8) & 7 : 0, bnd = (int)(w >> 11) & 15;
-                const int tcw = del ? lb + d.off_tc() + rev * 4 * 512 : (int)((w & 0x3FF00u) >> 2);
-                int ll = ln;
-                if (ll >= d.G) ll -= d.G;
-                if (ll >= d.G) ll -= d.G;
-                if (ll >= d.G) ll -= d.G;
-                const int side = ll >= d.nl8;
-                const int m8 = 8 * (ll - side * d.nl8);
-                u32 vm, em;
-                lane_masks4(d, side, m8, vm, em);
-                u32 x = (s8 ^ r8) & em;
-                const int b_mis = lb + d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = lb + d.off_cmp() + (rev ? 2 * L * 4 : 0);
-                while (x) {
-                    const int jb = (__ffs((int)x) - 1) >> 2;
-                    const int sh = 4 * jb;
-                    x &= ~(0xFu << sh);
-                    const int rc = cls4((r8 >> sh) & 15u), sc = cls4((s8 >> sh) & 15u);
+            // the packed kernel's events: one nibble each, 64 at a time; only a nibble that holds a base was counted
+            const int n = qcount;
+            const u32 *const ovf = ev_ovf_w;
+            if (n > MDX_PK_QCAP) {
+                // (the wavefront's own stores to its overflow list: complete before they are read back)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+#pragma unroll 1
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                if (i < n) {
+                    const u32 w = i < MDX_PK_QCAP ? qE[i] : ovf[i - MDX_PK_QCAP];
+                    const int sc = cls4(w & 15u), rc = cls4((w >> 4) & 15u);
+                    const int jb = (int)(w >> 8) & 7, ln = (int)(w >> 11) & 63, rev = (int)(w >> 17) & 1;
+                    const bool del = (w >> 18) & 1u;
+                    const int g = del ? (int)(w >> 19) & 7 : 0, bnd = (int)(w >> 22) & 15;
+                    int ll = ln;  // lane within its slot (R <= 4)
+                    if (ll >= d.G) ll -= d.G;
+                    if (ll >= d.G) ll -= d.G;
+                    if (ll >= d.G) ll -= d.G;
+                    const int side = ll >= d.nl8;
+                    const int m8 = 8 * (ll - side * d.nl8);
                     const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
+                    // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
+                    // CMP[p - g] (its query index) instead of the lane's counters
                     const bool direct = del && (side ? jb < bnd : jb >= bnd);
                     const int pc = direct ? p - g : p;
-                    const int sp = (side ? L : 0) + p;
+                    const int sp = (side ? L : 0) + p, spc = (side ? L : 0) + pc;
+                    const int b_mis = d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = d.off_cmp() + (rev ? 2 * L * 4 : 0);
                     if (rc < 4) {
                         if (direct) {
-                            bump_n<USE_LDS>(lds, raw, b_mis + __mul24(sp, 25) + rc, 0xFFFFFFFFu);
-                            bump_n<USE_LDS>(lds, raw, b_cmp + ((side ? L : 0) + pc) * 4 + rc, 0xFFFFFFFFu);
+                            atomicAdd(&lds[b_mis + __mul24(sp, 25) + rc], 0xFFFFFFFFu);
+                            atomicAdd(&lds[b_cmp + spc * 4 + rc], 0xFFFFFFFFu);
                         } else {
-                            bump_n<USE_LDS>(lds, raw, tcw + (rc << 9) + 64 * jb + ln, 0xFFFFFFFFu);  // -1
+                            atomicAdd(&lds[d.off_tc() + rev * 2048 + (rc << 9) + 64 * jb + ln], 0xFFFFFFFFu);  // -1
                         }
                     }
                     // what the column really is (rare_column): the read base, and a substitution / indel
-                    if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + ((side ? L : 0) + pc) * 4 + sc);
-                    if (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) bump<USE_LDS>(lds, raw, b_mis + __mul24(sp, 25) + mis_col(rc, sc));
+                    if (sc < 4) atomicAdd(&lds[b_cmp + spc * 4 + sc], 1u);
+                    if (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) atomicAdd(&lds[b_mis + __mul24(sp, 25) + mis_col(rc, sc)], 1u);
                 }
             }
             qcount = 0;
@@ -1082,6 +1095,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // ---- the packed kernel's run: same entries, same lanes, nibbles instead of bytes (see "The packed form")
                 if (bs_steps + nsteps > 255) bs_flush();
                 bs_steps += nsteps;
+                // (STEP_C keeps no record word per step in flight: with one library per launch the strand — bit 31 of sa — says it all)
                 struct St4 { u32x2 s, r; u32 sa, ra, pk, aux; int lim; bool valid; };
                 auto fill4 = [&](St4 &st) {
                     st.valid = kf < nsteps;
@@ -1093,7 +1107,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     const uint4 ent = stg[e0 + k * R + c_slot];
                     const u32 t = ent.z & c_cm;
                     u32 ro = ent.x + c_ro + t;
-                    u32 so = ent.y + c_so + t;
+                    u32 so = ro + ent.y;
                     st.aux = 0u;
                     if (KIND != STEP_C) {
                         const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
@@ -1122,11 +1136,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                                      ((c4(bnd) >> 2) << 27);
                         }
                     }
-                    // eight nibbles from bit 4 (offset & 7) of the aligned dword pair
-                    st.ra = ro << 2; st.sa = so << 2;
+                    // eight nibbles from bit 4 (offset & 7) of the aligned dword pair (v_alignbit_b32 looks at five bits of its
+                    // shift operand; bit 31 of sa: the strand)
+                    st.ra = ro << 2;
+                    st.sa = ((so << 2) & 0x7FFFFFFFu) | (ent.w & 0x80000000u);
                     st.r = *(const u32x2 *)(refW + ((ro >> 1) & ~3u));
                     st.s = *(const u32x2 *)(seqW + ((so >> 1) & ~3u));
-                    st.pk = ent.w;
+                    st.pk = KIND == STEP_C ? 0u : ent.w;
                 };
                 // one step: X = the nibbles this step counts (one-hot codes: the increments themselves), Xm = those of
                 // reverse-strand records
@@ -1136,7 +1152,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     u32 s8 = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa);
                     u32 r8 = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra);
                     u32 X;
-                    u32 evw = st.pk & 0xBF03FF00u;
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
                         X = act ? r8 : 0u;
@@ -1166,13 +1181,24 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                                 // CMP[column - g][base] by position instead of the counters
                                 const u32 beh = (Xk & sm) | (~Yk & ~sm);
                                 const u32 dmk = dyn & beh;
-                                evw = (st.pk & 0xBF000000u) | 0x40000000u | (((aux >> 24) & 0x7Fu) << 8);
                                 if (__ballot(dmk != 0u)) {
+                                    // (a rolled loop, one nibble at a time in position order — nibble j on the left side,
+                                    // 7 - j on the right: these steps are rare, their registers are the kernel's)
                                     const int g = (int)((aux >> 24) & 7u);
-                                    const int lbw = __mul24((int)((st.pk >> 24) & 0x3Fu), d.w_lib), rev = (int)(st.pk >> 31);
+                                    const int rev = (int)(st.pk >> 31);
                                     const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
-                                    direct8n<100>(lds, r8, (u32)(4 * (lbw + d.off_mis() + __mul24(row, 25))), dmk, c_side != 0);
-                                    direct8n<16>(lds, r8, (u32)(4 * (lbw + d.off_cmp() + (row - g) * 4)), dmk, c_side != 0);
+                                    u32 *pm = lds + d.off_mis() + __mul24(row, 25), *pc = lds + d.off_cmp() + (row - g) * 4;
+                                    u32 rr = c_side ? __builtin_bitreverse32(r8) : r8, dd = c_side ? __builtin_bitreverse32(dmk) : dmk;
+#pragma unroll 1
+                                    for (int j = 0; j < 8; j++) {
+                                        // (right side: the bits of a nibble are reversed too — class k is bit 3 - k)
+                                        const u32 nib = rr & 15u;
+                                        const bool on = (dd & 15u) != 0u && nib != 0u && (nib & (nib - 1u)) == 0u;
+                                        const int k0 = __ffs((int)nib) - 1;
+                                        const int k = on ? (c_side ? 3 - k0 : k0) : 0;
+                                        if (on) { atomicAdd(pm + k, 1u); atomicAdd(pc + k, 1u); }
+                                        rr >>= 4; dd >>= 4; pm += 25; pc += 4;
+                                    }
                                 }
                                 s8 &= dyn; r8 &= dyn;
                                 X = r8 & ~beh;
@@ -1184,46 +1210,58 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                         }
                     }
                     Xo = X;
-                    Mo = (int)st.pk < 0 ? X : 0u;
+                    Mo = (u32)((int)st.sa >> 31) & X;
                     u32 xx = (s8 ^ r8) & c_em_lo;
                     if (KIND == STEP_C && !FULL) xx = act ? xx : 0u;   // (the other kinds: no tasks in a slot without a record)
-                    const bool ev = xx != 0;
-                    const u64 mm = __ballot(ev);
-                    if (mm) {
-                        const int n = __popcll(mm);
-                        if (qcount + n > EVQ_CAP) drain_all();
-                        if (ev) {
+                    if (__ballot(xx != 0u)) {
+                        // one event per nibble that is not a plain match (see qE): the lowest one of every lane that has one,
+                        // again while some lane has another.  Beyond the LDS queue: the wavefront's overflow list.
+                        u32 evb = ((u32)lane << 11) | ((st.sa >> 31) << 17);
+                        if (KIND == STEP_GD) evb |= 0x40000u | (((st.aux >> 24) & 0x7Fu) << 19);
+                        do {
+                            const bool on = xx != 0u;
+                            const u64 mm = __ballot(on);
+                            const u32 sh = on ? (u32)(__ffs((int)xx) - 1) & ~3u : 0u;
+                            const u32 evn = ((s8 >> sh) & 15u) | (((r8 >> sh) & 15u) << 4) | (sh << 6) | evb;
                             const int slot = mbcnt64(mm, qcount);
-                            qS4[slot] = s8;
-                            qR4[slot] = r8;
-                            qW4[slot] = evw | (c_lane4 << 16);
-                        }
-                        qcount += n;
+                            if (on) {
+                                if (slot < MDX_PK_QCAP) qE[slot] = evn;
+                                else ev_ovf_w[slot - MDX_PK_QCAP] = evn;
+                            }
+                            qcount += __popcll(mm);
+                            xx &= ~(15u << sh);
+                        } while (__ballot(xx != 0u));
                     }
                 };
-                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : PIPE_DEPTH);
-                static_assert(PD4 >= 1 && PD4 <= 4, "bs_add takes up to four steps");
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : MDX_PK_PD);
+                static_assert(PD4 >= 1 && PD4 <= 4, "the accumulation below takes up to four steps");
                 St4 st[PD4];
 #pragma unroll
                 for (int dd = 0; dd < PD4; dd++) fill4(st[dd]);
-                for (int k = PD4; k < nsteps; k += PD4) {
-                    u32 xs[4] = {0u, 0u, 0u, 0u}, ms[4] = {0u, 0u, 0u, 0u};
+                // the words of a group of PD4 steps go through carry-save adders as they come: (x0, x1) -> plane 0 and a carry,
+                // (x2, x3) -> plane 0 and another, the two carries -> plane 1 and one of weight 4, which ripples upwards
+                auto group = [&](auto full_tag, const bool refill) {
+                    u32 x[4] = {0u, 0u, 0u, 0u}, m[4] = {0u, 0u, 0u, 0u};
+                    u32 cT = 0u, cM = 0u;
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) {
-                        count4(st[dd], std::true_type{}, xs[dd], ms[dd]);      // (never the last step of the run)
-                        fill4(st[dd]);
+                        if (refill || dd == 0 || st[dd].valid) count4(st[dd], full_tag, x[dd], m[dd]);
+                        if (refill) fill4(st[dd]);
+                        if (dd == 1) { bs_csa(bsT[0], x[0], x[1], cT); bs_csa(bsM[0], m[0], m[1], cM); }
                     }
-                    bs_add<PD4>(bsT, xs);
-                    bs_add<PD4>(bsM, ms);
-                }
-                {
-                    u32 xs[4] = {0u, 0u, 0u, 0u}, ms[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int dd = 0; dd < PD4; dd++)
-                        if (dd == 0 || st[dd].valid) count4(st[dd], std::false_type{}, xs[dd], ms[dd]);
-                    bs_add<PD4>(bsT, xs);
-                    bs_add<PD4>(bsM, ms);
-                }
+                    if (PD4 == 1) { bs_ripple<0>(bsT, x[0]); bs_ripple<0>(bsM, m[0]); }
+                    else if (PD4 == 2) { bs_ripple<1>(bsT, cT); bs_ripple<1>(bsM, cM); }
+                    else {
+                        u32 eT, eM;
+                        bs_csa(bsT[0], x[2], x[3], eT); bs_csa(bsM[0], m[2], m[3], eM);
+                        bs_csa(bsT[1], cT, eT, cT); bs_csa(bsM[1], cM, eM, cM);
+                        bs_ripple<2>(bsT, cT); bs_ripple<2>(bsM, cM);
+                    }
+                };
+                for (int k = PD4; k < nsteps; k += PD4) group(std::true_type{}, true);      // (never the last step of the run)
+                group(std::false_type{}, false);
+                // (the only place the packed kernel drains: behind a run, once a few passes' worth of events wait)
+                if (qcount >= MDX_PK_QCAP - 128) drain_all();
                 return;
             }
 #if MDX_ENT_AHEAD
@@ -1610,7 +1648,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             const int rev = w1 & D_REV;
             uint4 ent;
             ent.x = (u32)(rbase - A + 256);
-            ent.y = sq;
+            // (PK: the SEQ window offset of a lane is its reference window offset plus this — one lane constant less)
+            ent.y = PK ? sq - ent.x + pk_dso : sq;
             // (partial entries: the task bytes of each window, A + min(nq, L); complete ones do not look at them)
             ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
             ent.w = ((u32)(libid * d.w_lib + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
@@ -2127,7 +2166,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // staging entry (as in the general pass)
                 uint4 ent;
                 ent.x = c0 + (u32)c_pos - (u32)A + 256u;
-                ent.y = sq;
+                ent.y = PK ? sq - ent.x + pk_dso : sq;
                 ent.z = (u32)nq | ((u32)((A + (nq < L ? nq : L)) * 0x101) << 16);
                 ent.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) |
                         ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
@@ -2222,6 +2261,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             const int pend = nDef - dDone;
             if (pend >= 64 || (past && pend > 0)) {
                 const int m = pend < 64 ? pend : 64;
+                // (PK: the general pass is where the kernel wants the most registers: the bit-sliced counters are folded
+                // into TC in front of it — every dozen tiles, about as often as their eight planes ask for anyway — and
+                // are not live across it)
+                if (PK) bs_flush();
                 // (the wavefront's own stores: complete before they are read back)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

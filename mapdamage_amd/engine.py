@@ -33,7 +33,7 @@ EXPORTS = (
     "mdx_bam_stream_keep_raw", "mdx_bam_raw", "mdx_bam_patch_rescaled", "mdx_bam_qmin",
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
-    "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format",
+    "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
 )
 
 SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
@@ -103,6 +103,8 @@ def load_library(path=None):
     lib.mdx_rescale_summary_words.argtypes = [ctypes.c_void_p]
     lib.mdx_fused_launches.restype = ctypes.c_int64
     lib.mdx_fused_launches.argtypes = [ctypes.c_void_p]
+    lib.mdx_packed_launches.restype = ctypes.c_int64
+    lib.mdx_packed_launches.argtypes = [ctypes.c_void_p]
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
         getattr(lib, name).restype = ctypes.c_char_p
     lib.mdx_bam_qnames.restype = ctypes.c_void_p
@@ -418,6 +420,10 @@ class DamageEngine:
     def fused_launches(self):
         """Calls of rescale_device(with_tables=True) so far that ran as one fused launch."""
         return int(self._lib.mdx_fused_launches(self._ctx))
+
+    def packed_launches(self):
+        """Kernel launches so far that ran as the packed kernel (4-bit SEQ column and reference)."""
+        return int(self._lib.mdx_packed_launches(self._ctx))
 
     def rescale_timing_read(self):
         n = ctypes.c_int64(0)

@@ -373,7 +373,7 @@ class GpuBamStream:
     do not start at records — the caller then decodes on the host (``BamStream``)."""
 
     def __init__(self, engine, path, readgroups=(), lib_default=None, chunk_bytes=256 << 20, want_qual=False,
-                 want_mate=False, min_basequal=0):
+                 want_mate=False, min_basequal=0, packed=None):
         import ctypes
         self._lib = engine._lib
         self._engine = engine
@@ -397,6 +397,13 @@ class GpuBamStream:
         if min_basequal:
             # --min-basequal: unmaskable records are flagged on the device, see ``missing_qualities``
             self._lib.mdx_gbam_set_min_basequal(self._g, int(min_basequal))
+        # the SEQ column of the views: BAM's nibbles kept as nibbles (MDX_SEQ_4BIT: the packed kernel reads them) unless
+        # the launches behind it read ASCII anyway (--min-basequal, rescaling); ``packed`` overrides the choice
+        if packed is None:
+            packed = not (want_qual or min_basequal)
+        self.packed = bool(packed)
+        if self.packed:
+            self._lib.mdx_gbam_set_seq_format(self._g, 1)
 
     def missing_qualities(self):
         """A record the kernel counts has come by without qualities (main.py:185-192 warns once)."""

@@ -71,6 +71,36 @@ def test_device_columns_equal_host_decoder(tmp_path, chunk):
     np.testing.assert_array_equal(cat["lib"], want_lib)
 
 
+@pytest.mark.parametrize("chunk", [1 << 16, 1 << 28])
+def test_device_seq_column_in_its_4bit_form(tmp_path, chunk):
+    """MDX_SEQ_4BIT from the device decode path: BAM's nibbles kept as nibbles — recoded, low nibble first, records of odd
+    length followed by the next record's first base in the same byte — equal the host packer over the host decoder's SEQ."""
+    from mapdamage_amd.engine import SEQ_4BIT, DamageEngine, pack_seq
+    ref, b, rg, path = _write(tmp_path, frac_n_base=0.03)
+    hb = sam.read_bam_native(str(path)).batch
+    assert (hb.seq == ord("N")).any()
+    assert (np.diff(hb.seq_off.astype(np.int64)) & 1).any()          # records of odd length among them
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        with sam.GpuBamStream(eng, str(path), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)], chunk_bytes=chunk) as g:
+            assert g.packed
+            at = 0
+            while True:
+                v = g.next_view()
+                if v is None:
+                    break
+                eng.sync()
+                assert v.seq_format == SEQ_4BIT
+                k, nb = int(v.n_reads), int(v.n_bases)
+                so = _d2h(v.seq_off, k + 1, np.uint32)
+                s0 = int(hb.seq_off[at])
+                np.testing.assert_array_equal(so, hb.seq_off[at:at + k + 1] - np.uint32(s0))
+                got = _d2h(v.seq, (nb + 1) // 2, np.uint8)
+                np.testing.assert_array_equal(got, pack_seq(hb.seq[s0:s0 + nb]))
+                at += k
+            assert at == hb.n
+
+
 def test_tables_from_device_decode_equal_oracle(tmp_path):
     from mapdamage_amd.engine import DamageEngine
     from oracle import oracle

@@ -39,6 +39,10 @@ def run_engine(ref, batch, libraries, length, around, minqual=0, lgd_max=65536, 
                 dev.free()
             else:
                 eng.tabulate(part)
+        # the packed kernel is what runs for a 4-bit column in a plain tabulation (one launch per library), and only then
+        plain = eng.table_mode == "lds" and length + around <= 248 and not (minqual > 0 and batch.qual is not None)
+        want = splits * len(libraries) if (DamageEngine.default_packed and plain and batch.n) else 0
+        assert eng.packed_launches() == want
         return eng.finish()
 
 

@@ -21,8 +21,10 @@ def main():
     ap.add_argument("--fuzz", type=int, default=0)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--length", type=int, default=70)
+    ap.add_argument("--packed", action="store_true", help="resident SEQ columns in their 4-bit form (the packed kernel)")
     args = ap.parse_args()
     only = [v for v in args.variants.split("|") if v]
+    engine.DamageEngine.default_packed = args.packed
     ref = synth.make_genome()
     batches = {name: synth.parallel_batch(dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw), ref, args.reads, 3, workers=64)
                for name, kw in VARIANTS if name in only}
