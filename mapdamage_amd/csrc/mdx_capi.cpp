@@ -529,7 +529,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.lists = (uint4 *)c->lists.p;
             if (packed) {
                 a.ev_ovf_cap = mdx_pk_ovf_cap(a.dims);
-                HIP_TRY(c, c->ev_ovf.reserve((size_t)nwaves * (size_t)a.ev_ovf_cap * 4));
+                HIP_TRY(c, c->ev_ovf.reserve((size_t)nwaves * (size_t)a.ev_ovf_cap * 12));
                 a.ev_ovf = (uint32_t *)c->ev_ovf.p;
             }
         }

@@ -175,16 +175,16 @@ struct MdxTabArgs {
     // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
     uint32_t *tile_ctr;
     int tile_quota;
-    // Packed kernel: events (one per nibble, 4 bytes) beyond the wavefront's queue in the LDS go to its stretch of this
-    // list: ev_ovf_cap entries per wavefront, enough for every nibble of a run's steps (a tile over an assembly gap)
+    // Packed kernel: the events (12 bytes, three words) beyond the wavefront's queue in the LDS go to its stretch of this
+    // list: ev_ovf_cap events per wavefront, enough for every lane of a run's steps (a tile over an assembly gap)
     uint32_t *ev_ovf;
     int64_t ev_ovf_cap;
 };
-// nibble events of the packed kernel a wavefront's LDS queue holds (the event queue area: EVQ_BYTES of mdx_kernels.hip)
-#define MDX_PK_QCAP 320
+// events of the packed kernel a wavefront's LDS queue holds (the event queue area: EVQ_BYTES of mdx_kernels.hip)
+#define MDX_PK_QCAP 104
 static inline int64_t mdx_pk_ovf_cap(const MdxDims &d) {
     const int steps = d.R > 0 ? (64 + d.R - 1) / d.R + 1 : 0;
-    return (int64_t)512 * steps + 512;
+    return (int64_t)64 * steps + 128;
 }
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };

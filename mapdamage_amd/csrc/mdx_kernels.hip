@@ -421,6 +421,21 @@ __device__ __forceinline__ void bs_ripple(u32 (&p)[8], u32 c) {
         c = t;
     }
 }
+// the words of a group of N steps into one set of planes: (x0, x1) -> plane 0 and a carry, (x2, x3) -> plane 0 and another,
+// the two carries -> plane 1 and one of weight 4, which ripples upwards
+template <int N>
+__device__ __forceinline__ void bs_add_group(u32 (&pl)[8], const u32 (&x)[4]) {
+    if (N == 1) bs_ripple<0>(pl, x[0]);
+    else if (N == 2) { u32 c; bs_csa(pl[0], x[0], x[1], c); bs_ripple<1>(pl, c); }
+    else {
+        u32 c0, c1, c2;
+        bs_csa(pl[0], x[0], x[1], c0);
+        if (N == 3) { c1 = pl[0] & x[2]; pl[0] ^= x[2]; }
+        else bs_csa(pl[0], x[2], x[3], c1);
+        bs_csa(pl[1], c0, c1, c2);
+        bs_ripple<2>(pl, c2);
+    }
+}
 // N words of weight 1 into the planes (N a compile-time count of 1..4)
 template <int N>
 __device__ __forceinline__ void bs_add(u32 (&p)[8], const u32 (&x)[4]) {
@@ -620,17 +635,18 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     u32x2 *const qR = qS + EVQ_CAP;
     u32 *const qW = (u32 *)(qR + EVQ_CAP);
     int qcount = 0;
-    // PK: an event is one nibble that is not a plain match, four bytes: [3:0] read code | [7:4] reference code | [10:8] the
-    // lane's nibble | [16:11] lane | [17] reverse strand | [18] single-deletion entry, then [21:19] = deleted bases g and
-    // [25:22] = first nibble of the lane behind the deletion (right side: the nibbles below it).  MDX_PK_QCAP of them in
-    // the same area; what a run raises beyond that goes to the wavefront's stretch of MdxTabArgs::ev_ovf.  Nothing is
+    // PK: an event is a lane with a nibble that is not a plain match, three words: the lane's read nibbles, its reference
+    // nibbles, and [5:0] lane | [6] reverse strand | [7] single-deletion entry, then [10:8] = deleted bases g and [14:11] =
+    // first nibble of the lane behind the deletion (right side: the nibbles below it).  S[QCAP] | R[QCAP] | W[QCAP] in the
+    // same area; what a run raises beyond MDX_PK_QCAP goes to the wavefront's stretch of MdxTabArgs::ev_ovf.  Nothing is
     // drained inside a run: the drain's registers would be the hot loop's.
     u32 *const qE = (u32 *)qS;
-    u32 *const ev_ovf_w = PK ? a.ev_ovf + (size_t)gwave * (size_t)a.ev_ovf_cap : nullptr;
+    static_assert(!PK || MDX_PK_QCAP * 12 <= EVQ_BYTES, "the LDS event queue");
+    u32 *const ev_ovf_w = PK ? a.ev_ovf + (size_t)gwave * (size_t)a.ev_ovf_cap * 3 : nullptr;
     static_assert(!PK || MDX_PK_QCAP * 4 <= EVQ_BYTES, "the LDS event queue");
     // PK: the bit-sliced counters of this lane's eight window nibbles (bit 4 j + k of plane i = bit i of the count of
-    // base k at nibble j) — all records, and the reverse-strand ones — and the steps added since they were last folded
-    // into TC (at most 255: eight planes)
+    // base k at nibble j) — forward-strand records, and reverse-strand ones — and the steps added since they were last
+    // folded into TC (at most 255: eight planes)
     u32 bsT[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, bsM[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int bs_steps = 0;
     // fold the planes into TC[strand][base][64 j + lane] of the launch's library (the ASCII kernel's table, which the
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 for (int q = 0; q < 4; q++) {
                     const int b = sft + 8 * q, j = b >> 2, k = b & 3;
                     const u32 t = (accT >> (8 * q)) & 0xFFu, m = (accM >> (8 * q)) & 0xFFu;
-                    atomicAdd(&tcp[k * 512 + 64 * j], t - m);
+                    atomicAdd(&tcp[k * 512 + 64 * j], t);
                     atomicAdd(&tcp[(4 + k) * 512 + 64 * j], m);
                 }
             }
@@ -776,7 +792,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     };
     auto drain_all = [&]() {
         if (PK) {
-            // the packed kernel's events: one nibble each, 64 at a time; only a nibble that holds a base was counted
+            // the packed kernel's events, 64 lanes' worth at a time; only a nibble that holds a base was counted
             const int n = qcount;
             const u32 *const ovf = ev_ovf_w;
             if (n > MDX_PK_QCAP) {
@@ -788,35 +804,46 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             for (int base = 0; base < n; base += 64) {
                 const int i = base + lane;
                 if (i < n) {
-                    const u32 w = i < MDX_PK_QCAP ? qE[i] : ovf[i - MDX_PK_QCAP];
-                    const int sc = cls4(w & 15u), rc = cls4((w >> 4) & 15u);
-                    const int jb = (int)(w >> 8) & 7, ln = (int)(w >> 11) & 63, rev = (int)(w >> 17) & 1;
-                    const bool del = (w >> 18) & 1u;
-                    const int g = del ? (int)(w >> 19) & 7 : 0, bnd = (int)(w >> 22) & 15;
+                    u32 s8, r8, w;
+                    if (i < MDX_PK_QCAP) { s8 = qE[i]; r8 = qE[MDX_PK_QCAP + i]; w = qE[2 * MDX_PK_QCAP + i]; }
+                    else { const u32 *e = ovf + 3 * (size_t)(i - MDX_PK_QCAP); s8 = e[0]; r8 = e[1]; w = e[2]; }
+                    const int ln = (int)w & 63, rev = (int)(w >> 6) & 1;
+                    const bool del = (w >> 7) & 1u;
+                    const int g = del ? (int)(w >> 8) & 7 : 0, bnd = (int)(w >> 11) & 15;
                     int ll = ln;  // lane within its slot (R <= 4)
                     if (ll >= d.G) ll -= d.G;
                     if (ll >= d.G) ll -= d.G;
                     if (ll >= d.G) ll -= d.G;
                     const int side = ll >= d.nl8;
                     const int m8 = 8 * (ll - side * d.nl8);
-                    const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
-                    // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
-                    // CMP[p - g] (its query index) instead of the lane's counters
-                    const bool direct = del && (side ? jb < bnd : jb >= bnd);
-                    const int pc = direct ? p - g : p;
-                    const int sp = (side ? L : 0) + p, spc = (side ? L : 0) + pc;
+                    u32 vm, em;
+                    lane_masks4(d, side, m8, vm, em);
+                    u32 x = (s8 ^ r8) & em;
                     const int b_mis = d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = d.off_cmp() + (rev ? 2 * L * 4 : 0);
-                    if (rc < 4) {
-                        if (direct) {
-                            atomicAdd(&lds[b_mis + __mul24(sp, 25) + rc], 0xFFFFFFFFu);
-                            atomicAdd(&lds[b_cmp + spc * 4 + rc], 0xFFFFFFFFu);
-                        } else {
-                            atomicAdd(&lds[d.off_tc() + rev * 2048 + (rc << 9) + 64 * jb + ln], 0xFFFFFFFFu);  // -1
+                    // usually exactly one nibble of the lane differs: the lowest one (all lanes busy), again while some
+                    // lane has another
+                    while (x) {
+                        const int sh = (__ffs((int)x) - 1) & ~3, jb = sh >> 2;
+                        x &= ~(15u << sh);
+                        const int sc = cls4((s8 >> sh) & 15u), rc = cls4((r8 >> sh) & 15u);
+                        const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
+                        // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
+                        // CMP[p - g] (its query index) instead of the lane's counters
+                        const bool direct = del && (side ? jb < bnd : jb >= bnd);
+                        const int pc = direct ? p - g : p;
+                        const int sp = (side ? L : 0) + p, spc = (side ? L : 0) + pc;
+                        if (rc < 4) {
+                            if (direct) {
+                                atomicAdd(&lds[b_mis + __mul24(sp, 25) + rc], 0xFFFFFFFFu);
+                                atomicAdd(&lds[b_cmp + spc * 4 + rc], 0xFFFFFFFFu);
+                            } else {
+                                atomicAdd(&lds[d.off_tc() + rev * 2048 + (rc << 9) + 64 * jb + ln], 0xFFFFFFFFu);  // -1
+                            }
                         }
+                        // what the column really is (rare_column): the read base, and a substitution / indel
+                        if (sc < 4) atomicAdd(&lds[b_cmp + spc * 4 + sc], 1u);
+                        if (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) atomicAdd(&lds[b_mis + __mul24(sp, 25) + mis_col(rc, sc)], 1u);
                     }
-                    // what the column really is (rare_column): the read base, and a substitution / indel
-                    if (sc < 4) atomicAdd(&lds[b_cmp + spc * 4 + sc], 1u);
-                    if (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) atomicAdd(&lds[b_mis + __mul24(sp, 25) + mis_col(rc, sc)], 1u);
                 }
             }
             qcount = 0;
@@ -1086,7 +1113,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     // ---- the fast path's runs (used by the tile loop for the complete records and, behind it, for the lists)
         const int R = d.R, G = d.G;
         // A run = the steps of the nrec staged records from entry e0 on, all of one kind (count())
-        auto run = [&](const int e0, const int nrec, auto kind_tag, auto qm_tag) {
+        // (n_plus >= 0 — PK, complete runs of the tile loop: the entries are sorted by strand, the first n_plus of them forward)
+        auto run = [&](const int e0, const int nrec, auto kind_tag, auto qm_tag, const int n_plus = -1) {
             constexpr int KIND = decltype(kind_tag)::value;
             constexpr bool QM = MASK && decltype(qm_tag)::value;
             const int nsteps = (nrec + R - 1) / R;
@@ -1096,7 +1124,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 if (bs_steps + nsteps > 255) bs_flush();
                 bs_steps += nsteps;
                 // (STEP_C keeps no record word per step in flight: with one library per launch the strand — bit 31 of sa — says it all)
-                struct St4 { u32x2 s, r; u32 sa, ra, pk, aux; int lim; bool valid; };
+                struct St4 { u32x2 s, r; u32 sa, ra, pk, aux; int lim, k; bool valid; };
                 auto fill4 = [&](St4 &st) {
                     st.valid = kf < nsteps;
                     const int k = st.valid ? kf : nsteps - 1;
@@ -1139,14 +1167,16 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     // eight nibbles from bit 4 (offset & 7) of the aligned dword pair (v_alignbit_b32 looks at five bits of its
                     // shift operand; bit 31 of sa: the strand)
                     st.ra = ro << 2;
-                    st.sa = ((so << 2) & 0x7FFFFFFFu) | (ent.w & 0x80000000u);
+                    // (a run sorted by strand knows a step's strand from its place)
+                    st.sa = n_plus >= 0 ? so << 2 : ((so << 2) & 0x7FFFFFFFu) | (ent.w & 0x80000000u);
+                    st.k = k;
                     st.r = *(const u32x2 *)(refW + ((ro >> 1) & ~3u));
                     st.s = *(const u32x2 *)(seqW + ((so >> 1) & ~3u));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
                 };
                 // one step: X = the nibbles this step counts (one-hot codes: the increments themselves), Xm = those of
                 // reverse-strand records
-                auto count4 = [&](const St4 &st, auto full_tag, u32 &Xo, u32 &Mo) {
+                auto count4 = [&](const St4 &st, auto full_tag, u32 &Xo) {
                     constexpr bool FULL = decltype(full_tag)::value;
                     const bool act = FULL || lane < st.lim;
                     u32 s8 = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa);
@@ -1210,27 +1240,22 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                         }
                     }
                     Xo = X;
-                    Mo = (u32)((int)st.sa >> 31) & X;
                     u32 xx = (s8 ^ r8) & c_em_lo;
                     if (KIND == STEP_C && !FULL) xx = act ? xx : 0u;   // (the other kinds: no tasks in a slot without a record)
-                    if (__ballot(xx != 0u)) {
-                        // one event per nibble that is not a plain match (see qE): the lowest one of every lane that has one,
-                        // again while some lane has another.  Beyond the LDS queue: the wavefront's overflow list.
-                        u32 evb = ((u32)lane << 11) | ((st.sa >> 31) << 17);
-                        if (KIND == STEP_GD) evb |= 0x40000u | (((st.aux >> 24) & 0x7Fu) << 19);
-                        do {
-                            const bool on = xx != 0u;
-                            const u64 mm = __ballot(on);
-                            const u32 sh = on ? (u32)(__ffs((int)xx) - 1) & ~3u : 0u;
-                            const u32 evn = ((s8 >> sh) & 15u) | (((r8 >> sh) & 15u) << 4) | (sh << 6) | evb;
+                    const bool ev = xx != 0u;
+                    const u64 mm = __ballot(ev);
+                    if (mm) {
+                        // the lanes holding a nibble that is not a plain match queue their two dwords (see qE); beyond the LDS
+                        // queue: the wavefront's overflow list
+                        if (ev) {
+                            const u32 rev_ = n_plus >= 0 ? (st.k * R + c_slot >= n_plus ? 1u : 0u) : st.sa >> 31;
+                            u32 evw = (u32)lane | (rev_ << 6);
+                            if (KIND == STEP_GD) evw |= 0x80u | (((st.aux >> 24) & 0x7Fu) << 8);
                             const int slot = mbcnt64(mm, qcount);
-                            if (on) {
-                                if (slot < MDX_PK_QCAP) qE[slot] = evn;
-                                else ev_ovf_w[slot - MDX_PK_QCAP] = evn;
-                            }
-                            qcount += __popcll(mm);
-                            xx &= ~(15u << sh);
-                        } while (__ballot(xx != 0u));
+                            if (slot < MDX_PK_QCAP) { qE[slot] = s8; qE[MDX_PK_QCAP + slot] = r8; qE[2 * MDX_PK_QCAP + slot] = evw; }
+                            else { u32 *e = ev_ovf_w + 3 * (size_t)(slot - MDX_PK_QCAP); e[0] = s8; e[1] = r8; e[2] = evw; }
+                        }
+                        qcount += __popcll(mm);
                     }
                 };
                 constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : MDX_PK_PD);
@@ -1238,30 +1263,53 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 St4 st[PD4];
 #pragma unroll
                 for (int dd = 0; dd < PD4; dd++) fill4(st[dd]);
-                // the words of a group of PD4 steps go through carry-save adders as they come: (x0, x1) -> plane 0 and a carry,
-                // (x2, x3) -> plane 0 and another, the two carries -> plane 1 and one of weight 4, which ripples upwards
-                auto group = [&](auto full_tag, const bool refill) {
-                    u32 x[4] = {0u, 0u, 0u, 0u}, m[4] = {0u, 0u, 0u, 0u};
-                    u32 cT = 0u, cM = 0u;
+                // The words of a group of PD4 steps go through carry-save adders: (x0, x1) -> plane 0 and a carry, (x2, x3) ->
+                // plane 0 and another, the two carries -> plane 1 and one of weight 4, which ripples upwards.  A group of a run
+                // sorted by strand that lies in front of the first reverse-strand entry, or behind the last forward one, adds
+                // to one set of planes only; any other group splits every word by the strand of its lane's record.
+                int kc = 0;         // first step of the group
+                // MODE 0 / 1: every step of the group holds forward / reverse-strand records only (a run sorted by strand):
+                // one set of planes; 2: the words are split by the strand of each lane's record
+                auto group = [&](auto full_tag, auto mode_tag, const bool refill) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    u32 x[4] = {0u, 0u, 0u, 0u};
+                    u32 rv[4] = {0u, 0u, 0u, 0u};     // all ones in the lanes of reverse-strand records
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) {
-                        if (refill || dd == 0 || st[dd].valid) count4(st[dd], full_tag, x[dd], m[dd]);
+                        if (refill || dd == 0 || st[dd].valid) {
+                            count4(st[dd], full_tag, x[dd]);
+                            if (MODE == 2) rv[dd] = n_plus >= 0 ? (st[dd].k * R + c_slot >= n_plus ? ~0u : 0u) : (u32)((int)st[dd].sa >> 31);
+                        }
                         if (refill) fill4(st[dd]);
-                        if (dd == 1) { bs_csa(bsT[0], x[0], x[1], cT); bs_csa(bsM[0], m[0], m[1], cM); }
                     }
-                    if (PD4 == 1) { bs_ripple<0>(bsT, x[0]); bs_ripple<0>(bsM, m[0]); }
-                    else if (PD4 == 2) { bs_ripple<1>(bsT, cT); bs_ripple<1>(bsM, cM); }
+                    kc += PD4;
+                    if (MODE == 0) bs_add_group<PD4>(bsT, x);
+                    else if (MODE == 1) bs_add_group<PD4>(bsM, x);
                     else {
-                        u32 eT, eM;
-                        bs_csa(bsT[0], x[2], x[3], eT); bs_csa(bsM[0], m[2], m[3], eM);
-                        bs_csa(bsT[1], cT, eT, cT); bs_csa(bsM[1], cM, eM, cM);
-                        bs_ripple<2>(bsT, cT); bs_ripple<2>(bsM, cM);
+                        u32 xp[4], xm[4];
+#pragma unroll
+                        for (int dd = 0; dd < 4; dd++) { xm[dd] = x[dd] & rv[dd]; xp[dd] = x[dd] & ~rv[dd]; }
+                        bs_add_group<PD4>(bsT, xp);
+                        bs_add_group<PD4>(bsM, xm);
                     }
                 };
-                for (int k = PD4; k < nsteps; k += PD4) group(std::true_type{}, true);      // (never the last step of the run)
-                group(std::false_type{}, false);
+                typedef std::integral_constant<int, 0> M0;
+                typedef std::integral_constant<int, 1> M1;
+                typedef std::integral_constant<int, 2> M2;
+                // (three loops over the same pipeline, each with its planes fixed at compile time: the groups in front of the
+                // border between the strands, the one that holds it — every group of an unsorted run —, those behind it;
+                // never the last step of the run)
+                int k = PD4;
+                for (; k < nsteps && n_plus >= 0 && (kc + PD4) * R <= n_plus; k += PD4) group(std::true_type{}, M0{}, true);
+                for (; k < nsteps && (n_plus < 0 || kc * R < n_plus); k += PD4) group(std::true_type{}, M2{}, true);
+                for (; k < nsteps; k += PD4) group(std::true_type{}, M1{}, true);
+                // (the asm comments keep the ends of the three branches from being merged into one over pointers into the planes,
+                // which would send the planes to memory)
+                if (n_plus >= 0 && (kc + PD4) * R <= n_plus) { group(std::false_type{}, M0{}, false); asm volatile("; end of a forward run"); }
+                else if (n_plus < 0 || kc * R < n_plus) { group(std::false_type{}, M2{}, false); asm volatile("; end of a mixed run"); }
+                else { group(std::false_type{}, M1{}, false); asm volatile("; end of a reverse run"); }
                 // (the only place the packed kernel drains: behind a run, once a few passes' worth of events wait)
-                if (qcount >= MDX_PK_QCAP - 128) drain_all();
+                if (qcount >= 64) drain_all();
                 return;
             }
 #if MDX_ENT_AHEAD
@@ -1941,7 +1989,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         }
         for (;;) {
             const bool past = cur == 0xFFFFFFFFu;
-            int nF = 0, nF0 = 0;
+            int nF = 0, nF0 = 0, nFp = 0;
             u32 nxt2_raw = 0xFFFFFFFFu;
             if (!past) {
                 if (!RS || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
@@ -2181,8 +2229,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // counted by a run of their own that does not look at qualities — the unmasked step
                 const u64 mF0 = MASK ? __ballot(isF && !(ent.w & 0x40000000u)) : 0ull;
                 nF0 = MASK ? __popcll(mF0) : 0;
+                // PK: the complete records are staged by strand, the forward ones first: all steps of the run but the one that
+                // holds the border count into one set of planes
+                const u64 mFm = PK ? __ballot(isF && rev) : 0ull;
+                nFp = PK ? nF - __popcll(mFm) : 0;
                 if (mF) {
-                    if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
+                    if (PK) { if (isF) stg[rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0)] = ent; }
+                    else if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
                     // the slots past the last record of a step shadow a real record (and are masked out); a run of the
                     // clean records in front (MASK) reads its own last slots from the maskable records' entries
                     if (MASK || nF % R) {
@@ -2215,8 +2268,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // Bytes that are not plain matches are not handled here: they are appended as events to a
                 // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
                 // classification code runs once per 64 events instead of once per record.
+                if (PK) { if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp); }
+                else {
                 if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
                 if (nF - nF0) run(nF0, nF - nF0, std::integral_constant<int, STEP_C>{}, std::true_type{});
+                }
                 if (RS) {
                     // The run has drained its events.  One round trip for what is left of the tile's fused records: the
                     // qualities of their listed transitions (rsq_flush) and the reference bytes of the columns the left

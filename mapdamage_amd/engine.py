@@ -6,6 +6,7 @@ creates in mapdamage/main.py:147-155 and the loop body main.py:165-217 that feed
 """
 
 import ctypes
+import os
 import pathlib
 
 import numpy as np
@@ -202,7 +203,8 @@ class DamageEngine:
 
     # the form in which ``upload`` / ``tabulate`` hand a host batch's SEQ column over when the caller does not say
     # (False: ASCII as it stands, True: packed to 4 bits first); the tests run every parity case through both
-    default_packed = False
+    # (MDX_SEQ_4BIT=1 in the environment: packed, for the profiling scripts under tools/)
+    default_packed = os.environ.get("MDX_SEQ_4BIT", "") == "1"
 
     def __init__(self, libraries, length=70, around=10, minqual=0, lgd_max=65536, device=0,
                  lgd_over_cap=1 << 20):
