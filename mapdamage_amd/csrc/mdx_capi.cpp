@@ -258,7 +258,7 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
         c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
         HIP_TRY(c, mdx_k_prepare(c->lds_bytes));
         // (the packed kernel counts one library per launch)
-        HIP_TRY(c, mdx_k_prepare_packed(mdx_k_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds))));
+        HIP_TRY(c, mdx_k_prepare_packed(mdx_k_pk_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds))));
         HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * gdims.w_total * 4));
     } else {
         c->mode = MDX_MODE_GLOBAL;  // tables do not fit the LDS: global-atomic fallback
@@ -467,7 +467,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     a.n_bases = b->n_bases;
     a.ref32 = ref32 ? 1 : 0;
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
-    const int wpb = mdx_k_block_threads() / 64;
+    const int wpb = (packed ? mdx_k_pk_block_threads() : mdx_k_block_threads()) / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;
     const int64_t want = (ntiles + wpb - 1) / wpb;
     if (b->n_reads >= (int64_t)1 << 30) return fail(c, MDX_ERR_ARG, "batch of 2^30 records or more; split it");
@@ -485,14 +485,15 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.dims = gn == c->cfg.nlib ? c->dims : mdx_make_dims(c->cfg.length, c->cfg.around, gn, c->cfg.lgd_max, c->dims.lgd_lds);
             a.raw = c->d_raw + (size_t)lo * c->dims.w_lib;
             a.lgd_dense = c->d_lgd_dense + (size_t)lo * 4 * c->cfg.lgd_max;
-            lds = mdx_k_lds_bytes(a.dims);
+            lds = packed ? mdx_k_pk_lds_bytes(a.dims) : mdx_k_lds_bytes(a.dims);
             int per_cu = (int)(kLdsLimit / lds);
-            const int by_threads = 2048 / mdx_k_block_threads();
+            // (the packed kernel: two blocks per CU at most — its registers)
+            const int by_threads = packed ? mdx_k_pk_blocks_per_cu() : 2048 / mdx_k_block_threads();
             if (per_cu > by_threads) per_cu = by_threads;
             max_grid = c->n_cu * per_cu;
         }
         a.stage_off = mdx_k_stage_off(a.dims);
-        a.queue_off = mdx_k_queue_off(a.dims);
+        a.queue_off = packed ? mdx_k_pk_queue_off(a.dims) : mdx_k_queue_off(a.dims);
         int grid = (int)(want < max_grid ? want : max_grid);
         int wpb_l = wpb;
         if (fuse) {
@@ -529,7 +530,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.lists = (uint4 *)c->lists.p;
             if (packed) {
                 a.ev_ovf_cap = mdx_pk_ovf_cap(a.dims);
-                HIP_TRY(c, c->ev_ovf.reserve((size_t)nwaves * (size_t)a.ev_ovf_cap * 12));
+                HIP_TRY(c, c->ev_ovf.reserve((size_t)nwaves * (size_t)a.ev_ovf_cap * 20));
                 a.ev_ovf = (uint32_t *)c->ev_ovf.p;
             }
         }

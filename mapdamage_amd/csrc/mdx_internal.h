@@ -41,6 +41,12 @@ struct MdxDims {
     int L, A, nlib, lgd_max, lgd_lds;
     int nl8;              // 8-byte lanes per side (0: no fast path)
     int G, R;             // lanes per record, records per wavefront step
+    // The packed kernel's own geometry (tabulate_kernel<.., PK>): a lane owns sixteen consecutive window bases — eight bytes of
+    // 4-bit codes —, a record takes G4 = 2 nl16 lanes, and the slots of a step are tied to a strand: slots [0, H4) take
+    // forward-strand records, [H4, 2 H4) reverse-strand ones, so that a lane's counters belong to one strand.  Its TC
+    // table in the LDS is [base 4][16 j + ... : 64 j + lane], the same 4096 words; the block's partial slot receives it in
+    // the layout above (slot 0), so nothing downstream knows.
+    int nl16, G4, H4;
     int t_pad;            // words per TC plane: 512 with the fast path
     int w_mis, w_cmp, w_mc, w_tc, w_dmp, w_lgd, w_lib;
     int64_t w_total;      // nlib * w_lib + 1
@@ -88,6 +94,10 @@ static inline MdxDims mdx_make_dims(int L, int A, int nlib, int lgd_max, int lgd
     d.nl8 = (L + A + 7) / 8;
     d.G = 2 * d.nl8;
     d.t_pad = 512;
+    d.nl16 = (L + A + 15) / 16;
+    d.G4 = 2 * d.nl16;
+    d.H4 = d.G4 > 0 ? 32 / d.G4 : 0;
+    if (d.H4 > 3) d.H4 = 3;
     if (d.G > 64 || L + A > 248) {  // no fast path
         d.nl8 = 0; d.G = 0; d.R = 0;
         d.t_pad = ((2 * A + 63) / 64) * 64;
@@ -175,15 +185,16 @@ struct MdxTabArgs {
     // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
     uint32_t *tile_ctr;
     int tile_quota;
-    // Packed kernel: the events (12 bytes, three words) beyond the wavefront's queue in the LDS go to its stretch of this
+    // Packed kernel: the events (20 bytes, five words) beyond the wavefront's queue in the LDS go to its stretch of this
     // list: ev_ovf_cap events per wavefront, enough for every lane of a run's steps (a tile over an assembly gap)
     uint32_t *ev_ovf;
     int64_t ev_ovf_cap;
 };
 // events of the packed kernel a wavefront's LDS queue holds (the event queue area: EVQ_BYTES of mdx_kernels.hip)
-#define MDX_PK_QCAP 104
+#define MDX_PK_QCAP 64
 static inline int64_t mdx_pk_ovf_cap(const MdxDims &d) {
-    const int steps = d.R > 0 ? (64 + d.R - 1) / d.R + 1 : 0;
+    // (a run of 64 entries of one strand: 64 / H4 steps, every lane of every step)
+    const int steps = d.H4 > 0 ? (64 + d.H4 - 1) / d.H4 + 1 : 0;
     return (int64_t)64 * steps + 128;
 }
 
@@ -207,6 +218,11 @@ void mdx_k_encode_ref4(const uint8_t *d_codes, uint8_t *d_ref4, int64_t n, hipSt
 // SEQ columns between the two forms of mdx_batch::seq (n bases; the packed column holds (n + 1) / 2 bytes)
 void mdx_k_pack_seq(const uint8_t *d_ascii, uint8_t *d_packed, int64_t n, hipStream_t s);
 void mdx_k_unpack_seq(const uint8_t *d_packed, uint8_t *d_ascii, int64_t n, hipStream_t s);
+// the packed kernel's own block size and LDS image (queue offset, bytes; the staging offset is mdx_k_stage_off)
+int mdx_k_pk_block_threads();
+int mdx_k_pk_blocks_per_cu();     // by its registers
+int mdx_k_pk_queue_off(const MdxDims &d);
+size_t mdx_k_pk_lds_bytes(const MdxDims &d);
 hipError_t mdx_k_prepare_packed(size_t lds_bytes);
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);

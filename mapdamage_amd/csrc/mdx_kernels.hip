@@ -114,8 +114,11 @@ typedef long long i64;
 #ifndef MDX_QPREFETCH
 #define MDX_QPREFETCH 1                 // MASK: the quality windows requested with the other two, PIPE_DEPTH steps ahead
 #endif
+#ifndef MDX_PK_PREFETCH
+#define MDX_PK_PREFETCH 0               // the packed kernel requests a tile's phase-1 loads a tile ahead (measured: no gain; 26 registers)
+#endif
 #ifndef MDX_PK_PD
-#define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
+#define MDX_PK_PD 3                     // ... and of the packed kernel's complete runs
 #endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
@@ -150,8 +153,8 @@ int mdx_k_block_threads() { return MDX_BLOCK; }
 // LDS image: [tables w_total words, padded to 16 B][staging, 12 x mdx_stage_entries x 16 B][event queues, 12 x EVQ_BYTES]
 int mdx_k_stage_off(const MdxDims &d) { return (int)((d.w_total + 3) / 4 * 4); }
 int mdx_k_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_BLOCK / 64) * mdx_stage_entries(d) * 4; }
-// ... [byte-mask table: 9 x u64, entry n = the low n bytes set]
-#define LT_BYTES 72
+// ... [byte-mask table: 9 x u64, entry n = the low n bytes set; PK: 17 x u64, entry n = the low n nibbles set]
+#define LT_BYTES 136
 size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4 + (size_t)(MDX_BLOCK / 64) * EVQ_BYTES + LT_BYTES; }
 // The fused tabulate + rescale kernel (tabulate_kernel<.., RS>): one block of 1024 threads per CU — 16 wavefronts with
 // 128 registers each instead of 24 with 80 (measured with the plain kernel: +3 % on config 3) — because its image does
@@ -167,6 +170,19 @@ size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4
 #define MDX_FUSE_RSQ 192                // per wavefront: transitions of fused records waiting for their qualities (8 bytes each)
 #define MDX_FUSE_MRM 72                 // per wavefront: one 64-bit word per staging entry (the MR terms of its record)
 int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
+// The packed kernel (tabulate_kernel<.., PK>): two blocks of 512 threads per CU — 16 wavefronts with 128 registers each: its
+// sixteen-base lanes need half the instructions per record and half the wavefronts to keep the units busy, and its bit-sliced
+// counters want the registers (at 80 the hot loop spills)
+#ifndef MDX_PK_BLOCK
+#define MDX_PK_BLOCK 512
+#endif
+#ifndef MDX_PK_WPS
+#define MDX_PK_WPS 4
+#endif
+int mdx_k_pk_block_threads() { return MDX_PK_BLOCK; }
+int mdx_k_pk_blocks_per_cu() { return MDX_PK_WPS * 256 / MDX_PK_BLOCK; }
+int mdx_k_pk_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_PK_BLOCK / 64) * mdx_stage_entries(d) * 4; }
+size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * EVQ_BYTES + LT_BYTES; }
 int mdx_k_fuse_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_FUSE_BLOCK / 64) * mdx_stage_entries(d) * 4; }
 int mdx_k_fuse_tcb_off(const MdxDims &d) {
     const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * EVQ_BYTES + LT_BYTES;
@@ -373,36 +389,42 @@ __device__ __forceinline__ T ld32(const T *base, u32 idx) {
 // ---------------------------------------------------------------------------------------------------------------
 // The packed form (tabulate_kernel<.., PK>): SEQ and the resident reference as 4-bit codes (MDX_SEQ_4BIT, include/mdx.h:
 // 1 = A, 2 = C, 4 = T, 8 = G — bit k = symbol class k — and 0 for anything else; 15 = the gap symbol, in registers and
-// events only), two bases per byte, low nibble first.  A lane still owns eight consecutive bases of a record's window —
-// one dword now: an aligned dwordx2 load and one v_alignbit_b32 per operand — and the geometry (MdxDims) is the ASCII
-// kernel's.  What changes is the counting: a code is one-hot, so the eight reference nibbles of a lane *are* the 32
-// increments of its step — bit 4 j + k set: base k at the lane's byte j — and they are added into bit-sliced counters
-// held in registers (eight planes: bit b of plane i = bit i of counter b; two sets, all records and reverse-strand
-// ones), three steps' worth with two v_bitop3_b32 per carry-save adder.  No LDS update per plain match; the planes are
-// folded into TC (same table, same indices) every 255 steps at most.  A nibble that is not a task is zeroed and counts
-// nothing (no DMP correction), an event undoes the count of its reference nibble in TC like the ASCII kernel's.
+// events only), two bases per byte, low nibble first.  A lane owns SIXTEEN consecutive bases of a record's window — two
+// dwords: an aligned dwordx3 load and two v_alignbit_b32 per operand — so a record takes G4 = 2 ceil((A + L) / 16) lanes
+// (10 at the defaults) and a step counts six records with the vector-memory instructions that count three in the ASCII
+// kernel (every such instruction costs the texture addresser its 16+ cycles whatever it loads).  What changes most is the
+// counting: a code is one-hot, so the sixteen reference nibbles of a lane *are* the 64 increments of its step — bit
+// 4 j + k set: base k at the lane's nibble j — and they are added into bit-sliced counters held in registers (eight
+// planes of two dwords: bit b of plane i = bit i of counter b), four steps' worth with two v_bitop3_b32 per carry-save
+// adder.  The slots of a step are tied to a strand — [0, H4) forward records, [H4, 2 H4) reverse ones; the entries of a
+// run are sorted by strand — so one set of planes does.  No LDS update per plain match; the planes are folded into the
+// block's TC table ([base][64 j + lane]) every 255 steps at most, and the table reaches the block's partial slot in the
+// ASCII kernel's layout.  A nibble that is not a task is zeroed and counts nothing (no DMP correction); an event undoes
+// the count of its reference nibble in TC like the ASCII kernel's.  Events are queued per half lane (one dword of each
+// string); nothing is drained inside a run — what does not fit the LDS queue goes to the wavefront's overflow list.
 #define SYM4_GAP 15u
 // 4-bit code -> symbol class (A, C, T, G = 0..3; '-' = 4; anything else 5)
 __device__ __forceinline__ int cls4(u32 nib) {
     const bool one = nib != 0u && (nib & (nib - 1u)) == 0u;
     return one ? __ffs((int)nib) - 1 : (nib == SYM4_GAP ? SYM_GAP : SYM_OTHER);
 }
-// nibbles [lo, hi) of a dword, the range clamped to [0, 8)
-__device__ __forceinline__ u32 nibble_range(int lo, int hi) {
+// nibbles [lo, hi) of a 64-bit word, the range clamped to [0, 16)
+__device__ __forceinline__ u64 nibble_range16(int lo, int hi) {
     lo = lo < 0 ? 0 : lo;
-    hi = hi > 8 ? 8 : hi;
-    if (hi <= lo) return 0u;
-    const u32 upto = hi >= 8 ? ~0u : ((1u << (4 * hi)) - 1u);
-    return upto & ~((1u << (4 * lo)) - 1u);
+    hi = hi > 16 ? 16 : hi;
+    if (hi <= lo) return 0ull;
+    const u64 upto = hi >= 16 ? ~0ull : ((1ull << (4 * hi)) - 1ull);
+    return upto & ~((1ull << (4 * lo)) - 1ull);
 }
-// lane_masks for nibbles: vm = the nibble is a task of a complete record, em = it is a read column
-__device__ __forceinline__ void lane_masks4(const MdxDims &d, int side, int m8, u32 &vm, u32 &em) {
+// lane_masks for the packed kernel's lanes of sixteen nibbles (side, first window nibble m16): vm = the nibble is a task of
+// a complete record, em = it is a read column
+__device__ __forceinline__ void lane_masks16(const MdxDims &d, int side, int m16, u64 &vm, u64 &em) {
     if (!side) {
-        vm = nibble_range(0, d.A + d.L - m8);
-        em = vm & nibble_range(d.A - m8, 8);
+        vm = nibble_range16(0, d.A + d.L - m16);
+        em = vm & nibble_range16(d.A - m16, 16);
     } else {
-        vm = nibble_range(m8 + 8 - d.A - d.L, 8);
-        em = vm & nibble_range(0, m8 + 8 - d.A);
+        vm = nibble_range16(m16 + 16 - d.A - d.L, 16);
+        em = vm & nibble_range16(0, m16 + 16 - d.A);
     }
 }
 // carry-save adder over 32 one-bit columns: p + a + b = p' + 2 c
@@ -436,30 +458,6 @@ __device__ __forceinline__ void bs_add_group(u32 (&pl)[8], const u32 (&x)[4]) {
         bs_ripple<2>(pl, c2);
     }
 }
-// N words of weight 1 into the planes (N a compile-time count of 1..4)
-template <int N>
-__device__ __forceinline__ void bs_add(u32 (&p)[8], const u32 (&x)[4]) {
-    if (N == 1) bs_ripple<0>(p, x[0]);
-    else if (N == 2) { u32 c; bs_csa(p[0], x[0], x[1], c); bs_ripple<1>(p, c); }
-    else if (N == 3) { u32 c, e; bs_csa(p[0], x[0], x[1], c); e = p[0] & x[2]; p[0] ^= x[2]; bs_csa(p[1], c, e, c); bs_ripple<2>(p, c); }
-    else { u32 c0, c1, c2; bs_csa(p[0], x[0], x[1], c0); bs_csa(p[0], x[2], x[3], c1); bs_csa(p[1], c0, c1, c2); bs_ripple<2>(p, c2); }
-}
-// Eight optimistic increments by position of the packed kernel's single-deletion steps: word (base_bytes / 4) +
-// (STRIDE / 4) j + class of the reference nibble at position j of the lane (rising positions: nibble j on the left
-// side, nibble 7 - j on the right side), for the nibbles of the mask that hold a base
-template <int STRIDE>
-__device__ __forceinline__ void direct8n(u32 *lds, u32 r8, u32 base_bytes, u32 m8, bool reversed) {
-    u32 *const row = lds + (base_bytes >> 2);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int sh = 4 * (reversed ? 7 - j : j);
-        const u32 nib = (r8 >> sh) & 15u;
-        const bool on = ((m8 >> sh) & 1u) && nib != 0u && (nib & (nib - 1u)) == 0u;
-        const u32 k = on ? (u32)(__ffs((int)nib) - 1) : 0u;
-        atomicAdd(&row[j * (STRIDE / 4) + k], on ? 1u : 0u);
-    }
-}
-
 // resident reference bytes (encode_ref_kernel's, guard bands included) -> 4-bit codes, eight bases per thread and step
 __device__ __forceinline__ u32 code4_of_ref(u32 b) {
     // 'A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47: class (b >> 1) & 3; 0x84 / 0x85: nothing
@@ -518,10 +516,10 @@ void mdx_k_unpack_seq(const u8 *d_packed, u8 *d_ascii, int64_t n, hipStream_t s)
 // RS: the fused tabulate + rescale launch (MdxFuse; mapdamage/rescale.py:195-365 for the records of the tile loop)
 // PK: the packed form — 4-bit SEQ and reference, bit-sliced counting (see above); one library per launch
 template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false>
-__global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS : MDX_WPS) void tabulate_kernel(MdxTabArgs a) {
+__global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK), RS ? MDX_FUSE_WPS : (PK ? MDX_PK_WPS : MDX_WPS)) void tabulate_kernel(MdxTabArgs a) {
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
     static_assert(!PK || (USE_LDS && FAST && !MASK && !RS), "the packed kernel is the plain fast LDS kernel");
-    constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : MDX_BLOCK;
+    constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK);
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
@@ -557,8 +555,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     if (USE_LDS) {
         for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) lds[i] = 0;
         if (FAST && !PK && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
-        // (PK: nine 32-bit masks, entry n = the low n nibbles set)
-        if (PK && threadIdx.x < 9) ((u32 *)ltab)[threadIdx.x] = threadIdx.x >= 8 ? ~0u : ((1u << (4 * threadIdx.x)) - 1u);
+        // (PK: seventeen 64-bit masks, entry n = the low n nibbles set)
+        if (PK && threadIdx.x < 17) ltab[threadIdx.x] = threadIdx.x >= 16 ? ~0ull : ((1ull << (4 * threadIdx.x)) - 1ull);
         if (RS) {
             for (int i = threadIdx.x; i < d.nlib * d.w_tc + 4; i += BLOCK) lds[a.rs.tcb_off + i] = 0;
             for (int i = threadIdx.x; i < 2 * rs_npos * 94; i += BLOCK) ((u8 *)(rs_cnt + 4))[i] = a.rs.lut[i];
@@ -592,7 +590,27 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     int c_slot = 0, c_side = 0, c_m8 = 0;
     u32 c_ro = 0, c_so = (u32)(-A), c_cm = 0;
     u32 c_vm_lo = 0, c_vm_hi = 0, c_em_lo = 0, c_em_hi = 0;  // em is a subset of vm
-    if (FAST) {
+    int p_strand = 0;      // PK: the strand of this lane's slot
+    u32 c_evw = 0;         // PK: the lane's part of an event word (see qE)
+    if (FAST && PK) {
+        // the packed kernel's lanes: slot g = lane / G4 — [0, H4) forward-strand records, [H4, 2 H4) reverse-strand ones —,
+        // within the slot lanes [0, nl16) are the left side, [nl16, 2 nl16) the right side; lane (side, m) owns sixteen bases
+        const int g = lane / d.G4, ll = lane - g * d.G4;
+        if (g < 2 * d.H4) {
+            p_strand = g >= d.H4;
+            c_slot = g - p_strand * d.H4;
+            c_side = ll >= d.nl16;
+            c_m8 = 16 * (ll - c_side * d.nl16);
+            if (c_side) { c_ro = (u32)(2 * A - 16 - c_m8); c_cm = 0x7FFFu; }
+            else c_ro = (u32)c_m8;
+            u64 vm, em;
+            lane_masks16(d, c_side, c_m8, vm, em);
+            c_vm_lo = (u32)vm; c_vm_hi = (u32)(vm >> 32);
+            c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
+        }
+        c_evw = (u32)lane | ((u32)c_side << 6) | ((u32)(c_m8 >> 4) << 7) | ((u32)p_strand << 11);
+    }
+    if (FAST && !PK) {
         const int g = lane / d.G, ll = lane - g * d.G;
         if (g < d.R) {
             c_slot = g;
@@ -603,15 +621,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             } else {
                 c_ro = (u32)c_m8; c_so = (u32)(c_m8 - A);
             }
-            if (PK) {
-                // (one dword of eight nibbles per lane: the masks live in the low halves)
-                lane_masks4(d, c_side, c_m8, c_vm_lo, c_em_lo);
-            } else {
-                u64 vm, em;
-                lane_masks(d, c_side, c_m8, vm, em);
-                c_vm_lo = (u32)vm; c_vm_hi = (u32)(vm >> 32);
-                c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
-            }
+            u64 vm, em;
+            lane_masks(d, c_side, c_m8, vm, em);
+            c_vm_lo = (u32)vm; c_vm_hi = (u32)(vm >> 32);
+            c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
         }
     }
     c_ro += ph_ref;   // the phases of the aligned-down bases
@@ -635,44 +648,42 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     u32x2 *const qR = qS + EVQ_CAP;
     u32 *const qW = (u32 *)(qR + EVQ_CAP);
     int qcount = 0;
-    // PK: an event is a lane with a nibble that is not a plain match, three words: the lane's read nibbles, its reference
-    // nibbles, and [5:0] lane | [6] reverse strand | [7] single-deletion entry, then [10:8] = deleted bases g and [14:11] =
-    // first nibble of the lane behind the deletion (right side: the nibbles below it).  S[QCAP] | R[QCAP] | W[QCAP] in the
-    // same area; what a run raises beyond MDX_PK_QCAP goes to the wavefront's stretch of MdxTabArgs::ev_ovf.  Nothing is
-    // drained inside a run: the drain's registers would be the hot loop's.
+    // PK: an event is a half lane (eight nibbles, one dword of each string) with a nibble that is not a plain match, three
+    // words: its read nibbles, its reference nibbles, and [5:0] lane | [6] side | [10:7] the lane's first window nibble / 16 |
+    // [11] reverse strand | [12] single-deletion entry, then [15:13] = deleted bases g and [20:16] = first nibble of the lane
+    // behind the deletion (right side: the nibbles below it) | [21] the lane's upper half.  S[QCAP] | R[QCAP] | W[QCAP] in the
+    // event area; what a run raises beyond MDX_PK_QCAP goes to the wavefront's stretch of MdxTabArgs::ev_ovf (qovf events).
+    // Nothing is drained inside a run: the drain's registers would be the hot loop's.
     u32 *const qE = (u32 *)qS;
     static_assert(!PK || MDX_PK_QCAP * 12 <= EVQ_BYTES, "the LDS event queue");
     u32 *const ev_ovf_w = PK ? a.ev_ovf + (size_t)gwave * (size_t)a.ev_ovf_cap * 3 : nullptr;
-    static_assert(!PK || MDX_PK_QCAP * 4 <= EVQ_BYTES, "the LDS event queue");
-    // PK: the bit-sliced counters of this lane's eight window nibbles (bit 4 j + k of plane i = bit i of the count of
-    // base k at nibble j) — forward-strand records, and reverse-strand ones — and the steps added since they were last
-    // folded into TC (at most 255: eight planes)
-    u32 bsT[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, bsM[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int qovf = 0;
+    // PK: the bit-sliced counters of this lane's sixteen window nibbles (bit 4 j + k of plane i, low / high dword = nibbles
+    // 0-7 / 8-15: bit i of the count of base k at nibble j; the lane's slot fixes the strand) and the steps added since they
+    // were last folded into TC (at most 255: eight planes)
+    u32 bsL[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, bsH[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int bs_steps = 0;
-    // fold the planes into TC[strand][base][64 j + lane] of the launch's library (the ASCII kernel's table, which the
-    // events' undo and finalize_kernel address): per bit position s of the bytes, the four counters of bits s, s + 8,
-    // s + 16, s + 24 are gathered as the bytes of one word
+    // fold the planes into the block's TC table, PK layout: word [base k][64 j + lane]; per bit position s of the bytes of
+    // a plane, the four counters of bits s, s + 8, s + 16, s + 24 are gathered as the bytes of one word
     auto bs_flush = [&]() {
         if (PK) {
             u32 *const tcp = lds + d.off_tc() + lane;
 #pragma unroll
-            for (int sft = 0; sft < 8; sft++) {
-                u32 accT = 0u, accM = 0u;
+            for (int half = 0; half < 2; half++) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    accT |= ((bsT[i] >> sft) & 0x01010101u) << i;
-                    accM |= ((bsM[i] >> sft) & 0x01010101u) << i;
-                }
+                for (int sft = 0; sft < 8; sft++) {
+                    u32 acc = 0u;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int b = sft + 8 * q, j = b >> 2, k = b & 3;
-                    const u32 t = (accT >> (8 * q)) & 0xFFu, m = (accM >> (8 * q)) & 0xFFu;
-                    atomicAdd(&tcp[k * 512 + 64 * j], t);
-                    atomicAdd(&tcp[(4 + k) * 512 + 64 * j], m);
+                    for (int i = 0; i < 8; i++) acc |= (((half ? bsH[i] : bsL[i]) >> sft) & 0x01010101u) << i;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int b = sft + 8 * q, j = 8 * half + (b >> 2), k = b & 3;
+                        atomicAdd(&tcp[k * 1024 + 64 * j], (acc >> (8 * q)) & 0xFFu);
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) { bsT[i] = 0u; bsM[i] = 0u; }
+            for (int i = 0; i < 8; i++) { bsL[i] = 0u; bsH[i] = 0u; }
             bs_steps = 0;
         }
     };
@@ -792,41 +803,32 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     };
     auto drain_all = [&]() {
         if (PK) {
-            // the packed kernel's events, 64 lanes' worth at a time; only a nibble that holds a base was counted
-            const int n = qcount;
+            // the packed kernel's events, 64 half lanes at a time; only a nibble that holds a base was counted
+            const int n = qcount, no = qovf;
             const u32 *const ovf = ev_ovf_w;
-            if (n > MDX_PK_QCAP) {
+            if (no) {
                 // (the wavefront's own stores to its overflow list: complete before they are read back)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
 #pragma unroll 1
-            for (int base = 0; base < n; base += 64) {
+            for (int base = 0; base < n + no; base += 64) {
                 const int i = base + lane;
-                if (i < n) {
+                if (i < n + no) {
                     u32 s8, r8, w;
-                    if (i < MDX_PK_QCAP) { s8 = qE[i]; r8 = qE[MDX_PK_QCAP + i]; w = qE[2 * MDX_PK_QCAP + i]; }
-                    else { const u32 *e = ovf + 3 * (size_t)(i - MDX_PK_QCAP); s8 = e[0]; r8 = e[1]; w = e[2]; }
-                    const int ln = (int)w & 63, rev = (int)(w >> 6) & 1;
-                    const bool del = (w >> 7) & 1u;
-                    const int g = del ? (int)(w >> 8) & 7 : 0, bnd = (int)(w >> 11) & 15;
-                    int ll = ln;  // lane within its slot (R <= 4)
-                    if (ll >= d.G) ll -= d.G;
-                    if (ll >= d.G) ll -= d.G;
-                    if (ll >= d.G) ll -= d.G;
-                    const int side = ll >= d.nl8;
-                    const int m8 = 8 * (ll - side * d.nl8);
-                    u32 vm, em;
-                    lane_masks4(d, side, m8, vm, em);
-                    u32 x = (s8 ^ r8) & em;
+                    if (i < n) { s8 = qE[i]; r8 = qE[MDX_PK_QCAP + i]; w = qE[2 * MDX_PK_QCAP + i]; }
+                    else { const u32 *e = ovf + 3u * (u32)(i - n); s8 = e[0]; r8 = e[1]; w = e[2]; }
+                    const int ln = (int)w & 63, side = (int)(w >> 6) & 1, m16 = (int)((w >> 7) & 15u) << 4, rev = (int)(w >> 11) & 1;
+                    const bool del = (w >> 12) & 1u;
+                    const int g = del ? (int)(w >> 13) & 7 : 0, bnd = (int)(w >> 16) & 31, half = (int)(w >> 21) & 1;
+                    u32 x = s8 ^ r8;        // (only read columns differ: the step has seen to it)
                     const int b_mis = d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = d.off_cmp() + (rev ? 2 * L * 4 : 0);
-                    // usually exactly one nibble of the lane differs: the lowest one (all lanes busy), again while some
-                    // lane has another
+                    // usually exactly one nibble differs: the lowest one (all lanes busy), again while some lane has another
                     while (x) {
-                        const int sh = (__ffs((int)x) - 1) & ~3, jb = sh >> 2;
+                        const int sh = (__ffs((int)x) - 1) & ~3, jb = 8 * half + (sh >> 2);
                         x &= ~(15u << sh);
                         const int sc = cls4((s8 >> sh) & 15u), rc = cls4((r8 >> sh) & 15u);
-                        const int p = (side ? m8 + 7 - jb : m8 + jb) - A;
+                        const int p = (side ? m16 + 15 - jb : m16 + jb) - A;
                         // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
                         // CMP[p - g] (its query index) instead of the lane's counters
                         const bool direct = del && (side ? jb < bnd : jb >= bnd);
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                                 atomicAdd(&lds[b_mis + __mul24(sp, 25) + rc], 0xFFFFFFFFu);
                                 atomicAdd(&lds[b_cmp + spc * 4 + rc], 0xFFFFFFFFu);
                             } else {
-                                atomicAdd(&lds[d.off_tc() + rev * 2048 + (rc << 9) + 64 * jb + ln], 0xFFFFFFFFu);  // -1
+                                atomicAdd(&lds[d.off_tc() + (rc << 10) + 64 * jb + ln], 0xFFFFFFFFu);  // -1
                             }
                         }
                         // what the column really is (rare_column): the read base, and a substitution / indel
@@ -846,6 +848,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     }
                 }
             }
+            qovf = 0;
             qcount = 0;
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             return;
@@ -1120,196 +1123,198 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             const int nsteps = (nrec + R - 1) / R;
             int kf = 0;
             if constexpr (PK) {
-                // ---- the packed kernel's run: same entries, same lanes, nibbles instead of bytes (see "The packed form")
-                if (bs_steps + nsteps > 255) bs_flush();
-                bs_steps += nsteps;
-                // (STEP_C keeps no record word per step in flight: with one library per launch the strand — bit 31 of sa — says it all)
-                struct St4 { u32x2 s, r; u32 sa, ra, pk, aux; int lim, k; bool valid; };
-                auto fill4 = [&](St4 &st) {
-                    st.valid = kf < nsteps;
-                    const int k = st.valid ? kf : nsteps - 1;
+                // ---- the packed kernel's run: the entries [e0, e0 + nrec) are sorted by strand, the first n_plus of them
+                // forward.  Step k takes the forward entries H k .. H k + H - 1 into its slots [0, H) and the reverse entries
+                // with the same numbers into [H, 2 H); a slot past its strand's last entry shadows entry e0 and is masked out.
+                const int H = d.H4;
+                const int nP_ = n_plus, nM_ = nrec - n_plus;
+                const int nsteps4 = ((nP_ > nM_ ? nP_ : nM_) + H - 1) / H;
+                const int nfull = (nP_ < nM_ ? nP_ : nM_) / H;       // steps in which every slot holds a record
+                if (bs_steps + nsteps4 > 255) bs_flush();
+                bs_steps += nsteps4;
+                const int base_l = e0 + (p_strand ? nP_ : 0) + c_slot, lim_l = (p_strand ? nM_ : nP_) - c_slot;
+                struct St16 { u32x3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
+                auto fill16 = [&](St16 &st) {
+                    st.valid = kf < nsteps4;
+                    const int k = st.valid ? kf : nsteps4 - 1;
                     kf++;
-                    int nv = nrec - k * R;
-                    nv = nv > R ? R : nv;
-                    st.lim = nv * G;
-                    const uint4 ent = stg[e0 + k * R + c_slot];
+                    // (the slot holds a record iff H k + slot < the entries of its strand)
+                    bool act = true;
+                    int idx = base_l + H * k;
+                    if (k >= nfull) {               // (wave-uniform: the last steps of a run only)
+                        act = H * k < lim_l;
+                        idx = act ? idx : e0;
+                    }
+                    st.k = k;
+                    const uint4 ent = stg[idx];
                     const u32 t = ent.z & c_cm;
                     u32 ro = ent.x + c_ro + t;
                     u32 so = ro + ent.y;
-                    st.aux = 0u;
+                    st.aux = 0u; st.aux2 = 0u;
                     if (KIND != STEP_C) {
                         const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
                         ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
                         const u32 z = ent.z;
                         const int nq_ = (int)(z & 0x7FFFu);
                         const int t8 = (int)((z >> (16 + 8 * c_side)) & 0xFFu);      // task nibbles / run length of this side
-                        const int jo = c_side ? c_m8 + 8 - A : A - c_m8, sgn = 1 - 2 * c_side;
-                        const bool act = lane < st.lim;
-                        auto c4 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 8 ? 8 : v)) << 2; };   // offset into the nibble-mask table
+                        // nibble of column k: jo + k on the left side, jo - 1 - k on the right side
+                        const int jo = c_side ? c_m8 + 16 - A : A - c_m8, sgn = 1 - 2 * c_side;
+                        auto c16 = [](int v) -> u32 { return (u32)(v < 0 ? 0 : (v > 16 ? 16 : v)) << 3; };   // offset into the nibble-mask table
                         if (KIND == STEP_P) {
+                            // the lane's tasks: its nibbles [0, t8 - m16) on the left side, [16 - (t8 - m16), 16) on the right
                             const int dm = t8 - c_m8;
-                            st.aux = act ? c4(c_side ? 8 - dm : dm) : (c_side ? 32u : 0u);
+                            st.aux = act ? c16(c_side ? 16 - dm : dm) : (c_side ? 128u : 0u);
                         } else {
+                            // one indel of g bases behind the first (left) / last (right) match run of t8 columns: the gap is
+                            // nibbles [ta, tb), the tasks end (left) / start (right) at nibble tl (see the ASCII kernel's fill)
                             const int dd = (int)(i8)(ent.w & 0xFFu);
                             const int g = KIND == STEP_GD ? dd : -dd;
                             const int ncol = KIND == STEP_GD ? nq_ + g : nq_;
                             const int Lm = ncol < L ? ncol : L;
                             const int ta = jo + sgn * t8 - (c_side ? g : 0), tb = ta + g;
-                            const int tl = act ? jo + sgn * Lm : (c_side ? 8 : 0);
-                            const bool blane = c_side ? tb >= 8 : ta <= 0;
+                            const int tl = act ? jo + sgn * Lm : (c_side ? 16 : 0);
+                            const bool blane = c_side ? tb >= 16 : ta <= 0;
                             const u32 off = blane ? (u32)(-sgn * g) : 0u;
                             if (KIND == STEP_GD) so += off; else ro += off;
                             const int bnd = c_side ? ta : tb;
-                            st.aux = c4(ta) | (c4(tb) << 7) | (c4(tl) << 14) | ((blane ? 0u : (u32)g) << 21) | ((u32)g << 24) |
-                                     ((c4(bnd) >> 2) << 27);
+                            st.aux = c16(ta) | (c16(tb) << 8) | (c16(tl) << 16) | ((blane ? 0u : (u32)g) << 24);
+                            st.aux2 = (u32)g | ((c16(bnd) >> 3) << 3);
                         }
                     }
-                    // eight nibbles from bit 4 (offset & 7) of the aligned dword pair (v_alignbit_b32 looks at five bits of its
-                    // shift operand; bit 31 of sa: the strand)
-                    st.ra = ro << 2;
-                    // (a run sorted by strand knows a step's strand from its place)
-                    st.sa = n_plus >= 0 ? so << 2 : ((so << 2) & 0x7FFFFFFFu) | (ent.w & 0x80000000u);
-                    st.k = k;
-                    st.r = *(const u32x2 *)(refW + ((ro >> 1) & ~3u));
-                    st.s = *(const u32x2 *)(seqW + ((so >> 1) & ~3u));
+                    // sixteen nibbles from bit 4 (offset & 7) of the aligned dword triple
+                    st.ra = ro << 2; st.sa = so << 2;
+                    st.r = *(const u32x3 *)(refW + ((ro >> 1) & ~3u));
+                    st.s = *(const u32x3 *)(seqW + ((so >> 1) & ~3u));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
                 };
-                // one step: X = the nibbles this step counts (one-hot codes: the increments themselves), Xm = those of
-                // reverse-strand records
-                auto count4 = [&](const St4 &st, auto full_tag, u32 &Xo) {
+                // one step: X = the nibbles this step counts (one-hot codes: the increments themselves)
+                auto count16 = [&](const St16 &st, auto full_tag, u32 &Xlo, u32 &Xhi) {
                     constexpr bool FULL = decltype(full_tag)::value;
-                    const bool act = FULL || lane < st.lim;
-                    u32 s8 = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa);
-                    u32 r8 = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra);
-                    u32 X;
+                    u32 s_lo = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa), s_hi = __builtin_amdgcn_alignbit(st.s.z, st.s.y, st.sa);
+                    u32 r_lo = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra), r_hi = __builtin_amdgcn_alignbit(st.r.z, st.r.y, st.ra);
+                    u32 evw = c_evw;
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
-                        X = act ? r8 : 0u;
+                        if (!FULL) {
+                            // (a slot past its strand's last entry: nothing counted, no event)
+                            const u32 actm = H * st.k < lim_l ? ~0u : 0u;
+                            r_lo &= actm; r_hi &= actm; s_lo &= actm; s_hi &= actm;
+                        }
+                        Xlo = r_lo; Xhi = r_hi;
                     } else {
                         const u32 aux = st.aux;
-                        const u32 sm = 0u - (u32)c_side;                         // all ones on the right side
-                        const u32 *const lt4 = (const u32 *)ltab;
+                        const u64 sm = c_side ? ~0ull : 0ull;                      // all ones on the right side
+                        const u64 vm64 = (u64)c_vm_lo | ((u64)c_vm_hi << 32);
+                        u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32), X64;
                         if (KIND == STEP_P) {
-                            const u32 Mk = *(const u32 *)((const u8 *)lt4 + aux);
-                            const u32 dyn = (Mk ^ sm) & c_vm_lo;
-                            s8 &= dyn; r8 &= dyn;
-                            X = r8;
+                            const u64 Mk = *(const u64 *)((const u8 *)ltab + aux);
+                            const u64 dyn = (Mk ^ sm) & vm64;
+                            s64 &= dyn; r64 &= dyn;
+                            X64 = r64;
                         } else {
-                            const u32 Xk = *(const u32 *)((const u8 *)lt4 + (aux & 0x7Fu)), Yk = *(const u32 *)((const u8 *)lt4 + ((aux >> 7) & 0x7Fu)),
-                                      Tk = *(const u32 *)((const u8 *)lt4 + ((aux >> 14) & 0x7Fu));
-                            const u32 dyn = (Tk ^ sm) & c_vm_lo;
+                            const u64 Xk = *(const u64 *)((const u8 *)ltab + (aux & 0xFFu)), Yk = *(const u64 *)((const u8 *)ltab + ((aux >> 8) & 0xFFu)),
+                                      Tk = *(const u64 *)((const u8 *)ltab + ((aux >> 16) & 0xFFu));
+                            const u64 dyn = (Tk ^ sm) & vm64;
                             // the string that carries the gap: its nibbles in front of the gap as loaded, the gap symbol,
                             // its nibbles behind the gap moved by g within the lane that straddles it
-                            const u32 shb = ((aux >> 21) & 7u) << 2, shr = shb & sm, shl = shb & ~sm;
-                            const u32 star = KIND == STEP_GD ? s8 : r8;
-                            const u32 low = star >> shr, high = star << shl;
-                            u32 m = (Xk & low) | ~Xk;                            // (the gap symbol: 15)
+                            const u32 shb = ((aux >> 24) & 7u) << 2, shr = c_side ? shb : 0u, shl = c_side ? 0u : shb;
+                            const u64 star = KIND == STEP_GD ? s64 : r64;
+                            const u64 low = star >> shr, high = star << shl;
+                            u64 m = (Xk & low) | ~Xk;                            // (the gap symbol: 15)
                             m = (Yk & m) | (~Yk & high);
                             if (KIND == STEP_GD) {
-                                s8 = m;
+                                s64 = m;
                                 // nibbles behind the deletion (left: from tb on, right: below ta): MIS[column][base] and
                                 // CMP[column - g][base] by position instead of the counters
-                                const u32 beh = (Xk & sm) | (~Yk & ~sm);
-                                const u32 dmk = dyn & beh;
-                                if (__ballot(dmk != 0u)) {
+                                const u64 beh = (Xk & sm) | (~Yk & ~sm);
+                                const u64 dmk = dyn & beh;
+                                evw |= 0x1000u | ((st.aux2 & 7u) << 13) | ((st.aux2 >> 3) << 16);
+                                if (__ballot(dmk != 0ull)) {
                                     // (a rolled loop, one nibble at a time in position order — nibble j on the left side,
-                                    // 7 - j on the right: these steps are rare, their registers are the kernel's)
-                                    const int g = (int)((aux >> 24) & 7u);
+                                    // 15 - j on the right: these steps are rare, their registers are the kernel's)
+                                    const int g = (int)(st.aux2 & 7u);
                                     const int rev = (int)(st.pk >> 31);
                                     const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
                                     u32 *pm = lds + d.off_mis() + __mul24(row, 25), *pc = lds + d.off_cmp() + (row - g) * 4;
-                                    u32 rr = c_side ? __builtin_bitreverse32(r8) : r8, dd = c_side ? __builtin_bitreverse32(dmk) : dmk;
+                                    u64 rr = c_side ? __builtin_bitreverse64(r64) : r64, dd = c_side ? __builtin_bitreverse64(dmk) : dmk;
 #pragma unroll 1
-                                    for (int j = 0; j < 8; j++) {
+                                    for (int j = 0; j < 16; j++) {
                                         // (right side: the bits of a nibble are reversed too — class k is bit 3 - k)
-                                        const u32 nib = rr & 15u;
-                                        const bool on = (dd & 15u) != 0u && nib != 0u && (nib & (nib - 1u)) == 0u;
+                                        const u32 nib = (u32)rr & 15u;
+                                        const bool on = ((u32)dd & 15u) != 0u && nib != 0u && (nib & (nib - 1u)) == 0u;
                                         const int k0 = __ffs((int)nib) - 1;
                                         const int k = on ? (c_side ? 3 - k0 : k0) : 0;
                                         if (on) { atomicAdd(pm + k, 1u); atomicAdd(pc + k, 1u); }
                                         rr >>= 4; dd >>= 4; pm += 25; pc += 4;
                                     }
                                 }
-                                s8 &= dyn; r8 &= dyn;
-                                X = r8 & ~beh;
+                                s64 &= dyn; r64 &= dyn;
+                                X64 = r64 & ~beh;
                             } else {
-                                r8 = m;
-                                s8 &= dyn; r8 &= dyn;
-                                X = r8 & (Xk | ~Yk);                             // (not the gap symbols)
+                                r64 = m;
+                                s64 &= dyn; r64 &= dyn;
+                                X64 = r64 & (Xk | ~Yk);                          // (not the gap symbols)
+                            }
+                        }
+                        s_lo = (u32)s64; s_hi = (u32)(s64 >> 32); r_lo = (u32)r64; r_hi = (u32)(r64 >> 32);
+                        Xlo = (u32)X64; Xhi = (u32)(X64 >> 32);
+                    }
+                    // the half lanes holding a nibble that is not a plain match queue their two dwords (see qE): a step's events
+                    // go to the LDS queue if they all fit, else to the wavefront's overflow list
+                    const u32 x_lo = (s_lo ^ r_lo) & c_em_lo, x_hi = (s_hi ^ r_hi) & c_em_hi;
+                    if (__ballot((x_lo | x_hi) != 0u)) {
+#pragma unroll
+                        for (int half = 0; half < 2; half++) {
+                            const bool ev = (half ? x_hi : x_lo) != 0u;
+                            const u64 mm = __ballot(ev);
+                            if (mm) {
+                                const int n = __popcll(mm);
+                                // (the read nibbles that are not read columns are queued as copies of the reference's: the drain
+                                // finds the columns that differ by an XOR, without the lane's masks)
+                                const u32 e_r = half ? r_hi : r_lo, e_m = half ? c_em_hi : c_em_lo;
+                                const u32 e_s = ((half ? s_hi : s_lo) & e_m) | (e_r & ~e_m), e_w = evw | ((u32)half << 21);
+                                if (qcount + n <= MDX_PK_QCAP) {
+                                    if (ev) { const int slot = mbcnt64(mm, qcount); qE[slot] = e_s; qE[MDX_PK_QCAP + slot] = e_r; qE[2 * MDX_PK_QCAP + slot] = e_w; }
+                                    qcount += n;
+                                } else {
+                                    if (ev) { u32 *e = ev_ovf_w + 3u * (u32)mbcnt64(mm, qovf); e[0] = e_s; e[1] = e_r; e[2] = e_w; }
+                                    qovf += n;
+                                }
                             }
                         }
                     }
-                    Xo = X;
-                    u32 xx = (s8 ^ r8) & c_em_lo;
-                    if (KIND == STEP_C && !FULL) xx = act ? xx : 0u;   // (the other kinds: no tasks in a slot without a record)
-                    const bool ev = xx != 0u;
-                    const u64 mm = __ballot(ev);
-                    if (mm) {
-                        // the lanes holding a nibble that is not a plain match queue their two dwords (see qE); beyond the LDS
-                        // queue: the wavefront's overflow list
-                        if (ev) {
-                            const u32 rev_ = n_plus >= 0 ? (st.k * R + c_slot >= n_plus ? 1u : 0u) : st.sa >> 31;
-                            u32 evw = (u32)lane | (rev_ << 6);
-                            if (KIND == STEP_GD) evw |= 0x80u | (((st.aux >> 24) & 0x7Fu) << 8);
-                            const int slot = mbcnt64(mm, qcount);
-                            if (slot < MDX_PK_QCAP) { qE[slot] = s8; qE[MDX_PK_QCAP + slot] = r8; qE[2 * MDX_PK_QCAP + slot] = evw; }
-                            else { u32 *e = ev_ovf_w + 3 * (size_t)(slot - MDX_PK_QCAP); e[0] = s8; e[1] = r8; e[2] = evw; }
-                        }
-                        qcount += __popcll(mm);
-                    }
                 };
                 constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : MDX_PK_PD);
-                static_assert(PD4 >= 1 && PD4 <= 4, "the accumulation below takes up to four steps");
-                St4 st[PD4];
+                static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
+                St16 st[PD4];
 #pragma unroll
-                for (int dd = 0; dd < PD4; dd++) fill4(st[dd]);
-                // The words of a group of PD4 steps go through carry-save adders: (x0, x1) -> plane 0 and a carry, (x2, x3) ->
-                // plane 0 and another, the two carries -> plane 1 and one of weight 4, which ripples upwards.  A group of a run
-                // sorted by strand that lies in front of the first reverse-strand entry, or behind the last forward one, adds
-                // to one set of planes only; any other group splits every word by the strand of its lane's record.
-                int kc = 0;         // first step of the group
-                // MODE 0 / 1: every step of the group holds forward / reverse-strand records only (a run sorted by strand):
-                // one set of planes; 2: the words are split by the strand of each lane's record
-                auto group = [&](auto full_tag, auto mode_tag, const bool refill) {
-                    constexpr int MODE = decltype(mode_tag)::value;
-                    u32 x[4] = {0u, 0u, 0u, 0u};
-                    u32 rv[4] = {0u, 0u, 0u, 0u};     // all ones in the lanes of reverse-strand records
+                for (int dd = 0; dd < PD4; dd++) fill16(st[dd]);
+                // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
+                // low and high dwords
+                auto group = [&](auto full_tag, const bool refill) {
+                    u32 xl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, xh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) {
-                        if (refill || dd == 0 || st[dd].valid) {
-                            count4(st[dd], full_tag, x[dd]);
-                            if (MODE == 2) rv[dd] = n_plus >= 0 ? (st[dd].k * R + c_slot >= n_plus ? ~0u : 0u) : (u32)((int)st[dd].sa >> 31);
+                        if (refill || dd == 0 || st[dd].valid) count16(st[dd], full_tag, xl[dd], xh[dd]);
+                        if (refill) fill16(st[dd]);
+                        if ((dd & 3) == 3 || dd == PD4 - 1) {
+                            const u32 al[4] = {xl[dd & ~3], xl[(dd & ~3) + 1], xl[(dd & ~3) + 2], xl[(dd & ~3) + 3]};
+                            const u32 ah[4] = {xh[dd & ~3], xh[(dd & ~3) + 1], xh[(dd & ~3) + 2], xh[(dd & ~3) + 3]};
+                            if ((dd & 3) == 3) { bs_add_group<4>(bsL, al); bs_add_group<4>(bsH, ah); }
+                            else if ((dd & 3) == 2) { bs_add_group<3>(bsL, al); bs_add_group<3>(bsH, ah); }
+                            else if ((dd & 3) == 1) { bs_add_group<2>(bsL, al); bs_add_group<2>(bsH, ah); }
+                            else { bs_add_group<1>(bsL, al); bs_add_group<1>(bsH, ah); }
                         }
-                        if (refill) fill4(st[dd]);
-                    }
-                    kc += PD4;
-                    if (MODE == 0) bs_add_group<PD4>(bsT, x);
-                    else if (MODE == 1) bs_add_group<PD4>(bsM, x);
-                    else {
-                        u32 xp[4], xm[4];
-#pragma unroll
-                        for (int dd = 0; dd < 4; dd++) { xm[dd] = x[dd] & rv[dd]; xp[dd] = x[dd] & ~rv[dd]; }
-                        bs_add_group<PD4>(bsT, xp);
-                        bs_add_group<PD4>(bsM, xm);
                     }
                 };
-                typedef std::integral_constant<int, 0> M0;
-                typedef std::integral_constant<int, 1> M1;
-                typedef std::integral_constant<int, 2> M2;
-                // (three loops over the same pipeline, each with its planes fixed at compile time: the groups in front of the
-                // border between the strands, the one that holds it — every group of an unsorted run —, those behind it;
-                // never the last step of the run)
+                // (two loops over the same pipeline: the groups all of whose slots hold records, then the others; never the last
+                // step of the run)
                 int k = PD4;
-                for (; k < nsteps && n_plus >= 0 && (kc + PD4) * R <= n_plus; k += PD4) group(std::true_type{}, M0{}, true);
-                for (; k < nsteps && (n_plus < 0 || kc * R < n_plus); k += PD4) group(std::true_type{}, M2{}, true);
-                for (; k < nsteps; k += PD4) group(std::true_type{}, M1{}, true);
-                // (the asm comments keep the ends of the three branches from being merged into one over pointers into the planes,
-                // which would send the planes to memory)
-                if (n_plus >= 0 && (kc + PD4) * R <= n_plus) { group(std::false_type{}, M0{}, false); asm volatile("; end of a forward run"); }
-                else if (n_plus < 0 || kc * R < n_plus) { group(std::false_type{}, M2{}, false); asm volatile("; end of a mixed run"); }
-                else { group(std::false_type{}, M1{}, false); asm volatile("; end of a reverse run"); }
+                for (; k < nsteps4 && k <= nfull; k += PD4) group(std::true_type{}, true);
+                for (; k < nsteps4; k += PD4) group(std::false_type{}, true);
+                group(std::false_type{}, false);
                 // (the only place the packed kernel drains: behind a run, once a few passes' worth of events wait)
-                if (qcount >= 64) drain_all();
+                if (qcount + qovf >= 64) drain_all();
                 return;
             }
 #if MDX_ENT_AHEAD
@@ -1921,6 +1926,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 const int dist = (side ? t - A : t) + 1;
                 if (dist <= (side ? s_na : s_nb)) {
                     const int r = ref_cls(s_rbase + (side ? s_n0 - 1 + dist : -dist));
+                    if (PK) {
+                        // the packed kernel's TC table: [base][64 j + lane], the lane of the strand's first slot that owns window
+                        // nibble A - dist of the side (right side: counted from the window's outer end, nibble 15 - j)
+                        const int wn = A - dist, ln4 = (rev ? d.H4 : 0) * d.G4 + side * d.nl16 + (wn >> 4);
+                        if (r < 4) atomicAdd(&lds[d.off_tc() + (r << 10) + 64 * (side ? 15 - (wn & 15) : (wn & 15)) + ln4], 1u);
+                    } else
                     if (r < 4) bump<USE_LDS>(lds, raw, b_tc + r * d.t_pad + (side ? d.tau_rflank(dist) : d.tau_lflank(dist)));
                 }
             }
@@ -1982,7 +1993,44 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
         // a tile ahead — and asks for the one after; the others ask for the next one: a wavefront that finds its pool
         // empty has one tile less left to do)
         u32 cur = tile_of(grab());
-        u32 nxt = RS && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
+        constexpr bool PF = PK && MDX_PK_PREFETCH;
+        u32 nxt = (RS || PF) && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
+        // PK: the loads of a tile's phase 1 — its nine column values, then the operations and contig bounds they lead to —
+        // are requested a tile ahead, the first round trip in front of the current tile's phase 1 and the second in front of
+        // its run: with sixteen-base lanes the units have the slack, and what bounds a wavefront is the chain of round trips
+        // per tile (phase 1 alone was half of the kernel's time)
+        struct Cols { u32 fl; int lib, tid, pos, tlen; u32 co0, co1, so0, so1; };
+        struct Rt2 { u32 g0, g1, g2, c0, clen; };
+        auto p_cols = [&](const u32 tile) -> Cols {
+            const u32 tb = tile * T, rh = tb + T < n_rec ? tb + T : n_rec;
+            const u32 ri_ = tb + lane;
+            const bool v_ = ri_ < rh;
+            const u32 rj_ = v_ ? ri_ : tb;
+            Cols c;
+            c.fl = v_ ? (u32)ld32(a.flag, rj_) : 0x4u;
+            c.lib = ld32(a.lib, rj_); c.tid = ld32(a.tid, rj_); c.pos = ld32(a.pos, rj_); c.tlen = ld32(a.tlen, rj_);
+            c.co0 = ld32(a.cigar_off, rj_); c.co1 = ld32(a.cigar_off, rj_ + 1); c.so0 = ld32(a.seq_off, rj_); c.so1 = ld32(a.seq_off, rj_ + 1);
+            return c;
+        };
+        auto p_rt2 = [&](const Cols &c) -> Rt2 {
+            bool kept_ = (c.fl & 0xF04u) == 0;
+            if (c.lib < a.nlib_total && (c.lib < a.lib_lo || c.lib >= a.lib_lo + d.nlib)) kept_ = false;
+            const u32 cn_ = c.co1 - c.co0;
+            const bool cand_ = kept_ && cn_ - 1u < 3u && c.tid >= 0 && c.tid < a.n_contig && c.lib < a.nlib_total;
+            Rt2 g;
+            g.g0 = g.g1 = g.g2 = 0xFu; g.c0 = 0u; g.clen = 0u;
+            if (cand_) {
+                g.g0 = a.cigar[c.co0];
+                if (cn_ >= 2u) g.g1 = a.cigar[c.co0 + 1];
+                if (cn_ >= 3u) g.g2 = a.cigar[c.co0 + 2];
+                g.c0 = (u32)a.contig_off[c.tid];
+                g.clen = (u32)a.contig_off[c.tid + 1] - g.c0;
+            }
+            return g;
+        };
+        Cols Cc = {}, Cn = {};
+        Rt2 Gc = {}, Gn = {};
+        if (PF && cur != 0xFFFFFFFFu) { Cc = p_cols(cur); Gc = p_rt2(Cc); }
         if (RS && cur != 0xFFFFFFFFu) {
             const u32 tb0 = cur * T, rh0 = tb0 + T < n_rec ? tb0 + T : n_rec;
             nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
@@ -1992,7 +2040,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             int nF = 0, nF0 = 0, nFp = 0;
             u32 nxt2_raw = 0xFFFFFFFFu;
             if (!past) {
-                if (!RS || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
+                if (!(RS || PF) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
+                if (PF && nxt != 0xFFFFFFFFu) Cn = p_cols(nxt);
                 const MdxTabArgs *kp = ka;
                 asm volatile("" : "+s"(kp));
                 const MdxTabArgs &p = *kp;
@@ -2030,9 +2079,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 const u32 ri = r_lo + lane;
                 const bool valid = ri < r_hi;
                 const u32 rj = valid ? ri : tbase;
-                const u32 fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
-                const int c_lib = ld32(a.lib, rj), c_tid = ld32(a.tid, rj), c_pos = ld32(a.pos, rj), c_tlen = ld32(a.tlen, rj);
-                const u32 c_co0 = ld32(a.cigar_off, rj), c_co1 = ld32(a.cigar_off, rj + 1), c_so0 = ld32(a.seq_off, rj), c_so1 = ld32(a.seq_off, rj + 1);
+                const u32 fl = PF ? Cc.fl : (valid ? (u32)ld32(a.flag, rj) : 0x4u);
+                const int c_lib = PF ? Cc.lib : ld32(a.lib, rj), c_tid = PF ? Cc.tid : ld32(a.tid, rj), c_pos = PF ? Cc.pos : ld32(a.pos, rj),
+                          c_tlen = PF ? Cc.tlen : ld32(a.tlen, rj);
+                const u32 c_co0 = PF ? Cc.co0 : ld32(a.cigar_off, rj), c_co1 = PF ? Cc.co1 : ld32(a.cigar_off, rj + 1),
+                          c_so0 = PF ? Cc.so0 : ld32(a.seq_off, rj), c_so1 = PF ? Cc.so1 : ld32(a.seq_off, rj + 1);
                 int c_mtid = 0, c_mpos = 0;
                 bool rs_anyhi = false;       // RS: some quality byte of the tile has bit 7 set (0xFF: a record without qualities)
                 if (RS) {
@@ -2070,7 +2121,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // (32-bit reference coordinates: the fast path runs on references shorter than 4 GiB, MdxTabArgs::ref32)
                 u32 c0 = 0, clen = 0;
                 u32 q0 = 0xFFu;
-                if (cand) {
+                if (PF) { g0 = Gc.g0; g1 = Gc.g1; g2 = Gc.g2; c0 = Gc.c0; clen = Gc.clen; }
+                else if (cand) {
                     g0 = a.cigar[c_co0];
                     if (cn >= 2u) g1 = a.cigar[c_co0 + 1];
                     if (cn >= 3u) g2 = a.cigar[c_co0 + 2];
@@ -2238,7 +2290,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     else if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
                     // the slots past the last record of a step shadow a real record (and are masked out); a run of the
                     // clean records in front (MASK) reads its own last slots from the maskable records' entries
-                    if (MASK || nF % R) {
+                    // (PK: a slot past its strand's last entry reads the run's first entry, no padding)
+                    if (!PK && (MASK || nF % R)) {
                         const int first = __ffsll((long long)mF) - 1;
                         uint4 pad;
                         pad.x = (u32)rl((int)ent.x, first); pad.y = (u32)rl((int)ent.y, first);
@@ -2268,6 +2321,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                 // Bytes that are not plain matches are not handled here: they are appended as events to a
                 // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
                 // classification code runs once per 64 events instead of once per record.
+                // (PK: the next tile's columns have had this tile's phase 1 to arrive: its second round trip goes out under the run)
+                if (PF && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) { if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp); }
                 else {
                 if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
@@ -2332,8 +2387,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             }
             if (past && dDone >= nDef) break;
             if (!past) {
-                if (RS) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
+                if (RS || PF) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
                 else cur = tile_of(nxt2_raw);
+                if (PF) { Cc = Cn; Gc = Gn; }
             }
         }
         if (lane == 0 && n_kept_lite) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), n_kept_lite);
@@ -2352,8 +2408,17 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             for (int e = 0; e < n; e += TL) {
                 const int m = n - e < TL ? n - e : TL;
                 const uint4 ent = lists[first + (i64)dir * (e + (lane < m ? lane : 0))];
+                int n_fwd = -1;
+                if (PK) {
+                    // (sorted by strand, the forward entries first)
+                    const bool mine = lane < m, rv_ = (ent.w >> 31) != 0u;
+                    const u64 mR = __ballot(mine && rv_), mW = __ballot(mine && !rv_);
+                    n_fwd = __popcll(mW);
+                    if (mine) stg[rv_ ? n_fwd + mbcnt64(mR, 0) : mbcnt64(mW, 0)] = ent;
+                } else {
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
+                }
                 constexpr bool RSP = RS && decltype(kind_tag)::value == STEP_P;
                 u32 ri_l = 0;
                 if (RSP) {
@@ -2361,7 +2426,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
                     mrm[lane] = 0ull;
                     if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
                 }
-                run(0, m, kind_tag, std::true_type{});
+                run(0, m, kind_tag, std::true_type{}, n_fwd);
                 if (RSP) rsq_flush();
                 // RS: the MR sums of the fused records among them (known by their TC table)
                 if (RSP && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
@@ -2378,7 +2443,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
     }
 #endif
     if (FAST) {
-        if (qcount > 0) drain_all();
+        if (qcount + qovf > 0) drain_all();
         if (PK) bs_flush();
     }
     if (USE_LDS) {
@@ -2417,6 +2482,27 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : MDX_BLOCK, RS ? MDX_FUSE_WPS 
             __syncthreads();
         }
         u32 *out = a.partials + (i64)blockIdx.x * d.w_total;
+        if (PK) {
+            // The TC words of the slot in the layout every consumer knows (MdxDims: [strand][base][64 byte + lane], the counts
+            // in the words of slot 0): word (strand, k, lane (side, m), byte jb) = window byte b = 8 m + jb of the left side /
+            // e = 8 m + 7 - jb of the right side, summed over the H4 slots of the strand in this kernel's table.
+            for (int i = threadIdx.x; i < d.w_tc; i += BLOCK) {
+                const int w = i & 511, k = (i >> 9) & 3, strand = (i >> 11) & 1;
+                const int ln = w & 63, jb = w >> 6;
+                u32 v = 0u;
+                if (ln < d.G) {
+                    const int side = ln >= d.nl8, m = ln - side * d.nl8;
+                    const int wn = side ? 8 * m + 7 - jb : 8 * m + jb;          // window nibble (right side: from the outer end)
+                    if (wn < A + L) {
+                        const int j = side ? 15 - (wn & 15) : (wn & 15);
+                        for (int gs = 0; gs < d.H4; gs++)
+                            v += lds[d.off_tc() + (k << 10) + 64 * j + (strand * d.H4 + gs) * d.G4 + side * d.nl16 + (wn >> 4)];
+                    }
+                }
+                out[d.off_tc() + i] = v;
+            }
+            for (i64 i = d.w_tc + threadIdx.x; i < d.w_total; i += BLOCK) out[i] = lds[i];
+        } else
         for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) out[i] = lds[i];
     }
 }
@@ -2445,7 +2531,7 @@ hipError_t mdx_k_prepare_packed(size_t lds_bytes) {
 // the packed kernel: 4-bit SEQ column and 4-bit reference, one library per launch
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(MDX_BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
 
 hipError_t mdx_k_prepare(size_t lds_bytes) {
