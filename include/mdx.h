@@ -338,6 +338,10 @@ int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual);
 int mdx_gbam_set_seq_format(mdx_gbam *g, int32_t seq_format);
 int mdx_gbam_missing_qualities(const mdx_gbam *g);
 int mdx_gbam_at_end(const mdx_gbam *g);
+/* Steps over the slab mdx_gbam_next would decode next (same chunk_bytes, same borders) without touching the device: in a
+ * run over several GPUs (one process and one mdx_gbam per GPU) rank r decodes the slabs r, r + N, ... and skips
+ * the others — the loop of mapdamage/main.py:165-217 sharded by record with no exchange until the tables are summed. */
+int mdx_gbam_skip(mdx_gbam *g, int64_t chunk_bytes);
 void mdx_gbam_close(mdx_gbam *g);
 /* Introspection for tests: the device inflate and CRC32 stages of the decode path alone, on BGZF payloads the caller
  * supplies (host buffers).  blk holds four words per block — payload offset in comp, payload bytes, offset in out,

@@ -1109,6 +1109,26 @@ int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual) {
     return MDX_OK;
 }
 
+int mdx_gbam_skip(mdx_gbam *g, int64_t chunk_bytes) {
+    // the slab mdx_gbam_next would take now, left undecoded (same borders: the ranks of a multi-GPU run agree on them)
+    try {
+        if (!g) return MDX_ERR_ARG;
+        const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
+        if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + want + 65536)) return MDX_ERR_ARG;
+        if (g->next_block >= g->blocks.size()) return MDX_OK;
+        const size_t b0 = g->next_block, in0 = g->blocks[b0].in_off;
+        size_t b1 = b0, unc_bytes = 0;
+        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && unc_bytes + g->blocks[b1].out_size < 0xF0000000ull))) {
+            unc_bytes += g->blocks[b1].out_size;
+            b1++;
+        }
+        g->next_block = b1;
+        return MDX_OK;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
+}
+
 int mdx_gbam_set_seq_format(mdx_gbam *g, int32_t seq_format) {
     if (!g || (seq_format != MDX_SEQ_ASCII && seq_format != MDX_SEQ_4BIT)) return MDX_ERR_ARG;
     g->seq_format = seq_format;

@@ -8,8 +8,8 @@ the packed uint64 table block at the end of the pass (RCCL over xGMI with backen
 histogram, i.e. latency-bound: a single all-reduce, no bucketing.
 
 Two equivalent routes:
-* ``reduce_engine_tables`` — through torch.distributed (the bench and the command line use it: the
-  process group exists anyway);
+* ``reduce_engine_tables`` — through torch.distributed (``bench.py --gpus N`` and ``python -m mapdamage_amd
+  --gpus N`` use it: the process group exists anyway; main.py ``_Ranks``);
 * the C-ABI route (``DamageEngine.comm_init`` + ``finish()``, include/mdx.h ``mdx_comm_*``): the library
   calls RCCL itself, for consumers without torch.  ``attach_rccl`` wires it up from a torch process group
   (the unique id travels through ``broadcast_object_list``).

@@ -35,6 +35,7 @@ EXPORTS = (
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
+    "mdx_gbam_skip",
 )
 
 SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
@@ -131,6 +132,7 @@ def load_library(path=None):
                                        ctypes.c_int, ctypes.c_int]
     lib.mdx_gbam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mdx_gbam_at_end.argtypes = [ctypes.c_void_p]
+    lib.mdx_gbam_skip.argtypes = [ctypes.c_void_p, ctypes.c_int64]
     lib.mdx_gbam_set_min_basequal.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mdx_gbam_set_seq_format.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mdx_pack_seq.restype = ctypes.c_int

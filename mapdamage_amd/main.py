@@ -75,6 +75,17 @@ def build_parser():
     g.add_argument("--rescale-length-3p", type=int)
     g = p.add_argument_group("MI355X engine")
     g.add_argument("--device", type=int, default=0, help="HIP device ordinal")
+    g.add_argument("--gpus", type=_ranged(int, 1), default=1,
+                   help="tabulate on this many GPUs of the node: one process per GPU (the command re-executes itself under "
+                        "torch.distributed.run unless it was launched that way), the records sharded by slab of the file, the "
+                        "tables summed with one RCCL all-reduce, rank 0 writes the output files")
+    g.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                   help="torch.distributed backend of the table reduction: nccl = RCCL over xGMI; gloo sums on the host")
+    g.add_argument("--share-gpu", action="store_true",
+                   help="every rank uses --device instead of its own GPU (tests of the multi-rank path on a 1-GPU box; "
+                        "needs --dist-backend gloo: RCCL refuses two ranks on one device)")
+    g.add_argument("--print-launch", action="store_true",
+                   help="with --gpus N > 1: print the torchrun command the run would re-execute itself under, and exit")
     g.add_argument("--freq-files", action="store_true",
                    help="EXPERIMENTAL: also write 5pCtoT_freq.txt / 3pGtoA_freq.txt (mapDamage 2.0-2.2 outputs that "
                         "this reference snapshot no longer produces; format unpinned)")
@@ -170,12 +181,78 @@ def rescale_qual(options):
     return 0
 
 
-def _tabulate_on_host(options, reader, ref, libraries, logger):
+class _Ranks:
+    """The ranks of a multi-GPU run (mapdamage/main.py:165-217 sharded by record): one process per GPU under
+    torch.distributed; rank r of W takes the slabs (device decode) or the shard of every chunk (host decode) that are
+    its own, nothing is exchanged until the tables are summed."""
+
+    def __init__(self, options):
+        import os
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.backend = options.dist_backend
+        self.device = options.device
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            if not options.share_gpu:
+                self.device = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(self.device)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+                else:
+                    dist.init_process_group("gloo")
+
+    def finish(self, engine, error=None):
+        """The tables of the whole run, on every rank.  ``error``: what this rank's part of the run died of, if it did —
+        the ranks agree on it before any collective, the failing one re-raises it, the others raise RuntimeError."""
+        if self.world == 1:
+            if error is not None:
+                raise error
+            return engine.finish()
+        from . import distributed
+        if self.backend == "nccl":
+            import torch
+            dev = torch.device("cuda", self.device)
+            distributed.agree_on_error(error, dev)
+            return distributed.reduce_engine_tables(engine, dev)
+        own = None
+        if error is None:
+            try:
+                own = engine.finish()
+            except (BadReadError, MdxError) as exc:
+                error = exc
+        distributed.agree_on_error(error)
+        return distributed.reduce_tableset(own, engine.lgd_max)
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
+
+
+def launch_command(argv, gpus):
+    """The command ``--gpus N`` re-executes itself under: one rank per GPU of this node."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    keep = [a for a in argv if a != "--print-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "mapdamage_amd"] + keep
+
+
+def _tabulate_on_host(options, reader, ref, libraries, logger, ranks):
     """The records decoded on the host (native BGZF/BAM decoder or SAM text), uploaded batch by batch."""
     with DamageEngine(libraries, options.length, options.around, options.minqual,
-                      device=options.device) as engine:
+                      device=ranks.device) as engine:
         engine.set_reference(ref)
         n_reads, warned_about_quals = 0, False
+        error = None
         # a BAM file arrives in chunks (bounded host memory; chunk k+1 is decoded while chunk k is tabulated)
         for batch in reader.iter_batches():
             if options.minqual and not warned_about_quals and batch.n:
@@ -195,11 +272,22 @@ def _tabulate_on_host(options, reader, ref, libraries, logger):
             # the slices of a chunk are enqueued one behind the other — the copy of slice k+1 runs under the kernel of
             # slice k — and the chunk is waited for once; a bad record comes back with its index among all records
             # iterated so far (the reference would name the read)
-            for lo in range(0, batch.n, options.batch_reads):
-                engine.tabulate(batch.slice(lo, lo + options.batch_reads, copy=False), sync=False, record_base=n_reads + lo)
-            engine.sync()
+            # (several ranks: every rank decodes the chunk — the host decoder is one stream of records — and counts its
+            # own contiguous shard of it)
+            from .distributed import shard_bounds
+            s_lo, s_hi = shard_bounds(batch.n, ranks.rank, ranks.world)
+            try:
+                for lo in range(s_lo, s_hi, options.batch_reads):
+                    engine.tabulate(batch.slice(lo, min(s_hi, lo + options.batch_reads), copy=False), sync=False,
+                                    record_base=n_reads + lo)
+                engine.sync()
+            except (BadReadError, MdxError) as exc:
+                if ranks.world == 1:
+                    raise
+                error = exc
+                break
             n_reads += batch.n
-        tables = engine.finish()
+        tables = ranks.finish(engine, error)
     return tables
 
 
@@ -209,7 +297,7 @@ def _device_path_applies(options):
     return str(options.filename) != "-" and is_bam(options.filename) and options.downsample is None
 
 
-def _tabulate_on_device(options, reader, ref, libraries, logger):
+def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
     """--gpu-decode: the file inflated, unpacked and counted on the GPU.  None: not a case for it (the caller decodes
     on the host, which also words the errors the way the reference does)."""
     from .sam import GpuBamStream, GpuDecodeUnsupported
@@ -222,22 +310,37 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
         readgroups = [(rg, libraries.index(lib)) for rg, lib in reader._readgroups.items()]
         lib_default = None
     try:
-        with DamageEngine(libraries, options.length, options.around, options.minqual, device=options.device) as engine:
+        with DamageEngine(libraries, options.length, options.around, options.minqual, device=ranks.device) as engine:
             engine.set_reference(ref)
             warned_about_quals = False
+            error = None
             # (a slab of compressed bytes inflates to about four times its size)
             slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
             with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
                               chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
-                while True:
-                    view = stream.next_view()
-                    if view is None:
-                        break
-                    if options.minqual and not warned_about_quals and stream.missing_qualities():
-                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
-                        warned_about_quals = True
-                    engine.tabulate_view(view)
-                return engine.finish()
+                # (several ranks: rank r decodes the slabs r, r + W, ... and steps over the others)
+                slab = 0
+                try:
+                    while True:
+                        mine = slab % ranks.world == ranks.rank
+                        slab += 1
+                        if not mine:
+                            if not stream.skip():
+                                break
+                            continue
+                        view = stream.next_view()
+                        if view is None:
+                            break
+                        if options.minqual and not warned_about_quals and stream.missing_qualities():
+                            logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                            warned_about_quals = True
+                        engine.tabulate_view(view)
+                    engine.sync()
+                except (BadReadError, ValueError, MdxError) as exc:
+                    if ranks.world == 1:
+                        raise
+                    error = exc         # (the ranks agree on it in finish(): all of them take the host path then)
+                return ranks.finish(engine, error)
     except GpuDecodeUnsupported as error:
         reason = "file layout the device path does not take (MDX_ERR_UNSUPPORTED): %s" % error
     except BadReadError as error:
@@ -247,6 +350,9 @@ def _tabulate_on_device(options, reader, ref, libraries, logger):
         # a damaged file (the host decoder finds the same damage and words the error), or the device path out of
         # memory: either way the host path has the last word
         reason = "%s (libmdx code %s)" % (error, getattr(error, "code", "n/a"))
+    except RuntimeError as error:
+        # (several ranks: another rank's part of the file failed — every rank takes the host path, like that one)
+        reason = str(error)
     # never silent: a regression of the device path must not show up as nothing but a slow run
     options.gpu_decode_fallbacks = getattr(options, "gpu_decode_fallbacks", 0) + 1
     logger.warning("GPU decode path gave up: %s; decoding on the host (the whole file again)", reason)
@@ -261,8 +367,23 @@ def main(argv):
         options = parse_args(argv)
     except SystemExit as error:
         return int(error.code or 0) and 1
-    logging.getLogger().setLevel(options.log_level)
-    handler = logging.FileHandler(options.folder / "Runtime_log.txt")
+    import os
+    if options.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: the run re-executes itself under torchrun (or is launched that way to begin with)
+        import subprocess
+        cmd = launch_command(list(argv), options.gpus)
+        if options.print_launch:
+            import json
+            print(json.dumps(cmd))
+            return 0
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return subprocess.call(cmd, env=env)
+    ranks = _Ranks(options)
+    first = ranks.rank == 0
+    # (rank 0 keeps the log file and writes the tables; the other ranks speak up only when something is wrong)
+    logging.getLogger().setLevel(options.log_level if first else "WARNING")
+    handler = logging.FileHandler(options.folder / "Runtime_log.txt") if first else logging.NullHandler()
     handler.setFormatter(logging.Formatter(_LOG_FORMAT))
     handler.setLevel(options.log_level)
     logging.getLogger().addHandler(handler)
@@ -270,7 +391,10 @@ def main(argv):
         logger.info("Started with the command: " + " ".join(sys.argv))
         if options.rescale_only:
             logger.info("Starting rescaling...")
-            return rescale_qual(options)
+            return rescale_qual(options) if first else 0
+        if ranks.world > 1:
+            logger.info("Rank 0 of %d: one process per GPU, records sharded by slab of the file, tables summed over %s",
+                        ranks.world, "RCCL" if ranks.backend == "nccl" else "gloo (host)")
         reader = BAMReader(options.filename, merge_libraries=options.merge_libraries,
                            downsample_to=options.downsample, downsample_seed=options.downsample_seed,
                            chunk_bytes=int(options.chunk_mb * (1 << 20)))
@@ -288,9 +412,9 @@ def main(argv):
             logger.info("Filtering out bases with a Phred score < %d", options.minqual)
         logger.info("Writing results to '%s/'", options.folder)
 
-        tables = _tabulate_on_device(options, reader, ref, libraries, logger) if options.gpu_decode else None
+        tables = _tabulate_on_device(options, reader, ref, libraries, logger, ranks) if options.gpu_decode else None
         if tables is None:
-            tables = _tabulate_on_host(options, reader, ref, libraries, logger)
+            tables = _tabulate_on_host(options, reader, ref, libraries, logger, ranks)
         fallbacks = getattr(options, "gpu_decode_fallbacks", 0)
         if options.gpu_decode:
             logger.log(logging.WARNING if fallbacks else logging.DEBUG, "Decode path: %s; fallbacks from the device path: %d",
@@ -298,6 +422,8 @@ def main(argv):
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)
 
+        if not first:
+            return 0
         tables.write(options.folder)
         if options.freq_files:
             (options.folder / "5pCtoT_freq.txt").write_text(tables.damage_frequency_text("5p", options.readplot))
@@ -316,6 +442,7 @@ def main(argv):
     finally:
         logging.getLogger().removeHandler(handler)
         handler.close()
+        ranks.close()
 
 
 def entry_point():

@@ -427,6 +427,15 @@ class GpuBamStream:
         view.mtid, view.mpos = mtid.value, mpos.value       # (python attributes: not fields of the C struct)
         return view
 
+    def skip(self):
+        """Step over the slab ``next_view`` would decode (a run over several GPUs: the slabs of the other ranks).
+        False at the end of the file."""
+        if self._lib.mdx_gbam_at_end(self._g):
+            return False
+        if self._lib.mdx_gbam_skip(self._g, self.chunk_bytes) != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
+        return True
+
     def close(self):
         if self._g:
             self._lib.mdx_gbam_close(self._g)

@@ -80,3 +80,69 @@ def test_bench_line_with_rccl_initialised(tmp_path):
     flat = [v for k, v in sec.items() if k != "config3_genome3g"] + list(sec["config3_genome3g"].values())
     assert all(v["parity"].startswith("bit-exact") for v in flat)
     assert sec["file_to_tables"]["device_decode"]["reads_per_s"] > 0 and sec["file_to_tables"]["host_decode"]["reads_per_s"] > 0
+
+
+def _cli(args, gpus=1, port=29557, timeout=900):
+    """`python -m mapdamage_amd ...` in a process of its own (the multi-GPU form re-executes itself under torchrun)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "mapdamage_amd"] + [str(a) for a in args]
+    if gpus > 1:
+        cmd += ["--gpus", str(gpus), "--dist-backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decode", ["--gpu-decode", "--host-decode"])
+def test_cli_on_two_ranks_writes_the_reference_tables(tmp_path, decode):
+    """`python -m mapdamage_amd --gpus 2` (two ranks on cuda:0, tables summed over gloo: what a 1-GPU box allows): the
+    three tables of the reference's golden run, byte for byte, from either decode path."""
+    import numpy as np
+
+    from mapdamage_amd import fasta, sam
+    from tests.util import Golden
+    name = "config1_L70_A10_Q20"
+    g = Golden(name)
+    rgs = [{"ID": "rg%d" % i, "SM": s, "LB": l} for i, (s, l) in enumerate(g.meta["libraries"])]
+    raw_lib = np.load(str(ROOT / "tests" / "golden" / (name + ".npz")))["lib"]
+    path = tmp_path / "in.bam"
+    sam.write_bam(path, g.batch, g.ref.names, g.ref.lengths, rgs, ["rg%d" % int(l) for l in raw_lib])
+    fasta.write_fasta(tmp_path / "ref.fa", g.ref)
+    out = tmp_path / "res2"
+    _cli(["-i", path, "-r", tmp_path / "ref.fa", "-d", out, "-Q", "20", "--no-stats", decode], gpus=2)
+    for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
+        assert (out / f).read_text() == g.txt[f], f
+    log = (out / "Runtime_log.txt").read_text()
+    assert "Rank 0 of 2" in log and "Successful run" in log
+
+
+@pytest.mark.gpu
+def test_cli_on_two_ranks_shards_the_slabs_of_a_file(tmp_path):
+    """A file of several slabs: rank r decodes the slabs r, r + 2, ... on the device and steps over the others; the
+    tables equal the one-GPU run's byte for byte, and the oracle's."""
+    import numpy as np
+
+    from mapdamage_amd import fasta, sam, synth
+    from oracle import oracle
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500, lower_run=3000)
+    b = synth.make_reads(ref, 150_000, 21, len_range=(30, 140), paired=True, frac_softclip=0.1, frac_ins=0.04, frac_del=0.04,
+                         frac_skip=0.005, frac_filtered=0.03)
+    path = tmp_path / "big.bam"
+    sam.write_bam(path, b, ref.names, ref.lengths, [{"ID": "rg1", "SM": "s", "LB": "l"}], ["rg1"] * b.n)
+    assert path.stat().st_size > 3 << 20          # three slabs of 1 MiB and more
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    one, two = tmp_path / "one", tmp_path / "two"
+    common = ["-i", path, "-r", tmp_path / "ref.fa", "--no-stats", "--chunk-mb", "4", "--log-level", "DEBUG"]
+    _cli(common + ["-d", one])
+    _cli(common + ["-d", two], gpus=2, port=29558)
+    for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
+        assert (one / f).read_bytes() == (two / f).read_bytes(), f
+    assert "fallbacks from the device path: 0" in (two / "Runtime_log.txt").read_text()
+    # ... and both are the oracle's
+    from mapdamage_amd.tables import TableSet
+    w = oracle.tabulate(ref, b, 1, 70, 10)
+    want = TableSet([("s", "l")], 70, 10, w["mis"], w["comp"], w["lgd"], w["lgd_over"], w["n_kept"])
+    assert (one / "misincorporation.txt").read_text() == want.misincorporation_text()
+    assert (one / "dnacomp.txt").read_text() == want.dnacomp_text()

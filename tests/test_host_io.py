@@ -414,3 +414,19 @@ def test_decoders_clear_flag_bit_15(files, tmp_path):
     has_q = np.asarray([batch.qual[batch.seq_off[i]] != 0xFF if batch.seq_off[i + 1] > batch.seq_off[i] else False
                         for i in range(batch.n)])
     assert not (marked.flag[has_q] & 0x8000).any() and not nothing
+
+
+def test_cli_gpus_prints_the_launch_it_would_re_execute_itself_under(tmp_path, capsys):
+    """`--gpus 8 --print-launch`: one rank per GPU under torch.distributed.run on 127.0.0.1, the command's own
+    arguments behind it (no GPU needed: nothing is launched)."""
+    import json
+
+    from mapdamage_amd.main import main
+    argv = ["-i", str(tmp_path / "x.bam"), "-r", str(tmp_path / "ref.fa"), "-d", str(tmp_path / "out"), "--gpus", "8",
+            "--print-launch"]
+    assert main(argv) == 0
+    cmd = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index("mapdamage_amd") + 1:]
+    assert tail == [a for a in argv if a != "--print-launch"] and cmd[cmd.index("mapdamage_amd") - 1] == "-m"
