@@ -191,6 +191,9 @@ int mdx_comm_unique_id(uint8_t *id /* MDX_COMM_ID_BYTES */);
 int mdx_comm_init(mdx_ctx *ctx, const uint8_t *id, int32_t nranks, int32_t rank);
 int mdx_comm_adopt(mdx_ctx *ctx, void *rccl_comm, int32_t nranks, int32_t rank);
 int mdx_comm_size(const mdx_ctx *ctx);   /* 0 = no communicator attached */
+/* The ranks RCCL itself counts in the attached communicator (ncclCommCount; 0 = none attached, < 0 = error): what a
+ * benchmark line quotes as proof that the collective ran over that many ranks. */
+int mdx_comm_count(mdx_ctx *ctx);
 int mdx_finish_allreduce(mdx_ctx *ctx, uint64_t *d_tables);
 
 /* Zero all accumulators (new run with the same options and reference). */

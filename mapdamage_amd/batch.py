@@ -233,13 +233,15 @@ class Reference:
 
     def concat(self):
         """(bases u8[total], contig_off i64[n+1]); built once per object (a genome of human size is not joined again
-        for every caller), read-only."""
+        for every caller).  Both arrays are shared between callers and read-only: they must not be modified."""
         cat = self.__dict__.get("_cat")
-        if cat is None or cat[2] != [id(s) for s in self.seqs]:
+        # (the cache holds the contig objects it was built from: none of them can have been freed and its address
+        # reused; a replaced contig is another object)
+        if cat is None or len(cat[2]) != len(self.seqs) or any(a is not b for a, b in zip(cat[2], self.seqs)):
             offs = np.zeros(len(self.seqs) + 1, np.int64)
             for i, s in enumerate(self.seqs):
                 offs[i + 1] = offs[i] + len(s)
             bases = np.frombuffer(b"".join(self.seqs), dtype=np.uint8)
             offs.setflags(write=False)
-            cat = self.__dict__["_cat"] = (bases, offs, [id(s) for s in self.seqs])
+            cat = self.__dict__["_cat"] = (bases, offs, list(self.seqs))
         return cat[0], cat[1]

@@ -7,29 +7,29 @@ is written exactly as the reference does: ``csv.writer`` defaults (``\\r\\n`` li
 
 import csv
 
+_BASES = ("A", "C", "G", "T")
+
 
 def base_frequencies(counts):
-    """counts: array [n_contig][4] (A, C, G, T) -> dict of frequencies (composition.py:10-17)."""
-    bases = {"A": 0, "C": 0, "G": 0, "T": 0}
-    for row in counts:
-        for key, value in zip("ACGT", row):
-            bases[key] += int(value)
-    total = sum(bases.values())
-    return {key: bases[key] / total for key in bases}
+    """Per-contig counts [n_contig][4] (A, C, G, T; ``DamageEngine.genome_composition``) -> the genome-wide frequency
+    of each base (what mapdamage/composition.py:10-17 derives from seqtk's counts)."""
+    totals = [sum(int(row[k]) for row in counts) for k in range(len(_BASES))]
+    n = sum(totals)
+    return {base: total / n for base, total in zip(_BASES, totals)}
 
 
 def write_base_comp(counts, destination):
+    """``dnacomp_genome.csv``: a header row and one row of frequencies, csv-module formatting (``repr`` floats, CRLF)."""
     freqs = base_frequencies(counts)
     with open(destination, "wt", newline="") as handle:
-        writer = csv.writer(handle)
-        header = ["A", "C", "G", "T"]
-        writer.writerow(header)
-        writer.writerow(freqs[key] for key in header)
+        csv.writer(handle).writerows([_BASES, [freqs[base] for base in _BASES]])
 
 
 def read_base_comp(filename):
-    """First data row of a file written by ``write_base_comp`` (composition.py:28-35)."""
+    """The frequencies of a file written by ``write_base_comp`` as ``{base: text}`` (mapdamage/composition.py:28-35)."""
     with open(filename, newline="") as handle:
-        for row in csv.DictReader(handle):
-            return row
-    raise csv.Error("No rows found in %r" % (filename,))
+        rows = csv.reader(handle)
+        header, first = next(rows, None), next(rows, None)
+    if not header or first is None:
+        raise csv.Error("No rows found in %r" % (filename,))
+    return dict(zip(header, first))

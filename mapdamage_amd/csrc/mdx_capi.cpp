@@ -46,6 +46,7 @@ struct Rccl {
     int (*GetUniqueId)(RcclId *) = nullptr;
     int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -67,6 +68,7 @@ const Rccl *rccl() {
         g_rccl.GetUniqueId = (int (*)(RcclId *))sym("ncclGetUniqueId");
         g_rccl.CommInitRank = (int (*)(void **, int, RcclId, int))sym("ncclCommInitRank");
         g_rccl.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        g_rccl.CommCount = (int (*)(void *, int *))sym("ncclCommCount");
         g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
         g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllGather");
         g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
@@ -709,6 +711,16 @@ int mdx_comm_adopt(mdx_ctx *c, void *rccl_comm, int32_t nranks, int32_t rank) {
 
 int mdx_comm_size(const mdx_ctx *c) { return c && c->comm ? c->comm_size : 0; }
 
+int mdx_comm_count(mdx_ctx *c) {
+    if (!c) return MDX_ERR_ARG;
+    if (!c->comm) return 0;
+    const Rccl *r = rccl();
+    if (!r) return fail(c, MDX_ERR_COMM, g_rccl.err);
+    int n = 0;
+    RCCL_TRY(c, r, r->CommCount(c->comm, &n));
+    return n;
+}
+
 int mdx_finish_allreduce(mdx_ctx *c, uint64_t *d_tables) {
     if (!c || !d_tables) return MDX_ERR_ARG;
     if (!c->comm) return fail(c, MDX_ERR_STATE, "mdx_comm_init / mdx_comm_adopt first");
@@ -801,6 +813,8 @@ int mdx_finish(mdx_ctx *c, uint64_t *mis, uint64_t *comp, uint64_t *lgd, int64_t
                     // stay within the caller's buffer — an error, not a silently shortened list
                     nov = (int64_t)gathered.size() / 4;
                     if (nov > lgd_over_cap) {
+                        // (the tables and n_kept are out already; *n_lgd_over says how many entries a retry needs)
+                        if (n_lgd_over) *n_lgd_over = nov;
                         (void)hipFree(d);
                         return fail(c, MDX_ERR_LGD_OVERFLOW, "the out-of-range fragment lengths of all ranks exceed the "
                                     "caller's lgd_over buffer (give it comm_size x lgd_over_cap entries)");

@@ -113,6 +113,25 @@ def attach_rccl(engine):
     return engine
 
 
+def adopt_torch_rccl(engine, device):
+    """Hand the engine the ``ncclComm_t`` torch's default process group uses on ``device`` (mdx_comm_adopt): the C-ABI
+    reduction then runs over the very communicator torch.distributed has set up.  Returns False when this torch build
+    does not expose the pointer (``ProcessGroupNCCL._comm_ptr``)."""
+    import torch
+    import torch.distributed as dist
+    if not _active() or dist.get_backend() != "nccl":
+        return False
+    # (the communicator exists once a collective has run on the device)
+    dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=device))
+    torch.cuda.synchronize(device)
+    pg = dist.distributed_c10d._get_default_group()._get_backend(torch.device(device))
+    ptr = getattr(pg, "_comm_ptr", None)
+    if ptr is None:
+        return False
+    engine.comm_adopt(int(ptr()), dist.get_world_size(), dist.get_rank())
+    return True
+
+
 def reduce_tableset(ts: TableSet, lgd_max) -> TableSet:
     """All-reduce a host TableSet (CPU/gloo path used by the tests)."""
     import torch

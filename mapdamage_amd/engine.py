@@ -35,7 +35,7 @@ EXPORTS = (
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
-    "mdx_gbam_skip",
+    "mdx_gbam_skip", "mdx_comm_count",
 )
 
 SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
@@ -101,6 +101,8 @@ def load_library(path=None):
                  "mdx_set_record_base"):
         getattr(lib, name).restype = ctypes.c_int
     lib.mdx_comm_size.argtypes = [ctypes.c_void_p]
+    lib.mdx_comm_count.argtypes = [ctypes.c_void_p]
+    lib.mdx_comm_adopt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
     lib.mdx_rescale_summary_words.restype = ctypes.c_int64
     lib.mdx_rescale_summary_words.argtypes = [ctypes.c_void_p]
     lib.mdx_fused_launches.restype = ctypes.c_int64
@@ -337,9 +339,21 @@ class DamageEngine:
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.mdx_comm_init(self._ctx, buf, ctypes.c_int32(nranks), ctypes.c_int32(rank)))
 
+    def comm_adopt(self, rccl_comm: int, nranks: int, rank: int):
+        """Use a communicator the caller owns (an ``ncclComm_t`` as an integer, e.g. torch's
+        ``ProcessGroupNCCL._comm_ptr()``); it is not destroyed with the engine."""
+        self._check(self._lib.mdx_comm_adopt(self._ctx, ctypes.c_void_p(rccl_comm), ctypes.c_int32(nranks), ctypes.c_int32(rank)))
+
     @property
     def comm_size(self):
         return int(self._lib.mdx_comm_size(self._ctx))
+
+    def comm_count(self):
+        """The ranks RCCL counts in the attached communicator (ncclCommCount); 0 without one."""
+        n = int(self._lib.mdx_comm_count(self._ctx))
+        if n < 0:
+            self._check(n)
+        return n
 
     def finish_allreduce(self, device_ptr):
         """finish_device + in-place ncclAllReduce(uint64, sum) on the context's stream (collective)."""

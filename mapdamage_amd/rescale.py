@@ -23,23 +23,29 @@ class RescaleError(RuntimeError):
 
 
 def get_corr_prob(filepath, rescale_length_5p, rescale_length_3p):
-    """``{(ref, read, position): probability}`` from Stats_out_MCMC_correct_prob.csv
-    (rescale.py:23-46)."""
-    filepath = pathlib.Path(filepath)
-    try:
-        with filepath.open(newline="") as handle:
-            reader = csv.DictReader(handle, strict=True)
-            corr_prob = {}
-            for line in reader:
-                position = int(line["Position"])
-                if -rescale_length_3p <= position <= rescale_length_5p:
-                    corr_prob[("C", "T", position)] = float(line["C.T"])
-                    corr_prob[("G", "A", position)] = float(line["G.A"])
-            return corr_prob
-    except FileNotFoundError:
+    """The posterior damage probabilities the rescaling uses, ``{(ref, read, position): probability}``, from the
+    ``Stats_out_MCMC_correct_prob.csv`` the reference's R stage writes (header ``"","Position","C.T","G.A"``; what
+    mapdamage/rescale.py:23-46 reads): positions 1 .. ``rescale_length_5p`` from the 5' end, -1 .. -``rescale_length_3p``
+    from the 3' end."""
+    path = pathlib.Path(filepath)
+    if not path.is_file():
         raise RescaleError("File does not exist; please re-run mapDamage")
-    except csv.Error as error:
-        raise RescaleError("Error while reading line %d: %s" % (reader.line_num, error))
+    wanted = range(-int(rescale_length_3p), int(rescale_length_5p) + 1)
+    columns = {"C.T": ("C", "T"), "G.A": ("G", "A")}
+    table = {}
+    with path.open(newline="") as handle:
+        rows = csv.reader(handle, strict=True)
+        try:
+            header = next(rows, [])
+            at = {name: header.index(name) for name in ("Position", *columns)}
+            for row in rows:
+                position = int(row[at["Position"]])
+                if position in wanted:
+                    for name, (ref, read) in columns.items():
+                        table[(ref, read, position)] = float(row[at[name]])
+        except csv.Error as error:
+            raise RescaleError("Error while reading line %d: %s" % (rows.line_num, error))
+    return table
 
 
 def _phred_pval_to_raw(pval):

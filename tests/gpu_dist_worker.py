@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from mapdamage_amd import synth  # noqa: E402
 from mapdamage_amd.batch import concat_batches  # noqa: E402
-from mapdamage_amd.distributed import attach_rccl, reduce_engine_tables, shard_bounds  # noqa: E402
+from mapdamage_amd.distributed import adopt_torch_rccl, attach_rccl, reduce_engine_tables, shard_bounds  # noqa: E402
 from mapdamage_amd.engine import BadReadError, DamageEngine, MdxError  # noqa: E402
 from tests.util import assert_tables_equal, oracle_tableset  # noqa: E402
 
@@ -46,8 +46,9 @@ def main():
             assert total.misincorporation_text() == want.misincorporation_text()
             assert total.lgdistribution_text() == want.lgdistribution_text()
             # the same totals through the library's own communicator (collective finish)
+            assert eng.comm_count() == 0
             attach_rccl(eng)
-            assert eng.comm_size == world
+            assert eng.comm_size == world and eng.comm_count() == world     # (ncclCommCount of the library's own communicator)
             total2 = eng.finish()
             assert_tables_equal(total2, want)
             assert total2.lgdistribution_text() == want.lgdistribution_text()
@@ -58,6 +59,18 @@ def main():
             eng.sync()
             total3 = eng.unpack_tables(words.cpu().numpy().view(np.uint64), total2.lgd_over)
             assert_tables_equal(total3, want)
+
+    # the C-ABI reduction over the communicator torch itself uses (mdx_comm_adopt)
+    want = oracle_tableset(ref, batch, libs, L, A, 0, lgd_max)
+    with DamageEngine(libs, L, A, 0, lgd_max=lgd_max, device=local) as eng:
+        eng.set_reference(ref)
+        eng.tabulate(batch.slice(lo, hi))
+        if adopt_torch_rccl(eng, dev):
+            assert eng.comm_size == world and eng.comm_count() == world
+            assert_tables_equal(eng.finish(), want)
+            adopted = "adopted"
+        else:
+            adopted = "no _comm_ptr in this torch"
 
     # a record past its contig end on the last rank: every rank raises
     with DamageEngine(libs, L, A, 0, lgd_max=lgd_max, device=local) as eng:
@@ -86,7 +99,7 @@ def main():
         dbatch.free()
     dist.barrier()
     if rank == 0:
-        print("gpu dist ok: world=%d kept=%d" % (world, total.n_kept))
+        print("gpu dist ok: world=%d kept=%d torch communicator: %s" % (world, total.n_kept, adopted))
     dist.destroy_process_group()
 
 
