@@ -112,7 +112,6 @@ struct mdx_ctx {
     int st_turn = 0;
     int64_t record_base = 0;   // added to the batch index of a record in the error word (mdx_set_record_base)
     DevBuf unpacked;       // ASCII copy of a 4-bit SEQ column, for the launches the packed kernel does not take
-    DevBuf ev_ovf;         // per-wavefront event overflow lists of the packed kernel (MdxTabArgs::ev_ovf)
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
     DevBuf rs_part;        // per-block summary counters of the rescale kernel (MdxRescaleArgs::subs_part)
     DevBuf rs_lists;       // per-wavefront lists of the records left to rescale_walk_kernel (MdxRescaleArgs::gen_list)
@@ -292,7 +291,6 @@ void mdx_destroy(mdx_ctx *c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->lists.release();
     c->unpacked.release();
-    c->ev_ovf.release();
     c->rs_part.release();
     c->rs_lists.release();
     c->rs_in.release();
@@ -530,11 +528,6 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.tile_ctr = c->d_tile_ctr;
             HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16));
             a.lists = (uint4 *)c->lists.p;
-            if (packed) {
-                a.ev_ovf_cap = mdx_pk_ovf_cap(a.dims);
-                HIP_TRY(c, c->ev_ovf.reserve((size_t)nwaves * (size_t)a.ev_ovf_cap * 20));
-                a.ev_ovf = (uint32_t *)c->ev_ovf.p;
-            }
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {

@@ -185,18 +185,12 @@ struct MdxTabArgs {
     // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
     uint32_t *tile_ctr;
     int tile_quota;
-    // Packed kernel: the events (20 bytes, five words) beyond the wavefront's queue in the LDS go to its stretch of this
-    // list: ev_ovf_cap events per wavefront, enough for every lane of a run's steps (a tile over an assembly gap)
-    uint32_t *ev_ovf;
-    int64_t ev_ovf_cap;
 };
-// events of the packed kernel a wavefront's LDS queue holds (the event queue area: EVQ_BYTES of mdx_kernels.hip)
-#define MDX_PK_QCAP 64
-static inline int64_t mdx_pk_ovf_cap(const MdxDims &d) {
-    // (a run of 64 entries of one strand: 64 / H4 steps, every lane of every step)
-    const int steps = d.H4 > 0 ? (64 + d.H4 - 1) / d.H4 + 1 : 0;
-    return (int64_t)64 * steps + 128;
-}
+// events (12 bytes: a half lane) of the packed kernel a wavefront's LDS queue holds (MDX_PK_EVQ_BYTES of mdx_kernels.hip);
+// at least 64: the events of a half step fit an empty queue
+#ifndef MDX_PK_QCAP
+#define MDX_PK_QCAP 192
+#endif
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };
 

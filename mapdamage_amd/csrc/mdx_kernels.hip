@@ -125,6 +125,7 @@ typedef long long i64;
 #endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
+#define MDX_PK_EVQ_BYTES (MDX_PK_QCAP * 12)   // the packed kernel's: S[QCAP] | R[QCAP] | W[QCAP], one dword each
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -182,7 +183,7 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 int mdx_k_pk_block_threads() { return MDX_PK_BLOCK; }
 int mdx_k_pk_blocks_per_cu() { return MDX_PK_WPS * 256 / MDX_PK_BLOCK; }
 int mdx_k_pk_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_PK_BLOCK / 64) * mdx_stage_entries(d) * 4; }
-size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * EVQ_BYTES + LT_BYTES; }
+size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * MDX_PK_EVQ_BYTES + LT_BYTES; }
 int mdx_k_fuse_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_FUSE_BLOCK / 64) * mdx_stage_entries(d) * 4; }
 int mdx_k_fuse_tcb_off(const MdxDims &d) {
     const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * EVQ_BYTES + LT_BYTES;
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 
     // nine-entry LDS table of byte masks (entry n = the low n bytes of a 64-bit word set): the per-record byte masks
     // of the partial steps are two or three lookups instead of 64-bit shifts
-    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (BLOCK / 64) * EVQ_BYTES);
+    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (BLOCK / 64) * (PK ? MDX_PK_EVQ_BYTES : EVQ_BYTES));
     // RS: the fused records count into a TC table of their own (the reference bases of their columns are part of the
     // rescale summary, rescale.py:142-143), added to the first one at block end; behind it four words for those counts,
     // the lookup table and the terms of the model
@@ -652,12 +653,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // words: its read nibbles, its reference nibbles, and [5:0] lane | [6] side | [10:7] the lane's first window nibble / 16 |
     // [11] reverse strand | [12] single-deletion entry, then [15:13] = deleted bases g and [20:16] = first nibble of the lane
     // behind the deletion (right side: the nibbles below it) | [21] the lane's upper half.  S[QCAP] | R[QCAP] | W[QCAP] in the
-    // event area; what a run raises beyond MDX_PK_QCAP goes to the wavefront's stretch of MdxTabArgs::ev_ovf (qovf events).
-    // Nothing is drained inside a run: the drain's registers would be the hot loop's.
-    u32 *const qE = (u32 *)qS;
-    static_assert(!PK || MDX_PK_QCAP * 12 <= EVQ_BYTES, "the LDS event queue");
-    u32 *const ev_ovf_w = PK ? a.ev_ovf + (size_t)gwave * (size_t)a.ev_ovf_cap * 3 : nullptr;
-    int qovf = 0;
+    // wavefront's event area (MDX_PK_QCAP events).  The queue is drained behind a run once 64 events wait, and inside one
+    // only when a half step's events would not fit (a tile over a stretch of mismatches).  Nothing in a run stores to
+    // global memory: with a store possibly pending the compiler waits for vmcnt(0) at the head of the pipelined loop —
+    // loads and stores share the counter and may retire out of order — instead of for the oldest step's loads only.
+    u32 *const qE = PK ? lds + a.queue_off + wave * (MDX_PK_EVQ_BYTES / 4) : (u32 *)qS;
+    static_assert(MDX_PK_QCAP >= 64, "a half step's events fit an empty queue");
     // PK: the bit-sliced counters of this lane's sixteen window nibbles (bit 4 j + k of plane i, low / high dword = nibbles
     // 0-7 / 8-15: bit i of the count of base k at nibble j; the lane's slot fixes the strand) and the steps added since they
     // were last folded into TC (at most 255: eight planes)
@@ -804,20 +805,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     auto drain_all = [&]() {
         if (PK) {
             // the packed kernel's events, 64 half lanes at a time; only a nibble that holds a base was counted
-            const int n = qcount, no = qovf;
-            const u32 *const ovf = ev_ovf_w;
-            if (no) {
-                // (the wavefront's own stores to its overflow list: complete before they are read back)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
+            const int n = qcount;
 #pragma unroll 1
-            for (int base = 0; base < n + no; base += 64) {
+            for (int base = 0; base < n; base += 64) {
                 const int i = base + lane;
-                if (i < n + no) {
-                    u32 s8, r8, w;
-                    if (i < n) { s8 = qE[i]; r8 = qE[MDX_PK_QCAP + i]; w = qE[2 * MDX_PK_QCAP + i]; }
-                    else { const u32 *e = ovf + 3u * (u32)(i - n); s8 = e[0]; r8 = e[1]; w = e[2]; }
+                if (i < n) {
+                    const u32 s8 = qE[i], r8 = qE[MDX_PK_QCAP + i], w = qE[2 * MDX_PK_QCAP + i];
                     const int ln = (int)w & 63, side = (int)(w >> 6) & 1, m16 = (int)((w >> 7) & 15u) << 4, rev = (int)(w >> 11) & 1;
                     const bool del = (w >> 12) & 1u;
                     const int g = del ? (int)(w >> 13) & 7 : 0, bnd = (int)(w >> 16) & 31, half = (int)(w >> 21) & 1;
@@ -848,7 +841,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 }
             }
-            qovf = 0;
             qcount = 0;
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             return;
@@ -1133,7 +1125,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (bs_steps + nsteps4 > 255) bs_flush();
                 bs_steps += nsteps4;
                 const int base_l = e0 + (p_strand ? nP_ : 0) + c_slot, lim_l = (p_strand ? nM_ : nP_) - c_slot;
-                struct St16 { u32x3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
+                // (one <3 x i32> load per operand: a struct of three words is taken apart and put together again as the
+                // vectorizer likes — two overlapping dwordx2 loads at times)
+                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
                 auto fill16 = [&](St16 &st) {
                     st.valid = kf < nsteps4;
                     const int k = st.valid ? kf : nsteps4 - 1;
@@ -1183,16 +1177,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                     // sixteen nibbles from bit 4 (offset & 7) of the aligned dword triple
                     st.ra = ro << 2; st.sa = so << 2;
-                    st.r = *(const u32x3 *)(refW + ((ro >> 1) & ~3u));
-                    st.s = *(const u32x3 *)(seqW + ((so >> 1) & ~3u));
+                    st.r = *(const u32v3_u *)(refW + ((ro >> 1) & ~3u));
+                    st.s = *(const u32v3_u *)(seqW + ((so >> 1) & ~3u));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
                 };
-                // one step: X = the nibbles this step counts (one-hot codes: the increments themselves)
+                // one step: X = the nibbles this step counts (one-hot codes: the increments themselves).  A step whose events do
+                // not fit the queue does nothing and reports itself (ovf, kredo): the run stops behind the group, drains and
+                // starts again from that step
+                bool ovf = false;
+                int kredo = 0;
                 auto count16 = [&](const St16 &st, auto full_tag, u32 &Xlo, u32 &Xhi) {
                     constexpr bool FULL = decltype(full_tag)::value;
                     u32 s_lo = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa), s_hi = __builtin_amdgcn_alignbit(st.s.z, st.s.y, st.sa);
                     u32 r_lo = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra), r_hi = __builtin_amdgcn_alignbit(st.r.z, st.r.y, st.ra);
                     u32 evw = c_evw;
+                    u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
                         if (!FULL) {
@@ -1225,29 +1224,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             if (KIND == STEP_GD) {
                                 s64 = m;
                                 // nibbles behind the deletion (left: from tb on, right: below ta): MIS[column][base] and
-                                // CMP[column - g][base] by position instead of the counters
+                                // CMP[column - g][base] by position instead of the counters (below)
                                 const u64 beh = (Xk & sm) | (~Yk & ~sm);
-                                const u64 dmk = dyn & beh;
+                                dmk = dyn & beh;
                                 evw |= 0x1000u | ((st.aux2 & 7u) << 13) | ((st.aux2 >> 3) << 16);
-                                if (__ballot(dmk != 0ull)) {
-                                    // (a rolled loop, one nibble at a time in position order — nibble j on the left side,
-                                    // 15 - j on the right: these steps are rare, their registers are the kernel's)
-                                    const int g = (int)(st.aux2 & 7u);
-                                    const int rev = (int)(st.pk >> 31);
-                                    const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
-                                    u32 *pm = lds + d.off_mis() + __mul24(row, 25), *pc = lds + d.off_cmp() + (row - g) * 4;
-                                    u64 rr = c_side ? __builtin_bitreverse64(r64) : r64, dd = c_side ? __builtin_bitreverse64(dmk) : dmk;
-#pragma unroll 1
-                                    for (int j = 0; j < 16; j++) {
-                                        // (right side: the bits of a nibble are reversed too — class k is bit 3 - k)
-                                        const u32 nib = (u32)rr & 15u;
-                                        const bool on = ((u32)dd & 15u) != 0u && nib != 0u && (nib & (nib - 1u)) == 0u;
-                                        const int k0 = __ffs((int)nib) - 1;
-                                        const int k = on ? (c_side ? 3 - k0 : k0) : 0;
-                                        if (on) { atomicAdd(pm + k, 1u); atomicAdd(pc + k, 1u); }
-                                        rr >>= 4; dd >>= 4; pm += 25; pc += 4;
-                                    }
-                                }
                                 s64 &= dyn; r64 &= dyn;
                                 X64 = r64 & ~beh;
                             } else {
@@ -1259,43 +1239,60 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         s_lo = (u32)s64; s_hi = (u32)(s64 >> 32); r_lo = (u32)r64; r_hi = (u32)(r64 >> 32);
                         Xlo = (u32)X64; Xhi = (u32)(X64 >> 32);
                     }
-                    // the half lanes holding a nibble that is not a plain match queue their two dwords (see qE): a step's events
-                    // go to the LDS queue if they all fit, else to the wavefront's overflow list
+                    // the half lanes holding a nibble that is not a plain match queue their two dwords (see qE)
                     const u32 x_lo = (s_lo ^ r_lo) & c_em_lo, x_hi = (s_hi ^ r_hi) & c_em_hi;
                     if (__ballot((x_lo | x_hi) != 0u)) {
-#pragma unroll
-                        for (int half = 0; half < 2; half++) {
-                            const bool ev = (half ? x_hi : x_lo) != 0u;
-                            const u64 mm = __ballot(ev);
-                            if (mm) {
-                                const int n = __popcll(mm);
-                                // (the read nibbles that are not read columns are queued as copies of the reference's: the drain
-                                // finds the columns that differ by an XOR, without the lane's masks)
-                                const u32 e_r = half ? r_hi : r_lo, e_m = half ? c_em_hi : c_em_lo;
-                                const u32 e_s = ((half ? s_hi : s_lo) & e_m) | (e_r & ~e_m), e_w = evw | ((u32)half << 21);
-                                if (qcount + n <= MDX_PK_QCAP) {
-                                    if (ev) { const int slot = mbcnt64(mm, qcount); qE[slot] = e_s; qE[MDX_PK_QCAP + slot] = e_r; qE[2 * MDX_PK_QCAP + slot] = e_w; }
-                                    qcount += n;
-                                } else {
-                                    if (ev) { u32 *e = ev_ovf_w + 3u * (u32)mbcnt64(mm, qovf); e[0] = e_s; e[1] = e_r; e[2] = e_w; }
-                                    qovf += n;
-                                }
-                            }
+                        const bool e0 = x_lo != 0u, e1 = x_hi != 0u;
+                        const u64 m0 = __ballot(e0), m1 = __ballot(e1);
+                        const int n0 = __popcll(m0), n = n0 + __popcll(m1);
+                        if (qcount + n > MDX_PK_QCAP) {
+                            ovf = true; kredo = st.k;
+                            Xlo = 0u; Xhi = 0u;
+                            return;
+                        }
+                        // (the read nibbles that are not read columns are queued as copies of the reference's: the drain
+                        // finds the columns that differ by an XOR, without the lane's masks)
+                        if (e0) {
+                            const int slot = mbcnt64(m0, qcount);
+                            qE[slot] = (s_lo & c_em_lo) | (r_lo & ~c_em_lo); qE[MDX_PK_QCAP + slot] = r_lo; qE[2 * MDX_PK_QCAP + slot] = evw;
+                        }
+                        if (e1) {
+                            const int slot = mbcnt64(m1, qcount + n0);
+                            qE[slot] = (s_hi & c_em_hi) | (r_hi & ~c_em_hi); qE[MDX_PK_QCAP + slot] = r_hi; qE[2 * MDX_PK_QCAP + slot] = evw | (1u << 21);
+                        }
+                        qcount += n;
+                    }
+                    if (KIND == STEP_GD && __ballot(dmk != 0ull)) {
+                        // (a rolled loop, one nibble at a time in position order — nibble j on the left side,
+                        // 15 - j on the right: these steps are rare, their registers are the kernel's)
+                        const u64 r64 = (u64)r_lo | ((u64)r_hi << 32);
+                        const int g = (int)(st.aux2 & 7u);
+                        const int rev = (int)(st.pk >> 31);
+                        const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
+                        u32 *pm = lds + d.off_mis() + __mul24(row, 25), *pc = lds + d.off_cmp() + (row - g) * 4;
+                        u64 rr = c_side ? __builtin_bitreverse64(r64) : r64, dd = c_side ? __builtin_bitreverse64(dmk) : dmk;
+#pragma unroll 1
+                        for (int j = 0; j < 16; j++) {
+                            // (right side: the bits of a nibble are reversed too — class k is bit 3 - k)
+                            const u32 nib = (u32)rr & 15u;
+                            const bool on = ((u32)dd & 15u) != 0u && nib != 0u && (nib & (nib - 1u)) == 0u;
+                            const int k0 = __ffs((int)nib) - 1;
+                            const int k = on ? (c_side ? 3 - k0 : k0) : 0;
+                            if (on) { atomicAdd(pm + k, 1u); atomicAdd(pc + k, 1u); }
+                            rr >>= 4; dd >>= 4; pm += 25; pc += 4;
                         }
                     }
                 };
                 constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : MDX_PK_PD);
                 static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
                 St16 st[PD4];
-#pragma unroll
-                for (int dd = 0; dd < PD4; dd++) fill16(st[dd]);
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
                 // low and high dwords
                 auto group = [&](auto full_tag, const bool refill) {
                     u32 xl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, xh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) {
-                        if (refill || dd == 0 || st[dd].valid) count16(st[dd], full_tag, xl[dd], xh[dd]);
+                        if (!ovf && (refill || dd == 0 || st[dd].valid)) count16(st[dd], full_tag, xl[dd], xh[dd]);
                         if (refill) fill16(st[dd]);
                         if ((dd & 3) == 3 || dd == PD4 - 1) {
                             const u32 al[4] = {xl[dd & ~3], xl[(dd & ~3) + 1], xl[(dd & ~3) + 2], xl[(dd & ~3) + 3]};
@@ -1308,13 +1305,27 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 };
                 // (two loops over the same pipeline: the groups all of whose slots hold records, then the others; never the last
-                // step of the run)
-                int k = PD4;
-                for (; k < nsteps4 && k <= nfull; k += PD4) group(std::true_type{}, true);
-                for (; k < nsteps4; k += PD4) group(std::false_type{}, true);
-                group(std::false_type{}, false);
-                // (the only place the packed kernel drains: behind a run, once a few passes' worth of events wait)
-                if (qcount + qovf >= 64) drain_all();
+                // step of the run.  As a rule once through: again from step kredo, the queue drained, when that step's events
+                // did not fit)
+                // (nothing but these loads in flight in the loops below — the stores of the tile's phase 1 have had that phase to
+                // retire —: with a store possibly pending the head of the loop would wait for vmcnt(0))
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll 1
+                for (int kstart = 0;;) {
+                    kf = kstart;
+                    ovf = false;
+#pragma unroll
+                    for (int dd = 0; dd < PD4; dd++) fill16(st[dd]);
+                    int k = kstart + PD4;
+                    for (; k < nsteps4 && k <= nfull && !ovf; k += PD4) group(std::true_type{}, true);
+                    for (; k < nsteps4 && !ovf; k += PD4) group(std::false_type{}, true);
+                    if (!ovf) group(std::false_type{}, false);
+                    if (!ovf) break;
+                    drain_all();
+                    kstart = kredo;
+                }
+                // (where the packed kernel drains as a rule: behind a run, once a pass's worth of events waits)
+                if (qcount >= 64) drain_all();
                 return;
             }
 #if MDX_ENT_AHEAD
@@ -2443,7 +2454,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     }
 #endif
     if (FAST) {
-        if (qcount + qovf > 0) drain_all();
+        if (qcount > 0) drain_all();
         if (PK) bs_flush();
     }
     if (USE_LDS) {
