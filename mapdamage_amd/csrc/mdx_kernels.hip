@@ -118,7 +118,7 @@ typedef long long i64;
 #define MDX_PK_PREFETCH 0               // the packed kernel requests a tile's phase-1 loads a tile ahead (measured: no gain; 26 registers)
 #endif
 #ifndef MDX_PK_PD
-#define MDX_PK_PD 3                     // ... and of the packed kernel's complete runs
+#define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
 #endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
