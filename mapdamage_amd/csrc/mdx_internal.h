@@ -186,10 +186,10 @@ struct MdxTabArgs {
     uint32_t *tile_ctr;
     int tile_quota;
 };
-// events (12 bytes: a half lane) of the packed kernel a wavefront's LDS queue holds (MDX_PK_EVQ_BYTES of mdx_kernels.hip);
-// at least 64: the events of a half step fit an empty queue
+// events (20 bytes: a lane's sixteen read and reference nibbles and a word) of the packed kernel a wavefront's LDS queue
+// holds (MDX_PK_EVQ_BYTES of mdx_kernels.hip); at least 64: the events of a step fit an empty queue
 #ifndef MDX_PK_QCAP
-#define MDX_PK_QCAP 192
+#define MDX_PK_QCAP 112
 #endif
 
 enum { MDX_MODE_LDS = 0, MDX_MODE_GLOBAL = 1 };

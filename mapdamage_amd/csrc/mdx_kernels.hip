@@ -125,7 +125,8 @@ typedef long long i64;
 #endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
-#define MDX_PK_EVQ_BYTES (MDX_PK_QCAP * 12)   // the packed kernel's: S[QCAP] | R[QCAP] | W[QCAP], one dword each
+#define MDX_PK_EVQ_BYTES (MDX_PK_QCAP * 20)   // the packed kernel's: {read 8 B, reference 8 B}[QCAP] | W[QCAP]
+#define MDX_PK_TAB_BYTES 1024                 // ... and per block: the lanes' read-column masks (64 x 8 B), the symbol-pair table (256 x 2 B)
 #define COL_S 24
 #define ERR_BAD_READ 6
 // symbol classes on the device: 0..3 = A,C,T,G ((ascii >> 1) & 3), 4 = '-', 5 = anything else
@@ -183,7 +184,7 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 int mdx_k_pk_block_threads() { return MDX_PK_BLOCK; }
 int mdx_k_pk_blocks_per_cu() { return MDX_PK_WPS * 256 / MDX_PK_BLOCK; }
 int mdx_k_pk_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_PK_BLOCK / 64) * mdx_stage_entries(d) * 4; }
-size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * MDX_PK_EVQ_BYTES + LT_BYTES; }
+size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * MDX_PK_EVQ_BYTES + LT_BYTES + MDX_PK_TAB_BYTES; }
 int mdx_k_fuse_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_FUSE_BLOCK / 64) * mdx_stage_entries(d) * 4; }
 int mdx_k_fuse_tcb_off(const MdxDims &d) {
     const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * EVQ_BYTES + LT_BYTES;
@@ -429,18 +430,23 @@ __device__ __forceinline__ void lane_masks16(const MdxDims &d, int side, int m16
     }
 }
 // carry-save adder over 32 one-bit columns: p + a + b = p' + 2 c
+// (written out: the carry first, then the sum over p itself — left to the scheduler the sum comes first into a register of
+// its own and every plane is copied back at the end of the loop body: 37 v_mov per group of four steps)
 __device__ __forceinline__ void bs_csa(u32 &p, const u32 a, const u32 b, u32 &c) {
-    const u32 sum = __builtin_amdgcn_bitop3_b32(p, a, b, 0x96);      // p ^ a ^ b
-    c = __builtin_amdgcn_bitop3_b32(p, a, b, 0xE8);                  // majority
-    p = sum;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96"    // majority; p ^ a ^ b
+        : "=&v"(c), "+v"(p) : "v"(a), "v"(b));
+}
+// half adder: p + a = p' + 2 c
+__device__ __forceinline__ void bs_ha(u32 &p, const u32 a, u32 &c) {
+    asm("v_and_b32 %0, %1, %2\n\tv_xor_b32 %1, %1, %2" : "=&v"(c), "+v"(p) : "v"(a));
 }
 // c, a word of weight 2^from, into the planes from `from` upwards
 template <int FROM>
 __device__ __forceinline__ void bs_ripple(u32 (&p)[8], u32 c) {
 #pragma unroll
     for (int i = FROM; i < 8; i++) {
-        const u32 t = p[i] & c;
-        p[i] ^= c;
+        u32 t;
+        bs_ha(p[i], c, t);
         c = t;
     }
 }
@@ -453,7 +459,7 @@ __device__ __forceinline__ void bs_add_group(u32 (&pl)[8], const u32 (&x)[4]) {
     else {
         u32 c0, c1, c2;
         bs_csa(pl[0], x[0], x[1], c0);
-        if (N == 3) { c1 = pl[0] & x[2]; pl[0] ^= x[2]; }
+        if (N == 3) bs_ha(pl[0], x[2], c1);
         else bs_csa(pl[0], x[2], x[3], c1);
         bs_csa(pl[1], c0, c1, c2);
         bs_ripple<2>(pl, c2);
@@ -558,6 +564,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         if (FAST && !PK && threadIdx.x < 9) ltab[threadIdx.x] = threadIdx.x >= 8 ? ~0ull : ((1ull << (8 * threadIdx.x)) - 1ull);
         // (PK: seventeen 64-bit masks, entry n = the low n nibbles set)
         if (PK && threadIdx.x < 17) ltab[threadIdx.x] = threadIdx.x >= 16 ? ~0ull : ((1ull << (4 * threadIdx.x)) - 1ull);
+        // (PK: what the drain wants to know of a pair of nibbles, reference << 4 | read: [2:0] class of the reference symbol,
+        // [5:3] of the read symbol, [10:6] the MIS column of the pair — 31: none, statistics.py:26-35)
+        if (PK && threadIdx.x < 256) {
+            const int rc = cls4(threadIdx.x >> 4), sc = cls4(threadIdx.x & 15u);
+            const int col = (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) ? mis_col(rc, sc) : 31;
+            ((u16 *)(ltab + 17 + 64))[threadIdx.x] = (u16)(rc | (sc << 3) | (col << 6));
+        }
         if (RS) {
             for (int i = threadIdx.x; i < d.nlib * d.w_tc + 4; i += BLOCK) lds[a.rs.tcb_off + i] = 0;
             for (int i = threadIdx.x; i < 2 * rs_npos * 94; i += BLOCK) ((u8 *)(rs_cnt + 4))[i] = a.rs.lut[i];
@@ -610,6 +623,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             c_em_lo = (u32)em; c_em_hi = (u32)(em >> 32);
         }
         c_evw = (u32)lane | ((u32)c_side << 6) | ((u32)(c_m8 >> 4) << 7) | ((u32)p_strand << 11);
+        // (the read-column masks by lane, for the drain; every wavefront writes the same words and reads them after its own write)
+        ltab[17 + lane] = (u64)c_em_lo | ((u64)c_em_hi << 32);
     }
     if (FAST && !PK) {
         const int g = lane / d.G, ll = lane - g * d.G;
@@ -649,16 +664,20 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     u32x2 *const qR = qS + EVQ_CAP;
     u32 *const qW = (u32 *)(qR + EVQ_CAP);
     int qcount = 0;
-    // PK: an event is a half lane (eight nibbles, one dword of each string) with a nibble that is not a plain match, three
-    // words: its read nibbles, its reference nibbles, and [5:0] lane | [6] side | [10:7] the lane's first window nibble / 16 |
-    // [11] reverse strand | [12] single-deletion entry, then [15:13] = deleted bases g and [20:16] = first nibble of the lane
-    // behind the deletion (right side: the nibbles below it) | [21] the lane's upper half.  S[QCAP] | R[QCAP] | W[QCAP] in the
-    // wavefront's event area (MDX_PK_QCAP events).  The queue is drained behind a run once 64 events wait, and inside one
-    // only when a half step's events would not fit (a tile over a stretch of mismatches).  Nothing in a run stores to
-    // global memory: with a store possibly pending the compiler waits for vmcnt(0) at the head of the pipelined loop —
-    // loads and stores share the counter and may retire out of order — instead of for the oldest step's loads only.
-    u32 *const qE = PK ? lds + a.queue_off + wave * (MDX_PK_EVQ_BYTES / 4) : (u32 *)qS;
-    static_assert(MDX_PK_QCAP >= 64, "a half step's events fit an empty queue");
+    // PK: an event is a lane (sixteen nibbles) with a read column that is not a plain match, five words: its read nibbles, its
+    // reference nibbles (as the step saw them: outside the step's tasks both are zero), and [5:0] lane | [6] side |
+    // [10:7] the lane's first window nibble / 16 | [11] reverse strand | [12] single-deletion entry, then [15:13] = deleted
+    // bases g and [20:16] = first nibble of the lane behind the deletion (right side: the nibbles below it).
+    // {S, R}[QCAP] | W[QCAP] in the wavefront's event area (MDX_PK_QCAP events).  The queue is drained behind a run once
+    // 64 events wait, and inside one only when a step's events would not fit (a tile over a stretch of mismatches).
+    // Nothing in a run stores to global memory: with a store possibly pending the compiler waits for vmcnt(0) at the head
+    // of the pipelined loop — loads and stores share the counter and may retire out of order — instead of for the oldest
+    // step's loads only.
+    uint4 *const qQ = (uint4 *)(lds + a.queue_off + (PK ? wave * (MDX_PK_EVQ_BYTES / 4) : 0));
+    u32 *const qE = (u32 *)(qQ + MDX_PK_QCAP);
+    static_assert(MDX_PK_QCAP >= 64 && MDX_PK_QCAP % 4 == 0, "a step's events fit an empty queue");
+    const u32x2 *const emtab = (const u32x2 *)(ltab + 17);
+    const u16 *const pktab = (const u16 *)(ltab + 17 + 64);
     // PK: the bit-sliced counters of this lane's sixteen window nibbles (bit 4 j + k of plane i, low / high dword = nibbles
     // 0-7 / 8-15: bit i of the count of base k at nibble j; the lane's slot fixes the strand) and the steps added since they
     // were last folded into TC (at most 255: eight planes)
@@ -667,6 +686,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // fold the planes into the block's TC table, PK layout: word [base k][64 j + lane]; per bit position s of the bytes of
     // a plane, the four counters of bits s, s + 8, s + 16, s + 24 are gathered as the bytes of one word
     auto bs_flush = [&]() {
+#ifdef MDX_ABL_NOFLUSH       // (ablation builds — wrong tables, the instruction counts of what is left: tools/ablate.sh)
+        bs_steps = 0;
+        return;
+#endif
         if (PK) {
             u32 *const tcp = lds + d.off_tc() + lane;
 #pragma unroll
@@ -802,25 +825,34 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         }
         return mr;
     };
-    auto drain_all = [&]() {
+    // (PK: the events from `lo` on — behind a run lo = qcount % 64: full passes only, the rest waits for company)
+    auto drain_all = [&](const int lo = 0) {
         if (PK) {
-            // the packed kernel's events, 64 half lanes at a time; only a nibble that holds a base was counted
+#ifdef MDX_ABL_NODRAIN
+            qcount = lo;
+            return;
+#endif
+            // the packed kernel's events, 64 lanes at a time; only a nibble that holds a base was counted
             const int n = qcount;
 #pragma unroll 1
-            for (int base = 0; base < n; base += 64) {
+            for (int base = lo; base < n; base += 64) {
                 const int i = base + lane;
                 if (i < n) {
-                    const u32 s8 = qE[i], r8 = qE[MDX_PK_QCAP + i], w = qE[2 * MDX_PK_QCAP + i];
+                    const uint4 q = qQ[i];          // read nibbles (x, y), reference nibbles (z, w)
+                    const u32 w = qE[i];
                     const int ln = (int)w & 63, side = (int)(w >> 6) & 1, m16 = (int)((w >> 7) & 15u) << 4, rev = (int)(w >> 11) & 1;
                     const bool del = (w >> 12) & 1u;
-                    const int g = del ? (int)(w >> 13) & 7 : 0, bnd = (int)(w >> 16) & 31, half = (int)(w >> 21) & 1;
-                    u32 x = s8 ^ r8;        // (only read columns differ: the step has seen to it)
+                    const int g = del ? (int)(w >> 13) & 7 : 0, bnd = (int)(w >> 16) & 31;
+                    const u32x2 em = emtab[ln];
+                    const u64 s64 = (u64)q.x | ((u64)q.y << 32), r64 = (u64)q.z | ((u64)q.w << 32);
+                    u64 x = (s64 ^ r64) & ((u64)em.x | ((u64)em.y << 32));      // the read columns that differ
                     const int b_mis = d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = d.off_cmp() + (rev ? 2 * L * 4 : 0);
                     // usually exactly one nibble differs: the lowest one (all lanes busy), again while some lane has another
                     while (x) {
-                        const int sh = (__ffs((int)x) - 1) & ~3, jb = 8 * half + (sh >> 2);
-                        x &= ~(15u << sh);
-                        const int sc = cls4((s8 >> sh) & 15u), rc = cls4((r8 >> sh) & 15u);
+                        const int sh = (__ffsll((long long)x) - 1) & ~3, jb = sh >> 2;
+                        x &= ~(15ull << sh);
+                        const u32 t = pktab[((u32)(r64 >> sh) & 15u) << 4 | ((u32)(s64 >> sh) & 15u)];
+                        const int rc = (int)(t & 7u), sc = (int)((t >> 3) & 7u), col = (int)(t >> 6);
                         const int p = (side ? m16 + 15 - jb : m16 + jb) - A;
                         // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
                         // CMP[p - g] (its query index) instead of the lane's counters
@@ -837,11 +869,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         }
                         // what the column really is (rare_column): the read base, and a substitution / indel
                         if (sc < 4) atomicAdd(&lds[b_cmp + spc * 4 + sc], 1u);
-                        if (sc <= SYM_GAP && rc <= SYM_GAP && rc != sc) atomicAdd(&lds[b_mis + __mul24(sp, 25) + mis_col(rc, sc)], 1u);
+                        if (col != 31) atomicAdd(&lds[b_mis + __mul24(sp, 25) + col], 1u);
                     }
                 }
             }
-            qcount = 0;
+            qcount = lo;
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             return;
         }
@@ -1239,26 +1271,25 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         s_lo = (u32)s64; s_hi = (u32)(s64 >> 32); r_lo = (u32)r64; r_hi = (u32)(r64 >> 32);
                         Xlo = (u32)X64; Xhi = (u32)(X64 >> 32);
                     }
-                    // the half lanes holding a nibble that is not a plain match queue their two dwords (see qE)
+                    // the lanes holding a read column that is not a plain match queue their four dwords (see qQ)
                     const u32 x_lo = (s_lo ^ r_lo) & c_em_lo, x_hi = (s_hi ^ r_hi) & c_em_hi;
-                    if (__ballot((x_lo | x_hi) != 0u)) {
-                        const bool e0 = x_lo != 0u, e1 = x_hi != 0u;
-                        const u64 m0 = __ballot(e0), m1 = __ballot(e1);
-                        const int n0 = __popcll(m0), n = n0 + __popcll(m1);
+                    const bool ev = (x_lo | x_hi) != 0u;
+#ifdef MDX_ABL_NOEVQ
+                    const u64 mm = 0ull;
+#else
+                    const u64 mm = __ballot(ev);
+#endif
+                    if (mm) {
+                        const int n = __popcll(mm);
                         if (qcount + n > MDX_PK_QCAP) {
                             ovf = true; kredo = st.k;
                             Xlo = 0u; Xhi = 0u;
                             return;
                         }
-                        // (the read nibbles that are not read columns are queued as copies of the reference's: the drain
-                        // finds the columns that differ by an XOR, without the lane's masks)
-                        if (e0) {
-                            const int slot = mbcnt64(m0, qcount);
-                            qE[slot] = (s_lo & c_em_lo) | (r_lo & ~c_em_lo); qE[MDX_PK_QCAP + slot] = r_lo; qE[2 * MDX_PK_QCAP + slot] = evw;
-                        }
-                        if (e1) {
-                            const int slot = mbcnt64(m1, qcount + n0);
-                            qE[slot] = (s_hi & c_em_hi) | (r_hi & ~c_em_hi); qE[MDX_PK_QCAP + slot] = r_hi; qE[2 * MDX_PK_QCAP + slot] = evw | (1u << 21);
+                        if (ev) {
+                            const int slot = mbcnt64(mm, qcount);
+                            qQ[slot] = make_uint4(s_lo, s_hi, r_lo, r_hi);
+                            qE[slot] = evw;
                         }
                         qcount += n;
                     }
@@ -1294,7 +1325,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     for (int dd = 0; dd < PD4; dd++) {
                         if (!ovf && (refill || dd == 0 || st[dd].valid)) count16(st[dd], full_tag, xl[dd], xh[dd]);
                         if (refill) fill16(st[dd]);
+#ifdef MDX_ABL_NOCSA
+                        bsL[0] |= xl[dd]; bsH[0] |= xh[dd];
+                        if (false) {
+#else
                         if ((dd & 3) == 3 || dd == PD4 - 1) {
+#endif
                             const u32 al[4] = {xl[dd & ~3], xl[(dd & ~3) + 1], xl[(dd & ~3) + 2], xl[(dd & ~3) + 3]};
                             const u32 ah[4] = {xh[dd & ~3], xh[(dd & ~3) + 1], xh[(dd & ~3) + 2], xh[(dd & ~3) + 3]};
                             if ((dd & 3) == 3) { bs_add_group<4>(bsL, al); bs_add_group<4>(bsH, ah); }
@@ -1324,8 +1360,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     drain_all();
                     kstart = kredo;
                 }
-                // (where the packed kernel drains as a rule: behind a run, once a pass's worth of events waits)
-                if (qcount >= 64) drain_all();
+                // (where the packed kernel drains as a rule: behind a run, once a pass's worth of events waits — whole passes)
+                if (qcount >= 64) drain_all(qcount & 63);
                 return;
             }
 #if MDX_ENT_AHEAD
@@ -2386,7 +2422,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (PK: the general pass is where the kernel wants the most registers: the bit-sliced counters are folded
                 // into TC in front of it — every dozen tiles, about as often as their eight planes ask for anyway — and
                 // are not live across it)
+#ifdef MDX_PK_FLUSH_GENERAL
                 if (PK) bs_flush();
+#endif
                 // (the wavefront's own stores: complete before they are read back)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
