@@ -1294,23 +1294,22 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         qcount += n;
                     }
                     if (KIND == STEP_GD && __ballot(dmk != 0ull)) {
-                        // (a rolled loop, one nibble at a time in position order — nibble j on the left side,
-                        // 15 - j on the right: these steps are rare, their registers are the kernel's)
-                        const u64 r64 = (u64)r_lo | ((u64)r_hi << 32);
+                        // one nibble at a time in position order — nibble j on the left side, 15 - j on the right (whose bits
+                        // are reversed too: class k is bit 3 - k) —, unrolled: the class of the (one-hot or zero) nibble picks
+                        // the word of the row
+                        const u64 r64 = ((u64)r_lo | ((u64)r_hi << 32)) & dmk;
                         const int g = (int)(st.aux2 & 7u);
                         const int rev = (int)(st.pk >> 31);
                         const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;        // row of the lane's lowest position
-                        u32 *pm = lds + d.off_mis() + __mul24(row, 25), *pc = lds + d.off_cmp() + (row - g) * 4;
-                        u64 rr = c_side ? __builtin_bitreverse64(r64) : r64, dd = c_side ? __builtin_bitreverse64(dmk) : dmk;
-#pragma unroll 1
+                        u32 *const pm = lds + d.off_mis() + __mul24(row, 25), *const pc = lds + d.off_cmp() + (row - g) * 4;
+                        const u64 rr = c_side ? __builtin_bitreverse64(r64) : r64;
+                        const u32 kx = c_side ? 3u : 0u;
+#pragma unroll
                         for (int j = 0; j < 16; j++) {
-                            // (right side: the bits of a nibble are reversed too — class k is bit 3 - k)
-                            const u32 nib = (u32)rr & 15u;
-                            const bool on = ((u32)dd & 15u) != 0u && nib != 0u && (nib & (nib - 1u)) == 0u;
-                            const int k0 = __ffs((int)nib) - 1;
-                            const int k = on ? (c_side ? 3 - k0 : k0) : 0;
-                            if (on) { atomicAdd(pm + k, 1u); atomicAdd(pc + k, 1u); }
-                            rr >>= 4; dd >>= 4; pm += 25; pc += 4;
+                            const u32 nib = __builtin_amdgcn_ubfe(j < 8 ? (u32)rr : (u32)(rr >> 32), 4 * (j & 7), 4);
+                            const u32 k = (u32)(__ffs((int)nib) - 1) ^ kx;
+                            // (only the lanes that count take part: an add of 0 costs the LDS what an add of 1 costs)
+                            if (nib) { atomicAdd(pm + 25 * j + k, 1u); atomicAdd(pc + 4 * j + k, 1u); }
                         }
                     }
                 };
