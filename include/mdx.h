@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 2   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format */
+#define MDX_ABI_VERSION 3   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -36,7 +36,7 @@ extern "C" {
                                      contig end (pysam ValueError from align.py:33 / main.py:180),
                                      tid/library out of range, CIGAR/SEQ length mismatch */
 
-#define MDX_ERR_UNSUPPORTED (-8)  /* mdx_gbam_*: a file layout the GPU decode path does not take (use mdx_bam_*) */
+#define MDX_ERR_UNSUPPORTED (-8)  /* mdx_gbam_*: something the GPU decode path does not take (use mdx_bam_*, from mdx_gbam_tell on) */
 #define MDX_ERR_COMM (-7)         /* RCCL failure, or another rank of the communicator reported an error */
 
 /* Optional hint in the `flag` column (a bit SAM does not define): every base quality of the record is at least
@@ -294,6 +294,9 @@ typedef struct mdx_bam_stream mdx_bam_stream;
 int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out);
 const mdx_bam *mdx_bam_stream_header(const mdx_bam_stream *stream);
 int mdx_bam_next(mdx_bam_stream *stream, int64_t chunk_bytes, mdx_bam **out);
+/* Points the stream at the BGZF block at compressed offset comp_off; the next chunk starts with the record `phase`
+ * inflated bytes into that block (the pair mdx_gbam_tell hands out; 0, 0 of a file's first record block rewinds). */
+int mdx_bam_seek(mdx_bam_stream *stream, int64_t comp_off, int64_t phase);
 void mdx_bam_close(mdx_bam_stream *stream);
 /* Rewriting a BAM (the `--rescale-only` output of mapdamage/rescale.py:285-365, which writes every record back
  * through pysam): with mdx_bam_stream_keep_raw(stream, 1) each chunk keeps its encoded records as they stood in
@@ -318,8 +321,13 @@ int mdx_table_mode(const mdx_ctx *ctx);
  * accessors).  mdx_gbam_configure: the header's read-group ids with the library of each, the library of a record
  * without RG tag (-1: none — such a record gets library 0xFFFF, MDX_ERR_BAD_READ at mdx_sync if it is one the kernel
  * counts, as is a read group the header does not list), and whether the quality and mate columns are wanted.
- * Every BGZF block must start at a record (htslib writes them so: bgzf_flush_try in bam_write1) and the header must
- * fill blocks of its own: any other layout is MDX_ERR_UNSUPPORTED, and the caller decodes on the host instead.  The
+ * Any BGZF layout is taken: htslib starts every block at a record and flushes the header into blocks of its own
+ * (bgzf_flush_try in bam_write1); htsjdk / Picard, sambamba and biobambam fill their blocks whatever the record
+ * boundaries.  The inflated blocks of a slab lie back to back in HBM, every block guesses where its first record
+ * starts, and a guess counts only if the chain of records in front of it ends there (a block whose guess was wrong is
+ * scanned again: mdx_gbam_fixups); a slab's batch holds the records that START in it — the blocks behind it are inflated
+ * as far as its last record reaches.  MDX_ERR_UNSUPPORTED is what is left: a record longer than a gigabyte, and (see
+ * mdx_gbam_skip) a sharded run over a file whose record boundaries cannot be told without the slab in front.  The
  * CRC32 of every block is checked on the device, like its ISIZE (MDX_ERR_ARG, as in the host decoder).
  * chunk_bytes: compressed bytes per slab.  mdx_gbam_next at the end of the file: MDX_OK, n_reads 0,
  * mdx_gbam_at_end 1.  mdx_ctx_stream: the HIP stream (hipStream_t) and device the context works on. */
@@ -345,6 +353,14 @@ int mdx_gbam_at_end(const mdx_gbam *g);
  * run over several GPUs (one process and one mdx_gbam per GPU) rank r decodes the slabs r, r + N, ... and skips
  * the others — the loop of mapdamage/main.py:165-217 sharded by record with no exchange until the tables are summed. */
 int mdx_gbam_skip(mdx_gbam *g, int64_t chunk_bytes);
+/* Where the next slab begins: compressed offset of its first BGZF block and the inflated bytes in front of its first
+ * record (a record may straddle BGZF blocks and slabs; a slab holds the records that start in it).  mdx_bam_seek takes the
+ * pair: when mdx_gbam_next fails, the tables hold the slabs in front and the host decoder can go on from here.
+ * MDX_ERR_STATE behind mdx_gbam_skip (the offset is the device scan's guess then). */
+int mdx_gbam_tell(const mdx_gbam *g, int64_t *comp_off, int64_t *phase);
+/* BGZF blocks whose guessed first record was not where the chain of records in front of it ended; such a block is scanned
+ * again from the right offset (the batch is exact either way; 0 for a file laid out the way htslib does). */
+int mdx_gbam_fixups(const mdx_gbam *g);
 void mdx_gbam_close(mdx_gbam *g);
 /* Introspection for tests: the device inflate and CRC32 stages of the decode path alone, on BGZF payloads the caller
  * supplies (host buffers).  blk holds four words per block — payload offset in comp, payload bytes, offset in out,

@@ -149,6 +149,7 @@ struct mdx_bam_stream {
     std::vector<size_t> hints;       // offsets into `pending` where a BGZF block began (unpack_records)
     size_t inflated = 0;             // uncompressed bytes inflated so far
     size_t header_bytes = 0;         // uncompressed size of the BAM header (set by mdx_bam_open)
+    size_t skip = 0;                 // inflated bytes to drop in front of the next record (mdx_bam_seek)
 };
 
 namespace {
@@ -695,8 +696,17 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
         };
         for (;;) {
             // BGZF members hold at most 64 KiB each; BAM compresses about 3-4x
-            while (!s->eof && s->pending.size() < limit)
+            while (!s->eof && s->pending.size() < limit + s->skip)
                 if (!stream_fill(s, std::max<size_t>(limit / 4, (size_t)1 << 16))) return MDX_ERR_ARG;
+            if (s->skip) {
+                // (mdx_bam_seek: the tail of a record that began in front of the block the stream was pointed at)
+                if (s->pending.size() < s->skip) { s->head.error = "mdx_bam_seek: offset beyond the data"; return MDX_ERR_ARG; }
+                s->pending.erase(s->pending.begin(), s->pending.begin() + (std::ptrdiff_t)s->skip);
+                size_t kept = 0;
+                for (size_t h : s->hints) if (h >= s->skip) s->hints[kept++] = h - s->skip;
+                s->hints.resize(kept);
+                s->skip = 0;
+            }
             lap("inflate");
             const size_t total = std::min(limit, s->pending.size());
             const bool partial = !(s->eof && total == s->pending.size());
@@ -732,6 +742,20 @@ int mdx_bam_next(mdx_bam_stream *s, int64_t chunk_bytes, mdx_bam **out) {
     } catch (const std::exception &e) {
         if (s) s->head.error = std::string("mdx_bam_next: ") + e.what();
         return MDX_ERR_ARG;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
+}
+
+int mdx_bam_seek(mdx_bam_stream *s, int64_t comp_off, int64_t phase) {
+    try {
+        if (!s || !s->file || comp_off < 0 || phase < 0 || (size_t)comp_off > s->file->size()) return MDX_ERR_ARG;
+        s->pending.clear();
+        s->hints.clear();
+        s->coff = (size_t)comp_off;
+        s->eof = s->coff >= s->file->size();
+        s->skip = (size_t)phase;
+        return MDX_OK;
     } catch (...) {
         return MDX_ERR_ARG;
     }
@@ -811,6 +835,14 @@ struct mdx_gbam {
     }
     bool whole_file_scanned() const { return scanned >= hs->file->size(); }
     size_t next_block = 0;               // first block not decoded yet
+    // Records may straddle BGZF blocks and slabs: a slab's batch holds the records that START in it (the blocks behind it
+    // are inflated as far as its last record reaches), and `phase` is where the first record of the next slab starts,
+    // counted from that slab's first inflated byte; unknown (phase_known false) behind mdx_gbam_skip, where the device
+    // scan's guess stands in — and next_verified says whether that guess, seen from this side, is the true offset.
+    size_t phase = 0;
+    bool phase_known = true, next_verified = true;
+    int fixups = 0;                      // segments whose guessed first record the chain did not confirm (rescanned)
+    int slabs_done = 0;
     std::string error;
     bool want_qual = false, want_mate = false;
     int minqual = 0;                     // --min-basequal on the device path (mdx_gbam_set_min_basequal)
@@ -825,7 +857,7 @@ struct mdx_gbam {
     void *d_crc_tables = nullptr;        // mdx_crc32::Tables
     // device buffers, grown on demand
     struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, crc, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
-        cigar_off, cigar, seq_off, seq, qual, small, arena;     // (all but `arena` point into it)
+        cigar_off, cigar, seq_off, seq, qual, small, info, forced, arena;     // (all but `arena` point into it)
     std::vector<Buf *> all() { return {&arena}; }
     bool reserve(Buf &b, size_t bytes) {
         if (bytes <= b.cap) return true;
@@ -850,18 +882,16 @@ int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out) {
         g->stream = (hipStream_t)st;
         int rc = mdx_bam_open(path, 4, &g->hs);
         if (rc != MDX_OK) { g->error = g->hs ? g->hs->head.error : "cannot open"; return rc; }
-        // the records must start where a block starts (htslib flushes the header into blocks of its own)
+        // the first slab starts with the block that holds the first record (htslib flushes the header into blocks of its
+        // own; other writers let it share a block with records): `phase` bytes into it
         size_t k = 0;
         for (;;) {
-            while (k < g->blocks.size() && g->blocks[k].out_off < g->hs->header_bytes) k++;
+            while (k < g->blocks.size() && g->blocks[k].out_off + g->blocks[k].out_size <= g->hs->header_bytes) k++;
             if (k < g->blocks.size() || g->whole_file_scanned()) break;
             if (!g->scan_to(g->scanned + ((size_t)1 << 20))) return MDX_ERR_ARG;
         }
-        if (k < g->blocks.size() ? g->blocks[k].out_off != g->hs->header_bytes : g->scanned_out != g->hs->header_bytes) {
-            g->error = "the BAM header does not end at a BGZF block boundary";
-            return MDX_ERR_UNSUPPORTED;
-        }
         g->next_block = k;
+        g->phase = k < g->blocks.size() ? g->hs->header_bytes - g->blocks[k].out_off : 0;
         if (hipSetDevice(g->device) != hipSuccess || mdx_k_gbam_prepare() != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
         {
             static mdx_crc32::Tables tables;
@@ -919,8 +949,15 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
         // (the block headers of this slab, unless the previous call has already walked them)
         if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + want + 65536)) return MDX_ERR_ARG;
-        if (g->next_block >= g->blocks.size()) return MDX_OK;             // end of file: an empty view
+        if (g->next_block >= g->blocks.size()) {                          // end of file: an empty view
+            if (g->phase_known && g->phase != 0) { g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG; }
+            return MDX_OK;
+        }
         if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+        // (tests of the caller's fallback: MDX_GBAM_FAIL_AT=k makes the k-th slab decoded by this handle fail)
+        if (const char *fail = std::getenv("MDX_GBAM_FAIL_AT")) {
+            if (g->slabs_done == std::atoi(fail)) { g->error = "MDX_GBAM_FAIL_AT"; return MDX_ERR_UNSUPPORTED; }
+        }
         // MDX_BAM_TIMING=1: stage times on stderr (each lap waits for the stream)
         const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
         auto t_last = std::chrono::steady_clock::now();
@@ -933,18 +970,35 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         };
         // the slab: blocks [b0, b1), about `want` compressed bytes, less than 4 GiB inflated
         const size_t b0 = g->next_block;
-        size_t b1 = b0, unc_bytes = 0;
+        size_t b1 = b0, slab_bytes = 0;
         const size_t in0 = g->blocks[b0].in_off;
-        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && unc_bytes + g->blocks[b1].out_size < 0xF0000000ull))) {
-            unc_bytes += g->blocks[b1].out_size;
+        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && slab_bytes + g->blocks[b1].out_size < 0xE0000000ull))) {
+            slab_bytes += g->blocks[b1].out_size;
             b1++;
         }
         const size_t nb = b1 - b0;
-        const size_t in1 = g->blocks[b1 - 1].in_off + g->blocks[b1 - 1].in_size;
-        const size_t comp_bytes = in1 - in0;
         const size_t out0 = g->blocks[b0].out_off;
-        std::vector<uint32_t> blk(4 * nb), crcs(nb);
-        for (size_t i = 0; i < nb; i++) {
+        hipStream_t st = g->stream;
+        // ... and the blocks behind it that the slab's last record may reach into: `ahead` inflated bytes of them, more if
+        // the record turns out to be longer (a second pass of the whole slab: reads of a quarter of a megabyte are rare)
+        size_t ahead = (size_t)256 << 10;
+        for (;;) {
+        size_t b2 = b1, unc_bytes = slab_bytes;
+        while (unc_bytes - slab_bytes < ahead && unc_bytes < 0xF0000000ull) {
+            if (b2 >= g->blocks.size()) {
+                if (g->whole_file_scanned()) break;
+                if (!g->scan_to(g->scanned + ((size_t)4 << 20))) return MDX_ERR_ARG;
+                continue;
+            }
+            unc_bytes += g->blocks[b2].out_size;
+            b2++;
+        }
+        const bool more_file = b2 < g->blocks.size() || !g->whole_file_scanned();
+        const size_t nba = b2 - b0;               // blocks inflated: the slab's and those ahead
+        const size_t in1 = g->blocks[b2 - 1].in_off + g->blocks[b2 - 1].in_size;
+        const size_t comp_bytes = in1 - in0;
+        std::vector<uint32_t> blk(4 * nba), crcs(nba);
+        for (size_t i = 0; i < nba; i++) {
             const Block &b = g->blocks[b0 + i];
             crcs[i] = b.crc;
             blk[4 * i] = (uint32_t)(b.in_off - in0); blk[4 * i + 1] = (uint32_t)b.in_size;
@@ -957,9 +1011,9 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         {
             struct Want { mdx_gbam::Buf *b; size_t bytes; };
             const Want wants[] = {
-                {&g->comp, comp_bytes + 64}, {&g->blk, nb * 16}, {&g->crc, nb * 4}, {&g->status, nb * 4}, {&g->unc, unc_bytes + 64}, {&g->cnt, nb * 16},
-                {&g->pre, nb * 16}, {&g->small, 64}, {&g->rec_off, rec_cap * 4}, {&g->flag, rec_cap * 2}, {&g->lib, rec_cap * 2},
-                {&g->tid, rec_cap * 4}, {&g->pos, rec_cap * 4}, {&g->tlen, rec_cap * 4}, {&g->cigar_off, rec_cap * 4},
+                {&g->comp, comp_bytes + 64}, {&g->blk, nba * 16}, {&g->crc, nba * 4}, {&g->status, nba * 4}, {&g->unc, unc_bytes + 64}, {&g->cnt, nba * 16},
+                {&g->pre, nba * 16}, {&g->info, nba * 16}, {&g->forced, nba * 4}, {&g->small, 64}, {&g->rec_off, rec_cap * 4}, {&g->flag, rec_cap * 2},
+                {&g->lib, rec_cap * 2}, {&g->tid, rec_cap * 4}, {&g->pos, rec_cap * 4}, {&g->tlen, rec_cap * 4}, {&g->cigar_off, rec_cap * 4},
                 {&g->seq_off, rec_cap * 4}, {&g->cigar, cig_cap * 4}, {&g->seq, seq_cap}, {&g->qual, g->want_qual ? seq_cap : 0},
                 {&g->mtid, g->want_mate ? rec_cap * 4 : 0}, {&g->mpos, g->want_mate ? rec_cap * 4 : 0}};
             size_t total_bytes = 0;
@@ -970,46 +1024,116 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             size_t at = 0;
             for (const Want &w : wants) { w.b->p = w.bytes ? (char *)g->arena.p + at : nullptr; w.b->cap = 0; at += (w.bytes + 255) & ~(size_t)255; }
         }
-        hipStream_t st = g->stream;
         lap("allocate");
         // the previous slab's columns may still be read by the tabulation kernel
         if (hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
         if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(g->blk.p, blk.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(g->crc.p, crcs.data(), nb * 4, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
-        unsigned long long *d_tot = (unsigned long long *)g->small.p;
-        int *d_bad = (int *)((char *)g->small.p + 32), *d_bad_crc = (int *)((char *)g->small.p + 40);
+            hipMemcpyAsync(g->blk.p, blk.data(), nba * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(g->crc.p, crcs.data(), nba * 4, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
+        int *d_bad_crc = (int *)((char *)g->small.p + 40);
         const int no_bad = 0x7FFFFFFF;
-        (void)hipMemcpyAsync(d_bad, &no_bad, 4, hipMemcpyHostToDevice, st);
         (void)hipMemcpyAsync(d_bad_crc, &no_bad, 4, hipMemcpyHostToDevice, st);
+        (void)hipMemsetAsync(g->forced.p, 0xFF, nba * 4, st);
         lap("upload");
-        mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nb, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nba, (uint8_t *)g->unc.p, (int *)g->status.p, st);
         // (the next slab's block headers, while the device inflates this one)
         if (!timing && !g->scan_to(in1 + want + 65536)) return MDX_ERR_ARG;
         lap("inflate");
-        mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nb, d_bad_crc, st);
+        mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nba, d_bad_crc, st);
         lap("crc32");
-        mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)nb, (uint4 *)g->cnt.p,
-                        (uint4 *)g->pre.p, d_tot, d_bad, st);
+        // the chains of the segments (every block inflated is one: those ahead of the slab say whether the next slab's
+        // first record can be found without this one), then their check on the host
+        const int n_ref = (int)g->hs->head.ref_names.size();
+        const uint32_t start0 = g->phase_known ? (uint32_t)g->phase : 0xFFFFFFFFu;
+        mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)nba, 0, nullptr, start0,
+                        (uint32_t)unc_bytes, n_ref, (uint4 *)g->info.p, (uint4 *)g->cnt.p, st);
         lap("scan");
-        unsigned long long tot[3] = {0, 0, 0};
-        int bad = no_bad, bad_crc = no_bad;
-        if (hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        std::vector<uint32_t> info(4 * nba), cnt(4 * nba);
+        int bad_crc = no_bad;
+        if (hipMemcpyAsync(info.data(), g->info.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(cnt.data(), g->cnt.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(&bad_crc, d_bad_crc, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             g->error = std::string("GPU decode failed: ") + hipGetErrorString(hipGetLastError());
             return MDX_ERR_HIP;
         }
-        if (bad != no_bad) {
-            int stv = 0;
-            (void)hipMemcpy(&stv, (const int *)g->status.p + bad, 4, hipMemcpyDeviceToHost);
-            if (stv < 0) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad) + " (inflate code " + std::to_string(stv) + ")"; return MDX_ERR_ARG; }
-            if (bad_crc != no_bad && bad_crc <= bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
-            g->error = "BGZF block " + std::to_string(b0 + (size_t)bad) + " does not hold whole records";
-            return MDX_ERR_UNSUPPORTED;
-        }
+        for (size_t i = 0; i < nba; i++)
+            if ((int32_t)info[4 * i + 2] == -2) {
+                int stv = 0;
+                (void)hipMemcpy(&stv, (const int *)g->status.p + i, 4, hipMemcpyDeviceToHost);
+                g->error = "corrupt BGZF block " + std::to_string(b0 + i) + " (inflate code " + std::to_string(stv) + ")";
+                return MDX_ERR_ARG;
+            }
         if (bad_crc != no_bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
+        // The walk: `at` = where the next record starts, known exactly; the segment that holds it must have begun its chain
+        // there — if its guess was another offset it is scanned again from the right one — and says where the chain lands.
+        const size_t slab_end = slab_bytes;
+        std::vector<uint8_t> used(nba, 0);
+        size_t at = 0, seg = 0;
+        bool have = g->phase_known;
+        if (have) at = g->phase;
+        else {
+            // behind a skipped slab: the first guess of this slab stands (its neighbour checks it: next_verified)
+            for (size_t i = 0; i < nb && !have; i++)
+                if (info[4 * i + 2] != 1u) { have = true; at = info[4 * i]; }
+            if (!have) at = slab_end;              // no record starts in this slab
+        }
+        bool grow = false;
+        while (at < slab_end) {
+            while (seg < nba && (size_t)blk[4 * seg + 2] + blk[4 * seg + 3] <= at) seg++;
+            if (seg >= nb) break;
+            if (info[4 * seg] != (uint32_t)at || info[4 * seg + 2] == 1u) {
+                // (rare: a guess that was not the record's start, or a segment whose first record begins behind a long one)
+                const int32_t f = (int32_t)at;
+                if (hipMemcpyAsync((int32_t *)g->forced.p + seg, &f, 4, hipMemcpyHostToDevice, st) != hipSuccess) return MDX_ERR_HIP;
+                mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)seg + 1, (int)seg,
+                                (const int *)g->forced.p, start0, (uint32_t)unc_bytes, n_ref, (uint4 *)g->info.p, (uint4 *)g->cnt.p, st);
+                if (hipMemcpyAsync(&info[4 * seg], (const uint4 *)g->info.p + seg, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipMemcpyAsync(&cnt[4 * seg], (const uint4 *)g->cnt.p + seg, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
+                g->fixups++;
+            }
+            const int32_t stv = (int32_t)info[4 * seg + 2];
+            if (stv == -1) { g->error = "corrupt BAM record in BGZF block " + std::to_string(b0 + seg); return MDX_ERR_ARG; }
+            if (stv == 2 && cnt[4 * seg] == 0 && info[4 * seg + 1] == (uint32_t)at && !more_file) {
+                g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG;
+            }
+            used[seg] = 1;
+            const size_t land = info[4 * seg + 1];
+            if (stv == 2 && land < slab_end) {
+                // the chain stopped at a record that starts in the slab and is not complete in what was inflated
+                if (!more_file) { g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG; }
+                grow = true;
+                break;
+            }
+            if (land <= at) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
+            at = land;
+        }
+        if (grow) {
+            if (ahead >= ((size_t)1 << 30)) { g->error = "a BAM record of more than a gigabyte"; return MDX_ERR_UNSUPPORTED; }
+            ahead *= 8;
+            continue;
+        }
+        // where the next slab's first record starts — and whether a process that has not seen this slab would find it: the
+        // segment ahead that holds it must have guessed exactly that offset (mdx_gbam_skip refuses to go on otherwise)
+        const size_t next_phase = at > slab_end ? at - slab_end : 0;
+        {
+            size_t sg = nb;
+            while (sg < nba && (size_t)blk[4 * sg + 2] + blk[4 * sg + 3] <= at) sg++;
+            if (b1 >= g->blocks.size() && g->whole_file_scanned()) g->next_verified = true;      // nothing follows
+            else g->next_verified = sg < nba && info[4 * sg + 2] != 1u && info[4 * sg] == (uint32_t)at;
+        }
+        // prefix sums over the segments that hold the chain
+        std::vector<uint32_t> pre(4 * nb);
+        unsigned long long tot[3] = {0, 0, 0};
+        for (size_t i = 0; i < nb; i++) {
+            if (!used[i]) { cnt[4 * i] = cnt[4 * i + 1] = cnt[4 * i + 2] = 0; }
+            pre[4 * i] = (uint32_t)tot[0]; pre[4 * i + 1] = (uint32_t)tot[1]; pre[4 * i + 2] = (uint32_t)tot[2]; pre[4 * i + 3] = info[4 * i];
+            tot[0] += cnt[4 * i]; tot[1] += cnt[4 * i + 1]; tot[2] += cnt[4 * i + 2];
+        }
         if (tot[0] > rec_cap - 2 || tot[1] > cig_cap - 2 || tot[2] > seq_cap - 64 || tot[2] > 0xFFFFFFFFull) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
+        if (hipMemcpyAsync(g->pre.p, pre.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(g->cnt.p, cnt.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess) return MDX_ERR_HIP;
+        lap("chains");
         MdxGbamCols c{};
         c.flag = (uint16_t *)g->flag.p; c.lib = (uint16_t *)g->lib.p; c.tid = (int32_t *)g->tid.p; c.pos = (int32_t *)g->pos.p;
         c.tlen = (int32_t *)g->tlen.p; c.mtid = g->want_mate ? (int32_t *)g->mtid.p : nullptr; c.mpos = g->want_mate ? (int32_t *)g->mpos.p : nullptr;
@@ -1023,8 +1147,8 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         c.seq_packed = g->seq_format == MDX_SEQ_4BIT ? 1 : 0;
         // (the unpack kernel ORs the nibbles of a record into the column: zeroed first, with the dword behind the last base)
         if (c.seq_packed && hipMemsetAsync(c.seq, 0, (size_t)(tot[2] + 1) / 2 + 8, st) != hipSuccess) return MDX_ERR_HIP;
-        mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
-                          (uint32_t)tot[0], (uint32_t *)g->rec_off.p, c, st);
+        mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
+                          (uint32_t)tot[0], (uint32_t)tot[1], (uint32_t)tot[2], (uint32_t *)g->rec_off.p, c, st);
         if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
         lap("unpack");
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
@@ -1040,7 +1164,11 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         if (d_mtid) *d_mtid = c.mtid;
         if (d_mpos) *d_mpos = c.mpos;
         g->next_block = b1;
+        g->phase = next_phase;
+        g->phase_known = have;
+        g->slabs_done++;
         return MDX_OK;
+        }
     } catch (const std::exception &e) {
         if (g) g->error = std::string("mdx_gbam_next: ") + e.what();
         return MDX_ERR_ARG;
@@ -1110,23 +1238,45 @@ int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual) {
 }
 
 int mdx_gbam_skip(mdx_gbam *g, int64_t chunk_bytes) {
-    // the slab mdx_gbam_next would take now, left undecoded (same borders: the ranks of a multi-GPU run agree on them)
+    // the slab mdx_gbam_next would take now, left undecoded (same borders: the ranks of a multi-GPU run agree on them).
+    // Where the first record behind it starts is then the device scan's guess — which the process that decodes the slab
+    // in front checks against the truth (next_verified): if this process is that one and the guess would be wrong, it
+    // says so here, before anybody counts a record twice or not at all.
     try {
         if (!g) return MDX_ERR_ARG;
         const size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
         if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + want + 65536)) return MDX_ERR_ARG;
         if (g->next_block >= g->blocks.size()) return MDX_OK;
+        if (g->phase_known && !g->next_verified) {
+            g->error = "the first record behind BGZF block " + std::to_string(g->next_block) + " cannot be found without the slab in front of it";
+            return MDX_ERR_UNSUPPORTED;
+        }
         const size_t b0 = g->next_block, in0 = g->blocks[b0].in_off;
         size_t b1 = b0, unc_bytes = 0;
-        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && unc_bytes + g->blocks[b1].out_size < 0xF0000000ull))) {
+        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && unc_bytes + g->blocks[b1].out_size < 0xE0000000ull))) {
             unc_bytes += g->blocks[b1].out_size;
             b1++;
         }
         g->next_block = b1;
+        g->phase_known = false;
+        g->phase = 0;
         return MDX_OK;
     } catch (...) {
         return MDX_ERR_ARG;
     }
+}
+
+int mdx_gbam_fixups(const mdx_gbam *g) { return g ? g->fixups : 0; }
+
+int mdx_gbam_tell(const mdx_gbam *g, int64_t *comp_off, int64_t *phase) {
+    if (!g || !comp_off || !phase || !g->hs) return MDX_ERR_ARG;
+    if (!g->phase_known) return MDX_ERR_STATE;
+    // (a Block knows where its DEFLATE payload starts: the block itself starts where the one in front ends, 8 bytes of
+    // CRC32 and ISIZE behind that one's payload)
+    const size_t k = g->next_block;
+    *comp_off = k >= g->blocks.size() ? (int64_t)g->scanned : (k == 0 ? 0 : (int64_t)(g->blocks[k - 1].in_off + g->blocks[k - 1].in_size + 8));
+    *phase = (int64_t)g->phase;
+    return MDX_OK;
 }
 
 int mdx_gbam_set_seq_format(mdx_gbam *g, int32_t seq_format) {

@@ -6,9 +6,9 @@
 //                         the LDS (~10 KB: sixteen blocks per CU), output written to HBM 2 KiB at a time, 16 bytes per
 //                         lane; matches that reach further back read the output in HBM
 //   gbam_crc_kernel       one wavefront per BGZF block: CRC32 of the inflated bytes against the gzip trailer
-//   gbam_scan_kernel      one lane per BGZF block: follows the chain of block_size fields (htslib starts every BGZF
-//                         block at a record: bgzf_flush_try in bam_write1), counts records, CIGAR operations, bases
-//   gbam_prefix_kernel    exclusive prefix sums of the three counts over the blocks (one workgroup)
+//   gbam_scan_kernel      one lane per BGZF block: the chain of block_size fields of the records that start in it, from a
+//                         guessed first record (any layout: records may straddle blocks; the host accepts a guess only
+//                         if the chain before it lands on it), counts records, CIGAR operations, bases
 //   gbam_offsets_kernel   one lane per BGZF block again: record offsets and the cigar_off / seq_off columns
 //   gbam_unpack_kernel    eight lanes per record: fixed fields, CIGAR, 4-bit bases -> ASCII, qualities, RG:Z -> library
 #include <hip/hip_runtime.h>
@@ -71,78 +71,99 @@ __global__ __launch_bounds__(64) void gbam_crc_kernel(const u8 *__restrict__ unc
     if (lane == 0 && total != want[blockIdx.x]) atomicMin(bad, (int)blockIdx.x);
 }
 
-// cnt[b] = (records, CIGAR operations, bases, 0) of BGZF block b; status < 0: the chain of records does not end at
-// the block's end (a record straddles two blocks, or the data is not BAM)
+// Does data[o, total) look like the start of a BAM record?  The fields a writer cannot choose freely: block_size against
+// the sizes it must hold, reference ids against the header's dictionary, a read name that ends in NUL where l_read_name
+// says.  Returns the record's block_size (>= 32), 0 when the bytes are not a record, and 1 when the record's fixed part
+// does not lie inside the data (nothing can be said).
+__device__ __forceinline__ u32 gbam_plausible(const u8 *__restrict__ unc, u32 o, u32 total, int n_ref) {
+    if (o + 36u > total) return 1u;
+    const u8 *r = unc + o + 4;
+    const u32 bs = g32(unc + o);
+    if (bs < 32u || bs > 0x10000000u) return 0u;
+    const int tid = (int)g32(r), mtid = (int)g32(r + 20);
+    const u32 l_name = r[8], n_c = g16(r + 12), l_seq = g32(r + 16);
+    if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || l_name == 0u || l_seq > 0x7FFFFFFFu) return 0u;
+    if ((int)g32(r + 4) < -1 || (int)g32(r + 24) < -1) return 0u;
+    if ((unsigned long long)32u + l_name + 4ull * n_c + ((unsigned long long)l_seq + 1u) / 2u + l_seq > bs) return 0u;
+    const u32 nul = o + 4u + 32u + l_name - 1u;
+    if (nul < total && unc[nul] != 0u) return 0u;
+    return bs;
+}
+
+// One lane per BGZF block (segment) of the slab: the chain of records that starts in it.  The inflated blocks lie back
+// to back in `unc`, so a record may straddle any number of them (htsjdk, sambamba and biobambam fill their blocks
+// whatever the record boundaries; htslib starts every block at a record: bgzf_flush_try in bam_write1).  Where the
+// first record of a segment starts is known for the slab's first segment only (`start0`; forced[b] >= 0 the same for
+// segment b: a repair pass of the host).  Every other lane guesses: the first offset of its segment at which three
+// plausible records follow one another (for an htslib file the segment's first byte).  The chain is followed from there
+// to the first record that starts at or behind the segment's end.  info[b] = (first record, landing offset, status, 0)
+// with status 0 = fine, 1 = no record starts in the segment, 2 = the chain ends in a record that is not complete in
+// `unc` (landing = its start), -1 = a record that cannot be one, -2 = the block did not inflate;
+// cnt[b] = (records, CIGAR operations, bases, 0) of the chain.  The host accepts a guess only if the chain before it lands
+// on it (mdx_gbam_next) — the result is exact whatever the guesses were.
 __global__ void gbam_scan_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk, const int *__restrict__ inflated,
-                                 int n_blocks, uint4 *__restrict__ cnt, int *__restrict__ bad) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+                                 int n_blocks, int first, const int *__restrict__ forced, u32 start0, u32 total, int n_ref,
+                                 uint4 *__restrict__ info, uint4 *__restrict__ cnt) {
+    const int b = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (b >= n_blocks) return;
     const uint4 e = blk[b];
+    const u32 lo = e.z, hi = e.z + e.w;
+    if (inflated[b] < 0) { info[b] = make_uint4(lo, lo, (u32)-2, 0); cnt[b] = make_uint4(0, 0, 0, 0); return; }
+    u32 f = 0xFFFFFFFFu;
+    if (forced && forced[b] >= 0) f = (u32)forced[b];
+    else if (b == 0 && start0 != 0xFFFFFFFFu) f = start0;       // (0xFFFFFFFF: unknown — the slab behind a skipped one)
+    else {
+        for (u32 o = lo; o < hi && f == 0xFFFFFFFFu; o++) {
+            u32 at = o;
+            bool ok = true;
+            for (int k = 0; k < 3 && ok; k++) {
+                const u32 bs = gbam_plausible(unc, at, total, n_ref);
+                if (bs == 0u) ok = false;
+                else if (bs == 1u) break;              // the data ends: as far as can be seen, records
+                else at += 4u + bs;
+                if (at > total) break;
+            }
+            if (ok) f = o;
+        }
+    }
     u32 n_rec = 0, n_cig = 0, n_seq = 0;
-    if (inflated[b] < 0) { atomicMin(bad, b); cnt[b] = make_uint4(0, 0, 0, 0); return; }
-    const u8 *__restrict__ p = unc + e.z;
-    u32 off = 0;
-    while (off + 4u <= e.w) {
-        const u32 bs = g32(p + off);
-        if (bs < 32u || bs > e.w - off - 4u) { atomicMin(bad, b); break; }
-        const u8 *r = p + off + 4;
+    if (f == 0xFFFFFFFFu) { info[b] = make_uint4(hi, hi, 1u, 0); cnt[b] = make_uint4(0, 0, 0, 0); return; }
+    u32 off = f, status = 0;
+    while (off < hi) {
+        if (off + 36u > total) { status = 2u; break; }
+        const u32 bs = g32(unc + off);
+        const u8 *r = unc + off + 4;
         const u32 l_name = r[8], n_c = g16(r + 12), l_seq = g32(r + 16);
-        if (32u + l_name + 4u * n_c + (l_seq + 1u) / 2u + l_seq > bs || l_seq > 0x7FFFFFFFu) { atomicMin(bad, b); break; }
+        if (bs < 32u || bs > 0x7FFFFFF0u || l_seq > 0x7FFFFFFFu ||
+            (unsigned long long)32u + l_name + 4ull * n_c + ((unsigned long long)l_seq + 1u) / 2u + l_seq > bs) { status = (u32)-1; break; }
+        if ((unsigned long long)off + 4u + bs > total) { status = 2u; break; }
         n_rec++; n_cig += n_c; n_seq += l_seq;
         off += 4u + bs;
     }
-    if (off != e.w) atomicMin(bad, b);
+    info[b] = make_uint4(f, off, status, 0);
     cnt[b] = make_uint4(n_rec, n_cig, n_seq, 0);
 }
 
-// pre[b] = exclusive prefix sums of cnt over the blocks; tot = the three totals
-__global__ __launch_bounds__(1024) void gbam_prefix_kernel(const uint4 *__restrict__ cnt, int n_blocks, uint4 *__restrict__ pre,
-                                                            unsigned long long *__restrict__ tot) {
-    __shared__ unsigned long long part[3][1024];
-    const int t = threadIdx.x;
-    const int per = (n_blocks + 1023) / 1024;
-    const int lo = t * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
-    unsigned long long s0 = 0, s1 = 0, s2 = 0;
-    for (int i = lo; i < hi; i++) { const uint4 c = cnt[i]; s0 += c.x; s1 += c.y; s2 += c.z; }
-    part[0][t] = s0; part[1][t] = s1; part[2][t] = s2;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long a0 = 0, a1 = 0, a2 = 0;
-        for (int i = 0; i < 1024; i++) {
-            const unsigned long long v0 = part[0][i], v1 = part[1][i], v2 = part[2][i];
-            part[0][i] = a0; part[1][i] = a1; part[2][i] = a2;
-            a0 += v0; a1 += v1; a2 += v2;
-        }
-        tot[0] = a0; tot[1] = a1; tot[2] = a2;
-    }
-    __syncthreads();
-    unsigned long long a0 = part[0][t], a1 = part[1][t], a2 = part[2][t];
-    for (int i = lo; i < hi; i++) {
-        const uint4 c = cnt[i];
-        pre[i] = make_uint4((u32)a0, (u32)a1, (u32)a2, 0);       // (the host has checked that the totals fit 32 bits)
-        a0 += c.x; a1 += c.y; a2 += c.z;
-    }
-}
-
-// rec_off[r] = offset of record r's first field (behind block_size) in `unc`; cigar_off / seq_off: the columns
-__global__ void gbam_offsets_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk, const uint4 *__restrict__ pre,
+// rec_off[r] = offset of record r's first field (behind block_size) in `unc`; cigar_off / seq_off: the columns.
+// pre[b] = (records, CIGAR operations, bases in front of segment b's chain, first record of the chain), cnt[b].x = the
+// records of the chain (0: the segment is skipped) — both from the host, which has checked the chains against each other
+__global__ void gbam_offsets_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ pre,
                                     const uint4 *__restrict__ cnt, int n_blocks, u32 *__restrict__ rec_off,
-                                    u32 *__restrict__ cigar_off, u32 *__restrict__ seq_off) {
+                                    u32 *__restrict__ cigar_off, u32 *__restrict__ seq_off, u32 n_rec, u32 n_cig, u32 n_seq) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
-    const uint4 e = blk[b], s = pre[b], c = cnt[b];
-    const u8 *__restrict__ p = unc + e.z;
-    u32 off = 0, r = s.x, co = s.y, so = s.z;
+    const uint4 s = pre[b], c = cnt[b];
+    u32 off = s.w, r = s.x, co = s.y, so = s.z;
     for (u32 k = 0; k < c.x; k++) {
-        const u32 bs = g32(p + off);
-        const u8 *q = p + off + 4;
-        rec_off[r] = e.z + off + 4u;
+        const u32 bs = g32(unc + off);
+        const u8 *q = unc + off + 4;
+        rec_off[r] = off + 4u;
         cigar_off[r] = co; seq_off[r] = so;
         co += g16(q + 12); so += g32(q + 16);
         r++;
         off += 4u + bs;
     }
-    if (b == n_blocks - 1) { cigar_off[r] = co; seq_off[r] = so; }     // the columns' closing entries
+    if (b == 0) { cigar_off[n_rec] = n_cig; seq_off[n_rec] = n_seq; }     // the columns' closing entries
 }
 
 // eight lanes per record: the fixed fields and the read group by the first of them, the CIGAR, the bases (four per
@@ -289,18 +310,18 @@ void mdx_k_gbam_crc(const uint8_t *unc, const uint4 *blk, const uint32_t *want, 
     hipLaunchKernelGGL(gbam_crc_kernel, dim3(n_blocks), dim3(64), 0, s, unc, blk, want, (const mdx_crc32::Tables *)tables, bad);
 }
 
-void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, uint4 *cnt, uint4 *pre,
-                     unsigned long long *tot, int *bad, hipStream_t s) {
-    if (n_blocks <= 0) return;
-    hipLaunchKernelGGL(gbam_scan_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, s, unc, blk, status, n_blocks, cnt, bad);
-    hipLaunchKernelGGL(gbam_prefix_kernel, dim3(1), dim3(1024), 0, s, cnt, n_blocks, pre, tot);
+void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, int first, const int *forced,
+                     uint32_t start0, uint32_t total, int n_ref, uint4 *info, uint4 *cnt, hipStream_t s) {
+    if (n_blocks - first <= 0) return;
+    hipLaunchKernelGGL(gbam_scan_kernel, dim3((n_blocks - first + 63) / 64), dim3(64), 0, s, unc, blk, status, n_blocks, first, forced,
+                       start0, total, n_ref, info, cnt);
 }
 
-void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *blk, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec,
-                       uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s) {
+void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec, uint32_t n_cig,
+                       uint32_t n_seq, uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s) {
     if (n_blocks <= 0) return;
-    hipLaunchKernelGGL(gbam_offsets_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, s, unc, blk, pre, cnt, n_blocks, rec_off,
-                       c.cigar_off, c.seq_off);
+    hipLaunchKernelGGL(gbam_offsets_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, s, unc, pre, cnt, n_blocks, rec_off,
+                       c.cigar_off, c.seq_off, n_rec, n_cig, n_seq);
     if (n_rec > 0)
         hipLaunchKernelGGL(gbam_unpack_kernel, dim3((n_rec + 31) / 32), dim3(256), 0, s, unc, rec_off, n_rec, c);
 }

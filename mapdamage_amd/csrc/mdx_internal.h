@@ -299,7 +299,10 @@ hipError_t mdx_k_gbam_prepare();
 void mdx_k_gbam_inflate(const uint8_t *comp, const uint4 *blk, int n_blocks, uint8_t *unc, int *status, hipStream_t s);
 // want[b] = CRC32 of block b's inflated bytes (gzip trailer); tables: a device copy of mdx_crc32::Tables; *bad = min failing block
 void mdx_k_gbam_crc(const uint8_t *unc, const uint4 *blk, const uint32_t *want, const void *tables, int n_blocks, int *bad, hipStream_t s);
-void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, uint4 *cnt, uint4 *pre,
-                     unsigned long long *tot, int *bad, hipStream_t s);
-void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *blk, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec,
-                       uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s);
+// info[b] = (first record of segment b's chain, landing offset, status, 0), cnt[b] = (records, CIGAR operations, bases) —
+// see gbam_scan_kernel; segments [first, n_blocks); forced: per segment a known first record (>= 0) or null
+void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, int n_blocks, int first, const int *forced,
+                     uint32_t start0, uint32_t total, int n_ref, uint4 *info, uint4 *cnt, hipStream_t s);
+// pre[b] = (records, CIGAR operations, bases in front of segment b, first record of its chain); cnt[b].x = its records
+void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec, uint32_t n_cig,
+                       uint32_t n_seq, uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s);

@@ -35,7 +35,7 @@ EXPORTS = (
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
-    "mdx_gbam_skip", "mdx_comm_count",
+    "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek",
 )
 
 SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
@@ -135,6 +135,9 @@ def load_library(path=None):
     lib.mdx_gbam_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mdx_gbam_at_end.argtypes = [ctypes.c_void_p]
     lib.mdx_gbam_skip.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    lib.mdx_gbam_tell.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mdx_gbam_fixups.argtypes = [ctypes.c_void_p]
+    lib.mdx_bam_seek.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
     lib.mdx_gbam_set_min_basequal.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mdx_gbam_set_seq_format.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.mdx_pack_seq.restype = ctypes.c_int

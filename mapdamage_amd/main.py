@@ -246,15 +246,24 @@ def launch_command(argv, gpus):
             "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "mapdamage_amd"] + keep
 
 
-def _tabulate_on_host(options, reader, ref, libraries, logger, ranks):
-    """The records decoded on the host (native BGZF/BAM decoder or SAM text), uploaded batch by batch."""
-    with DamageEngine(libraries, options.length, options.around, options.minqual,
-                      device=ranks.device) as engine:
-        engine.set_reference(ref)
-        n_reads, warned_about_quals = 0, False
+def _tabulate_on_host(options, reader, ref, libraries, logger, ranks, carry=None):
+    """The records decoded on the host (native BGZF/BAM decoder or SAM text), uploaded batch by batch.
+    ``carry``: (engine, resume position, records counted so far) of a device decode that gave up part of the way: the
+    same engine — its tables hold the slabs already counted — goes on with the rest of the file."""
+    import contextlib
+    with contextlib.ExitStack() as stack:
+        if carry is None:
+            engine = stack.enter_context(DamageEngine(libraries, options.length, options.around, options.minqual,
+                                                      device=ranks.device))
+            engine.set_reference(ref)
+            n_reads, resume = 0, None
+        else:
+            engine, resume, n_reads = carry
+            stack.enter_context(engine)
+        warned_about_quals = False
         error = None
         # a BAM file arrives in chunks (bounded host memory; chunk k+1 is decoded while chunk k is tabulated)
-        for batch in reader.iter_batches():
+        for batch in reader.iter_batches(resume=resume):
             if options.minqual and not warned_about_quals and batch.n:
                 # main.py:185-192: the first iterated read without qualities (`not read.qual`: absent or
                 # empty) triggers the warning, once
@@ -298,54 +307,73 @@ def _device_path_applies(options):
 
 
 def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
-    """--gpu-decode: the file inflated, unpacked and counted on the GPU.  None: not a case for it (the caller decodes
-    on the host, which also words the errors the way the reference does)."""
+    """--gpu-decode: the file inflated, unpacked and counted on the GPU.  Returns (tables, None), or (None, carry) when
+    the path does not apply or has given up — the caller decodes on the host, which also words the errors the way the
+    reference does: the whole file (carry None), or, when the device path failed on a slab it had not begun to count,
+    the rest of it with the same engine (``_tabulate_on_host``'s ``carry``)."""
     from .sam import GpuBamStream, GpuDecodeUnsupported
     if not _device_path_applies(options):
         logger.debug("the GPU decode path does not apply to this run; decoding on the host")
-        return None
+        return None, None
     if options.merge_libraries:
         readgroups, lib_default = [], 0
     else:
         readgroups = [(rg, libraries.index(lib)) for rg, lib in reader._readgroups.items()]
         lib_default = None
+    engine = DamageEngine(libraries, options.length, options.around, options.minqual, device=ranks.device)
+    carry = None
     try:
-        with DamageEngine(libraries, options.length, options.around, options.minqual, device=ranks.device) as engine:
-            engine.set_reference(ref)
-            warned_about_quals = False
-            error = None
-            # (a slab of compressed bytes inflates to about four times its size)
-            slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
-            with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
-                              chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
-                # (several ranks: rank r decodes the slabs r, r + W, ... and steps over the others)
-                slab = 0
-                try:
-                    while True:
-                        mine = slab % ranks.world == ranks.rank
-                        slab += 1
-                        if not mine:
-                            if not stream.skip():
-                                break
-                            continue
-                        view = stream.next_view()
-                        if view is None:
+        engine.set_reference(ref)
+        warned_about_quals = False
+        error = None
+        # (a slab of compressed bytes inflates to about four times its size)
+        slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
+        with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
+                          chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
+            # (several ranks: rank r decodes the slabs r, r + W, ... and steps over the others)
+            slab, n_reads = 0, 0
+            try:
+                while True:
+                    mine = slab % ranks.world == ranks.rank
+                    slab += 1
+                    if not mine:
+                        if not stream.skip():
                             break
-                        if options.minqual and not warned_about_quals and stream.missing_qualities():
-                            logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
-                            warned_about_quals = True
-                        engine.tabulate_view(view)
-                    engine.sync()
-                except (BadReadError, ValueError, MdxError) as exc:
-                    if ranks.world == 1:
+                        continue
+                    try:
+                        view = stream.next_view()
+                    except ValueError:
+                        # the decode of a slab failed before any of its records was counted: everything in front of it
+                        # is in the engine's tables, and the host decoder can go on from the slab's first record
+                        if ranks.world == 1:
+                            engine.sync()
+                            where = stream.tell()
+                            if where is not None and slab > 1:
+                                carry = (engine, where, n_reads)
                         raise
-                    error = exc         # (the ranks agree on it in finish(): all of them take the host path then)
-                return ranks.finish(engine, error)
+                    if view is None:
+                        break
+                    if options.minqual and not warned_about_quals and stream.missing_qualities():
+                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                        warned_about_quals = True
+                    engine.tabulate_view(view, record_base=n_reads)
+                    n_reads += int(view.n_reads)
+                engine.sync()
+                if stream.fixups():
+                    logger.debug("device decode: %d BGZF blocks rescanned from the record their predecessor's chain ended on", stream.fixups())
+            except (BadReadError, ValueError, MdxError) as exc:
+                if ranks.world == 1:
+                    raise
+                error = exc         # (the ranks agree on it in finish(): all of them take the host path then)
+            tables = ranks.finish(engine, error)
+            engine.close()
+            return tables, None
     except GpuDecodeUnsupported as error:
         reason = "file layout the device path does not take (MDX_ERR_UNSUPPORTED): %s" % error
     except BadReadError as error:
         # a record the reference cannot process, or one without a usable read group: the host path names it
-        reason = "a record the device path cannot count (MDX_ERR_BAD_READ, record %d of its slab)" % error.read_index
+        reason = "a record the device path cannot count (MDX_ERR_BAD_READ, record %d)" % error.read_index
+        carry = None
     except (ValueError, MdxError) as error:
         # a damaged file (the host decoder finds the same damage and words the error), or the device path out of
         # memory: either way the host path has the last word
@@ -355,8 +383,13 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
         reason = str(error)
     # never silent: a regression of the device path must not show up as nothing but a slow run
     options.gpu_decode_fallbacks = getattr(options, "gpu_decode_fallbacks", 0) + 1
-    logger.warning("GPU decode path gave up: %s; decoding on the host (the whole file again)", reason)
-    return None
+    if carry is None:
+        engine.close()
+        logger.warning("GPU decode path gave up: %s; decoding on the host (the whole file again)", reason)
+    else:
+        logger.warning("GPU decode path gave up: %s; decoding on the host (from compressed offset %d on: %d records are counted)",
+                       reason, carry[1][0], carry[2])
+    return None, carry
 
 
 def main(argv):
@@ -412,9 +445,9 @@ def main(argv):
             logger.info("Filtering out bases with a Phred score < %d", options.minqual)
         logger.info("Writing results to '%s/'", options.folder)
 
-        tables = _tabulate_on_device(options, reader, ref, libraries, logger, ranks) if options.gpu_decode else None
+        tables, carry = _tabulate_on_device(options, reader, ref, libraries, logger, ranks) if options.gpu_decode else (None, None)
         if tables is None:
-            tables = _tabulate_on_host(options, reader, ref, libraries, logger, ranks)
+            tables = _tabulate_on_host(options, reader, ref, libraries, logger, ranks, carry)
         fallbacks = getattr(options, "gpu_decode_fallbacks", 0)
         if options.gpu_decode:
             logger.log(logging.WARNING if fallbacks else logging.DEBUG, "Decode path: %s; fallbacks from the device path: %d",

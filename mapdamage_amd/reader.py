@@ -62,10 +62,16 @@ class BAMReader:
             readgroups[line["ID"]] = (line["SM"], line["LB"])
         return readgroups
 
-    def iter_batches(self):
+    def iter_batches(self, resume=None):
         """The records the reference would iterate over (reader.py:83-96, 121-164), in its order, as
         ``ReadBatch``es with the library column filled in: one per decoded chunk, or the whole file
-        at once.  The decode of chunk k+1 runs on a helper thread while the caller works on chunk k."""
+        at once.  The decode of chunk k+1 runs on a helper thread while the caller works on chunk k.
+        ``resume``: (compressed offset of a BGZF block, inflated bytes in front of the first record wanted) — the records
+        from there on only (chunked BAM decode: ``BamStream.seek``)."""
+        if resume is not None:
+            if self._chunks is None:
+                raise ValueError("resuming needs the chunked BAM decoder")
+            self._chunks.seek(*resume)
         if self._chunks is None:
             indices = self.kept_indices()
             batch = self.handle.batch

@@ -369,8 +369,10 @@ class GpuBamStream:
     blocks at a time and is inflated and unpacked there; ``next_view`` returns an ``MdxBatch`` of DEVICE pointers for
     ``DamageEngine.tabulate_view`` (valid until the next call), or None at the end of the file.  ``readgroups``: the
     header's read-group ids with the library index of each; ``lib_default``: library of a record without RG tag
-    (None: such a record is an error when it is counted).  Raises ``GpuDecodeUnsupported`` for a file whose BGZF blocks
-    do not start at records — the caller then decodes on the host (``BamStream``)."""
+    (None: such a record is an error when it is counted).  Any BGZF layout: records may straddle blocks and slabs, the
+    header may share a block with records.  Raises ``GpuDecodeUnsupported`` for what is left (a record longer than a
+    gigabyte; in a sharded run a slab whose first record cannot be told without the slab in front) — the caller then
+    decodes on the host (``BamStream``), from ``tell()`` on if it likes."""
 
     def __init__(self, engine, path, readgroups=(), lib_default=None, chunk_bytes=256 << 20, want_qual=False,
                  want_mate=False, min_basequal=0, packed=None):
@@ -427,12 +429,29 @@ class GpuBamStream:
         view.mtid, view.mpos = mtid.value, mpos.value       # (python attributes: not fields of the C struct)
         return view
 
+    def tell(self):
+        """(compressed offset of the next slab's first BGZF block, inflated bytes in front of its first record) — where
+        ``BamStream.seek`` takes up the file — or None when the device path does not know (behind ``skip``)."""
+        import ctypes
+        coff, phase = ctypes.c_int64(), ctypes.c_int64()
+        if self._lib.mdx_gbam_tell(self._g, ctypes.byref(coff), ctypes.byref(phase)) != 0:
+            return None
+        return coff.value, phase.value
+
+    def fixups(self):
+        """BGZF blocks whose guessed first record was not where the chain of the records in front of it ended (rescanned
+        from the right offset: the result is exact either way)."""
+        return int(self._lib.mdx_gbam_fixups(self._g))
+
     def skip(self):
         """Step over the slab ``next_view`` would decode (a run over several GPUs: the slabs of the other ranks).
         False at the end of the file."""
         if self._lib.mdx_gbam_at_end(self._g):
             return False
-        if self._lib.mdx_gbam_skip(self._g, self.chunk_bytes) != 0:
+        rc = self._lib.mdx_gbam_skip(self._g, self.chunk_bytes)
+        if rc == -8:
+            raise GpuDecodeUnsupported("%r: %s" % (str(self.path), self._error()))
+        if rc != 0:
             raise ValueError("%r: %s" % (str(self.path), self._error()))
         return True
 
@@ -482,6 +501,13 @@ class BamStream:
         if not self._stream:
             return "BAM decode failed"
         return self._lib.mdx_bam_error(self._lib.mdx_bam_stream_header(self._stream)).decode()
+
+    def seek(self, comp_off, phase=0):
+        """Go on from the BGZF block at compressed offset ``comp_off``, the first record ``phase`` inflated bytes into it
+        (``GpuBamStream.tell``)."""
+        import ctypes
+        if self._lib.mdx_bam_seek(self._stream, ctypes.c_int64(int(comp_off)), ctypes.c_int64(int(phase))) != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
 
     def next_chunk(self):
         """The next ``Alignments`` or None at the end of the file."""
@@ -638,11 +664,12 @@ def _bam_record(batch, i, rg):
 
 
 def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None, htslib_blocks=True,
-              workers=1):
+              workers=1, block_bytes=0xFF00):
     """``htslib_blocks``: lay the BGZF blocks out as htslib does (the header flushed on its own, and a block closed
     early when the next record would not fit, ``bgzf_flush_try`` in ``bam_write1``), so that every block starts
     at a record — what the files mapDamage sees in practice look like, and what the native decoder's parallel
-    record scan speculates on.  False: blocks of 0xFF00 bytes cut anywhere (records straddle them).
+    record scan speculates on.  False: header and records as one stream cut into blocks of ``block_bytes`` anywhere — the
+    header shares a block with records, records straddle blocks (htsjdk / Picard fill 65 498 bytes per block).
     ``workers`` > 1 (htslib layout only): the records are encoded and deflated by forked worker processes, a slice
     each (call it before the process touches the GPU); a slice starts a block of its own, otherwise the same file."""
     text = header_text(ref_names, ref_lengths, read_groups).encode()
@@ -691,7 +718,7 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
             del pieces[-2][room:]
     if not htslib_blocks:
         data = raw.getvalue()
-        pieces = [data[lo:lo + room] for lo in range(0, len(data), room)]
+        pieces = [data[lo:lo + block_bytes] for lo in range(0, len(data), block_bytes)]
     with open(path, "wb") as out:
         for piece in pieces:
             if len(piece):

@@ -12,14 +12,21 @@ pytestmark = pytest.mark.gpu
 RGS = [{"ID": "rgA", "SM": "s", "LB": "lib1"}, {"ID": "rg_b2", "SM": "s", "LB": "lib2"}, {"ID": "x", "SM": "s", "LB": "lib1"}]
 
 
-def _write(tmp_path, n=30_000, seed=4, **kw):
+# how the BGZF blocks of a test file are laid out: as htslib does (every block starts at a record, the header in blocks of
+# its own), or header and records as one stream cut anywhere — 0xFF00 bytes, htsjdk's 65 498, and blocks so small that a
+# record spans several of them
+LAYOUTS = {"htslib": dict(), "cut": dict(htslib_blocks=False), "htsjdk": dict(htslib_blocks=False, block_bytes=65498),
+           "tiny": dict(htslib_blocks=False, block_bytes=90)}
+
+
+def _write(tmp_path, n=30_000, seed=4, layout="htslib", **kw):
     ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500, lower_run=3000)
     b = synth.make_reads(ref, n, seed, len_range=(25, 160), paired=True, frac_softclip=0.2, frac_ins=0.08, frac_del=0.08,
                          frac_skip=0.01, with_qual=True, frac_filtered=0.05, **kw)
     rng = np.random.default_rng(seed)
     rg = [RGS[i]["ID"] for i in rng.integers(0, 3, size=b.n)]
     path = tmp_path / "g.bam"
-    sam.write_bam(str(path), b, ref.names, ref.lengths, RGS, rg_of_record=rg)
+    sam.write_bam(str(path), b, ref.names, ref.lengths, RGS, rg_of_record=rg, **LAYOUTS[layout])
     return ref, b, rg, path
 
 
@@ -33,10 +40,12 @@ def _d2h(ptr, n, dtype):
     return out
 
 
-@pytest.mark.parametrize("chunk", [1 << 16, 1 << 20, 1 << 28])
-def test_device_columns_equal_host_decoder(tmp_path, chunk):
+@pytest.mark.parametrize("chunk,layout", [(1 << 16, "htslib"), (1 << 20, "htslib"), (1 << 28, "htslib"), (1 << 16, "cut"),
+                                          (1 << 28, "cut"), (1 << 18, "htsjdk"), (1 << 16, "tiny")])
+def test_device_columns_equal_host_decoder(tmp_path, chunk, layout):
+    """... whatever the BGZF layout: records that straddle blocks and slabs, a header that shares its block with records."""
     from mapdamage_amd.engine import DamageEngine
-    ref, b, rg, path = _write(tmp_path)
+    ref, b, rg, path = _write(tmp_path, n=3_000 if layout == "tiny" else 30_000, layout=layout)
     host = sam.read_bam_native(str(path))
     hb = host.batch
     lib_of = {"rgA": 0, "rg_b2": 1, "x": 0}
@@ -155,21 +164,29 @@ def test_cli_gpu_decode_writes_the_reference_tables(tmp_path, golden, extra):
         assert "decoding on the host" not in (out / "Runtime_log.txt").read_text()
 
 
-def test_layouts_the_device_path_does_not_take(tmp_path):
-    """Records straddling BGZF blocks (not what htslib writes): MDX_ERR_UNSUPPORTED, and the command line falls back to
-    the host decoder with the same tables; a corrupt block is an error."""
+@pytest.mark.parametrize("layout", ["cut", "htsjdk", "tiny"])
+def test_any_bgzf_layout_on_the_device_path(tmp_path, layout):
+    """Records straddling BGZF blocks, a header sharing its block with records (htsjdk / Picard, sambamba, biobambam): the
+    device path takes the file — no fallback — and the command line writes what the host decoder writes."""
     from mapdamage_amd import fasta
-    from mapdamage_amd.engine import DamageEngine
     from mapdamage_amd.main import main
+    ref, b, rg, path = _write(tmp_path, n=2_000 if layout == "tiny" else 20_000, layout=layout)
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    outs = []
+    for name, flags in (("host", ["--host-decode"]), ("dev", ["--gpu-decode", "--chunk-mb", "1"])):
+        out = tmp_path / name
+        assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "--log-level", "DEBUG"] + flags) == 0
+        outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
+    assert outs[0] == outs[1]
+    log = (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    assert "decoding on the host" not in log and "gave up" not in log
+
+
+def test_a_damaged_block_is_an_error_on_the_device_path(tmp_path):
+    from mapdamage_amd.engine import DamageEngine
     ref, b, rg, path = _write(tmp_path, n=5000)
-    odd = tmp_path / "odd.bam"
-    sam.write_bam(str(odd), b, ref.names, ref.lengths, RGS, rg_of_record=rg, htslib_blocks=False)
     with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
         eng.set_reference(ref)
-        with pytest.raises(sam.GpuDecodeUnsupported):
-            with sam.GpuBamStream(eng, str(odd), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)]) as g:
-                while g.next_view() is not None:
-                    pass
         # a flipped byte in the middle of a block's payload
         raw = bytearray(path.read_bytes())
         raw[len(raw) // 2] ^= 0x5A
@@ -180,17 +197,55 @@ def test_layouts_the_device_path_does_not_take(tmp_path):
                 while (v := g.next_view()) is not None:
                     eng.tabulate_view(v)
                 eng.sync()
-    fasta.write_fasta(tmp_path / "ref.fa", ref)
-    outs = []
-    for name, flags in (("host", ["--host-decode"]), ("dev", ["--gpu-decode"])):
-        out = tmp_path / name
-        assert main(["-i", str(odd), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats"] + flags) == 0
-        outs.append([(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")])
-    assert outs[0] == outs[1]
-    log = (tmp_path / "dev" / "Runtime_log.txt").read_text()
-    # the fallback is loud: a WARNING that names the library's code, and the count in the run's log
-    assert "WARNING GPU decode path gave up" in log and "MDX_ERR_UNSUPPORTED" in log and "decoding on the host" in log
-    assert "WARNING Decode path: host decoder; fallbacks from the device path: 1" in log
+    # a file that ends inside a record
+    cut = tmp_path / "cut.bam"
+    sam.write_bam(str(cut), b, ref.names, ref.lengths, RGS, rg_of_record=rg, htslib_blocks=False)
+    whole = cut.read_bytes()
+    stream = sam.read_bam_native(str(cut))          # (sanity: the file is fine as written)
+    assert stream.batch.n == b.n
+    # drop the last data block (keep the EOF marker): the record that straddled into it is incomplete
+    import struct
+    offs, at = [], 0
+    while at < len(whole):
+        offs.append(at)
+        at += struct.unpack_from("<H", whole, at + 16)[0] + 1
+    short = tmp_path / "short.bam"
+    short.write_bytes(whole[:offs[-2]] + whole[offs[-1]:])
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        eng.set_reference(ref)
+        with pytest.raises(ValueError, match="incomplete|truncated"):
+            with sam.GpuBamStream(eng, str(short), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)], chunk_bytes=1 << 16) as g:
+                while g.next_view() is not None:
+                    pass
+
+
+def test_the_fallback_goes_on_where_the_device_path_stopped(tmp_path, monkeypatch):
+    """A slab the device path gives up on (forced: MDX_GBAM_FAIL_AT): the slabs in front of it stay counted, the host
+    decoder takes the file up at that slab's first record — a record that straddles the slab border included — and the
+    tables are those of a run on either path alone; the log says so."""
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    for layout in ("htslib", "cut"):
+        d = tmp_path / layout
+        d.mkdir()
+        ref, b, rg, path = _write(d, n=40_000, layout=layout)
+        fasta.write_fasta(d / "ref.fa", ref)
+        outs = {}
+        for name, flags, fail in (("host", ["--host-decode"], None), ("dev", ["--gpu-decode", "--chunk-mb", "1"], None),
+                                  ("resumed", ["--gpu-decode", "--chunk-mb", "1"], "3")):
+            if fail is None:
+                monkeypatch.delenv("MDX_GBAM_FAIL_AT", raising=False)
+            else:
+                monkeypatch.setenv("MDX_GBAM_FAIL_AT", fail)
+            out = d / name
+            assert main(["-i", str(path), "-r", str(d / "ref.fa"), "-d", str(out), "--no-stats", "--log-level", "DEBUG"] + flags) == 0
+            outs[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
+        monkeypatch.delenv("MDX_GBAM_FAIL_AT", raising=False)
+        assert outs["host"] == outs["dev"] == outs["resumed"], layout
+        log = (d / "resumed" / "Runtime_log.txt").read_text()
+        assert "WARNING GPU decode path gave up" in log and "MDX_ERR_UNSUPPORTED" in log
+        assert "from compressed offset" in log and "the whole file again" not in log
+        assert "WARNING Decode path: host decoder; fallbacks from the device path: 1" in log
 
 
 def test_empty_file_and_records_without_read_group(tmp_path):

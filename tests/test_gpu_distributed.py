@@ -119,9 +119,12 @@ def test_cli_on_two_ranks_writes_the_reference_tables(tmp_path, decode):
 
 
 @pytest.mark.gpu
-def test_cli_on_two_ranks_shards_the_slabs_of_a_file(tmp_path):
+@pytest.mark.parametrize("layout", [dict(), dict(htslib_blocks=False, block_bytes=65498)], ids=["htslib", "htsjdk"])
+def test_cli_on_two_ranks_shards_the_slabs_of_a_file(tmp_path, layout):
     """A file of several slabs: rank r decodes the slabs r, r + 2, ... on the device and steps over the others; the
-    tables equal the one-GPU run's byte for byte, and the oracle's."""
+    tables equal the one-GPU run's byte for byte, and the oracle's.  With records that straddle BGZF blocks and slabs
+    too: a slab's records are those that start in it, and a rank that has not seen the slab in front finds its first
+    record by the device scan's guess (which the rank that has seen it checks)."""
     import numpy as np
 
     from mapdamage_amd import fasta, sam, synth
@@ -130,7 +133,7 @@ def test_cli_on_two_ranks_shards_the_slabs_of_a_file(tmp_path):
     b = synth.make_reads(ref, 150_000, 21, len_range=(30, 140), paired=True, frac_softclip=0.1, frac_ins=0.04, frac_del=0.04,
                          frac_skip=0.005, frac_filtered=0.03)
     path = tmp_path / "big.bam"
-    sam.write_bam(path, b, ref.names, ref.lengths, [{"ID": "rg1", "SM": "s", "LB": "l"}], ["rg1"] * b.n)
+    sam.write_bam(path, b, ref.names, ref.lengths, [{"ID": "rg1", "SM": "s", "LB": "l"}], ["rg1"] * b.n, **layout)
     assert path.stat().st_size > 3 << 20          # three slabs of 1 MiB and more
     fasta.write_fasta(tmp_path / "ref.fa", ref)
     one, two = tmp_path / "one", tmp_path / "two"

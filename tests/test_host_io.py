@@ -208,6 +208,46 @@ def test_native_bam_stream_matches_whole_file_decode(files, chunk_bytes):
     assert [q for c in chunks for q in c.qname] == whole.qname
 
 
+def test_native_bam_stream_takes_a_file_up_in_the_middle(files, tmp_path):
+    """mdx_bam_seek (what a device decode that gave up hands over, mdx_gbam_tell): the BGZF block at a compressed offset and
+    the inflated bytes in front of the first record wanted — with records that straddle the blocks of the file."""
+    import struct
+    d, ref, batch, rg_of = files
+    path = tmp_path / "cut.bam"
+    sam.write_bam(path, batch, ref.names, ref.lengths, RGS, rg_of, htslib_blocks=False, block_bytes=700)
+    whole = sam.read_bam_native(path)
+    raw = path.read_bytes()
+    # compressed offset and inflated size of every block; inflated offset of every record
+    blocks, at, out = [], 0, 0
+    while at < len(raw):
+        size = struct.unpack_from("<H", raw, at + 16)[0] + 1
+        isize = struct.unpack_from("<I", raw, at + size - 4)[0]
+        blocks.append((at, out))
+        out += isize
+        at += size
+    with sam.BamStream(path, threads=2, chunk_bytes=1 << 20, keep_raw=True) as stream:
+        chunk = stream.next_chunk()
+        assert chunk.batch.n == whole.batch.n
+        import ctypes
+        data, rec_off = ctypes.c_void_p(), ctypes.c_void_p()
+        assert stream._lib.mdx_bam_raw(chunk.native, ctypes.byref(data), ctypes.byref(rec_off)) == 0
+        offs = np.ctypeslib.as_array(ctypes.cast(rec_off, ctypes.POINTER(ctypes.c_uint64)), (whole.batch.n + 1,)).copy()
+        header_bytes = out - int(offs[-1])
+        for k in (1, whole.batch.n // 3, whole.batch.n - 2):
+            start = header_bytes + int(offs[k])                 # inflated offset of record k
+            b = max(i for i, (_, o) in enumerate(blocks) if o <= start)
+            stream.seek(blocks[b][0], start - blocks[b][1])
+            rest = stream.next_chunk()
+            assert rest.batch.n == whole.batch.n - k
+            np.testing.assert_array_equal(rest.batch.pos, whole.batch.pos[k:])
+            np.testing.assert_array_equal(rest.batch.seq, whole.batch.seq[int(whole.batch.seq_off[k]):])
+            assert rest.qname == whole.qname[k:]
+            assert stream.next_chunk() is None
+        with pytest.raises(ValueError):
+            stream.seek(blocks[3][0] + 1, 0)                    # not a block boundary
+            stream.next_chunk()
+
+
 def test_native_bam_stream_rejects_garbage_and_truncation(files, tmp_path):
     d = files[0]
     (tmp_path / "bad.bam").write_bytes(b"\x1f\x8bnot really a bam file at all")
