@@ -501,8 +501,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             const int npos = 1 + fuse->len5p + fuse->len3p;
             a.rs = *fuse;
             a.queue_off = mdx_k_fuse_queue_off(a.dims);
-            a.rs.tcb_off = mdx_k_fuse_tcb_off(a.dims);
-            lds = mdx_k_fuse_lds_bytes(a.dims, npos);
+            a.rs.qcap = mdx_k_fuse_qcap(a.dims, npos, kLdsLimit);
+            a.rs.tcb_off = mdx_k_fuse_tcb_off(a.dims, a.rs.qcap);
+            lds = mdx_k_fuse_lds_bytes(a.dims, npos, a.rs.qcap);
             wpb_l = mdx_k_fuse_block_threads() / 64;
             const int64_t want_f = (ntiles + wpb_l - 1) / wpb_l;
             grid = (int)(want_f < c->n_cu ? want_f : c->n_cu);
@@ -526,7 +527,15 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             if (!c->d_tile_ctr) HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)4096 * 4));
             if (n_pools > 4096) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
             a.tile_ctr = c->d_tile_ctr;
-            HIP_TRY(c, c->lists.reserve((size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16));
+            {
+                // (scratch of the launch: 88 bytes per record a wavefront may be handed — twice its even share —, 180 bytes
+                // per record of the batch, of which the kernel touches a dozen; a batch the device cannot give that to is
+                // one to split, and the caller is told so)
+                const size_t list_bytes = (size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16;
+                if (c->lists.reserve(list_bytes) != hipSuccess)
+                    return fail(c, MDX_ERR_HIP, "the per-wavefront lists of this launch (" + std::to_string(list_bytes >> 20) + " MiB for " +
+                                std::to_string(b->n_reads) + " records) could not be allocated: tabulate the batch in smaller pieces");
+            }
             a.lists = (uint4 *)c->lists.p;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -987,9 +996,9 @@ static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b) {
     const int npos = 1 + c->len5p + c->len3p;
     // (the MR terms of a record are noted as bits sub * npos + key of one 64-bit word)
     if (!c->key0_plain || npos > 32 || !c->d_subs) return false;
-    if (mdx_k_fuse_lds_bytes(c->dims, npos) > kLdsLimit) return false;
+    if (mdx_k_fuse_lds_bytes(c->dims, npos, 64) > kLdsLimit) return false;
     // (the second TC table's byte offset travels in 10 bits of a staging entry, in units of 256 bytes)
-    if ((size_t)mdx_k_fuse_tcb_off(c->dims) * 4 + (size_t)c->dims.nlib * c->dims.w_tc * 4 > ((size_t)1 << 18)) return false;
+    if ((size_t)mdx_k_fuse_tcb_off(c->dims, 160) * 4 + (size_t)c->dims.nlib * c->dims.w_tc * 4 > ((size_t)1 << 18)) return false;
     return b->n_reads > 0 && b->n_bases <= 0xFFFF0000LL;
 }
 

@@ -131,6 +131,7 @@ struct MdxFuse {
     int len5p, len3p;
     uint32_t *subs_part;        // [grid][752 + 2 npos 94]: the block's own summary row (zeroed by the block itself)
     uint32_t *gen_list, *gen_count;
+    int qcap;                   // events of a wavefront's queue (mdx_k_fuse_qcap)
     int tcb_off;                // word offset in the LDS of the second TC table (the fused records' own), then 4 words of
                                 // reference-base counts, the lookup table and the terms (mdx_k_fuse_lds_bytes)
 };
@@ -203,8 +204,14 @@ hipError_t mdx_k_prepare(size_t lds_bytes);
 // rescale model), queue offset and size of its image, the word offset of the second TC table in it
 int mdx_k_fuse_block_threads();
 int mdx_k_fuse_queue_off(const MdxDims &d);
-int mdx_k_fuse_tcb_off(const MdxDims &d);
-size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos);
+int mdx_k_fuse_tcb_off(const MdxDims &d, int qcap);
+size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos, int qcap);
+// events of the fused kernel's queue per wavefront: what the LDS has room for, between 64 and 160 (even)
+static inline int mdx_k_fuse_qcap(const MdxDims &d, int npos, size_t lds_limit) {
+    int q = 160;
+    while (q > 64 && mdx_k_fuse_lds_bytes(d, npos, q) > lds_limit) q -= 2;
+    return q;
+}
 hipError_t mdx_k_fuse_prepare(size_t lds_bytes);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
 // resident reference bytes (guard bands included, n even) -> 4-bit codes, n / 2 bytes

@@ -125,6 +125,10 @@ typedef long long i64;
 #endif
 #define EVQ_CAP 64                      // rare-event queue capacity per wavefront
 #define EVQ_BYTES (EVQ_CAP * 20)        // per wavefront: S[64] u32x2 | R[64] u32x2 | W[64] u32
+// The fused kernel (one 1024-thread block per CU: the LDS has the room) holds the events of a whole run, as a rule: it never
+// drains inside one — the drain of a fused record's event may touch global memory (rs_event), and with a store or an atomic
+// possibly pending every wait of the pipelined loop is a vmcnt(0) — but stops the run, drains, and takes it up again
+// (MdxFuse::qcap events per wavefront: as many as the image has room for, mdx_k_fuse_qcap)
 #define MDX_PK_EVQ_BYTES (MDX_PK_QCAP * 20)   // the packed kernel's: {read 8 B, reference 8 B}[QCAP] | W[QCAP]
 #define MDX_PK_TAB_BYTES 1024                 // ... and per block: the lanes' read-column masks (64 x 8 B), the symbol-pair table (256 x 2 B)
 #define COL_S 24
@@ -186,12 +190,12 @@ int mdx_k_pk_blocks_per_cu() { return MDX_PK_WPS * 256 / MDX_PK_BLOCK; }
 int mdx_k_pk_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_PK_BLOCK / 64) * mdx_stage_entries(d) * 4; }
 size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * MDX_PK_EVQ_BYTES + LT_BYTES + MDX_PK_TAB_BYTES; }
 int mdx_k_fuse_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_FUSE_BLOCK / 64) * mdx_stage_entries(d) * 4; }
-int mdx_k_fuse_tcb_off(const MdxDims &d) {
-    const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * EVQ_BYTES + LT_BYTES;
+int mdx_k_fuse_tcb_off(const MdxDims &d, int qcap) {
+    const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * (size_t)qcap * 20 + LT_BYTES;
     return (int)(((end + 255) & ~(size_t)255) / 4);
 }
-size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos) {
-    return (size_t)mdx_k_fuse_tcb_off(d) * 4 + (size_t)d.nlib * d.w_tc * 4 + 16 + (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 +
+size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos, int qcap) {
+    return (size_t)mdx_k_fuse_tcb_off(d, qcap) * 4 + (size_t)d.nlib * d.w_tc * 4 + 16 + (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 +
            (size_t)(MDX_FUSE_BLOCK / 64) * (MDX_FUSE_MRM * 8 + MDX_FUSE_RSQ * 8 + 8);
 }
 
@@ -540,7 +544,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 
     // nine-entry LDS table of byte masks (entry n = the low n bytes of a 64-bit word set): the per-record byte masks
     // of the partial steps are two or three lookups instead of 64-bit shifts
-    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (BLOCK / 64) * (PK ? MDX_PK_EVQ_BYTES : EVQ_BYTES));
+    const int QCAP = RS ? a.rs.qcap : EVQ_CAP;      // events of the ASCII kernels' queue (20 bytes each)
+    u64 *const ltab = (u64 *)((u8 *)(lds + a.queue_off) + (BLOCK / 64) * (PK ? MDX_PK_EVQ_BYTES : QCAP * 20));
     // RS: the fused records count into a TC table of their own (the reference bases of their columns are part of the
     // rescale summary, rescale.py:142-143), added to the first one at block end; behind it four words for those counts,
     // the lookup table and the terms of the model
@@ -660,9 +665,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // Rare-event queue (wave-private, LDS): the lanes holding a byte that is not a plain match append
     // {read 8 bytes, reference 8 bytes, record word | lane << 18 | masked-quality flags [7:0]}; the queue is
     // drained completely, 64 events in parallel, whenever the next step might not fit.
-    u32x2 *const qS = (u32x2 *)((u8 *)(lds + a.queue_off) + wave * EVQ_BYTES);
-    u32x2 *const qR = qS + EVQ_CAP;
-    u32 *const qW = (u32 *)(qR + EVQ_CAP);
+    u32x2 *const qS = (u32x2 *)((u8 *)(lds + a.queue_off) + wave * (QCAP * 20));
+    u32x2 *const qR = qS + QCAP;
+    u32 *const qW = (u32 *)(qR + QCAP);
+    // RS: a step that finds the queue too full for a step's worth of events does nothing and says so (count()); the run
+    // stops behind it, drains outside its pipelined loop and starts again from that step (run())
+    bool rs_ovf = false;
+    int rs_kredo = 0;
     int qcount = 0;
     // PK: an event is a lane (sixteen nibbles) with a read column that is not a plain match, five words: its read nibbles, its
     // reference nibbles (as the step saw them: outside the step's tasks both are zero), and [5:0] lane | [6] side |
@@ -877,9 +886,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             return;
         }
-        if (lane < qcount) {
-            const u32x2 es = qS[lane], er = qR[lane];
-            const u32 w = qW[lane];
+#pragma unroll 1
+        for (int qb = 0; qb < qcount; qb += 64)
+        if (qb + lane < qcount) {
+            const u32x2 es = qS[qb + lane], er = qR[qb + lane];
+            const u32 w = qW[qb + lane];
             // (RS: an event of a fused record is known by its TC table — the second one)
             const bool rsev = RS && !((w >> 30) & 1u) && ((w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off;
             uint4 rent = make_uint4(0u, 0u, 0u, 0u);
@@ -935,7 +946,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
-    struct Stage { u32x3 s12, r12, q12; u32 ro, so, pk, aux; int lim; bool valid; };
+    struct Stage { u32x3 s12, r12, q12; u32 ro, so, pk, aux; int lim, k; bool valid; };
     // Three kinds of steps (one instantiation each):
     //   STEP_C  complete records: every task present, static byte masks;
     //   STEP_P  a column range per side: short records and contig edges ([-flank, min(nq, L))), gapped records whose
@@ -961,6 +972,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         const bool act = FULL || lane < st.lim;
         u32 s_lo = __builtin_amdgcn_alignbyte(st.s12.y, st.s12.x, st.so), s_hi = __builtin_amdgcn_alignbyte(st.s12.z, st.s12.y, st.so);
         u32 r_lo = __builtin_amdgcn_alignbyte(st.r12.y, st.r12.x, st.ro), r_hi = __builtin_amdgcn_alignbyte(st.r12.z, st.r12.y, st.ro);
+        // (RS: not unless the queue takes what this step raises — see rs_ovf; a complete step's events are known before it
+        // has touched a table, the other kinds make room for a whole step's worth)
+        if (RS && KIND == STEP_C) {
+            const u32 x0 = ((s_lo ^ r_lo) & c_em_lo) | (r_lo & c_hivm_lo) | ((s_hi ^ r_hi) & c_em_hi) | (r_hi & c_hivm_hi);
+            if (qcount + __popcll(__ballot(act && x0 != 0u)) > QCAP) { rs_ovf = true; rs_kredo = st.k; return; }
+        } else if (RS && qcount > QCAP - 64) { rs_ovf = true; rs_kredo = st.k; return; }
         u32 emvm_lo = c_em_lo, emvm_hi = c_em_hi;
         const u32 base_b = tc_base(st.pk, c_lane4);
         u32 q_lo = 0, q_hi = 0, qo_ = 0;
@@ -1122,7 +1139,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         const u64 mm = __ballot(ev);
         if (mm) {
             const int n = __popcll(mm);
-            if (qcount + n > EVQ_CAP) drain_all();
+            if (!RS && qcount + n > QCAP) drain_all();
             if (ev) {
                 const int slot = mbcnt64(mm, qcount);
                 u32x2 es, er;
@@ -1376,6 +1393,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 int nv = nrec - k * R;
                 nv = nv > R ? R : nv;
                 st.lim = nv * G;
+                st.k = k;
 #if MDX_ENT_AHEAD
                 const uint4 ent = ent_next;
                 {
@@ -1451,18 +1469,30 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             // records 2 %, config 3 1.8 % faster than with three; the masked kernel, with its third window, would spill)
             constexpr int PD = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : ((KIND == STEP_P || MASK) ? MDX_PD_P : (RS ? MDX_FUSE_PD : PIPE_DEPTH));
             Stage st[PD];
+            // (as a rule once through; RS: again from step rs_kredo, the queue drained — outside the pipelined loop, whose
+            // waits stay counted —, when a step found it too full)
+#pragma unroll 1
+            for (int kstart = 0;;) {
+                kf = kstart;
+                rs_ovf = false;
     #pragma unroll
-            for (int dd = 0; dd < PD; dd++) fill(st[dd]);
-            for (int k = PD; k < nsteps; k += PD) {
+                for (int dd = 0; dd < PD; dd++) fill(st[dd]);
+                for (int k = kstart + PD; k < nsteps && !(RS && rs_ovf); k += PD) {
     #pragma unroll
-                for (int dd = 0; dd < PD; dd++) {
-                    count(st[dd], kind_tag, std::true_type{}, qm_tag);      // (never the last step of the run)
-                    fill(st[dd]);
+                    for (int dd = 0; dd < PD; dd++) {
+                        if (!(RS && rs_ovf)) count(st[dd], kind_tag, std::true_type{}, qm_tag);      // (never the last step of the run)
+                        fill(st[dd]);
+                    }
                 }
-            }
     #pragma unroll
-            for (int dd = 0; dd < PD; dd++)
-                if (dd == 0 || st[dd].valid) count(st[dd], kind_tag, std::false_type{}, qm_tag);
+                for (int dd = 0; dd < PD; dd++)
+                    if (!(RS && rs_ovf) && (dd == 0 || st[dd].valid)) count(st[dd], kind_tag, std::false_type{}, qm_tag);
+                if (!RS || !rs_ovf) break;
+                drain_all();
+                rsq_flush();
+                __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): nothing but the run's loads in flight in its loop
+                kstart = rs_kredo;
+            }
             // (RS: the events of fused records look their staging entries up: drained before those are overwritten)
 #ifndef MDX_RSABL_NOFD
             if (RS && qcount > 0) drain_all();
@@ -2369,7 +2399,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (PK: the next tile's columns have had this tile's phase 1 to arrive: its second round trip goes out under the run)
                 // (PK: the stores of this phase 1 retired — they have had the phase —, so that the run's loops see nothing but
                 // loads in flight; the next tile's second round trip goes out behind that wait and lands under the run)
-                if (PK) __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (PK || RS) __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (PF && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) { if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp); }
                 else {
@@ -2476,7 +2506,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     mrm[lane] = 0ull;
                     if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
                 }
-                if (PK) __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
+                if (PK || RS) __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
                 run(0, m, kind_tag, std::true_type{}, n_fwd);
                 if (RSP) rsq_flush();
                 // RS: the MR sums of the fused records among them (known by their TC table)
