@@ -18,6 +18,14 @@
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU
+#ifdef MDX_WAVE_CLK
+static unsigned long long *g_dbg_clk = nullptr;
+extern "C" int mdx_dbg_clk_read(unsigned long long *out, int n) {
+    if (!g_dbg_clk) return -1;
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpy(out, g_dbg_clk, (size_t)n * 24, hipMemcpyDeviceToHost);
+}
+#endif
 constexpr int kLgdLds = 256;           // fragment lengths below this are counted in the LDS
 
 struct DevBuf {
@@ -432,7 +440,10 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     // A 4-bit SEQ column runs through the packed kernel when the launch is the plain fast tabulation: tables in the
     // LDS, 8-base lanes, 32-bit reference offsets, no quality masking, no fused rescaling.  Anything else reads an ASCII
     // copy (MDX_NO_PACKED=1 in the environment: always, for A/B runs).
-    const bool ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL;
+    // (MDX_FORCE_REF64=1 in the environment, tests only: every launch takes the path of a reference of 4 Gbases and more —
+    // 64-bit window offsets, the generic CIGAR walk for every record — at whatever geometry)
+    const bool force_ref64 = [] { const char *e = getenv("MDX_FORCE_REF64"); return e && *e && *e != '0'; }();
+    const bool ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL && !force_ref64;
     static const bool no_packed = [] { const char *e = getenv("MDX_NO_PACKED"); return e && *e && *e != '0'; }();
     const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 && !fuse &&
                         !(c->cfg.minqual > 0 && b_in->qual != nullptr) && !no_packed;
@@ -462,6 +473,10 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     a.n_lgd_over = c->d_n_lgd_over;
     a.err = c->d_err;
     a.record_base = c->record_base;
+#ifdef MDX_WAVE_CLK
+    if (!g_dbg_clk) (void)hipMalloc((void **)&g_dbg_clk, 3 * 8 * 20000);
+    a.dbg_clk = g_dbg_clk;
+#endif
     a.stage_off = mdx_k_stage_off(c->dims);
     a.queue_off = mdx_k_queue_off(c->dims);
     a.n_bases = b->n_bases;
@@ -992,6 +1007,7 @@ static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b) {
     const char *env = getenv("MDX_NO_FUSE");
     const bool off = env && *env && *env != '0';
     if (off || c->mode != MDX_MODE_LDS || c->lib_group != c->cfg.nlib || !c->dims.fast_ok()) return false;
+    { const char *e = getenv("MDX_FORCE_REF64"); if (e && *e && *e != '0') return false; }
     if (c->cfg.minqual > 0 || !(c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL)) return false;
     const int npos = 1 + c->len5p + c->len3p;
     // (the MR terms of a record are noted as bits sub * npos + key of one 64-bit word)

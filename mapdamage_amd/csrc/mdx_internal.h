@@ -186,6 +186,11 @@ struct MdxTabArgs {
     // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
     uint32_t *tile_ctr;
     int tile_quota;
+#ifdef MDX_WAVE_CLK
+    // instrumented builds (-DMDX_WAVE_CLK, tools/experiments/wave_clk.py): three clock readings per wavefront — start,
+    // end of the tile loop, end — read back with mdx_dbg_clk_read
+    unsigned long long *dbg_clk;
+#endif
 };
 // events (20 bytes: a lane's sixteen read and reference nibbles and a word) of the packed kernel a wavefront's LDS queue
 // holds (MDX_PK_EVQ_BYTES of mdx_kernels.hip); at least 64: the events of a step fit an empty queue

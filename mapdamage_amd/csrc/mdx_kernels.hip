@@ -541,6 +541,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     const u32 gwave = blockIdx.x * waves_per_block + wave;
     const u32 nwaves = gridDim.x * waves_per_block;
     u64 *raw = a.raw;
+#ifdef MDX_WAVE_CLK       // (instrumented builds: the wavefront's clock at its start, behind its tile loop and at its end)
+    if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave] = wall_clock64();
+#endif
 
     // nine-entry LDS table of byte masks (entry n = the low n bytes of a 64-bit word set): the per-record byte masks
     // of the partial steps are two or three lookups instead of 64-bit shifts
@@ -2476,6 +2479,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         if (RS && lane == 0) a.rs.gen_count[gwave] = n_rs;
     }
 
+#ifdef MDX_WAVE_CLK
+    if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave + 1] = wall_clock64();
+#endif
 #ifndef MDX_ONLY_PHASE1
     if (FAST && (lP | lI | lD | lC)) {
         // the entries this wavefront appended (its own stores: complete before they are read back)
@@ -2527,6 +2533,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         if (qcount > 0) drain_all();
         if (PK) bs_flush();
     }
+#ifdef MDX_WAVE_CLK
+    if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave + 2] = wall_clock64();
+#endif
     if (USE_LDS) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // the hand-written ds_adds of this wavefront
         __syncthreads();

@@ -201,6 +201,34 @@ def test_hip_global_atomic_fallback_matches_oracle(mid_genome):
     assert_tables_equal(got, want)
 
 
+@pytest.mark.parametrize("Q", [0, 20])
+def test_hip_path_of_a_reference_of_4_gbases_and_more(mid_genome, monkeypatch, Q):
+    """A reference of 4 Gbases and more (with its guard bands) takes 64-bit window offsets and the generic CIGAR walk for
+    every record (`FAST = false`) — forced here at the default geometry (MDX_FORCE_REF64, a test-only switch: no test
+    can hold a 4 Gb genome), against the oracle, with and without --min-basequal, from both forms of the SEQ column."""
+    from mapdamage_amd.engine import DamageEngine
+    batch = synth.make_reads(mid_genome, 60_000, 81, len_range=(25, 160), nlib=2, paired=True, frac_softclip=0.15,
+                             frac_ins=0.06, frac_del=0.06, frac_skip=0.01, frac_hardclip=0.01, with_qual=True, frac_filtered=0.03)
+    libs = [("S%d" % i, "L%d" % i) for i in range(2)]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, Q)
+    monkeypatch.setenv("MDX_FORCE_REF64", "1")
+    for packed in (False, True):
+        with DamageEngine(libs, 70, 10, Q) as eng:
+            assert eng.table_mode == "lds"
+            eng.set_reference(mid_genome)
+            eng.tabulate(batch, packed=packed)
+            got = eng.finish()
+            assert eng.packed_launches() == 0          # (the packed kernel reads 32-bit offsets: not this path)
+        assert_tables_equal(got, want)
+    monkeypatch.delenv("MDX_FORCE_REF64")
+    with DamageEngine(libs, 70, 10, Q) as eng:
+        eng.set_reference(mid_genome)
+        eng.tabulate(batch, packed=True)
+        got = eng.finish()
+        assert eng.packed_launches() == (0 if Q else 2)
+    assert_tables_equal(got, want)
+
+
 def test_hip_rejects_alignment_past_contig_end():
     from mapdamage_amd.engine import BadReadError, DamageEngine
     ref = synth.small_genome()

@@ -1,9 +1,9 @@
 """Per-wavefront start / end-of-tile-loop / end clocks of the tabulation kernel: how much of a launch is the tail of its
 slowest wavefronts, and who they are ("The hand-out of tiles").  Needs the instrumented build:
-    git apply tools/experiments/wave_clk.patch && python -m mapdamage_amd.build
-    gpurun -- python tools/experiments/wave_clk.py 25000000 ["config 3" | "config 4" | ...]      (tools/split_cost.py VARIANTS)
-    git checkout mapdamage_amd/csrc
-(three stores of the 100 MHz clock per wavefront; the library of the tree does not carry them)."""
+    tools/mkvariant.sh clk -DMDX_WAVE_CLK
+    gpurun -- 'MDX_LIB=tools/bin/libmdx_clk.so python tools/experiments/wave_clk.py 25000000 ["config 3" | "config 4" | ...]'   (tools/split_cost.py VARIANTS)
+(three stores of the 100 MHz clock per wavefront behind -DMDX_WAVE_CLK; the library of the tree does not carry them;
+MDX_SEQ_4BIT=1 for the packed kernel: 512 x 8 wavefronts)."""
 import ctypes, os, sys, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
@@ -11,6 +11,8 @@ sys.path.insert(0, str(ROOT))
 os.environ["MDX_DBG_CLK"] = "1"
 from mapdamage_amd import engine, synth
 from tools.split_cost import VARIANTS
+if os.environ.get('MDX_LIB'):
+    engine._lib = engine.load_library(os.environ['MDX_LIB'])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
 kw = dict(VARIANTS)[sys.argv[2] if len(sys.argv) > 2 else "config 3"]
 ref = synth.make_genome()

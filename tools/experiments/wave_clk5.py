@@ -1,5 +1,5 @@
 """wave_clk.py for the fused tabulate + rescale kernel (config 5): per-wavefront clocks of its 256 x 16 wavefronts.
-Needs the instrumented build (tools/experiments/wave_clk.patch)."""
+Needs the instrumented build (tools/mkvariant.sh clk -DMDX_WAVE_CLK; MDX_LIB=tools/bin/libmdx_clk.so)."""
 import ctypes, os, sys, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
