@@ -2400,9 +2400,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // wave-private LDS queue and counted later 64 at a time (drain_all), so the divergent
                 // classification code runs once per 64 events instead of once per record.
                 // (PK: the next tile's columns have had this tile's phase 1 to arrive: its second round trip goes out under the run)
-                // (PK: the stores of this phase 1 retired — they have had the phase —, so that the run's loops see nothing but
-                // loads in flight; the next tile's second round trip goes out behind that wait and lands under the run)
-                if (PK || RS) __builtin_amdgcn_s_waitcnt(0x0F70);
+                // (the stores of this phase 1 retired — they have had the phase —, so that the run's loops see nothing but loads
+                // in flight and their waits are counted; PK: the next tile's second round trip goes out behind that wait and
+                // lands under the run)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (PF && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) { if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp); }
                 else {
@@ -2512,7 +2513,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     mrm[lane] = 0ull;
                     if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
                 }
-                if (PK || RS) __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
+                __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
                 run(0, m, kind_tag, std::true_type{}, n_fwd);
                 if (RSP) rsq_flush();
                 // RS: the MR sums of the fused records among them (known by their TC table)
