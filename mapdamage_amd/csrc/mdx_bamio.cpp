@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -161,22 +163,22 @@ struct Block { size_t in_off, in_size, out_off, out_size; uint32_t crc; };   // 
 struct MappedFile {
     const uint8_t *p = nullptr;
     size_t n = 0;
+    int fd = -1;                     // kept open: the device decode's host threads read their blocks with pread()
     bool open(const char *path, std::string &err) {
-        const int fd = ::open(path, O_RDONLY);
+        fd = ::open(path, O_RDONLY);
         if (fd < 0) { err = std::string("cannot open ") + path; return false; }
         struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); err = std::string("not a regular file: ") + path; return false; }
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); fd = -1; err = std::string("not a regular file: ") + path; return false; }
         n = (size_t)st.st_size;
         if (n) {
             void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { ::close(fd); n = 0; err = std::string("cannot map ") + path; return false; }
+            if (m == MAP_FAILED) { ::close(fd); fd = -1; n = 0; err = std::string("cannot map ") + path; return false; }
             (void)madvise(m, n, MADV_SEQUENTIAL);
             p = (const uint8_t *)m;
         }
-        ::close(fd);
         return true;
     }
-    void close() { if (p) munmap((void *)p, n); p = nullptr; n = 0; }
+    void close() { if (p) munmap((void *)p, n); p = nullptr; n = 0; if (fd >= 0) ::close(fd); fd = -1; }
     ~MappedFile() { close(); }
     size_t size() const { return n; }
     const uint8_t &operator[](size_t i) const { return p[i]; }
@@ -291,6 +293,74 @@ void parallel_for(size_t n, int threads, F body) {
         });
     for (auto &th : pool) th.join();
 }
+
+// A pool of worker threads that lives as long as its owner (the device decode hands a share of every slab's BGZF blocks to
+// the host: starting a hundred threads per slab would cost what they save).  run(n, body): body(i) for i in [0, n), taken in
+// ascending chunks; returns at once, wait() joins the job.
+struct WorkerPool {
+    // a job lives as long as somebody holds it: a thread that wakes up late finds the items of *its* job all taken and
+    // goes back to sleep — nobody waits for threads, only for items
+    struct Job {
+        std::function<void(size_t)> body;
+        size_t n = 0, chunk = 1;
+        std::atomic<size_t> next{0}, done{0};
+    };
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::shared_ptr<Job> job;
+    size_t generation = 0;
+    bool stop = false;
+    explicit WorkerPool(int count) {
+        for (int t = 0; t < count; t++)
+            threads.emplace_back([this]() {
+                size_t seen = 0;
+                for (;;) {
+                    std::shared_ptr<Job> j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation;
+                        j = job;
+                    }
+                    for (;;) {
+                        const size_t lo = j->next.fetch_add(j->chunk);
+                        if (lo >= j->n) break;
+                        const size_t hi = std::min(j->n, lo + j->chunk);
+                        for (size_t i = lo; i < hi; i++) j->body(i);
+                        j->done.fetch_add(hi - lo, std::memory_order_release);
+                    }
+                }
+            });
+    }
+    void run(size_t count, size_t chunk_, std::function<void(size_t)> f) {
+        auto j = std::make_shared<Job>();
+        j->body = std::move(f); j->n = count; j->chunk = chunk_ ? chunk_ : 1;
+        std::lock_guard<std::mutex> lk(mu);
+        job = j; generation++;
+        cv.notify_all();
+    }
+    // every item of the last job done (the caller's thread helps itself to items meanwhile)
+    void wait() {
+        std::shared_ptr<Job> j;
+        { std::lock_guard<std::mutex> lk(mu); j = job; }
+        if (!j) return;
+        for (;;) {
+            const size_t lo = j->next.fetch_add(j->chunk);
+            if (lo >= j->n) break;
+            const size_t hi = std::min(j->n, lo + j->chunk);
+            for (size_t i = lo; i < hi; i++) j->body(i);
+            j->done.fetch_add(hi - lo, std::memory_order_release);
+        }
+        while (j->done.load(std::memory_order_acquire) < j->n) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
 
 // BAM magic, header text and reference dictionary at the start of the uncompressed stream.  Returns 0 and the
 // offset of the first record, 1 when `partial` and the header is not complete yet, -1 on a corrupt header.
@@ -809,6 +879,54 @@ void mdx_bam_close(mdx_bam_stream *s) {
 
 
 #ifndef MDX_HOST_ONLY
+namespace {
+// the process's pool of inflating threads (half of the hardware threads, 128 at most; MDX_GBAM_HOST_THREADS) and the buffer
+// they inflate into: both outlive a file — a hundred threads take milliseconds to start and to join, and a buffer of a
+// few hundred megabytes as long to fault in
+WorkerPool *host_pool() {
+    static std::mutex mu;
+    static std::unique_ptr<WorkerPool> pool;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool) {
+        // half of the hardware threads, 128 at most — and not more than the CPU time the control group grants (cpu.max:
+        // "quota period"): threads beyond the quota use it up in a fraction of the period and then the whole process
+        // stands still for the rest of it (a pod with 256 hardware threads and 16 CPUs' worth of quota: slabs took 60 ms
+        // now and then instead of 5 with 128 threads)
+        const unsigned hc = std::thread::hardware_concurrency();
+        int want_threads = (int)(hc > 8 ? hc / 2 : (hc ? hc : 4));
+        if (want_threads > 128) want_threads = 128;
+        if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long period = 0;
+            if (std::fscanf(fh, "%63s %ld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+                const long cpus = std::atol(q) / period;
+                if (cpus >= 1 && want_threads > (int)cpus - 2) want_threads = (int)std::max<long>(1, cpus - 2);
+            }
+            std::fclose(fh);
+        }
+        if (const char *e = std::getenv("MDX_GBAM_HOST_THREADS")) want_threads = std::max(1, std::atoi(e));
+        pool.reset(new WorkerPool(want_threads));
+    }
+    return pool.get();
+}
+// (pinned: a copy out of pageable memory has the runtime pin and unpin the pages it reads, under the address space's lock
+// — with a hundred threads faulting pages in at the same time, slabs took 50 ms now and then instead of 5)
+std::mutex g_hbuf_mu;
+uint8_t *g_hbuf = nullptr;
+size_t g_hbuf_cap = 0;
+std::atomic<double> g_host_share{0.12};      // what the last file's slabs settled on: where the next file starts
+void host_buffer_take(uint8_t *&p, size_t &cap) {
+    std::lock_guard<std::mutex> lk(g_hbuf_mu);
+    p = g_hbuf; cap = g_hbuf_cap; g_hbuf = nullptr; g_hbuf_cap = 0;
+}
+void host_buffer_give(uint8_t *&p, size_t &cap) {
+    std::lock_guard<std::mutex> lk(g_hbuf_mu);
+    if (p && cap > g_hbuf_cap) { std::swap(p, g_hbuf); std::swap(cap, g_hbuf_cap); }
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 // GPU-side decode (mdx_gbam.hip): the compressed file goes to HBM a slab of BGZF blocks at a time, is inflated and
 // unpacked there, and the batch columns never exist on the host.
@@ -843,6 +961,18 @@ struct mdx_gbam {
     bool phase_known = true, next_verified = true;
     int fixups = 0;                      // segments whose guessed first record the chain did not confirm (rescanned)
     int slabs_done = 0;
+    // The host's share of a slab's inflate (round 4): the device inflater is bound by instruction issue — more wavefronts
+    // do not help it — while the host's cores idle: the last `host_share` of a slab's inflated bytes are inflated by a
+    // pool of host threads into `hbuf` and copied to their place in HBM on a stream of their own, in pieces, under the
+    // device's inflate of the rest (whose compressed bytes alone are uploaded).  Adjusted slab by slab to whoever
+    // finished first; MDX_GBAM_HOST_SHARE in the environment fixes it (0: the device inflates everything).
+    double host_share = 0.12;
+    bool host_share_fixed = false, slabs_timed = false;
+    WorkerPool *pool = nullptr;          // (the process's: host_pool())
+    uint8_t *hbuf = nullptr;             // pinned host memory (the process's: host_buffer_take / _give)
+    size_t hbuf_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_infl = nullptr, ev_infl0 = nullptr;
     std::string error;
     bool want_qual = false, want_mate = false;
     int minqual = 0;                     // --min-basequal on the device path (mdx_gbam_set_min_basequal)
@@ -892,13 +1022,20 @@ int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out) {
         }
         g->next_block = k;
         g->phase = k < g->blocks.size() ? g->hs->header_bytes - g->blocks[k].out_off : 0;
+        g->host_share = g_host_share.load();
+        if (const char *e = std::getenv("MDX_GBAM_HOST_SHARE")) {
+            g->host_share = std::min(0.9, std::max(0.0, std::atof(e)));
+            g->host_share_fixed = true;
+        }
         if (hipSetDevice(g->device) != hipSuccess || mdx_k_gbam_prepare() != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
         {
             static mdx_crc32::Tables tables;
             static std::once_flag once;
             std::call_once(once, [] { mdx_crc32::make_tables(tables); });
-            if (hipMalloc(&g->d_crc_tables, sizeof(tables)) != hipSuccess ||
-                hipMemcpy(g->d_crc_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+            // (what the previous file of this context left behind: its arena and the tables)
+            mdx_ctx_scratch_take(ctx, &g->arena.p, &g->arena.cap, &g->d_crc_tables, (void **)&g->copy_stream, (void **)&g->ev_infl);
+            if (!g->d_crc_tables && (hipMalloc(&g->d_crc_tables, sizeof(tables)) != hipSuccess ||
+                hipMemcpy(g->d_crc_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess)) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
         }
         return MDX_OK;
     } catch (const std::exception &e) {
@@ -1027,19 +1164,141 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         lap("allocate");
         // the previous slab's columns may still be read by the tabulation kernel
         if (hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
-        if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+        // the host's share: the blocks [nh, nba), the last `host_share` of the inflated bytes (slabs of a few hundred blocks
+        // are the device's alone)
+        size_t nh = nba;
+        // (MDX_GBAM_HOST_MIN_BLOCKS: tests put small files through the host's share)
+        static const size_t host_min_blocks = [] { const char *e = std::getenv("MDX_GBAM_HOST_MIN_BLOCKS"); return e ? (size_t)std::max(2, std::atoi(e)) : (size_t)512; }();
+        if (g->host_share > 0.0 && nba >= host_min_blocks) {
+            const size_t target = (size_t)((double)unc_bytes * g->host_share);
+            size_t acc = 0;
+            while (nh > 1 && acc + g->blocks[b0 + nh - 1].out_size <= target) { acc += g->blocks[b0 + nh - 1].out_size; nh--; }
+            if (nba - nh < std::min<size_t>(64, host_min_blocks / 2)) nh = nba;
+        }
+        const size_t head_comp = nh == nba ? comp_bytes : (size_t)blk[4 * nh];        // compressed bytes the device needs
+        if (nh < nba && g->ev_infl0) (void)hipEventRecord(g->ev_infl0, st);
+        if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, head_comp, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(g->blk.p, blk.data(), nba * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(g->crc.p, crcs.data(), nba * 4, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
         int *d_bad_crc = (int *)((char *)g->small.p + 40);
         const int no_bad = 0x7FFFFFFF;
         (void)hipMemcpyAsync(d_bad_crc, &no_bad, 4, hipMemcpyHostToDevice, st);
         (void)hipMemsetAsync(g->forced.p, 0xFF, nba * 4, st);
+        // (the host's threads are about to fault in the pages of the file they read; the runtime, copying from pageable memory,
+        // works on the same address space: one after the other)
+        if (nh < nba && !std::getenv("MDX_GBAM_NO_UPLOAD_SYNC") && hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
         lap("upload");
-        mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nba, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nh, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        if (nh < nba) {
+            // ---- the host's blocks: inflated (and CRC-checked) by the pool into hbuf, piece by piece; this thread copies
+            // every finished piece to its place in `unc` on the copy stream, under the device's inflate
+            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) return MDX_ERR_HIP;
+            if (!g->ev_infl && hipEventCreate(&g->ev_infl) != hipSuccess) return MDX_ERR_HIP;
+            if (!g->ev_infl0 && hipEventCreate(&g->ev_infl0) != hipSuccess) return MDX_ERR_HIP;
+            (void)hipEventRecord(g->ev_infl, st);
+            if (!g->pool) g->pool = host_pool();
+            if (!g->hbuf) host_buffer_take(g->hbuf, g->hbuf_cap);
+            const size_t nt = nba - nh, tail0 = blk[4 * nh + 2], tail_bytes = unc_bytes - tail0;
+            if (g->hbuf_cap < tail_bytes + 64) {
+                // (room for the largest share of a slab like this one, so that it need not grow again)
+                if (g->hbuf) (void)hipHostFree(g->hbuf);
+                g->hbuf = nullptr;
+                g->hbuf_cap = std::max(tail_bytes + 64, (size_t)((double)unc_bytes * 0.46) + ((size_t)1 << 20));
+                const auto t_p = std::chrono::steady_clock::now();
+                if (hipHostMalloc((void **)&g->hbuf, g->hbuf_cap, hipHostMallocDefault) != hipSuccess) { g->hbuf_cap = 0; g->error = "out of pinned host memory"; return MDX_ERR_HIP; }
+                if (timing) std::fprintf(stderr, "mdx_gbam_next pinned buffer of %.0f MB: %.1f ms\n", g->hbuf_cap / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p).count());
+            }
+            // pieces of about 8 MiB of inflated bytes; done[j] counts the finished blocks of piece j
+            std::vector<size_t> piece_lo;          // first block (relative to nh) of every piece, and the end
+            {
+                size_t acc = 0;
+                piece_lo.push_back(0);
+                for (size_t i = 0; i < nt; i++) {
+                    acc += blk[4 * (nh + i) + 3];
+                    if (acc >= ((size_t)8 << 20) && i + 1 < nt) { piece_lo.push_back(i + 1); acc = 0; }
+                }
+                piece_lo.push_back(nt);
+            }
+            const size_t np = piece_lo.size() - 1;
+            std::vector<uint32_t> piece_of(nt);
+            for (size_t j = 0; j < np; j++) for (size_t i = piece_lo[j]; i < piece_lo[j + 1]; i++) piece_of[i] = (uint32_t)j;
+            std::unique_ptr<std::atomic<uint32_t>[]> done(new std::atomic<uint32_t>[np]);
+            for (size_t j = 0; j < np; j++) done[j] = 0;
+            std::atomic<int> bad_block{-1};
+            std::vector<int32_t> host_status(nt);
+            const MappedFile &file = *g->hs->file;
+            const Block *const bl = &g->blocks[b0 + nh];
+            uint8_t *const hb = g->hbuf;
+            g->pool->run(nt, 4, [&, bl, hb, tail0](size_t i) {
+                const Block &k = bl[i];
+                const size_t off = (size_t)(k.out_off - out0) - tail0;
+                // (the block's compressed bytes through pread() into a buffer of the thread's own: a hundred threads faulting
+                // pages of the file's mapping in — under the address space's lock, next to whatever else maps and unmaps —
+                // stalled for tens of milliseconds now and then)
+                thread_local std::vector<uint8_t> mine;
+                const uint8_t *src = &file[k.in_off];
+                if (file.fd >= 0 && k.in_size) {
+                    if (mine.size() < k.in_size) mine.resize(std::max<size_t>(k.in_size, 80 << 10));
+                    size_t got = 0;
+                    while (got < k.in_size) {
+                        const ssize_t r = pread(file.fd, mine.data() + got, k.in_size - got, (off_t)(k.in_off + got));
+                        if (r <= 0) break;
+                        got += (size_t)r;
+                    }
+                    if (got == k.in_size) src = mine.data();
+                }
+                const bool ok = k.out_size == 0 || inflate_block(src, k.in_size, hb + off, k.out_size, k.crc);
+                host_status[i] = ok ? (int32_t)k.out_size : -1;
+                if (!ok) { int expect = -1; bad_block.compare_exchange_strong(expect, (int)i); }
+                done[piece_of[i]].fetch_add(1, std::memory_order_release);
+            });
+            bool copy_failed = false;
+            const auto t_h0 = std::chrono::steady_clock::now();
+            double t_waited = 0, t_copied = 0;
+            for (size_t j = 0; j < np; j++) {
+                const auto t_a = std::chrono::steady_clock::now();
+                const uint32_t need = (uint32_t)(piece_lo[j + 1] - piece_lo[j]);
+                while (done[j].load(std::memory_order_acquire) < need) std::this_thread::sleep_for(std::chrono::microseconds(30));
+                const auto t_b = std::chrono::steady_clock::now();
+                const size_t lo = (size_t)blk[4 * (nh + piece_lo[j]) + 2] - tail0;
+                const size_t hi = piece_lo[j + 1] < nt ? (size_t)blk[4 * (nh + piece_lo[j + 1]) + 2] - tail0 : tail_bytes;
+                if (hi > lo && hipMemcpyAsync((char *)g->unc.p + tail0 + lo, hb + lo, hi - lo, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess)
+                    copy_failed = true;
+                const auto t_c = std::chrono::steady_clock::now();
+                t_waited += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+                t_copied += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+            }
+            g->pool->wait();
+            if (timing)
+                std::fprintf(stderr, "mdx_gbam_next host share  %.2f: %zu of %zu blocks, %.1f MB inflated on %zu threads; waited for them %.2f ms, copies %.2f ms, all %.2f ms; device %s\n",
+                             g->host_share, nt, nba, tail_bytes / 1e6, g->pool->threads.size(), t_waited, t_copied,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count(),
+                             hipEventQuery(g->ev_infl) == hipSuccess ? "done" : "still inflating");
+            // (the share that would have let both sides finish together, from the two rates of this slab — the device's
+            // upload and inflate of its blocks, the host's inflate and copies of the others — approached by halves)
+            const double t_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+            float t_dev = 0.f;
+            if (!g->host_share_fixed && g->slabs_timed && hipEventSynchronize(g->ev_infl) == hipSuccess &&
+                hipEventElapsedTime(&t_dev, g->ev_infl0, g->ev_infl) == hipSuccess && t_dev > 0.1f && t_host > 0.1) {
+                const double f = (double)tail_bytes / (double)unc_bytes;
+                const double r_host = f / t_host, r_dev = (1.0 - f) / (double)t_dev;
+                const double balanced = r_host / (r_host + r_dev);
+                // (aiming a little below the balance: a host that finishes early costs nothing, one that finishes late costs its lateness)
+                g->host_share = std::min(0.45, std::max(0.04, 0.5 * g->host_share + 0.5 * 0.85 * balanced));
+                g_host_share.store(g->host_share);
+            }
+            g->slabs_timed = true;      // (the first slab of a handle has no start event of its own yet)
+            if (copy_failed || hipMemcpyAsync((int32_t *)g->status.p + nh, host_status.data(), nt * 4, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess ||
+                hipStreamSynchronize(g->copy_stream) != hipSuccess) { g->error = "upload of the host-inflated blocks failed"; return MDX_ERR_HIP; }
+            if (bad_block.load() >= 0) {
+                g->error = "corrupt BGZF block " + std::to_string(b0 + nh + (size_t)bad_block.load()) + " (DEFLATE stream, ISIZE or CRC32)";
+                return MDX_ERR_ARG;
+            }
+        }
         // (the next slab's block headers, while the device inflates this one)
         if (!timing && !g->scan_to(in1 + want + 65536)) return MDX_ERR_ARG;
         lap("inflate");
-        mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nba, d_bad_crc, st);
+        mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nh, d_bad_crc, st);
         lap("crc32");
         // the chains of the segments (every block inflated is one: those ahead of the slab say whether the next slab's
         // first record can be found without this one), then their check on the host
@@ -1291,12 +1550,28 @@ int mdx_gbam_at_end(const mdx_gbam *g) { return (!g || (g->next_block >= g->bloc
 
 void mdx_gbam_close(mdx_gbam *g) {
     if (!g) return;
+    const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mdx_gbam_close %-11s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
-    for (auto *b : g->all()) if (b->p) (void)hipFree(b->p);
-    for (void *p : {g->d_rg_names, g->d_rg_off, g->d_lib_of_rg, g->d_crc_tables}) if (p) (void)hipFree(p);
+    lap("sync");
+    // (arena, CRC tables, copy stream and the host's buffer stay with the context / the process for the next file: the
+    // context must still be alive — it owns the stream this handle works on)
+    host_buffer_give(g->hbuf, g->hbuf_cap);
+    if (g->ev_infl0) (void)hipEventDestroy(g->ev_infl0);
+    mdx_ctx_scratch_give(g->ctx, g->arena.p, g->arena.cap, g->d_crc_tables, g->copy_stream, g->ev_infl);
+    for (void *p : {g->d_rg_names, g->d_rg_off, g->d_lib_of_rg}) if (p) (void)hipFree(p);
+    lap("device");
     if (g->hs) mdx_bam_close(g->hs);
+    lap("file");
     delete g;
+    lap("handle");
 }
 
 #endif  // MDX_HOST_ONLY

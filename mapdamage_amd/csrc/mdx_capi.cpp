@@ -118,6 +118,10 @@ struct mdx_ctx {
     hipEvent_t st_copied[2] = {nullptr, nullptr}, st_done[2] = {nullptr, nullptr};
     bool st_busy[2] = {false, false};
     int st_turn = 0;
+    void *gbam_arena = nullptr;      // the device decode's arena and CRC tables, kept between files (mdx_ctx_scratch_*)
+    size_t gbam_arena_cap = 0;
+    void *gbam_tables = nullptr;
+    void *gbam_stream = nullptr, *gbam_event = nullptr;
     int64_t record_base = 0;   // added to the batch index of a record in the error word (mdx_set_record_base)
     DevBuf unpacked;       // ASCII copy of a 4-bit SEQ column, for the launches the packed kernel does not take
     DevBuf lists;          // per-wavefront entry lists of the tabulation kernel (MdxTabArgs::lists)
@@ -297,6 +301,10 @@ void mdx_destroy(mdx_ctx *c) {
         if (c->st_done[i]) (void)hipEventDestroy(c->st_done[i]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->gbam_arena) (void)hipFree(c->gbam_arena);
+    if (c->gbam_tables) (void)hipFree(c->gbam_tables);
+    if (c->gbam_stream) (void)hipStreamDestroy((hipStream_t)c->gbam_stream);
+    if (c->gbam_event) (void)hipEventDestroy((hipEvent_t)c->gbam_event);
     c->lists.release();
     c->unpacked.release();
     c->rs_part.release();
@@ -884,6 +892,31 @@ int mdx_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
 }
 
 int mdx_table_mode(const mdx_ctx *c) { return c ? c->mode : -1; }
+
+// The device decode (mdx_gbam_*) leaves its arena and its CRC tables with the context when a file is closed and takes them
+// back when the next one is opened: freeing and allocating a few hundred megabytes costs milliseconds per file.
+void mdx_ctx_scratch_give(mdx_ctx *c, void *arena, size_t cap, void *tables, void *stream, void *event) {
+    if (!c) {
+        if (arena) (void)hipFree(arena);
+        if (tables) (void)hipFree(tables);
+        if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+        if (event) (void)hipEventDestroy((hipEvent_t)event);
+        return;
+    }
+    if (arena) {
+        if (c->gbam_arena && c->gbam_arena_cap >= cap) (void)hipFree(arena);
+        else { if (c->gbam_arena) (void)hipFree(c->gbam_arena); c->gbam_arena = arena; c->gbam_arena_cap = cap; }
+    }
+    if (tables) { if (c->gbam_tables) (void)hipFree(tables); else c->gbam_tables = tables; }
+    if (stream) { if (c->gbam_stream) (void)hipStreamDestroy((hipStream_t)stream); else c->gbam_stream = stream; }
+    if (event) { if (c->gbam_event) (void)hipEventDestroy((hipEvent_t)event); else c->gbam_event = event; }
+}
+void mdx_ctx_scratch_take(mdx_ctx *c, void **arena, size_t *cap, void **tables, void **stream, void **event) {
+    *arena = nullptr; *cap = 0; *tables = nullptr; *stream = nullptr; *event = nullptr;
+    if (!c) return;
+    *arena = c->gbam_arena; *cap = c->gbam_arena_cap; *tables = c->gbam_tables; *stream = c->gbam_stream; *event = c->gbam_event;
+    c->gbam_arena = nullptr; c->gbam_arena_cap = 0; c->gbam_tables = nullptr; c->gbam_stream = nullptr; c->gbam_event = nullptr;
+}
 
 int mdx_ctx_stream(mdx_ctx *c, void **stream, int *device) {
     if (!c) return MDX_ERR_ARG;

@@ -287,6 +287,11 @@ void mdx_k_rescale_lists_pass(const MdxRescaleArgs &a, int fused_rows, int n_cu,
 size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu);
 void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *cap);
 
+// (mdx_capi.cpp) the device decode's arena and CRC tables, kept by the context between files
+struct mdx_ctx;
+extern "C" void mdx_ctx_scratch_give(mdx_ctx *c, void *arena, size_t cap, void *tables, void *stream, void *event);
+extern "C" void mdx_ctx_scratch_take(mdx_ctx *c, void **arena, size_t *cap, void **tables, void **stream, void **event);
+
 // ---- GPU-side BAM decode (mdx_gbam.hip; host side: mdx_gbam_* in mdx_bamio.cpp)
 struct MdxGbamCols {
     uint16_t *flag, *lib;

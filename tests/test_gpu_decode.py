@@ -182,6 +182,61 @@ def test_any_bgzf_layout_on_the_device_path(tmp_path, layout):
     assert "decoding on the host" not in log and "gave up" not in log
 
 
+def test_the_hosts_share_of_the_inflate(tmp_path):
+    """The last part of a slab's BGZF blocks inflated by host threads into pinned memory and copied to their place in HBM
+    under the device's inflate of the rest (forced on a small file: MDX_GBAM_HOST_SHARE / _MIN_BLOCKS, read when the library
+    first decodes — hence a process of its own): same columns as the host decoder for both block layouts, and a damaged
+    block in the host's part is the error it is in the device's."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from tests import test_gpu_decode as t
+        from mapdamage_amd import sam
+        from mapdamage_amd.engine import DamageEngine
+        import pathlib, tempfile
+        for layout in ("htslib", "cut"):
+            d = pathlib.Path(tempfile.mkdtemp())
+            ref, b, rg, path = t._write(d, n=30000, layout=layout)
+            host = sam.read_bam_native(str(path))
+            with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+                eng.set_reference(ref)
+                with sam.GpuBamStream(eng, str(path), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)], chunk_bytes=1 << 20,
+                                      want_qual=True) as g:
+                    pos, seq, qual, n = [], [], [], 0
+                    while (v := g.next_view()) is not None:
+                        eng.sync()
+                        k = int(v.n_reads); n += k
+                        pos.append(t._d2h(v.pos, k, np.int32)); seq.append(t._d2h(v.seq, int(v.n_bases), np.uint8))
+                        qual.append(t._d2h(v.qual, int(v.n_bases), np.uint8))
+                assert n == host.batch.n
+                np.testing.assert_array_equal(np.concatenate(pos), host.batch.pos)
+                np.testing.assert_array_equal(np.concatenate(seq), host.batch.seq)
+                np.testing.assert_array_equal(np.concatenate(qual), host.batch.qual)
+                # a flipped byte near the end of the file: in the host's share of the last slab
+                raw = bytearray(path.read_bytes())
+                raw[len(raw) - 3000] ^= 0x5A
+                broken = d / "broken.bam"
+                broken.write_bytes(bytes(raw))
+                try:
+                    with sam.GpuBamStream(eng, str(broken), readgroups=[("rgA", 0), ("rg_b2", 1), ("x", 0)], chunk_bytes=1 << 20) as g:
+                        while g.next_view() is not None:
+                            pass
+                    raise SystemExit("a damaged block went unnoticed")
+                except ValueError as e:
+                    assert "corrupt BGZF block" in str(e), e
+        print("host share ok")
+    """ % root)
+    env = dict(os.environ, MDX_GBAM_HOST_SHARE="0.5", MDX_GBAM_HOST_MIN_BLOCKS="8", MDX_GBAM_HOST_THREADS="6")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "host share ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_a_damaged_block_is_an_error_on_the_device_path(tmp_path):
     from mapdamage_amd.engine import DamageEngine
     ref, b, rg, path = _write(tmp_path, n=5000)
