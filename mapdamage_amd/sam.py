@@ -22,6 +22,21 @@ for _i, _c in enumerate(b"=ACMGRSVTWYHKDBN"):
     _SEQ_ENCODE[ord(chr(_c).lower())] = _i
 
 
+def usable_cpus():
+    """CPUs this process may keep busy: its affinity mask, cut down to what the control group grants (``cpu.max``: a pod
+    with 256 hardware threads and 16 CPUs' worth of quota stalls for most of every period under 64 busy threads)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class BAMError(RuntimeError):
     """Read-group problems (mapdamage/reader.py:16-17)."""
 
@@ -244,7 +259,7 @@ class BgzfWriter:
         import os
         from concurrent.futures import ThreadPoolExecutor
         self._out = open(path, "wb")
-        self._pool = ThreadPoolExecutor(threads or min(32, os.cpu_count() or 1))
+        self._pool = ThreadPoolExecutor(threads or min(32, usable_cpus()))
         self._tail = b""
 
     def write(self, data):
@@ -356,7 +371,7 @@ def read_bam_native(path, threads=None):
     from .engine import MdxBatch, load_library
     lib = load_library()
     handle = ctypes.c_void_p()
-    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
+    rc = lib.mdx_bam_read(str(path).encode(), ctypes.c_int(threads or min(64, usable_cpus())),
                           ctypes.byref(handle))
     owner = _NativeBam(lib, handle)
     if rc != 0:
@@ -487,7 +502,7 @@ class BamStream:
         self._lib = load_library()
         self._stream = ctypes.c_void_p()
         self.path, self.chunk_bytes, self.keep_raw = path, int(chunk_bytes), bool(keep_raw)
-        rc = self._lib.mdx_bam_open(str(path).encode(), ctypes.c_int(threads or min(64, os.cpu_count() or 1)),
+        rc = self._lib.mdx_bam_open(str(path).encode(), ctypes.c_int(threads or min(64, usable_cpus())),
                                     ctypes.byref(self._stream))
         if rc != 0:
             message = self._error()

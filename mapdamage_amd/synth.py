@@ -402,7 +402,8 @@ def parallel_batch(maker, ref, n, seed, workers=None, shard=500_000):
     import os
     global _PAR_REF
     jobs = [(maker, min(shard, n - lo), [seed, k]) for k, lo in enumerate(range(0, n, shard))]
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from .sam import usable_cpus
+    avail = usable_cpus()
     workers = max(1, min(workers or avail, len(jobs)))
     _PAR_REF = ref
     try:
