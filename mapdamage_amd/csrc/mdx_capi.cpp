@@ -130,6 +130,7 @@ struct mdx_ctx {
     DevBuf rs_in;          // fused launch: per-wavefront lists of the records left to the rescale kernels (MdxFuse::gen_list)
     uint32_t *d_tile_ctr = nullptr; // tile counters of the fast kernels' pools (MdxTabArgs::tile_ctr)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
+    size_t pkf_prepared = 0;       // ... and the packed fused kernel
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
     int64_t n_packed = 0;          // launches of the packed kernel so far (mdx_packed_launches)
     int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
@@ -453,8 +454,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     const bool force_ref64 = [] { const char *e = getenv("MDX_FORCE_REF64"); return e && *e && *e != '0'; }();
     const bool ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL && !force_ref64;
     static const bool no_packed = [] { const char *e = getenv("MDX_NO_PACKED"); return e && *e && *e != '0'; }();
-    const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 && !fuse &&
-                        !(c->cfg.minqual > 0 && b_in->qual != nullptr) && !no_packed;
+    // (a fused launch: the packed fused kernel, one library — its caller has checked that it applies, packed_fuse_applies)
+    const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 &&
+                        (fuse ? c->cfg.nlib == 1 : !(c->cfg.minqual > 0 && b_in->qual != nullptr)) && !no_packed;
     mdx_batch b_ascii;
     const mdx_batch *b = b_in;
     if (!packed) {
@@ -524,15 +526,22 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             const int npos = 1 + fuse->len5p + fuse->len3p;
             a.rs = *fuse;
             a.queue_off = mdx_k_fuse_queue_off(a.dims);
-            a.rs.qcap = mdx_k_fuse_qcap(a.dims, npos, kLdsLimit);
-            a.rs.tcb_off = mdx_k_fuse_tcb_off(a.dims, a.rs.qcap);
-            lds = mdx_k_fuse_lds_bytes(a.dims, npos, a.rs.qcap);
+            if (packed) {
+                a.rs.qcap = MDX_PK_QCAP;
+                a.rs.tcb_off = mdx_k_pkf_tcb_off(a.dims);
+                lds = mdx_k_pkf_lds_bytes(a.dims, npos);
+            } else {
+                a.rs.qcap = mdx_k_fuse_qcap(a.dims, npos, kLdsLimit);
+                a.rs.tcb_off = mdx_k_fuse_tcb_off(a.dims, a.rs.qcap);
+                lds = mdx_k_fuse_lds_bytes(a.dims, npos, a.rs.qcap);
+            }
             wpb_l = mdx_k_fuse_block_threads() / 64;
             const int64_t want_f = (ntiles + wpb_l - 1) / wpb_l;
             grid = (int)(want_f < c->n_cu ? want_f : c->n_cu);
-            if (!c->fuse_prepared || c->fuse_prepared < lds) {
-                HIP_TRY(c, mdx_k_fuse_prepare(lds));
-                c->fuse_prepared = lds;
+            size_t &prepared = packed ? c->pkf_prepared : c->fuse_prepared;
+            if (!prepared || prepared < lds) {
+                HIP_TRY(c, packed ? mdx_k_pkf_prepare(lds) : mdx_k_fuse_prepare(lds));
+                prepared = lds;
             }
         }
         {
@@ -577,7 +586,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             HIP_TRY(c, c->rs_in.reserve((size_t)nwaves * (size_t)(a.list_cap + 1) * 4));
             a.rs.gen_count = (uint32_t *)c->rs_in.p;
             a.rs.gen_list = a.rs.gen_count + nwaves;
-            mdx_k_tabulate_fused(a, grid, lds, c->stream);
+            if (packed) { mdx_k_tabulate_packed_fused(a, grid, lds, c->stream); c->n_packed++; }
+            else mdx_k_tabulate_fused(a, grid, lds, c->stream);
             c->fuse_list_cap = a.list_cap;
             if (fused_grid) *fused_grid = grid;
         } else if (packed) {
@@ -1036,7 +1046,7 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid,
 // The fused launch applies when the tabulation is the plain fast kernel in one launch (tables in the LDS, all libraries
 // at once, no --min-basequal, 32-bit reference offsets) and the model is one the end-window walk can take (key 0 the
 // identity) whose tables fit the image next to a second TC table.  MDX_NO_FUSE=1 in the environment: never (A/B).
-static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b) {
+static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b, bool packed_form = false) {
     const char *env = getenv("MDX_NO_FUSE");
     const bool off = env && *env && *env != '0';
     if (off || c->mode != MDX_MODE_LDS || c->lib_group != c->cfg.nlib || !c->dims.fast_ok()) return false;
@@ -1045,6 +1055,13 @@ static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b) {
     const int npos = 1 + c->len5p + c->len3p;
     // (the MR terms of a record are noted as bits sub * npos + key of one 64-bit word)
     if (!c->key0_plain || npos > 32 || !c->d_subs) return false;
+    if (packed_form) {
+        // (the packed fused kernel: one library, its own image — no second TC table)
+        static const bool no_packed = [] { const char *e = getenv("MDX_NO_PACKED"); return e && *e && *e != '0'; }();
+        static const bool no_pkf = [] { const char *e = getenv("MDX_NO_PACKED_FUSE"); return e && *e && *e != '0'; }();
+        if (no_packed || no_pkf || c->cfg.nlib != 1 || mdx_k_pkf_lds_bytes(c->dims, npos) > kLdsLimit) return false;
+        return b->n_reads > 0 && b->n_bases <= 0xFFFF0000LL;
+    }
     if (mdx_k_fuse_lds_bytes(c->dims, npos, 64) > kLdsLimit) return false;
     // (the second TC table's byte offset travels in 10 bits of a staging entry, in units of 256 bytes)
     if ((size_t)mdx_k_fuse_tcb_off(c->dims, 160) * 4 + (size_t)c->dims.nlib * c->dims.w_tc * 4 > ((size_t)1 << 18)) return false;
@@ -1056,14 +1073,25 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     // one pass over one resident batch: the tables and, from the same columns in HBM, the rescaled qualities
     int rc = check_batch(c, b_in);
     if (rc != MDX_OK) return rc;
-    mdx_batch b_ascii;
-    rc = ascii_view(c, b_in, &b_ascii);
-    if (rc != MDX_OK) return rc;
-    const mdx_batch *b = &b_ascii;
     // (the fused kernel copies the quality column in 16-byte units: both columns at the same 16-byte phase — true of any two
     // device allocations)
-    if (!c->d_ref || !c->d_lut || !b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status || d_qual_out == b->qual ||
-        (((uintptr_t)d_qual_out ^ (uintptr_t)b->qual) & 15) != 0 || !fuse_applies(c, b)) {
+    const bool args_ok = c->d_ref && c->d_lut && b_in->qual && d_mtid && d_mpos && d_qual_out && d_mr_raw && d_status &&
+                         d_qual_out != b_in->qual && (((uintptr_t)d_qual_out ^ (uintptr_t)b_in->qual) & 15) == 0;
+    // A 4-bit SEQ column goes through the packed fused kernel as it is (one library); the records that kernel lists for the
+    // rescale kernels, which read ASCII, get their stretches of an ASCII scratch column written behind it (mdx_k_unpack_listed)
+    const bool pkf = args_ok && b_in->seq_format == MDX_SEQ_4BIT && b_in->n_bases > 0 && fuse_applies(c, b_in, true);
+    mdx_batch b_ascii;
+    if (pkf) {
+        b_ascii = *b_in;
+        HIP_TRY(c, c->unpacked.reserve((size_t)b_in->n_bases + 64));
+        b_ascii.seq = (const uint8_t *)c->unpacked.p;
+        b_ascii.seq_format = MDX_SEQ_ASCII;
+    } else {
+        rc = ascii_view(c, b_in, &b_ascii);
+        if (rc != MDX_OK) return rc;
+    }
+    const mdx_batch *b = &b_ascii;
+    if (!pkf && (!args_ok || !fuse_applies(c, b))) {
         rc = mdx_tabulate_device(c, b_in);
         if (rc != MDX_OK) return rc;
         return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);
@@ -1080,7 +1108,7 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     HIP_TRY(c, c->rs_part.reserve(mdx_k_rescale_part_bytes(c->len5p, c->len3p, c->n_cu) + (size_t)c->n_cu * n_cnt * 4));
     f.subs_part = (uint32_t *)c->rs_part.p;
     int fgrid = 0;
-    rc = tabulate_impl(c, b, &f, &fgrid);
+    rc = tabulate_impl(c, pkf ? b_in : b, &f, &fgrid);
     if (rc != MDX_OK) return rc;
     MdxRescaleArgs a{};
     a.n_reads = b->n_reads; a.n_bases = b->n_bases; a.flag = b->flag; a.tid = b->tid; a.pos = b->pos; a.mtid = d_mtid; a.mpos = d_mpos;
@@ -1105,6 +1133,7 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
         (void)hipEventRecord(e0, c->stream);
+    if (pkf) mdx_k_unpack_listed(a.in_count, a.in_list, a.in_cap, a.n_in, b->seq_off, b_in->seq, (uint8_t *)c->unpacked.p, b->n_bases, c->stream);
     mdx_k_rescale_lists_pass(a, fgrid, c->n_cu, c->stream);
     c->n_fused++;
     if (e0 && e1) {

@@ -218,6 +218,16 @@ static inline int mdx_k_fuse_qcap(const MdxDims &d, int npos, size_t lds_limit) 
     return q;
 }
 hipError_t mdx_k_fuse_prepare(size_t lds_bytes);
+// the packed fused kernel (4-bit SEQ column and reference, one library): one 1024-thread block per CU too, no second TC
+// table; MdxFuse::tcb_off = mdx_k_pkf_tcb_off, the queue offset is mdx_k_fuse_queue_off, MdxFuse::qcap unused
+int mdx_k_pkf_tcb_off(const MdxDims &d);
+size_t mdx_k_pkf_lds_bytes(const MdxDims &d, int npos);
+hipError_t mdx_k_pkf_prepare(size_t lds_bytes);
+void mdx_k_tabulate_packed_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
+// the SEQ stretches of the records of n_in lists (in_list[l * in_cap ..], in_count[l]) from the 4-bit column to ASCII at the
+// same offsets of `out` (n_bases + 8 bytes at least)
+void mdx_k_unpack_listed(const uint32_t *in_count, const uint32_t *in_list, int64_t in_cap, int n_in, const uint32_t *seq_off,
+                         const uint8_t *seq4, uint8_t *out, int64_t n_bases, hipStream_t s);
 void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipStream_t s);
 // resident reference bytes (guard bands included, n even) -> 4-bit codes, n / 2 bytes
 void mdx_k_encode_ref4(const uint8_t *d_codes, uint8_t *d_ref4, int64_t n, hipStream_t s);

@@ -199,6 +199,20 @@ size_t mdx_k_fuse_lds_bytes(const MdxDims &d, int npos, int qcap) {
            (size_t)(MDX_FUSE_BLOCK / 64) * (MDX_FUSE_MRM * 8 + MDX_FUSE_RSQ * 8 + 8);
 }
 
+// The packed fused kernel (tabulate_kernel<.., RS, PK>): the packed kernel's steps in the fused kernel's frame — one block
+// of 1024 threads per CU (16 wavefronts with 128 registers, like the packed kernel's two blocks of 512: the rescale model,
+// the MR words and the transition lists do not fit the LDS twice).  No second TC table: the image behind the packed
+// kernel's [tables][staging][event queues][mask tables] is, 256-byte aligned, [4 words][lookup table][terms][MR words]
+// [transition lists] (MdxFuse::tcb_off = the word offset of the four words).
+int mdx_k_pkf_tcb_off(const MdxDims &d) {
+    const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * MDX_PK_EVQ_BYTES + LT_BYTES + MDX_PK_TAB_BYTES;
+    return (int)(((end + 255) & ~(size_t)255) / 4);
+}
+size_t mdx_k_pkf_lds_bytes(const MdxDims &d, int npos) {
+    return (size_t)mdx_k_pkf_tcb_off(d) * 4 + 16 + (size_t)((2 * npos * 94 + 15) & ~15) + (size_t)2 * npos * 8 +
+           (size_t)(MDX_FUSE_BLOCK / 64) * (MDX_FUSE_MRM * 8 + MDX_FUSE_RSQ * 8 + 8);
+}
+
 // read byte -> class; accepted only if it is exactly the upper-case letter
 // ("nt in 'ACGT-'", statistics.py:27)
 __device__ __forceinline__ int classify_read(u32 ch) {
@@ -529,7 +543,7 @@ void mdx_k_unpack_seq(const u8 *d_packed, u8 *d_ascii, int64_t n, hipStream_t s)
 template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false>
 __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK), RS ? MDX_FUSE_WPS : (PK ? MDX_PK_WPS : MDX_WPS)) void tabulate_kernel(MdxTabArgs a) {
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
-    static_assert(!PK || (USE_LDS && FAST && !MASK && !RS), "the packed kernel is the plain fast LDS kernel");
+    static_assert(!PK || (USE_LDS && FAST && !MASK), "the packed kernel is the plain fast LDS kernel (with or without the fused rescaling)");
     constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK);
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -554,7 +568,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // the lookup table and the terms of the model
     const int rs_npos = RS ? 1 + a.rs.len5p + a.rs.len3p : 0;
     const int rs_ncnt = 752 + 2 * rs_npos * 94;
-    u32 *const rs_cnt = lds + (RS ? a.rs.tcb_off + d.nlib * d.w_tc : 0);
+    // (PK: no second table — the packed steps count the reference bases of the fused records' columns themselves, see count16)
+    u32 *const rs_cnt = lds + (RS ? a.rs.tcb_off + (PK ? 0 : d.nlib * d.w_tc) : 0);
     const u8 *const l_lut = (const u8 *)(rs_cnt + 4);
     const double *const l_term = (const double *)(l_lut + ((2 * rs_npos * 94 + 15) & ~15));
     // ... and per wavefront one 64-bit word per staging entry: bit sub * npos + key = the record has a rescaled column of
@@ -580,7 +595,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             ((u16 *)(ltab + 17 + 64))[threadIdx.x] = (u16)(rc | (sc << 3) | (col << 6));
         }
         if (RS) {
-            for (int i = threadIdx.x; i < d.nlib * d.w_tc + 4; i += BLOCK) lds[a.rs.tcb_off + i] = 0;
+            for (int i = threadIdx.x; i < (PK ? 0 : d.nlib * d.w_tc) + 4; i += BLOCK) lds[a.rs.tcb_off + i] = 0;
             for (int i = threadIdx.x; i < 2 * rs_npos * 94; i += BLOCK) ((u8 *)(rs_cnt + 4))[i] = a.rs.lut[i];
             for (int i = threadIdx.x; i < 2 * rs_npos; i += BLOCK) ((double *)(l_lut + ((2 * rs_npos * 94 + 15) & ~15)))[i] = a.rs.term[i];
             // the block's summary row: zeroed here, counted into with global atomics by this block alone
@@ -779,20 +794,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // column is counted here (the plain matches: the second TC table).  A transition — each column once: the left
     // side's [0, min(nq, L)), the right side's columns beyond — is listed for rs_apply (rsq), and the MR term of a
     // C>T / G>A one with a position key is noted in mrm.
-    auto rs_event = [&](const uint4 &e, const int ix, const int rev, const int side, const int p, const u32 sb, const u32 rb) {
+    // (rs_transition: the column is read column p of its side, `kind` its transition on the read's own strand — 0 C>T,
+    // 1 G>A (rescaled), 2 T>C, 3 A>G —, sq the index of the record's first aligned base in the SEQ / quality columns)
+    auto rs_transition = [&](const uint4 &e, const int ix, const int rev, const int side, const int p, const int kind, const u32 sq) {
         const int nq = (int)(e.z & 0x7FFFu);
-        if (!side && rb < 0x80u) {
-            const u32 k = (rb >> 1) & 3u;           // A,C,T,G
-            u32 b = k ^ (k >> 1);                   // A,C,G,T
-            if (rev) b = 3u - b;
-            bcA += b == 0u; bcC += b == 1u; bcG += b == 2u; bcT += b == 3u;
-        }
-        if (side && p >= nq - L) return;
-        const u32 pr = sb | (rb << 8);
-        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
-        const int kind = (int)(pr == ('T' | 'C' << 8)) * (1 + rev) + (int)(pr == ('A' | 'G' << 8)) * (2 - rev) +
-                         (int)(pr == ('C' | 'T' << 8)) * (3 + rev) + (int)(pr == ('G' | 'A' << 8)) * (4 - rev) - 1;
-        if (kind < 0) return;
         const MdxTabArgs *kp = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const int qi = side ? nq - 1 - p : p;
@@ -808,7 +813,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         const int idx = kind >= 2 ? (kind == 2 ? 2 : 6) * 94 : 752 + (kind * rs_npos + key) * 94;
         const u32 slot = atomicAdd(rsq_cnt, 1u);
         u32x2 ent2;
-        ent2.x = e.y + (u32)qi; ent2.y = (u32)idx | (resc ? 0x8000u : 0u);
+        ent2.x = sq + (u32)qi; ent2.y = (u32)idx | (resc ? 0x8000u : 0u);
         if (slot < (u32)MDX_FUSE_RSQ) rsq[slot] = ent2;
         else {
             // (a tile with more transitions than the list holds: at once — behind the stores of the tile's quality copy)
@@ -816,6 +821,34 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
             rs_apply(ent2, q);
         }
+    };
+    auto rs_event = [&](const uint4 &e, const int ix, const int rev, const int side, const int p, const u32 sb, const u32 rb) {
+        const int nq = (int)(e.z & 0x7FFFu);
+        if (!side && rb < 0x80u) {
+            const u32 k = (rb >> 1) & 3u;           // A,C,T,G
+            u32 b = k ^ (k >> 1);                   // A,C,G,T
+            if (rev) b = 3u - b;
+            bcA += b == 0u; bcC += b == 1u; bcG += b == 2u; bcT += b == 3u;
+        }
+        if (side && p >= nq - L) return;
+        const u32 pr = sb | (rb << 8);
+        // stored pair -> transition of the read's own strand: 0 C>T, 1 G>A (rescaled), 2 T>C, 3 A>G
+        const int kind = (int)(pr == ('T' | 'C' << 8)) * (1 + rev) + (int)(pr == ('A' | 'G' << 8)) * (2 - rev) +
+                         (int)(pr == ('C' | 'T' << 8)) * (3 + rev) + (int)(pr == ('G' | 'A' << 8)) * (4 - rev) - 1;
+        if (kind < 0) return;
+        rs_transition(e, ix, rev, side, p, kind, e.y);
+    };
+    // PK: the same for a pair of 4-bit codes (A, C, T, G = 1, 2, 4, 8) — the reference bases of a fused record's columns are
+    // counted by the steps themselves (count16), so only the transitions are looked at here; an entry's second word is its
+    // SEQ window offset less its reference window offset (see the staging entries)
+    auto rs_event4 = [&](const uint4 &e, const int ix, const int rev, const int side, const int p, const u32 sn, const u32 rn) {
+        const int nq = (int)(e.z & 0x7FFFu);
+        if (side && p >= nq - L) return;
+        const u32 pr = sn | (rn << 4);
+        const int kind = (int)(pr == 0x24u) * (1 + rev) + (int)(pr == 0x81u) * (2 - rev) +
+                         (int)(pr == 0x42u) * (3 + rev) + (int)(pr == 0x18u) * (4 - rev) - 1;
+        if (kind < 0) return;
+        rs_transition(e, ix, rev, side, p, kind, e.y + e.x - pk_dso);
     };
     // the MR sum of a record from its word of mrm: the terms in column order — 5' keys upwards, then 3' keys downwards
     auto mr_of = [&](const u64 m) -> double {
@@ -856,6 +889,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     const bool del = (w >> 12) & 1u;
                     const int g = del ? (int)(w >> 13) & 7 : 0, bnd = (int)(w >> 16) & 31;
                     const u32x2 em = emtab[ln];
+                    // (RS: an event of a fused record carries the place of its staging entry, [27:21], and bit 28)
+                    const bool rsev = RS && ((w >> 28) & 1u);
+                    uint4 rent = make_uint4(0u, 0u, 0u, 0u);
+                    if (RS && rsev) rent = stg[(w >> 21) & 0x7Fu];
                     const u64 s64 = (u64)q.x | ((u64)q.y << 32), r64 = (u64)q.z | ((u64)q.w << 32);
                     u64 x = (s64 ^ r64) & ((u64)em.x | ((u64)em.y << 32));      // the read columns that differ
                     const int b_mis = d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = d.off_cmp() + (rev ? 2 * L * 4 : 0);
@@ -882,6 +919,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         // what the column really is (rare_column): the read base, and a substitution / indel
                         if (sc < 4) atomicAdd(&lds[b_cmp + spc * 4 + sc], 1u);
                         if (col != 31) atomicAdd(&lds[b_mis + __mul24(sp, 25) + col], 1u);
+#ifndef MDX_RSABL_NOEV
+                        if (RS && rsev) rs_event4(rent, (int)((w >> 21) & 0x7Fu), rev, side, p, (u32)(s64 >> sh) & 15u, (u32)(r64 >> sh) & 15u);
+#endif
                     }
                 }
             }
@@ -1197,6 +1237,16 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     u32 ro = ent.x + c_ro + t;
                     u32 so = ro + ent.y;
                     st.aux = 0u; st.aux2 = 0u;
+                    if (RS && KIND == STEP_C) {
+                        // a fused record (bit 18 of its entry): its events carry the entry's place, and the reference bases of
+                        // its columns — each column once: the left side's, and the right side's beyond them, p < nq - L, the
+                        // nibbles from t on — are counted by the step (subs[nt_ref], rescale.py:142-143); aux = the offset of
+                        // the nibble-mask table's entry t (a record that is not fused: no nibble on either side)
+                        const bool fz = act && ((ent.w >> 18) & 1u);
+                        int t = c_side ? c_m8 + 16 - A + L - (int)(ent.z & 0x7FFFu) : 16;
+                        t = t < 0 ? 0 : (t > 16 ? 16 : t);
+                        st.aux = fz ? (((u32)t << 3) | ((u32)idx << 21) | (1u << 28)) : (c_side ? 128u : 0u);
+                    }
                     if (KIND != STEP_C) {
                         const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
                         ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
@@ -1243,6 +1293,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     u32 s_lo = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa), s_hi = __builtin_amdgcn_alignbit(st.s.z, st.s.y, st.sa);
                     u32 r_lo = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra), r_hi = __builtin_amdgcn_alignbit(st.r.z, st.r.y, st.ra);
                     u32 evw = c_evw;
+                    if (RS && KIND == STEP_C) evw |= st.aux & 0x1FE00000u;
                     u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
@@ -1313,6 +1364,17 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         }
                         qcount += n;
                     }
+                    if (RS && KIND == STEP_C) {
+                        // the reference bases of a fused record's columns, by class (a code is one-hot: four population counts
+                        // per dword), in this lane's own counters — its slot fixes the strand
+                        const u64 Mk = *(const u64 *)((const u8 *)ltab + (st.aux & 0xFFu));
+                        const u32 sm = c_side ? ~0u : 0u;
+                        const u32 y_lo = r_lo & ((u32)Mk ^ sm) & c_em_lo, y_hi = r_hi & ((u32)(Mk >> 32) ^ sm) & c_em_hi;
+                        bcA += __builtin_popcount(y_lo & 0x11111111u) + __builtin_popcount(y_hi & 0x11111111u);
+                        bcC += __builtin_popcount(y_lo & 0x22222222u) + __builtin_popcount(y_hi & 0x22222222u);
+                        bcT += __builtin_popcount(y_lo & 0x44444444u) + __builtin_popcount(y_hi & 0x44444444u);
+                        bcG += __builtin_popcount(y_lo & 0x88888888u) + __builtin_popcount(y_hi & 0x88888888u);
+                    }
                     if (KIND == STEP_GD && __ballot(dmk != 0ull)) {
                         // one nibble at a time in position order — nibble j on the left side, 15 - j on the right (whose bits
                         // are reversed too: class k is bit 3 - k) —, unrolled: the class of the (one-hot or zero) nibble picks
@@ -1376,10 +1438,17 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (!ovf) group(std::false_type{}, false);
                     if (!ovf) break;
                     drain_all();
+                    if (RS) {
+                        rsq_flush();
+                        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): nothing but the run's loads in flight in its loop
+                    }
                     kstart = kredo;
                 }
-                // (where the packed kernel drains as a rule: behind a run, once a pass's worth of events waits — whole passes)
-                if (qcount >= 64) drain_all(qcount & 63);
+                // (where the packed kernel drains as a rule: behind a run, once a pass's worth of events waits — whole passes;
+                // RS: all of them — the events of fused records look their staging entries up, and the MR sums of the tile's
+                // records are formed behind its run)
+                if (RS) { if (qcount > 0) drain_all(); }
+                else if (qcount >= 64) drain_all(qcount & 63);
                 return;
             }
 #if MDX_ENT_AHEAD
@@ -2264,7 +2333,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         else rs_st = 4;
                     } else rs_st = 2;
                     const bool want = valid && (rs_st == 2 || rs_st == 3);
-                    rs_fused = want && triv && nq <= 2 * L && (u64)c_so0 + lseq + 16u <= (u64)a.n_bases;
+                    // (PK: the complete ones among them — a record shorter than --length goes through the wavefront's list of
+                    // partial entries behind the tile loop, when its tile's MR words are gone, and is left to the rescale kernels)
+                    rs_fused = want && triv && nq <= 2 * L && (u64)c_so0 + lseq + 16u <= (u64)a.n_bases && (!PK || nq >= L);
                     // status of the records this kernel is done with (rescale.py:300-342): the fused ones and those written
                     // back unchanged (mr_raw is preset to NaN by the launch: such a record keeps it); the others go to the
                     // wavefront's list
@@ -2350,9 +2421,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         ((MASK && !(fl & 0x8000u) && q0 != 0xFFu) ? 0x40000000u : 0u) | ((u32)rev << 31);
                 // (RS: a fused record counts into the second TC table — which is what marks its entry and events; bit 20 =
                 // rescaled from the 5' end only)
-                if (RS && rs_fused)
+                // (PK: no second table — bit 18 marks the entry)
+                if (RS && rs_fused) {
+                    if (PK) ent.w |= (1u << 18) | ((u32)rs_fwd << 20);
+                    else
                     ent.w = ((u32)(p.rs.tcb_off + __mul24(libid, d.w_tc) + rev * 4 * 512) << 2) | ((u32)libid << 24) | ((u32)rev << 31) |
                             ((u32)rs_fwd << 20);
+                }
                 const u64 mF = __ballot(isF), mP = mT & ~mF;
                 nF = __popcll(mF);
                 // MASK: the complete records that cannot be masked (no qualities, or the caller's hint) are staged first and
@@ -2384,7 +2459,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const int k1 = nq < L ? nq : L;
                         if (!PK && k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
                         lists[lP + mbcnt64(mP, 0)] = ent;
-                        if (RS) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
+                        if (RS && !PK) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
                     }
                     lP += __popcll(mP);
                 }
@@ -2410,7 +2485,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
                 if (nF - nF0) run(nF0, nF - nF0, std::integral_constant<int, STEP_C>{}, std::true_type{});
                 }
-                if (RS) {
+                if (RS && PK) {
+                    // The run has drained its events and counted the reference bases of the fused records' columns.  What is
+                    // left: the qualities of the listed transitions, and the MR sums from the records' words.
+                    rsq_flush();
+                    if (rs_fused) p.rs.mr_raw[ri] = mr_of(mrm[rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0)]);
+                }
+                if (RS && !PK) {
                     // The run has drained its events.  One round trip for what is left of the tile's fused records: the
                     // qualities of their listed transitions (rsq_flush) and the reference bytes of the columns the left
                     // windows do not hold, [L, nq) — subs[nt_ref], rescale.py:142-143 (the first 32 of them requested
@@ -2506,7 +2587,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
                 }
-                constexpr bool RSP = RS && decltype(kind_tag)::value == STEP_P;
+                constexpr bool RSP = RS && !PK && decltype(kind_tag)::value == STEP_P;
                 u32 ri_l = 0;
                 if (RSP) {
                     ri_l = lri[e + (lane < m ? lane : 0)];
@@ -2546,7 +2627,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             // column iff A <= 8 m + j < A + L), everything else from the lanes' own counts; words 0..3 of the block's
             // summary row.  Then the second table is added to the first.
             int tA = 0, tC = 0, tG = 0, tT = 0;
-            const int n_tcb = d.nlib * d.w_tc;
+            // (PK: no second table; the lanes' own counts are by class — A, C, T, G — of the stored strand, and a lane's slot
+            // fixes the strand: complemented here for the reverse slots)
+            const int n_tcb = PK ? 0 : d.nlib * d.w_tc;
+            if (PK) {
+                const int cA = bcA, cC = bcC, cT = bcT, cG = bcG;
+                bcA = p_strand ? cT : cA; bcC = p_strand ? cG : cC; bcG = p_strand ? cC : cG; bcT = p_strand ? cA : cT;
+            }
             for (int i = threadIdx.x; i < n_tcb; i += BLOCK) {
                 const int w = i & 511, k = (i >> 9) & 3, strand = (i >> 11) & 1;
                 const int ln = w & 63, jb = w >> 6;
@@ -2612,6 +2699,62 @@ hipError_t mdx_k_fuse_prepare(size_t lds_bytes) {
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
     hipLaunchKernelGGL((tabulate_kernel<true, false, true, true>), dim3(grid), dim3(MDX_FUSE_BLOCK), lds_bytes, s, a);
+}
+
+hipError_t mdx_k_pkf_prepare(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, false, true, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+void mdx_k_tabulate_packed_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    if (a.n_reads <= 0) return;
+    hipLaunchKernelGGL((tabulate_kernel<true, false, true, true, true>), dim3(grid), dim3(MDX_FUSE_BLOCK), lds_bytes, s, a);
+}
+
+// Behind the packed fused kernel: the records it has listed for the rescale kernels, which read ASCII — their stretches
+// of the 4-bit SEQ column (soft clips included) written out as ASCII at the same offsets of a scratch column, eight bases
+// per lane and step (whole aligned groups of eight: what lies outside a record belongs to its neighbours and is the same
+// bytes whoever writes them), sixteen lanes per record, four wavefronts per list.
+typedef u32 __attribute__((aligned(1))) u32_u1;
+#define UNPK_SPLIT 4
+__global__ __launch_bounds__(256) void unpack_listed_kernel(const u32 *__restrict__ in_count, const u32 *__restrict__ in_list, i64 in_cap, int n_in,
+                                                            const u32 *__restrict__ seq_off, const u8 *__restrict__ seq4,
+                                                            u8 *__restrict__ out, i64 n_bases) {
+    const int lane = threadIdx.x & 63;
+    const i64 gw = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const i64 l = gw / UNPK_SPLIT;
+    const int part = (int)(gw - l * UNPK_SPLIT);
+    if (l >= n_in) return;
+    const u32 n = in_count[l];
+    const u32 *const list = in_list + l * in_cap;
+    for (u32 i = (u32)(part * 4 + (lane >> 4)); i < n; i += 4u * UNPK_SPLIT) {
+        const u32 ri = list[i];
+        const u32 so0 = seq_off[ri], so1 = seq_off[ri + 1];
+        for (u32 o = (so0 & ~7u) + 8u * (u32)(lane & 15); o < so1; o += 128u) {
+            u32 v;
+            if ((i64)o + 8 <= n_bases) v = *(const u32_u1 *)(seq4 + (o >> 1));
+            else {
+                v = 0u;
+                for (u32 k = 0; k < 4u && (i64)o + 2 * k < n_bases; k++) v |= (u32)seq4[(o >> 1) + k] << (8 * k);
+            }
+            u32 w[2] = {0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 nib = (v >> (4 * k)) & 15u;
+                const u32 ch = nib == 1u ? 'A' : (nib == 2u ? 'C' : (nib == 4u ? 'T' : (nib == 8u ? 'G' : 'N')));
+                w[k >> 2] |= ch << (8 * (k & 3));
+            }
+            u32x2 ww; ww.x = w[0]; ww.y = w[1];
+            *(u32x2 *)(out + o) = ww;
+        }
+    }
+}
+void mdx_k_unpack_listed(const uint32_t *in_count, const uint32_t *in_list, int64_t in_cap, int n_in, const uint32_t *seq_off,
+                         const uint8_t *seq4, uint8_t *out, int64_t n_bases, hipStream_t s) {
+    if (n_in <= 0) return;
+    const i64 waves = (i64)n_in * UNPK_SPLIT;
+    hipLaunchKernelGGL(unpack_listed_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in_count, in_list, (i64)in_cap, n_in,
+                       seq_off, seq4, out, (i64)n_bases);
 }
 
 hipError_t mdx_k_prepare_packed(size_t lds_bytes) {

@@ -394,12 +394,12 @@ def test_hip_tabulate_and_rescale_in_one_pass(tmp_path):
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
 
 
-def one_pass(eng, b):
-    """mdx_tabulate_rescale_device on the uploaded batch -> (qualities, MR, status) as host arrays; the tables stay in the
-    engine."""
+def one_pass(eng, b, packed=False):
+    """mdx_tabulate_rescale_device on the uploaded batch (``packed``: its SEQ column in the 4-bit form) -> (qualities, MR,
+    status) as host arrays; the tables stay in the engine."""
     import torch
     dev = torch.device("cuda", 0)
-    db = eng.upload(b)
+    db = eng.upload(b, packed=packed)
     mtid, mpos = torch.from_numpy(b.mtid).to(dev), torch.from_numpy(b.mpos).to(dev)
     qout = torch.zeros(b.seq.shape[0] + 64, dtype=torch.uint8, device=dev)
     mr = torch.zeros(b.n, dtype=torch.float64, device=dev)
@@ -413,14 +413,17 @@ def one_pass(eng, b):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seq_form", ["ascii", "4bit"])
 @pytest.mark.parametrize("length,l5,l3,lens", [(70, 12, 12, (25, 160)), (25, 12, 12, (20, 120)), (70, 20, 3, (15, 90)),
                                                (12, 0, 30, (15, 60))])
-def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, monkeypatch, length, l5, l3, lens):
+def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, monkeypatch, length, l5, l3, lens, seq_form):
     """The fused launch (the tabulation kernel rescales the records of its own tile loop and lists the others for the
     rescale kernels): tables, qualities, MR, routing and every summary word — against the oracle, and the summary
     word for word against the two-kernel path on the same batch.  Record lengths on both sides of --length and of
     2 x --length (longer records are listed), records the tabulation drops but the rescaling takes, models with
-    uneven windows."""
+    uneven windows.  Both forms of the SEQ column: an ASCII one runs the fused ASCII kernel, a 4-bit one the packed fused
+    kernel (the records it lists are unpacked for the rescale kernels behind it)."""
+    packed = seq_form == "4bit"
     from mapdamage_amd.engine import DamageEngine
     from mapdamage_amd.rescale import RescaleModel
     from oracle import oracle
@@ -450,8 +453,9 @@ def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, mon
         with DamageEngine(libs, length, 10, 0) as eng:
             eng.set_reference(ref)
             eng.set_rescale_model(model)
-            q, mr, st = one_pass(eng, b)
+            q, mr, st = one_pass(eng, b, packed)
             assert eng.fused_launches() == (1 if fuse else 0)
+            assert eng.packed_launches() == (1 if packed else 0)
             words = eng.rescale_summary()
             tables = eng.finish()
         assert_tables_equal(tables, want_tables)
