@@ -173,6 +173,9 @@ size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4
 #ifndef MDX_FUSE_PD
 #define MDX_FUSE_PD 4                   // steps in flight of the complete runs in the fused kernel
 #endif
+#ifndef MDX_FUSE_CP2
+#define MDX_FUSE_CP2 1                  // the passes of the quality copy behind the first: two units per lane and round trip
+#endif
 #define MDX_FUSE_RSQ 192                // per wavefront: transitions of fused records waiting for their qualities (8 bytes each)
 #define MDX_FUSE_MRM 72                 // per wavefront: one 64-bit word per staging entry (the MR terms of its record)
 int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
@@ -841,14 +844,15 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // PK: the same for a pair of 4-bit codes (A, C, T, G = 1, 2, 4, 8) — the reference bases of a fused record's columns are
     // counted by the steps themselves (count16), so only the transitions are looked at here; an entry's second word is its
     // SEQ window offset less its reference window offset (see the staging entries)
-    auto rs_event4 = [&](const uint4 &e, const int ix, const int rev, const int side, const int p, const u32 sn, const u32 rn) {
+    // (p: the column of its side, pc: its query index from that end — less than p behind a deletion of g bases)
+    auto rs_event4 = [&](const uint4 &e, const int ix, const int rev, const int side, const int p, const int pc, const int g, const u32 sn, const u32 rn) {
         const int nq = (int)(e.z & 0x7FFFu);
-        if (side && p >= nq - L) return;
+        if (side && p >= nq + g - L) return;
         const u32 pr = sn | (rn << 4);
         const int kind = (int)(pr == 0x24u) * (1 + rev) + (int)(pr == 0x81u) * (2 - rev) +
                          (int)(pr == 0x42u) * (3 + rev) + (int)(pr == 0x18u) * (4 - rev) - 1;
         if (kind < 0) return;
-        rs_transition(e, ix, rev, side, p, kind, e.y + e.x - pk_dso);
+        rs_transition(e, ix, rev, side, pc, kind, e.y + e.x - pk_dso);
     };
     // the MR sum of a record from its word of mrm: the terms in column order — 5' keys upwards, then 3' keys downwards
     auto mr_of = [&](const u64 m) -> double {
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         if (sc < 4) atomicAdd(&lds[b_cmp + spc * 4 + sc], 1u);
                         if (col != 31) atomicAdd(&lds[b_mis + __mul24(sp, 25) + col], 1u);
 #ifndef MDX_RSABL_NOEV
-                        if (RS && rsev) rs_event4(rent, (int)((w >> 21) & 0x7Fu), rev, side, p, (u32)(s64 >> sh) & 15u, (u32)(r64 >> sh) & 15u);
+                        if (RS && rsev) rs_event4(rent, (int)((w >> 21) & 0x7Fu), rev, side, p, pc, g, (u32)(s64 >> sh) & 15u, (u32)(r64 >> sh) & 15u);
 #endif
                     }
                 }
@@ -1275,6 +1279,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             const int bnd = c_side ? ta : tb;
                             st.aux = c16(ta) | (c16(tb) << 8) | (c16(tl) << 16) | ((blane ? 0u : (u32)g) << 24);
                             st.aux2 = (u32)g | ((c16(bnd) >> 3) << 3);
+                            if (RS) {
+                                // (a fused single-indel record, see the complete ones above: ncol columns, each once; [15:8] the
+                                // offset of the nibble-mask table's entry, [27:21] the entry's place, bit 28)
+                                const bool fz = act && ((ent.w >> 18) & 1u);
+                                int t = c_side ? c_m8 + 16 - A + L - ncol : 16;
+                                t = t < 0 ? 0 : (t > 16 ? 16 : t);
+                                st.aux2 |= fz ? (((u32)t << 11) | ((u32)idx << 21) | (1u << 28)) : (c_side ? 128u << 8 : 0u);
+                            }
                         }
                     }
                     // sixteen nibbles from bit 4 (offset & 7) of the aligned dword triple
@@ -1294,6 +1306,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     u32 r_lo = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra), r_hi = __builtin_amdgcn_alignbit(st.r.z, st.r.y, st.ra);
                     u32 evw = c_evw;
                     if (RS && KIND == STEP_C) evw |= st.aux & 0x1FE00000u;
+                    if (RS && (KIND == STEP_GI || KIND == STEP_GD)) evw |= st.aux2 & 0x1FE00000u;
+                    u32 by_lo = 0u, by_hi = 0u;     // RS, single-indel steps: the reference bases of the step's columns
                     u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
@@ -1330,13 +1344,15 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                                 // CMP[column - g][base] by position instead of the counters (below)
                                 const u64 beh = (Xk & sm) | (~Yk & ~sm);
                                 dmk = dyn & beh;
-                                evw |= 0x1000u | ((st.aux2 & 7u) << 13) | ((st.aux2 >> 3) << 16);
+                                evw |= 0x1000u | ((st.aux2 & 7u) << 13) | (((st.aux2 >> 3) & 31u) << 16);
                                 s64 &= dyn; r64 &= dyn;
                                 X64 = r64 & ~beh;
+                                if (RS) { by_lo = (u32)r64; by_hi = (u32)(r64 >> 32); }
                             } else {
                                 r64 = m;
                                 s64 &= dyn; r64 &= dyn;
                                 X64 = r64 & (Xk | ~Yk);                          // (not the gap symbols)
+                                if (RS) { by_lo = (u32)X64; by_hi = (u32)(X64 >> 32); }
                             }
                         }
                         s_lo = (u32)s64; s_hi = (u32)(s64 >> 32); r_lo = (u32)r64; r_hi = (u32)(r64 >> 32);
@@ -1364,17 +1380,19 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         }
                         qcount += n;
                     }
-                    if (RS && KIND == STEP_C) {
+#ifndef MDX_RSABL_NOBC
+                    if (RS && (KIND == STEP_C || KIND == STEP_GI || KIND == STEP_GD)) {
                         // the reference bases of a fused record's columns, by class (a code is one-hot: four population counts
                         // per dword), in this lane's own counters — its slot fixes the strand
-                        const u64 Mk = *(const u64 *)((const u8 *)ltab + (st.aux & 0xFFu));
+                        const u64 Mk = *(const u64 *)((const u8 *)ltab + (KIND == STEP_C ? st.aux & 0xFFu : (st.aux2 >> 8) & 0xFFu));
                         const u32 sm = c_side ? ~0u : 0u;
-                        const u32 y_lo = r_lo & ((u32)Mk ^ sm) & c_em_lo, y_hi = r_hi & ((u32)(Mk >> 32) ^ sm) & c_em_hi;
+                        const u32 y_lo = (KIND == STEP_C ? r_lo : by_lo) & ((u32)Mk ^ sm) & c_em_lo, y_hi = (KIND == STEP_C ? r_hi : by_hi) & ((u32)(Mk >> 32) ^ sm) & c_em_hi;
                         bcA += __builtin_popcount(y_lo & 0x11111111u) + __builtin_popcount(y_hi & 0x11111111u);
                         bcC += __builtin_popcount(y_lo & 0x22222222u) + __builtin_popcount(y_hi & 0x22222222u);
                         bcT += __builtin_popcount(y_lo & 0x44444444u) + __builtin_popcount(y_hi & 0x44444444u);
                         bcG += __builtin_popcount(y_lo & 0x88888888u) + __builtin_popcount(y_hi & 0x88888888u);
                     }
+#endif
                     if (KIND == STEP_GD && __ballot(dmk != 0ull)) {
                         // one nibble at a time in position order — nibble j on the left side, 15 - j on the right (whose bits
                         // are reversed too: class k is bit 3 - k) —, unrolled: the class of the (one-hot or zero) nibble picks
@@ -1597,6 +1615,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     u32 *const dlist = (u32 *)(lists + 5 * a.list_cap);
     u32 *const lri = (u32 *)(lists + 5 * a.list_cap + a.list_cap / 4 + 1);
     int lP = 0, lI = 0, lD = 0, lC = 0;
+    u32 n_rs = 0;           // RS: records left to the rescale kernels behind this one
 
     // class of the read symbol at index i of the SEQ column / of the reference symbol at (concatenated) genome coordinate i,
     // which may lie in the guard bands — in either form of the two columns
@@ -1614,8 +1633,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // cannot take (anything but a single match operation) — their entries go to the wavefront's lists; otherwise it is
     // the whole tile loop.
     // (the record's columns come with it: the tile loop has read them once already and hands them over through the list)
+    // (rs_code — the packed fused kernel: 0 the record is not to be rescaled, or the tile loop has seen to it; 1 / 2 it is, from
+    // both ends / from its 5' end only: a single-indel record of [L, 2 L] columns is then rescaled by its own steps — its entry
+    // marked like a fused record of the tile loop —, any other one is listed for the rescale kernels here)
     auto general = [&](const u32 ri, const bool valid, const u32 fl, const int c_lib, const int c_tid, const int c_pos,
-                       const int c_tlen, const u32 c_co0, const u32 c_co1, const u32 c_so0, const u32 c_so1) {
+                       const int c_tlen, const u32 c_co0, const u32 c_co1, const u32 c_so0, const u32 c_so1, const u32 rs_code = 0u) {
         // the arguments phase 1 needs are read from the kernel-argument segment when they are used (scalar loads through
         // the constant cache) instead of living in SGPRs across the whole kernel: the kernel wants far more scalar
         // registers than there are, and every spilled one costs a v_readlane per use
@@ -1835,6 +1857,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         const int rb_lo = (int)(rbase & 0xFFFFFFFFll), rb_hi = (int)(rbase >> 32);
         u64 todo_g = todo_all;
         int nF = 0, nP = 0, nS = 0, nSI = 0;
+        bool rsS = false;       // RS, PK: a single-indel record rescaled by its own steps
         if (FAST) {
             // (a record at a contig edge — a flank cut short — walks: the entries of the partial list have complete flanks,
             // so that a partial step's tasks are a prefix of each window)
@@ -1875,6 +1898,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     ent.z = (u32)nq | 0x8000u | ((u32)(isS ? vlr : vlr + A * 0x101) << 16);
                     // n0 - nq: 11 bits, the low eight in the low byte (all a D_ONE entry needs), the rest in [23:21]
                     ent.w |= ((u32)dnq & 0xFFu) | ((((u32)dnq >> 8) & 7u) << 21) | (isS ? PK_ONE : 0u);
+                    if (RS && PK) {
+                        // (every column a task of one of the two windows, and each window complete)
+                        rsS = isS && rs_code != 0u && ncols >= L && ncols <= 2 * L;
+                        if (rsS) ent.w |= (1u << 18) | ((rs_code == 2u ? 1u : 0u) << 20);
+                    }
                     // both runs reach --length: the entry covers every task of the record, nothing is left to walk
                     // (an N between two long match runs: a spliced read)
                     covered = !isS && (((vlr & 0xFF) == L && (vlr >> 8) == L) || nonly);
@@ -1940,10 +1968,20 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if ((plain && !isF) || (gpre && !isS)) at = lP + mbcnt64(mP, 0);
                 else if (isS) at = isD ? 2 * a.list_cap - 1 - (lD + mbcnt64(mS & ~mSI, 0)) : a.list_cap + lI + mbcnt64(mSI, 0);
                 if (at >= 0) lists[at] = ent;
+                if (RS && PK && isS) lri[at - a.list_cap] = ri;      // (the record of a single-indel entry: where its MR goes)
                 lP += nP; lI += nSI; lD += nS - nSI;
             }
         }
 
+        if (RS && PK) {
+            if (rsS) p.rs.status[ri] = (u8)(rs_code + 1u);     // (rescale.py:300-342: 2 = unpaired, 3 = an inward pair's mate)
+            const bool lst = valid && rs_code != 0u && !rsS;
+            const u64 mW = __ballot(lst);
+            if (mW) {
+                if (lst) (p.rs.gen_list + (size_t)gwave * (size_t)p.list_cap)[n_rs + (u32)mbcnt64(mW, 0)] = ri;
+                n_rs += (u32)__popcll(mW);
+            }
+        }
         // ------------------------------------------------------------ phase 2b: gapped records
         while (todo_g) {
             const int j = __ffsll((long long)todo_g) - 1;
@@ -2107,7 +2145,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // their general passes at different moments, under the counting of the others.
         int nDef = 0, dDone = 0;
         u32 n_kept_lite = 0;
-        u32 n_rs = 0;           // RS: records left to the rescale kernels behind this one
         u32 nb0 = 0, nb1 = 0;   // RS: byte range of the next tile's qualities (requested a tile ahead)
         // Tiles are handed out on demand within a *pool*: the two blocks that share a CU (blocks p and p + gridDim / 2: the
         // dispatcher places the first gridDim / 2 blocks one per CU, then the second half) own a contiguous stretch of the
@@ -2247,11 +2284,24 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             hi |= cpv[k].x | cpv[k].y | cpv[k].z | cpv[k].w;
                         }
                     }
+#if MDX_FUSE_CP2
+                    // (two units per lane and round trip)
+                    for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 128u) {
+                        const u32x4 v = cp_load(qin + (cp_a0 + 16u * u));
+                        u32x4 v2 = u32x4{0u, 0u, 0u, 0u};
+                        const bool two = u + 64u < cp_nu;
+                        if (two) v2 = cp_load(qin + (cp_a0 + 16u * (u + 64u)));
+                        cp_store(qout + (cp_a0 + 16u * u), v);
+                        if (two) cp_store(qout + (cp_a0 + 16u * (u + 64u)), v2);
+                        hi |= v.x | v.y | v.z | v.w | v2.x | v2.y | v2.z | v2.w;
+                    }
+#else
                     for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 64u) {
                         const u32x4 v = cp_load(qin + (cp_a0 + 16u * u));
                         cp_store(qout + (cp_a0 + 16u * u), v);
                         hi |= v.x | v.y | v.z | v.w;
                     }
+#endif
                     if (cp_b0 + (u32)lane < cp_a0) { const u8 b = qin[cp_b0 + (u32)lane]; qout[cp_b0 + (u32)lane] = b; hi |= b; }
                     const u32 t0 = cp_a0 + 16u * cp_nu + (u32)lane;
                     if (t0 < cp_b1) { const u8 b = qin[t0]; qout[t0] = b; hi |= b; }
@@ -2300,6 +2350,23 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const u32 lseq = c_so1 - c_so0, nb32 = (u32)a.n_bases, pad8 = (u32)(8 * d.nl8);
                 const bool triv = cand && shape && ((qs | tr) >> 28) == 0u && qs + len + tr == lseq && len - 1u < 32767u && c_pos >= A &&
                                   (u32)c_pos + len + (u32)A <= clen && sq >= pad8 && len + pad8 <= nb32 && sq <= nb32 - len - pad8;
+                // RS: record routing (rescale.py:300-342) — 0 unmapped, 1 no qualities, 2 unpaired, 3 the mate of an inward pair
+                // (rescaled from its 5' end only), 4 any other pair
+                int rs_st = 0, rs_fwd = 0;
+                bool want = false;
+                if (RS) {
+                    const int rev_ = (fl >> 4) & 1, mate_rev = (fl >> 5) & 1;
+                    if (fl & 0x4u) rs_st = 0;
+                    else if (c_so1 == c_so0 || rs_qf == 0xFFu) rs_st = 1;
+                    else if (fl & 0x1u) {
+                        const bool same = c_tid == c_mtid;
+                        if ((!rev_ && mate_rev && c_mpos > c_pos && same) || (rev_ && !mate_rev && c_mpos < c_pos && same)) { rs_st = 3; rs_fwd = 1; }
+                        else rs_st = 4;
+                    } else rs_st = 2;
+                    want = valid && (rs_st == 2 || rs_st == 3);
+                }
+                // (PK: a record of the general pass that is to be rescaled says so there — see general())
+                const u32 rs_def = (RS && PK && want) ? (u32)(1 + rs_fwd) : 0u;
                 const u64 mDef = __ballot(kept && !triv);
                 if (mDef) {
                     if (kept && !triv) {
@@ -2308,7 +2375,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         uint4 c0_, c1_;
                         c0_.x = fl | ((u32)c_lib << 16); c0_.y = (u32)c_tid; c0_.z = (u32)c_pos; c0_.w = (u32)c_tlen;
                         c1_.x = c_co0; c1_.y = c_co1; c1_.z = c_so0; c1_.w = c_so1;
-                        dlist[at] = ri;
+                        dlist[at] = ri | (rs_def << 30);
                         dcols[2 * at] = c0_;
                         dcols[2 * at + 1] = c1_;
                     }
@@ -2322,17 +2389,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // fetched eight bytes at a time; any other record that wants rescaling goes to the list of the kernels
                 // behind this one.
                 bool rs_fused = false;
-                int rs_st = 0, rs_fwd = 0;
                 if (RS) {
-                    const int mate_rev = (fl >> 5) & 1;
-                    if (fl & 0x4u) rs_st = 0;
-                    else if (c_so1 == c_so0 || rs_qf == 0xFFu) rs_st = 1;
-                    else if (fl & 0x1u) {
-                        const bool same = c_tid == c_mtid;
-                        if ((!rev && mate_rev && c_mpos > c_pos && same) || (rev && !mate_rev && c_mpos < c_pos && same)) { rs_st = 3; rs_fwd = 1; }
-                        else rs_st = 4;
-                    } else rs_st = 2;
-                    const bool want = valid && (rs_st == 2 || rs_st == 3);
                     // (PK: the complete ones among them — a record shorter than --length goes through the wavefront's list of
                     // partial entries behind the tile loop, when its tile's MR words are gone, and is left to the rescale kernels)
                     rs_fused = want && triv && nq <= 2 * L && (u64)c_so0 + lseq + 16u <= (u64)a.n_bases && (!PK || nq >= L);
@@ -2342,13 +2399,15 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #ifndef MDX_RSABL_NOST
                     if (valid && (rs_fused || !want)) p.rs.status[ri] = (u8)rs_st;
 #endif
+                    // (PK: the general pass lists its own records)
+                    const bool lst = want && !rs_fused && !(PK && kept && !triv);
 #ifdef MDX_RSABL_NOLIST
                     const u64 mW = 0;
 #else
-                    const u64 mW = __ballot(want && !rs_fused);
+                    const u64 mW = __ballot(lst);
 #endif
                     if (mW) {
-                        if (want && !rs_fused) (p.rs.gen_list + (size_t)gwave * (size_t)p.list_cap)[n_rs + (u32)mbcnt64(mW, 0)] = ri;
+                        if (lst) (p.rs.gen_list + (size_t)gwave * (size_t)p.list_cap)[n_rs + (u32)mbcnt64(mW, 0)] = ri;
                         n_rs += (u32)__popcll(mW);
                     }
                 }
@@ -2545,9 +2604,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int at = dDone + (lane < m ? lane : 0);
-                const u32 rk = dlist[at];
+                const u32 rk = dlist[at];       // (record indices are below 2^30; [31:30]: the packed fused kernel's rs_code)
                 const uint4 c0_ = dcols[2 * at], c1_ = dcols[2 * at + 1];
-                general(rk, lane < m, c0_.x & 0xFFFFu, (int)(c0_.x >> 16), (int)c0_.y, (int)c0_.z, (int)c0_.w, c1_.x, c1_.y, c1_.z, c1_.w);
+                general(rk & 0x3FFFFFFFu, lane < m, c0_.x & 0xFFFFu, (int)(c0_.x >> 16), (int)c0_.y, (int)c0_.z, (int)c0_.w, c1_.x, c1_.y, c1_.z, c1_.w,
+                        (RS && PK) ? rk >> 30 : 0u);
                 dDone += m;
             }
             if (past && dDone >= nDef) break;
@@ -2577,18 +2637,27 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const int m = n - e < TL ? n - e : TL;
                 const uint4 ent = lists[first + (i64)dir * (e + (lane < m ? lane : 0))];
                 int n_fwd = -1;
+                int sidx = 0;       // (PK: where this lane's entry is staged)
                 if (PK) {
                     // (sorted by strand, the forward entries first)
                     const bool mine = lane < m, rv_ = (ent.w >> 31) != 0u;
                     const u64 mR = __ballot(mine && rv_), mW = __ballot(mine && !rv_);
                     n_fwd = __popcll(mW);
-                    if (mine) stg[rv_ ? n_fwd + mbcnt64(mR, 0) : mbcnt64(mW, 0)] = ent;
+                    sidx = rv_ ? n_fwd + mbcnt64(mR, 0) : mbcnt64(mW, 0);
+                    if (mine) stg[sidx] = ent;
                 } else {
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
                 }
                 constexpr bool RSP = RS && !PK && decltype(kind_tag)::value == STEP_P;
+                // (PK: the fused single-indel entries — bit 18 —, their records in lri by the entry's place in its list)
+                constexpr bool RSG = RS && PK && (decltype(kind_tag)::value == STEP_GI || decltype(kind_tag)::value == STEP_GD);
                 u32 ri_l = 0;
+                if (RSG) {
+                    ri_l = lri[first + (i64)dir * (e + (lane < m ? lane : 0)) - a.list_cap];
+                    mrm[lane] = 0ull;
+                    if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
+                }
                 if (RSP) {
                     ri_l = lri[e + (lane < m ? lane : 0)];
                     mrm[lane] = 0ull;
@@ -2596,7 +2665,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
                 run(0, m, kind_tag, std::true_type{}, n_fwd);
-                if (RSP) rsq_flush();
+                if (RSP || RSG) rsq_flush();
+                if (RSG && lane < m && ((ent.w >> 18) & 1u)) a.rs.mr_raw[ri_l] = mr_of(mrm[sidx]);
                 // RS: the MR sums of the fused records among them (known by their TC table)
                 if (RSP && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
             }
@@ -2727,25 +2797,36 @@ __global__ __launch_bounds__(256) void unpack_listed_kernel(const u32 *__restric
     if (l >= n_in) return;
     const u32 n = in_count[l];
     const u32 *const list = in_list + l * in_cap;
-    for (u32 i = (u32)(part * 4 + (lane >> 4)); i < n; i += 4u * UNPK_SPLIT) {
-        const u32 ri = list[i];
-        const u32 so0 = seq_off[ri], so1 = seq_off[ri + 1];
-        for (u32 o = (so0 & ~7u) + 8u * (u32)(lane & 15); o < so1; o += 128u) {
-            u32 v;
-            if ((i64)o + 8 <= n_bases) v = *(const u32_u1 *)(seq4 + (o >> 1));
-            else {
-                v = 0u;
-                for (u32 k = 0; k < 4u && (i64)o + 2 * k < n_bases; k++) v |= (u32)seq4[(o >> 1) + k] << (8 * k);
-            }
-            u32 w[2] = {0u, 0u};
+    // 64 records per pass: a lane fetches the bounds of one (two round trips for the pass), then sixteen lanes take a record,
+    // four records at a time — the loads of a pass do not depend on one another
+    for (u32 base = 64u * (u32)part; base < n; base += 64u * UNPK_SPLIT) {
+        u32 o0 = 0, o1 = 0;
+        if (base + (u32)lane < n) {
+            const u32 ri = list[base + (u32)lane];
+            o0 = seq_off[ri] & ~7u; o1 = seq_off[ri + 1];
+        }
+        const u32 m = n - base < 64u ? n - base : 64u;
+#pragma unroll 4
+        for (u32 r0 = 0; r0 < m; r0 += 4u) {
+            const int r = (int)r0 + (lane >> 4);
+            const u32 a0 = (u32)__shfl((int)o0, r), a1 = (u32)__shfl((int)o1, r);
+            for (u32 o = a0 + 8u * (u32)(lane & 15); o < a1; o += 128u) {
+                u32 v;
+                if ((i64)o + 8 <= n_bases) v = *(const u32_u1 *)(seq4 + (o >> 1));
+                else {
+                    v = 0u;
+                    for (u32 k = 0; k < 4u && (i64)o + 2 * k < n_bases; k++) v |= (u32)seq4[(o >> 1) + k] << (8 * k);
+                }
+                u32 w[2] = {0u, 0u};
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const u32 nib = (v >> (4 * k)) & 15u;
-                const u32 ch = nib == 1u ? 'A' : (nib == 2u ? 'C' : (nib == 4u ? 'T' : (nib == 8u ? 'G' : 'N')));
-                w[k >> 2] |= ch << (8 * (k & 3));
+                for (int k = 0; k < 8; k++) {
+                    const u32 nib = (v >> (4 * k)) & 15u;
+                    const u32 ch = nib == 1u ? 'A' : (nib == 2u ? 'C' : (nib == 4u ? 'T' : (nib == 8u ? 'G' : 'N')));
+                    w[k >> 2] |= ch << (8 * (k & 3));
+                }
+                u32x2 ww; ww.x = w[0]; ww.y = w[1];
+                *(u32x2 *)(out + o) = ww;
             }
-            u32x2 ww; ww.x = w[0]; ww.y = w[1];
-            *(u32x2 *)(out + o) = ww;
         }
     }
 }
