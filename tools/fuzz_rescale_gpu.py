@@ -57,23 +57,28 @@ def main():
             want_tables = oracle_tableset(ref, b, libs, length, 10, 0)
         except Exception as e:      # (fuzzed batches hold records the tabulation rejects: then only the rescaling is compared)
             want_tables = None
-        with DamageEngine(libs, length, 10, 0) as eng:
-            eng.set_reference(ref)
-            eng.set_rescale_model(model)
-            try:
-                fq, fmr, fst = one_pass(eng, b)
-                fwords = eng.rescale_summary()
-                ftables = eng.finish() if want_tables is not None else None
-                okf = (np.array_equal(fq, want_q) and np.array_equal(fst, want_st) and np.array_equal(np.isnan(fmr), np.isnan(want_mr))
-                       and np.array_equal(fmr[~np.isnan(fmr)], want_mr[~np.isnan(want_mr)]) and np.array_equal(fwords, words))
-                if ftables is not None:
-                    try:
-                        assert_tables_equal(ftables, want_tables)
-                    except AssertionError:
-                        okf = False
-            except Exception as e:
-                okf = want_tables is None
-                print("   fused pass raised:", type(e).__name__, str(e)[:100])
+        okf = True
+        for packed in (False, True):       # (both forms of the SEQ column: the fused ASCII kernel, the packed fused kernel)
+            with DamageEngine(libs, length, 10, 0) as eng:
+                eng.set_reference(ref)
+                eng.set_rescale_model(model)
+                try:
+                    fq, fmr, fst = one_pass(eng, b, packed)
+                    fwords = eng.rescale_summary()
+                    ftables = eng.finish() if want_tables is not None else None
+                    okf1 = (np.array_equal(fq, want_q) and np.array_equal(fst, want_st) and np.array_equal(np.isnan(fmr), np.isnan(want_mr))
+                           and np.array_equal(fmr[~np.isnan(fmr)], want_mr[~np.isnan(want_mr)]) and np.array_equal(fwords, words))
+                    if ftables is not None:
+                        try:
+                            assert_tables_equal(ftables, want_tables)
+                        except AssertionError:
+                            okf1 = False
+                except Exception as e:
+                    okf1 = want_tables is None
+                    print("   fused pass (%s) raised:" % ("4-bit" if packed else "ASCII"), type(e).__name__, str(e)[:100])
+            if not okf1:
+                print("   fused pass (%s): MISMATCH" % ("4-bit" if packed else "ASCII"))
+            okf = okf and okf1
         ok = ok and okf
         print("round %d (%s, model %d+%d, %d records): %s" % (k, "fuzzed CIGARs" if k % 2 == 0 else "short records", l5, l3, b.n,
                                                               "equal" if ok else "MISMATCH"), flush=True)

@@ -17,7 +17,7 @@ COMMON="--reads 25000000 --no-cpu --no-secondary --batch-cache /tmp/mdx_bc $*"
 BENCH="python $R/bench.py --steps 50 --warmup 5 $COMMON"
 SHORT="python $R/bench.py --steps 6 --warmup 2 $COMMON"
 # (config 5: the rescale kernels behind the fused tabulation kernel belong to the launch)
-case "$*" in *"--config 5"*) KPAT="tabulate_kernel|rescale_kernel|rescale_walk_kernel|rescale_reduce_kernel";; *) KPAT=tabulate_kernel;; esac
+case "$*" in *"--config 5"*) KPAT="tabulate_kernel|rescale_kernel|rescale_walk_kernel|rescale_reduce_kernel|unpack_listed_kernel";; *) KPAT=tabulate_kernel;; esac
 echo "$BENCH" > $OUT/command.txt
 $BENCH > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1

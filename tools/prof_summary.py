@@ -21,7 +21,7 @@ durs = []
 # config 5 (tabulation + rescaling in one call): a launch is the fused tabulation kernel and the rescale kernels behind it
 # (rescale_kernel over the records it lists, the walk kernel, the reduction of the summary rows) — their durations summed
 config5 = "--config 5" in res["command"]
-extra = ("rescale_kernel", "rescale_walk_kernel", "rescale_reduce_kernel") if config5 else ()
+extra = ("rescale_kernel", "rescale_walk_kernel", "rescale_reduce_kernel", "unpack_listed_kernel") if config5 else ()
 try:
     allrows = list(csv.DictReader(open(os.path.join(out, "kernel_trace_full.csv"))))
     rows = [r for r in allrows if "tabulate_kernel" in r["Kernel_Name"]]
