@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 3   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek */
+#define MDX_ABI_VERSION 4   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer) */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -101,6 +101,12 @@ typedef struct {
     const uint8_t *qual;       /* may be NULL */
     int32_t seq_format;        /* MDX_SEQ_ASCII (0) or MDX_SEQ_4BIT */
     int32_t reserved;          /* 0 */
+    /* Optional, device batches only, used with --min-basequal by the packed kernel (a 4-bit seq column): bit i & 31 of
+     * 32-bit word i / 32 = qual[i] is below the context's --min-basequal (align.py:65-71; 0xFF — no qualities — is not);
+     * (n_bases + 31) / 32 + 2 words, the last two zero, 4-byte aligned.  NULL: the library builds it from `qual` in front
+     * of every launch (one pass over the quality column).  mdx_batch_upload fills it in when the context has a
+     * --min-basequal, mdx_batch_free releases it. */
+    const uint8_t *lowq;
 } mdx_batch;
 
 /* ASCII SEQ bytes -> the MDX_SEQ_4BIT column (host buffers; `packed` holds (n_bases + 1) / 2 bytes; `threads` host

@@ -131,6 +131,8 @@ struct mdx_ctx {
     uint32_t *d_tile_ctr = nullptr; // tile counters of the fast kernels' pools (MdxTabArgs::tile_ctr)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
     size_t pkf_prepared = 0;       // ... and the packed fused kernel
+    bool pkm_prepared = false;     // the packed kernel's masked form
+    DevBuf lowq;           // --min-basequal, packed kernel: the bitmap of the batch's qualities below the threshold
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
     int64_t n_packed = 0;          // launches of the packed kernel so far (mdx_packed_launches)
     int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
@@ -308,6 +310,7 @@ void mdx_destroy(mdx_ctx *c) {
     if (c->gbam_event) (void)hipEventDestroy((hipEvent_t)c->gbam_event);
     c->lists.release();
     c->unpacked.release();
+    c->lowq.release();
     c->rs_part.release();
     c->rs_lists.release();
     c->rs_in.release();
@@ -425,6 +428,19 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
         *col.dst = p;
         HIP_TRY(c, hipMemcpyAsync(p, col.src, col.bytes, hipMemcpyHostToDevice, c->stream));
     }
+    // --min-basequal and a 4-bit SEQ column: the bitmap of the qualities below the threshold travels with the resident batch
+    // (mdx_batch::lowq) instead of being built in front of every launch
+    // (MDX_NO_BATCH_LOWQ=1 in the environment: not — every launch builds its own, for A/B runs)
+    static const bool no_batch_lowq = [] { const char *e = getenv("MDX_NO_BATCH_LOWQ"); return e && *e && *e != '0'; }();
+    if (c->cfg.minqual > 0 && dv->qual && h->seq_format == MDX_SEQ_4BIT && h->n_bases > 0 && !no_batch_lowq) {
+        const int64_t n_words = (h->n_bases + 31) / 32;
+        void *p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, (size_t)(n_words + 2) * 4 + 64));
+        dv->lowq = (const uint8_t *)p;
+        HIP_TRY(c, hipMemsetAsync((char *)p + (size_t)n_words * 4, 0, 8, c->stream));
+        mdx_k_lowq_bitmap(dv->qual, h->n_bases, c->cfg.minqual, (uint32_t *)p, n_words, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MDX_OK;
 }
@@ -433,7 +449,7 @@ int mdx_batch_free(mdx_ctx *c, mdx_batch *dv) {
     if (!c || !dv) return MDX_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const void *ptrs[] = {dv->flag, dv->lib, dv->tid, dv->pos, dv->tlen, dv->cigar_off,
-                          dv->cigar, dv->seq_off, dv->seq, dv->qual};
+                          dv->cigar, dv->seq_off, dv->seq, dv->qual, dv->lowq};
     for (const void *p : ptrs) if (p) (void)hipFree(const_cast<void *>(p));
     std::memset(dv, 0, sizeof(*dv));
     return MDX_OK;
@@ -455,8 +471,13 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     const bool ref32 = c->ref_len + 1024 < (int64_t)0xFFFFFFFFLL && !force_ref64;
     static const bool no_packed = [] { const char *e = getenv("MDX_NO_PACKED"); return e && *e && *e != '0'; }();
     // (a fused launch: the packed fused kernel, one library — its caller has checked that it applies, packed_fuse_applies)
+    // (--min-basequal: the packed kernel's masked form reads a bitmap of the qualities below the threshold, built in front of
+    // the launch — MDX_NO_PACKED_MASK=1: the ASCII kernel instead, for A/B runs)
+    static const bool no_pkm = [] { const char *e = getenv("MDX_NO_PACKED_MASK"); return e && *e && *e != '0'; }();
+    const bool want_mask = c->cfg.minqual > 0 && b_in->qual != nullptr;
     const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 &&
-                        (fuse ? c->cfg.nlib == 1 : !(c->cfg.minqual > 0 && b_in->qual != nullptr)) && !no_packed;
+                        (fuse ? c->cfg.nlib == 1 : !(want_mask && no_pkm)) && !no_packed;
+    const bool pmask = packed && !fuse && want_mask;
     mdx_batch b_ascii;
     const mdx_batch *b = b_in;
     if (!packed) {
@@ -576,6 +597,26 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             HIP_TRY(c, hipEventCreate(&e1));
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         }
+        if (pmask && b->lowq && ((uintptr_t)b->lowq & 3) == 0) {
+            // (the batch brings its bitmap)
+            if (!c->pkm_prepared) {
+                HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds))));
+                c->pkm_prepared = true;
+            }
+            a.lowq = b->lowq;
+        } else if (pmask && lo == 0) {
+            // the bitmap of the qualities below the threshold (one pass over the quality column, inside the timed region;
+            // two guard words behind it)
+            const int64_t n_words = (b->n_bases + 31) / 32;
+            HIP_TRY(c, c->lowq.reserve((size_t)(n_words + 2) * 4 + 64));
+            HIP_TRY(c, hipMemsetAsync((char *)c->lowq.p + (size_t)n_words * 4, 0, 8, c->stream));
+            mdx_k_lowq_bitmap(b->qual, b->n_bases, c->cfg.minqual, (uint32_t *)c->lowq.p, n_words, c->stream);
+            if (!c->pkm_prepared) {
+                HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds))));
+                c->pkm_prepared = true;
+            }
+        }
+        if (pmask && !a.lowq) a.lowq = (const uint8_t *)c->lowq.p;
         // (the pools' tile counters: inside the timed region)
         HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)4096 * 4, c->stream));
         if (fuse) {
@@ -591,7 +632,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             c->fuse_list_cap = a.list_cap;
             if (fused_grid) *fused_grid = grid;
         } else if (packed) {
-            mdx_k_tabulate_packed(a, grid, lds, c->stream);
+            if (pmask) mdx_k_tabulate_packed_masked(a, grid, lds, c->stream);
+            else mdx_k_tabulate_packed(a, grid, lds, c->stream);
             c->n_packed++;
         } else {
             mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);

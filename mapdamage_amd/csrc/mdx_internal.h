@@ -155,6 +155,9 @@ struct MdxTabArgs {
     // genome coordinate i - 256), read by the packed kernel (tabulate_kernel<.., PK>) together with a 4-bit SEQ column
     const uint8_t *ref4;
     int seq_packed;                  // the batch's seq column holds MDX_SEQ_4BIT codes (include/mdx.h)
+    // the packed kernel with --min-basequal: bit i (of 32-bit words: 4-byte aligned) = the quality of base i of the seq column
+    // is below the threshold; (n_bases + 31) / 32 + 2 words
+    const uint8_t *lowq;
     const int64_t *contig_off;
     int n_contig;
     int minqual;
@@ -240,6 +243,10 @@ int mdx_k_pk_blocks_per_cu();     // by its registers
 int mdx_k_pk_queue_off(const MdxDims &d);
 size_t mdx_k_pk_lds_bytes(const MdxDims &d);
 hipError_t mdx_k_prepare_packed(size_t lds_bytes);
+// ... with --min-basequal (MdxTabArgs::lowq), and the bitmap from a quality column (words beyond the column: zero)
+hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes);
+void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
+void mdx_k_lowq_bitmap(const uint8_t *qual, int64_t n_bases, int minqual, uint32_t *out, int64_t n_words, hipStream_t s);
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);

@@ -44,6 +44,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 __attribute__((aligned(1))) u32x2_u;
+typedef u32x2 __attribute__((aligned(4))) u32x2_a4;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 typedef u32 __attribute__((aligned(1))) u32_u;
@@ -119,6 +120,9 @@ typedef long long i64;
 #endif
 #ifndef MDX_PK_PD
 #define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
+#endif
+#ifndef MDX_PKM_PD
+#define MDX_PKM_PD 3                    // ... and with --min-basequal
 #endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
@@ -450,6 +454,14 @@ __device__ __forceinline__ void lane_masks16(const MdxDims &d, int side, int m16
         em = vm & nibble_range16(0, m16 + 16 - d.A);
     }
 }
+// eight bits -> eight nibbles (bit j -> all four bits of nibble j)
+__device__ __forceinline__ u32 spread8(u32 b) {
+    u32 x = b & 0xFFu;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return (x << 4) - x;
+}
 // carry-save adder over 32 one-bit columns: p + a + b = p' + 2 c
 // (written out: the carry first, then the sum over p itself — left to the scheduler the sum comes first into a register of
 // its own and every plane is copied back at the end of the loop body: 37 v_mov per group of four steps)
@@ -546,7 +558,7 @@ void mdx_k_unpack_seq(const u8 *d_packed, u8 *d_ascii, int64_t n, hipStream_t s)
 template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false>
 __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK), RS ? MDX_FUSE_WPS : (PK ? MDX_PK_WPS : MDX_WPS)) void tabulate_kernel(MdxTabArgs a) {
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
-    static_assert(!PK || (USE_LDS && FAST && !MASK), "the packed kernel is the plain fast LDS kernel (with or without the fused rescaling)");
+    static_assert(!PK || (USE_LDS && FAST), "the packed kernel is the fast LDS kernel (plain, with the fused rescaling, or with --min-basequal)");
     constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK);
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -712,10 +724,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // 0-7 / 8-15: bit i of the count of base k at nibble j; the lane's slot fixes the strand) and the steps added since they
     // were last folded into TC (at most 255: eight planes)
     u32 bsL[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, bsH[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    // PK with --min-basequal: a second set — the read bases of the masked columns (align.py:65-71 turns both symbols of such a
+    // column into N: it counts its read base in the composition table and nothing else), folded into CMP by position
+    u32 b2L[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, b2H[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int bs_steps = 0;
     // fold the planes into the block's TC table, PK layout: word [base k][64 j + lane]; per bit position s of the bytes of
     // a plane, the four counters of bits s, s + 8, s + 16, s + 24 are gathered as the bytes of one word
-    auto bs_flush = [&]() {
+    // (inlined at every call site: a call would take the planes through memory)
+    auto bs_flush = [&]() __attribute__((always_inline)) {
 #ifdef MDX_ABL_NOFLUSH       // (ablation builds — wrong tables, the instruction counts of what is left: tools/ablate.sh)
         bs_steps = 0;
         return;
@@ -738,6 +754,29 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) { bsL[i] = 0u; bsH[i] = 0u; }
+            if (MASK) {
+                // nibble j of this lane is read column p = (right side: m16 + 15 - j, left: m16 + j) - A of its side; only
+                // read columns have counted
+                u32 *const cmp = lds + d.off_cmp() + (p_strand ? 2 * L * 4 : 0) + (c_side ? L * 4 : 0);
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+#pragma unroll
+                    for (int sft = 0; sft < 8; sft++) {
+                        u32 acc = 0u;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) acc |= (((half ? b2H[i] : b2L[i]) >> sft) & 0x01010101u) << i;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int b = sft + 8 * q, j = 8 * half + (b >> 2), k = b & 3;
+                            const u32 cnt = (acc >> (8 * q)) & 0xFFu;
+                            const int pcol = (c_side ? c_m8 + 15 - j : c_m8 + j) - A;
+                            if (cnt) atomicAdd(&cmp[pcol * 4 + k], cnt);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) { b2L[i] = 0u; b2H[i] = 0u; }
+            }
             bs_steps = 0;
         }
     };
@@ -1223,7 +1262,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const int base_l = e0 + (p_strand ? nP_ : 0) + c_slot, lim_l = (p_strand ? nM_ : nP_) - c_slot;
                 // (one <3 x i32> load per operand: a struct of three words is taken apart and put together again as the
                 // vectorizer likes — two overlapping dwordx2 loads at times)
-                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
+                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; u32x2 lq; int k; bool valid; };
                 auto fill16 = [&](St16 &st) {
                     st.valid = kf < nsteps4;
                     const int k = st.valid ? kf : nsteps4 - 1;
@@ -1293,6 +1332,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     st.ra = ro << 2; st.sa = so << 2;
                     st.r = *(const u32v3_u *)(refW + ((ro >> 1) & ~3u));
                     st.s = *(const u32v3_u *)(seqW + ((so >> 1) & ~3u));
+                    // (--min-basequal: the sixteen bits of the lane's bases in the batch's bitmap of low qualities, see count16)
+                    if (MASK) st.lq = *(const u32x2_a4 *)(a.lowq + (((so - ph_seq) >> 5) << 2));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
                 };
                 // one step: X = the nibbles this step counts (one-hot codes: the increments themselves).  A step whose events do
@@ -1300,7 +1341,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // starts again from that step
                 bool ovf = false;
                 int kredo = 0;
-                auto count16 = [&](const St16 &st, auto full_tag, u32 &Xlo, u32 &Xhi) {
+                bool grp_y = false;     // MASK: some step of the group holds masked columns
+                auto count16 = [&](const St16 &st, auto full_tag, u32 &Xlo, u32 &Xhi, u32 &Ylo, u32 &Yhi) {
                     constexpr bool FULL = decltype(full_tag)::value;
                     u32 s_lo = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa), s_hi = __builtin_amdgcn_alignbit(st.s.z, st.s.y, st.sa);
                     u32 r_lo = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra), r_hi = __builtin_amdgcn_alignbit(st.r.z, st.r.y, st.ra);
@@ -1358,6 +1400,20 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         s_lo = (u32)s64; s_hi = (u32)(s64 >> 32); r_lo = (u32)r64; r_hi = (u32)(r64 >> 32);
                         Xlo = (u32)X64; Xhi = (u32)(X64 >> 32);
                     }
+                    if (MASK) {
+                        // --min-basequal: bit i of MdxTabArgs::lowq = the quality of base i of the SEQ column is below the
+                        // threshold.  A masked read column counts its read base — the second set of planes — and nothing
+                        // else: it leaves both strings (no count of its reference base, no event)
+                        // (a step none of whose lanes holds a low quality — clean data, vouched-for records — is the unmasked step)
+                        const u32 mb = __builtin_amdgcn_alignbit(st.lq.y, st.lq.x, (st.sa >> 2) - ph_seq) & 0xFFFFu;
+                        if (__ballot(mb != 0u)) {
+                            const u32 mk_lo = spread8(mb) & c_em_lo, mk_hi = spread8(mb >> 8) & c_em_hi;
+                            Ylo = s_lo & mk_lo; Yhi = s_hi & mk_hi;
+                            s_lo &= ~mk_lo; s_hi &= ~mk_hi; r_lo &= ~mk_lo; r_hi &= ~mk_hi;
+                            Xlo &= ~mk_lo; Xhi &= ~mk_hi;
+                            grp_y = true;
+                        }
+                    }
                     // the lanes holding a read column that is not a plain match queue their four dwords (see qQ)
                     const u32 x_lo = (s_lo ^ r_lo) & c_em_lo, x_hi = (s_hi ^ r_hi) & c_em_hi;
                     const bool ev = (x_lo | x_hi) != 0u;
@@ -1370,7 +1426,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const int n = __popcll(mm);
                         if (qcount + n > MDX_PK_QCAP) {
                             ovf = true; kredo = st.k;
-                            Xlo = 0u; Xhi = 0u;
+                            Xlo = 0u; Xhi = 0u; Ylo = 0u; Yhi = 0u;
                             return;
                         }
                         if (ev) {
@@ -1413,16 +1469,19 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         }
                     }
                 };
-                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : MDX_PK_PD);
+                // (--min-basequal: three — the second set of planes and the bitmap words want the registers of the fourth)
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : (MASK ? MDX_PKM_PD : MDX_PK_PD));
                 static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
                 St16 st[PD4];
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
                 // low and high dwords
                 auto group = [&](auto full_tag, const bool refill) {
                     u32 xl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, xh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                    u32 yl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, yh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                    grp_y = false;
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) {
-                        if (!ovf && (refill || dd == 0 || st[dd].valid)) count16(st[dd], full_tag, xl[dd], xh[dd]);
+                        if (!ovf && (refill || dd == 0 || st[dd].valid)) count16(st[dd], full_tag, xl[dd], xh[dd], yl[dd], yh[dd]);
                         if (refill) fill16(st[dd]);
 #ifdef MDX_ABL_NOCSA
                         bsL[0] |= xl[dd]; bsH[0] |= xh[dd];
@@ -1436,6 +1495,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             else if ((dd & 3) == 2) { bs_add_group<3>(bsL, al); bs_add_group<3>(bsH, ah); }
                             else if ((dd & 3) == 1) { bs_add_group<2>(bsL, al); bs_add_group<2>(bsH, ah); }
                             else { bs_add_group<1>(bsL, al); bs_add_group<1>(bsH, ah); }
+                            if (MASK && grp_y) {
+                                const u32 cl[4] = {yl[dd & ~3], yl[(dd & ~3) + 1], yl[(dd & ~3) + 2], yl[(dd & ~3) + 3]};
+                                const u32 ch[4] = {yh[dd & ~3], yh[(dd & ~3) + 1], yh[(dd & ~3) + 2], yh[(dd & ~3) + 3]};
+                                if ((dd & 3) == 3) { bs_add_group<4>(b2L, cl); bs_add_group<4>(b2H, ch); }
+                                else if ((dd & 3) == 2) { bs_add_group<3>(b2L, cl); bs_add_group<3>(b2H, ch); }
+                                else if ((dd & 3) == 1) { bs_add_group<2>(b2L, cl); bs_add_group<2>(b2H, ch); }
+                                else { bs_add_group<1>(b2L, cl); bs_add_group<1>(b2H, ch); }
+                            }
                         }
                     }
                 };
@@ -1891,7 +1958,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // ... and those with a single short indel between two match runs are counted by the fast path entirely,
                 // one entry each (STEP_G in count())
                 // (up to seven bases: three bits of the event word; longer ones keep the CIGAR walk)
-                isS = gpre && one && dnq >= -7 && dnq <= 7;
+                // (PK with --min-basequal: the packed single-indel steps do not move the mask with the read — such records keep
+                // their first / last run in the partial list and walk the rest)
+                isS = gpre && one && dnq >= -7 && dnq <= 7 && !(PK && MASK);
                 if (gpre) {
                     w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
                     // (single-indel entries carry the two run lengths, the others the task bytes of each window)
@@ -2325,7 +2394,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (cn >= 3u) g2 = a.cigar[c_co0 + 2];
                     c0 = (u32)a.contig_off[c_tid];
                     clen = (u32)a.contig_off[c_tid + 1] - c0;
-                    if (MASK && a.qual != nullptr) q0 = a.qual[c_so0];
+                    if (MASK && !PK && a.qual != nullptr) q0 = a.qual[c_so0];
                 }
                 u32 rs_qf = 0xFFu;          // RS: the record's first quality (0xFF: none, rescale.py:306)
                 if (RS) {
@@ -2836,6 +2905,41 @@ void mdx_k_unpack_listed(const uint32_t *in_count, const uint32_t *in_list, int6
     const i64 waves = (i64)n_in * UNPK_SPLIT;
     hipLaunchKernelGGL(unpack_listed_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in_count, in_list, (i64)in_cap, n_in,
                        seq_off, seq4, out, (i64)n_bases);
+}
+
+hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void *)tabulate_kernel<true, true, true, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    if (a.n_reads <= 0) return;
+    hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+}
+// --min-basequal for the packed kernel: bit i of `out` (32-bit words, bit i & 31 of word i / 32) = quality i is below the
+// threshold (align.py:65-71; 0xFF — no qualities — is not); one thread per word
+__global__ void lowq_bitmap_kernel(const u8 *__restrict__ qual, i64 n, u32 minq, u32 *__restrict__ out, i64 n_words) {
+    const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const i64 b0 = w * 32;
+    u32 bits = 0u;
+    if (b0 + 32 <= n) {
+        const u32x4 v0 = *(const u32x4_u *)(qual + b0), v1 = *(const u32x4_u *)(qual + b0 + 16);
+        const u32 q[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const u32 m4 = minq * 0x01010101u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            // bit 7 of a byte: its quality is below the threshold (qualities of 128 and more — 0xFF — never are)
+            const u32 low = ~((q[k] | 0x80808080u) - m4) & ~q[k] & 0x80808080u;
+            bits |= ((((low >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
+        }
+    } else {
+        for (int k = 0; k < 32 && b0 + k < n; k++) bits |= (u32)(qual[b0 + k] < minq) << k;
+    }
+    out[w] = bits;
+}
+void mdx_k_lowq_bitmap(const uint8_t *qual, int64_t n_bases, int minqual, uint32_t *out, int64_t n_words, hipStream_t s) {
+    if (n_words <= 0) return;
+    hipLaunchKernelGGL(lowq_bitmap_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, qual, (i64)n_bases, (u32)minqual, out, (i64)n_words);
 }
 
 hipError_t mdx_k_prepare_packed(size_t lds_bytes) {

@@ -56,7 +56,7 @@ class MdxBatch(ctypes.Structure):
                 ("cigar_off", ctypes.c_void_p), ("cigar", ctypes.c_void_p),
                 ("seq_off", ctypes.c_void_p), ("seq", ctypes.c_void_p),
                 ("qual", ctypes.c_void_p),
-                ("seq_format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("seq_format", ctypes.c_int32), ("reserved", ctypes.c_int32), ("lowq", ctypes.c_void_p)]
 
 
 class MdxError(RuntimeError):

@@ -414,10 +414,11 @@ class GpuBamStream:
         if min_basequal:
             # --min-basequal: unmaskable records are flagged on the device, see ``missing_qualities``
             self._lib.mdx_gbam_set_min_basequal(self._g, int(min_basequal))
-        # the SEQ column of the views: BAM's nibbles kept as nibbles (MDX_SEQ_4BIT: the packed kernel reads them) unless
-        # the launches behind it read ASCII anyway (--min-basequal, rescaling); ``packed`` overrides the choice
+        # the SEQ column of the views: BAM's nibbles kept as nibbles (MDX_SEQ_4BIT: the packed kernel — with --min-basequal
+        # its masked form — reads them) unless the launches behind it read ASCII anyway (the rescale kernels of
+        # --rescale-only want the qualities without a threshold); ``packed`` overrides the choice
         if packed is None:
-            packed = not (want_qual or min_basequal)
+            packed = bool(min_basequal) or not want_qual
         self.packed = bool(packed)
         if self.packed:
             self._lib.mdx_gbam_set_seq_format(self._g, 1)

@@ -33,10 +33,10 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.mdx_abi_version() == 3       # 3: mdx_gbam_tell, mdx_gbam_fixups, mdx_bam_seek
+    assert lib.mdx_abi_version() == 4       # 4: mdx_batch::lowq
     import re
     hdr = (pathlib.Path(__file__).resolve().parent.parent / "include" / "mdx.h").read_text()
-    assert int(re.search(r"#define MDX_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    assert int(re.search(r"#define MDX_ABI_VERSION (\d+)", hdr).group(1)) == 4
     assert lib.mdx_strerror(0) == b"ok"
     assert b"contig" in lib.mdx_strerror(-6)
 

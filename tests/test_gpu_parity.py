@@ -39,8 +39,9 @@ def run_engine(ref, batch, libraries, length, around, minqual=0, lgd_max=65536, 
                 dev.free()
             else:
                 eng.tabulate(part)
-        # the packed kernel is what runs for a 4-bit column in a plain tabulation (one launch per library), and only then
-        plain = eng.table_mode == "lds" and length + around <= 248 and not (minqual > 0 and batch.qual is not None)
+        # the packed kernel is what runs for a 4-bit column in a tabulation with the fast geometry (one launch per library; with
+        # --min-basequal its masked form), and only then
+        plain = eng.table_mode == "lds" and length + around <= 248
         want = splits * len(libraries) if (DamageEngine.default_packed and plain and batch.n) else 0
         assert eng.packed_launches() == want
         return eng.finish()
@@ -225,7 +226,7 @@ def test_hip_path_of_a_reference_of_4_gbases_and_more(mid_genome, monkeypatch, Q
         eng.set_reference(mid_genome)
         eng.tabulate(batch, packed=True)
         got = eng.finish()
-        assert eng.packed_launches() == (0 if Q else 2)
+        assert eng.packed_launches() == 2
     assert_tables_equal(got, want)
 
 
