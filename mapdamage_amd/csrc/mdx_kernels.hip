@@ -1351,6 +1351,16 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (RS && (KIND == STEP_GI || KIND == STEP_GD)) evw |= st.aux2 & 0x1FE00000u;
                     u32 by_lo = 0u, by_hi = 0u;     // RS, single-indel steps: the reference bases of the step's columns
                     u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
+                    // --min-basequal: bit i of MdxTabArgs::lowq = the quality of base i of the SEQ column is below the threshold;
+                    // mk64 = the lane's nibbles whose base is (the sixteen bits from its own SEQ window offset on; a step none of
+                    // whose lanes holds a low quality — clean data, vouched-for records — is the unmasked step)
+                    u64 mk64 = 0ull, behm = 0ull, ymk = 0ull;
+                    bool has_m = false;
+                    if (MASK) {
+                        const u32 mb = __builtin_amdgcn_alignbit(st.lq.y, st.lq.x, (st.sa >> 2) - ph_seq) & 0xFFFFu;
+                        has_m = __ballot(mb != 0u) != 0ull;
+                        if (has_m) mk64 = (u64)spread8(mb) | ((u64)spread8(mb >> 8) << 32);
+                    }
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
                         if (!FULL) {
@@ -1382,9 +1392,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             m = (Yk & m) | (~Yk & high);
                             if (KIND == STEP_GD) {
                                 s64 = m;
+                                // (the mask travels with the read; a deleted column has no quality: never masked, align.py:67)
+                                if (MASK && has_m) mk64 = (Yk & Xk & (mk64 >> shr)) | (~Yk & (mk64 << shl));
                                 // nibbles behind the deletion (left: from tb on, right: below ta): MIS[column][base] and
                                 // CMP[column - g][base] by position instead of the counters (below)
                                 const u64 beh = (Xk & sm) | (~Yk & ~sm);
+                                behm = beh;
                                 dmk = dyn & beh;
                                 evw |= 0x1000u | ((st.aux2 & 7u) << 13) | (((st.aux2 >> 3) & 31u) << 16);
                                 s64 &= dyn; r64 &= dyn;
@@ -1400,19 +1413,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         s_lo = (u32)s64; s_hi = (u32)(s64 >> 32); r_lo = (u32)r64; r_hi = (u32)(r64 >> 32);
                         Xlo = (u32)X64; Xhi = (u32)(X64 >> 32);
                     }
-                    if (MASK) {
-                        // --min-basequal: bit i of MdxTabArgs::lowq = the quality of base i of the SEQ column is below the
-                        // threshold.  A masked read column counts its read base — the second set of planes — and nothing
-                        // else: it leaves both strings (no count of its reference base, no event)
-                        // (a step none of whose lanes holds a low quality — clean data, vouched-for records — is the unmasked step)
-                        const u32 mb = __builtin_amdgcn_alignbit(st.lq.y, st.lq.x, (st.sa >> 2) - ph_seq) & 0xFFFFu;
-                        if (__ballot(mb != 0u)) {
-                            const u32 mk_lo = spread8(mb) & c_em_lo, mk_hi = spread8(mb >> 8) & c_em_hi;
-                            Ylo = s_lo & mk_lo; Yhi = s_hi & mk_hi;
-                            s_lo &= ~mk_lo; s_hi &= ~mk_hi; r_lo &= ~mk_lo; r_hi &= ~mk_hi;
-                            Xlo &= ~mk_lo; Xhi &= ~mk_hi;
-                            grp_y = true;
+                    if (MASK && has_m) {
+                        // A masked read column counts its read base — the second set of planes — and nothing else: it leaves both
+                        // strings (no count of its reference base, no event)
+                        const u32 mk_lo = (u32)mk64 & c_em_lo, mk_hi = (u32)(mk64 >> 32) & c_em_hi;
+                        Ylo = s_lo & mk_lo; Yhi = s_hi & mk_hi;
+                        s_lo &= ~mk_lo; s_hi &= ~mk_hi; r_lo &= ~mk_lo; r_hi &= ~mk_hi;
+                        Xlo &= ~mk_lo; Xhi &= ~mk_hi;
+                        if (KIND == STEP_GD) {
+                            // (behind the deletion of its record a column's composition position is g less than the lane's:
+                            // those read bases by position, below — not through the planes)
+                            dmk &= ~((u64)mk_lo | ((u64)mk_hi << 32));
+                            ymk = ((u64)Ylo | ((u64)Yhi << 32)) & behm;
+                            Ylo &= ~(u32)behm; Yhi &= ~(u32)(behm >> 32);
                         }
+                        grp_y = true;
                     }
                     // the lanes holding a read column that is not a plain match queue their four dwords (see qQ)
                     const u32 x_lo = (s_lo ^ r_lo) & c_em_lo, x_hi = (s_hi ^ r_hi) & c_em_hi;
@@ -1449,6 +1464,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         bcG += __builtin_popcount(y_lo & 0x88888888u) + __builtin_popcount(y_hi & 0x88888888u);
                     }
 #endif
+                    if (MASK && KIND == STEP_GD && __ballot(ymk != 0ull)) {
+                        // (the masked read bases behind the deletion: CMP[column - g][base], like the pass below)
+                        const int g = (int)(st.aux2 & 7u);
+                        const int rev = (int)(st.pk >> 31);
+                        const int row = __mul24(rev * 2 + c_side, L) + c_m8 - A;
+                        u32 *const pc = lds + d.off_cmp() + (row - g) * 4;
+                        const u64 rr = c_side ? __builtin_bitreverse64(ymk) : ymk;
+                        const u32 kx = c_side ? 3u : 0u;
+#pragma unroll 1
+                        for (int j = 0; j < 16; j++) {
+                            const u32 nib = (u32)(rr >> (4 * j)) & 15u;
+                            const u32 k = (u32)(__ffs((int)nib) - 1) ^ kx;
+                            if (nib) atomicAdd(pc + 4 * j + k, 1u);
+                        }
+                    }
                     if (KIND == STEP_GD && __ballot(dmk != 0ull)) {
                         // one nibble at a time in position order — nibble j on the left side, 15 - j on the right (whose bits
                         // are reversed too: class k is bit 3 - k) —, unrolled: the class of the (one-hot or zero) nibble picks
@@ -1958,9 +1988,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // ... and those with a single short indel between two match runs are counted by the fast path entirely,
                 // one entry each (STEP_G in count())
                 // (up to seven bases: three bits of the event word; longer ones keep the CIGAR walk)
-                // (PK with --min-basequal: the packed single-indel steps do not move the mask with the read — such records keep
-                // their first / last run in the partial list and walk the rest)
-                isS = gpre && one && dnq >= -7 && dnq <= 7 && !(PK && MASK);
+                isS = gpre && one && dnq >= -7 && dnq <= 7;
                 if (gpre) {
                     w1 |= isS ? (D_PRE | D_ONE) : D_PRE;
                     // (single-indel entries carry the two run lengths, the others the task bytes of each window)
@@ -2875,7 +2903,6 @@ __global__ __launch_bounds__(256) void unpack_listed_kernel(const u32 *__restric
             o0 = seq_off[ri] & ~7u; o1 = seq_off[ri + 1];
         }
         const u32 m = n - base < 64u ? n - base : 64u;
-#pragma unroll 4
         for (u32 r0 = 0; r0 < m; r0 += 4u) {
             const int r = (int)r0 + (lane >> 4);
             const u32 a0 = (u32)__shfl((int)o0, r), a1 = (u32)__shfl((int)o1, r);
