@@ -72,10 +72,10 @@ typedef struct {
  *                  of "ACGT" (statistics.py:27, 101; rescale.py:228-246), every other one behaves alike.  seq_off and
  *                  n_bases keep counting bases; the column holds (n_bases + 1) / 2 bytes.  mdx_pack_seq converts;
  *                  mdx_gbam_set_seq_format makes the device decode path write this form straight from BAM's nibbles.
- *                  Such a batch runs through the packed kernel (half the SEQ and reference bytes, no LDS update per
- *                  plain match) whenever the launch is the plain tabulation — no --min-basequal, no rescaling, tables
- *                  in the LDS, reference below 4 Gbases; for anything else the library unpacks it into a scratch column
- *                  first and the results are the same bytes. */
+ *                  Such a batch runs through the packed kernels (half the SEQ and reference bytes, no LDS update per
+ *                  plain match): the plain tabulation, --min-basequal (mdx_batch::lowq) and, with one library,
+ *                  mdx_tabulate_rescale_device — tables in the LDS, reference below 4 Gbases; for anything else the
+ *                  library unpacks it into a scratch column first and the results are the same bytes. */
 #define MDX_SEQ_ASCII 0
 #define MDX_SEQ_4BIT 1
 
