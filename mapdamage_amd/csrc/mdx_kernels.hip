@@ -121,6 +121,9 @@ typedef long long i64;
 #ifndef MDX_PK_PD
 #define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
 #endif
+#ifndef MDX_PK_PTILE
+#define MDX_PK_PTILE 1                  // the packed kernels count a tile's partial records in the tile loop (0: through the wavefront's list behind it; the fused one always does)
+#endif
 #ifndef MDX_PKM_PD
 #define MDX_PKM_PD 3                    // ... and with --min-basequal
 #endif
@@ -1303,6 +1306,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             // the lane's tasks: its nibbles [0, t8 - m16) on the left side, [16 - (t8 - m16), 16) on the right
                             const int dm = t8 - c_m8;
                             st.aux = act ? c16(c_side ? 16 - dm : dm) : (c_side ? 128u : 0u);
+                            if (RS) {
+                                // (a fused partial record, see the complete ones above: a record shorter than --length has all its
+                                // columns in its left window; [15:8] the offset of the nibble-mask table's entry, [27:21], bit 28)
+                                const bool fz = act && ((ent.w >> 18) & 1u);
+                                int t = c_side ? c_m8 + 16 - A + L - nq_ : 16;
+                                t = t < 0 ? 0 : (t > 16 ? 16 : t);
+                                st.aux |= fz ? (((u32)t << 11) | ((u32)idx << 21) | (1u << 28)) : (c_side ? 128u << 8 : 0u);
+                            }
                         } else {
                             // one indel of g bases behind the first (left) / last (right) match run of t8 columns: the gap is
                             // nibbles [ta, tb), the tasks end (left) / start (right) at nibble tl (see the ASCII kernel's fill)
@@ -1347,7 +1358,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     u32 s_lo = __builtin_amdgcn_alignbit(st.s.y, st.s.x, st.sa), s_hi = __builtin_amdgcn_alignbit(st.s.z, st.s.y, st.sa);
                     u32 r_lo = __builtin_amdgcn_alignbit(st.r.y, st.r.x, st.ra), r_hi = __builtin_amdgcn_alignbit(st.r.z, st.r.y, st.ra);
                     u32 evw = c_evw;
-                    if (RS && KIND == STEP_C) evw |= st.aux & 0x1FE00000u;
+                    if (RS && (KIND == STEP_C || KIND == STEP_P)) evw |= st.aux & 0x1FE00000u;
                     if (RS && (KIND == STEP_GI || KIND == STEP_GD)) evw |= st.aux2 & 0x1FE00000u;
                     u32 by_lo = 0u, by_hi = 0u;     // RS, single-indel steps: the reference bases of the step's columns
                     u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
@@ -1375,7 +1386,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const u64 vm64 = (u64)c_vm_lo | ((u64)c_vm_hi << 32);
                         u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32), X64;
                         if (KIND == STEP_P) {
-                            const u64 Mk = *(const u64 *)((const u8 *)ltab + aux);
+                            const u64 Mk = *(const u64 *)((const u8 *)ltab + (aux & 0xFFu));
                             const u64 dyn = (Mk ^ sm) & vm64;
                             s64 &= dyn; r64 &= dyn;
                             X64 = r64;
@@ -1452,12 +1463,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         qcount += n;
                     }
 #ifndef MDX_RSABL_NOBC
-                    if (RS && (KIND == STEP_C || KIND == STEP_GI || KIND == STEP_GD)) {
+                    if (RS) {
                         // the reference bases of a fused record's columns, by class (a code is one-hot: four population counts
                         // per dword), in this lane's own counters — its slot fixes the strand
-                        const u64 Mk = *(const u64 *)((const u8 *)ltab + (KIND == STEP_C ? st.aux & 0xFFu : (st.aux2 >> 8) & 0xFFu));
+                        constexpr bool GK = KIND == STEP_GI || KIND == STEP_GD;
+                        const u64 Mk = *(const u64 *)((const u8 *)ltab + (KIND == STEP_C ? st.aux & 0xFFu : (KIND == STEP_P ? (st.aux >> 8) & 0xFFu : (st.aux2 >> 8) & 0xFFu)));
                         const u32 sm = c_side ? ~0u : 0u;
-                        const u32 y_lo = (KIND == STEP_C ? r_lo : by_lo) & ((u32)Mk ^ sm) & c_em_lo, y_hi = (KIND == STEP_C ? r_hi : by_hi) & ((u32)(Mk >> 32) ^ sm) & c_em_hi;
+                        const u32 y_lo = (GK ? by_lo : r_lo) & ((u32)Mk ^ sm) & c_em_lo, y_hi = (GK ? by_hi : r_hi) & ((u32)(Mk >> 32) ^ sm) & c_em_hi;
                         bcA += __builtin_popcount(y_lo & 0x11111111u) + __builtin_popcount(y_hi & 0x11111111u);
                         bcC += __builtin_popcount(y_lo & 0x22222222u) + __builtin_popcount(y_hi & 0x22222222u);
                         bcT += __builtin_popcount(y_lo & 0x44444444u) + __builtin_popcount(y_hi & 0x44444444u);
@@ -2487,9 +2499,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // behind this one.
                 bool rs_fused = false;
                 if (RS) {
-                    // (PK: the complete ones among them — a record shorter than --length goes through the wavefront's list of
-                    // partial entries behind the tile loop, when its tile's MR words are gone, and is left to the rescale kernels)
-                    rs_fused = want && triv && nq <= 2 * L && (u64)c_so0 + lseq + 16u <= (u64)a.n_bases && (!PK || nq >= L);
+                    rs_fused = want && triv && nq <= 2 * L && (u64)c_so0 + lseq + 16u <= (u64)a.n_bases;
                     // status of the records this kernel is done with (rescale.py:300-342): the fused ones and those written
                     // back unchanged (mr_raw is preset to NaN by the launch: such a record keeps it); the others go to the
                     // wavefront's list
@@ -2608,7 +2618,16 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         if (lane < d.R - 1) stg[nF + lane] = pad;
                     }
                 }
-                if (mP) {
+                // (PTILE — the packed fused kernel: the partial records of the tile are staged behind its complete ones, by strand,
+                // and counted by a run of their own in the tile loop: their MR words are the tile's)
+                constexpr bool PTILE = PK && (RS || MDX_PK_PTILE);
+                int nPt = 0, nPtp = 0;
+                const u64 mPm = PTILE ? __ballot(triv && !isF && rev) : 0ull;
+                if (PTILE && mP) {
+                    nPt = __popcll(mP); nPtp = nPt - __popcll(mPm);
+                    if (triv && !isF) stg[nF + (rev ? nPtp + mbcnt64(mPm, 0) : mbcnt64(mP & ~mPm, 0))] = ent;
+                }
+                if (!PTILE && mP) {
                     // short records and contig edges: tasks [-flank, min(nq, L)) per side (the list of partial records; DMP)
                     if (triv && !isF) {
                         const int dl = lbase + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
@@ -2636,7 +2655,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // lands under the run)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (PF && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
-                if (PK) { if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp); }
+                if (PK) {
+                    if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp);
+                    if (PTILE && nPt) run(nF, nPt, std::integral_constant<int, STEP_P>{}, std::true_type{}, nPtp);
+                }
                 else {
                 if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
                 if (nF - nF0) run(nF0, nF - nF0, std::integral_constant<int, STEP_C>{}, std::true_type{});
@@ -2645,7 +2667,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // The run has drained its events and counted the reference bases of the fused records' columns.  What is
                     // left: the qualities of the listed transitions, and the MR sums from the records' words.
                     rsq_flush();
-                    if (rs_fused) p.rs.mr_raw[ri] = mr_of(mrm[rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0)]);
+                    if (rs_fused) p.rs.mr_raw[ri] = mr_of(mrm[isF ? (rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0))
+                                                                  : nF + (rev ? nPtp + mbcnt64(mPm, 0) : mbcnt64(mP & ~mPm, 0))]);
                 }
                 if (RS && !PK) {
                     // The run has drained its events.  One round trip for what is left of the tile's fused records: the
