@@ -925,6 +925,49 @@ void host_buffer_give(uint8_t *&p, size_t &cap) {
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
 }
+// The read-group tables of a handle (names, offsets, libraries) in one small device allocation that outlives the handle:
+// three hipMalloc / hipMemcpy pairs at configure and three hipFree at close were 4 ms of an 8 M-record file's 63.
+struct RgBuf { int device; void *p; size_t cap; };
+std::mutex g_rgbuf_mu;
+std::vector<RgBuf> g_rgbufs;
+void *rg_buffer_take(int device, size_t need, size_t &cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+        for (size_t i = 0; i < g_rgbufs.size(); i++)
+            if (g_rgbufs[i].device == device && g_rgbufs[i].cap >= need) {
+                void *p = g_rgbufs[i].p; cap = g_rgbufs[i].cap;
+                g_rgbufs.erase(g_rgbufs.begin() + (long)i);
+                return p;
+            }
+    }
+    void *p = nullptr;
+    cap = std::max(need, (size_t)64 << 10);
+    if (hipMalloc(&p, cap) != hipSuccess) { cap = 0; return nullptr; }
+    return p;
+}
+// ... and the two buffers a handle sends the next slab's compressed bytes ahead into (mdx_gbam::pf_buf)
+std::vector<RgBuf> g_pfbufs;
+void pf_buffer_take(int device, size_t need, void *&p, size_t &cap) {
+    std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+    for (size_t i = 0; i < g_pfbufs.size(); i++)
+        if (g_pfbufs[i].device == device && g_pfbufs[i].cap >= need) {
+            p = g_pfbufs[i].p; cap = g_pfbufs[i].cap;
+            g_pfbufs.erase(g_pfbufs.begin() + (long)i);
+            return;
+        }
+}
+void pf_buffer_give(int device, void *p, size_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+    if (g_pfbufs.size() < 4) g_pfbufs.push_back(RgBuf{device, p, cap});
+    else (void)hipFree(p);
+}
+void rg_buffer_give(int device, void *p, size_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+    if (g_rgbufs.size() < 16) g_rgbufs.push_back(RgBuf{device, p, cap});
+    else (void)hipFree(p);
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -983,7 +1026,17 @@ struct mdx_gbam {
     std::vector<uint32_t> rg_off;
     std::vector<int32_t> lib_of_rg;
     int lib_default = -1;
-    void *d_rg_names = nullptr, *d_rg_off = nullptr, *d_lib_of_rg = nullptr;
+    void *d_rg_names = nullptr, *d_rg_off = nullptr, *d_lib_of_rg = nullptr;    // (parts of d_rg: rg_buffer_take)
+    void *d_rg = nullptr;
+    size_t d_rg_cap = 0;
+    // The next slab's compressed bytes, uploaded under this slab's inflate (the device's part of them: the host's share
+    // reads the file itself) into one of two buffers of the handle's own — the arena moves from slab to slab; pf_cur = the
+    // buffer that holds bytes [pf_in0, pf_in0 + pf_bytes) of the file (-1: none), pf_used = the one the current slab's
+    // inflate reads (-1: the arena's).  MDX_GBAM_NO_PREFETCH=1: off (A/B runs).
+    void *pf_buf[2] = {nullptr, nullptr};
+    size_t pf_cap[2] = {0, 0};
+    int pf_cur = -1, pf_used = -1;
+    size_t pf_in0 = 0, pf_bytes = 0;
     void *d_crc_tables = nullptr;        // mdx_crc32::Tables
     // device buffers, grown on demand
     struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, crc, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
@@ -1063,13 +1116,20 @@ int mdx_gbam_configure(mdx_gbam *g, int32_t n_rg, const char *const *rg_ids, con
         g->lib_default = lib_default;
         g->want_qual = want_qual != 0; g->want_mate = want_mate != 0;
         if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
-        for (void **p : {&g->d_rg_names, &g->d_rg_off, &g->d_lib_of_rg}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        g->d_rg_names = g->d_rg_off = g->d_lib_of_rg = nullptr;
         if (n_rg > 0) {
-            if (hipMalloc(&g->d_rg_names, g->rg_names.size() + 1) != hipSuccess || hipMalloc(&g->d_rg_off, g->rg_off.size() * 4) != hipSuccess ||
-                hipMalloc(&g->d_lib_of_rg, g->lib_of_rg.size() * 4) != hipSuccess) { g->error = "out of device memory"; return MDX_ERR_HIP; }
-            (void)hipMemcpy(g->d_rg_names, g->rg_names.data(), g->rg_names.size(), hipMemcpyHostToDevice);
-            (void)hipMemcpy(g->d_rg_off, g->rg_off.data(), g->rg_off.size() * 4, hipMemcpyHostToDevice);
-            (void)hipMemcpy(g->d_lib_of_rg, g->lib_of_rg.data(), g->lib_of_rg.size() * 4, hipMemcpyHostToDevice);
+            // one allocation, one copy: [offsets][libraries][names]
+            const size_t b_off = g->rg_off.size() * 4, b_lib = g->lib_of_rg.size() * 4, b_nm = g->rg_names.size() + 1;
+            const size_t need = b_off + b_lib + b_nm;
+            if (g->d_rg && g->d_rg_cap < need) { rg_buffer_give(g->device, g->d_rg, g->d_rg_cap); g->d_rg = nullptr; g->d_rg_cap = 0; }
+            if (!g->d_rg) g->d_rg = rg_buffer_take(g->device, need, g->d_rg_cap);
+            if (!g->d_rg) { g->error = "out of device memory"; return MDX_ERR_HIP; }
+            std::vector<uint8_t> img(need, 0);
+            std::memcpy(img.data(), g->rg_off.data(), b_off);
+            std::memcpy(img.data() + b_off, g->lib_of_rg.data(), b_lib);
+            std::memcpy(img.data() + b_off + b_lib, g->rg_names.data(), g->rg_names.size());
+            if (hipMemcpy(g->d_rg, img.data(), need, hipMemcpyHostToDevice) != hipSuccess) { g->error = "upload of the read-group tables failed"; return MDX_ERR_HIP; }
+            g->d_rg_off = g->d_rg; g->d_lib_of_rg = (char *)g->d_rg + b_off; g->d_rg_names = (char *)g->d_rg + b_off + b_lib;
         }
         return MDX_OK;
     } catch (...) {
@@ -1177,7 +1237,21 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         }
         const size_t head_comp = nh == nba ? comp_bytes : (size_t)blk[4 * nh];        // compressed bytes the device needs
         if (nh < nba && g->ev_infl0) (void)hipEventRecord(g->ev_infl0, st);
-        if (hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, head_comp, hipMemcpyHostToDevice, st) != hipSuccess ||
+        // (the bytes the previous call sent ahead, if they are these: what is missing of them is sent behind)
+        const uint8_t *comp_dev = (const uint8_t *)g->comp.p;
+        g->pf_used = -1;
+        if (g->pf_cur >= 0 && g->pf_in0 == in0 && g->pf_bytes > 0 && g->pf_cap[g->pf_cur] >= head_comp + 64) {
+            const int k = g->pf_cur;
+            if (g->copy_stream && hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+            if (g->pf_bytes < head_comp &&
+                hipMemcpyAsync((char *)g->pf_buf[k] + g->pf_bytes, g->hs->file->p + in0 + g->pf_bytes, head_comp - g->pf_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+                g->error = "upload failed"; return MDX_ERR_HIP;
+            }
+            comp_dev = (const uint8_t *)g->pf_buf[k];
+            g->pf_used = k;
+        }
+        g->pf_cur = -1;
+        if ((g->pf_used < 0 && hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, head_comp, hipMemcpyHostToDevice, st) != hipSuccess) ||
             hipMemcpyAsync(g->blk.p, blk.data(), nba * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(g->crc.p, crcs.data(), nba * 4, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
         int *d_bad_crc = (int *)((char *)g->small.p + 40);
@@ -1188,7 +1262,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         // works on the same address space: one after the other)
         if (nh < nba && !std::getenv("MDX_GBAM_NO_UPLOAD_SYNC") && hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
         lap("upload");
-        mdx_k_gbam_inflate((const uint8_t *)g->comp.p, (const uint4 *)g->blk.p, (int)nh, (uint8_t *)g->unc.p, (int *)g->status.p, st);
+        mdx_k_gbam_inflate(comp_dev, (const uint4 *)g->blk.p, (int)nh, (uint8_t *)g->unc.p, (int *)g->status.p, st);
         if (nh < nba) {
             // ---- the host's blocks: inflated (and CRC-checked) by the pool into hbuf, piece by piece; this thread copies
             // every finished piece to its place in `unc` on the copy stream, under the device's inflate
@@ -1297,6 +1371,41 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         }
         // (the next slab's block headers, while the device inflates this one)
         if (!timing && !g->scan_to(in1 + want + 65536)) return MDX_ERR_ARG;
+        // ... and the device's part of its compressed bytes, sent ahead: the copy out of the file's (pageable) mapping keeps
+        // this thread busy for as long as it takes, which is time the device spends on this slab's inflate
+        static const bool no_prefetch = [] { const char *e = std::getenv("MDX_GBAM_NO_PREFETCH"); return e && *e && *e != '0'; }();
+        if (!timing && !no_prefetch && b1 < g->blocks.size()) {
+            size_t p1 = b1, pbytes = 0;
+            const size_t pin0 = g->blocks[b1].in_off;
+            while (p1 < g->blocks.size() && (p1 == b1 || (g->blocks[p1].in_off - pin0 < want && pbytes + g->blocks[p1].out_size < 0xE0000000ull))) {
+                pbytes += g->blocks[p1].out_size;
+                p1++;
+            }
+            // (all of the slab's own blocks but the host's share of the inflated bytes, as the next call will split them)
+            size_t upto = p1;
+            if (g->host_share > 0.0 && p1 - b1 >= host_min_blocks) {
+                const size_t target = (size_t)((double)pbytes * g->host_share);
+                size_t acc = 0;
+                while (upto > b1 + 1 && acc + g->blocks[upto - 1].out_size <= target) { acc += g->blocks[upto - 1].out_size; upto--; }
+            }
+            const size_t bytes = (upto < g->blocks.size() ? g->blocks[upto].in_off : g->blocks[upto - 1].in_off + g->blocks[upto - 1].in_size) - pin0;
+            const int k = g->pf_used == 0 ? 1 : 0;
+            const size_t cap_want = (size_t)want + ((size_t)16 << 20);
+            if (g->pf_cap[k] < cap_want) {
+                if (g->pf_buf[k]) (void)hipFree(g->pf_buf[k]);
+                g->pf_buf[k] = nullptr; g->pf_cap[k] = 0;
+                pf_buffer_take(g->device, cap_want, g->pf_buf[k], g->pf_cap[k]);
+                if (!g->pf_buf[k]) {
+                    if (hipMalloc(&g->pf_buf[k], cap_want) == hipSuccess) g->pf_cap[k] = cap_want;
+                    else (void)hipGetLastError();
+                }
+            }
+            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) return MDX_ERR_HIP;
+            if (g->pf_cap[k] >= bytes + 64 && bytes > 0 &&
+                hipMemcpyAsync(g->pf_buf[k], g->hs->file->p + pin0, bytes, hipMemcpyHostToDevice, g->copy_stream) == hipSuccess) {
+                g->pf_cur = k; g->pf_in0 = pin0; g->pf_bytes = bytes;
+            }
+        }
         lap("inflate");
         mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nh, d_bad_crc, st);
         lap("crc32");
@@ -1566,8 +1675,12 @@ void mdx_gbam_close(mdx_gbam *g) {
     host_buffer_give(g->hbuf, g->hbuf_cap);
     if (g->ev_infl0) (void)hipEventDestroy(g->ev_infl0);
     mdx_ctx_scratch_give(g->ctx, g->arena.p, g->arena.cap, g->d_crc_tables, g->copy_stream, g->ev_infl);
-    for (void *p : {g->d_rg_names, g->d_rg_off, g->d_lib_of_rg}) if (p) (void)hipFree(p);
+    rg_buffer_give(g->device, g->d_rg, g->d_rg_cap);
+    if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    for (int k = 0; k < 2; k++) pf_buffer_give(g->device, g->pf_buf[k], g->pf_cap[k]);
     lap("device");
+    // (unmapping the file — a few hundred thousand touched pages — is 3-4 ms of an 8 M-record file's 63; done behind the
+    // caller's back it holds the address space's lock against the next file's mmap and page faults, which then wait as long)
     if (g->hs) mdx_bam_close(g->hs);
     lap("file");
     delete g;
