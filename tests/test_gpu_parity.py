@@ -230,6 +230,38 @@ def test_hip_path_of_a_reference_of_4_gbases_and_more(mid_genome, monkeypatch, Q
     assert_tables_equal(got, want)
 
 
+def test_hip_min_basequal_bitmap_with_the_batch_or_per_launch(mid_genome):
+    """--min-basequal through the packed masked kernel: the bitmap of the qualities below the threshold travels with a
+    batch that mdx_batch_upload made (mdx_batch::lowq) — or, for a batch without one (the device decode's views), is
+    built in front of the launch; both against the oracle, with half of the bases masked and with none."""
+    import copy
+    import ctypes
+
+    from mapdamage_amd.engine import DamageEngine, MdxBatch
+    batch = synth.make_reads(mid_genome, 50_000, 17, len_range=(25, 160), paired=True, frac_softclip=0.15, frac_ins=0.06,
+                             frac_del=0.06, frac_skip=0.01, with_qual=True, frac_filtered=0.03)
+    libs = [("s", "l")]
+    for Q in (20, 1):
+        want = oracle_tableset(mid_genome, batch, libs, 70, 10, Q)
+        with DamageEngine(libs, 70, 10, Q) as eng:
+            eng.set_reference(mid_genome)
+            db = eng.upload(batch, packed=True)
+            assert db.dev.lowq                      # (built at upload: the context has a --min-basequal)
+            eng.tabulate(db)
+            got_resident = eng.finish()
+            assert eng.packed_launches() == 1
+            eng.reset()
+            view = MdxBatch()
+            ctypes.memmove(ctypes.byref(view), ctypes.byref(db.dev), ctypes.sizeof(MdxBatch))
+            view.lowq = None                        # (a batch that does not bring its bitmap)
+            eng.tabulate_view(view)
+            got_per_launch = eng.finish()
+            assert eng.packed_launches() == 2
+            db.free()
+        assert_tables_equal(got_resident, want)
+        assert_tables_equal(got_per_launch, want)
+
+
 def test_hip_rejects_alignment_past_contig_end():
     from mapdamage_amd.engine import BadReadError, DamageEngine
     ref = synth.small_genome()
