@@ -131,6 +131,7 @@ struct mdx_ctx {
     uint32_t *d_tile_ctr = nullptr; // tile counters of the fast kernels' pools (MdxTabArgs::tile_ctr)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
     size_t pkf_prepared = 0;       // ... and the packed fused kernel
+    bool tile_ctr_clean = false;   // d_tile_ctr is all zero (the reduction behind a launch leaves it so)
     bool pkm_prepared = false;     // the packed kernel's masked form
     DevBuf lowq;           // --min-basequal, packed kernel: the bitmap of the batch's qualities below the threshold
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
@@ -617,8 +618,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             }
         }
         if (pmask && !a.lowq) a.lowq = (const uint8_t *)c->lowq.p;
-        // (the pools' tile counters: inside the timed region)
-        HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)4096 * 4, c->stream));
+        // (the pools' tile counters: zeroed by the reduction behind the previous launch, as a rule; else here, inside the timed region)
+        if (!c->tile_ctr_clean) HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)4096 * 4, c->stream));
+        c->tile_ctr_clean = false;
         if (fuse) {
             // (a record written back unchanged keeps this NaN — all ones; inside the timed region)
             HIP_TRY(c, hipMemsetAsync(fuse->mr_raw, 0xFF, (size_t)b->n_reads * 8, c->stream));
@@ -644,7 +646,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         }
         HIP_TRY(c, hipGetLastError());
         if (c->mode == MDX_MODE_LDS) {
-            mdx_k_reduce_partials(c->d_partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream);
+            mdx_k_reduce_partials(c->d_partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream, c->d_tile_ctr);
+            c->tile_ctr_clean = a.dims.w_total >= 4096;
             HIP_TRY(c, hipGetLastError());
         }
     }

@@ -250,8 +250,9 @@ void mdx_k_lowq_bitmap(const uint8_t *qual, int64_t n_bases, int minqual, uint32
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
+// (tile_ctr, if not null and w_total >= 4096: 4096 words zeroed on the way — the next launch's tile counters)
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
-                           int64_t w_total, int grid, hipStream_t s);
+                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr = nullptr);
 void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
                     const unsigned long long *n_lgd_over, MdxDims d, unsigned long long *out,
                     hipStream_t s);

@@ -3036,11 +3036,14 @@ void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t l
 
 // raw[w] += sum over block slots; blocks are split into `parts` groups to expose parallelism
 // (the last word, the number of kept reads, goes to *raw_tail: a launch may hold a group of the libraries only)
+// (tile_ctr: the pools' tile counters of the launch just reduced — 4096 words, fewer than any table — zeroed here for the
+// next launch: one memset node less in front of every launch)
 __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__restrict__ raw, u64 *__restrict__ raw_tail,
-                                       i64 w_total, int grid, int parts) {
+                                       i64 w_total, int grid, int parts, u32 *__restrict__ tile_ctr) {
     const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= w_total) return;
     const int part = blockIdx.y;
+    if (tile_ctr && part == 0 && w < 4096) tile_ctr[w] = 0u;
     const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
     u64 acc = 0;
     for (int b = b0; b < b1; b++) acc += (u64)(i64)(int)partials[(i64)b * w_total + w];   // signed (soft-clip differences)
@@ -3048,13 +3051,13 @@ __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__
 }
 
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
-                           int64_t w_total, int grid, hipStream_t s) {
+                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr) {
     const int threads = 256;
     const int blocks = (int)((w_total + threads - 1) / threads);
     int parts = grid < 32 ? grid : 32;
     if (parts < 1) parts = 1;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts), dim3(threads), 0, s, partials, raw, raw_tail,
-                       (i64)w_total, grid, parts);
+                       (i64)w_total, grid, parts, w_total >= 4096 ? tile_ctr : nullptr);
 }
 
 // raw (reference orientation) -> canonical tables (mapdamage_amd/layout.py):
