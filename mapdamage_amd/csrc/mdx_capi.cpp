@@ -585,7 +585,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
                 // (scratch of the launch: 88 bytes per record a wavefront may be handed — twice its even share —, 180 bytes
                 // per record of the batch, of which the kernel touches a dozen; a batch the device cannot give that to is
                 // one to split, and the caller is told so)
-                const size_t list_bytes = (size_t)nwaves * (size_t)(5 * a.list_cap + a.list_cap / 2 + 2) * 16;
+                const size_t list_bytes = (size_t)nwaves * (size_t)MDX_LIST_STRIDE(a.list_cap) * 16;
                 if (c->lists.reserve(list_bytes) != hipSuccess)
                     return fail(c, MDX_ERR_HIP, "the per-wavefront lists of this launch (" + std::to_string(list_bytes >> 20) + " MiB for " +
                                 std::to_string(b->n_reads) + " records) could not be allocated: tabulate the batch in smaller pieces");

@@ -136,6 +136,7 @@ struct MdxFuse {
                                 // reference-base counts, the lookup table and the terms (mdx_k_fuse_lds_bytes)
 };
 
+#define MDX_LIST_STRIDE(cap) (5 * (cap) + 3 * ((cap) / 4 + 1))
 struct MdxTabArgs {
     // batch (device pointers)
     int64_t n_reads;
@@ -176,8 +177,9 @@ struct MdxTabArgs {
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
-    // Per-wavefront lists (16-byte staging entries): wavefront w owns 5 list_cap + list_cap / 2 + 2 entries (the last
-    // list_cap / 4 + 1: the fused kernel's record indices of the partial list) — partial
+    // Per-wavefront lists (16-byte staging entries): wavefront w owns MDX_LIST_STRIDE(list_cap) entries (the last two
+    // stretches of list_cap / 4 + 1: the fused kernels' record indices of the partial list, and the packed fused kernel's
+    // of the single-indel lists) — partial
     // records upwards from 0, single insertions upwards from list_cap, single deletions downwards from 2 list_cap - 1,
     // the complete records the general pass finds upwards from 2 list_cap, from 3 list_cap on the columns (two entries
     // per record) and from 5 list_cap on the indices (u32) of the records the tile loop leaves to the general pass;

@@ -124,6 +124,10 @@ typedef long long i64;
 #ifndef MDX_PK_PTILE
 #define MDX_PK_PTILE 1                  // the packed kernels count a tile's partial records in the tile loop (0: through the wavefront's list behind it; the fused one always does)
 #endif
+#ifndef MDX_PKF_PTILE
+#define MDX_PKF_PTILE 0                 // ... and the packed fused kernel: no — through its list, rescaled by the list's passes (the run in the
+                                        // tile loop cost the kernel's registers 3 % on config 5, which has no such record)
+#endif
 #ifndef MDX_PKM_PD
 #define MDX_PKM_PD 3                    // ... and with --min-basequal
 #endif
@@ -1718,11 +1722,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     //   [2 cap, 3 cap)  complete records found by the general pass, upwards
     //   [3 cap, 5 cap)  the columns (two entries each) of the records the tile loop leaves to the general pass,
     //   [5 cap, ...)    and their indices (u32)
-    //   [5 cap + cap / 4 + 1, ...)  RS: the record index of every entry of the partial list (u32)
-    uint4 *const lists = a.lists + (i64)gwave * (5 * a.list_cap + a.list_cap / 2 + 2);
+    //   [5 cap + cap / 4 + 1, ...)  RS: the record index of every entry of the partial list (u32),
+    //   [5 cap + 2 (cap / 4 + 1), ...)  RS, PK: of every single-indel entry (by its place in [cap, 2 cap))
+    uint4 *const lists = a.lists + (i64)gwave * MDX_LIST_STRIDE(a.list_cap);
     uint4 *const dcols = lists + 3 * a.list_cap;
     u32 *const dlist = (u32 *)(lists + 5 * a.list_cap);
     u32 *const lri = (u32 *)(lists + 5 * a.list_cap + a.list_cap / 4 + 1);
+    u32 *const lri_g = (u32 *)(lists + 5 * a.list_cap + 2 * (a.list_cap / 4 + 1));
     int lP = 0, lI = 0, lD = 0, lC = 0;
     u32 n_rs = 0;           // RS: records left to the rescale kernels behind this one
 
@@ -2077,7 +2083,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if ((plain && !isF) || (gpre && !isS)) at = lP + mbcnt64(mP, 0);
                 else if (isS) at = isD ? 2 * a.list_cap - 1 - (lD + mbcnt64(mS & ~mSI, 0)) : a.list_cap + lI + mbcnt64(mSI, 0);
                 if (at >= 0) lists[at] = ent;
-                if (RS && PK && isS) lri[at - a.list_cap] = ri;      // (the record of a single-indel entry: where its MR goes)
+                if (RS && PK && isS) lri_g[at - a.list_cap] = ri;      // (the record of a single-indel entry: where its MR goes)
                 lP += nP; lI += nSI; lD += nS - nSI;
             }
         }
@@ -2620,7 +2626,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 }
                 // (PTILE — the packed fused kernel: the partial records of the tile are staged behind its complete ones, by strand,
                 // and counted by a run of their own in the tile loop: their MR words are the tile's)
-                constexpr bool PTILE = PK && (RS || MDX_PK_PTILE);
+                constexpr bool PTILE = PK && (RS ? MDX_PKF_PTILE : MDX_PK_PTILE);
                 int nPt = 0, nPtp = 0;
                 const u64 mPm = PTILE ? __ballot(triv && !isF && rev) : 0ull;
                 if (PTILE && mP) {
@@ -2634,7 +2640,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const int k1 = nq < L ? nq : L;
                         if (!PK && k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
                         lists[lP + mbcnt64(mP, 0)] = ent;
-                        if (RS && !PK) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
+                        if (RS) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
                     }
                     lP += __popcll(mP);
                 }
@@ -2667,7 +2673,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // The run has drained its events and counted the reference bases of the fused records' columns.  What is
                     // left: the qualities of the listed transitions, and the MR sums from the records' words.
                     rsq_flush();
-                    if (rs_fused) p.rs.mr_raw[ri] = mr_of(mrm[isF ? (rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0))
+                    // (a partial record that goes through the wavefront's list: behind the pass of the list that counts it)
+                    if (rs_fused && (isF || PTILE)) p.rs.mr_raw[ri] = mr_of(mrm[isF ? (rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0))
                                                                   : nF + (rev ? nPtp + mbcnt64(mPm, 0) : mbcnt64(mP & ~mPm, 0))]);
                 }
                 if (RS && !PK) {
@@ -2769,12 +2776,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
                 }
-                constexpr bool RSP = RS && !PK && decltype(kind_tag)::value == STEP_P;
+                constexpr bool RSP = RS && decltype(kind_tag)::value == STEP_P;
                 // (PK: the fused single-indel entries — bit 18 —, their records in lri by the entry's place in its list)
                 constexpr bool RSG = RS && PK && (decltype(kind_tag)::value == STEP_GI || decltype(kind_tag)::value == STEP_GD);
                 u32 ri_l = 0;
                 if (RSG) {
-                    ri_l = lri[first + (i64)dir * (e + (lane < m ? lane : 0)) - a.list_cap];
+                    ri_l = lri_g[first + (i64)dir * (e + (lane < m ? lane : 0)) - a.list_cap];
                     mrm[lane] = 0ull;
                     if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
                 }
@@ -2786,9 +2793,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
                 run(0, m, kind_tag, std::true_type{}, n_fwd);
                 if (RSP || RSG) rsq_flush();
-                if (RSG && lane < m && ((ent.w >> 18) & 1u)) a.rs.mr_raw[ri_l] = mr_of(mrm[sidx]);
+                if ((RSG || (RSP && PK)) && lane < m && ((ent.w >> 18) & 1u)) a.rs.mr_raw[ri_l] = mr_of(mrm[sidx]);
                 // RS: the MR sums of the fused records among them (known by their TC table)
-                if (RSP && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
+                if (RSP && !PK && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
             }
         };
         list_runs(2 * a.list_cap, 1, lC, std::integral_constant<int, STEP_C>{});
