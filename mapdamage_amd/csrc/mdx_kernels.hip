@@ -181,6 +181,9 @@ size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4
 #ifndef MDX_FUSE_CPU
 #define MDX_FUSE_CPU 2                  // 16-byte units per lane of the first pass of a tile's quality copy (measured: 2 3.64 ms, 4 3.74, 7 4.18 — the registers)
 #endif
+#ifndef MDX_PKF_CPU
+#define MDX_PKF_CPU 1                   // ... of the packed fused kernel
+#endif
 #ifndef MDX_FUSE_PD
 #define MDX_FUSE_PD 4                   // steps in flight of the complete runs in the fused kernel
 #endif
@@ -2347,7 +2350,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const u32 tbase = cur * T;
                 const u32 r_lo = tbase;
                 const u32 r_hi = tbase + T < n_rec ? tbase + T : n_rec;
-                u32x4 cpv[MDX_FUSE_CPU];
+                // (the packed fused kernel: one unit — its registers are the tighter: config 5 2.79 -> 2.71 ms on one box)
+                constexpr int FCPU = PK ? MDX_PKF_CPU : MDX_FUSE_CPU;
+                u32x4 cpv[FCPU];
                 u32 cp_a0 = 0, cp_nu = 0, cp_b0 = 0, cp_b1 = 0;
                 if (RS) {
                     // qual_out starts as a copy of the quality column: the tile's own stretch (its bounds were requested a
@@ -2365,7 +2370,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #endif
                     const u8 *__restrict__ qin = p.qual;
 #pragma unroll
-                    for (int k = 0; k < MDX_FUSE_CPU; k++) {
+                    for (int k = 0; k < FCPU; k++) {
                         const u32 u = (u32)lane + 64u * k;
                         if (u < cp_nu) cpv[k] = cp_load(qin + (cp_a0 + 16u * u));
                     }
@@ -2392,7 +2397,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     u8 *__restrict__ qout = p.rs.qual_out;
                     u32 hi = 0;
 #pragma unroll
-                    for (int k = 0; k < MDX_FUSE_CPU; k++) {
+                    for (int k = 0; k < FCPU; k++) {
                         const u32 u = (u32)lane + 64u * k;
                         if (u < cp_nu) {
                             cp_store(qout + (cp_a0 + 16u * u), cpv[k]);
@@ -2401,7 +2406,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
 #if MDX_FUSE_CP2
                     // (two units per lane and round trip)
-                    for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 128u) {
+                    for (u32 u = 64u * FCPU + (u32)lane; u < cp_nu; u += 128u) {
                         const u32x4 v = cp_load(qin + (cp_a0 + 16u * u));
                         u32x4 v2 = u32x4{0u, 0u, 0u, 0u};
                         const bool two = u + 64u < cp_nu;
@@ -2411,7 +2416,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         hi |= v.x | v.y | v.z | v.w | v2.x | v2.y | v2.z | v2.w;
                     }
 #else
-                    for (u32 u = 64u * MDX_FUSE_CPU + (u32)lane; u < cp_nu; u += 64u) {
+                    for (u32 u = 64u * FCPU + (u32)lane; u < cp_nu; u += 64u) {
                         const u32x4 v = cp_load(qin + (cp_a0 + 16u * u));
                         cp_store(qout + (cp_a0 + 16u * u), v);
                         hi |= v.x | v.y | v.z | v.w;
