@@ -269,7 +269,8 @@ class DamageEngine:
 
     def upload(self, batch: ReadBatch, packed=None) -> DeviceBatch:
         """Resident copy of a host batch; ``packed``: with the SEQ column in its 4-bit form (``pack_seq``), which the
-        plain tabulation then reads through the packed kernel."""
+        tabulation (plain, with ``--min-basequal`` — the bitmap of the low qualities is built here, ``mdx_batch::lowq`` —
+        or with the rescaling fused in) then reads through the packed kernels."""
         hb = _host_batch(batch, self.default_packed if packed is None else packed)
         dev = MdxBatch()
         self._check(self._lib.mdx_batch_upload(self._ctx, ctypes.byref(hb), ctypes.byref(dev)))

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["ascii", "4bit"])
 def seq_form(request):
     """Every case of this module runs through both forms of the SEQ column (include/mdx.h MDX_SEQ_*): as ASCII, and
-    packed to 4 bits on the host — the packed kernel where the launch is a plain tabulation, an ASCII scratch copy made by
-    the library where it is not (--min-basequal, the generic path)."""
+    packed to 4 bits on the host — the packed kernels where the launch has the fast geometry (with --min-basequal the
+    masked form), an ASCII scratch copy made by the library where it has not (the generic path)."""
     from mapdamage_amd.engine import DamageEngine
     old = DamageEngine.default_packed
     DamageEngine.default_packed = request.param == "4bit"
