@@ -51,7 +51,7 @@ def main():
               and np.array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
               and np.array_equal(words[:756], summary_ints_from_oracle(want_counts)))
         # the same batch through the fused launch (mdx_tabulate_rescale_device) at a random --length: tables too
-        length = int(rng.integers(8, 90))
+        length = int(rng.integers(8, 125))
         libs = [("s", "l")]
         try:
             want_tables = oracle_tableset(ref, b, libs, length, 10, 0)
