@@ -106,6 +106,9 @@ typedef long long i64;
 #ifndef MDX_ENT_AHEAD
 #define MDX_ENT_AHEAD 0                 // staging entries read one fill ahead
 #endif
+#ifndef MDX_PK_ENT_AHEAD
+#define MDX_PK_ENT_AHEAD 0              // ... in the packed kernels (measured: +-1 % on every workload — the other wavefronts cover that wait)
+#endif
 #ifndef MDX_PD_G
 #define MDX_PD_G 2                      // steps in flight of the single-indel runs
 #endif
@@ -1273,19 +1276,33 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (one <3 x i32> load per operand: a struct of three words is taken apart and put together again as the
                 // vectorizer likes — two overlapping dwordx2 loads at times)
                 struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; u32x2 lq; int k; bool valid; };
-                auto fill16 = [&](St16 &st) {
-                    st.valid = kf < nsteps4;
-                    const int k = st.valid ? kf : nsteps4 - 1;
-                    kf++;
-                    // (the slot holds a record iff H k + slot < the entries of its strand)
-                    bool act = true;
+                // (MDX_PK_ENT_AHEAD: the staging entry of a step is read from the LDS one fill ahead — LDS operations return in
+                // order, so a fill that reads its own entry waits, in front of its window loads, for that read and for the
+                // event writes of the step just counted)
+                auto ent_index = [&](const int kk, bool &act) -> int {
+                    const int k = kk < nsteps4 ? kk : nsteps4 - 1;
+                    act = true;
                     int idx = base_l + H * k;
                     if (k >= nfull) {               // (wave-uniform: the last steps of a run only)
                         act = H * k < lim_l;
                         idx = act ? idx : e0;
                     }
+                    return idx;
+                };
+                uint4 ent_next = make_uint4(0u, 0u, 0u, 0u);
+                auto fill16 = [&](St16 &st) {
+                    st.valid = kf < nsteps4;
+                    const int k = st.valid ? kf : nsteps4 - 1;
+                    // (the slot holds a record iff H k + slot < the entries of its strand)
+                    bool act = true;
+                    const int idx = ent_index(kf, act);
+                    kf++;
                     st.k = k;
+#if MDX_PK_ENT_AHEAD
+                    const uint4 ent = ent_next;
+#else
                     const uint4 ent = stg[idx];
+#endif
                     const u32 t = ent.z & c_cm;
                     u32 ro = ent.x + c_ro + t;
                     u32 so = ro + ent.y;
@@ -1353,6 +1370,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // (--min-basequal: the sixteen bits of the lane's bases in the batch's bitmap of low qualities, see count16)
                     if (MASK) st.lq = *(const u32x2_a4 *)(a.lowq + (((so - ph_seq) >> 5) << 2));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
+#if MDX_PK_ENT_AHEAD
+                    { bool a_; ent_next = stg[ent_index(kf, a_)]; }
+#endif
                 };
                 // one step: X = the nibbles this step counts (one-hot codes: the increments themselves).  A step whose events do
                 // not fit the queue does nothing and reports itself (ovf, kredo): the run stops behind the group, drains and
@@ -1450,7 +1470,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // the lanes holding a read column that is not a plain match queue their four dwords (see qQ)
                     const u32 x_lo = (s_lo ^ r_lo) & c_em_lo, x_hi = (s_hi ^ r_hi) & c_em_hi;
                     const bool ev = (x_lo | x_hi) != 0u;
-#ifdef MDX_ABL_NOEVQ
+#ifdef MDX_ABL_NOEVQ        // (instruction counts only: with no event the SEQ windows of a complete step are dead and their loads go
+                           // too — a third of the kernel's time, which is not the queue's)
                     const u64 mm = 0ull;
 #else
                     const u64 mm = __ballot(ev);
@@ -1564,6 +1585,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 for (int kstart = 0;;) {
                     kf = kstart;
                     ovf = false;
+#if MDX_PK_ENT_AHEAD
+                    { bool a_; ent_next = stg[ent_index(kf, a_)]; }
+#endif
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) fill16(st[dd]);
                     int k = kstart + PD4;
