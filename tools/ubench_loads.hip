@@ -43,6 +43,23 @@ __global__ __launch_bounds__(768) void k(const uint8_t *buf, u32 mask, int iters
                 // tabulation-like SEQ gather: the same windows over consecutive 100-byte records
                 const int seg = lane / 10, l = lane - seg * 10, rec = seg >> 1, side = seg & 1;
                 off = ((h >> 4) & mask & ~1023u) + misalign + rec * 100 + side * 40 + l * W;
+            } else if (pattern == 5 || pattern == 6) {
+                // the packed kernel's step: six records x two windows of five lanes (sixteen 4-bit bases = 8 bytes per lane,
+                // read as 12), the right window 15 bytes behind the left (100-base reads, --length 70 --around 10);
+                // 5 = reference-like (records at random bases), 6 = SEQ-like (consecutive 50-byte records)
+                const int seg = lane / 5, l = lane - seg * 5, rec = seg >> 1, side = seg & 1;
+                if (seg >= 12) { off = 0; }
+                else if (pattern == 5) {
+                    u32 hs = (h ^ (rec * 0x9E3779B9u)) * 2246822519u;
+                    off = ((hs >> 4) & mask & ~63u) + ((hs & 63u) & ~3u) + side * 12 + l * 8;
+                } else off = ((h >> 4) & mask & ~1023u) + rec * 52 + side * 12 + l * 8;
+            } else if (pattern == 7 || pattern == 8) {
+                // the union of a record's two windows as one stretch of four lanes x 16 bytes, sixteen records per load
+                const int rec = lane >> 2, l = lane & 3;
+                if (pattern == 7) {
+                    u32 hs = (h ^ (rec * 0x9E3779B9u)) * 2246822519u;
+                    off = ((hs >> 4) & mask & ~63u) + ((hs & 63u) & ~3u) + l * 16;
+                } else off = ((h >> 4) & mask & ~1023u) + rec * 52 + l * 16;
             } else if (pattern == 4) {
                 // union windows: one contiguous run of `seglanes` lanes per record at a random base
                 const int seg = lane / seglanes, l = lane - seg * seglanes;
@@ -159,6 +176,10 @@ int main(int argc, char **argv) {
         printf("4 16 %d 16 %.2f\n", mis, run<u32x4_u>(buf, mask, mis, 4, 16, out));
         printf("4 4 %d 32 %.2f\n", mis, run<u32_u>(buf, mask, mis, 4, 32, out));
     }
+    printf("# the packed kernel's step (6 records x 2 windows x 5 lanes, 12-byte loads): reference-like %.2f  SEQ-like %.2f ns per wave-load and CU (6 records each)\n",
+           run<u32x3_a>(buf, mask, 0, 5, 5, out), run<u32x3_a>(buf, mask, 0, 6, 5, out));
+    printf("# union windows (16 records x 4 lanes x 16 bytes): reference-like %.2f  SEQ-like %.2f ns per wave-load and CU (16 records each)\n",
+           run<u32x4_u>(buf, mask, 0, 7, 4, out), run<u32x4_u>(buf, mask, 0, 8, 4, out));
     printf("# alignment sweep, 8 bytes per lane: pattern 2 (ref-like) and 3 (seq-like) at byte phase 0..4\n");
     for (int mis = 0; mis <= 4; mis++)
         printf("phase %d: seq-like %.2f\n", mis, run<u32x2_u>(buf, mask, mis, 3, 10, out));
