@@ -41,6 +41,27 @@ def test_abi_version_and_strerror(lib):
     assert b"contig" in lib.mdx_strerror(-6)
 
 
+def test_ctypes_mirrors_match_the_header(tmp_path):
+    """The ctypes structures of mapdamage_amd/engine.py against what a C compiler makes of include/mdx.h: sizes, and the
+    offsets of the fields behind the columns (the library writes a whole mdx_batch into the binder's memory)."""
+    import shutil
+    import subprocess
+
+    from mapdamage_amd.engine import MdxBatch, MdxConfig
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler")
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mdx.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mdx_config), sizeof(mdx_batch), offsetof(mdx_batch, qual), '
+                   'offsetof(mdx_batch, seq_format), offsetof(mdx_batch, reserved), offsetof(mdx_batch, lowq)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call([cc, "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(MdxConfig), ctypes.sizeof(MdxBatch), MdxBatch.qual.offset, MdxBatch.seq_format.offset,
+                   MdxBatch.reserved.offset, MdxBatch.lowq.offset]
+
+
 def test_create_rejects_bad_config(lib):
     from mapdamage_amd.engine import MdxConfig
     ctx = ctypes.c_void_p()
