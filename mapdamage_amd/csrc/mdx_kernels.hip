@@ -1289,7 +1289,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                     return idx;
                 };
+#if MDX_PK_ENT_AHEAD
                 uint4 ent_next = make_uint4(0u, 0u, 0u, 0u);
+#endif
                 auto fill16 = [&](St16 &st) {
                     st.valid = kf < nsteps4;
                     const int k = st.valid ? kf : nsteps4 - 1;
