@@ -725,9 +725,11 @@ int mdx_bam_open(const char *path, int threads, mdx_bam_stream **out) {
         s->file = new (std::nothrow) MappedFile();
         if (!s->file || !s->file->open(path, s->head.error)) return MDX_ERR_ARG;
         if (s->file->size() == 0) s->eof = true;
-        // the header may span several blocks: inflate until it parses
-        for (;;) {
-            if (!stream_fill(s, (size_t)1 << 20)) return MDX_ERR_ARG;
+        // the header may span several blocks: inflate until it parses (one block's worth first — the header of most files
+        // — then a megabyte at a time: the device decode path opens the file for its header alone, and a megabyte of blocks
+        // inflated for nothing was 2 of its 2.5 ms)
+        for (size_t want = 65536;; want = (size_t)1 << 20) {
+            if (!stream_fill(s, want)) return MDX_ERR_ARG;
             size_t first = 0;
             const int rc = parse_header(&s->head, s->pending.data(), s->pending.size(), !s->eof, &first);
             if (rc < 0) return MDX_ERR_ARG;
