@@ -964,6 +964,23 @@ void pf_buffer_give(int device, void *p, size_t cap) {
     if (g_pfbufs.size() < 4) g_pfbufs.push_back(RgBuf{device, p, cap});
     else (void)hipFree(p);
 }
+// ... and the 64 pinned bytes a handle's CRC verdict lands in
+std::vector<int *> g_pins;
+int *pin_take() {
+    {
+        std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+        if (!g_pins.empty()) { int *p = g_pins.back(); g_pins.pop_back(); return p; }
+    }
+    int *p = nullptr;
+    if (hipHostMalloc((void **)&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pin_give(int *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+    if (g_pins.size() < 16) g_pins.push_back(p);
+    else (void)hipHostFree(p);
+}
 void rg_buffer_give(int device, void *p, size_t cap) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_rgbuf_mu);
@@ -1018,6 +1035,10 @@ struct mdx_gbam {
     size_t hbuf_cap = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_infl = nullptr, ev_infl0 = nullptr;
+    // the CRC of the device-inflated blocks runs on the copy stream, under the scan, the chain walk and the unpack of the same
+    // slab: ev_crc = the inflate is done; pin_bad = where its verdict lands (pinned: an asynchronous copy)
+    hipEvent_t ev_crc = nullptr;
+    int *pin_bad = nullptr;
     std::string error;
     bool want_qual = false, want_mate = false;
     int minqual = 0;                     // --min-basequal on the device path (mdx_gbam_set_min_basequal)
@@ -1426,6 +1447,21 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             }
         }
         lap("inflate");
+        // (the CRC beside what follows, on the copy stream; its verdict is looked at before the slab is handed out.
+        // MDX_BAM_TIMING: in line, so that its lap is its own)
+        bool crc_aside = !timing;
+        if (crc_aside) {
+            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) return MDX_ERR_HIP;
+            if (!g->ev_crc && hipEventCreateWithFlags(&g->ev_crc, hipEventDisableTiming) != hipSuccess) return MDX_ERR_HIP;
+            if (!g->pin_bad) g->pin_bad = pin_take();
+            if (!g->pin_bad) crc_aside = false;
+        }
+        if (crc_aside) {
+            *g->pin_bad = no_bad;
+            if (hipEventRecord(g->ev_crc, st) != hipSuccess || hipStreamWaitEvent(g->copy_stream, g->ev_crc, 0) != hipSuccess) return MDX_ERR_HIP;
+            mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nh, d_bad_crc, g->copy_stream);
+            if (hipMemcpyAsync(g->pin_bad, d_bad_crc, 4, hipMemcpyDeviceToHost, g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+        } else
         mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nh, d_bad_crc, st);
         lap("crc32");
         // the chains of the segments (every block inflated is one: those ahead of the slab say whether the next slab's
@@ -1439,7 +1475,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         int bad_crc = no_bad;
         if (hipMemcpyAsync(info.data(), g->info.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(cnt.data(), g->cnt.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&bad_crc, d_bad_crc, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            (!crc_aside && hipMemcpyAsync(&bad_crc, d_bad_crc, 4, hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess) {
             g->error = std::string("GPU decode failed: ") + hipGetErrorString(hipGetLastError());
             return MDX_ERR_HIP;
         }
@@ -1451,6 +1487,13 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
                 return MDX_ERR_ARG;
             }
         if (bad_crc != no_bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
+        // (crc_aside: the same check behind the unpack's launch, below)
+        auto crc_verdict = [&]() -> bool {
+            if (!crc_aside) return true;
+            if (hipStreamSynchronize(g->copy_stream) != hipSuccess) { g->error = "GPU decode failed (CRC32 pass)"; return false; }
+            if (*g->pin_bad != no_bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)*g->pin_bad) + " (CRC32)"; return false; }
+            return true;
+        };
         // The walk: `at` = where the next record starts, known exactly; the segment that holds it must have begun its chain
         // there — if its guess was another offset it is scanned again from the right one — and says where the chain lands.
         const size_t slab_end = slab_bytes;
@@ -1496,6 +1539,8 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             at = land;
         }
         if (grow) {
+            // (the CRC pass of this attempt reads the bytes the next one writes)
+            if (crc_aside && hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
             if (ahead >= ((size_t)1 << 30)) { g->error = "a BAM record of more than a gigabyte"; return MDX_ERR_UNSUPPORTED; }
             ahead *= 8;
             continue;
@@ -1537,6 +1582,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
                           (uint32_t)tot[0], (uint32_t)tot[1], (uint32_t)tot[2], (uint32_t *)g->rec_off.p, c, st);
         if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
+        if (!crc_verdict()) return g->error.find("corrupt") != std::string::npos ? MDX_ERR_ARG : MDX_ERR_HIP;
         lap("unpack");
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
         view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
@@ -1693,6 +1739,8 @@ void mdx_gbam_close(mdx_gbam *g) {
     // context must still be alive — it owns the stream this handle works on)
     host_buffer_give(g->hbuf, g->hbuf_cap);
     if (g->ev_infl0) (void)hipEventDestroy(g->ev_infl0);
+    if (g->ev_crc) (void)hipEventDestroy(g->ev_crc);
+    pin_give(g->pin_bad);
     mdx_ctx_scratch_give(g->ctx, g->arena.p, g->arena.cap, g->d_crc_tables, g->copy_stream, g->ev_infl);
     rg_buffer_give(g->device, g->d_rg, g->d_rg_cap);
     if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
