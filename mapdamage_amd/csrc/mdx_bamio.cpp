@@ -1552,7 +1552,13 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             size_t sg = nb;
             while (sg < nba && (size_t)blk[4 * sg + 2] + blk[4 * sg + 3] <= at) sg++;
             if (b1 >= g->blocks.size() && g->whole_file_scanned()) g->next_verified = true;      // nothing follows
-            else g->next_verified = sg < nba && info[4 * sg + 2] != 1u && info[4 * sg] == (uint32_t)at;
+            else {
+                // (the rank behind takes the first segment of its slab that has any guess: a segment in front of the right one —
+                // inside a record that straddles whole blocks — must not have produced one)
+                bool clean = true;
+                for (size_t i = nb; i < sg && i < nba; i++) clean = clean && info[4 * i + 2] == 1u;
+                g->next_verified = clean && sg < nba && info[4 * sg + 2] != 1u && info[4 * sg] == (uint32_t)at;
+            }
         }
         // prefix sums over the segments that hold the chain
         std::vector<uint32_t> pre(4 * nb);
@@ -1741,9 +1747,11 @@ void mdx_gbam_close(mdx_gbam *g) {
     if (g->ev_infl0) (void)hipEventDestroy(g->ev_infl0);
     if (g->ev_crc) (void)hipEventDestroy(g->ev_crc);
     pin_give(g->pin_bad);
-    mdx_ctx_scratch_give(g->ctx, g->arena.p, g->arena.cap, g->d_crc_tables, g->copy_stream, g->ev_infl);
-    rg_buffer_give(g->device, g->d_rg, g->d_rg_cap);
+    // (drained before it is given away: a context that already holds a copy stream — two handles on one context — destroys this one)
     if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    mdx_ctx_scratch_give(g->ctx, g->arena.p, g->arena.cap, g->d_crc_tables, g->copy_stream, g->ev_infl);
+    g->copy_stream = nullptr;
+    rg_buffer_give(g->device, g->d_rg, g->d_rg_cap);
     for (int k = 0; k < 2; k++) pf_buffer_give(g->device, g->pf_buf[k], g->pf_cap[k]);
     lap("device");
     // (unmapping the file — a few hundred thousand touched pages — is 3-4 ms of an 8 M-record file's 63; done behind the

@@ -154,11 +154,15 @@ def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
-def pack_seq(seq, threads=0):
+def pack_seq(seq, threads=None):
     """ASCII SEQ bytes -> the 4-bit column of ``MDX_SEQ_4BIT`` (include/mdx.h): two bases per byte, low nibble first,
     1 = A, 2 = C, 4 = T, 8 = G, 0 = anything else — all the reference's loop distinguishes (statistics.py:27, 101)."""
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     out = np.empty((seq.shape[0] + 1) // 2, np.uint8)
+    if threads is None:
+        # (the control group's quota, not the hardware's thread count: mdx_pack_seq with 0 would start one thread per hardware thread)
+        from .sam import usable_cpus
+        threads = min(64, usable_cpus())
     rc = load_library().mdx_pack_seq(_ptr(seq), ctypes.c_int64(seq.shape[0]), _ptr(out), ctypes.c_int32(threads))
     if rc != 0:
         raise MdxError(rc, "mdx_pack_seq")
@@ -239,6 +243,10 @@ class DamageEngine:
 
     def close(self):
         if self._ctx:
+            # (a device decode stream hands its arena back to the context when it closes — mdx_gbam_close — so the streams
+            # opened on this engine are closed before the context goes)
+            for stream in list(getattr(self, "_streams", ())):
+                stream.close()
             self._lib.mdx_destroy(self._ctx)
             self._ctx = None
 

@@ -352,7 +352,9 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
                         if ranks.world == 1:
                             engine.sync()
                             where = stream.tell()
-                            if where is not None and slab > 1:
+                            # (resuming needs the chunked host decoder, reader.iter_batches(resume=...): with --chunk-mb 0
+                            # the host path reads the file in one piece, so the whole file is counted again)
+                            if where is not None and slab > 1 and reader._chunks is not None:
                                 carry = (engine, where, n_reads)
                         raise
                     if view is None:
@@ -370,8 +372,9 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
                     raise
                 error = exc         # (the ranks agree on it in finish(): all of them take the host path then)
             tables = ranks.finish(engine, error)
-            engine.close()
-            return tables, None
+        # (the stream is closed first: mdx_gbam_close hands its arena back to the context, which must still be alive)
+        engine.close()
+        return tables, None
     except GpuDecodeUnsupported as error:
         reason = "file layout the device path does not take (MDX_ERR_UNSUPPORTED): %s" % error
     except BadReadError as error:
@@ -405,6 +408,15 @@ def main(argv):
     except SystemExit as error:
         return int(error.code or 0) and 1
     import os
+    if options.rescale_only:
+        # the rescaling pass rewrites one BAM file in file order (rescale.py:285-365): one process, one GPU — under a launcher
+        # that started several ranks the others leave at once instead of waiting in a process group for rank 0's whole pass
+        if int(os.environ.get("RANK", "0")) != 0:
+            return 0
+        options.gpus = 1
+        if os.environ.get("WORLD_SIZE", "1") != "1":
+            for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+                os.environ.pop(key, None)
     if options.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one process per GPU: the run re-executes itself under torchrun (or is launched that way to begin with)
         import subprocess

@@ -396,7 +396,14 @@ class GpuBamStream:
         self._engine = engine
         self._g = ctypes.c_void_p()
         self.path, self.chunk_bytes = path, int(chunk_bytes)
+        if not engine._ctx:
+            raise ValueError("the engine is closed")
         rc = self._lib.mdx_gbam_open(engine._ctx, str(path).encode(), ctypes.byref(self._g))
+        # (the engine closes the streams still open on it before it destroys its context: DamageEngine.close)
+        if not hasattr(engine, "_streams"):
+            import weakref
+            engine._streams = weakref.WeakSet()
+        engine._streams.add(self)
         if rc != 0:
             message = self._error()
             self.close()
@@ -473,8 +480,13 @@ class GpuBamStream:
 
     def close(self):
         if self._g:
+            # (mdx_gbam_close gives the arena back to the context: never reached with the context gone — the engine closes
+            # its streams first)
             self._lib.mdx_gbam_close(self._g)
             self._g = None
+            streams = getattr(self._engine, "_streams", None)
+            if streams is not None:
+                streams.discard(self)
 
     def __enter__(self):
         return self
@@ -483,7 +495,10 @@ class GpuBamStream:
         self.close()
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GpuDecodeUnsupported(ValueError):
