@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 4   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer) */
+#define MDX_ABI_VERSION 5   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -107,6 +107,12 @@ typedef struct {
      * of every launch (one pass over the quality column).  mdx_batch_upload fills it in when the context has a
      * --min-basequal, mdx_batch_free releases it. */
     const uint8_t *lowq;
+    /* Optional, device batches only, used when the context has several libraries and the seq column is 4-bit: the
+     * per-record columns bucketed by library (reader.py:47-50, statistics.py:12-20 — the tables are keyed by library, a file
+     * interleaves them): an opaque device blob.  The packed kernel then counts all libraries in ONE launch, one after the
+     * other, each over its own records.  NULL: the library sorts in front of every launch (mdx_libsorts counts those).
+     * mdx_batch_upload fills it in, mdx_batch_free releases it; a caller that builds mdx_batch itself leaves it NULL. */
+    const uint8_t *libsort;
 } mdx_batch;
 
 /* ASCII SEQ bytes -> the MDX_SEQ_4BIT column (host buffers; `packed` holds (n_bases + 1) / 2 bytes; `threads` host
@@ -143,7 +149,8 @@ int mdx_batch_free(mdx_ctx *ctx, mdx_batch *dev);
  * updates (statistics.py:22-51,75-93,117-126).  Accumulates; may be called repeatedly.
  * _host: columns in (pageable) host memory, copied through two pinned bounce buffers of the context, the call
  * returns when the last column has left the caller's buffers; _device: columns already in HBM.
- * More libraries than fit the LDS at once: one kernel launch per group of libraries, transparently. */
+ * Several libraries: a 4-bit seq column is counted by one launch over the records bucketed by library (mdx_batch::libsort);
+ * an ASCII one by one launch per group of libraries that fits the LDS, each over all records.  Transparently. */
 int mdx_tabulate_host(mdx_ctx *ctx, const mdx_batch *batch);
 int mdx_tabulate_device(mdx_ctx *ctx, const mdx_batch *batch);
 
@@ -253,8 +260,11 @@ int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const 
 int mdx_rescale_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
 /* Calls of mdx_tabulate_rescale_device so far that ran as the fused launch (the others: two kernels). */
 int64_t mdx_fused_launches(const mdx_ctx *ctx);
-/* Kernel launches so far that ran as the packed kernel (a MDX_SEQ_4BIT batch in a plain tabulation; one per library). */
+/* Kernel launches so far that ran as the packed kernel (a MDX_SEQ_4BIT batch in a plain tabulation or with --min-basequal:
+ * one per call whatever the number of libraries — up to some twenty libraries per launch). */
 int64_t mdx_packed_launches(const mdx_ctx *ctx);
+/* Calls so far that bucketed their batch by library themselves (several libraries, a batch without mdx_batch::libsort). */
+int64_t mdx_libsorts(const mdx_ctx *ctx);
 /* The integer content of the `subs` dictionary that _rescale_qual_read fills through _record_subs
  * (rescale.py:82-143) and _print_subs logs (:159-192), accumulated over every mdx_rescale_host call
  * since mdx_rescale_set_model.  words (uint64), npos = 1 + len5p + len3p:

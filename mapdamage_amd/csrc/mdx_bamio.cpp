@@ -693,7 +693,7 @@ int mdx_bam_batch(const mdx_bam *b, mdx_batch *view, const int32_t **mtid, const
     view->flag = b->flag.data(); view->lib = b->lib.data(); view->tid = b->tid.data(); view->pos = b->pos.data();
     view->tlen = b->tlen.data(); view->cigar_off = b->cigar_off.data(); view->cigar = b->cigar.data();
     view->seq_off = b->seq_off.data(); view->seq = b->seq.data(); view->qual = b->qual.data();
-    view->seq_format = MDX_SEQ_ASCII; view->reserved = 0; view->lowq = nullptr;
+    view->seq_format = MDX_SEQ_ASCII; view->reserved = 0; view->lowq = nullptr; view->libsort = nullptr;
     if (mtid) *mtid = b->mtid.data();
     if (mpos) *mpos = b->mpos.data();
     if (rg_index) *rg_index = b->rg_index.data();
@@ -1593,7 +1593,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
         view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
         view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
-        view->seq_format = g->seq_format; view->reserved = 0; view->lowq = nullptr;
+        view->seq_format = g->seq_format; view->reserved = 0; view->lowq = nullptr; view->libsort = nullptr;
         if (c.minqual > 0) {
             uint32_t counters[2] = {0, 0};
             if (hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;

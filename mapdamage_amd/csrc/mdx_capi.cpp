@@ -134,6 +134,10 @@ struct mdx_ctx {
     bool tile_ctr_clean = false;   // d_tile_ctr is all zero (the reduction behind a launch leaves it so)
     bool pkm_prepared = false;     // the packed kernel's masked form
     DevBuf lowq;           // --min-basequal, packed kernel: the bitmap of the batch's qualities below the threshold
+    DevBuf libsort;        // several libraries, packed kernel: the batch's columns bucketed by library (a batch that does not bring them)
+    DevBuf libsort_scratch;
+    DevBuf ml_partials;    // ... and the blocks' slots of an epoch launch, [library][block]
+    int64_t n_libsorts = 0;        // sorts done inside a launch so far (a resident batch brings its own: mdx_batch::libsort)
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
     int64_t n_packed = 0;          // launches of the packed kernel so far (mdx_packed_launches)
     int64_t fuse_list_cap = 0;     // entries per list of rs_in (the last fused launch)
@@ -312,6 +316,9 @@ void mdx_destroy(mdx_ctx *c) {
     c->lists.release();
     c->unpacked.release();
     c->lowq.release();
+    c->libsort.release();
+    c->libsort_scratch.release();
+    c->ml_partials.release();
     c->rs_part.release();
     c->rs_lists.release();
     c->rs_in.release();
@@ -401,6 +408,19 @@ static int ascii_view(mdx_ctx *c, const mdx_batch *b, mdx_batch *out) {
     return MDX_OK;
 }
 
+// A device batch with a 4-bit SEQ column, ordered by library, into `blob` (mdx_k_libsort_bytes; enqueued on the stream);
+// lowq: the batch's bitmap of low qualities (--min-basequal), reordered with it, or null
+static bool libsort_with_lowq(const mdx_ctx *c, const mdx_batch *b) { return c->cfg.minqual > 0 && b->qual != nullptr; }
+static int build_libsort(mdx_ctx *c, const mdx_batch *b, const uint8_t *lowq, void *blob) {
+    MdxLibSort ls;
+    mdx_k_libsort_layout(blob, b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, lowq ? 1 : 0, &ls);
+    HIP_TRY(c, c->libsort_scratch.reserve(mdx_k_libsort_scratch_bytes(b->n_reads, c->cfg.nlib)));
+    mdx_k_libsort(b->n_reads, b->n_cigar, b->n_bases, b->flag, b->lib, b->tid, b->pos, b->tlen, b->cigar_off, b->cigar, b->seq_off, b->seq,
+                  lowq, c->cfg.nlib, c->libsort_scratch.p, ls, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return MDX_OK;
+}
+
 int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
     int rc = check_batch(c, h);
     if (rc != MDX_OK) return rc;
@@ -442,6 +462,18 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
         mdx_k_lowq_bitmap(dv->qual, h->n_bases, c->cfg.minqual, (uint32_t *)p, n_words, c->stream);
         HIP_TRY(c, hipGetLastError());
     }
+    // several libraries and a 4-bit SEQ column: the batch ordered by library travels with the resident batch
+    // (mdx_batch::libsort) instead of being sorted in front of every launch
+    // (MDX_NO_BATCH_LIBSORT=1 in the environment: not, for A/B runs)
+    static const bool no_batch_sort = [] { const char *e = getenv("MDX_NO_BATCH_LIBSORT"); return e && *e && *e != '0'; }();
+    if (c->cfg.nlib > 1 && h->seq_format == MDX_SEQ_4BIT && n > 0 && c->mode == MDX_MODE_LDS && !no_batch_sort) {
+        void *p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, mdx_k_libsort_bytes(n, h->n_cigar, h->n_bases, c->cfg.nlib, dv->lowq ? 1 : 0)));
+        dv->libsort = (const uint8_t *)p;
+        // (a record with a library the context does not know has no place: the blob remembers the first, the launches report it)
+        rc = build_libsort(c, dv, dv->lowq, p);
+        if (rc != MDX_OK) return rc;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MDX_OK;
 }
@@ -450,7 +482,7 @@ int mdx_batch_free(mdx_ctx *c, mdx_batch *dv) {
     if (!c || !dv) return MDX_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const void *ptrs[] = {dv->flag, dv->lib, dv->tid, dv->pos, dv->tlen, dv->cigar_off,
-                          dv->cigar, dv->seq_off, dv->seq, dv->qual, dv->lowq};
+                          dv->cigar, dv->seq_off, dv->seq, dv->qual, dv->lowq, dv->libsort};
     for (const void *p : ptrs) if (p) (void)hipFree(const_cast<void *>(p));
     std::memset(dv, 0, sizeof(*dv));
     return MDX_OK;
@@ -479,6 +511,11 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 &&
                         (fuse ? c->cfg.nlib == 1 : !(want_mask && no_pkm)) && !no_packed;
     const bool pmask = packed && !fuse && want_mask;
+    // Several libraries through the packed kernel: ONE launch that counts the libraries one after the other (an epoch each)
+    // over the columns bucketed by library — the batch's own (mdx_batch::libsort, a resident batch) or sorted here, inside the
+    // launch's timed region.  (MDX_NO_ML=1 in the environment: one launch per library, each over all records, for A/B runs)
+    static const bool no_ml = [] { const char *e = getenv("MDX_NO_ML"); return e && *e && *e != '0'; }();
+    const bool ml = packed && !fuse && c->cfg.nlib > 1 && !no_ml;
     mdx_batch b_ascii;
     const mdx_batch *b = b_in;
     if (!packed) {
@@ -522,14 +559,24 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     // LDS mode: one launch per group of libraries (usually a single one); every launch scans all records and
     // counts those of its group
     // (the packed kernel: one library per launch — its bit-sliced counters are one table's)
-    const int group = packed ? 1 : (c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib);
+    int group = packed ? 1 : (c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib);
+    const MdxDims dims1 = mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds);
+    if (ml) {
+        // (as many epochs per launch as half a gigabyte of block slots holds — [library][block], one library's image each —
+        // and as there are tile counters for; a launch touches the records of its own libraries only)
+        const int64_t slot_bytes = (int64_t)c->n_cu * mdx_k_pk_blocks_per_cu() * dims1.w_total * 4;
+        int64_t g = ((int64_t)512 << 20) / slot_bytes;
+        if (g > 65536 / c->n_cu) g = 65536 / c->n_cu;
+        group = (int)(g < 1 ? 1 : (g > c->cfg.nlib ? c->cfg.nlib : g));
+    }
     for (int lo = 0; lo < c->cfg.nlib; lo += group) {
         const int gn = c->cfg.nlib - lo < group ? c->cfg.nlib - lo : group;
         a.lib_lo = lo;
+        a.n_epochs = ml ? gn : 0;
         size_t lds = 0;
         int max_grid = c->max_grid;
         if (c->mode == MDX_MODE_LDS) {
-            a.dims = gn == c->cfg.nlib ? c->dims : mdx_make_dims(c->cfg.length, c->cfg.around, gn, c->cfg.lgd_max, c->dims.lgd_lds);
+            a.dims = ml ? dims1 : (gn == c->cfg.nlib ? c->dims : mdx_make_dims(c->cfg.length, c->cfg.around, gn, c->cfg.lgd_max, c->dims.lgd_lds));
             a.raw = c->d_raw + (size_t)lo * c->dims.w_lib;
             a.lgd_dense = c->d_lgd_dense + (size_t)lo * 4 * c->cfg.lgd_max;
             lds = packed ? mdx_k_pk_lds_bytes(a.dims) : mdx_k_lds_bytes(a.dims);
@@ -578,8 +625,11 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             const int64_t pool_tiles = ((n_tiles + n_pools * chunk - 1) / (n_pools * chunk)) * chunk, pool_waves = (grid / n_pools) * wpb_l;
             a.tile_quota = (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2);
             a.list_cap = (int64_t)a.tile_quota * T + 128;
-            if (!c->d_tile_ctr) HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)4096 * 4));
-            if (n_pools > 4096) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
+            if (!c->d_tile_ctr) {
+                HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)65536 * 4));
+                HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)65536 * 4, c->stream));
+            }
+            if (n_pools > 4096 || n_pools * (ml ? gn : 1) > 65536) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
             a.tile_ctr = c->d_tile_ctr;
             {
                 // (scratch of the launch: 88 bytes per record a wavefront may be handed — twice its even share —, 180 bytes
@@ -598,28 +648,51 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             HIP_TRY(c, hipEventCreate(&e1));
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         }
-        if (pmask && b->lowq && ((uintptr_t)b->lowq & 3) == 0) {
-            // (the batch brings its bitmap)
-            if (!c->pkm_prepared) {
-                HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds))));
-                c->pkm_prepared = true;
-            }
-            a.lowq = b->lowq;
-        } else if (pmask && lo == 0) {
+        // (an epoch launch with --min-basequal reads the bitmap in the batch's new order: the batch's own bitmap — or the one
+        // built below — is reordered with the batch)
+        const bool batch_lowq = pmask && b->lowq && ((uintptr_t)b->lowq & 3) == 0;
+        if (pmask && !batch_lowq && lo == 0) {
             // the bitmap of the qualities below the threshold (one pass over the quality column, inside the timed region;
             // two guard words behind it)
             const int64_t n_words = (b->n_bases + 31) / 32;
             HIP_TRY(c, c->lowq.reserve((size_t)(n_words + 2) * 4 + 64));
             HIP_TRY(c, hipMemsetAsync((char *)c->lowq.p + (size_t)n_words * 4, 0, 8, c->stream));
             mdx_k_lowq_bitmap(b->qual, b->n_bases, c->cfg.minqual, (uint32_t *)c->lowq.p, n_words, c->stream);
-            if (!c->pkm_prepared) {
-                HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds))));
-                c->pkm_prepared = true;
-            }
         }
-        if (pmask && !a.lowq) a.lowq = (const uint8_t *)c->lowq.p;
+        if (pmask && !c->pkm_prepared) {
+            HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(dims1)));
+            c->pkm_prepared = true;
+        }
+        if (pmask) a.lowq = batch_lowq ? b->lowq : (const uint8_t *)c->lowq.p;
+        if (ml) {
+            // the batch ordered by library: its own copy (a resident batch's), or sorted now (once for all launches of the call)
+            const void *blob = b->libsort;
+            const bool with_lowq = pmask;
+            if (!blob) {
+                if (lo == 0) {
+                    HIP_TRY(c, c->libsort.reserve(mdx_k_libsort_bytes(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, with_lowq ? 1 : 0)));
+                    rc = build_libsort(c, b, with_lowq ? a.lowq : nullptr, c->libsort.p);
+                    if (rc != MDX_OK) return rc;
+                    c->n_libsorts++;
+                }
+                blob = c->libsort.p;
+            }
+            MdxLibSort ls;
+            // (a resident batch's copy holds the bitmap iff the batch has one: mdx_batch_upload)
+            mdx_k_libsort_layout(const_cast<void *>(blob), b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib,
+                                 b->libsort ? (b->lowq ? 1 : 0) : (with_lowq ? 1 : 0), &ls);
+            if (pmask && !ls.lowq) return fail(c, MDX_ERR_ARG, "mdx_batch::libsort was built without the batch's low-quality bitmap (upload the batch with the context it is tabulated with)");
+            a.flag = ls.flag; a.tid = ls.tid; a.pos = ls.pos; a.tlen = ls.tlen;
+            a.cigar_off = ls.cigar_off; a.cigar = ls.cigar; a.seq_off = ls.seq_off; a.seq = ls.seq;
+            if (pmask) { a.lowq = (const uint8_t *)ls.lowq; a.qual_so = ls.qual_so; }
+            a.perm = ls.perm; a.lib_start = ls.lib_start; a.sort_bad = ls.bad;
+            HIP_TRY(c, c->ml_partials.reserve((size_t)grid * gn * a.dims.w_total * 4));
+            a.partials = (uint32_t *)c->ml_partials.p;
+        }
         // (the pools' tile counters: zeroed by the reduction behind the previous launch, as a rule; else here, inside the timed region)
-        if (!c->tile_ctr_clean) HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)4096 * 4, c->stream));
+        // (an epoch launch: one counter per (library, pool))
+        const size_t n_ctr = ml ? (size_t)gn * (size_t)((grid >= 2 && !(grid & 1)) ? grid / 2 : grid) : 4096;
+        if (!c->tile_ctr_clean || n_ctr > 4096) HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (n_ctr > 4096 ? n_ctr : 4096) * 4, c->stream));
         c->tile_ctr_clean = false;
         if (fuse) {
             // (a record written back unchanged keeps this NaN — all ones; inside the timed region)
@@ -646,8 +719,10 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         }
         HIP_TRY(c, hipGetLastError());
         if (c->mode == MDX_MODE_LDS) {
+            if (ml) mdx_k_reduce_partials(a.partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream, c->d_tile_ctr, gn, c->dims.w_lib);
+            else
             mdx_k_reduce_partials(c->d_partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream, c->d_tile_ctr);
-            c->tile_ctr_clean = a.dims.w_total >= 4096;
+            c->tile_ctr_clean = a.dims.w_total >= 4096 && n_ctr <= 4096;
             HIP_TRY(c, hipGetLastError());
         }
     }
@@ -1229,6 +1304,7 @@ int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const 
 
 int64_t mdx_fused_launches(const mdx_ctx *c) { return c ? c->n_fused : -1; }
 int64_t mdx_packed_launches(const mdx_ctx *c) { return c ? c->n_packed : -1; }
+int64_t mdx_libsorts(const mdx_ctx *c) { return c ? c->n_libsorts : -1; }
 
 int mdx_rescale_timing_read(mdx_ctx *c, int64_t *n_launches, double *total_ms) {
     if (!c) return MDX_ERR_ARG;

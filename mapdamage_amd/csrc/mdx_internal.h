@@ -191,6 +191,16 @@ struct MdxTabArgs {
     // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
     uint32_t *tile_ctr;
     int tile_quota;
+    // Several libraries in one launch of the packed kernel (tabulate_kernel<.., PK, ML>; n_epochs > 0): the batch above is the
+    // copy of mdx_libsort.hip, ordered by library — place i holding one kept record (the flag filter of reader.py:121-132
+    // applied on the way), the records of library l at places [lib_start[l], lib_start[l + 1]) in batch order, CIGAR, SEQ and
+    // low-quality bitmap in the same order; perm = a record's index within the caller's batch (for the error word).  The
+    // launch counts the libraries [lib_lo, lib_lo + n_epochs), one epoch each; dims are one library's; partials holds
+    // [n_epochs][grid] slots; tile_ctr one counter per (epoch, pool).
+    const uint32_t *perm, *lib_start;
+    const uint32_t *qual_so;                // --min-basequal: a place's first index in the quality column, which stays in the caller's order
+    const unsigned long long *sort_bad;     // MdxLibSort::bad
+    int n_epochs;
 #ifdef MDX_WAVE_CLK
     // instrumented builds (-DMDX_WAVE_CLK, tools/experiments/wave_clk.py): three clock readings per wavefront — start,
     // end of the tile loop, end — read back with mdx_dbg_clk_read
@@ -253,8 +263,35 @@ void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipS
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 // (tile_ctr, if not null and w_total >= 4096: 4096 words zeroed on the way — the next launch's tile counters)
+// (n_lib > 1: the slots of an epoch launch, [library][block], each library summed into its own stretch of raw, lib_stride words apart)
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
-                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr = nullptr);
+                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr = nullptr, int n_lib = 1, int64_t lib_stride = 0);
+
+// ---- bucketing a batch's records by library (mdx_libsort.hip), for the packed kernel's epoch launches
+struct MdxLibSort {
+    unsigned long long *bad; // min over index << 8 | code of the kept records whose library is not below nlib (~0: none): they have
+                             // no place, and every launch over the bucketed columns reports the first of them (MdxTabArgs::sort_bad)
+    uint32_t *lib_start;     // [nlib + 1]; lib_start[nlib] = the kept records
+    uint32_t *perm;          // place -> index within the batch
+    uint16_t *flag;
+    int32_t *tid, *pos, *tlen;
+    uint32_t *cigar_off, *seq_off;   // [kept + 1]
+    uint32_t *cigar;
+    uint8_t *seq;            // 4-bit codes, (n_bases + 1) / 2 + 64 bytes, what lies behind the last kept base zero
+    size_t seq_bytes;
+    uint32_t *lowq;          // the bitmap of MdxTabArgs::lowq in the new order, or null
+    size_t lowq_bytes;
+    uint32_t *qual_so;       // with lowq: the record's offset in the caller's SEQ / quality columns (MdxTabArgs::qual_so)
+};
+// bytes of the blob that holds all of it for a batch of n records (n_cigar operations, n_bases bases), and the pointers into one
+size_t mdx_k_libsort_bytes(int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, int with_lowq);
+void mdx_k_libsort_layout(void *blob, int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, int with_lowq, MdxLibSort *out);
+// scratch of one sort
+size_t mdx_k_libsort_scratch_bytes(int64_t n, int nlib);
+// a batch (device columns, 4-bit SEQ; lowq: its bitmap of low qualities, 4-byte aligned, or null) -> out
+void mdx_k_libsort(int64_t n, int64_t n_cigar, int64_t n_bases, const uint16_t *flag, const uint16_t *lib, const int32_t *tid,
+                   const int32_t *pos, const int32_t *tlen, const uint32_t *cigar_off, const uint32_t *cigar, const uint32_t *seq_off,
+                   const uint8_t *seq4, const uint8_t *lowq, int nlib, void *scratch, const MdxLibSort &out, hipStream_t s);
 void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
                     const unsigned long long *n_lgd_over, MdxDims d, unsigned long long *out,
                     hipStream_t s);

@@ -567,11 +567,17 @@ void mdx_k_unpack_seq(const u8 *d_packed, u8 *d_ascii, int64_t n, hipStream_t s)
 // FAST: the 8-byte-lane path for plain records (MdxDims::fast_ok(), reference shorter than 4 GiB);
 // otherwise every record takes the generic CIGAR walk.
 // RS: the fused tabulate + rescale launch (MdxFuse; mapdamage/rescale.py:195-365 for the records of the tile loop)
-// PK: the packed form — 4-bit SEQ and reference, bit-sliced counting (see above); one library per launch
-template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false>
+// PK: the packed form — 4-bit SEQ and reference, bit-sliced counting (see above); the LDS image holds one library
+// ML: several libraries in one launch of the packed kernel (reader.py:47-50, statistics.py:12-20: the tables are keyed by
+//     library).  The batch arrives ordered by library (mdx_libsort.hip: MdxTabArgs::perm, ::lib_start — the flag filter
+//     applied on the way) and the kernel runs one *epoch* per library over that library's records: tiles
+//     handed out per (library, pool), the LDS image — one library's tables — stored to the block's slot of that library
+//     at the end of the epoch and zeroed for the next one.  Nothing but the blocks of a pool wait for one another.
+template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false, bool ML = false>
 __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK), RS ? MDX_FUSE_WPS : (PK ? MDX_PK_WPS : MDX_WPS)) void tabulate_kernel(MdxTabArgs a) {
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
     static_assert(!PK || (USE_LDS && FAST), "the packed kernel is the fast LDS kernel (plain, with the fused rescaling, or with --min-basequal)");
+    static_assert(!ML || (PK && !RS), "epochs by library: the packed kernels (plain and --min-basequal)");
     constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK);
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -1738,7 +1744,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // (record indices fit 32 bits: mdx_tabulate_device rejects batches of 2^30 records and more)
     // A tile holds a multiple of R records (63 at three per step): the fast run of a tile of complete
     // records ends on a full step.
-    const u32 n_rec = (u32)a.n_reads;
+    // (ML: the records of the epoch's library, places [rec_lo, rec_lo + n_rec) of the bucketed columns; ml_lib = that library,
+    // counted from the launch's first one)
+    u32 n_rec = (u32)a.n_reads, rec_lo = 0u;
+    int ml_lib = 0;
+    u32 ml_chunk0 = 0u;     // ML: chunks of tiles handed out by the epochs so far (the pools take them round-robin across epochs)
     const u32 T = FAST ? 64u - 64u % (u32)d.R : 64u;
     const u32 rounds = (n_rec / T) / nwaves;
     const u32 rem_lo = rounds * nwaves * T, rem = n_rec - rem_lo;
@@ -1792,9 +1802,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         bool kept = valid && (fl & 0xF04u) == 0;  // reader.py:121-132
         // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
         // the others are left to their own launch (a library id beyond the last one is an error in every launch)
-        if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
+        if (!ML && c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
+        // (ML: the image holds the epoch's library alone — table offsets are library 0's, the fragment lengths beyond the
+        // LDS histogram go by lg_lib)
+        const int lg_lib = ML ? ml_lib : c_lib - a.lib_lo;
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
+        u32 qd = 0u;        // ML with --min-basequal: the record's place in the quality column less its place in the SEQ column
         bool one = false;   // [H][S] M {I|D} M [S][H]: one indel between two match runs
         bool skips = false; // an N or P operation (or four and more indels)
         bool nonly = false; // gapped by N / P operations only
@@ -1803,7 +1817,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         int lkey = -1;  // fragment-length key for the LDS histogram
         if (kept) {
             const int rev = (fl >> 4) & 1;
-            libid = c_lib - a.lib_lo;
+            libid = ML ? 0 : c_lib - a.lib_lo;
             const int tid = c_tid;
             const int pos = c_pos;
             cig_o = c_co0;
@@ -1920,7 +1934,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             // a CIGAR that disagrees with SEQ cannot come out of htslib
             bad = bad || over || cig_n == 0 || aend > clen || nq64 != (i64)sQ || sC > 0x3FFFFFFFu || n0u + sI > 0x3FFFFFFFu;
             if (bad) {
-                flag_error(p.err, (i64)ri + p.record_base, ERR_BAD_READ);
+                flag_error(p.err, (i64)(ML ? p.perm[ri] : ri) + p.record_base, ERR_BAD_READ);
                 kept = false;
             } else {
                 const int n_gap = nID + 4 * (nE - nID);
@@ -1943,7 +1957,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
                 // (flag bit 0x8000, include/mdx.h: the caller vouches that no quality of the record is below the threshold)
-                if (MASK && !(fl & 0x8000u) && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
+                // (ML: the quality column stays in the caller's order — only its bitmap moves with the records; qd = what to add to
+                // an index of the reordered SEQ column to find the quality of that base)
+                if (ML && MASK) qd = p.qual_so[ri] - so;
+                if (MASK && !(fl & 0x8000u) && a.qual != nullptr && a.qual[so + qd] != 0xFF) w1 |= D_HASQ;
                 // statistics.py:117-126
                 int kind = -1;
                 i64 flen = 0;
@@ -1962,11 +1979,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         lkey = lbase + d.off_lgd() + (kind * 2 + rev) * d.lgd_lds + (int)flen;
                     } else if (flen < d.lgd_max) {
                         atomicAdd(&p.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
-                                               (((i64)libid * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
+                                               (((i64)lg_lib * 2 + kind) * 2 + rev) * d.lgd_max + flen], 1ull);
                     } else {
                         const u64 slot = atomicAdd(p.n_lgd_over, 1ull);
                         if ((i64)slot < p.lgd_over_cap) {
-                            p.lgd_over[4 * slot + 0] = libid + a.lib_lo;
+                            p.lgd_over[4 * slot + 0] = lg_lib + a.lib_lo;
                             p.lgd_over[4 * slot + 1] = kind;
                             p.lgd_over[4 * slot + 2] = rev;
                             p.lgd_over[4 * slot + 3] = flen;
@@ -2149,7 +2166,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const int b_mis = lb + d.off_mis() + rev * 2 * L * 25;
             const int b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
             const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad;
-            const u8 *__restrict__ qp = MASK ? a.qual + s_sq : nullptr;
+            const u8 *__restrict__ qp = MASK ? a.qual + (s_sq + ((ML && MASK) ? (u32)rl((int)qd, j) : 0u)) : nullptr;
             // flank lengths: from the packed descriptor (A < 248 with the fast path), else recomputed
             int s_nb = (s_w1 >> D_NB_SHIFT) & 0xFF, s_na = (s_w1 >> D_NA_SHIFT) & 0xFF;
             if (!FAST) {
@@ -2268,6 +2285,28 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 
     };   // general
 
+    // (ML: one epoch per library of the launch, see the template's comment; otherwise once through)
+#pragma unroll 1
+    for (int ep = 0; ep < (ML ? a.n_epochs : 1); ep++) {
+    if (ML) {
+        const MdxTabArgs *kp = ka;
+        asm volatile("" : "+s"(kp));
+        // (a kept record whose library the context does not know was given no place by the sort: reported here, like the
+        // record the one-library kernel finds)
+        if (ep == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+            const u64 v = *kp->sort_bad;
+            if (v != ~0ull) flag_error(kp->err, (i64)(v >> 8) + kp->record_base, (int)(v & 0xFFu));
+        }
+        ml_lib = ep;
+        // (empty at the end of an epoch; said again so that nothing of them is live around the loop)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { bsL[i] = 0u; bsH[i] = 0u; b2L[i] = 0u; b2H[i] = 0u; }
+        bs_steps = 0; qcount = 0;
+        // (the wavefront's lists are written anew: no line of them left in this CU's L1 from the epoch before)
+        if (ep > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        rec_lo = kp->lib_start[a.lib_lo + ep];
+        n_rec = kp->lib_start[a.lib_lo + ep + 1] - rec_lo;
+    }
     if (!FAST) {
         for (u32 it = 0; it < n_it; it++) {
             const u32 tbase = it < rounds ? (it * nwaves + gwave) * T : t_lo + (it - rounds) * T;
@@ -2304,17 +2343,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // (a pool's tiles: chunks of MDX_POOL_CHUNK consecutive tiles, the pools' chunks interleaved — the whole chip works
         // on one neighbourhood of a coordinate-sorted batch at a time and shares its reference lines in the L2s, as it did
         // when the tiles were dealt round-robin; a stretch of its own per pool cost such a batch 5 %)
+        static_assert(!(ML && MDX_PK_PREFETCH), "the prefetched columns know no epochs");
         u32 grabs = 0;
         auto grab = [&]() -> u32 {
             // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
             u32 v = 0xFFFFFFFFu;
-            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + pool, 1u); grabs++; }
+            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + (ML ? (u32)ep * n_pools : 0u) + pool, 1u); grabs++; }
             return v;
         };
+        // (ML: the chunks of an epoch go on round-robin over the pools where the epoch before stopped — chunk c of the launch
+        // is pool c % n_pools's —, so that libraries of a few chunks each do not all begin with pool 0)
+        const u32 ch_first = ML ? (pool + n_pools - ml_chunk0 % n_pools) % n_pools : pool;
         auto tile_of = [&](const u32 raw) -> u32 {
             const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)raw);
             if (v == 0xFFFFFFFFu) return v;
-            const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * n_pools + pool) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
+            const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * n_pools + ch_first) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
             return tile < n_tiles ? tile : 0xFFFFFFFFu;
         };
         // (the fused kernel knows its next tile while it works on one — the bounds of that tile's quality copy are requested
@@ -2406,11 +2449,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 }
                 // ---------------------------------------------------- phase 1 of the single-match records
-                const u32 ri = r_lo + lane;
-                const bool valid = ri < r_hi;
-                const u32 rj = valid ? ri : tbase;
+                // (ML: place rec_lo + ... of the batch ordered by library; the record's library is the epoch's)
+                const u32 ri = r_lo + lane + (ML ? rec_lo : 0u);
+                const bool valid = r_lo + lane < r_hi;
+                const u32 rj = valid ? ri : tbase + (ML ? rec_lo : 0u);
                 const u32 fl = PF ? Cc.fl : (valid ? (u32)ld32(a.flag, rj) : 0x4u);
-                const int c_lib = PF ? Cc.lib : ld32(a.lib, rj), c_tid = PF ? Cc.tid : ld32(a.tid, rj), c_pos = PF ? Cc.pos : ld32(a.pos, rj),
+                const int c_lib = PF ? Cc.lib : (ML ? a.lib_lo + ml_lib : ld32(a.lib, rj)), c_tid = PF ? Cc.tid : ld32(a.tid, rj), c_pos = PF ? Cc.pos : ld32(a.pos, rj),
                           c_tlen = PF ? Cc.tlen : ld32(a.tlen, rj);
                 const u32 c_co0 = PF ? Cc.co0 : ld32(a.cigar_off, rj), c_co1 = PF ? Cc.co1 : ld32(a.cigar_off, rj + 1),
                           c_so0 = PF ? Cc.so0 : ld32(a.seq_off, rj), c_so1 = PF ? Cc.so1 : ld32(a.seq_off, rj + 1);
@@ -2454,7 +2498,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     rs_anyhi = __ballot((hi & 0x80808080u) != 0u) != 0ull;
                 }
                 bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
-                if (c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
+                if (!ML && c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
                 // second round trip of the tile: the (up to three) operations, the contig bounds and (MASK) the first quality
                 // together.  The tile loop's own records: one match operation (M, = or X), alone or between soft clips —
                 // [S] M [S] — over the whole of SEQ.
@@ -2527,7 +2571,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                     nDef += __popcll(mDef);
                 }
-                const int rev = (fl >> 4) & 1, libid = c_lib - a.lib_lo, nq = (int)len;
+                const int rev = (fl >> 4) & 1, libid = ML ? 0 : c_lib - a.lib_lo, nq = (int)len;
+                const int lg_lib = ML ? ml_lib : libid;       // (the library for the dense length histogram and the overflow list)
                 const int lbase = __mul24(libid, d.w_lib);
                 const bool isF = triv && nq >= L;
                 // RS: record routing (rescale.py:300-342).  Rescaled here, while it is counted: a record of this loop with
@@ -2582,11 +2627,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         if (counts && flen >= (u32)d.lgd_lds) {
                             if (flen < (u32)d.lgd_max) {
                                 atomicAdd(&p.lgd_dense[(i64)(blockIdx.x & (MDX_LGD_COPIES - 1)) * ((i64)a.nlib_total * 4 * d.lgd_max) +
-                                                       ((i64)libid * 4 + krow) * d.lgd_max + flen], 1ull);
+                                                       ((i64)lg_lib * 4 + krow) * d.lgd_max + flen], 1ull);
                             } else {
                                 const u64 slot = atomicAdd(p.n_lgd_over, 1ull);
                                 if ((i64)slot < p.lgd_over_cap) {
-                                    p.lgd_over[4 * slot + 0] = libid + a.lib_lo;
+                                    p.lgd_over[4 * slot + 0] = lg_lib + a.lib_lo;
                                     p.lgd_over[4 * slot + 1] = paired ? 0 : 1;
                                     p.lgd_over[4 * slot + 2] = rev;
                                     p.lgd_over[4 * slot + 3] = (i64)flen;
@@ -2887,7 +2932,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             if (threadIdx.x < 4) a.rs.subs_part[(size_t)blockIdx.x * rs_ncnt + threadIdx.x] = rs_cnt[threadIdx.x];
             __syncthreads();
         }
-        u32 *out = a.partials + (i64)blockIdx.x * d.w_total;
+        // (ML: the block's slot of the epoch's library, [library][block])
+        u32 *out = a.partials + ((i64)(ML ? ep : 0) * gridDim.x + blockIdx.x) * d.w_total;
         if (PK) {
             // The TC words of the slot in the layout every consumer knows (MdxDims: [strand][base][64 byte + lane], the counts
             // in the words of slot 0): word (strand, k, lane (side, m), byte jb) = window byte b = 8 m + jb of the left side /
@@ -2911,6 +2957,15 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         } else
         for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) out[i] = lds[i];
     }
+    if (ML) {
+        // the next epoch: an empty image, empty lists (the event queue and the bit-sliced counters are empty already)
+        __syncthreads();
+        for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) lds[i] = 0;
+        __syncthreads();
+        lP = 0; lI = 0; lD = 0; lC = 0;
+        ml_chunk0 += ((n_rec + T - 1) / T + MDX_POOL_CHUNK - 1) / MDX_POOL_CHUNK;
+    }
+    }   // epochs
 }
 
 template <bool MASK, bool FAST>
@@ -2996,11 +3051,17 @@ void mdx_k_unpack_listed(const uint32_t *in_count, const uint32_t *in_list, int6
 }
 
 hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void *)tabulate_kernel<true, true, true, false, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)tabulate_kernel<true, true, true, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tabulate_kernel<true, true, true, false, true, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return e;
 }
+// (a.n_epochs > 0: the libraries [lib_lo, lib_lo + n_epochs) in one launch over the bucketed columns, see ML)
 void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
+    if (a.n_epochs > 0) hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    else
     hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
 // --min-basequal for the packed kernel: bit i of `out` (32-bit words, bit i & 31 of word i / 32) = quality i is below the
@@ -3031,13 +3092,19 @@ void mdx_k_lowq_bitmap(const uint8_t *qual, int64_t n_bases, int minqual, uint32
 }
 
 hipError_t mdx_k_prepare_packed(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void *)tabulate_kernel<true, false, true, false, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)tabulate_kernel<true, false, true, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tabulate_kernel<true, false, true, false, true, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return e;
 }
 
-// the packed kernel: 4-bit SEQ column and 4-bit reference, one library per launch
+// the packed kernel: 4-bit SEQ column and 4-bit reference; one library per launch, or (a.n_epochs > 0) the libraries
+// [lib_lo, lib_lo + n_epochs) one after the other over the bucketed columns
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
+    if (a.n_epochs > 0) hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    else
     hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
 
@@ -3076,26 +3143,31 @@ void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t l
 // (the last word, the number of kept reads, goes to *raw_tail: a launch may hold a group of the libraries only)
 // (tile_ctr: the pools' tile counters of the launch just reduced — 4096 words, fewer than any table — zeroed here for the
 // next launch: one memset node less in front of every launch)
+// (blockIdx.z: the library of an epoch launch — slots [library][block] of w_total = one library's words + 1, summed into
+// that library's stretch of raw, lib_stride words on)
 __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__restrict__ raw, u64 *__restrict__ raw_tail,
-                                       i64 w_total, int grid, int parts, u32 *__restrict__ tile_ctr) {
+                                       i64 w_total, int grid, int parts, u32 *__restrict__ tile_ctr, i64 lib_stride) {
     const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= w_total) return;
     const int part = blockIdx.y;
-    if (tile_ctr && part == 0 && w < 4096) tile_ctr[w] = 0u;
+    const i64 z = blockIdx.z;
+    if (tile_ctr && part == 0 && z == 0 && w < 4096) tile_ctr[w] = 0u;
     const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
+    const u32 *const pz = partials + z * (i64)grid * w_total;
     u64 acc = 0;
-    for (int b = b0; b < b1; b++) acc += (u64)(i64)(int)partials[(i64)b * w_total + w];   // signed (soft-clip differences)
-    if (acc) atomicAdd(w == w_total - 1 ? raw_tail : &raw[w], acc);
+    for (int b = b0; b < b1; b++) acc += (u64)(i64)(int)pz[(i64)b * w_total + w];   // signed (soft-clip differences)
+    if (acc) atomicAdd(w == w_total - 1 ? raw_tail : &raw[z * lib_stride + w], acc);
 }
 
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
-                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr) {
+                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr, int n_lib, int64_t lib_stride) {
     const int threads = 256;
     const int blocks = (int)((w_total + threads - 1) / threads);
     int parts = grid < 32 ? grid : 32;
+    if (n_lib > 8 && parts > 8) parts = 8;
     if (parts < 1) parts = 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts), dim3(threads), 0, s, partials, raw, raw_tail,
-                       (i64)w_total, grid, parts, w_total >= 4096 ? tile_ctr : nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts, n_lib), dim3(threads), 0, s, partials, raw, raw_tail,
+                       (i64)w_total, grid, parts, w_total >= 4096 ? tile_ctr : nullptr, (i64)lib_stride);
 }
 
 // raw (reference orientation) -> canonical tables (mapdamage_amd/layout.py):

@@ -35,7 +35,7 @@ EXPORTS = (
     "mdx_ctx_stream", "mdx_gbam_open", "mdx_gbam_header", "mdx_gbam_error", "mdx_gbam_configure", "mdx_gbam_next",
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
-    "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek",
+    "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
 )
 
 SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
@@ -56,7 +56,8 @@ class MdxBatch(ctypes.Structure):
                 ("cigar_off", ctypes.c_void_p), ("cigar", ctypes.c_void_p),
                 ("seq_off", ctypes.c_void_p), ("seq", ctypes.c_void_p),
                 ("qual", ctypes.c_void_p),
-                ("seq_format", ctypes.c_int32), ("reserved", ctypes.c_int32), ("lowq", ctypes.c_void_p)]
+                ("seq_format", ctypes.c_int32), ("reserved", ctypes.c_int32), ("lowq", ctypes.c_void_p),
+                ("libsort", ctypes.c_void_p)]
 
 
 class MdxError(RuntimeError):
@@ -109,6 +110,8 @@ def load_library(path=None):
     lib.mdx_fused_launches.argtypes = [ctypes.c_void_p]
     lib.mdx_packed_launches.restype = ctypes.c_int64
     lib.mdx_packed_launches.argtypes = [ctypes.c_void_p]
+    lib.mdx_libsorts.restype = ctypes.c_int64
+    lib.mdx_libsorts.argtypes = [ctypes.c_void_p]
     for name in ("mdx_bam_error", "mdx_bam_header_text", "mdx_bam_ref_name", "mdx_bam_rg_name"):
         getattr(lib, name).restype = ctypes.c_char_p
     lib.mdx_bam_qnames.restype = ctypes.c_void_p
@@ -454,6 +457,11 @@ class DamageEngine:
     def packed_launches(self):
         """Kernel launches so far that ran as the packed kernel (4-bit SEQ column and reference)."""
         return int(self._lib.mdx_packed_launches(self._ctx))
+
+    def libsorts(self):
+        """Calls so far that bucketed their batch by library inside the launch (several libraries, a batch that did not
+        bring the sorted columns: ``upload`` does)."""
+        return int(self._lib.mdx_libsorts(self._ctx))
 
     def rescale_timing_read(self):
         n = ctypes.c_int64(0)

@@ -33,10 +33,10 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.mdx_abi_version() == 4       # 4: mdx_batch::lowq
+    assert lib.mdx_abi_version() == 5       # 5: mdx_batch::libsort
     import re
     hdr = (pathlib.Path(__file__).resolve().parent.parent / "include" / "mdx.h").read_text()
-    assert int(re.search(r"#define MDX_ABI_VERSION (\d+)", hdr).group(1)) == 4
+    assert int(re.search(r"#define MDX_ABI_VERSION (\d+)", hdr).group(1)) == 5
     assert lib.mdx_strerror(0) == b"ok"
     assert b"contig" in lib.mdx_strerror(-6)
 
@@ -53,13 +53,14 @@ def test_ctypes_mirrors_match_the_header(tmp_path):
         pytest.skip("no C compiler")
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mdx.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mdx_config), sizeof(mdx_batch), offsetof(mdx_batch, qual), '
-                   'offsetof(mdx_batch, seq_format), offsetof(mdx_batch, reserved), offsetof(mdx_batch, lowq)); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mdx_config), sizeof(mdx_batch), offsetof(mdx_batch, qual), '
+                   'offsetof(mdx_batch, seq_format), offsetof(mdx_batch, reserved), offsetof(mdx_batch, lowq), '
+                   'offsetof(mdx_batch, libsort)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.check_call([cc, "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [ctypes.sizeof(MdxConfig), ctypes.sizeof(MdxBatch), MdxBatch.qual.offset, MdxBatch.seq_format.offset,
-                   MdxBatch.reserved.offset, MdxBatch.lowq.offset]
+                   MdxBatch.reserved.offset, MdxBatch.lowq.offset, MdxBatch.libsort.offset]
 
 
 def test_create_rejects_bad_config(lib):

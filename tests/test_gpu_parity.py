@@ -39,11 +39,14 @@ def run_engine(ref, batch, libraries, length, around, minqual=0, lgd_max=65536, 
                 dev.free()
             else:
                 eng.tabulate(part)
-        # the packed kernel is what runs for a 4-bit column in a tabulation with the fast geometry (one launch per library; with
-        # --min-basequal its masked form), and only then
+        # the packed kernel is what runs for a 4-bit column in a tabulation with the fast geometry (ONE launch per call whatever
+        # the number of libraries — an epoch each over the records bucketed by library; with --min-basequal its masked form),
+        # and only then
         plain = eng.table_mode == "lds" and length + around <= 248
-        want = splits * len(libraries) if (DamageEngine.default_packed and plain and batch.n) else 0
+        want = splits if (DamageEngine.default_packed and plain and batch.n) else 0
         assert eng.packed_launches() == want
+        # (several libraries: a resident batch brings the bucketed columns, a host batch is sorted inside its launch)
+        assert eng.libsorts() == (want if len(libraries) > 1 and not resident else 0)
         return eng.finish()
 
 
@@ -163,6 +166,8 @@ def test_hip_library_groups_match_oracle(nlib, Q, mid_genome):
         eng.tabulate(batch)
         eng.tabulate(batch.slice(0, 1000))
         got = eng.finish()
+        # (a 4-bit column: one launch per call — an epoch per library over the records bucketed by library — not one per library)
+        assert eng.packed_launches() == (2 if DamageEngine.default_packed else 0)
     want2 = oracle_tableset(mid_genome, batch.slice(0, 1000), libs, 70, 10, Q, lgd_max=300)
     np.testing.assert_array_equal(got.mis, want.mis + want2.mis)
     np.testing.assert_array_equal(got.comp, want.comp + want2.comp)
@@ -171,6 +176,80 @@ def test_hip_library_groups_match_oracle(nlib, Q, mid_genome):
     for key in want.lgd_sparse() + want2.lgd_sparse():
         merged[key[:-1]] = merged.get(key[:-1], 0) + key[-1]
     assert sorted(got.lgd_sparse()) == sorted(k + (v,) for k, v in merged.items())
+
+
+@pytest.mark.parametrize("nlib", [2, 5, 40, 300])
+def test_hip_one_pass_over_the_libraries_of_a_resident_batch(nlib, mid_genome):
+    """reader.py:47-50, statistics.py:12-20: the tables are keyed by library and a file interleaves the libraries.  A resident
+    4-bit batch brings its columns bucketed by library (mdx_batch::libsort) and every call is one launch of the packed kernel
+    per twenty-odd libraries — an epoch per library over its own records —, libraries without a single record, filtered
+    records and skewed library sizes included; accumulating calls, and the same batch through the in-launch sort."""
+    from mapdamage_amd.engine import DamageEngine
+    batch = synth.make_reads(mid_genome, 30_000, 8 + nlib, len_range=(30, 120), nlib=nlib, frac_softclip=0.1, frac_ins=0.05,
+                             frac_del=0.05, paired=True, frac_filtered=0.05)
+    rng = np.random.default_rng(nlib)
+    # skewed: half of the records in library 1, nothing in the last library
+    batch.lib[rng.random(batch.n) < 0.5] = 1
+    batch.lib[batch.lib == nlib - 1] = 0
+    libs = [("S%d" % i, "L%d" % i) for i in range(nlib)]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 0, lgd_max=300)
+    with DamageEngine(libs, 70, 10, 0, lgd_max=300) as eng:
+        eng.set_reference(mid_genome)
+        dev = eng.upload(batch, packed=True)
+        assert dev.dev.libsort
+        eng.tabulate(dev)
+        eng.tabulate(dev)
+        eng.sync()
+        launches = eng.packed_launches()
+        assert eng.libsorts() == 0
+        # (a batch that does not bring the bucketed columns: sorted inside the launch)
+        view = type(dev.dev)()
+        import ctypes
+        ctypes.memmove(ctypes.byref(view), ctypes.byref(dev.dev), ctypes.sizeof(view))
+        view.libsort = None
+        eng.tabulate_view(view)
+        eng.sync()
+        assert eng.libsorts() == 1
+        got = eng.finish()
+        dev.free()
+    assert launches % 2 == 0 and launches // 2 <= (nlib + 15) // 16 + 1      # not one launch per library
+    np.testing.assert_array_equal(got.mis, 3 * want.mis)
+    np.testing.assert_array_equal(got.comp, 3 * want.comp)
+    assert got.n_kept == 3 * want.n_kept
+    assert sorted(got.lgd_sparse()) == sorted(k[:-1] + (3 * k[-1],) for k in want.lgd_sparse())
+
+
+def test_hip_one_pass_over_the_libraries_with_min_basequal(mid_genome):
+    from mapdamage_amd.engine import DamageEngine
+    batch = synth.make_reads(mid_genome, 40_000, 77, len_range=(30, 120), nlib=6, frac_softclip=0.1, frac_ins=0.05,
+                             frac_del=0.05, with_qual=True, paired=True, frac_filtered=0.03)
+    libs = [("S%d" % i, "L%d" % i) for i in range(6)]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 20, lgd_max=300)
+    with DamageEngine(libs, 70, 10, 20, lgd_max=300) as eng:
+        eng.set_reference(mid_genome)
+        dev = eng.upload(batch, packed=True)
+        assert dev.dev.libsort and dev.dev.lowq
+        eng.tabulate(dev)
+        got = eng.finish()
+        assert eng.packed_launches() == 1 and eng.libsorts() == 0
+        dev.free()
+    assert_tables_equal(got, want)
+
+
+def test_hip_library_id_beyond_the_last_in_a_resident_batch(mid_genome):
+    """The sort gives such a record no place; every launch over the bucketed columns reports it, with the caller's base."""
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    batch = synth.make_reads(mid_genome, 5_000, 8, read_len=60, nlib=5)
+    batch.lib[1234] = 7
+    batch.lib[4321] = 9
+    with DamageEngine([("S%d" % i, "L") for i in range(5)]) as eng:
+        eng.set_reference(mid_genome)
+        dev = eng.upload(batch, packed=True)
+        eng.tabulate(dev, record_base=100)
+        with pytest.raises(BadReadError) as err:
+            eng.sync()
+        assert err.value.read_index == 1334
+        dev.free()
 
 
 def test_hip_library_id_beyond_the_last_is_an_error(mid_genome):

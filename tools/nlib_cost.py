@@ -1,5 +1,11 @@
-"""Kernel time of the tabulation pass by number of libraries (2 M config-2-style records): one library keeps its
-tables in the LDS; more than one does not fit next to the staging areas.  Run on the GPU box."""
+"""Kernel time of the tabulation pass by number of libraries (config-3 records dealt to the libraries at random, as the
+read groups of a BAM file are; reader.py:47-50, statistics.py:12-20): the packed kernel over a resident 4-bit batch —
+ONE launch, an epoch per library over the records bucketed by library (mdx_batch::libsort, built at upload) —, the same
+with the sort inside every launch (a batch that does not bring it), and the ASCII kernel (one launch per group of
+libraries that fits the LDS, each over all records).  MDX_NO_ML=1 in the environment: the packed kernel as it was
+before round 5, one launch per library over all records.  Run on the GPU box:
+    python tools/nlib_cost.py [records] [libraries ...]"""
+import ctypes
 import json
 import pathlib
 import sys
@@ -11,25 +17,55 @@ from mapdamage_amd import synth  # noqa: E402
 from mapdamage_amd.engine import DamageEngine  # noqa: E402
 
 
+def timed(eng, what, reps=5):
+    what()
+    eng.sync()
+    eng.timing(True)
+    for _ in range(reps):
+        what()
+    eng.sync()
+    n_launch, ms = eng.timing_read()
+    eng.timing(False)
+    return n_launch // reps, ms / reps
+
+
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
+    counts = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
     ref = synth.make_genome()
-    for nlib in (1, 2, 3, 8):
+    base = None
+    for nlib in counts:
         libs = [("s", "l%d" % i) for i in range(nlib)]
-        b = synth.make_reads(ref, n, 2, read_len=100, nlib=nlib, contigs=[0, 1])
+        b = synth.make_reads(ref, n, 3, read_len=100, nlib=nlib, contigs=[0, 1], paired=True, frac_softclip=0.10,
+                             frac_ins=0.04, frac_del=0.04, frac_skip=0.002, frac_hardclip=0.001)
+        row = {"records": n, "libraries": nlib}
         with DamageEngine(libs, 70, 10, 0, lgd_max=4096) as eng:
             eng.set_reference(ref)
-            db = eng.upload(b)
-            eng.tabulate(db)
-            eng.sync()
-            eng.timing(True)
-            for _ in range(5):
-                eng.tabulate(db)
-            eng.sync()
-            n_launch, ms = eng.timing_read()
+            db = eng.upload(b, packed=True)
+            row["packed_launches_per_pass"], row["packed_ms"] = timed(eng, lambda: eng.tabulate(db))
+            if nlib > 1:
+                view = type(db.dev)()
+                ctypes.memmove(ctypes.byref(view), ctypes.byref(db.dev), ctypes.sizeof(view))
+                view.libsort = None
+                _, row["packed_sort_in_launch_ms"] = timed(eng, lambda: eng.tabulate_view(view))
             db.free()
-            print(json.dumps({"libraries": nlib, "table_mode": eng.table_mode, "launches_per_pass": n_launch // 5,
-                              "kernel_ms": ms / 5, "Greads_per_s": n / (ms / 5 * 1e-3) / 1e9}), flush=True)
+            da = eng.upload(b, packed=False)
+            row["ascii_launches_per_pass"], row["ascii_ms"] = timed(eng, lambda: eng.tabulate(da))
+            da.free()
+        if nlib == 2:
+            # (the epoch kernel itself: two libraries, every record in the first)
+            b.lib[:] = 0
+            with DamageEngine(libs, 70, 10, 0, lgd_max=4096) as eng:
+                eng.set_reference(ref)
+                db = eng.upload(b, packed=True)
+                _, row["packed_all_in_library_0_ms"] = timed(eng, lambda: eng.tabulate(db))
+                db.free()
+        if nlib == 1:
+            base = row["packed_ms"]
+        if base:
+            row["packed_x_one_library"] = round(row["packed_ms"] / base, 3)
+        row["packed_Greads_per_s"] = round(n / (row["packed_ms"] * 1e-3) / 1e9, 3)
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
