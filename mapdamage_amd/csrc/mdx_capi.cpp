@@ -113,7 +113,8 @@ struct mdx_ctx {
     uint32_t *d_partials = nullptr;
     // staging for mdx_tabulate_host: device columns, and two pinned bounce buffers the host columns go through
     // (the CPU fills one while the DMA engine drains the other)
-    DevBuf st[2][10];      // two sets: the columns of batch k+1 are copied while the kernel of batch k reads its own
+    DevBuf st[2][11];      // two sets: the columns of batch k+1 are copied while the kernel of batch k reads its own ([10]: the
+                           // bitmap of the low qualities, built on the copy stream behind the copies)
     hipStream_t copy_stream = nullptr;
     hipEvent_t st_copied[2] = {nullptr, nullptr}, st_done[2] = {nullptr, nullptr};
     bool st_busy[2] = {false, false};
@@ -757,7 +758,11 @@ int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
     DevBuf *const st = c->st[s];
     // (a buffer that has to grow is freed first: the kernel that read it must be done — rare, the sets settle at the
     // size of the largest batch)
-    bool grow = false;
+    // (--min-basequal and a 4-bit SEQ column: the bitmap the packed masked kernel reads, mdx_batch::lowq, is built on the copy
+    // stream behind the copies — under the kernel of the batch before — instead of in front of this batch's launch)
+    const bool stage_lowq = c->cfg.minqual > 0 && h->qual && h->seq_format == MDX_SEQ_4BIT && h->n_bases > 0 && c->mode == MDX_MODE_LDS;
+    const size_t lowq_bytes = stage_lowq ? (size_t)((h->n_bases + 31) / 32 + 2) * 4 : 0;
+    bool grow = stage_lowq && lowq_bytes + 64 > st[10].cap;
     for (int i = 0; i < 10; i++) grow = grow || (src[i] && bytes[i] + 64 > st[i].cap);
     if (c->st_busy[s]) {
         if (grow) HIP_TRY(c, hipEventSynchronize(c->st_done[s]));
@@ -779,9 +784,17 @@ int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
             turn ^= 1;
         }
     }
+    if (stage_lowq) {
+        HIP_TRY(c, st[10].reserve(lowq_bytes + 64));
+        HIP_TRY(c, hipMemsetAsync((char *)st[10].p + lowq_bytes - 8, 0, 8, c->copy_stream));
+        mdx_k_lowq_bitmap((const uint8_t *)st[9].p, h->n_bases, c->cfg.minqual, (uint32_t *)st[10].p, (h->n_bases + 31) / 32, c->copy_stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipEventRecord(c->st_copied[s], c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->st_copied[s], 0));
     mdx_batch dv = *h;
+    dv.lowq = stage_lowq ? (const uint8_t *)st[10].p : nullptr;
+    dv.libsort = nullptr;
     dv.flag = (const uint16_t *)st[0].p; dv.lib = (const uint16_t *)st[1].p;
     dv.tid = (const int32_t *)st[2].p; dv.pos = (const int32_t *)st[3].p;
     dv.tlen = (const int32_t *)st[4].p; dv.cigar_off = (const uint32_t *)st[5].p;

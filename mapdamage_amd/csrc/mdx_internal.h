@@ -366,6 +366,9 @@ struct MdxGbamCols {
     // records that hold a quality below the threshold
     int minqual;
     uint32_t *counters;
+    // ... and, with a 4-bit SEQ column: the bitmap of the qualities below the threshold (mdx_batch::lowq: bit i = quality i of
+    // the column; zeroed beforehand, (n_bases + 31) / 32 words and two guard words), or null
+    uint32_t *lowq;
 };
 size_t mdx_k_gbam_inflate_lds();
 hipError_t mdx_k_gbam_prepare();

@@ -332,6 +332,9 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
         slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
         if ranks.world == 1 and options.chunk_mb == 1024:
             slab = 1 << 30
+        import os
+        if os.environ.get("MDX_GBAM_SLAB_BYTES"):      # (tests: several slabs out of a small file whatever --chunk-mb says)
+            slab = max(1 << 16, int(os.environ["MDX_GBAM_SLAB_BYTES"]))
         with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
                           chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
             # (several ranks: rank r decodes the slabs r, r + W, ... and steps over the others)

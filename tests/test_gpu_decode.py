@@ -491,6 +491,68 @@ def test_min_basequal_on_the_device_path(tmp_path):
     assert res["q0"] == res["qlow"]
 
 
+def test_the_device_decoder_hands_over_the_bitmap_of_the_low_qualities(tmp_path):
+    """--min-basequal on the device path: the unpack kernel sees every quality byte and writes the bitmap the packed masked
+    kernel reads (mdx_batch::lowq; align.py:65-71: bit i = quality i of the column is below the threshold, 0xFF — no
+    qualities — is not) with the columns; no pass over the quality column in front of the launches.  Held against the
+    quality column of the same view, slab by slab, with several libraries (the launches reorder batch and bitmap)."""
+    from mapdamage_amd.engine import DamageEngine
+    from tests.util import assert_tables_equal, oracle_tableset
+    ref, b, rg, path = _write(tmp_path, n=25_000, seed=12)
+    for i in np.random.default_rng(5).choice(b.n, 30, replace=False):
+        b.qual[b.seq_off[i]:b.seq_off[i + 1]] = 0xFF
+    sam.write_bam(str(path), b, ref.names, ref.lengths, RGS, rg_of_record=rg)
+    libs = [("s", "lib1"), ("s", "lib2")]
+    lib_of = {"rgA": 0, "rg_b2": 1, "x": 0}
+    b.lib = np.array([lib_of[r] for r in rg], np.uint16)
+    Q = 22
+    want = oracle_tableset(ref, b, libs, 70, 10, Q)
+    with DamageEngine(libs, 70, 10, Q) as eng:
+        eng.set_reference(ref)
+        with sam.GpuBamStream(eng, str(path), readgroups=list(lib_of.items()), chunk_bytes=1 << 19, want_qual=True, min_basequal=Q) as g:
+            assert g.packed
+            slabs = 0
+            while True:
+                view = g.next_view()
+                if view is None:
+                    break
+                assert view.qual and view.lowq
+                nb = int(view.n_bases)
+                qual = _d2h(view.qual, nb, np.uint8)
+                bits = _d2h(view.lowq, (nb + 31) // 32 + 2, np.uint32)
+                expect = np.zeros(((nb + 31) // 32 + 2) * 32, np.uint8)
+                expect[:nb] = qual < Q
+                np.testing.assert_array_equal(np.unpackbits(bits.view(np.uint8), bitorder="little"), expect)
+                eng.tabulate_view(view)
+                slabs += 1
+            got = eng.finish()
+            assert slabs > 2 and eng.packed_launches() == slabs
+    assert_tables_equal(got, want)
+
+
+def test_the_fallback_without_the_chunked_host_decoder_counts_the_file_again(tmp_path, monkeypatch):
+    """--chunk-mb 0: the host path reads the file in one piece and cannot take it up in the middle — a device decode that
+    gives up part of the way hands the WHOLE file to it (no resume position), and the tables are those of a host run."""
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    ref, b, rg, path = _write(tmp_path, n=40_000)
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    monkeypatch.setenv("MDX_GBAM_SLAB_BYTES", str(1 << 20))
+    outs = {}
+    for name, flags, fail in (("host", ["--host-decode", "--chunk-mb", "0"], None), ("resumed", ["--gpu-decode", "--chunk-mb", "0"], "2")):
+        if fail is None:
+            monkeypatch.delenv("MDX_GBAM_FAIL_AT", raising=False)
+        else:
+            monkeypatch.setenv("MDX_GBAM_FAIL_AT", fail)
+        out = tmp_path / name
+        assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "--log-level", "DEBUG"] + flags) == 0
+        outs[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
+    monkeypatch.delenv("MDX_GBAM_FAIL_AT", raising=False)
+    assert outs["host"] == outs["resumed"]
+    log = (tmp_path / "resumed" / "Runtime_log.txt").read_text()
+    assert "WARNING GPU decode path gave up" in log and "the whole file again" in log
+
+
 def test_flag_bit_15_of_a_file_is_not_the_kernels_hint(tmp_path):
     """MDX_FLAG_QUAL_ABOVE_MIN (0x8000) is a hint the library sets itself; a file whose FLAG field carries that bit
     (htslib does not reject it) must still be masked by its qualities alone (align.py:53-73): every decoder clears it."""

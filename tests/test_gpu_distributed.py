@@ -76,8 +76,10 @@ def test_bench_line_with_rccl_initialised(tmp_path):
     assert line["n_gpus"] == 1 and line["parity"].startswith("bit-exact")
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     sec = line["secondary"]
-    assert set(sec) == {"config2", "config4", "config5", "minqual", "file_to_tables", "config3_genome3g"}
+    assert set(sec) == {"config2", "config4", "config5", "minqual", "nlib8", "file_to_tables", "config3_genome3g"}
     assert sec["minqual"]["q20_kernel_ms"] > 0 and sec["minqual"]["q0_kernel_ms"] > 0
+    # (eight libraries: one launch of the packed kernel per call, the resident batch brings its copy ordered by library)
+    assert sec["nlib8"]["packed_launches_per_call"] == 1 and sec["nlib8"]["sorts_inside_the_launches"] == 0
     flat = [v for k, v in sec.items() if k != "config3_genome3g"] + list(sec["config3_genome3g"].values())
     assert all(v["parity"].startswith("bit-exact") for v in flat)
     assert sec["file_to_tables"]["device_decode"]["reads_per_s"] > 0 and sec["file_to_tables"]["host_decode"]["reads_per_s"] > 0
