@@ -392,6 +392,42 @@ int parse_header(mdx_bam *b, const uint8_t *data, size_t total, bool partial, si
 
 // One step of the record chain at `off`: 1 = a complete record (sizes returned), 0 = data ends inside it
 // (or fewer than 4 bytes are left), -1 = corrupt.
+// A CIGAR of more than 65 535 operations does not fit the record's 16-bit count: the SAM specification (section 4.2.2) stores
+// it in a `CG:B,I` tag and leaves the placeholder `<l_seq>S<reference length>N` in the CIGAR field; htslib, behind the
+// reference's pysam (read.cigar, align.py:76-88), puts the real operations back when it reads the record.  Returns the tag's
+// operations (and their number) if record r — its fixed part, bs bytes — is such a record, else null.
+inline const uint8_t *long_cigar(const uint8_t *r, size_t bs, uint32_t *count) {
+    const uint32_t l_name = r[8], n_cig = rd16(r + 12);
+    const int32_t l_seq = rdi32(r + 16);
+    if (n_cig != 2 || l_seq < 0) return nullptr;
+    const uint8_t *p = r + 32 + l_name;
+    if (32 + (size_t)l_name + 8 > bs) return nullptr;
+    if (rd32(p) != (((uint32_t)l_seq << 4) | 4u) || (rd32(p + 4) & 15u) != 3u) return nullptr;
+    p += 8 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    const uint8_t *end = r + bs;
+    while (p + 3 <= end) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        if (ty == 'Z' || ty == 'H') {
+            const uint8_t *z = (const uint8_t *)std::memchr(p, 0, (size_t)(end - p));
+            if (!z) return nullptr;
+            p = z + 1;
+        } else if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
+        else if (ty == 's' || ty == 'S') p += 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
+        else if (ty == 'B') {
+            if (p + 5 > end) return nullptr;
+            const uint8_t sub = p[0];
+            const uint32_t cnt = rd32(p + 1);
+            const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if ((size_t)cnt * w > (size_t)(end - p - 5)) return nullptr;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') { *count = cnt; return p + 5; }
+            p += 5 + (size_t)cnt * w;
+        } else return nullptr;
+    }
+    return nullptr;
+}
+
 inline int record_at(const uint8_t *data, size_t off, size_t total, uint32_t *n_cig, uint32_t *l_seq, uint32_t *l_qname,
                      size_t *next) {
     if (off + 4 > total) return 0;
@@ -406,6 +442,8 @@ inline int record_at(const uint8_t *data, size_t off, size_t total, uint32_t *n_
     *l_seq = (uint32_t)ls;
     *l_qname = l_name ? l_name - 1 : 0;
     *next = off + 4 + (size_t)bs;
+    // (the real CIGAR of a record that keeps it in its CG tag)
+    if (*n_cig == 2) { uint32_t cnt = 0; if (long_cigar(r, (size_t)bs, &cnt)) *n_cig = cnt; }
     return 1;
 }
 
@@ -528,7 +566,12 @@ int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, in
         const uint8_t *p = r + 32;
         if (l_name) std::memcpy(&b->qnames[noff[i]], p, l_name - 1);
         p += l_name;
-        for (uint32_t k = 0; k < n_cig; k++) b->cigar[coff[i] + k] = rd32(p + 4 * k);
+        {
+            uint32_t n_long = 0;
+            const uint8_t *cg = n_cig == 2 ? long_cigar(r, bs, &n_long) : nullptr;
+            if (cg) for (uint32_t k = 0; k < n_long; k++) b->cigar[coff[i] + k] = rd32(cg + 4 * k);
+            else for (uint32_t k = 0; k < n_cig; k++) b->cigar[coff[i] + k] = rd32(p + 4 * k);
+        }
         p += 4 * (size_t)n_cig;
         uint8_t *s = &b->seq[soff[i]];
         for (int32_t k = 0; k < l_seq; k++) {
@@ -1526,6 +1569,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
             }
             const int32_t stv = (int32_t)info[4 * seg + 2];
             if (stv == -1) { g->error = "corrupt BAM record in BGZF block " + std::to_string(b0 + seg); return MDX_ERR_ARG; }
+            if (stv == 3) { g->error = "a record that keeps its CIGAR in a CG tag (more than 65 535 operations): the host decoder's"; return MDX_ERR_UNSUPPORTED; }
             if (stv == 2 && cnt[4 * seg] == 0 && info[4 * seg + 1] == (uint32_t)at && !more_file) {
                 g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG;
             }

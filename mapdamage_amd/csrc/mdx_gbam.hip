@@ -98,7 +98,8 @@ __device__ __forceinline__ u32 gbam_plausible(const u8 *__restrict__ unc, u32 o,
 // plausible records follow one another (for an htslib file the segment's first byte).  The chain is followed from there
 // to the first record that starts at or behind the segment's end.  info[b] = (first record, landing offset, status, 0)
 // with status 0 = fine, 1 = no record starts in the segment, 2 = the chain ends in a record that is not complete in
-// `unc` (landing = its start), -1 = a record that cannot be one, -2 = the block did not inflate;
+// `unc` (landing = its start), 3 = a record whose CIGAR field is the placeholder of a CG tag, -1 = a record that cannot be
+// one, -2 = the block did not inflate;
 // cnt[b] = (records, CIGAR operations, bases, 0) of the chain.  The host accepts a guess only if the chain before it lands
 // on it (mdx_gbam_next) — the result is exact whatever the guesses were.
 __global__ void gbam_scan_kernel(const u8 *__restrict__ unc, const uint4 *__restrict__ blk, const int *__restrict__ inflated,
@@ -137,6 +138,9 @@ __global__ void gbam_scan_kernel(const u8 *__restrict__ unc, const uint4 *__rest
         if (bs < 32u || bs > 0x7FFFFFF0u || l_seq > 0x7FFFFFFFu ||
             (unsigned long long)32u + l_name + 4ull * n_c + ((unsigned long long)l_seq + 1u) / 2u + l_seq > bs) { status = (u32)-1; break; }
         if ((unsigned long long)off + 4u + bs > total) { status = 2u; break; }
+        // (a CIGAR of more than 65 535 operations lives in the record's CG tag, the field holds the placeholder <l_seq>S<n>N:
+        // the device path does not take such a file — status 3, MDX_ERR_UNSUPPORTED, the host decoder puts the operations back)
+        if (n_c == 2u && g32(r + 32 + l_name) == ((l_seq << 4) | 4u) && (g32(r + 36 + l_name) & 15u) == 3u) { status = 3u; break; }
         n_rec++; n_cig += n_c; n_seq += l_seq;
         off += 4u + bs;
     }

@@ -224,6 +224,11 @@ def read_bam(path, keep_raw=False):
             elif typ == b"B":
                 sub = aux[q:q + 1]
                 cnt, = struct.unpack_from("<i", aux, q + 1)
+                if (tag == b"CG" and sub == b"I" and n_cigar == 2 and int(cig[0]) == ((l_seq << 4) | 4) and (int(cig[1]) & 15) == 3):
+                    # SAMv1 4.2.2: a CIGAR of more than 65 535 operations lives here, the field holds <l_seq>S<n>N (htslib
+                    # puts it back behind the reference's pysam)
+                    cig = np.frombuffer(aux[q + 5:q + 5 + 4 * cnt], dtype="<u4")
+                    n_cigar = cnt
                 q += 5 + cnt * {b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}[sub]
             else:
                 break
