@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 5   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts */
+#define MDX_ABI_VERSION 5   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -377,6 +377,13 @@ int mdx_gbam_tell(const mdx_gbam *g, int64_t *comp_off, int64_t *phase);
 /* BGZF blocks whose guessed first record was not where the chain of records in front of it ended; such a block is scanned
  * again from the right offset (the batch is exact either way; 0 for a file laid out the way htslib does). */
 int mdx_gbam_fixups(const mdx_gbam *g);
+/* --downsample on the device path (mapdamage/reader.py:134-146: a record the flag filter keeps stays with probability p,
+ * one draw of Python's random.Random per kept record in file order — the generator stays with the caller).
+ * mdx_gbam_view_flags copies the flag column of the view mdx_gbam_next handed out last to the host (n = its n_reads;
+ * 2 bytes per record), mdx_gbam_view_set_flags writes it back: the caller draws, marks the records that leave with a bit
+ * the flag filter drops (0x200) and tabulates the view.  Both synchronous. */
+int mdx_gbam_view_flags(mdx_gbam *g, uint16_t *flags, int64_t n);
+int mdx_gbam_view_set_flags(mdx_gbam *g, const uint16_t *flags, int64_t n);
 void mdx_gbam_close(mdx_gbam *g);
 /* Introspection for tests: the device inflate and CRC32 stages of the decode path alone, on BGZF payloads the caller
  * supplies (host buffers).  blk holds four words per block — payload offset in comp, payload bytes, offset in out,

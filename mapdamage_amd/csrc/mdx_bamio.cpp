@@ -1066,6 +1066,7 @@ struct mdx_gbam {
     bool phase_known = true, next_verified = true;
     int fixups = 0;                      // segments whose guessed first record the chain did not confirm (rescanned)
     int slabs_done = 0;
+    int64_t view_reads = 0;          // records of the view mdx_gbam_next handed out last (mdx_gbam_view_flags)
     // The host's share of a slab's inflate (round 4): the device inflater is bound by instruction issue — more wavefronts
     // do not help it — while the host's cores idle: the last `host_share` of a slab's inflated bytes are inflated by a
     // pool of host threads into `hbuf` and copied to their place in HBM on a stream of their own, in pieces, under the
@@ -1655,6 +1656,7 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         g->phase = next_phase;
         g->phase_known = have;
         g->slabs_done++;
+        g->view_reads = view->n_reads;
         return MDX_OK;
         }
     } catch (const std::exception &e) {
@@ -1755,6 +1757,25 @@ int mdx_gbam_skip(mdx_gbam *g, int64_t chunk_bytes) {
 }
 
 int mdx_gbam_fixups(const mdx_gbam *g) { return g ? g->fixups : 0; }
+
+int mdx_gbam_view_flags(mdx_gbam *g, uint16_t *flags, int64_t n) {
+    if (!g || n < 0 || n != g->view_reads || (n > 0 && !flags)) return MDX_ERR_ARG;
+    if (n == 0) return MDX_OK;
+    if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+    if (hipMemcpyAsync(flags, g->flag.p, (size_t)n * 2, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+        hipStreamSynchronize(g->stream) != hipSuccess) { g->error = "copy of the flag column failed"; return MDX_ERR_HIP; }
+    return MDX_OK;
+}
+
+int mdx_gbam_view_set_flags(mdx_gbam *g, const uint16_t *flags, int64_t n) {
+    if (!g || n < 0 || n != g->view_reads || (n > 0 && !flags)) return MDX_ERR_ARG;
+    if (n == 0) return MDX_OK;
+    if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+    // (synchronous: the caller's buffer is free again when the call returns)
+    if (hipMemcpyAsync(g->flag.p, flags, (size_t)n * 2, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+        hipStreamSynchronize(g->stream) != hipSuccess) { g->error = "copy of the flag column failed"; return MDX_ERR_HIP; }
+    return MDX_OK;
+}
 
 int mdx_gbam_tell(const mdx_gbam *g, int64_t *comp_off, int64_t *phase) {
     if (!g || !comp_off || !phase || !g->hs) return MDX_ERR_ARG;

@@ -36,6 +36,7 @@ EXPORTS = (
     "mdx_gbam_at_end", "mdx_gbam_close", "mdx_gbam_set_min_basequal", "mdx_gbam_missing_qualities",
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
+    "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
 )
 
 SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*

@@ -17,7 +17,8 @@ from . import __version__
 from .batch import mark_unmaskable
 from .engine import BadReadError, DamageEngine, MdxError
 from .fasta import compare_sequence_dicts, read_fasta_index, reference_for_bam
-from .reader import BAMReader
+from .layout import FLAG_FILTER
+from .reader import BAMReader, draw_uniform
 from .sam import BAMError
 from .statistics import check_table_and_warn_if_dmg_freq_is_low
 
@@ -92,8 +93,8 @@ def build_parser():
     g.add_argument("--batch-reads", type=int, default=4_000_000, help="records per device batch")
     g.add_argument("--gpu-decode", dest="gpu_decode", action="store_true", default=True,
                    help="inflate and unpack a BAM file on the GPU (include/mdx.h mdx_gbam_*): the compressed file goes "
-                        "to HBM, the batch columns never exist on the host (the default; SAM input, --downsample and "
-                        "files whose BGZF blocks do not start at records are decoded on the host)")
+                        "to HBM, the batch columns never exist on the host (the default; SAM input and --downsample to a fixed "
+                        "number of reads are decoded on the host)")
     g.add_argument("--host-decode", dest="gpu_decode", action="store_false",
                    help="decode on the host (multi-threaded BGZF/BAM decoder) even where the GPU path applies")
     g.add_argument("--chunk-mb", type=_ranged(float, 0), default=1024,
@@ -300,10 +301,14 @@ def _tabulate_on_host(options, reader, ref, libraries, logger, ranks, carry=None
     return tables
 
 
-def _device_path_applies(options):
-    """BAM files on disk, every record wanted (--downsample draws from Python's RNG on the host)."""
+def _device_path_applies(options, world=1):
+    """BAM files on disk; --downsample to a fraction too (the draws are made on the host from the flag column of every slab,
+    reader.py:134-146) unless several ranks share the file (a rank steps over the slabs of the others without seeing their
+    flags, and the stream of draws is the whole file's); a fixed number of reads is reservoir sampling over the whole file
+    (reader.py:148-164): the host's."""
     from .sam import is_bam
-    return str(options.filename) != "-" and is_bam(options.filename) and options.downsample is None
+    return str(options.filename) != "-" and is_bam(options.filename) and (
+        options.downsample is None or (options.downsample < 1 and world == 1))
 
 
 def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
@@ -312,9 +317,11 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
     reference does: the whole file (carry None), or, when the device path failed on a slab it had not begun to count,
     the rest of it with the same engine (``_tabulate_on_host``'s ``carry``)."""
     from .sam import GpuBamStream, GpuDecodeUnsupported
-    if not _device_path_applies(options):
+    if not _device_path_applies(options, ranks.world):
         logger.debug("the GPU decode path does not apply to this run; decoding on the host")
         return None, None
+    import random
+    downsample_rand = random.Random(options.downsample_seed)
     if options.merge_libraries:
         readgroups, lib_default = [], 0
     else:
@@ -357,7 +364,8 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
                             where = stream.tell()
                             # (resuming needs the chunked host decoder, reader.iter_batches(resume=...): with --chunk-mb 0
                             # the host path reads the file in one piece, so the whole file is counted again)
-                            if where is not None and slab > 1 and reader._chunks is not None:
+                            # (... and --downsample: the host decoder starts its stream of draws at the file's first record)
+                            if where is not None and slab > 1 and reader._chunks is not None and options.downsample is None:
                                 carry = (engine, where, n_reads)
                         raise
                     if view is None:
@@ -365,6 +373,15 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
                     if options.minqual and not warned_about_quals and stream.missing_qualities():
                         logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
                         warned_about_quals = True
+                    if options.downsample is not None:
+                        # reader.py:134-146: one draw per record the flag filter keeps, in file order, from the run's one
+                        # generator; the records that leave get a bit the kernel's flag filter drops
+                        # (several ranks: every rank draws for the slabs of the others too — the stream of draws is the file's)
+                        flags = stream.view_flags(view)
+                        kept = np.nonzero((flags & FLAG_FILTER) == 0)[0]
+                        gone = kept[draw_uniform(downsample_rand, len(kept)) >= options.downsample]
+                        flags[gone] |= 0x200
+                        stream.set_view_flags(view, flags)
                     engine.tabulate_view(view, record_base=n_reads)
                     n_reads += int(view.n_reads)
                 engine.sync()
@@ -470,7 +487,7 @@ def main(argv):
         fallbacks = getattr(options, "gpu_decode_fallbacks", 0)
         if options.gpu_decode:
             logger.log(logging.WARNING if fallbacks else logging.DEBUG, "Decode path: %s; fallbacks from the device path: %d",
-                       "host decoder" if (fallbacks or not _device_path_applies(options)) else "device", fallbacks)
+                       "host decoder" if (fallbacks or not _device_path_applies(options, ranks.world)) else "device", fallbacks)
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)
 

@@ -12,6 +12,42 @@ from .batch import ReadBatch
 from .sam import Alignments, BamStream, BAMError, is_bam, read_alignments
 
 
+def draw_uniform(rand, n):
+    """The next ``n`` values of ``rand.random()`` (a ``random.Random``), drawn at once: numpy's legacy generator is the same
+    Mersenne Twister with the same 53-bit conversion, so the state goes over, ``n`` doubles come back and the state
+    returns — the stream of draws of reader.py:139-141 without a Python call per record."""
+    st = rand.getstate()
+    rs = np.random.RandomState()
+    rs.set_state(("MT19937", np.array(st[1][:-1], dtype=np.uint32), st[1][-1]))
+    out = rs.random_sample(int(n))
+    ns = rs.get_state()
+    rand.setstate((st[0], tuple(int(x) for x in ns[1]) + (int(ns[2]),), st[2]))
+    return out
+
+
+def downsample_indices(flag, tid, pos, downsample_to, rand):
+    """Indices of the records of one stretch of a file that the reference iterates over (reader.py:83-96): the flag filter
+    (reader.py:121-132), then — ``downsample_to`` below 1 — one draw of ``rand`` per kept record in file order
+    (reader.py:134-146), or — 1 and more — reservoir sampling and a stable sort by (tid, pos) (reader.py:148-164).
+    ``rand``: the ``random.Random`` that carries the draws from stretch to stretch."""
+    kept = np.nonzero((np.asarray(flag) & L.FLAG_FILTER) == 0)[0]
+    if downsample_to is None:
+        return kept
+    if downsample_to < 1:
+        return kept[draw_uniform(rand, len(kept)) < downsample_to].astype(np.int64)
+    size = int(downsample_to)
+    sample = [None] * size
+    for index, record in enumerate(kept):
+        if index >= size:
+            index = rand.randint(0, index)
+            if index >= size:
+                continue
+        sample[index] = record
+    result = [r for r in sample if r is not None]
+    result.sort(key=lambda r: (int(tid[r]), int(pos[r])))
+    return np.asarray(result, dtype=np.int64)
+
+
 class BAMReader:
     def __init__(self, filepath, merge_libraries=False, downsample_to=None, downsample_seed=None,
                  chunk_bytes=None):
@@ -101,26 +137,10 @@ class BAMReader:
         """Indices of the records the reference would iterate over, in its order
         (reader.py:83-96, 121-164).  ``handle``/``rand``: one chunk of a file decoded in pieces, and
         the generator that carries the --downsample stream of draws across chunks."""
-        flag = (handle or self.handle).batch.flag
-        kept = np.nonzero((flag & L.FLAG_FILTER) == 0)[0]
-        if self.downsample_to is None:
-            return kept
+        b = (handle or self.handle).batch
         if rand is None:
             rand = random.Random(self.downsample_seed)
-        if self.downsample_to < 1:
-            return np.asarray([i for i in kept if rand.random() < self.downsample_to], dtype=np.int64)
-        size = int(self.downsample_to)
-        sample = [None] * size
-        for index, record in enumerate(kept):
-            if index >= size:
-                index = rand.randint(0, index)
-                if index >= size:
-                    continue
-            sample[index] = record
-        result = [r for r in sample if r is not None]
-        b = self.handle.batch
-        result.sort(key=lambda r: (int(b.tid[r]), int(b.pos[r])))
-        return np.asarray(result, dtype=np.int64)
+        return downsample_indices(b.flag, b.tid, b.pos, self.downsample_to, rand)
 
     def library_column(self, indices, handle=None):
         """Library id (index into ``get_libraries()``) of each selected record; raises

@@ -466,6 +466,30 @@ class GpuBamStream:
             return None
         return coff.value, phase.value
 
+    def view_flags(self, view):
+        """The flag column of the view ``next_view`` handed out last, on the host (--downsample on the device path:
+        reader.py:134-146 draws once per record the flag filter keeps, in file order)."""
+        import ctypes
+        import numpy as np
+        n = int(view.n_reads)
+        out = np.empty(n, np.uint16)
+        self._lib.mdx_gbam_view_flags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        rc = self._lib.mdx_gbam_view_flags(self._g, ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(n))
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
+        return out
+
+    def set_view_flags(self, view, flags):
+        """... and back: the caller has marked the records that leave (a bit the flag filter drops)."""
+        import ctypes
+        import numpy as np
+        flags = np.ascontiguousarray(flags, dtype=np.uint16)
+        assert flags.shape[0] == int(view.n_reads)
+        self._lib.mdx_gbam_view_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        rc = self._lib.mdx_gbam_view_set_flags(self._g, ctypes.c_void_p(flags.ctypes.data), ctypes.c_int64(flags.shape[0]))
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
+
     def fixups(self):
         """BGZF blocks whose guessed first record was not where the chain of the records in front of it ended (rescanned
         from the right offset: the result is exact either way)."""

@@ -553,6 +553,44 @@ def test_the_fallback_without_the_chunked_host_decoder_counts_the_file_again(tmp
     assert "WARNING GPU decode path gave up" in log and "the whole file again" in log
 
 
+def test_downsample_to_a_fraction_on_the_device_path(tmp_path):
+    """-n 0.3 --downsample-seed 7 (reader.py:134-146): the device path draws on the host from the flag column of every slab,
+    with the run's one generator, and marks the records that leave — the tables of the host path, which are the tables of
+    the records the reference's own _downsample_to_fraction keeps (the same stream of draws: tests/golden/downsample.npz
+    pins the function both paths call), over several slabs; a fixed number of reads stays the host decoder's."""
+    import random
+
+    from mapdamage_amd import fasta
+    from mapdamage_amd.main import main
+    from mapdamage_amd.reader import BAMReader
+    from tests.util import oracle_tableset
+    ref, b, rg, path = _write(tmp_path, n=30_000, seed=21)
+    fasta.write_fasta(tmp_path / "ref.fa", ref)
+    lib_of = {"rgA": 0, "rg_b2": 1, "x": 0}
+    b.lib = np.array([lib_of[r] for r in rg], np.uint16)
+    kept = np.nonzero((b.flag & 0xF04) == 0)[0]
+    rand = random.Random(7)
+    chosen = np.array([i for i in kept if rand.random() < 0.3])
+    want = oracle_tableset(ref, b.take(chosen), [("s", "lib1"), ("s", "lib2")], 70, 10, 0)
+    outs = {}
+    for name, flags in (("dev", ["--gpu-decode", "--chunk-mb", "2"]), ("host", ["--host-decode", "--chunk-mb", "1"])):
+        out = tmp_path / name
+        assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "-n", "0.3", "--downsample-seed", "7",
+                     "--log-level", "DEBUG"] + flags) == 0
+        outs[name] = [(out / f).read_text() for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt")]
+        assert outs[name] == [want.misincorporation_text(), want.dnacomp_text(), want.lgdistribution_text()], name
+    log = (tmp_path / "dev" / "Runtime_log.txt").read_text()
+    assert "Decode path: device; fallbacks from the device path: 0" in log
+    out = tmp_path / "fixed"
+    assert main(["-i", str(path), "-r", str(tmp_path / "ref.fa"), "-d", str(out), "--no-stats", "-n", "500", "--downsample-seed", "7",
+                 "--log-level", "DEBUG", "--gpu-decode"]) == 0
+    assert "Decode path: host decoder" in (out / "Runtime_log.txt").read_text()
+    r = BAMReader(str(path), downsample_to=500, downsample_seed=7)
+    (fixed,) = list(r.iter_batches())
+    want500 = oracle_tableset(ref, fixed, [("s", "lib1"), ("s", "lib2")], 70, 10, 0)
+    assert (out / "misincorporation.txt").read_text() == want500.misincorporation_text()
+
+
 def test_flag_bit_15_of_a_file_is_not_the_kernels_hint(tmp_path):
     """MDX_FLAG_QUAL_ABOVE_MIN (0x8000) is a hint the library sets itself; a file whose FLAG field carries that bit
     (htslib does not reject it) must still be masked by its qualities alone (align.py:53-73): every decoder clears it."""

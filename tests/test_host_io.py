@@ -11,7 +11,7 @@ from mapdamage_amd.reader import BAMReader
 from mapdamage_amd.sam import BAMError
 from mapdamage_amd.statistics import (DNAComposition, FragmentLengths, MisincorporationRates,
                                       check_table_and_warn_if_dmg_freq_is_low)
-from tests.util import Golden, oracle_tableset
+from tests.util import GOLDEN, Golden, oracle_tableset
 
 RGS = [{"ID": "rgA", "SM": "Zed", "LB": "libB"}, {"ID": "rgB", "SM": "Alpha", "LB": "libA"},
        {"ID": "rgC", "SM": "Zed", "LB": "libB"}]
@@ -83,6 +83,26 @@ def test_reader_downsampling_follows_python_rng(files):
     assert len(got) == 100 and len(set(got.tolist())) == 100
     keys = [(int(batch.tid[i]), int(batch.pos[i])) for i in got]
     assert keys == sorted(keys)
+
+
+def test_downsampling_against_the_reference_golden():
+    """tests/golden/downsample.npz: what the reference's own BAMReader._downsample_to_fraction / _downsample_to_fixed_number
+    (reader.py:134-164) keep of seeded flag / tid / pos columns (tools/make_golden_downsample.py) — every case in one piece
+    and, the fraction cases, in stretches that hand the generator on (the chunked and the device decode paths)."""
+    import json
+
+    from mapdamage_amd.reader import downsample_indices
+    z = np.load(str(GOLDEN / "downsample.npz"))
+    flag, tid, pos = z["flag"], z["tid"], z["pos"]
+    for case in json.loads(bytes(z["cases"]).decode()):
+        to, seed, want = case["downsample_to"], case["seed"], z[case["kept"]]
+        got = downsample_indices(flag, tid, pos, to, random.Random(seed))
+        np.testing.assert_array_equal(got, want, err_msg=str(case))
+        if to < 1:
+            rand, parts = random.Random(seed), []
+            for lo in range(0, len(flag), 777):
+                parts.append(lo + downsample_indices(flag[lo:lo + 777], tid[lo:lo + 777], pos[lo:lo + 777], to, rand))
+            np.testing.assert_array_equal(np.concatenate(parts), want, err_msg="in stretches: %s" % case)
 
 
 def test_statistics_mirror_writes_reference_format(tmp_path):
