@@ -78,6 +78,16 @@ typedef struct {
  *                  library unpacks it into a scratch column first and the results are the same bytes. */
 #define MDX_SEQ_ASCII 0
 #define MDX_SEQ_4BIT 1
+/*   MDX_SEQ_4BITQ  MDX_SEQ_4BIT with --min-basequal folded in (align.py:53-73: a read column whose quality is below the
+ *                  threshold turns into N / N — it counts its read base in the composition table, statistics.py:100-103, and
+ *                  nothing else): a base whose quality is below the CONTEXT's threshold is stored as the complement of its
+ *                  code (14, 13, 11, 7 for A, C, T, G), every other nibble as in MDX_SEQ_4BIT.  The packed masked kernel reads
+ *                  nothing but this column — no quality byte, no bitmap.  Made by the library: mdx_batch_upload and the device
+ *                  decoder (mdx_gbam_set_min_basequal) hand such a column over when the context has a --min-basequal,
+ *                  mdx_tabulate_host folds on the copy stream; a MDX_SEQ_4BIT batch with qualities (or a bitmap, `lowq`) is
+ *                  folded into a scratch column in front of every launch.  The column belongs to the context whose threshold
+ *                  made it (a context without one refuses it). */
+#define MDX_SEQ_4BITQ 2
 
 /* One batch of alignment records as SoA columns: exactly what main.py:165-217 reads from each
  * pysam.AlignedSegment.  `seq` is the full SEQ (soft clips included); `qual`
@@ -99,13 +109,13 @@ typedef struct {
     const uint32_t *seq_off;   /* n_reads + 1 */
     const uint8_t *seq;
     const uint8_t *qual;       /* may be NULL */
-    int32_t seq_format;        /* MDX_SEQ_ASCII (0) or MDX_SEQ_4BIT */
+    int32_t seq_format;        /* MDX_SEQ_ASCII (0), MDX_SEQ_4BIT or MDX_SEQ_4BITQ */
     int32_t reserved;          /* 0 */
-    /* Optional, device batches only, used with --min-basequal by the packed kernel (a 4-bit seq column): bit i & 31 of
-     * 32-bit word i / 32 = qual[i] is below the context's --min-basequal (align.py:65-71; 0xFF — no qualities — is not);
-     * (n_bases + 31) / 32 + 2 words, the last two zero, 4-byte aligned.  NULL: the library builds it from `qual` in front
-     * of every launch (one pass over the quality column).  mdx_batch_upload fills it in when the context has a
-     * --min-basequal, mdx_batch_free releases it. */
+    /* Optional, device batches only, used with --min-basequal and a MDX_SEQ_4BIT column: bit i & 31 of 32-bit word i / 32 =
+     * qual[i] is below the context's --min-basequal (align.py:65-71; 0xFF — no qualities — is not); (n_bases + 31) / 32 words.
+     * A caller that has the bits spares the library the pass over the quality column when it folds the mask into a scratch
+     * copy of the column in front of the launch (MDX_SEQ_4BITQ).  NULL: folded from `qual`.  The library's own batches
+     * (mdx_batch_upload, the device decoder) are MDX_SEQ_4BITQ already and leave this NULL. */
     const uint8_t *lowq;
     /* Optional, device batches only, used when the context has several libraries and the seq column is 4-bit: the
      * per-record columns bucketed by library (reader.py:47-50, statistics.py:12-20 — the tables are keyed by library, a file
@@ -356,9 +366,10 @@ int mdx_gbam_configure(mdx_gbam *g, int32_t n_rg, const char *const *rg_ids, con
                        int want_qual, int want_mate);
 int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *dev_view, const int32_t **d_mtid, const int32_t **d_mpos);
 /* --min-basequal on the device path (needs want_qual): records none of whose qualities is below the threshold get
- * MDX_FLAG_QUAL_ABOVE_MIN in the flag column, a slab without a single maskable record is handed over without its
- * quality column (the unmasked kernel), and mdx_gbam_missing_qualities says whether a record the kernel counts has
- * come by without qualities so far (what main.py:185-192 warns about). */
+ * MDX_FLAG_QUAL_ABOVE_MIN in the flag column, a 4-bit SEQ column takes the mask into its nibbles (the views are
+ * MDX_SEQ_4BITQ), a slab without a single maskable record is handed over without its quality column (the unmasked
+ * kernel), and mdx_gbam_missing_qualities says whether a record the kernel counts has come by without qualities so far
+ * (what main.py:185-192 warns about). */
 int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual);
 /* MDX_SEQ_4BIT: the unpack kernel keeps BAM's nibbles (recoded, low nibble first) instead of expanding them to ASCII;
  * the views of mdx_gbam_next then carry seq_format = MDX_SEQ_4BIT.  Default MDX_SEQ_ASCII. */

@@ -1107,7 +1107,7 @@ struct mdx_gbam {
     void *d_crc_tables = nullptr;        // mdx_crc32::Tables
     // device buffers, grown on demand
     struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, crc, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
-        cigar_off, cigar, seq_off, seq, qual, lowq, small, info, forced, arena;     // (all but `arena` point into it)
+        cigar_off, cigar, seq_off, seq, qual, small, info, forced, arena;     // (all but `arena` point into it)
     std::vector<Buf *> all() { return {&arena}; }
     bool reserve(Buf &b, size_t bytes) {
         if (bytes <= b.cap) return true;
@@ -1296,8 +1296,6 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
                 {&g->pre, nba * 16}, {&g->info, nba * 16}, {&g->forced, nba * 4}, {&g->small, 64}, {&g->rec_off, rec_cap * 4}, {&g->flag, rec_cap * 2},
                 {&g->lib, rec_cap * 2}, {&g->tid, rec_cap * 4}, {&g->pos, rec_cap * 4}, {&g->tlen, rec_cap * 4}, {&g->cigar_off, rec_cap * 4},
                 {&g->seq_off, rec_cap * 4}, {&g->cigar, cig_cap * 4}, {&g->seq, seq_cap}, {&g->qual, g->want_qual ? seq_cap : 0},
-                // (--min-basequal with a 4-bit SEQ column: the bitmap of the qualities below the threshold, mdx_batch::lowq)
-                {&g->lowq, (g->want_qual && g->minqual > 0 && g->seq_format == MDX_SEQ_4BIT) ? seq_cap / 8 + 64 : 0},
                 {&g->mtid, g->want_mate ? rec_cap * 4 : 0}, {&g->mpos, g->want_mate ? rec_cap * 4 : 0}};
             size_t total_bytes = 0;
             for (const Want &w : wants) total_bytes += (w.bytes + 255) & ~(size_t)255;
@@ -1632,9 +1630,8 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         c.seq_packed = g->seq_format == MDX_SEQ_4BIT ? 1 : 0;
         // (the unpack kernel ORs the nibbles of a record into the column: zeroed first, with the dword behind the last base)
         if (c.seq_packed && hipMemsetAsync(c.seq, 0, (size_t)(tot[2] + 1) / 2 + 8, st) != hipSuccess) return MDX_ERR_HIP;
-        // (... and the bits of the low qualities into the bitmap: (n_bases + 31) / 32 words and two guard words)
-        c.lowq = (c.minqual > 0 && c.seq_packed) ? (uint32_t *)g->lowq.p : nullptr;
-        if (c.lowq && hipMemsetAsync(c.lowq, 0, ((size_t)tot[2] + 31) / 32 * 4 + 8, st) != hipSuccess) return MDX_ERR_HIP;
+        // (--min-basequal: the mask goes into the nibbles — MDX_SEQ_4BITQ, the packed masked kernel's input)
+        c.fold = (c.minqual > 0 && c.seq_packed) ? 1 : 0;
         mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
                           (uint32_t)tot[0], (uint32_t)tot[1], (uint32_t)tot[2], (uint32_t *)g->rec_off.p, c, st);
         if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
@@ -1643,12 +1640,13 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
         view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
         view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
-        view->seq_format = g->seq_format; view->reserved = 0; view->lowq = (const uint8_t *)c.lowq; view->libsort = nullptr;
+        view->seq_format = c.fold ? MDX_SEQ_4BITQ : g->seq_format; view->reserved = 0; view->lowq = nullptr; view->libsort = nullptr;
         if (c.minqual > 0) {
             uint32_t counters[2] = {0, 0};
             if (hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
             if (counters[0]) g->no_qual_seen = true;
-            if (counters[1] == 0) view->qual = nullptr;       // nothing in this slab can be masked: the unmasked kernel
+            // nothing in this slab can be masked: the unmasked kernel (no nibble of the column is a complement)
+            if (counters[1] == 0) { view->qual = nullptr; view->seq_format = g->seq_format; }
         }
         if (d_mtid) *d_mtid = c.mtid;
         if (d_mpos) *d_mpos = c.mpos;

@@ -113,8 +113,7 @@ struct mdx_ctx {
     uint32_t *d_partials = nullptr;
     // staging for mdx_tabulate_host: device columns, and two pinned bounce buffers the host columns go through
     // (the CPU fills one while the DMA engine drains the other)
-    DevBuf st[2][11];      // two sets: the columns of batch k+1 are copied while the kernel of batch k reads its own ([10]: the
-                           // bitmap of the low qualities, built on the copy stream behind the copies)
+    DevBuf st[2][10];      // two sets: the columns of batch k+1 are copied while the kernel of batch k reads its own
     hipStream_t copy_stream = nullptr;
     hipEvent_t st_copied[2] = {nullptr, nullptr}, st_done[2] = {nullptr, nullptr};
     bool st_busy[2] = {false, false};
@@ -134,7 +133,7 @@ struct mdx_ctx {
     size_t pkf_prepared = 0;       // ... and the packed fused kernel
     bool tile_ctr_clean = false;   // d_tile_ctr is all zero (the reduction behind a launch leaves it so)
     bool pkm_prepared = false;     // the packed kernel's masked form
-    DevBuf lowq;           // --min-basequal, packed kernel: the bitmap of the batch's qualities below the threshold
+    DevBuf lowq;           // --min-basequal, packed kernel: the scratch column a MDX_SEQ_4BIT batch's mask is folded into (MDX_SEQ_4BITQ)
     DevBuf libsort;        // several libraries, packed kernel: the batch's columns bucketed by library (a batch that does not bring them)
     DevBuf libsort_scratch;
     DevBuf ml_partials;    // ... and the blocks' slots of an epoch launch, [library][block]
@@ -386,20 +385,22 @@ static int check_batch(mdx_ctx *c, const mdx_batch *b) {
     if (b->n_reads > 0 && (!b->flag || !b->lib || !b->tid || !b->pos || !b->tlen || !b->cigar_off || !b->seq_off))
         return fail(c, MDX_ERR_ARG, "null column");
     if ((b->n_cigar > 0 && !b->cigar) || (b->n_bases > 0 && !b->seq)) return fail(c, MDX_ERR_ARG, "null column");
-    if (b->seq_format != MDX_SEQ_ASCII && b->seq_format != MDX_SEQ_4BIT) return fail(c, MDX_ERR_ARG, "unknown seq_format");
+    if (b->seq_format != MDX_SEQ_ASCII && b->seq_format != MDX_SEQ_4BIT && b->seq_format != MDX_SEQ_4BITQ) return fail(c, MDX_ERR_ARG, "unknown seq_format");
+    if (b->seq_format == MDX_SEQ_4BITQ && c->cfg.minqual == 0)
+        return fail(c, MDX_ERR_ARG, "a MDX_SEQ_4BITQ column carries the --min-basequal of the context that made it; this context has none");
     return MDX_OK;
 }
 
 // bytes of the seq column in its form
 static size_t seq_bytes(const mdx_batch *b) {
-    return b->seq_format == MDX_SEQ_4BIT ? ((size_t)b->n_bases + 1) / 2 : (size_t)b->n_bases;
+    return b->seq_format != MDX_SEQ_ASCII ? ((size_t)b->n_bases + 1) / 2 : (size_t)b->n_bases;
 }
 
 // For the launches that read ASCII: a batch whose SEQ column is 4-bit gets an ASCII copy in the context's scratch
 // column (enqueued on the stream; valid until the next such call).  *out = the batch to launch with.
 static int ascii_view(mdx_ctx *c, const mdx_batch *b, mdx_batch *out) {
     *out = *b;
-    if (b->seq_format != MDX_SEQ_4BIT || b->n_bases == 0) { out->seq_format = MDX_SEQ_ASCII; return MDX_OK; }
+    if (b->seq_format == MDX_SEQ_ASCII || b->n_bases == 0) { out->seq_format = MDX_SEQ_ASCII; return MDX_OK; }
     // (launches are in stream order: the kernels of the previous call are done with the scratch column when this one writes it)
     HIP_TRY(c, c->unpacked.reserve((size_t)b->n_bases + 64));
     mdx_k_unpack_seq(b->seq, (uint8_t *)c->unpacked.p, b->n_bases, c->stream);
@@ -409,15 +410,14 @@ static int ascii_view(mdx_ctx *c, const mdx_batch *b, mdx_batch *out) {
     return MDX_OK;
 }
 
-// A device batch with a 4-bit SEQ column, ordered by library, into `blob` (mdx_k_libsort_bytes; enqueued on the stream);
-// lowq: the batch's bitmap of low qualities (--min-basequal), reordered with it, or null
-static bool libsort_with_lowq(const mdx_ctx *c, const mdx_batch *b) { return c->cfg.minqual > 0 && b->qual != nullptr; }
-static int build_libsort(mdx_ctx *c, const mdx_batch *b, const uint8_t *lowq, void *blob) {
+// A device batch with a 4-bit SEQ column (either form), ordered by library, into `blob` (mdx_k_libsort_bytes; enqueued on
+// the stream)
+static int build_libsort(mdx_ctx *c, const mdx_batch *b, void *blob) {
     MdxLibSort ls;
-    mdx_k_libsort_layout(blob, b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, lowq ? 1 : 0, &ls);
+    mdx_k_libsort_layout(blob, b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, &ls);
     HIP_TRY(c, c->libsort_scratch.reserve(mdx_k_libsort_scratch_bytes(b->n_reads, c->cfg.nlib)));
     mdx_k_libsort(b->n_reads, b->n_cigar, b->n_bases, b->flag, b->lib, b->tid, b->pos, b->tlen, b->cigar_off, b->cigar, b->seq_off, b->seq,
-                  lowq, c->cfg.nlib, c->libsort_scratch.p, ls, c->stream);
+                  c->cfg.nlib, c->libsort_scratch.p, ls, c->stream);
     HIP_TRY(c, hipGetLastError());
     return MDX_OK;
 }
@@ -450,29 +450,25 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
         *col.dst = p;
         HIP_TRY(c, hipMemcpyAsync(p, col.src, col.bytes, hipMemcpyHostToDevice, c->stream));
     }
-    // --min-basequal and a 4-bit SEQ column: the bitmap of the qualities below the threshold travels with the resident batch
-    // (mdx_batch::lowq) instead of being built in front of every launch
-    // (MDX_NO_BATCH_LOWQ=1 in the environment: not — every launch builds its own, for A/B runs)
+    // --min-basequal and a 4-bit SEQ column: the mask goes into the resident column itself (MDX_SEQ_4BITQ, include/mdx.h) —
+    // the packed masked kernel then reads no quality, and nothing is folded in front of the launches
+    // (MDX_NO_BATCH_LOWQ=1 in the environment: not — every launch folds into a scratch column, for A/B runs)
     static const bool no_batch_lowq = [] { const char *e = getenv("MDX_NO_BATCH_LOWQ"); return e && *e && *e != '0'; }();
-    if (c->cfg.minqual > 0 && dv->qual && h->seq_format == MDX_SEQ_4BIT && h->n_bases > 0 && !no_batch_lowq) {
-        const int64_t n_words = (h->n_bases + 31) / 32;
-        void *p = nullptr;
-        HIP_TRY(c, hipMalloc(&p, (size_t)(n_words + 2) * 4 + 64));
-        dv->lowq = (const uint8_t *)p;
-        HIP_TRY(c, hipMemsetAsync((char *)p + (size_t)n_words * 4, 0, 8, c->stream));
-        mdx_k_lowq_bitmap(dv->qual, h->n_bases, c->cfg.minqual, (uint32_t *)p, n_words, c->stream);
+    if (c->cfg.minqual > 0 && dv->qual && h->seq_format == MDX_SEQ_4BIT && h->n_bases > 0 && c->mode == MDX_MODE_LDS && !no_batch_lowq) {
+        mdx_k_fold_mask(dv->seq, const_cast<uint8_t *>(dv->seq), dv->qual, nullptr, h->n_bases, c->cfg.minqual, c->stream);
         HIP_TRY(c, hipGetLastError());
+        dv->seq_format = MDX_SEQ_4BITQ;
     }
     // several libraries and a 4-bit SEQ column: the batch ordered by library travels with the resident batch
     // (mdx_batch::libsort) instead of being sorted in front of every launch
     // (MDX_NO_BATCH_LIBSORT=1 in the environment: not, for A/B runs)
     static const bool no_batch_sort = [] { const char *e = getenv("MDX_NO_BATCH_LIBSORT"); return e && *e && *e != '0'; }();
-    if (c->cfg.nlib > 1 && h->seq_format == MDX_SEQ_4BIT && n > 0 && c->mode == MDX_MODE_LDS && !no_batch_sort) {
+    if (c->cfg.nlib > 1 && h->seq_format != MDX_SEQ_ASCII && n > 0 && c->mode == MDX_MODE_LDS && !no_batch_sort) {
         void *p = nullptr;
-        HIP_TRY(c, hipMalloc(&p, mdx_k_libsort_bytes(n, h->n_cigar, h->n_bases, c->cfg.nlib, dv->lowq ? 1 : 0)));
+        HIP_TRY(c, hipMalloc(&p, mdx_k_libsort_bytes(n, h->n_cigar, h->n_bases, c->cfg.nlib)));
         dv->libsort = (const uint8_t *)p;
         // (a record with a library the context does not know has no place: the blob remembers the first, the launches report it)
-        rc = build_libsort(c, dv, dv->lowq, p);
+        rc = build_libsort(c, dv, p);
         if (rc != MDX_OK) return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -508,9 +504,12 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     // (--min-basequal: the packed kernel's masked form reads a bitmap of the qualities below the threshold, built in front of
     // the launch — MDX_NO_PACKED_MASK=1: the ASCII kernel instead, for A/B runs)
     static const bool no_pkm = [] { const char *e = getenv("MDX_NO_PACKED_MASK"); return e && *e && *e != '0'; }();
-    const bool want_mask = c->cfg.minqual > 0 && b_in->qual != nullptr;
-    const bool packed = b_in->seq_format == MDX_SEQ_4BIT && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 &&
-                        (fuse ? c->cfg.nlib == 1 : !(want_mask && no_pkm)) && !no_packed;
+    // (a MDX_SEQ_4BITQ column has the mask in its nibbles: the packed masked kernel's input; a MDX_SEQ_4BIT one with qualities
+    // is folded into a scratch column in front of the launch)
+    const bool folded = b_in->seq_format == MDX_SEQ_4BITQ;
+    const bool want_mask = c->cfg.minqual > 0 && (b_in->qual != nullptr || folded);
+    const bool packed = b_in->seq_format != MDX_SEQ_ASCII && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 &&
+                        (fuse ? (c->cfg.nlib == 1 && !folded) : !(want_mask && no_pkm)) && !no_packed;
     const bool pmask = packed && !fuse && want_mask;
     // Several libraries through the packed kernel: ONE launch that counts the libraries one after the other (an epoch each)
     // over the columns bucketed by library — the batch's own (mdx_batch::libsort, a resident batch) or sorted here, inside the
@@ -649,43 +648,43 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             HIP_TRY(c, hipEventCreate(&e1));
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         }
-        // (an epoch launch with --min-basequal reads the bitmap in the batch's new order: the batch's own bitmap — or the one
-        // built below — is reordered with the batch)
-        const bool batch_lowq = pmask && b->lowq && ((uintptr_t)b->lowq & 3) == 0;
-        if (pmask && !batch_lowq && lo == 0) {
-            // the bitmap of the qualities below the threshold (one pass over the quality column, inside the timed region;
-            // two guard words behind it)
-            const int64_t n_words = (b->n_bases + 31) / 32;
-            HIP_TRY(c, c->lowq.reserve((size_t)(n_words + 2) * 4 + 64));
-            HIP_TRY(c, hipMemsetAsync((char *)c->lowq.p + (size_t)n_words * 4, 0, 8, c->stream));
-            mdx_k_lowq_bitmap(b->qual, b->n_bases, c->cfg.minqual, (uint32_t *)c->lowq.p, n_words, c->stream);
+        mdx_batch b_fold;
+        const mdx_batch *bs = b;        // (the batch the sort below reads)
+        if (pmask && !folded) {
+            // a MDX_SEQ_4BIT column with qualities: the mask folded into a scratch copy of the column (one pass over column and
+            // qualities — or the caller's bitmap of them —, inside the timed region), once for all launches of the call
+            if (lo == 0) {
+                HIP_TRY(c, c->lowq.reserve(((size_t)b->n_bases + 1) / 2 + 64));
+                const bool bits = b->lowq != nullptr;
+                if (b->libsort) return fail(c, MDX_ERR_ARG, "mdx_batch::libsort of a MDX_SEQ_4BIT batch under --min-basequal: upload the batch with the context it is tabulated with");
+                mdx_k_fold_mask(b->seq, (uint8_t *)c->lowq.p, b->qual, bits ? b->lowq : nullptr, b->n_bases, c->cfg.minqual, c->stream);
+                HIP_TRY(c, hipGetLastError());
+            }
+            a.seq = (const uint8_t *)c->lowq.p;
+            b_fold = *b;
+            b_fold.seq = a.seq;
+            bs = &b_fold;
         }
         if (pmask && !c->pkm_prepared) {
             HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(dims1)));
             c->pkm_prepared = true;
         }
-        if (pmask) a.lowq = batch_lowq ? b->lowq : (const uint8_t *)c->lowq.p;
         if (ml) {
             // the batch ordered by library: its own copy (a resident batch's), or sorted now (once for all launches of the call)
             const void *blob = b->libsort;
-            const bool with_lowq = pmask;
             if (!blob) {
                 if (lo == 0) {
-                    HIP_TRY(c, c->libsort.reserve(mdx_k_libsort_bytes(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, with_lowq ? 1 : 0)));
-                    rc = build_libsort(c, b, with_lowq ? a.lowq : nullptr, c->libsort.p);
+                    HIP_TRY(c, c->libsort.reserve(mdx_k_libsort_bytes(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib)));
+                    rc = build_libsort(c, bs, c->libsort.p);
                     if (rc != MDX_OK) return rc;
                     c->n_libsorts++;
                 }
                 blob = c->libsort.p;
             }
             MdxLibSort ls;
-            // (a resident batch's copy holds the bitmap iff the batch has one: mdx_batch_upload)
-            mdx_k_libsort_layout(const_cast<void *>(blob), b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib,
-                                 b->libsort ? (b->lowq ? 1 : 0) : (with_lowq ? 1 : 0), &ls);
-            if (pmask && !ls.lowq) return fail(c, MDX_ERR_ARG, "mdx_batch::libsort was built without the batch's low-quality bitmap (upload the batch with the context it is tabulated with)");
+            mdx_k_libsort_layout(const_cast<void *>(blob), b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, &ls);
             a.flag = ls.flag; a.tid = ls.tid; a.pos = ls.pos; a.tlen = ls.tlen;
             a.cigar_off = ls.cigar_off; a.cigar = ls.cigar; a.seq_off = ls.seq_off; a.seq = ls.seq;
-            if (pmask) { a.lowq = (const uint8_t *)ls.lowq; a.qual_so = ls.qual_so; }
             a.perm = ls.perm; a.lib_start = ls.lib_start; a.sort_bad = ls.bad;
             HIP_TRY(c, c->ml_partials.reserve((size_t)grid * gn * a.dims.w_total * 4));
             a.partials = (uint32_t *)c->ml_partials.p;
@@ -758,11 +757,10 @@ int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
     DevBuf *const st = c->st[s];
     // (a buffer that has to grow is freed first: the kernel that read it must be done — rare, the sets settle at the
     // size of the largest batch)
-    // (--min-basequal and a 4-bit SEQ column: the bitmap the packed masked kernel reads, mdx_batch::lowq, is built on the copy
-    // stream behind the copies — under the kernel of the batch before — instead of in front of this batch's launch)
-    const bool stage_lowq = c->cfg.minqual > 0 && h->qual && h->seq_format == MDX_SEQ_4BIT && h->n_bases > 0 && c->mode == MDX_MODE_LDS;
-    const size_t lowq_bytes = stage_lowq ? (size_t)((h->n_bases + 31) / 32 + 2) * 4 : 0;
-    bool grow = stage_lowq && lowq_bytes + 64 > st[10].cap;
+    // (--min-basequal and a 4-bit SEQ column: the mask is folded into the staged column — MDX_SEQ_4BITQ, the packed masked
+    // kernel's input — on the copy stream behind the copies, under the kernel of the batch before)
+    const bool stage_fold = c->cfg.minqual > 0 && h->qual && h->seq_format == MDX_SEQ_4BIT && h->n_bases > 0 && c->mode == MDX_MODE_LDS;
+    bool grow = false;
     for (int i = 0; i < 10; i++) grow = grow || (src[i] && bytes[i] + 64 > st[i].cap);
     if (c->st_busy[s]) {
         if (grow) HIP_TRY(c, hipEventSynchronize(c->st_done[s]));
@@ -784,17 +782,16 @@ int mdx_tabulate_host(mdx_ctx *c, const mdx_batch *h) {
             turn ^= 1;
         }
     }
-    if (stage_lowq) {
-        HIP_TRY(c, st[10].reserve(lowq_bytes + 64));
-        HIP_TRY(c, hipMemsetAsync((char *)st[10].p + lowq_bytes - 8, 0, 8, c->copy_stream));
-        mdx_k_lowq_bitmap((const uint8_t *)st[9].p, h->n_bases, c->cfg.minqual, (uint32_t *)st[10].p, (h->n_bases + 31) / 32, c->copy_stream);
+    if (stage_fold) {
+        mdx_k_fold_mask((const uint8_t *)st[8].p, (uint8_t *)st[8].p, (const uint8_t *)st[9].p, nullptr, h->n_bases, c->cfg.minqual, c->copy_stream);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->st_copied[s], c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->st_copied[s], 0));
     mdx_batch dv = *h;
-    dv.lowq = stage_lowq ? (const uint8_t *)st[10].p : nullptr;
+    dv.lowq = nullptr;
     dv.libsort = nullptr;
+    if (stage_fold) dv.seq_format = MDX_SEQ_4BITQ;
     dv.flag = (const uint16_t *)st[0].p; dv.lib = (const uint16_t *)st[1].p;
     dv.tid = (const int32_t *)st[2].p; dv.pos = (const int32_t *)st[3].p;
     dv.tlen = (const int32_t *)st[4].p; dv.cigar_off = (const uint32_t *)st[5].p;

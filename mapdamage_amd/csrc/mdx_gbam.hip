@@ -207,12 +207,17 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
         const u64 lut = 0x0000000400080210ull;      // code of BAM nibble n at bits [4 n, 4 n + 4)
         auto code = [&](const u32 nib) -> u32 { return (u32)(lut >> (4u * nib)) & 15u; };
         const u32 n8 = (l_seq + 7u) >> 3;
+        // (--min-basequal, MDX_SEQ_4BITQ: a base whose quality is below the threshold goes into the column as the complement
+        // of its code — align.py:65-71 masks exactly those columns; 0xFF, no qualities, is not below any threshold)
+        const u8 *qq = q + (l_seq + 1u) / 2u;
         for (u32 k = j; k < n8; k += 8u) {
             const u32 nb = l_seq - 8u * k < 8u ? l_seq - 8u * k : 8u;       // bases of this step
             u32 v = 0;
             for (u32 i = 0; i < nb; i++) {
                 const u32 byte = q[4u * k + (i >> 1)];
-                v |= code((i & 1u) ? (byte & 15u) : (byte >> 4)) << (4u * i);
+                u32 cd = code((i & 1u) ? (byte & 15u) : (byte >> 4));
+                if (c.fold && cd && qq[8u * k + i] < (u32)c.minqual) cd ^= 15u;
+                v |= cd << (4u * i);
             }
             const u32 n0 = so + 8u * k, sh = 4u * (n0 & 7u);
             if (v << sh) atomicOr(&d32[n0 >> 3], v << sh);
@@ -233,29 +238,15 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
     u32 qmin = 0xFFu;                                  // lowest quality of the record (0xFF: none)
     if (c.qual) {
         u8 *__restrict__ ql = c.qual + so;
-        // (--min-basequal, 4-bit SEQ column: the bits of the qualities below the threshold go into the batch's bitmap on the way —
-        // align.py:65-71 masks exactly those columns; 0xFF, no qualities, is not below any threshold — four at a time, OR-ed
-        // across the word boundary)
-        const u32 m4 = (u32)c.minqual * 0x01010101u;
         for (u32 k = j; k < n4; k += 8u) {
             const u32 w = g32(q + 4 * k);
             *(u32u *)(ql + 4 * k) = w;
             const u32 a = w & 0xFFu, b = (w >> 8) & 0xFFu, cc = (w >> 16) & 0xFFu, d = w >> 24;
             const u32 m = min(min(a, b), min(cc, d));
             qmin = m < qmin ? m : qmin;
-            if (c.lowq && m < (u32)c.minqual) {
-                const u32 low = ~((w | 0x80808080u) - m4) & ~w & 0x80808080u;       // bit 7 of a byte: below the threshold
-                const u32 bits = (((low >> 7) * 0x00204081u) >> 21) & 0xFu;
-                const u32 i0 = so + 4u * k, sh = i0 & 31u;
-                atomicOr(&c.lowq[i0 >> 5], bits << sh);
-                if (sh > 28u && (bits >> (32u - sh))) atomicOr(&c.lowq[(i0 >> 5) + 1u], bits >> (32u - sh));
-            }
         }
         if (j == 0)
-            for (u32 k = 4 * n4; k < l_seq; k++) {
-                ql[k] = q[k]; qmin = q[k] < qmin ? q[k] : qmin;
-                if (c.lowq && q[k] < (u32)c.minqual) atomicOr(&c.lowq[(so + k) >> 5], 1u << ((so + k) & 31u));
-            }
+            for (u32 k = 4 * n4; k < l_seq; k++) { ql[k] = q[k]; qmin = q[k] < qmin ? q[k] : qmin; }
         if (c.minqual > 0)
             for (int o = 1; o < 8; o <<= 1) { const u32 other = (u32)__shfl_xor((int)qmin, o); qmin = other < qmin ? other : qmin; }
     }

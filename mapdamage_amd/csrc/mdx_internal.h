@@ -156,9 +156,6 @@ struct MdxTabArgs {
     // genome coordinate i - 256), read by the packed kernel (tabulate_kernel<.., PK>) together with a 4-bit SEQ column
     const uint8_t *ref4;
     int seq_packed;                  // the batch's seq column holds MDX_SEQ_4BIT codes (include/mdx.h)
-    // the packed kernel with --min-basequal: bit i (of 32-bit words: 4-byte aligned) = the quality of base i of the seq column
-    // is below the threshold; (n_bases + 31) / 32 + 2 words
-    const uint8_t *lowq;
     const int64_t *contig_off;
     int n_contig;
     int minqual;
@@ -198,7 +195,6 @@ struct MdxTabArgs {
     // launch counts the libraries [lib_lo, lib_lo + n_epochs), one epoch each; dims are one library's; partials holds
     // [n_epochs][grid] slots; tile_ctr one counter per (epoch, pool).
     const uint32_t *perm, *lib_start;
-    const uint32_t *qual_so;                // --min-basequal: a place's first index in the quality column, which stays in the caller's order
     const unsigned long long *sort_bad;     // MdxLibSort::bad
     int n_epochs;
 #ifdef MDX_WAVE_CLK
@@ -255,10 +251,13 @@ int mdx_k_pk_blocks_per_cu();     // by its registers
 int mdx_k_pk_queue_off(const MdxDims &d);
 size_t mdx_k_pk_lds_bytes(const MdxDims &d);
 hipError_t mdx_k_prepare_packed(size_t lds_bytes);
-// ... with --min-basequal (MdxTabArgs::lowq), and the bitmap from a quality column (words beyond the column: zero)
+// ... with --min-basequal (a MDX_SEQ_4BITQ column: the mask is in the nibbles)
 hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes);
 void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
-void mdx_k_lowq_bitmap(const uint8_t *qual, int64_t n_bases, int minqual, uint32_t *out, int64_t n_words, hipStream_t s);
+// MDX_SEQ_4BIT -> MDX_SEQ_4BITQ: the bases whose quality is below minqual (qual, or the bitmap lowq if not null) complemented;
+// seq4_out may be seq4_in
+void mdx_k_fold_mask(const uint8_t *seq4_in, uint8_t *seq4_out, const uint8_t *qual, const uint8_t *lowq, int64_t n_bases, int minqual,
+                     hipStream_t s);
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
@@ -279,19 +278,16 @@ struct MdxLibSort {
     uint32_t *cigar;
     uint8_t *seq;            // 4-bit codes, (n_bases + 1) / 2 + 64 bytes, what lies behind the last kept base zero
     size_t seq_bytes;
-    uint32_t *lowq;          // the bitmap of MdxTabArgs::lowq in the new order, or null
-    size_t lowq_bytes;
-    uint32_t *qual_so;       // with lowq: the record's offset in the caller's SEQ / quality columns (MdxTabArgs::qual_so)
 };
 // bytes of the blob that holds all of it for a batch of n records (n_cigar operations, n_bases bases), and the pointers into one
-size_t mdx_k_libsort_bytes(int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, int with_lowq);
-void mdx_k_libsort_layout(void *blob, int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, int with_lowq, MdxLibSort *out);
+size_t mdx_k_libsort_bytes(int64_t n, int64_t n_cigar, int64_t n_bases, int nlib);
+void mdx_k_libsort_layout(void *blob, int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, MdxLibSort *out);
 // scratch of one sort
 size_t mdx_k_libsort_scratch_bytes(int64_t n, int nlib);
-// a batch (device columns, 4-bit SEQ; lowq: its bitmap of low qualities, 4-byte aligned, or null) -> out
+// a batch (device columns, 4-bit SEQ) -> out
 void mdx_k_libsort(int64_t n, int64_t n_cigar, int64_t n_bases, const uint16_t *flag, const uint16_t *lib, const int32_t *tid,
                    const int32_t *pos, const int32_t *tlen, const uint32_t *cigar_off, const uint32_t *cigar, const uint32_t *seq_off,
-                   const uint8_t *seq4, const uint8_t *lowq, int nlib, void *scratch, const MdxLibSort &out, hipStream_t s);
+                   const uint8_t *seq4, int nlib, void *scratch, const MdxLibSort &out, hipStream_t s);
 void mdx_k_finalize(const unsigned long long *raw, const unsigned long long *lgd_dense,
                     const unsigned long long *n_lgd_over, MdxDims d, unsigned long long *out,
                     hipStream_t s);
@@ -366,9 +362,9 @@ struct MdxGbamCols {
     // records that hold a quality below the threshold
     int minqual;
     uint32_t *counters;
-    // ... and, with a 4-bit SEQ column: the bitmap of the qualities below the threshold (mdx_batch::lowq: bit i = quality i of
-    // the column; zeroed beforehand, (n_bases + 31) / 32 words and two guard words), or null
-    uint32_t *lowq;
+    // ... and a 4-bit SEQ column takes the mask into its nibbles (MDX_SEQ_4BITQ: a base whose quality is below the threshold
+    // is stored as the complement of its code)
+    int fold;
 };
 size_t mdx_k_gbam_inflate_lds();
 hipError_t mdx_k_gbam_prepare();

@@ -448,6 +448,13 @@ __device__ __forceinline__ int cls4(u32 nib) {
     const bool one = nib != 0u && (nib & (nib - 1u)) == 0u;
     return one ? __ffs((int)nib) - 1 : (nib == SYM4_GAP ? SYM_GAP : SYM_OTHER);
 }
+// --min-basequal folded into the column (MDX_SEQ_4BITQ): a base whose quality is below the threshold is stored as the
+// complement of its code — three bits set: 14, 13, 11, 7 for A, C, T, G —, a symbol that is no base stays 0.  The code the
+// nibble stands for, and whether it is masked:
+__device__ __forceinline__ u32 unmask4(u32 nib, bool &masked) {
+    masked = __builtin_popcount(nib) == 3;
+    return masked ? nib ^ 15u : nib;
+}
 // nibbles [lo, hi) of a 64-bit word, the range clamped to [0, 16)
 __device__ __forceinline__ u64 nibble_range16(int lo, int hi) {
     lo = lo < 0 ? 0 : lo;
@@ -553,7 +560,9 @@ __global__ void unpack_seq_kernel(const u8 *__restrict__ in, u8 *__restrict__ ou
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const u32 nib = (in[i >> 1] >> (4 * (i & 1))) & 15u;
+        // (MDX_SEQ_4BITQ: a masked base is the complement of its code — the base it is; the qualities say the rest)
+        bool m;
+        const u32 nib = unmask4((in[i >> 1] >> (4 * (i & 1))) & 15u, m);
         const int c = cls4(nib);
         out[i] = c < 4 ? (u8)((0x47544341u >> (8 * c)) & 0xFFu) : (u8)'N';
     }
@@ -1281,7 +1290,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const int base_l = e0 + (p_strand ? nP_ : 0) + c_slot, lim_l = (p_strand ? nM_ : nP_) - c_slot;
                 // (one <3 x i32> load per operand: a struct of three words is taken apart and put together again as the
                 // vectorizer likes — two overlapping dwordx2 loads at times)
-                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; u32x2 lq; int k; bool valid; };
+                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
                 // (MDX_PK_ENT_AHEAD: the staging entry of a step is read from the LDS one fill ahead — LDS operations return in
                 // order, so a fill that reads its own entry waits, in front of its window loads, for that read and for the
                 // event writes of the step just counted)
@@ -1375,8 +1384,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     st.ra = ro << 2; st.sa = so << 2;
                     st.r = *(const u32v3_u *)(refW + ((ro >> 1) & ~3u));
                     st.s = *(const u32v3_u *)(seqW + ((so >> 1) & ~3u));
-                    // (--min-basequal: the sixteen bits of the lane's bases in the batch's bitmap of low qualities, see count16)
-                    if (MASK) st.lq = *(const u32x2_a4 *)(a.lowq + (((so - ph_seq) >> 5) << 2));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
 #if MDX_PK_ENT_AHEAD
                     { bool a_; ent_next = stg[ent_index(kf, a_)]; }
@@ -1397,15 +1404,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (RS && (KIND == STEP_GI || KIND == STEP_GD)) evw |= st.aux2 & 0x1FE00000u;
                     u32 by_lo = 0u, by_hi = 0u;     // RS, single-indel steps: the reference bases of the step's columns
                     u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
-                    // --min-basequal: bit i of MdxTabArgs::lowq = the quality of base i of the SEQ column is below the threshold;
-                    // mk64 = the lane's nibbles whose base is (the sixteen bits from its own SEQ window offset on; a step none of
-                    // whose lanes holds a low quality — clean data, vouched-for records — is the unmasked step)
+                    // --min-basequal: the mask is in the column itself (MDX_SEQ_4BITQ) — a base whose quality is below the threshold
+                    // is the complement of its code, three bits set, and every three of a nibble's four bits hold an adjacent
+                    // pair.  mk64 = the lane's nibbles that hold such a base, which are turned back into codes here; a step none
+                    // of whose lanes holds one — clean data — is the unmasked step
                     u64 mk64 = 0ull, behm = 0ull, ymk = 0ull;
                     bool has_m = false;
                     if (MASK) {
-                        const u32 mb = __builtin_amdgcn_alignbit(st.lq.y, st.lq.x, (st.sa >> 2) - ph_seq) & 0xFFFFu;
-                        has_m = __ballot(mb != 0u) != 0ull;
-                        if (has_m) mk64 = (u64)spread8(mb) | ((u64)spread8(mb >> 8) << 32);
+                        const u32 a_lo = s_lo & (s_lo >> 1) & 0x77777777u, a_hi = s_hi & (s_hi >> 1) & 0x77777777u;
+                        has_m = __ballot((a_lo | a_hi) != 0u) != 0ull;
+                        if (has_m) {
+                            const u32 m_lo = (a_lo | (a_lo >> 1) | (a_lo >> 2)) & 0x11111111u, m_hi = (a_hi | (a_hi >> 1) | (a_hi >> 2)) & 0x11111111u;
+                            const u32 k_lo = (m_lo << 4) - m_lo, k_hi = (m_hi << 4) - m_hi;
+                            s_lo ^= k_lo; s_hi ^= k_hi;
+                            mk64 = (u64)k_lo | ((u64)k_hi << 32);
+                        }
                     }
                     if (KIND == STEP_C) {
                         // (a nibble that is not a task has counters of its own, which nothing reads)
@@ -1773,9 +1786,20 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 
     // class of the read symbol at index i of the SEQ column / of the reference symbol at (concatenated) genome coordinate i,
     // which may lie in the guard bands — in either form of the two columns
+    // (PK with --min-basequal: the column holds masked bases as the complements of their codes — seq_cls gives the base,
+    // seq_msk says whether its quality was below the threshold)
     auto seq_cls = [&](const u32 i) -> int {
-        if (PK) return cls4(((u32)a.seq[i >> 1] >> (4u * (i & 1u))) & 15u);
+        if (PK) {
+            u32 nib = ((u32)a.seq[i >> 1] >> (4u * (i & 1u))) & 15u;
+            if (MASK) { bool m; nib = unmask4(nib, m); }
+            return cls4(nib);
+        }
         return classify_read(a.seq[i]);
+    };
+    auto seq_msk = [&](const u32 i) -> bool {
+        bool m;
+        unmask4(((u32)a.seq[i >> 1] >> (4u * (i & 1u))) & 15u, m);
+        return m;
     };
     auto ref_cls = [&](const i64 i) -> int {
         if (PK) { const i64 n = i + 256; return cls4(((u32)a.ref4[n >> 1] >> (4 * (int)(n & 1))) & 15u); }
@@ -1808,7 +1832,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         const int lg_lib = ML ? ml_lib : c_lib - a.lib_lo;
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
         int vlr = 0;   // gapped records: columns of the first / last match run, capped at L (vl | vr << 8)
-        u32 qd = 0u;        // ML with --min-basequal: the record's place in the quality column less its place in the SEQ column
         bool one = false;   // [H][S] M {I|D} M [S][H]: one indel between two match runs
         bool skips = false; // an N or P operation (or four and more indels)
         bool nonly = false; // gapped by N / P operations only
@@ -1957,10 +1980,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 w1 = rev | (simple ? D_SIMPLE : 0) | ((nbefore & 0xFF) << D_NB_SHIFT) | ((nafter & 0xFF) << D_NA_SHIFT);
                 if (simple && nq >= L && nbefore == A && nafter == A) w1 |= D_FULL;
                 // (flag bit 0x8000, include/mdx.h: the caller vouches that no quality of the record is below the threshold)
-                // (ML: the quality column stays in the caller's order — only its bitmap moves with the records; qd = what to add to
-                // an index of the reordered SEQ column to find the quality of that base)
-                if (ML && MASK) qd = p.qual_so[ri] - so;
-                if (MASK && !(fl & 0x8000u) && a.qual != nullptr && a.qual[so + qd] != 0xFF) w1 |= D_HASQ;
+                // (PK: the masks are in the SEQ column — no quality is read)
+                if (MASK && PK) w1 |= D_HASQ;
+                else if (MASK && !(fl & 0x8000u) && a.qual != nullptr && a.qual[so] != 0xFF) w1 |= D_HASQ;
                 // statistics.py:117-126
                 int kind = -1;
                 i64 flen = 0;
@@ -2166,7 +2188,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const int b_mis = lb + d.off_mis() + rev * 2 * L * 25;
             const int b_cmp = lb + d.off_cmp() + rev * 2 * L * 4;
             const int b_tc = lb + d.off_tc() + rev * 4 * d.t_pad;
-            const u8 *__restrict__ qp = MASK ? a.qual + (s_sq + ((ML && MASK) ? (u32)rl((int)qd, j) : 0u)) : nullptr;
+            const u8 *__restrict__ qp = (MASK && !PK) ? a.qual + s_sq : nullptr;
             // flank lengths: from the packed descriptor (A < 248 with the fast path), else recomputed
             int s_nb = (s_w1 >> D_NB_SHIFT) & 0xFF, s_na = (s_w1 >> D_NA_SHIFT) & 0xFF;
             if (!FAST) {
@@ -2225,7 +2247,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 int s = qi < 0 ? SYM_GAP : seq_cls(s_sq + (u32)qi);
                 int r = rix < 0 ? SYM_GAP : ref_cls(s_rbase + rix);
                 if (hasq) {
-                    const bool ms = qi >= 0 && (int)qp[qi] < a.minqual;
+                    const bool ms = qi >= 0 && (PK ? seq_msk(s_sq + (u32)qi) : (int)qp[qi] < a.minqual);
                     bool mr = ms;
                     if (jr != js) {
                         // mask of the *reference* column jr follows the read column jr
@@ -2244,7 +2266,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                                     c2 += len;
                                 }
                             }
-                            mr = qj >= 0 && (int)qp[qj] < a.minqual;
+                            mr = qj >= 0 && (PK ? seq_msk(s_sq + (u32)qj) : (int)qp[qj] < a.minqual);
                         }
                     }
                     if (ms) s = SYM_OTHER;
@@ -3064,31 +3086,43 @@ void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_byte
     else
     hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
-// --min-basequal for the packed kernel: bit i of `out` (32-bit words, bit i & 31 of word i / 32) = quality i is below the
-// threshold (align.py:65-71; 0xFF — no qualities — is not); one thread per word
-__global__ void lowq_bitmap_kernel(const u8 *__restrict__ qual, i64 n, u32 minq, u32 *__restrict__ out, i64 n_words) {
-    const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const i64 b0 = w * 32;
+// --min-basequal for the packed kernels: the mask folded into the 4-bit SEQ column (MDX_SEQ_4BIT -> MDX_SEQ_4BITQ,
+// include/mdx.h) — a base whose quality is below the threshold (align.py:65-71; 0xFF, no qualities, is not) becomes the
+// complement of its code, a symbol that is no base stays 0.  Eight bases per thread; the mask from the quality column or,
+// if the caller brings one, from its bitmap (mdx_batch::lowq: bit i = quality i is below the threshold).  In place or
+// into a copy.
+__global__ void fold_mask_kernel(const u8 *__restrict__ seq_in, u8 *__restrict__ seq_out, const u8 *__restrict__ qual,
+                                 const u8 *__restrict__ lowq, i64 n_bases, u32 minq) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 b0 = 8 * t;
+    if (b0 >= n_bases) return;
+    const i64 n_bytes = (n_bases + 1) / 2;
     u32 bits = 0u;
-    if (b0 + 32 <= n) {
-        const u32x4 v0 = *(const u32x4_u *)(qual + b0), v1 = *(const u32x4_u *)(qual + b0 + 16);
-        const u32 q[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (lowq) bits = lowq[t];
+    else if (b0 + 8 <= n_bases) {
+        const u32x2 q = *(const u32x2_u *)(qual + b0);
         const u32 m4 = minq * 0x01010101u;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            // bit 7 of a byte: its quality is below the threshold (qualities of 128 and more — 0xFF — never are)
-            const u32 low = ~((q[k] | 0x80808080u) - m4) & ~q[k] & 0x80808080u;
-            bits |= ((((low >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
-        }
+        const u32 l0 = ~((q.x | 0x80808080u) - m4) & ~q.x & 0x80808080u, l1 = ~((q.y | 0x80808080u) - m4) & ~q.y & 0x80808080u;
+        bits = ((((l0 >> 7) * 0x00204081u) >> 21) & 0xFu) | (((((l1 >> 7) * 0x00204081u) >> 21) & 0xFu) << 4);
     } else {
-        for (int k = 0; k < 32 && b0 + k < n; k++) bits |= (u32)(qual[b0 + k] < minq) << k;
+        for (int k = 0; k < 8 && b0 + k < n_bases; k++) bits |= (u32)(qual[b0 + k] < minq) << k;
     }
-    out[w] = bits;
+    u32 v = 0u;
+    const int nb = (int)(n_bytes - 4 * t < 4 ? n_bytes - 4 * t : 4);
+    if (nb == 4) v = *(const u32_u *)(seq_in + 4 * t);
+    else for (int k = 0; k < nb; k++) v |= (u32)seq_in[4 * t + k] << (8 * k);
+    // the nibbles that hold a base, and of them the masked ones: all four bits flipped
+    u32 nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;
+    nz = (nz << 4) - nz;
+    v ^= spread8(bits) & nz;
+    if (nb == 4) *(u32_u *)(seq_out + 4 * t) = v;
+    else for (int k = 0; k < nb; k++) seq_out[4 * t + k] = (u8)(v >> (8 * k));
 }
-void mdx_k_lowq_bitmap(const uint8_t *qual, int64_t n_bases, int minqual, uint32_t *out, int64_t n_words, hipStream_t s) {
-    if (n_words <= 0) return;
-    hipLaunchKernelGGL(lowq_bitmap_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, qual, (i64)n_bases, (u32)minqual, out, (i64)n_words);
+void mdx_k_fold_mask(const uint8_t *seq4_in, uint8_t *seq4_out, const uint8_t *qual, const uint8_t *lowq, int64_t n_bases, int minqual,
+                     hipStream_t s) {
+    if (n_bases <= 0) return;
+    const i64 n = (n_bases + 7) / 8;
+    hipLaunchKernelGGL(fold_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seq4_in, seq4_out, qual, lowq, (i64)n_bases, (u32)minqual);
 }
 
 hipError_t mdx_k_prepare_packed(size_t lds_bytes) {

@@ -5,7 +5,7 @@
 // ONE library's tables in the LDS and counts plain matches in registers, so it wants a library's records together: this
 // file turns a batch into a copy of itself ordered by library, batch order kept within a library, the flag filter of
 // reader.py:121-132 applied on the way (a record it drops has no place) — the per-record columns, and the CIGAR
-// operations, the 4-bit SEQ codes and (--min-basequal) the bitmap of low qualities they point at.  The bytes a record
+// operations and the 4-bit SEQ codes they point at (with --min-basequal the mask is in those codes, MDX_SEQ_4BITQ).  The bytes a record
 // points at move with it because a library's records, left where the file put them, are every n-th record of the
 // columns: with 128-byte requests a SEQ line (two or three records) and a CIGAR line (twenty) would cross the fabric once
 // per library that owns a record in it — measured with the columns alone bucketed: 8 libraries 1.63 x the time of one.
@@ -14,8 +14,7 @@
 // read row by row, which is at once the first place of every library and of every block's share of it; the scatter of
 // the fixed columns, one wavefront per block walking its records in order, the places of a step's records of one
 // library handed out by ballot; an exclusive scan of the CIGAR and SEQ lengths in their new order (the new offset
-// columns); and the copy, sixteen lanes per record — CIGAR words, SEQ nibbles and quality bits shifted from the phase
-// they had to the phase they get.  HBM-bound streaming work, about 100 bytes in and 100 out per record.
+// columns); and the copy — CIGAR words, and SEQ nibbles shifted from the phase they had to the phase they get.  HBM-bound streaming work, about 100 bytes in and 100 out per record.
 #include "mdx_internal.h"
 
 typedef uint8_t u8;
@@ -69,13 +68,13 @@ Scratch scratch_layout(void *p, i64 n, int nlib) {
 
 }  // namespace
 
-size_t mdx_k_libsort_bytes(int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, int with_lowq) {
+size_t mdx_k_libsort_bytes(int64_t n, int64_t n_cigar, int64_t n_bases, int nlib) {
     const size_t n1 = (size_t)(n > 0 ? n : 0) + 16;
     return 16 + align16((size_t)(nlib + 1) * 4) + align16(n1 * 4) * 6 + align16(n1 * 2) + align16((size_t)(n_cigar + 16) * 4) +
-           align16(((size_t)n_bases + 1) / 2 + 64) + (with_lowq ? align16(((size_t)n_bases + 31) / 32 * 4 + 8) + align16(n1 * 4) : 0) + 256;
+           align16(((size_t)n_bases + 1) / 2 + 64) + 256;
 }
 
-void mdx_k_libsort_layout(void *blob, int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, int with_lowq, MdxLibSort *out) {
+void mdx_k_libsort_layout(void *blob, int64_t n, int64_t n_cigar, int64_t n_bases, int nlib, MdxLibSort *out) {
     const size_t n1 = (size_t)(n > 0 ? n : 0) + 16;
     u8 *p = (u8 *)blob;
     out->bad = (unsigned long long *)p; p += 16;
@@ -88,12 +87,8 @@ void mdx_k_libsort_layout(void *blob, int64_t n, int64_t n_cigar, int64_t n_base
     out->seq_off = (u32 *)p; p += align16(n1 * 4);
     out->flag = (u16 *)p; p += align16(n1 * 2);
     out->cigar = (u32 *)p; p += align16((size_t)(n_cigar + 16) * 4);
-    out->seq = p; p += align16(((size_t)n_bases + 1) / 2 + 64);
+    out->seq = p;
     out->seq_bytes = ((size_t)n_bases + 1) / 2 + 64;
-    out->lowq = with_lowq ? (u32 *)p : nullptr;
-    out->lowq_bytes = with_lowq ? ((size_t)n_bases + 31) / 32 * 4 + 8 : 0;
-    p += align16(out->lowq_bytes);
-    out->qual_so = with_lowq ? (u32 *)p : nullptr;
 }
 
 size_t mdx_k_libsort_scratch_bytes(int64_t n, int nlib) {
@@ -214,7 +209,6 @@ __global__ __launch_bounds__(64) void libsort_scatter_kernel(i64 n, i64 per, con
             // tabulation kernel's to report)
             out.cigar_off[dst] = c1 >= c0 ? c1 - c0 : 0u; out.seq_off[dst] = s1 >= s0 ? s1 - s0 : 0u;
             src_co[dst] = c0; src_so[dst] = s0;
-            if (out.qual_so) out.qual_so[dst] = s0;
         }
     }
 }
@@ -269,12 +263,11 @@ __global__ __launch_bounds__(256) void libsort_blockscan_kernel(const u32 *__res
 // whose first nibble lies in the stretch, finds the record that nibble belongs to among the 64 offsets in the LDS, and
 // funnels the nibbles of that record (and, at a border, of the next ones) out of the source column from nibble
 // src + ph on (ph: the nibbles between the dword-aligned base and the column's first one).  Whole dwords, plain stores, the
-// loads of a lane independent of one another.  The bits of the low-quality bitmap likewise, 32 to a word.
+// loads of a lane independent of one another.
 #define LS_COPY_WAVES 4
 __global__ __launch_bounds__(64 * LS_COPY_WAVES) void libsort_copy_kernel(const u32 *__restrict__ kept_p, const u32 *__restrict__ src_co,
                                                                           const u32 *__restrict__ src_so, const u32 *__restrict__ cigar,
-                                                                          const u32 *__restrict__ seq32, u32 ph, const u32 *__restrict__ lowq,
-                                                                          MdxLibSort out) {
+                                                                          const u32 *__restrict__ seq32, u32 ph, MdxLibSort out) {
     __shared__ u32 s_off[LS_COPY_WAVES][72], s_src[LS_COPY_WAVES][72];
     const i64 kept = *kept_p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -343,27 +336,6 @@ __global__ __launch_bounds__(64 * LS_COPY_WAVES) void libsort_copy_kernel(const 
             }
             oseq[j] = v;
         }
-        if (lowq) {
-            for (u64 j = ((D0 + 31) >> 5) + (u32)lane; j * 32 < D1; j += 64) {
-                const u64 w_lo = j * 32, w_hi = w_lo + 32;
-                int i = find(w_lo);
-                u32 v = 0u;
-                u64 x = w_lo;
-                while (x < w_hi) {
-                    u64 e = off_at(i + 1);
-                    while (e <= x && r0 + i + 1 < kept) { i++; e = off_at(i + 1); }
-                    if (e <= x) break;
-                    const u32 take = (u32)((e < w_hi ? e : w_hi) - x);
-                    const u64 sb = src_at(i) + (x - off_at(i));
-                    const u32 w0 = lowq[sb >> 5], w1 = lowq[(sb >> 5) + 1];
-                    u32 bits = __builtin_amdgcn_alignbit(w1, w0, (u32)(sb & 31));
-                    if (take < 32u) bits &= (1u << take) - 1u;
-                    v |= bits << (u32)(x - w_lo);
-                    x += take;
-                }
-                out.lowq[j] = v;
-            }
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -371,7 +343,7 @@ __global__ __launch_bounds__(64 * LS_COPY_WAVES) void libsort_copy_kernel(const 
 
 void mdx_k_libsort(int64_t n, int64_t n_cigar, int64_t n_bases, const uint16_t *flag, const uint16_t *lib, const int32_t *tid,
                    const int32_t *pos, const int32_t *tlen, const uint32_t *cigar_off, const uint32_t *cigar, const uint32_t *seq_off,
-                   const uint8_t *seq4, const uint8_t *lowq, int nlib, void *scratch, const MdxLibSort &out, hipStream_t s) {
+                   const uint8_t *seq4, int nlib, void *scratch, const MdxLibSort &out, hipStream_t s) {
     const Geometry g = geometry(n, nlib);
     const Scratch sc = scratch_layout(scratch, n, nlib);
     const i64 m = (i64)g.nblk * nlib;
@@ -379,7 +351,6 @@ void mdx_k_libsort(int64_t n, int64_t n_cigar, int64_t n_bases, const uint16_t *
     (void)hipMemsetAsync(out.bad, 0xFF, 8, s);
     // (what lies behind the last kept base stays zero)
     (void)hipMemsetAsync(out.seq, 0, out.seq_bytes, s);
-    if (out.lowq) (void)hipMemsetAsync(out.lowq, 0, out.lowq_bytes, s);
     hipLaunchKernelGGL(libsort_count_kernel, dim3(g.nblk), dim3(LS_COUNT_THREADS), 0, s, (i64)n, g.per, flag, lib, nlib, g.nblk, sc.cnt,
                        (u64 *)out.bad);
     hipLaunchKernelGGL(libsort_scan_kernel, dim3(1), dim3(1024), 0, s, sc.cnt, m);
@@ -397,6 +368,5 @@ void mdx_k_libsort(int64_t n, int64_t n_cigar, int64_t n_bases, const uint16_t *
     const u32 *const seq32 = (const u32 *)(seq4 - ((size_t)seq4 & 3));
     const i64 tiles = (n + 64 * LS_COPY_WAVES - 1) / (64 * LS_COPY_WAVES);
     const unsigned cgrid = (unsigned)(tiles < 8192 ? (tiles > 0 ? tiles : 1) : 8192);
-    hipLaunchKernelGGL(libsort_copy_kernel, dim3(cgrid), dim3(64 * LS_COPY_WAVES), 0, s, kept_p, sc.src_co, sc.src_so, cigar, seq32, ph,
-                       (const u32 *)(out.lowq ? lowq : nullptr), out);
+    hipLaunchKernelGGL(libsort_copy_kernel, dim3(cgrid), dim3(64 * LS_COPY_WAVES), 0, s, kept_p, sc.src_co, sc.src_so, cigar, seq32, ph, out);
 }

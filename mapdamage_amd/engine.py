@@ -39,7 +39,7 @@ EXPORTS = (
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
 )
 
-SEQ_ASCII, SEQ_4BIT = 0, 1      # include/mdx.h MDX_SEQ_*
+SEQ_ASCII, SEQ_4BIT, SEQ_4BITQ = 0, 1, 2      # include/mdx.h MDX_SEQ_*
 
 
 class MdxConfig(ctypes.Structure):
@@ -281,7 +281,7 @@ class DamageEngine:
 
     def upload(self, batch: ReadBatch, packed=None) -> DeviceBatch:
         """Resident copy of a host batch; ``packed``: with the SEQ column in its 4-bit form (``pack_seq``), which the
-        tabulation (plain, with ``--min-basequal`` — the bitmap of the low qualities is built here, ``mdx_batch::lowq`` —
+        tabulation (plain, with ``--min-basequal`` — the mask is folded into the column here, ``MDX_SEQ_4BITQ`` —
         or with the rescaling fused in) then reads through the packed kernels."""
         hb = _host_batch(batch, self.default_packed if packed is None else packed)
         dev = MdxBatch()

@@ -491,11 +491,12 @@ def test_min_basequal_on_the_device_path(tmp_path):
     assert res["q0"] == res["qlow"]
 
 
-def test_the_device_decoder_hands_over_the_bitmap_of_the_low_qualities(tmp_path):
-    """--min-basequal on the device path: the unpack kernel sees every quality byte and writes the bitmap the packed masked
-    kernel reads (mdx_batch::lowq; align.py:65-71: bit i = quality i of the column is below the threshold, 0xFF — no
-    qualities — is not) with the columns; no pass over the quality column in front of the launches.  Held against the
-    quality column of the same view, slab by slab, with several libraries (the launches reorder batch and bitmap)."""
+def test_the_device_decoder_folds_the_mask_into_the_seq_column(tmp_path):
+    """--min-basequal on the device path: the unpack kernel sees every quality byte and writes the SEQ column the packed
+    masked kernel reads (MDX_SEQ_4BITQ, include/mdx.h; align.py:65-71: a base whose quality is below the threshold is stored
+    as the complement of its code, 0xFF — no qualities — is not below any threshold) — no pass over the quality column in
+    front of the launches.  Held against the quality column of the same view, slab by slab, with several libraries (the
+    launches order batch and mask by library)."""
     from mapdamage_amd.engine import DamageEngine
     from tests.util import assert_tables_equal, oracle_tableset
     ref, b, rg, path = _write(tmp_path, n=25_000, seed=12)
@@ -507,6 +508,9 @@ def test_the_device_decoder_hands_over_the_bitmap_of_the_low_qualities(tmp_path)
     b.lib = np.array([lib_of[r] for r in rg], np.uint16)
     Q = 22
     want = oracle_tableset(ref, b, libs, 70, 10, Q)
+    lut = np.zeros(256, np.uint8)
+    lut[ord("A")], lut[ord("C")], lut[ord("T")], lut[ord("G")] = 1, 2, 4, 8
+    at = 0
     with DamageEngine(libs, 70, 10, Q) as eng:
         eng.set_reference(ref)
         with sam.GpuBamStream(eng, str(path), readgroups=list(lib_of.items()), chunk_bytes=1 << 19, want_qual=True, min_basequal=Q) as g:
@@ -516,13 +520,15 @@ def test_the_device_decoder_hands_over_the_bitmap_of_the_low_qualities(tmp_path)
                 view = g.next_view()
                 if view is None:
                     break
-                assert view.qual and view.lowq
+                assert view.qual and view.seq_format == 2 and not view.lowq
                 nb = int(view.n_bases)
                 qual = _d2h(view.qual, nb, np.uint8)
-                bits = _d2h(view.lowq, (nb + 31) // 32 + 2, np.uint32)
-                expect = np.zeros(((nb + 31) // 32 + 2) * 32, np.uint8)
-                expect[:nb] = qual < Q
-                np.testing.assert_array_equal(np.unpackbits(bits.view(np.uint8), bitorder="little"), expect)
+                nib = _d2h(view.seq, (nb + 1) // 2, np.uint8)
+                codes = np.stack([nib & 15, nib >> 4], axis=1).reshape(-1)[:nb]
+                plain = lut[b.seq[at:at + nb]]
+                expect = np.where((qual < Q) & (plain != 0), plain ^ 15, plain)
+                np.testing.assert_array_equal(codes, expect)
+                at += nb
                 eng.tabulate_view(view)
                 slabs += 1
             got = eng.finish()

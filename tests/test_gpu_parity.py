@@ -228,7 +228,7 @@ def test_hip_one_pass_over_the_libraries_with_min_basequal(mid_genome):
     with DamageEngine(libs, 70, 10, 20, lgd_max=300) as eng:
         eng.set_reference(mid_genome)
         dev = eng.upload(batch, packed=True)
-        assert dev.dev.libsort and dev.dev.lowq
+        assert dev.dev.libsort and dev.dev.seq_format == 2      # (MDX_SEQ_4BITQ: the mask is in the column, ordered with it)
         eng.tabulate(dev)
         got = eng.finish()
         assert eng.packed_launches() == 1 and eng.libsorts() == 0
@@ -309,36 +309,65 @@ def test_hip_path_of_a_reference_of_4_gbases_and_more(mid_genome, monkeypatch, Q
     assert_tables_equal(got, want)
 
 
-def test_hip_min_basequal_bitmap_with_the_batch_or_per_launch(mid_genome):
-    """--min-basequal through the packed masked kernel: the bitmap of the qualities below the threshold travels with a
-    batch that mdx_batch_upload made (mdx_batch::lowq) — or, for a batch without one (the device decode's views), is
-    built in front of the launch; both against the oracle, with half of the bases masked and with none."""
-    import copy
+def test_hip_min_basequal_mask_in_the_column_or_folded_per_launch(mid_genome):
+    """The packed masked kernel reads the mask from the SEQ column itself (MDX_SEQ_4BITQ, include/mdx.h: a base whose quality
+    is below the threshold is the complement of its code; align.py:65-71).  A batch uploaded to a context with a
+    --min-basequal is such a column; a MDX_SEQ_4BIT batch with qualities (a caller's own: here uploaded through a context
+    without a threshold) is folded into a scratch column in front of every launch — from its qualities, or from the
+    caller's bitmap of them (mdx_batch::lowq).  All against the oracle, with half of the bases masked and with none."""
     import ctypes
 
+    from mapdamage_amd.batch import ReadBatch
     from mapdamage_amd.engine import DamageEngine, MdxBatch
     batch = synth.make_reads(mid_genome, 50_000, 17, len_range=(25, 160), paired=True, frac_softclip=0.15, frac_ins=0.06,
                              frac_del=0.06, frac_skip=0.01, with_qual=True, frac_filtered=0.03)
     libs = [("s", "l")]
-    for Q in (20, 1):
-        want = oracle_tableset(mid_genome, batch, libs, 70, 10, Q)
-        with DamageEngine(libs, 70, 10, Q) as eng:
+    with DamageEngine(libs, 70, 10, 0) as eng0:
+        eng0.set_reference(mid_genome)
+        plain = eng0.upload(batch, packed=True)
+        assert plain.dev.seq_format == 1 and plain.dev.qual
+        for Q in (20, 1):
+            want = oracle_tableset(mid_genome, batch, libs, 70, 10, Q)
+            with DamageEngine(libs, 70, 10, Q) as eng:
+                eng.set_reference(mid_genome)
+                db = eng.upload(batch, packed=True)
+                assert db.dev.seq_format == 2 and not db.dev.lowq       # (folded at upload: the context has a --min-basequal)
+                eng.tabulate(db)
+                got_resident = eng.finish()
+                assert eng.packed_launches() == 1
+                eng.reset()
+                view = MdxBatch()
+                ctypes.memmove(ctypes.byref(view), ctypes.byref(plain.dev), ctypes.sizeof(MdxBatch))
+                eng.tabulate_view(view)                 # (folded in front of the launch, from the quality column)
+                got_per_launch = eng.finish()
+                assert eng.packed_launches() == 2
+                eng.reset()
+                # ... and from the caller's bitmap (its bytes brought to the device as the `seq` column of an ASCII upload)
+                bits = np.packbits(batch.qual < Q, bitorder="little")
+                carrier = ReadBatch(np.zeros(1, np.uint16), np.zeros(1, np.uint16), np.zeros(1, np.int32), np.zeros(1, np.int32),
+                                    np.zeros(1, np.int32), np.array([0, 0], np.uint32), np.zeros(0, np.uint32),
+                                    np.array([0, bits.shape[0]], np.uint32), bits, None)
+                dbits = eng.upload(carrier, packed=False)
+                view.lowq = dbits.dev.seq
+                view.qual = plain.dev.qual
+                eng.tabulate_view(view)
+                got_bitmap = eng.finish()
+                dbits.free()
+                db.free()
+            assert_tables_equal(got_resident, want)
+            assert_tables_equal(got_per_launch, want)
+            assert_tables_equal(got_bitmap, want)
+        # (a context without a threshold refuses a column that carries one)
+        with DamageEngine(libs, 70, 10, 20) as eng:
             eng.set_reference(mid_genome)
             db = eng.upload(batch, packed=True)
-            assert db.dev.lowq                      # (built at upload: the context has a --min-basequal)
-            eng.tabulate(db)
-            got_resident = eng.finish()
-            assert eng.packed_launches() == 1
-            eng.reset()
             view = MdxBatch()
             ctypes.memmove(ctypes.byref(view), ctypes.byref(db.dev), ctypes.sizeof(MdxBatch))
-            view.lowq = None                        # (a batch that does not bring its bitmap)
-            eng.tabulate_view(view)
-            got_per_launch = eng.finish()
-            assert eng.packed_launches() == 2
+            from mapdamage_amd.engine import MdxError
+            with pytest.raises(MdxError, match="MDX_SEQ_4BITQ"):
+                eng0.tabulate_view(view)
             db.free()
-        assert_tables_equal(got_resident, want)
-        assert_tables_equal(got_per_launch, want)
+        plain.free()
 
 
 def test_hip_rejects_alignment_past_contig_end():
