@@ -80,8 +80,8 @@ typedef struct {
 #define MDX_SEQ_4BIT 1
 /*   MDX_SEQ_4BITQ  MDX_SEQ_4BIT with --min-basequal folded in (align.py:53-73: a read column whose quality is below the
  *                  threshold turns into N / N — it counts its read base in the composition table, statistics.py:100-103, and
- *                  nothing else): a base whose quality is below the CONTEXT's threshold is stored as the complement of its
- *                  code (14, 13, 11, 7 for A, C, T, G), every other nibble as in MDX_SEQ_4BIT.  The packed masked kernel reads
+ *                  nothing else): a symbol whose quality is below the CONTEXT's threshold is stored as the complement of its
+ *                  code (14, 13, 11, 7 for A, C, T, G; 15 for a symbol that is no base), every other nibble as in MDX_SEQ_4BIT.  The packed masked kernel reads
  *                  nothing but this column — no quality byte, no bitmap.  Made by the library: mdx_batch_upload and the device
  *                  decoder (mdx_gbam_set_min_basequal) hand such a column over when the context has a --min-basequal,
  *                  mdx_tabulate_host folds on the copy stream; a MDX_SEQ_4BIT batch with qualities (or a bitmap, `lowq`) is

@@ -623,8 +623,14 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             // (a pool takes chunks of MDX_POOL_CHUNK tiles, the pools' chunks interleaved: at most one chunk more than its share)
             const int64_t chunk = MDX_POOL_CHUNK;
             const int64_t pool_tiles = ((n_tiles + n_pools * chunk - 1) / (n_pools * chunk)) * chunk, pool_waves = (grid / n_pools) * wpb_l;
-            a.tile_quota = (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2);
-            a.list_cap = (int64_t)a.tile_quota * T + 128;
+            // (the fused kernels and the epoch launches are held to a quota — their rings, and the fused kernels' lists of records
+            // left to the rescale kernels, are sized by it; the others work in rounds with rings of a fixed size)
+            const bool quota = fuse || ml;
+            a.tile_quota = quota ? (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2) : 0x7FFFFFFF;
+            a.list_cap = fuse ? (int64_t)a.tile_quota * T + 128 : 0;
+            a.round_tiles = MDX_ROUND_TILES;
+            a.ring_size = MDX_RING;
+            if (quota) while ((int64_t)a.ring_size < (int64_t)a.tile_quota * T + 128) a.ring_size *= 2;
             if (!c->d_tile_ctr) {
                 HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)65536 * 4));
                 HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)65536 * 4, c->stream));
@@ -632,13 +638,12 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             if (n_pools > 4096 || n_pools * (ml ? gn : 1) > 65536) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
             a.tile_ctr = c->d_tile_ctr;
             {
-                // (scratch of the launch: 88 bytes per record a wavefront may be handed — twice its even share —, 180 bytes
-                // per record of the batch, of which the kernel touches a dozen; a batch the device cannot give that to is
-                // one to split, and the caller is told so)
-                const size_t list_bytes = (size_t)nwaves * (size_t)MDX_LIST_STRIDE(a.list_cap) * 16;
+                // (scratch of the launch: rings of 81 KB per wavefront — 330 MB for the packed kernel's 4096 wavefronts —, whatever the
+                // batch; the fused kernels and the epoch launches: 150 bytes per record of the batch)
+                const size_t list_bytes = (size_t)nwaves * (size_t)MDX_WAVE_SCRATCH(a.ring_size) * 16;
                 if (c->lists.reserve(list_bytes) != hipSuccess)
-                    return fail(c, MDX_ERR_HIP, "the per-wavefront lists of this launch (" + std::to_string(list_bytes >> 20) + " MiB for " +
-                                std::to_string(b->n_reads) + " records) could not be allocated: tabulate the batch in smaller pieces");
+                    return fail(c, MDX_ERR_HIP, "the per-wavefront lists of this launch (" + std::to_string(list_bytes >> 20) + " MiB) could not be allocated" +
+                                (quota ? ": tabulate the batch in smaller pieces" : ""));
             }
             a.lists = (uint4 *)c->lists.p;
         }

@@ -216,7 +216,7 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
             for (u32 i = 0; i < nb; i++) {
                 const u32 byte = q[4u * k + (i >> 1)];
                 u32 cd = code((i & 1u) ? (byte & 15u) : (byte >> 4));
-                if (c.fold && cd && qq[8u * k + i] < (u32)c.minqual) cd ^= 15u;
+                if (c.fold && qq[8u * k + i] < (u32)c.minqual) cd ^= 15u;
                 v |= cd << (4u * i);
             }
             const u32 n0 = so + 8u * k, sh = 4u * (n0 & 7u);

@@ -136,7 +136,14 @@ struct MdxFuse {
                                 // reference-base counts, the lookup table and the terms (mdx_k_fuse_lds_bytes)
 };
 
-#define MDX_LIST_STRIDE(cap) (5 * (cap) + 3 * ((cap) / 4 + 1))
+// A wavefront's part of MdxTabArgs::lists, in 16-byte entries — rings, the same size whatever the batch (tabulate_kernel):
+// four lists of MDX_RING staging entries (partial records, single insertions, single deletions, the complete records the
+// general pass finds), MDX_DRING records waiting for the general pass (two entries of columns and an index each), and three
+// rings of record indices for the fused kernels
+#define MDX_RING 1024
+#define MDX_ROUND_TILES 14      // a round appends its records (63 x 14) and the < 64 that waited for the general pass, < 63 entries are left over: <= MDX_RING
+#define MDX_DRING 128
+#define MDX_WAVE_SCRATCH(ring) (4 * (ring) + 2 * MDX_DRING + MDX_DRING / 4 + 3 * ((ring) / 4))
 struct MdxTabArgs {
     // batch (device pointers)
     int64_t n_reads;
@@ -174,20 +181,22 @@ struct MdxTabArgs {
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
-    // Per-wavefront lists (16-byte staging entries): wavefront w owns MDX_LIST_STRIDE(list_cap) entries (the last two
-    // stretches of list_cap / 4 + 1: the fused kernels' record indices of the partial list, and the packed fused kernel's
-    // of the single-indel lists) — partial
-    // records upwards from 0, single insertions upwards from list_cap, single deletions downwards from 2 list_cap - 1,
-    // the complete records the general pass finds upwards from 2 list_cap, from 3 list_cap on the columns (two entries
-    // per record) and from 5 list_cap on the indices (u32) of the records the tile loop leaves to the general pass;
-    // list_cap >= the records a wavefront classifies.  Written in the tile loop, read back by the same wavefront.
+    // Per-wavefront lists: wavefront w owns MDX_WAVE_SCRATCH(ring_size) 16-byte entries (rings: see above and the kernel).
+    // Written in the tile loop, read back by the same wavefront at the end of its round.  ring_size (a power of two): MDX_RING —
+    // 81 KB per wavefront whatever the batch — for the kernels that work in rounds; for the fused kernels and the epoch
+    // launches, which do not, what a wavefront's tile_quota of tiles can append.
     uint4 *lists;
+    int ring_size;
+    // (the fused kernels: entries of a wavefront's list of records left to the rescale kernels, MdxFuse::gen_list — the
+    // records of tile_quota tiles)
     int64_t list_cap;
     MdxFuse rs;                      // used by the fused kernel only
     // Fast kernels: tiles are handed out on demand within pools of two blocks (the two that share a CU): one counter per
-    // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (list_cap holds their records)
+    // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (the fused kernels and the epoch launches —
+    // per epoch —: their rings, and the fused kernels' list_cap, hold the records of that many; the others: no limit)
     uint32_t *tile_ctr;
     int tile_quota;
+    int round_tiles;                 // tiles of a round (MDX_ROUND_TILES; the list rings hold a round's entries)
     // Several libraries in one launch of the packed kernel (tabulate_kernel<.., PK, ML>; n_epochs > 0): the batch above is the
     // copy of mdx_libsort.hip, ordered by library — place i holding one kept record (the flag filter of reader.py:121-132
     // applied on the way), the records of library l at places [lib_start[l], lib_start[l + 1]) in batch order, CIGAR, SEQ and

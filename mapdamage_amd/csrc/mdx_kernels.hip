@@ -448,11 +448,12 @@ __device__ __forceinline__ int cls4(u32 nib) {
     const bool one = nib != 0u && (nib & (nib - 1u)) == 0u;
     return one ? __ffs((int)nib) - 1 : (nib == SYM4_GAP ? SYM_GAP : SYM_OTHER);
 }
-// --min-basequal folded into the column (MDX_SEQ_4BITQ): a base whose quality is below the threshold is stored as the
-// complement of its code — three bits set: 14, 13, 11, 7 for A, C, T, G —, a symbol that is no base stays 0.  The code the
-// nibble stands for, and whether it is masked:
+// --min-basequal folded into the column (MDX_SEQ_4BITQ): a symbol whose quality is below the threshold is stored as the
+// complement of its code — three bits set: 14, 13, 11, 7 for A, C, T, G; all four for a symbol that is no base (its mask
+// matters too: behind an N operation align.py:65-71 masks the reference symbol of the same LEFT index, which pairs with
+// another read symbol from the right end).  The code the nibble stands for, and whether it is masked:
 __device__ __forceinline__ u32 unmask4(u32 nib, bool &masked) {
-    masked = __builtin_popcount(nib) == 3;
+    masked = __builtin_popcount(nib) >= 3;
     return masked ? nib ^ 15u : nib;
 }
 // nibbles [lo, hi) of a 64-bit word, the range clamped to [0, 16)
@@ -1404,9 +1405,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (RS && (KIND == STEP_GI || KIND == STEP_GD)) evw |= st.aux2 & 0x1FE00000u;
                     u32 by_lo = 0u, by_hi = 0u;     // RS, single-indel steps: the reference bases of the step's columns
                     u64 dmk = 0ull;         // STEP_GD: the nibbles behind the deletion, counted by position
-                    // --min-basequal: the mask is in the column itself (MDX_SEQ_4BITQ) — a base whose quality is below the threshold
-                    // is the complement of its code, three bits set, and every three of a nibble's four bits hold an adjacent
-                    // pair.  mk64 = the lane's nibbles that hold such a base, which are turned back into codes here; a step none
+                    // --min-basequal: the mask is in the column itself (MDX_SEQ_4BITQ) — a symbol whose quality is below the threshold
+                    // is the complement of its code, three or four bits set, and every three of a nibble's four bits hold an
+                    // adjacent pair.  mk64 = the lane's nibbles that hold such a base, which are turned back into codes here; a step none
                     // of whose lanes holds one — clean data — is the unmasked step
                     u64 mk64 = 0ull, behm = 0ull, ymk = 0ull;
                     bool has_m = false;
@@ -1769,19 +1770,34 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
     // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
     const MdxTabArgs *const ka = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    // Regions of the wavefront's part of MdxTabArgs::lists (16-byte entries; `cap` = list_cap):
-    //   [0, cap)        partial records, upwards            [cap, 2 cap)  single insertions upwards / deletions downwards
-    //   [2 cap, 3 cap)  complete records found by the general pass, upwards
-    //   [3 cap, 5 cap)  the columns (two entries each) of the records the tile loop leaves to the general pass,
-    //   [5 cap, ...)    and their indices (u32)
-    //   [5 cap + cap / 4 + 1, ...)  RS: the record index of every entry of the partial list (u32),
-    //   [5 cap + 2 (cap / 4 + 1), ...)  RS, PK: of every single-indel entry (by its place in [cap, 2 cap))
-    uint4 *const lists = a.lists + (i64)gwave * MDX_LIST_STRIDE(a.list_cap);
-    uint4 *const dcols = lists + 3 * a.list_cap;
-    u32 *const dlist = (u32 *)(lists + 5 * a.list_cap);
-    u32 *const lri = (u32 *)(lists + 5 * a.list_cap + a.list_cap / 4 + 1);
-    u32 *const lri_g = (u32 *)(lists + 5 * a.list_cap + 2 * (a.list_cap / 4 + 1));
-    int lP = 0, lI = 0, lD = 0, lC = 0;
+    // The wavefront's part of MdxTabArgs::lists (MDX_WAVE_SCRATCH(ring_size) 16-byte entries): rings.
+    //   ringP / ringI / ringD / ringC   MDX_RING entries each: partial records, single insertions, single deletions, the
+    //                                   complete records the general pass finds.  A list is emptied at the end of a round
+    //                                   of the tile loop (MdxTabArgs::round_tiles tiles), whole passes of 63 entries; a round
+    //                                   appends at most its records, 63 round_tiles, and fewer than 63 are left over.
+    //   dcols / dlist                   MDX_DRING records the tile loop leaves to the general pass (their columns, two entries
+    //                                   each, and their indices): taken 64 at a time as soon as 64 wait — fewer than 127 do
+    //   lri / lriI / lriD               RS: the record index of every entry of ringP (and, PK, of ringI / ringD)
+    // l* = entries appended so far, h* = entries taken so far (entry k of a ring sits at k & (size - 1)).  Written with plain
+    // stores and read back by the same wavefront past the vector L1 (ring_at: a line of a ring may sit there from the
+    // turn before).
+    // (the rings' size is the launch's: MDX_RING for the kernels that work in rounds; the fused kernels and the epoch launches —
+    // ROUNDS false: their registers do not take the loop of rounds around the tile loop, measured: config 5 -6 %, 8 libraries
+    // -4 % — keep one round and rings that hold what a wavefront's quota of tiles can append)
+    constexpr bool ROUNDS = !(RS || ML);
+    constexpr u32 DM = MDX_DRING - 1;
+    const u32 RM = (u32)a.ring_size - 1u;
+    uint4 *const lists = a.lists + (i64)gwave * MDX_WAVE_SCRATCH(a.ring_size);
+    uint4 *const ringP = lists, *const ringI = lists + a.ring_size, *const ringD = lists + 2 * a.ring_size, *const ringC = lists + 3 * a.ring_size;
+    uint4 *const dcols = lists + 4 * a.ring_size;
+    u32 *const dlist = (u32 *)(lists + 4 * a.ring_size + 2 * MDX_DRING);
+    u32 *const lri = dlist + MDX_DRING, *const lriI = lri + a.ring_size, *const lriD = lriI + a.ring_size;
+    u32 lP = 0, lI = 0, lD = 0, lC = 0, hP = 0, hI = 0, hD = 0, hC = 0;
+    auto ring_u32 = [](const u32 *p) -> u32 { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ring_at = [&](const uint4 *p) -> uint4 {
+        const u32 *q = (const u32 *)p;
+        return make_uint4(ring_u32(q), ring_u32(q + 1), ring_u32(q + 2), ring_u32(q + 3));
+    };
     u32 n_rs = 0;           // RS: records left to the rescale kernels behind this one
 
     // class of the read symbol at index i of the SEQ column / of the reference symbol at (concatenated) genome coordinate i,
@@ -2116,8 +2132,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             todo_g = todo_all & ~(mF | mPp | mS | __ballot(covered));
             if (mF) {
                 // complete records (soft-clipped ones, mostly): counted behind the tile loop like the other lists
-                if (isF) lists[2 * a.list_cap + lC + mbcnt64(mF, 0)] = ent;
-                lC += nF;
+                if (isF) ringC[(lC + (u32)mbcnt64(mF, 0)) & RM] = ent;
+                lC += (u32)nF;
             }
             if (mP | mS) {
                 // The steps of these records zero the reference bytes that are not their tasks (or, behind a deletion,
@@ -2147,12 +2163,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         if (er < L) atomicAdd(&lds[dr + A + er], 1u);
                     }
                 }
-                i64 at = -1;
-                if ((plain && !isF) || (gpre && !isS)) at = lP + mbcnt64(mP, 0);
-                else if (isS) at = isD ? 2 * a.list_cap - 1 - (lD + mbcnt64(mS & ~mSI, 0)) : a.list_cap + lI + mbcnt64(mSI, 0);
-                if (at >= 0) lists[at] = ent;
-                if (RS && PK && isS) lri_g[at - a.list_cap] = ri;      // (the record of a single-indel entry: where its MR goes)
-                lP += nP; lI += nSI; lD += nS - nSI;
+                if ((plain && !isF) || (gpre && !isS)) ringP[(lP + (u32)mbcnt64(mP, 0)) & RM] = ent;
+                else if (isS) {
+                    const u32 at = isD ? (lD + (u32)mbcnt64(mS & ~mSI, 0)) & RM : (lI + (u32)mbcnt64(mSI, 0)) & RM;
+                    (isD ? ringD : ringI)[at] = ent;
+                    if (RS && PK) (isD ? lriD : lriI)[at] = ri;      // (the record of a single-indel entry: where its MR goes)
+                }
+                lP += (u32)nP; lI += (u32)nSI; lD += (u32)(nS - nSI);
             }
         }
 
@@ -2357,8 +2374,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // out in advance the block dispatched first ran 30 % ahead of the other, and within a block the older wavefronts
         // ahead of the younger — the launch ended with a third of its time spent on half-empty CUs
         // (tools/experiments/wave_clk.py).  A wavefront asks for a tile two tiles before it starts it (the answer comes
-        // back under a tile's work) and takes at most tile_quota of them: its lists are sized for that many, and the
-        // quotas of a pool's wavefronts add up to twice its tiles.
+        // back under a tile's work) and — RS, whose list of records left to the rescale kernels is sized for that many — takes
+        // at most tile_quota of them (the quotas of a pool's wavefronts add up to twice its tiles).
         const u32 n_tiles = (n_rec + T - 1) / T;
         const u32 n_pools = (gridDim.x >= 2u && !(gridDim.x & 1u)) ? gridDim.x / 2u : gridDim.x;
         const u32 pool = blockIdx.x % n_pools;
@@ -2428,11 +2445,56 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const u32 tb0 = cur * T, rh0 = tb0 + T < n_rec ? tb0 + T : n_rec;
             nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
         }
+        // One pass over a list: up to TL entries from `head` on (whole steps: all but the last pass of a list), staged and
+        // counted by a run of their kind.  Returns the entries taken.
+        const int TL = 64 - 64 % d.R;
+        auto list_pass = [&](const uint4 *ring, const u32 *ridx, const u32 head, const u32 avail, auto kind_tag) -> u32 {
+            const int m = avail < (u32)TL ? (int)avail : TL;
+            const u32 at = (head + (u32)(lane < m ? lane : 0)) & RM;
+            const uint4 ent = ring_at(ring + at);
+            int n_fwd = -1;
+            int sidx = 0;       // (PK: where this lane's entry is staged)
+            if (PK) {
+                // (sorted by strand, the forward entries first)
+                const bool mine = lane < m, rv_ = (ent.w >> 31) != 0u;
+                const u64 mR = __ballot(mine && rv_), mW = __ballot(mine && !rv_);
+                n_fwd = __popcll(mW);
+                sidx = rv_ ? n_fwd + mbcnt64(mR, 0) : mbcnt64(mW, 0);
+                if (mine) stg[sidx] = ent;
+            } else {
+                if (lane < m) stg[lane] = ent;
+                if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
+            }
+            constexpr bool RSP = RS && decltype(kind_tag)::value == STEP_P;
+            // (PK: the fused single-indel entries — bit 18 —, their records in lriI / lriD by the entry's place in its ring)
+            constexpr bool RSG = RS && PK && (decltype(kind_tag)::value == STEP_GI || decltype(kind_tag)::value == STEP_GD);
+            u32 ri_l = 0;
+            if (RSG || RSP) {
+                ri_l = ring_u32(ridx + at);
+                mrm[lane] = 0ull;
+                if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
+            run(0, m, kind_tag, std::true_type{}, n_fwd);
+            if (RSP || RSG) rsq_flush();
+            if ((RSG || (RSP && PK)) && lane < m && ((ent.w >> 18) & 1u)) a.rs.mr_raw[ri_l] = mr_of(mrm[sidx]);
+            // RS: the MR sums of the fused records among them (known by their TC table)
+            if (RSP && !PK && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
+            return (u32)m;
+        };
+        // A wavefront works in ROUNDS of at most round_tiles tiles: the tile loop, then its lists (the rings hold a round's
+        // entries: MDX_RING >= 63 round_tiles + 63), then the next round while its pool has tiles.
         for (;;) {
-            const bool past = cur == 0xFFFFFFFFu;
+        u32 tiles_left = ROUNDS ? (u32)a.round_tiles : 0xFFFFFFFFu;
+        for (;;) {
+            // (over: the pool is empty — the records still waiting for the general pass are seen to, then the lists; past: no tile
+            // in this turn — that, or the round is over: its lists, and the records that wait go on waiting)
+            const bool over = cur == 0xFFFFFFFFu;
+            const bool past = over || tiles_left == 0u;
             int nF = 0, nF0 = 0, nFp = 0;
             u32 nxt2_raw = 0xFFFFFFFFu;
             if (!past) {
+                tiles_left--;
                 if (!(RS || PF) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
                 if (PF && nxt != 0xFFFFFFFFu) Cn = p_cols(nxt);
                 const MdxTabArgs *kp = ka;
@@ -2587,9 +2649,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         uint4 c0_, c1_;
                         c0_.x = fl | ((u32)c_lib << 16); c0_.y = (u32)c_tid; c0_.z = (u32)c_pos; c0_.w = (u32)c_tlen;
                         c1_.x = c_co0; c1_.y = c_co1; c1_.z = c_so0; c1_.w = c_so1;
-                        dlist[at] = ri | (rs_def << 30);
-                        dcols[2 * at] = c0_;
-                        dcols[2 * at + 1] = c1_;
+                        dlist[(u32)at & DM] = ri | (rs_def << 30);
+                        dcols[2 * ((u32)at & DM)] = c0_;
+                        dcols[2 * ((u32)at & DM) + 1] = c1_;
                     }
                     nDef += __popcll(mDef);
                 }
@@ -2737,10 +2799,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const int dl = lbase + d.off_dmp() + rev * 2 * (A + L), dr = dl + (A + L);
                         const int k1 = nq < L ? nq : L;
                         if (!PK && k1 < L) { atomicAdd(&lds[dl + A + k1], 1u); atomicAdd(&lds[dr + A + k1], 1u); }
-                        lists[lP + mbcnt64(mP, 0)] = ent;
-                        if (RS) lri[lP + mbcnt64(mP, 0)] = ri;      // (the record of the entry: where its MR goes)
+                        ringP[(lP + (u32)mbcnt64(mP, 0)) & RM] = ent;
+                        if (RS) lri[(lP + (u32)mbcnt64(mP, 0)) & RM] = ri;      // (the record of the entry: where its MR goes)
                     }
-                    lP += __popcll(mP);
+                    lP += (u32)__popcll(mP);
                 }
                 if (RS) {
                     // (the MR words of the tile's staging entries)
@@ -2817,7 +2879,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             }
             // ---------------------------------------------------- the general pass over the records left to it
             const int pend = nDef - dDone;
-            if (pend >= 64 || (past && pend > 0)) {
+            if (pend >= 64 || (over && pend > 0)) {
                 const int m = pend < 64 ? pend : 64;
                 // (PK: the general pass is where the kernel wants the most registers: the bit-sliced counters are folded
                 // into TC in front of it — every dozen tiles, about as often as their eight planes ask for anyway — and
@@ -2828,83 +2890,53 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (the wavefront's own stores: complete before they are read back)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const int at = dDone + (lane < m ? lane : 0);
-                const u32 rk = dlist[at];       // (record indices are below 2^30; [31:30]: the packed fused kernel's rs_code)
-                const uint4 c0_ = dcols[2 * at], c1_ = dcols[2 * at + 1];
+                const u32 at = (u32)(dDone + (lane < m ? lane : 0)) & DM;
+                const u32 rk = ring_u32(dlist + at);       // (record indices are below 2^30; [31:30]: the packed fused kernel's rs_code)
+                const uint4 c0_ = ring_at(dcols + 2 * at), c1_ = ring_at(dcols + 2 * at + 1);
                 general(rk & 0x3FFFFFFFu, lane < m, c0_.x & 0xFFFFu, (int)(c0_.x >> 16), (int)c0_.y, (int)c0_.z, (int)c0_.w, c1_.x, c1_.y, c1_.z, c1_.w,
                         (RS && PK) ? rk >> 30 : 0u);
                 dDone += m;
             }
-            if (past && dDone >= nDef) break;
+            if (over ? dDone >= nDef : past) break;
             if (!past) {
                 if (RS || PF) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
                 else cur = tile_of(nxt2_raw);
                 if (PF) { Cc = Cn; Gc = Gn; }
             }
         }
+        // ---------------------------------------------------- the lists, at the end of a round: whole passes (63 entries:
+        // whole steps) while a list holds one — what is left of a list waits for the next round's entries —, everything when
+        // no tile is to come any more.  The rings stay small whatever the batch, and their entries come back from the L2.
+#ifndef MDX_ONLY_PHASE1
+        {
+            const u32 need = (!ROUNDS || cur == 0xFFFFFFFFu) ? 1u : (u32)TL;
+            if (lC - hC >= need || lP - hP >= need || lI - hI >= need || lD - hD >= need) {
+                // the entries this wavefront appended (its own stores: complete before they are read back)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                while (lC - hC >= need) hC += list_pass(ringC, lri, hC, lC - hC, std::integral_constant<int, STEP_C>{});
+#ifndef MDX_ABL_NO_PRUN      // (ablation builds, tools/ablate.sh: wrong tables, instruction counts by part)
+                while (lP - hP >= need) hP += list_pass(ringP, lri, hP, lP - hP, std::integral_constant<int, STEP_P>{});
+#else
+                hP = lP;
+#endif
+#ifndef MDX_ABL_NO_GRUN
+                while (lI - hI >= need) hI += list_pass(ringI, lriI, hI, lI - hI, std::integral_constant<int, STEP_GI>{});
+                while (lD - hD >= need) hD += list_pass(ringD, lriD, hD, lD - hD, std::integral_constant<int, STEP_GD>{});
+#else
+                hI = lI; hD = lD;
+#endif
+            }
+        }
+#endif
+        if (!ROUNDS || cur == 0xFFFFFFFFu) break;
+        }   // rounds
         if (lane == 0 && n_kept_lite) bump_n<USE_LDS>(lds, raw, (int)(d.w_total - 1), n_kept_lite);
         if (RS && lane == 0) a.rs.gen_count[gwave] = n_rs;
     }
 
 #ifdef MDX_WAVE_CLK
     if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave + 1] = wall_clock64();
-#endif
-#ifndef MDX_ONLY_PHASE1
-    if (FAST && (lP | lI | lD | lC)) {
-        // the entries this wavefront appended (its own stores: complete before they are read back)
-        // (workgroup scope: the stores have reached the L2 and no line of the lists was read before, so nothing
-        // stale can sit in this CU's L1; an agent-scope release would write the whole L2 back, once per wavefront)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int TL = 64 - 64 % d.R;       // entries per pass: whole steps, all but the last pass of a list
-        auto list_runs = [&](const i64 first, const int dir, const int n, auto kind_tag) {
-            for (int e = 0; e < n; e += TL) {
-                const int m = n - e < TL ? n - e : TL;
-                const uint4 ent = lists[first + (i64)dir * (e + (lane < m ? lane : 0))];
-                int n_fwd = -1;
-                int sidx = 0;       // (PK: where this lane's entry is staged)
-                if (PK) {
-                    // (sorted by strand, the forward entries first)
-                    const bool mine = lane < m, rv_ = (ent.w >> 31) != 0u;
-                    const u64 mR = __ballot(mine && rv_), mW = __ballot(mine && !rv_);
-                    n_fwd = __popcll(mW);
-                    sidx = rv_ ? n_fwd + mbcnt64(mR, 0) : mbcnt64(mW, 0);
-                    if (mine) stg[sidx] = ent;
-                } else {
-                if (lane < m) stg[lane] = ent;
-                if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
-                }
-                constexpr bool RSP = RS && decltype(kind_tag)::value == STEP_P;
-                // (PK: the fused single-indel entries — bit 18 —, their records in lri by the entry's place in its list)
-                constexpr bool RSG = RS && PK && (decltype(kind_tag)::value == STEP_GI || decltype(kind_tag)::value == STEP_GD);
-                u32 ri_l = 0;
-                if (RSG) {
-                    ri_l = lri_g[first + (i64)dir * (e + (lane < m ? lane : 0)) - a.list_cap];
-                    mrm[lane] = 0ull;
-                    if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
-                }
-                if (RSP) {
-                    ri_l = lri[e + (lane < m ? lane : 0)];
-                    mrm[lane] = 0ull;
-                    if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
-                run(0, m, kind_tag, std::true_type{}, n_fwd);
-                if (RSP || RSG) rsq_flush();
-                if ((RSG || (RSP && PK)) && lane < m && ((ent.w >> 18) & 1u)) a.rs.mr_raw[ri_l] = mr_of(mrm[sidx]);
-                // RS: the MR sums of the fused records among them (known by their TC table)
-                if (RSP && !PK && lane < m && ((ent.w & 0x3FF00u) >> 2) >= (u32)a.rs.tcb_off) a.rs.mr_raw[ri_l] = mr_of(mrm[lane]);
-            }
-        };
-        list_runs(2 * a.list_cap, 1, lC, std::integral_constant<int, STEP_C>{});
-#ifndef MDX_ABL_NO_PRUN      // (ablation builds, tools/ablate.sh: wrong tables, instruction counts by part)
-        list_runs(0, 1, lP, std::integral_constant<int, STEP_P>{});
-#endif
-#ifndef MDX_ABL_NO_GRUN
-        list_runs(a.list_cap, 1, lI, std::integral_constant<int, STEP_GI>{});
-        list_runs(2 * a.list_cap - 1, -1, lD, std::integral_constant<int, STEP_GD>{});
-#endif
-    }
 #endif
     if (FAST) {
         if (qcount > 0) drain_all();
@@ -2984,7 +3016,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         __syncthreads();
         for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) lds[i] = 0;
         __syncthreads();
-        lP = 0; lI = 0; lD = 0; lC = 0;
         ml_chunk0 += ((n_rec + T - 1) / T + MDX_POOL_CHUNK - 1) / MDX_POOL_CHUNK;
     }
     }   // epochs
@@ -3087,8 +3118,8 @@ void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_byte
     hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
 // --min-basequal for the packed kernels: the mask folded into the 4-bit SEQ column (MDX_SEQ_4BIT -> MDX_SEQ_4BITQ,
-// include/mdx.h) — a base whose quality is below the threshold (align.py:65-71; 0xFF, no qualities, is not) becomes the
-// complement of its code, a symbol that is no base stays 0.  Eight bases per thread; the mask from the quality column or,
+// include/mdx.h) — a symbol whose quality is below the threshold (align.py:65-71; 0xFF, no qualities, is not) becomes the
+// complement of its code.  Eight bases per thread; the mask from the quality column or,
 // if the caller brings one, from its bitmap (mdx_batch::lowq: bit i = quality i is below the threshold).  In place or
 // into a copy.
 __global__ void fold_mask_kernel(const u8 *__restrict__ seq_in, u8 *__restrict__ seq_out, const u8 *__restrict__ qual,
@@ -3111,10 +3142,8 @@ __global__ void fold_mask_kernel(const u8 *__restrict__ seq_in, u8 *__restrict__
     const int nb = (int)(n_bytes - 4 * t < 4 ? n_bytes - 4 * t : 4);
     if (nb == 4) v = *(const u32_u *)(seq_in + 4 * t);
     else for (int k = 0; k < nb; k++) v |= (u32)seq_in[4 * t + k] << (8 * k);
-    // the nibbles that hold a base, and of them the masked ones: all four bits flipped
-    u32 nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;
-    nz = (nz << 4) - nz;
-    v ^= spread8(bits) & nz;
+    // the masked nibbles: all four bits flipped (beyond the column's last base: none — the bits end with the qualities)
+    v ^= spread8(bits);
     if (nb == 4) *(u32_u *)(seq_out + 4 * t) = v;
     else for (int k = 0; k < nb; k++) seq_out[4 * t + k] = (u8)(v >> (8 * k));
 }

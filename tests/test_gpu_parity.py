@@ -140,13 +140,15 @@ def test_hip_unaligned_column_pointers(phase, Q, mid_genome, seq_form):
             tseq[phase:phase + n] = torch.from_numpy(batch.seq).cuda()
         tqual[phase:phase + n] = torch.from_numpy(batch.qual).cuda()
         torch.cuda.synchronize()
-        own = (dev.dev.seq, dev.dev.qual)
+        own = (dev.dev.seq, dev.dev.qual, dev.dev.seq_format)
         dev.dev.seq, dev.dev.qual = tseq.data_ptr() + phase, tqual.data_ptr() + phase
+        if seq_form == "4bit":
+            dev.dev.seq_format = 1      # (the caller's own MDX_SEQ_4BIT column: with -Q the mask is folded in front of the launch)
         try:
             eng.tabulate(dev)
             got = eng.finish()
         finally:
-            dev.dev.seq, dev.dev.qual = own
+            dev.dev.seq, dev.dev.qual, dev.dev.seq_format = own
             dev.free()
     assert_tables_equal(got, want)
 
@@ -250,6 +252,39 @@ def test_hip_library_id_beyond_the_last_in_a_resident_batch(mid_genome):
             eng.sync()
         assert err.value.read_index == 1334
         dev.free()
+
+
+def test_hip_launch_scratch_does_not_grow_with_the_batch():
+    """The per-wavefront lists of a launch are rings of a fixed size (81 KB per wavefront: the kernel works in rounds of 14
+    tiles and empties its lists at the end of each) — a resident batch of 40 M records, as large as 32-bit SEQ offsets
+    allow for 100-base reads, is tabulated with a few hundred megabytes of scratch (round 4: 180 bytes per record, 7 GB),
+    and its tables are those of its sixteen identical parts."""
+    import torch
+    from mapdamage_amd.batch import concat_batches
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    ref = synth.make_genome()
+    part = synth.config3_batch(ref, 2_500_000, seed=77)     # (in this process: the forked generator wants an untouched GPU)
+    want, _ = oracle.tabulate_parallel(ref, part, 1, 70, 10, 0, lgd_max=4096)
+    big = concat_batches([part] * 16)
+    assert big.n == 40_000_000 and int(big.seq_off[-1]) == 4_000_000_000
+    with DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
+        eng.set_reference(ref)
+        dev = eng.upload(big, packed=True)
+        del big
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        eng.tabulate(dev)
+        eng.sync()
+        free1, _ = torch.cuda.mem_get_info()
+        got = eng.finish()
+        assert eng.packed_launches() == 1
+        dev.free()
+    assert free0 - free1 < (1 << 30), "launch scratch: %d MiB" % ((free0 - free1) >> 20)
+    np.testing.assert_array_equal(got.mis, 16 * want["mis"])
+    np.testing.assert_array_equal(got.comp, 16 * want["comp"])
+    np.testing.assert_array_equal(got.lgd, 16 * want["lgd"])
+    assert got.n_kept == 16 * want["n_kept"]
 
 
 def test_hip_library_id_beyond_the_last_is_an_error(mid_genome):
