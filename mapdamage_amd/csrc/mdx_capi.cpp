@@ -625,7 +625,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             const int64_t pool_tiles = ((n_tiles + n_pools * chunk - 1) / (n_pools * chunk)) * chunk, pool_waves = (grid / n_pools) * wpb_l;
             // (the fused kernels and the epoch launches are held to a quota — their rings, and the fused kernels' lists of records
             // left to the rescale kernels, are sized by it; the others work in rounds with rings of a fixed size)
-            const bool quota = fuse || ml;
+            const bool quota = fuse || ml || pmask;
             a.tile_quota = quota ? (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2) : 0x7FFFFFFF;
             a.list_cap = fuse ? (int64_t)a.tile_quota * T + 128 : 0;
             a.round_tiles = MDX_ROUND_TILES;

@@ -1781,10 +1781,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // l* = entries appended so far, h* = entries taken so far (entry k of a ring sits at k & (size - 1)).  Written with plain
     // stores and read back by the same wavefront past the vector L1 (ring_at: a line of a ring may sit there from the
     // turn before).
-    // (the rings' size is the launch's: MDX_RING for the kernels that work in rounds; the fused kernels and the epoch launches —
-    // ROUNDS false: their registers do not take the loop of rounds around the tile loop, measured: config 5 -6 %, 8 libraries
-    // -4 % — keep one round and rings that hold what a wavefront's quota of tiles can append)
-    constexpr bool ROUNDS = !(RS || ML);
+    // (the rings' size is the launch's: MDX_RING for the kernels that work in rounds; the fused kernels, the epoch launches and
+    // the packed masked kernel — ROUNDS false: their registers do not take the loop of rounds around the tile loop, measured:
+    // config 5 -6 %, 8 libraries -4 %, --min-basequal -6 % (10 registers spilled) — keep one round and rings that hold what a
+    // wavefront's quota of tiles can append)
+    constexpr bool ROUNDS = !(RS || ML || (MASK && PK));
     constexpr u32 DM = MDX_DRING - 1;
     const u32 RM = (u32)a.ring_size - 1u;
     uint4 *const lists = a.lists + (i64)gwave * MDX_WAVE_SCRATCH(a.ring_size);
