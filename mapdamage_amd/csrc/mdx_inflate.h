@@ -218,11 +218,19 @@ MDX_HD bool build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, ui
 // The numbers of codes of each length, read once per block into registers (on the device: scalar registers —
 // the walk below then costs a few scalar instructions per bit instead of an LDS round trip per bit, which is what
 // a distance code longer than the fast table's eight bits used to cost: two thirds of the whole kernel's time)
-struct Counts { uint32_t c[16]; };
-MDX_HD Counts counts_of(const uint16_t *count) {
+// (first / index: the state of the canonical walk behind the fast table's `fast_bits` lengths — a code the table does not
+// hold is longer than that, so the walk starts there instead of at length 1: eight of its steps saved for every long
+// distance code, eleven for a literal / length one)
+struct Counts { uint32_t c[16]; int first, index; };
+MDX_HD Counts counts_of(const uint16_t *count, int fast_bits) {
     Counts k;
 #pragma unroll
     for (int i = 0; i < 16; i++) k.c[i] = uni(count[i]);
+    int first = 0, index = 0;
+#pragma unroll
+    for (int len = 1; len <= 15; len++)
+        if (len <= fast_bits) { const int c = (int)k.c[len]; index += c; first += c; first <<= 1; }
+    k.first = first; k.index = index;
     return k;
 }
 
@@ -230,11 +238,17 @@ MDX_HD Counts counts_of(const uint16_t *count) {
 MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
     const uint32_t e = uni(fast[in.peek(fast_bits)]);
     if (__builtin_expect(e != 0u, 1)) { in.drop((int)(e & 15u)); return (int)(e >> 4); }
-    // canonical walk, one bit at a time (codes longer than fast_bits)
-    int code = 0, first = 0, index = 0;
-    uint64_t b = in.bits;
+    // canonical walk, one bit at a time, from the first length the fast table does not hold (the code so far: the
+    // stream's first fast_bits bits, which arrive LSB first, reversed)
+#if MDX_ON_DEVICE
+    int code = (int)(__builtin_bitreverse32(in.peek(fast_bits)) >> (32 - fast_bits)) << 1, first = k.first, index = k.index;
+#else
+    int code = (int)bitrev(in.peek(fast_bits), fast_bits) << 1, first = k.first, index = k.index;
+#endif
+    uint64_t b = in.bits >> fast_bits;
 #pragma unroll
     for (int len = 1; len <= 15; len++) {
+        if (len <= fast_bits) continue;
         code |= (int)(b & 1); b >>= 1;
         const int c = (int)k.c[len];
         if (code - c < first) { in.drop(len); return (int)uni(sym[index + (code - first)]); }
@@ -336,7 +350,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #if MDX_ON_DEVICE
                 __builtin_amdgcn_wave_barrier();
 #endif
-                const Counts kcl = counts_of(t.count_d);
+                const Counts kcl = counts_of(t.count_d, 7);
                 int i = 0;
                 while (i < nlen + ndist) {
                     in.refill();
@@ -367,7 +381,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #if MDX_ON_DEVICE
             __builtin_amdgcn_wave_barrier();
 #endif
-            const Counts kll = counts_of(t.count_ll), kd = counts_of(t.count_d);
+            const Counts kll = counts_of(t.count_ll, FAST_LL), kd = counts_of(t.count_d, FAST_D);
             for (;;) {
                 // the one place a finished stretch leaves the ring (a step of the loop adds at most 258 bytes: the
                 // stretch is still whole in the ring, and still older than anything a far match may ask for)
@@ -377,28 +391,38 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #if MDX_ON_DEVICE
                 {
                     // Lane L looks up the symbol that would begin at bit L of the buffer — one LDS access for all 64
-                    // candidates; the symbols that really follow one another are then picked out of the lanes'
-                    // registers (readlane: a few cycles each, where a look-up of its own costs a round trip to the
-                    // LDS).  A run of up to eight literals leaves in one step.
+                    // candidates.  The symbols that really follow one another are then found on the VECTOR unit (round 5:
+                    // the decoder's state is wavefront-uniform and lives on the scalar unit, which four wavefronts share and
+                    // which the counters show busy all the time — 15 scalar instructions per output byte against 2 vector
+                    // ones; the loop that picked the literals out of the lanes with readlane was a sixth of them):
+                    // g1[L] = where the symbol behind a short-coded literal at bit L begins (L itself where there is none:
+                    // the chain stops), g2 = g1 o g1, g4 = g2 o g2 by cross-lane permutes, and lane i walks to the bit its
+                    // i-th symbol begins at by the binary digits of i.  A run of up to seven literals leaves in one step.
                     const uint32_t e = t.fast_ll[(uint32_t)(in.bits >> lane) & ((1u << FAST_LL) - 1u)];
-                    int pbit = 0;
-                    uint32_t nlit = 0, ep = 0;
-                    uint64_t lits = 0;
-                    while (nlit < 8u && pbit + FAST_LL <= in.nbits) {
-                        ep = (uint32_t)__builtin_amdgcn_readlane((int)e, pbit);
-                        if (ep == 0u || (ep >> 4) >= 256u) break;         // a long code, a length or the end of the block
-                        lits |= (uint64_t)(ep >> 4) << (8u * nlit);
-                        nlit++;
-                        pbit += (int)(ep & 15u);
-                    }
+                    auto perm = [](const uint32_t from, const uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); };
+                    const uint32_t lim = (uint32_t)in.nbits;
+                    const bool lit_here = e != 0u && (e >> 4) < 256u && (uint32_t)lane + FAST_LL <= lim;
+                    const uint32_t g1 = lit_here ? (uint32_t)lane + (e & 15u) : (uint32_t)lane;
+                    const uint32_t g2 = perm(g1, g1), g4 = perm(g2, g2);
+                    uint32_t at = 0u;
+                    { const uint32_t q = perm(at, g1); at = (lane & 1) ? q : at; }
+                    { const uint32_t q = perm(at, g2); at = (lane & 2) ? q : at; }
+                    { const uint32_t q = perm(at, g4); at = (lane & 4) ? q : at; }
+                    const uint32_t ei = perm(at, e);
+                    const bool budget = at + FAST_LL <= lim;
+                    const bool lit_i = ei != 0u && (ei >> 4) < 256u && budget;
+                    // (the literals of the run are the lanes in front of the first one that holds none)
+                    const uint32_t nlit = (uint32_t)__builtin_popcountll(__ballot(lit_i && lane < 7));
+                    const int pbit = __builtin_amdgcn_readlane((int)at, (int)nlit);
+                    const uint32_t ep = (uint32_t)__builtin_amdgcn_readlane((int)(budget ? ei : 0u), (int)nlit);   // what follows the run
                     if (nlit) {
                         if (out + nlit > cap) return -2;
-                        if ((uint32_t)lane < nlit) win[(out + (uint32_t)lane) & (RING - 1)] = (uint8_t)(lits >> (8u * (uint32_t)lane));
+                        if ((uint32_t)lane < nlit) win[(out + (uint32_t)lane) & (RING - 1)] = (uint8_t)(ei >> 4);
                         out += nlit;
                         in.drop(pbit);
                         // the match behind the run in the same step when the buffer still holds all of it (its length
                         // code is known already: what follows needs up to 5 + 15 + 13 bits)
-                        if (!(nlit < 8u && ep && (ep >> 4) > 256u && in.nbits >= (int)(ep & 15u) + 33)) continue;
+                        if (!(ep && (ep >> 4) > 256u && in.nbits >= (int)(ep & 15u) + 33)) continue;
                     }
                     // the symbol at bit 0 is no literal with a short code
                     if (ep) { s = (int)(ep >> 4); in.drop((int)(ep & 15u)); }

@@ -1866,8 +1866,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const i64 lseq = (i64)c_so1 - (i64)so;
             bool bad = tid < 0 || tid >= a.n_contig || c_lib >= a.nlib_total || lseq <= 0 || pos < 0;
             const int lbase = bad ? 0 : libid * d.w_lib;
-            // second round trip of the tile: the first CIGAR operation and the contig bounds together
-            const u32 cg0 = cig_n > 0 ? a.cigar[cig_o] : 0u;
+            // second round trip of the tile: the first five CIGAR operations and the contig bounds together (a record with one
+            // indel between clips has five: the scan below then waits once, not once per operation)
+            const u32 cg0 = cig_n > 0 ? a.cigar[cig_o] : 0u, cg1 = cig_n > 1 ? a.cigar[cig_o + 1] : 0u, cg2 = cig_n > 2 ? a.cigar[cig_o + 2] : 0u,
+                      cg3 = cig_n > 3 ? a.cigar[cig_o + 3] : 0u, cg4 = cig_n > 4 ? a.cigar[cig_o + 4] : 0u;
             i64 c0 = 0, clen = 0;
             if (!bad) {
                 c0 = a.contig_off[tid];
@@ -1900,7 +1902,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             if (!redo) {
                 u32 big = 0, cl_l = 0, cl_r = 0, lopen = ~0u, leading = ~0u;
                 for (int k = 0; k < cig_n; k++) {
-                    const u32 c = k == 0 ? cg0 : a.cigar[cig_o + k];
+                    const u32 c = k == 0 ? cg0 : (k == 1 ? cg1 : (k == 2 ? cg2 : (k == 3 ? cg3 : (k == 4 ? cg4 : a.cigar[cig_o + k]))));
                     const u32 op = c & 0xFu, len = c >> 4;
                     big |= len >> 24;
                     const u32 m = (0x181u >> op) & 1u, e = (0xFE4Eu >> op) & 1u, keep = e - 1u;
