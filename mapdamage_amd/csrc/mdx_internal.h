@@ -367,8 +367,8 @@ struct MdxGbamCols {
     const uint32_t *rg_off;
     const int32_t *lib_of_rg;
     int n_rg, lib_default;
-    // --min-basequal (0: off; needs qual): counters[0] |= 1 when a counted record has no qualities, counters[1] += the
-    // records that hold a quality below the threshold
+    // --min-basequal (0: off; needs qual): counters[0] |= 1 when a counted record has no qualities, counters[1] != 0 when a
+    // record holds a quality below the threshold
     int minqual;
     uint32_t *counters;
     // ... and a 4-bit SEQ column takes the mask into its nibbles (MDX_SEQ_4BITQ: a base whose quality is below the threshold
