@@ -25,6 +25,17 @@ extern "C" int mdx_dbg_clk_read(unsigned long long *out, int n) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpy(out, g_dbg_clk, (size_t)n * 24, hipMemcpyDeviceToHost);
 }
+// (-DMDX_PHASE_CLK: twelve sums of shader-clock ticks over all wavefronts since the last reset, tools/experiments/phase_clk.py)
+extern "C" int mdx_dbg_phase_read(unsigned long long *out, int reset) {
+    if (!g_dbg_clk) return -1;
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)16 * 8192);
+    int rc = (int)hipMemcpy(h.data(), g_dbg_clk + 3 * 20000, h.size() * 8, hipMemcpyDeviceToHost);
+    for (int q = 0; q < 16; q++) out[q] = 0;
+    for (size_t w = 0; w < 8192; w++) for (int q = 0; q < 16; q++) out[q] += h[16 * w + q];
+    if (reset) rc |= (int)hipMemset(g_dbg_clk + 3 * 20000, 0, h.size() * 8);
+    return rc;
+}
 #endif
 constexpr int kLgdLds = 256;           // fragment lengths below this are counted in the LDS
 
@@ -543,7 +554,10 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     a.err = c->d_err;
     a.record_base = c->record_base;
 #ifdef MDX_WAVE_CLK
-    if (!g_dbg_clk) (void)hipMalloc((void **)&g_dbg_clk, 3 * 8 * 20000);
+    if (!g_dbg_clk) {
+        (void)hipMalloc((void **)&g_dbg_clk, 3 * 8 * 20000 + 16 * 8 * 8192);
+        (void)hipMemset(g_dbg_clk, 0, 3 * 8 * 20000 + 16 * 8 * 8192);
+    }
     a.dbg_clk = g_dbg_clk;
 #endif
     a.stage_off = mdx_k_stage_off(c->dims);
@@ -629,7 +643,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.tile_quota = quota ? (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2) : 0x7FFFFFFF;
             a.list_cap = fuse ? (int64_t)a.tile_quota * T + 128 : 0;
             a.round_tiles = MDX_ROUND_TILES;
-            a.ring_size = MDX_RING;
+            a.ring_size = MDX_LIST_RING;
             if (quota) while ((int64_t)a.ring_size < (int64_t)a.tile_quota * T + 128) a.ring_size *= 2;
             if (!c->d_tile_ctr) {
                 HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)65536 * 4));

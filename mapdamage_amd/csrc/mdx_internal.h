@@ -137,11 +137,11 @@ struct MdxFuse {
 };
 
 // A wavefront's part of MdxTabArgs::lists, in 16-byte entries — rings, the same size whatever the batch (tabulate_kernel):
-// four lists of MDX_RING staging entries (partial records, single insertions, single deletions, the complete records the
+// four lists of MDX_LIST_RING staging entries (partial records, single insertions, single deletions, the complete records the
 // general pass finds), MDX_DRING records waiting for the general pass (two entries of columns and an index each), and three
 // rings of record indices for the fused kernels
-#define MDX_RING 1024
-#define MDX_ROUND_TILES 14      // a round appends its records (63 x 14) and the < 64 that waited for the general pass, < 63 entries are left over: <= MDX_RING
+#define MDX_LIST_RING 1024
+#define MDX_ROUND_TILES 14      // a round appends its records (63 x 14) and the < 64 that waited for the general pass, < 63 entries are left over: <= MDX_LIST_RING
 #define MDX_DRING 128
 #define MDX_WAVE_SCRATCH(ring) (4 * (ring) + 2 * MDX_DRING + MDX_DRING / 4 + 3 * ((ring) / 4))
 struct MdxTabArgs {
@@ -182,7 +182,7 @@ struct MdxTabArgs {
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
     // Per-wavefront lists: wavefront w owns MDX_WAVE_SCRATCH(ring_size) 16-byte entries (rings: see above and the kernel).
-    // Written in the tile loop, read back by the same wavefront at the end of its round.  ring_size (a power of two): MDX_RING —
+    // Written in the tile loop, read back by the same wavefront at the end of its round.  ring_size (a power of two): MDX_LIST_RING —
     // 81 KB per wavefront whatever the batch — for the kernels that work in rounds; for the fused kernels and the epoch
     // launches, which do not, what a wavefront's tile_quota of tiles can append.
     uint4 *lists;

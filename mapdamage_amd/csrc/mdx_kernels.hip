@@ -92,6 +92,7 @@ __device__ __forceinline__ u32x3 ld12_stream(const u8 *p) {
     return r;
 }
 typedef unsigned long long u64;
+typedef u64 __attribute__((aligned(1))) u64_u;
 typedef long long i64;
 
 #ifndef MDX_BLOCK
@@ -201,6 +202,12 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 // counters want the registers (at 80 the hot loop spills)
 #ifndef MDX_PK_BLOCK
 #define MDX_PK_BLOCK 512
+#endif
+#ifndef MDX_PK_DEFER
+#define MDX_PK_DEFER 1                  // the plain packed kernel adds its groups of four steps in pairs (tabulate_kernel: HS)
+#endif
+#ifndef MDX_PK_DEFER_ML
+#define MDX_PK_DEFER_ML 0               // ... the epoch kernel does not: 128 registers, seven more spilled with the pair's words
 #endif
 #ifndef MDX_PK_WPS
 #define MDX_PK_WPS 4
@@ -519,6 +526,13 @@ __device__ __forceinline__ void bs_add_group(u32 (&pl)[8], const u32 (&x)[4]) {
         bs_ripple<2>(pl, c2);
     }
 }
+// ... the same for four words, the carry of weight 4 handed out instead of rippled (tabulate_kernel's paired groups)
+__device__ __forceinline__ void bs_group4(u32 (&pl)[8], const u32 (&x)[4], u32 &c2) {
+    u32 c0, c1;
+    bs_csa(pl[0], x[0], x[1], c0);
+    bs_csa(pl[0], x[2], x[3], c1);
+    bs_csa(pl[1], c0, c1, c2);
+}
 // resident reference bytes (encode_ref_kernel's, guard bands included) -> 4-bit codes, eight bases per thread and step
 __device__ __forceinline__ u32 code4_of_ref(u32 b) {
     // 'A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47: class (b >> 1) & 3; 0x84 / 0x85: nothing
@@ -601,6 +615,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     u64 *raw = a.raw;
 #ifdef MDX_WAVE_CLK       // (instrumented builds: the wavefront's clock at its start, behind its tile loop and at its end)
     if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave] = wall_clock64();
+#endif
+#ifdef MDX_PHASE_CLK      // (instrumented builds, tools/experiments/phase_clk.py: the wavefront's shader-clock ticks by part of the kernel)
+    u32 ph_acc[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int ph_cur = 0;
+    u64 ph_t0 = __builtin_amdgcn_s_memtime();
+#define MDX_PH(id) do { const u64 t_ = __builtin_amdgcn_s_memtime(); const u32 dt_ = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(t_ - ph_t0)); \
+        _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) ph_acc[q_] += ph_cur == q_ ? dt_ : 0u; ph_t0 = t_; ph_cur = (id); } while (0)
+#define MDX_PH_IN(id) const int ph_prev_ = ph_cur; MDX_PH(id)
+#define MDX_PH_OUT() MDX_PH(ph_prev_)
+#define MDX_PH_IMPL(x) x##_impl
+#else
+#define MDX_PH_IMPL(x) x
+#define MDX_PH(id) do { } while (0)
+#define MDX_PH_IN(id) do { } while (0)
+#define MDX_PH_OUT() do { } while (0)
 #endif
 
     // nine-entry LDS table of byte masks (entry n = the low n bytes of a 64-bit word set): the per-record byte masks
@@ -757,10 +786,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // column into N: it counts its read base in the composition table and nothing else), folded into CMP by position
     u32 b2L[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, b2H[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int bs_steps = 0;
+    // Paired groups (the kernels with the registers for them): a group of four steps leaves one word of weight 4 per dword;
+    // rippled through planes 2..7 that is twelve instructions.  Two groups one after the other hand their two words to one
+    // adder into plane 2, and its carry ripples from plane 3: fourteen for both.
+    constexpr bool HS = PK && MDX_PK_DEFER && !MASK && !RS && (!ML || MDX_PK_DEFER_ML);
     // fold the planes into the block's TC table, PK layout: word [base k][64 j + lane]; per bit position s of the bytes of
     // a plane, the four counters of bits s, s + 8, s + 16, s + 24 are gathered as the bytes of one word
     // (inlined at every call site: a call would take the planes through memory)
-    auto bs_flush = [&]() __attribute__((always_inline)) {
+    auto MDX_PH_IMPL(bs_flush) = [&]() __attribute__((always_inline)) {
 #ifdef MDX_ABL_NOFLUSH       // (ablation builds — wrong tables, the instruction counts of what is left: tools/ablate.sh)
         bs_steps = 0;
         return;
@@ -809,6 +842,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             bs_steps = 0;
         }
     };
+#ifdef MDX_PHASE_CLK
+    auto bs_flush = [&]() __attribute__((always_inline)) { MDX_PH_IN(5); bs_flush_impl(); MDX_PH_OUT(); };
+#endif
 
     // Undo the optimistic increment of each queued byte that was not a plain match and, for read
     // columns, count what the byte really is (rare_column) — lane-parallel over the queued events.
@@ -943,7 +979,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         return mr;
     };
     // (PK: the events from `lo` on — behind a run lo = qcount % 64: full passes only, the rest waits for company)
-    auto drain_all = [&](const int lo = 0) {
+    auto MDX_PH_IMPL(drain_all) = [&](const int lo = 0) {
         if (PK) {
 #ifdef MDX_ABL_NODRAIN
             qcount = lo;
@@ -969,6 +1005,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     u64 x = (s64 ^ r64) & ((u64)em.x | ((u64)em.y << 32));      // the read columns that differ
                     const int b_mis = d.off_mis() + (rev ? 2 * L * 25 : 0), b_cmp = d.off_cmp() + (rev ? 2 * L * 4 : 0);
                     // usually exactly one nibble differs: the lowest one (all lanes busy), again while some lane has another
+                    // (two copies of the loop: a pass without an event of a deletion step — most of them — carries none of the
+                    // by-position arithmetic)
+                    auto nibbles = [&](auto del_tag) {
+                    constexpr bool DEL = decltype(del_tag)::value;
                     while (x) {
                         const int sh = (__ffsll((long long)x) - 1) & ~3, jb = sh >> 2;
                         x &= ~(15ull << sh);
@@ -977,7 +1017,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const int p = (side ? m16 + 15 - jb : m16 + jb) - A;
                         // a column behind the deletion of its record was counted, optimistically, as a match in MIS[p] and
                         // CMP[p - g] (its query index) instead of the lane's counters
-                        const bool direct = del && (side ? jb < bnd : jb >= bnd);
+                        const bool direct = DEL && del && (side ? jb < bnd : jb >= bnd);
                         const int pc = direct ? p - g : p;
                         const int sp = (side ? L : 0) + p, spc = (side ? L : 0) + pc;
                         if (rc < 4) {
@@ -995,6 +1035,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         if (RS && rsev) rs_event4(rent, (int)((w >> 21) & 0x7Fu), rev, side, p, pc, g, (u32)(s64 >> sh) & 15u, (u32)(r64 >> sh) & 15u);
 #endif
                     }
+                    };
+                    if (__ballot(del)) nibbles(std::true_type{});
+                    else nibbles(std::false_type{});
                 }
             }
             qcount = lo;
@@ -1058,6 +1101,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // nothing LDS-returning may be pending when control rejoins the hot loop
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     };
+#ifdef MDX_PHASE_CLK
+    auto drain_all = [&](const int lo = 0) { MDX_PH_IN(4); drain_all_impl(lo); MDX_PH_OUT(); };
+#endif
 
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
@@ -1567,7 +1613,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 St16 st[PD4];
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
                 // low and high dwords
-                auto group = [&](auto full_tag, const bool refill) {
+                u32 pcL = 0u, pcH = 0u;     // (a pair of groups: the first one's words of weight 4)
+                auto group = [&](auto full_tag, const bool refill, auto pair_tag) {
+                    constexpr int PAIR = decltype(pair_tag)::value;     // 0: a group on its own; 1, 2: the first, second of a pair
                     u32 xl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, xh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
                     u32 yl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, yh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
                     grp_y = false;
@@ -1583,7 +1631,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #endif
                             const u32 al[4] = {xl[dd & ~3], xl[(dd & ~3) + 1], xl[(dd & ~3) + 2], xl[(dd & ~3) + 3]};
                             const u32 ah[4] = {xh[dd & ~3], xh[(dd & ~3) + 1], xh[(dd & ~3) + 2], xh[(dd & ~3) + 3]};
-                            if ((dd & 3) == 3) { bs_add_group<4>(bsL, al); bs_add_group<4>(bsH, ah); }
+                            if (PAIR == 1 && (dd & 3) == 3) { bs_group4(bsL, al, pcL); bs_group4(bsH, ah, pcH); }
+                            else if (PAIR == 2 && (dd & 3) == 3) {
+                                u32 cl_, ch_, dl_, dh_;
+                                bs_group4(bsL, al, cl_); bs_group4(bsH, ah, ch_);
+                                bs_csa(bsL[2], pcL, cl_, dl_); bs_csa(bsH[2], pcH, ch_, dh_);
+                                bs_ripple<3>(bsL, dl_); bs_ripple<3>(bsH, dh_);
+                            }
+                            else if ((dd & 3) == 3) { bs_add_group<4>(bsL, al); bs_add_group<4>(bsH, ah); }
                             else if ((dd & 3) == 2) { bs_add_group<3>(bsL, al); bs_add_group<3>(bsH, ah); }
                             else if ((dd & 3) == 1) { bs_add_group<2>(bsL, al); bs_add_group<2>(bsH, ah); }
                             else { bs_add_group<1>(bsL, al); bs_add_group<1>(bsH, ah); }
@@ -1613,9 +1668,18 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) fill16(st[dd]);
                     int k = kstart + PD4;
-                    for (; k < nsteps4 && k <= nfull && !ovf; k += PD4) group(std::true_type{}, true);
-                    for (; k < nsteps4 && !ovf; k += PD4) group(std::false_type{}, true);
-                    if (!ovf) group(std::false_type{}, false);
+                    using P0 = std::integral_constant<int, 0>;
+                    if (HS && PD4 == 4) {
+                        // (pairs while two whole groups of complete steps are left; the second one folds the first one's words
+                        // whatever happened to its own steps)
+                        for (; k + PD4 < nsteps4 && k + PD4 <= nfull && !ovf; k += 2 * PD4) {
+                            group(std::true_type{}, true, std::integral_constant<int, 1>{});
+                            group(std::true_type{}, true, std::integral_constant<int, 2>{});
+                        }
+                    }
+                    for (; k < nsteps4 && k <= nfull && !ovf; k += PD4) group(std::true_type{}, true, P0{});
+                    for (; k < nsteps4 && !ovf; k += PD4) group(std::false_type{}, true, P0{});
+                    if (!ovf) group(std::false_type{}, false, P0{});
                     if (!ovf) break;
                     drain_all();
                     if (RS) {
@@ -1771,7 +1835,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
     const MdxTabArgs *const ka = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     // The wavefront's part of MdxTabArgs::lists (MDX_WAVE_SCRATCH(ring_size) 16-byte entries): rings.
-    //   ringP / ringI / ringD / ringC   MDX_RING entries each: partial records, single insertions, single deletions, the
+    //   ringP / ringI / ringD / ringC   MDX_LIST_RING entries each: partial records, single insertions, single deletions, the
     //                                   complete records the general pass finds.  A list is emptied at the end of a round
     //                                   of the tile loop (MdxTabArgs::round_tiles tiles), whole passes of 63 entries; a round
     //                                   appends at most its records, 63 round_tiles, and fewer than 63 are left over.
@@ -1781,7 +1845,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // l* = entries appended so far, h* = entries taken so far (entry k of a ring sits at k & (size - 1)).  Written with plain
     // stores and read back by the same wavefront past the vector L1 (ring_at: a line of a ring may sit there from the
     // turn before).
-    // (the rings' size is the launch's: MDX_RING for the kernels that work in rounds; the fused kernels, the epoch launches and
+    // (the rings' size is the launch's: MDX_LIST_RING for the kernels that work in rounds; the fused kernels, the epoch launches and
     // the packed masked kernel — ROUNDS false: their registers do not take the loop of rounds around the tile loop, measured:
     // config 5 -6 %, 8 libraries -4 %, --min-basequal -6 % (10 registers spilled) — keep one round and rings that hold what a
     // wavefront's quota of tiles can append)
@@ -2114,21 +2178,44 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 mSI = __ballot(isS && dnq < 0);      // insertions first, then deletions (one kind of step each)
                 isD = isS && dnq > 0;
                 if (__ballot(isS && dnq > 0)) {
+                    MDX_PH_IN(13);
                     // A single deletion of g bases: the lanes of its entry work in column space and reach query index
                     // min(n0, L) - g - 1 at most; the read bases of the (up to g) composition positions above that,
                     // per side, are counted here (statistics.py:75-83).
                     if (isS && dnq > 0) {
                         const int g = dnq, u = vlr & 0xFF, v = vlr >> 8, Lq = nq < L ? nq : L;
                         const int b_cmp = libid * d.w_lib + d.off_cmp() + rev * 2 * L * 4;
-                        for (int q = u > L - g ? u : L - g; q < Lq; q++) {
+                        const int qa = u > L - g ? u : L - g, ia = v > L - g ? v : L - g;
+                        if (PK) {
+                            // (at most seven bases per side, adjacent in the read: one unaligned load of sixteen nibbles each, both
+                            // in flight together — a load per base was fourteen round trips one after the other)
+                            const u32 fl_ = sq + (u32)qa, fr_ = sq + (u32)(nq - Lq);
+                            const u64 wl = *(const u64_u *)(a.seq + (fl_ >> 1)), wr = *(const u64_u *)(a.seq + (fr_ >> 1));
+                            auto nib_cls = [&](const u64 w, const u32 k) -> int {
+                                u32 nib = (u32)(w >> (4u * k)) & 15u;
+                                if (MASK) { bool m; nib = unmask4(nib, m); }
+                                return cls4(nib);
+                            };
+                            for (int q = qa; q < Lq; q++) {
+                                const int sc = nib_cls(wl, (fl_ & 1u) + (u32)(q - qa));
+                                if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + q * 4 + sc);
+                            }
+                            for (int i = ia; i < Lq; i++) {
+                                const int sc = nib_cls(wr, (fr_ & 1u) + (u32)(Lq - 1 - i));
+                                if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + (L + i) * 4 + sc);
+                            }
+                        } else {
+                        for (int q = qa; q < Lq; q++) {
                             const int sc = seq_cls(sq + (u32)q);
                             if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + q * 4 + sc);
                         }
-                        for (int i = v > L - g ? v : L - g; i < Lq; i++) {
+                        for (int i = ia; i < Lq; i++) {
                             const int sc = seq_cls(sq + (u32)(nq - 1 - i));
                             if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + (L + i) * 4 + sc);
                         }
+                        }
                     }
+                    MDX_PH_OUT();
                 }
             }
             nF = __popcll(mF); nP = __popcll(mP); nS = __popcll(mS); nSI = __popcll(mSI);
@@ -2186,6 +2273,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             }
         }
         // ------------------------------------------------------------ phase 2b: gapped records
+        MDX_PH_IN(12);
         while (todo_g) {
             const int j = __ffsll((long long)todo_g) - 1;
             todo_g &= todo_g - 1;
@@ -2324,6 +2412,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 }
             }
         }
+        MDX_PH_OUT();
 
     };   // general
 
@@ -2478,7 +2567,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (lane < MDX_FUSE_MRM - 64) mrm[64 + lane] = 0ull;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);    // (see the tile loop's run)
+            MDX_PH_IN(14);
             run(0, m, kind_tag, std::true_type{}, n_fwd);
+            MDX_PH_OUT();
             if (RSP || RSG) rsq_flush();
             if ((RSG || (RSP && PK)) && lane < m && ((ent.w >> 18) & 1u)) a.rs.mr_raw[ri_l] = mr_of(mrm[sidx]);
             // RS: the MR sums of the fused records among them (known by their TC table)
@@ -2486,7 +2577,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             return (u32)m;
         };
         // A wavefront works in ROUNDS of at most round_tiles tiles: the tile loop, then its lists (the rings hold a round's
-        // entries: MDX_RING >= 63 round_tiles + 63), then the next round while its pool has tiles.
+        // entries: MDX_LIST_RING >= 63 round_tiles + 63), then the next round while its pool has tiles.
         for (;;) {
         u32 tiles_left = ROUNDS ? (u32)a.round_tiles : 0xFFFFFFFFu;
         for (;;) {
@@ -2497,6 +2588,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             int nF = 0, nF0 = 0, nFp = 0;
             u32 nxt2_raw = 0xFFFFFFFFu;
             if (!past) {
+                MDX_PH(1);
                 tiles_left--;
                 if (!(RS || PF) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
                 if (PF && nxt != 0xFFFFFFFFu) Cn = p_cols(nxt);
@@ -2825,8 +2917,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (PF && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) {
+                    MDX_PH(2);
                     if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp);
+                    MDX_PH(3);
                     if (PTILE && nPt) run(nF, nPt, std::integral_constant<int, STEP_P>{}, std::true_type{}, nPtp);
+                    MDX_PH(0);
                 }
                 else {
                 if (nF0) run(0, nF0, std::integral_constant<int, STEP_C>{}, std::false_type{});
@@ -2884,6 +2979,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const int pend = nDef - dDone;
             if (pend >= 64 || (over && pend > 0)) {
                 const int m = pend < 64 ? pend : 64;
+                MDX_PH(6);
                 // (PK: the general pass is where the kernel wants the most registers: the bit-sliced counters are folded
                 // into TC in front of it — every dozen tiles, about as often as their eight planes ask for anyway — and
                 // are not live across it)
@@ -2899,6 +2995,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 general(rk & 0x3FFFFFFFu, lane < m, c0_.x & 0xFFFFu, (int)(c0_.x >> 16), (int)c0_.y, (int)c0_.z, (int)c0_.w, c1_.x, c1_.y, c1_.z, c1_.w,
                         (RS && PK) ? rk >> 30 : 0u);
                 dDone += m;
+                MDX_PH(0);
             }
             if (over ? dDone >= nDef : past) break;
             if (!past) {
@@ -2917,6 +3014,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // the entries this wavefront appended (its own stores: complete before they are read back)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                MDX_PH(7);
                 while (lC - hC >= need) hC += list_pass(ringC, lri, hC, lC - hC, std::integral_constant<int, STEP_C>{});
 #ifndef MDX_ABL_NO_PRUN      // (ablation builds, tools/ablate.sh: wrong tables, instruction counts by part)
                 while (lP - hP >= need) hP += list_pass(ringP, lri, hP, lP - hP, std::integral_constant<int, STEP_P>{});
@@ -2924,11 +3022,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 hP = lP;
 #endif
 #ifndef MDX_ABL_NO_GRUN
+                MDX_PH(8);
                 while (lI - hI >= need) hI += list_pass(ringI, lriI, hI, lI - hI, std::integral_constant<int, STEP_GI>{});
+                MDX_PH(9);
                 while (lD - hD >= need) hD += list_pass(ringD, lriD, hD, lD - hD, std::integral_constant<int, STEP_GD>{});
 #else
                 hI = lI; hD = lD;
 #endif
+                MDX_PH(0);
             }
         }
 #endif
@@ -2941,12 +3042,20 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #ifdef MDX_WAVE_CLK
     if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave + 1] = wall_clock64();
 #endif
+    MDX_PH(10);
     if (FAST) {
         if (qcount > 0) drain_all();
         if (PK) bs_flush();
     }
 #ifdef MDX_WAVE_CLK
     if (a.dbg_clk && lane == 0) a.dbg_clk[3 * (size_t)gwave + 2] = wall_clock64();
+#endif
+#ifdef MDX_PHASE_CLK
+    MDX_PH(11);
+    if (a.dbg_clk && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) a.dbg_clk[3 * 20000 + 16 * (size_t)(gwave & 8191u) + q] += (unsigned long long)ph_acc[q];
+    }
 #endif
     if (USE_LDS) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // the hand-written ds_adds of this wavefront

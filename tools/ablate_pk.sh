@@ -5,7 +5,7 @@
 # usage: tools/ablate_pk.sh "variant a|variant b" [reads]
 V=$1; N=${2:-4000000}
 export MDX_SEQ_4BIT=1
-for t in "" abl_NOEVQ abl_NODRAIN abl_NOCSA abl_NOFLUSH p1; do
+for t in "" abl_NOEVQ abl_NODRAIN abl_NOCSA abl_NOFLUSH abl_NOGRUN p1; do
   echo "== ${t:-cur}"
   LIB=$t $GRAFT_REPO_ROOT/tools/pmc_split.sh $N "$V" | grep "^variant [0-9]*:" | cut -c1-125
 done

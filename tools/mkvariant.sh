@@ -7,5 +7,5 @@ tag=$1; shift
 mkdir -p tools/bin
 S=mapdamage_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -Wall -Wno-unused-function "$@" \
-  $S/mdx_kernels.hip $S/mdx_capi.cpp $S/mdx_bamio.cpp $S/mdx_gbam.hip -lz -lpthread -ldl -o tools/bin/libmdx_$tag.so
+  $S/mdx_kernels.hip $S/mdx_capi.cpp $S/mdx_bamio.cpp $S/mdx_gbam.hip $S/mdx_libsort.hip -lz -lpthread -ldl -o tools/bin/libmdx_$tag.so
 echo "built tools/bin/libmdx_$tag.so ($*)"
