@@ -869,7 +869,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         }
     };
     // the listed transitions, three per lane and round trip
-    auto rsq_flush = [&]() {
+    auto MDX_PH_IMPL(rsq_flush) = [&]() {
         u32 n = *rsq_cnt;
         if (n == 0u) return;
         n = n < (u32)MDX_FUSE_RSQ ? n : (u32)MDX_FUSE_RSQ;
@@ -896,6 +896,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             if ((u32)lane + 64u * k < n) rs_apply(t[k], q[k]);
         if (lane == 0) *rsq_cnt = 0u;
     };
+#ifdef MDX_PHASE_CLK
+    auto rsq_flush = [&]() { MDX_PH_IN(11); rsq_flush_impl(); MDX_PH_OUT(); };
+#endif
     // RS: an event byte of a fused record (its staging entry `e`, number `ix`, is still in place: the runs of the fused
     // kernel drain the queue before they return).  The byte is read column p of its side.  A reference base in a left
     // column is counted here (the plain matches: the second TC table).  A transition — each column once: the left
@@ -963,18 +966,27 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         double mr = 0.0;
         const u32 m0 = (u32)(m & ((1ull << rs_npos) - 1ull)), m1 = (u32)(m >> rs_npos);
         const u32 c = m0 | m1;
+        // the record's terms in the reference's order (rescale.py:49-79: the 5' positions upwards, then the 3' positions
+        // from the far one inwards), four at a time: their LDS reads go out together — one after the other, each behind the
+        // addition before it, a record of a dozen terms was a dozen round trips (a sixth of the fused kernel's time).  A
+        // place without a term adds 0.0, which changes nothing.
         u32 c5 = c & (u32)((2ull << a.rs.len5p) - 2ull);
-        while (c5) {
-            const int k = __ffs((int)c5) - 1;
-            c5 &= c5 - 1;
-            mr += l_term[((m0 >> k) & 1u) ? k : rs_npos + k];
-        }
         u32 c3 = (u32)((u64)c >> (a.rs.len5p + 1));
-        while (c3) {
-            const int j = 31 - __clz((int)c3);
-            c3 &= ~(1u << j);
-            const int k = a.rs.len5p + 1 + j;
-            mr += l_term[((m0 >> k) & 1u) ? k : rs_npos + k];
+        auto next = [&](bool &have) -> int {
+            int k = 0;
+            have = (c5 | c3) != 0u;
+            if (c5) { k = __ffs((int)c5) - 1; c5 &= c5 - 1; }
+            else if (c3) { const int j = 31 - __clz((int)c3); c3 &= ~(1u << j); k = a.rs.len5p + 1 + j; }
+            return ((m0 >> k) & 1u) ? k : rs_npos + k;
+        };
+        while (c5 | c3) {
+            bool h0, h1, h2, h3;
+            const int i0 = next(h0), i1 = next(h1), i2 = next(h2), i3 = next(h3);
+            const double t0 = l_term[i0], t1 = l_term[i1], t2 = l_term[i2], t3 = l_term[i3];
+            mr += h0 ? t0 : 0.0;
+            mr += h1 ? t1 : 0.0;
+            mr += h2 ? t2 : 0.0;
+            mr += h3 ? t3 : 0.0;
         }
         return mr;
     };
@@ -2608,6 +2620,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // up to 15 bytes in front of and behind the 16-byte units are moved byte by byte: the stretch belongs
                     // to this tile alone).  The loads of the first pass go out in front of the tile's column loads, its
                     // stores behind them: one round trip for both.
+                    MDX_PH(15);
                     cp_b0 = nb0; cp_b1 = nb1;
                     // (units at the same 16-byte phase as the source column: both columns are 16-byte aligned in any
                     // allocation this library is handed)
@@ -2675,6 +2688,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     const u32 t0 = cp_a0 + 16u * cp_nu + (u32)lane;
                     if (t0 < cp_b1) { const u8 b = qin[t0]; qout[t0] = b; hi |= b; }
                     rs_anyhi = __ballot((hi & 0x80808080u) != 0u) != 0ull;
+                    MDX_PH(1);
                 }
                 bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
                 if (!ML && c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
