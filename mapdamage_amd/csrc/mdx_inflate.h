@@ -234,10 +234,15 @@ MDX_HD Counts counts_of(const uint16_t *count, int fast_bits) {
     return k;
 }
 
+// (host builds of tools/experiments/inflate_stats.cpp count what the decoder meets)
+#ifndef MDX_INFLATE_STAT
+#define MDX_INFLATE_STAT(what, n) do { } while (0)
+#endif
 // one symbol; -1: invalid code
 MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_t *fast, int fast_bits) {
     const uint32_t e = uni(fast[in.peek(fast_bits)]);
     if (__builtin_expect(e != 0u, 1)) { in.drop((int)(e & 15u)); return (int)(e >> 4); }
+    MDX_INFLATE_STAT(fast_bits == FAST_D ? 6 : 7, 1);
     // canonical walk, one bit at a time, from the first length the fast table does not hold (the code so far: the
     // stream's first fast_bits bits, which arrive LSB first, reversed)
 #if MDX_ON_DEVICE
@@ -251,6 +256,7 @@ MDX_HD int decode(BitIn &in, const Counts &k, const uint16_t *sym, const uint16_
         if (len <= fast_bits) continue;
         code |= (int)(b & 1); b >>= 1;
         const int c = (int)k.c[len];
+        MDX_INFLATE_STAT(8, 1);
         if (code - c < first) { in.drop(len); return (int)uni(sym[index + (code - first)]); }
         index += c; first += c; first <<= 1; code <<= 1;
     }
@@ -433,6 +439,7 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
 #endif
                 if (s < 0) return -1;
                 if (s < 256) {
+                    MDX_INFLATE_STAT(0, 1);
                     if (out >= cap) return -2;
                     win[out & (RING - 1)] = (uint8_t)s;  // (every lane stores the same byte: cheaper than masking 63 off)
                     out++;
@@ -443,6 +450,9 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 if (s >= 29) return -1;
                 // length and distance codes -> base + extra bits (RFC 1951 3.2.5), computed: a table in memory costs a
                 // round trip per look-up on the device, four of them in the middle of every match
+                // (round 5: the same arithmetic on the vector unit, handed back through readfirstlane — thirty scalar
+                // instructions fewer per match, the scalar unit being what the kernel is bound by — changed nothing:
+                // 18.9 ms per 4 M records either way; what it saves it pays in the hand-over)
                 const int lx = s < 8 ? 0 : (s == 28 ? 0 : (s >> 2) - 1);
                 const uint32_t lb = s < 8 ? 3u + (uint32_t)s : (s == 28 ? 258u : ((4u + ((uint32_t)s & 3u)) << lx) + 3u);
                 const uint32_t len = lb + in.take(lx);
@@ -453,6 +463,10 @@ MDX_HD int inflate_block(const uint8_t *src, uint32_t in_len, uint8_t *win, uint
                 const uint32_t dist = db + in.take(dx);
                 if (dist > out) return -1;
                 if (out + len > cap) return -2;
+                MDX_INFLATE_STAT(1, 1); MDX_INFLATE_STAT(2, len);
+                if (dist > (uint32_t)RING) MDX_INFLATE_STAT(3, 1);
+                else if (len <= 64u && dist >= len) MDX_INFLATE_STAT(4, 1);
+                else if (dist < 64u) MDX_INFLATE_STAT(5, 1);
 #if MDX_ON_DEVICE
                 __builtin_amdgcn_wave_barrier();
                 if (RING < 32768 && __builtin_expect(dist > (uint32_t)RING, 0)) {
