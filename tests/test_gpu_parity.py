@@ -115,6 +115,21 @@ def test_hip_sorted_batch_with_gap_run(mid_genome):
     assert_tables_equal(got, want)
 
 
+def test_hip_every_column_an_event(mid_genome):
+    """Reads whose every base differs from the reference (A <-> C, G <-> T): every lane of every step queues an event, the
+    packed kernel's queue overflows in every group of steps — in the first and in the second of a pair of groups alike
+    (csrc/mdx_kernels.hip: run(), `ovf`) — and the run drains and starts again from the step that did not fit."""
+    batch = synth.make_reads(mid_genome, 60_000, 29, read_len=100, frac_softclip=0.1, frac_ins=0.03, frac_del=0.03)
+    swap = np.arange(256, dtype=np.uint8)
+    for a, b in (("A", "C"), ("G", "T")):
+        swap[ord(a)], swap[ord(b)] = ord(b), ord(a)
+    batch.seq[:] = swap[batch.seq]
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 0)
+    got = run_engine(mid_genome, batch, libs, 70, 10, 0, resident=True)
+    assert_tables_equal(got, want)
+
+
 @pytest.mark.parametrize("Q", [15, 0])
 @pytest.mark.parametrize("phase", [1, 2, 3])
 def test_hip_unaligned_column_pointers(phase, Q, mid_genome, seq_form):
