@@ -115,6 +115,19 @@ def test_hip_sorted_batch_with_gap_run(mid_genome):
     assert_tables_equal(got, want)
 
 
+@pytest.mark.parametrize("kw", [dict(frac_ins=0.5, frac_del=0.5), dict(frac_softclip=1.0, frac_ins=0.3, frac_del=0.3, frac_skip=0.2),
+                                dict(len_range=(20, 69), frac_ins=0.2, frac_del=0.2)])
+def test_hip_lists_full_in_every_round(kw, mid_genome):
+    """Batches none of whose records is a plain one: every tile appends 63 entries to the wavefront's rings (the lists of
+    single insertions, single deletions, partial records; the ring of records handed to the general pass), which wrap
+    within a launch and are emptied round by round (csrc/mdx_internal.h: MDX_LIST_RING, MDX_ROUND_TILES, MDX_DRING)."""
+    batch = synth.make_reads(mid_genome, 400_000, 31, read_len=100, **kw)
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, 70, 10, 0)
+    got = run_engine(mid_genome, batch, libs, 70, 10, 0, resident=True)
+    assert_tables_equal(got, want)
+
+
 def test_hip_every_column_an_event(mid_genome):
     """Reads whose every base differs from the reference (A <-> C, G <-> T): every lane of every step queues an event, the
     packed kernel's queue overflows in every group of steps — in the first and in the second of a pair of groups alike
