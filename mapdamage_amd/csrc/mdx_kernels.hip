@@ -125,6 +125,9 @@ typedef long long i64;
 #ifndef MDX_PK_PD
 #define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
 #endif
+#ifndef MDX_PK_PD_P
+#define MDX_PK_PD_P 4                   // ... and of its runs of partial entries (four: its groups are added in pairs)
+#endif
 #ifndef MDX_PK_PTILE
 #define MDX_PK_PTILE 1                  // the packed kernels count a tile's partial records in the tile loop (0: through the wavefront's list behind it; the fused one always does)
 #endif
@@ -1613,7 +1616,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 };
                 // (--min-basequal: three — the second set of planes and the bitmap words want the registers of the fourth)
-                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? MDX_PD_P : (MASK ? MDX_PKM_PD : MDX_PK_PD));
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : MDX_PD_P) : (MASK ? MDX_PKM_PD : MDX_PK_PD));
                 static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
                 St16 st[PD4];
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
