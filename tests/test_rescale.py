@@ -394,6 +394,52 @@ def test_hip_tabulate_and_rescale_in_one_pass(tmp_path):
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_tables", [True, False])
+def test_hip_rescale_of_a_batch_whose_seq_column_carries_the_min_basequal_mask(tmp_path, with_tables):
+    """A context with --min-basequal uploads a 4-bit batch as MDX_SEQ_4BITQ (the mask folded into the nibbles, include/mdx.h).
+    The rescaling reads the bases of such a column as the bases they are — rescale.py knows no --min-basequal — and the
+    tabulation of the same call counts with the mask (align.py:53-73)."""
+    import torch
+
+    from mapdamage_amd.engine import DamageEngine
+    from oracle import oracle
+    from tests.util import assert_tables_equal, oracle_tableset
+    _, _, model, corr_prob, _, _ = load(tmp_path)
+    ref = synth.make_genome(seed=11, sizes=(("chr1", 300_000), ("chr2", 100_000), ("chrS", 500)), n_run=500, lower_run=3000)
+    b = synth.make_reads(ref, 60_000, 27, len_range=(30, 150), paired=True, frac_softclip=0.15, frac_ins=0.06, frac_del=0.06,
+                         frac_skip=0.01, with_qual=True, frac_filtered=0.03)
+    rng = np.random.default_rng(5)
+    b.mtid = b.tid.copy()
+    b.mpos = (b.pos + rng.integers(-300, 300, size=b.n)).astype(np.int32)
+    libs = [("s", "l")]
+    Q = 20
+    want_q, want_mr, want_st = oracle.rescale(ref, b, corr_table(corr_prob, model), model.len5p, model.len3p)
+    dev = torch.device("cuda", 0)
+    with DamageEngine(libs, 70, 10, Q) as eng:
+        eng.set_reference(ref)
+        eng.set_rescale_model(model)
+        db = eng.upload(b, packed=True)
+        from mapdamage_amd.engine import SEQ_4BITQ
+        assert db.dev.seq_format == SEQ_4BITQ
+        mtid, mpos = torch.from_numpy(b.mtid).to(dev), torch.from_numpy(b.mpos).to(dev)
+        qout = torch.zeros(b.seq.shape[0] + 64, dtype=torch.uint8, device=dev)
+        mr = torch.zeros(b.n, dtype=torch.float64, device=dev)
+        st = torch.zeros(b.n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.rescale_device(db, mtid.data_ptr(), mpos.data_ptr(), qout.data_ptr(), mr.data_ptr(), st.data_ptr(), with_tables=with_tables)
+        if not with_tables:
+            eng.tabulate(db)
+        got_tables = eng.finish()
+        db.free()
+    assert_tables_equal(got_tables, oracle_tableset(ref, b, libs, 70, 10, Q))
+    np.testing.assert_array_equal(qout.cpu().numpy()[:b.seq.shape[0]], want_q)
+    np.testing.assert_array_equal(st.cpu().numpy(), want_st)
+    got_mr = mr.cpu().numpy()
+    assert np.array_equal(np.isnan(got_mr), np.isnan(want_mr))
+    np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
+
+
 def one_pass(eng, b, packed=False):
     """mdx_tabulate_rescale_device on the uploaded batch (``packed``: its SEQ column in the 4-bit form) -> (qualities, MR,
     status) as host arrays; the tables stay in the engine."""
