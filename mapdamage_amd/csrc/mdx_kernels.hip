@@ -209,6 +209,9 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 #ifndef MDX_PK_DEFER
 #define MDX_PK_DEFER 1                  // the plain packed kernel adds its groups of four steps in pairs (tabulate_kernel: HS)
 #endif
+#ifndef MDX_PK_STEAL
+#define MDX_PK_STEAL 2                    // pools a wavefront of the packed kernels asks for tiles once its own is empty (0: none)
+#endif
 #ifndef MDX_PK_DEFER_ML
 #define MDX_PK_DEFER_ML 0               // ... the epoch kernel does not: 128 registers, seven more spilled with the pair's words
 #endif
@@ -2484,18 +2487,44 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // when the tiles were dealt round-robin; a stretch of its own per pool cost such a batch 5 %)
         static_assert(!(ML && MDX_PK_PREFETCH), "the prefetched columns know no epochs");
         u32 grabs = 0;
+        // (STEAL — the packed kernels with one answer outstanding at a time, plain and --min-basequal: a wavefront whose pool has
+        // run dry goes on with the tiles of other pools, see tile_of; pool_cur = the pool it asks at present.  A stolen tile
+        // takes the place of the answer that found the pool empty: the quota counts it once)
+        constexpr bool STEAL = MDX_PK_STEAL && PK && !RS && !ML;
+        u32 pool_cur = pool;
         auto grab = [&]() -> u32 {
             // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
             u32 v = 0xFFFFFFFFu;
-            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + (ML ? (u32)ep * n_pools : 0u) + pool, 1u); grabs++; }
+            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + (ML ? (u32)ep * n_pools : 0u) + (STEAL ? pool_cur : pool), 1u); grabs++; }
             return v;
         };
         // (ML: the chunks of an epoch go on round-robin over the pools where the epoch before stopped — chunk c of the launch
         // is pool c % n_pools's —, so that libraries of a few chunks each do not all begin with pool 0)
         const u32 ch_first = ML ? (pool + n_pools - ml_chunk0 % n_pools) % n_pools : pool;
         auto tile_of = [&](const u32 raw) -> u32 {
-            const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)raw);
+            u32 v = (u32)__builtin_amdgcn_readfirstlane((int)raw);
             if (v == 0xFFFFFFFFu) return v;
+            if (STEAL) {
+                // The pools do not finish together — a CU's blocks run up to 5 % slower or faster than the chip's mean
+                // (tools/experiments/wave_clk.py), on some boxes of the pool far more — and a launch lasts as long as its
+                // slowest pool: a wavefront that finds its pool empty asks the counters of two others, 37 pools apart (a
+                // pool's answer says whether it has a tile left), and stays with the first that has.  One answer is
+                // outstanding at a time, asked of pool_cur and read here: a wavefront never reads an answer under another
+                // pool's name.  Two boxes, 25 M config-3 records: 1.125 -> 1.122 ms on one, 1.61 -> 1.25 ms on the other (six
+                // pools asked: 1.135 on the first — every wavefront's last act is then six round trips for nothing).
+                u32 tile = 0xFFFFFFFFu;
+#pragma unroll 1
+                for (int tries = 0;; tries++) {
+                    const u32 ch = v / MDX_POOL_CHUNK, t = (ch * n_pools + pool_cur) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
+                    if (t < n_tiles) { tile = t; break; }
+                    if (tries == MDX_PK_STEAL) break;
+                    pool_cur = (pool_cur + 37u) % n_pools;
+                    u32 r = 0u;
+                    if (lane == 0) r = atomicAdd(a.tile_ctr + pool_cur, 1u);
+                    v = (u32)__builtin_amdgcn_readfirstlane((int)r);
+                }
+                return tile;
+            }
             const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * n_pools + ch_first) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
             return tile < n_tiles ? tile : 0xFFFFFFFFu;
         };
