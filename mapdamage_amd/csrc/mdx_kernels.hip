@@ -2487,10 +2487,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // when the tiles were dealt round-robin; a stretch of its own per pool cost such a batch 5 %)
         static_assert(!(ML && MDX_PK_PREFETCH), "the prefetched columns know no epochs");
         u32 grabs = 0;
-        // (STEAL — the packed kernels with one answer outstanding at a time, plain and --min-basequal: a wavefront whose pool has
-        // run dry goes on with the tiles of other pools, see tile_of; pool_cur = the pool it asks at present.  A stolen tile
-        // takes the place of the answer that found the pool empty: the quota counts it once)
-        constexpr bool STEAL = MDX_PK_STEAL && PK && !RS && !ML;
+        // (STEAL — the packed kernels but the epoch launches, whose epochs are too short for it (8 libraries +2 %): a wavefront
+        // whose pool has run dry goes on with the tiles of other pools, see tile_of; pool_cur = the pool it asks at present.
+        // A stolen tile takes the place of the answer that found the pool empty: the quota counts it once)
+        constexpr bool STEAL = MDX_PK_STEAL && PK && !ML;
         u32 pool_cur = pool;
         auto grab = [&]() -> u32 {
             // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
