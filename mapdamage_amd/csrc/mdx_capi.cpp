@@ -580,7 +580,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         // and as there are tile counters for; a launch touches the records of its own libraries only)
         const int64_t slot_bytes = (int64_t)c->n_cu * mdx_k_pk_blocks_per_cu() * dims1.w_total * 4;
         int64_t g = ((int64_t)512 << 20) / slot_bytes;
-        if (g > 65536 / c->n_cu) g = 65536 / c->n_cu;
+        if (g > MDX_CTR_WORDS / (MDX_CTR_PAD * (int64_t)c->n_cu)) g = MDX_CTR_WORDS / (MDX_CTR_PAD * (int64_t)c->n_cu);
         group = (int)(g < 1 ? 1 : (g > c->cfg.nlib ? c->cfg.nlib : g));
     }
     for (int lo = 0; lo < c->cfg.nlib; lo += group) {
@@ -633,7 +633,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             const int64_t nwaves = (int64_t)grid * wpb_l;
             const int64_t T = a.dims.R > 0 ? 64 - 64 % a.dims.R : 64;
             const int64_t n_tiles = (b->n_reads + T - 1) / T;
-            const int64_t n_pools = (grid >= 2 && !(grid & 1)) ? grid / 2 : grid;
+            const int64_t n_pools = mdx_n_pools((unsigned)grid);
             // (a pool takes chunks of MDX_POOL_CHUNK tiles, the pools' chunks interleaved: at most one chunk more than its share)
             const int64_t chunk = MDX_POOL_CHUNK;
             const int64_t pool_tiles = ((n_tiles + n_pools * chunk - 1) / (n_pools * chunk)) * chunk, pool_waves = (grid / n_pools) * wpb_l;
@@ -646,10 +646,10 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.ring_size = MDX_LIST_RING;
             if (quota) while ((int64_t)a.ring_size < (int64_t)a.tile_quota * T + 128) a.ring_size *= 2;
             if (!c->d_tile_ctr) {
-                HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)65536 * 4));
-                HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)65536 * 4, c->stream));
+                HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)MDX_CTR_WORDS * 4));
+                HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)MDX_CTR_WORDS * 4, c->stream));
             }
-            if (n_pools > 4096 || n_pools * (ml ? gn : 1) > 65536) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
+            if (n_pools * MDX_CTR_PAD > MDX_CTR_WORDS / 2 || n_pools * (ml ? gn : 1) * MDX_CTR_PAD > MDX_CTR_WORDS) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
             a.tile_ctr = c->d_tile_ctr;
             {
                 // (scratch of the launch: rings of 81 KB per wavefront — 330 MB for the packed kernel's 4096 wavefronts —, whatever the
@@ -710,8 +710,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         }
         // (the pools' tile counters: zeroed by the reduction behind the previous launch, as a rule; else here, inside the timed region)
         // (an epoch launch: one counter per (library, pool))
-        const size_t n_ctr = ml ? (size_t)gn * (size_t)((grid >= 2 && !(grid & 1)) ? grid / 2 : grid) : 4096;
-        if (!c->tile_ctr_clean || n_ctr > 4096) HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (n_ctr > 4096 ? n_ctr : 4096) * 4, c->stream));
+        // (a counter per 128-byte line; the reduction behind a launch zeroes those of the first 4 096 pools)
+        const size_t n_ctr = (ml ? (size_t)gn : 1) * (size_t)mdx_n_pools((unsigned)grid);
+        if (!c->tile_ctr_clean || n_ctr > 4096) HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, n_ctr * MDX_CTR_PAD * 4, c->stream));
         c->tile_ctr_clean = false;
         if (fuse) {
             // (a record written back unchanged keeps this NaN — all ones; inside the timed region)

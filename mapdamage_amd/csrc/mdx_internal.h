@@ -76,6 +76,18 @@ struct MdxDims {
 };
 
 #define MDX_MAX_R 4       // records per wavefront step (staging pad = R - 1 entries)
+// blocks of a pool (the fast kernels' hand-out of tiles): the grid in pools of that many blocks each where it divides
+#ifndef MDX_POOL_BLOCKS
+#define MDX_POOL_BLOCKS 2
+#endif
+static inline __host__ __device__ unsigned mdx_n_pools(unsigned grid) {
+    return (grid >= MDX_POOL_BLOCKS && grid % MDX_POOL_BLOCKS == 0u) ? grid / MDX_POOL_BLOCKS : ((grid >= 2u && !(grid & 1u)) ? grid / 2u : grid);
+}
+// words between two tile counters: a counter per 128-byte line — atomics on one line queue at the L2, whichever word they add to
+#ifndef MDX_CTR_PAD
+#define MDX_CTR_PAD 32
+#endif
+#define MDX_CTR_WORDS 262144   // the counters' buffer (MdxTabArgs::tile_ctr)
 #ifndef MDX_POOL_CHUNK
 #define MDX_POOL_CHUNK 24  // consecutive tiles a pool of two blocks takes at a time (the fast kernels' hand-out of tiles)
 #endif

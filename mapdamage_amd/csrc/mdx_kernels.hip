@@ -2480,7 +2480,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // back under a tile's work) and — RS, whose list of records left to the rescale kernels is sized for that many — takes
         // at most tile_quota of them (the quotas of a pool's wavefronts add up to twice its tiles).
         const u32 n_tiles = (n_rec + T - 1) / T;
-        const u32 n_pools = (gridDim.x >= 2u && !(gridDim.x & 1u)) ? gridDim.x / 2u : gridDim.x;
+        const u32 n_pools = mdx_n_pools(gridDim.x);
         const u32 pool = blockIdx.x % n_pools;
         // (a pool's tiles: chunks of MDX_POOL_CHUNK consecutive tiles, the pools' chunks interleaved — the whole chip works
         // on one neighbourhood of a coordinate-sorted batch at a time and shares its reference lines in the L2s, as it did
@@ -2495,7 +2495,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         auto grab = [&]() -> u32 {
             // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
             u32 v = 0xFFFFFFFFu;
-            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + (ML ? (u32)ep * n_pools : 0u) + (STEAL ? pool_cur : pool), 1u); grabs++; }
+            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + ((ML ? (u32)ep * n_pools : 0u) + (STEAL ? pool_cur : pool)) * MDX_CTR_PAD, 1u); grabs++; }
             return v;
         };
         // (ML: the chunks of an epoch go on round-robin over the pools where the epoch before stopped — chunk c of the launch
@@ -2520,7 +2520,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (tries == MDX_PK_STEAL) break;
                     pool_cur = (pool_cur + 37u) % n_pools;
                     u32 r = 0u;
-                    if (lane == 0) r = atomicAdd(a.tile_ctr + pool_cur, 1u);
+                    if (lane == 0) r = atomicAdd(a.tile_ctr + pool_cur * MDX_CTR_PAD, 1u);
                     v = (u32)__builtin_amdgcn_readfirstlane((int)r);
                 }
                 return tile;
@@ -3365,7 +3365,7 @@ __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__
     if (w >= w_total) return;
     const int part = blockIdx.y;
     const i64 z = blockIdx.z;
-    if (tile_ctr && part == 0 && z == 0 && w < 4096) tile_ctr[w] = 0u;
+    if (tile_ctr && part == 0 && z == 0 && w < 4096) tile_ctr[w * MDX_CTR_PAD] = 0u;       // (the counters of up to 4 096 pools, a line apart)
     const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
     const u32 *const pz = partials + z * (i64)grid * w_total;
     u64 acc = 0;
