@@ -147,7 +147,7 @@ struct mdx_ctx {
     DevBuf lowq;           // --min-basequal, packed kernel: the scratch column a MDX_SEQ_4BIT batch's mask is folded into (MDX_SEQ_4BITQ)
     DevBuf libsort;        // several libraries, packed kernel: the batch's columns bucketed by library (a batch that does not bring them)
     DevBuf libsort_scratch;
-    DevBuf ml_partials;    // ... and the blocks' slots of an epoch launch, [library][block]
+    DevBuf ml_partials;    // ... and the plan of a launch over several libraries: which library a pool of blocks counts (MdxTabArgs::ml_plan)
     int64_t n_libsorts = 0;        // sorts done inside a launch so far (a resident batch brings its own: mdx_batch::libsort)
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
     int64_t n_packed = 0;          // launches of the packed kernel so far (mdx_packed_launches)
@@ -522,7 +522,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     const bool packed = b_in->seq_format != MDX_SEQ_ASCII && c->mode == MDX_MODE_LDS && c->dims.fast_ok() && ref32 &&
                         (fuse ? (c->cfg.nlib == 1 && !folded) : !(want_mask && no_pkm)) && !no_packed;
     const bool pmask = packed && !fuse && want_mask;
-    // Several libraries through the packed kernel: ONE launch that counts the libraries one after the other (an epoch each)
+    // Several libraries through the packed kernel: ONE launch that counts the libraries side by side (a library per pool of blocks)
     // over the columns bucketed by library — the batch's own (mdx_batch::libsort, a resident batch) or sorted here, inside the
     // launch's timed region.  (MDX_NO_ML=1 in the environment: one launch per library, each over all records, for A/B runs)
     static const bool no_ml = [] { const char *e = getenv("MDX_NO_ML"); return e && *e && *e != '0'; }();
@@ -576,17 +576,14 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     int group = packed ? 1 : (c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib);
     const MdxDims dims1 = mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds);
     if (ml) {
-        // (as many epochs per launch as half a gigabyte of block slots holds — [library][block], one library's image each —
-        // and as there are tile counters for; a launch touches the records of its own libraries only)
-        const int64_t slot_bytes = (int64_t)c->n_cu * mdx_k_pk_blocks_per_cu() * dims1.w_total * 4;
-        int64_t g = ((int64_t)512 << 20) / slot_bytes;
-        if (g > MDX_CTR_WORDS / (MDX_CTR_PAD * (int64_t)c->n_cu)) g = MDX_CTR_WORDS / (MDX_CTR_PAD * (int64_t)c->n_cu);
-        group = (int)(g < 1 ? 1 : (g > c->cfg.nlib ? c->cfg.nlib : g));
+        // (a pool of blocks counts one library: as many libraries per launch as a launch of the fewest blocks has pools — and
+        // as the plan's arrays hold)
+        group = c->cfg.nlib < MDX_ML_MAX_LIBS ? c->cfg.nlib : MDX_ML_MAX_LIBS;
     }
     for (int lo = 0; lo < c->cfg.nlib; lo += group) {
         const int gn = c->cfg.nlib - lo < group ? c->cfg.nlib - lo : group;
         a.lib_lo = lo;
-        a.n_epochs = ml ? gn : 0;
+        a.n_libs = ml ? gn : 0;
         size_t lds = 0;
         int max_grid = c->max_grid;
         if (c->mode == MDX_MODE_LDS) {
@@ -603,6 +600,9 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         a.stage_off = mdx_k_stage_off(a.dims);
         a.queue_off = packed ? mdx_k_pk_queue_off(a.dims) : mdx_k_queue_off(a.dims);
         int grid = (int)(want < max_grid ? want : max_grid);
+        // (several libraries: a pool — two blocks — for every library at least)
+        if (ml && grid < 2 * gn) grid = 2 * gn < max_grid ? 2 * gn : max_grid;
+        if (ml && (grid & 1)) grid++;
         int wpb_l = wpb;
         if (fuse) {
             // one 1024-thread block per CU (mdx_k_fuse_*): the whole batch in one launch, all libraries
@@ -637,9 +637,11 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             // (a pool takes chunks of MDX_POOL_CHUNK tiles, the pools' chunks interleaved: at most one chunk more than its share)
             const int64_t chunk = MDX_POOL_CHUNK;
             const int64_t pool_tiles = ((n_tiles + n_pools * chunk - 1) / (n_pools * chunk)) * chunk, pool_waves = (grid / n_pools) * wpb_l;
-            // (the fused kernels and the epoch launches are held to a quota — their rings, and the fused kernels' lists of records
+            // (the fused kernels and the masked one-library kernel are held to a quota — their rings, and the fused kernels' lists of records
             // left to the rescale kernels, are sized by it; the others work in rounds with rings of a fixed size)
-            const bool quota = fuse || ml || pmask;
+            // (a launch over several libraries works in rounds whatever else it is: its pools are as full as their libraries are
+            // large, and a quota would have to know the fullest)
+            const bool quota = fuse || (pmask && !ml);
             a.tile_quota = quota ? (int)(2 * ((pool_tiles + pool_waves - 1) / pool_waves) + 2) : 0x7FFFFFFF;
             a.list_cap = fuse ? (int64_t)a.tile_quota * T + 128 : 0;
             a.round_tiles = MDX_ROUND_TILES;
@@ -649,11 +651,11 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
                 HIP_TRY(c, hipMalloc((void **)&c->d_tile_ctr, (size_t)MDX_CTR_WORDS * 4));
                 HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, (size_t)MDX_CTR_WORDS * 4, c->stream));
             }
-            if (n_pools * MDX_CTR_PAD > MDX_CTR_WORDS / 2 || n_pools * (ml ? gn : 1) * MDX_CTR_PAD > MDX_CTR_WORDS) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
+            if (n_pools * MDX_CTR_PAD > MDX_CTR_WORDS / 2 || n_pools * MDX_CTR_PAD > MDX_CTR_WORDS) return fail(c, MDX_ERR_STATE, "more blocks than tile counters");
             a.tile_ctr = c->d_tile_ctr;
             {
                 // (scratch of the launch: rings of 81 KB per wavefront — 330 MB for the packed kernel's 4096 wavefronts —, whatever the
-                // batch; the fused kernels and the epoch launches: 150 bytes per record of the batch)
+                // batch; the fused kernels and the masked one-library kernel: 150 bytes per record of the batch)
                 const size_t list_bytes = (size_t)nwaves * (size_t)MDX_WAVE_SCRATCH(a.ring_size) * 16;
                 if (c->lists.reserve(list_bytes) != hipSuccess)
                     return fail(c, MDX_ERR_HIP, "the per-wavefront lists of this launch (" + std::to_string(list_bytes >> 20) + " MiB) could not be allocated" +
@@ -705,13 +707,14 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.flag = ls.flag; a.tid = ls.tid; a.pos = ls.pos; a.tlen = ls.tlen;
             a.cigar_off = ls.cigar_off; a.cigar = ls.cigar; a.seq_off = ls.seq_off; a.seq = ls.seq;
             a.perm = ls.perm; a.lib_start = ls.lib_start; a.sort_bad = ls.bad;
-            HIP_TRY(c, c->ml_partials.reserve((size_t)grid * gn * a.dims.w_total * 4));
-            a.partials = (uint32_t *)c->ml_partials.p;
+            // the pools dealt to the libraries by their sizes (on the device: nothing of the sort comes back to the host)
+            HIP_TRY(c, c->ml_partials.reserve((size_t)mdx_n_pools((unsigned)grid) * 16));
+            a.ml_plan = (const uint4 *)c->ml_partials.p;
+            mdx_k_ml_plan(ls.lib_start, lo, gn, (int)(a.dims.R > 0 ? 64 - 64 % a.dims.R : 64), grid, c->ml_partials.p, c->stream);
         }
         // (the pools' tile counters: zeroed by the reduction behind the previous launch, as a rule; else here, inside the timed region)
-        // (an epoch launch: one counter per (library, pool))
         // (a counter per 128-byte line; the reduction behind a launch zeroes those of the first 4 096 pools)
-        const size_t n_ctr = (ml ? (size_t)gn : 1) * (size_t)mdx_n_pools((unsigned)grid);
+        const size_t n_ctr = (size_t)mdx_n_pools((unsigned)grid);
         if (!c->tile_ctr_clean || n_ctr > 4096) HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, n_ctr * MDX_CTR_PAD * 4, c->stream));
         c->tile_ctr_clean = false;
         if (fuse) {
@@ -739,7 +742,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         }
         HIP_TRY(c, hipGetLastError());
         if (c->mode == MDX_MODE_LDS) {
-            if (ml) mdx_k_reduce_partials(a.partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream, c->d_tile_ctr, gn, c->dims.w_lib);
+            if (ml) mdx_k_reduce_partials(c->d_partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream, c->d_tile_ctr, gn, c->dims.w_lib, a.ml_plan);
             else
             mdx_k_reduce_partials(c->d_partials, a.raw, c->d_raw + c->dims.w_total - 1, a.dims.w_total, grid, c->stream, c->d_tile_ctr);
             c->tile_ctr_clean = a.dims.w_total >= 4096 && n_ctr <= 4096;

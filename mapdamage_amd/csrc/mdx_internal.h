@@ -88,6 +88,7 @@ static inline __host__ __device__ unsigned mdx_n_pools(unsigned grid) {
 #define MDX_CTR_PAD 32
 #endif
 #define MDX_CTR_WORDS 262144   // the counters' buffer (MdxTabArgs::tile_ctr)
+#define MDX_ML_MAX_LIBS 64     // libraries of a context the packed kernels count in one launch (six bits of a staging entry)
 #ifndef MDX_POOL_CHUNK
 #define MDX_POOL_CHUNK 24  // consecutive tiles a pool of two blocks takes at a time (the fast kernels' hand-out of tiles)
 #endif
@@ -195,7 +196,7 @@ struct MdxTabArgs {
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
     // Per-wavefront lists: wavefront w owns MDX_WAVE_SCRATCH(ring_size) 16-byte entries (rings: see above and the kernel).
     // Written in the tile loop, read back by the same wavefront at the end of its round.  ring_size (a power of two): MDX_LIST_RING —
-    // 81 KB per wavefront whatever the batch — for the kernels that work in rounds; for the fused kernels and the epoch
+    // 81 KB per wavefront whatever the batch — for the kernels that work in rounds; for the fused kernels and the masked
     // launches, which do not, what a wavefront's tile_quota of tiles can append.
     uint4 *lists;
     int ring_size;
@@ -204,20 +205,20 @@ struct MdxTabArgs {
     int64_t list_cap;
     MdxFuse rs;                      // used by the fused kernel only
     // Fast kernels: tiles are handed out on demand within pools of two blocks (the two that share a CU): one counter per
-    // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (the fused kernels and the epoch launches —
-    // per epoch —: their rings, and the fused kernels' list_cap, hold the records of that many; the others: no limit)
+    // pool, zeroed before the launch; a wavefront takes at most tile_quota tiles (the fused kernels and the masked kernel: their rings, and the fused kernels' list_cap, hold the records of that many; the others: no limit)
     uint32_t *tile_ctr;
+    const uint4 *ml_plan;            // launches over several libraries: per pool {library, place among its pools, their number, the first}
     int tile_quota;
     int round_tiles;                 // tiles of a round (MDX_ROUND_TILES; the list rings hold a round's entries)
-    // Several libraries in one launch of the packed kernel (tabulate_kernel<.., PK, ML>; n_epochs > 0): the batch above is the
+    // Several libraries in one launch of the packed kernel (tabulate_kernel<.., PK, ML>; n_libs > 0): the batch above is the
     // copy of mdx_libsort.hip, ordered by library — place i holding one kept record (the flag filter of reader.py:121-132
     // applied on the way), the records of library l at places [lib_start[l], lib_start[l + 1]) in batch order, CIGAR, SEQ and
     // low-quality bitmap in the same order; perm = a record's index within the caller's batch (for the error word).  The
-    // launch counts the libraries [lib_lo, lib_lo + n_epochs), one epoch each; dims are one library's; partials holds
-    // [n_epochs][grid] slots; tile_ctr one counter per (epoch, pool).
+    // launch counts the libraries [lib_lo, lib_lo + n_libs), every pool of blocks one of them (ml_plan); dims are one
+    // library's; partials holds a slot per block, tile_ctr a counter per pool, as in a one-library launch.
     const uint32_t *perm, *lib_start;
     const unsigned long long *sort_bad;     // MdxLibSort::bad
-    int n_epochs;
+    int n_libs;
 #ifdef MDX_WAVE_CLK
     // instrumented builds (-DMDX_WAVE_CLK, tools/experiments/wave_clk.py): three clock readings per wavefront — start,
     // end of the tile loop, end — read back with mdx_dbg_clk_read
@@ -283,11 +284,15 @@ void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipS
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 // (tile_ctr, if not null and w_total >= 4096: 4096 words zeroed on the way — the next launch's tile counters)
-// (n_lib > 1: the slots of an epoch launch, [library][block], each library summed into its own stretch of raw, lib_stride words apart)
+// (n_lib > 1: a launch over several libraries — `plan` says which library a block's slot holds; each library is summed into its
+// own stretch of raw, lib_stride words apart)
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
-                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr = nullptr, int n_lib = 1, int64_t lib_stride = 0);
+                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr = nullptr, int n_lib = 1, int64_t lib_stride = 0,
+                           const void *plan = nullptr);
+// the pools of a launch over several libraries dealt to the libraries (MdxTabArgs::ml_plan: n_pools x uint4)
+void mdx_k_ml_plan(const uint32_t *lib_start, int lib_lo, int nlib, int T, int grid, void *plan, hipStream_t s);
 
-// ---- bucketing a batch's records by library (mdx_libsort.hip), for the packed kernel's epoch launches
+// ---- bucketing a batch's records by library (mdx_libsort.hip), for the packed kernel's launches over several libraries
 struct MdxLibSort {
     unsigned long long *bad; // min over index << 8 | code of the kept records whose library is not below nlib (~0: none): they have
                              // no place, and every launch over the bucketed columns reports the first of them (MdxTabArgs::sort_bad)

@@ -213,7 +213,7 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 #define MDX_PK_STEAL 2                    // pools a wavefront of the packed kernels asks for tiles once its own is empty (0: none)
 #endif
 #ifndef MDX_PK_DEFER_ML
-#define MDX_PK_DEFER_ML 0               // ... the epoch kernel does not: 128 registers, seven more spilled with the pair's words
+#define MDX_PK_DEFER_ML 0               // ... the kernel of the launches over several libraries does not: 128 registers (with them: no faster)
 #endif
 #ifndef MDX_PK_WPS
 #define MDX_PK_WPS 4
@@ -600,14 +600,16 @@ void mdx_k_unpack_seq(const u8 *d_packed, u8 *d_ascii, int64_t n, hipStream_t s)
 // PK: the packed form — 4-bit SEQ and reference, bit-sliced counting (see above); the LDS image holds one library
 // ML: several libraries in one launch of the packed kernel (reader.py:47-50, statistics.py:12-20: the tables are keyed by
 //     library).  The batch arrives ordered by library (mdx_libsort.hip: MdxTabArgs::perm, ::lib_start — the flag filter
-//     applied on the way) and the kernel runs one *epoch* per library over that library's records: tiles
-//     handed out per (library, pool), the LDS image — one library's tables — stored to the block's slot of that library
-//     at the end of the epoch and zeroed for the next one.  Nothing but the blocks of a pool wait for one another.
+//     applied on the way) and every pool of blocks counts ONE library: the pools are dealt to the libraries in proportion to
+//     their tiles on the device (ml_plan_kernel, MdxTabArgs::ml_plan), a library's pools share its tiles among themselves as
+//     the pools of a one-library launch share the batch's, and the reduction adds a block's image to the tables of its pool's
+//     library.  (Until the end of round 5 every block went through all libraries, an epoch each: 8 libraries 1.27 x the
+//     one-library launch; now 1.03 x.)
 template <bool USE_LDS, bool MASK, bool FAST, bool RS = false, bool PK = false, bool ML = false>
 __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK), RS ? MDX_FUSE_WPS : (PK ? MDX_PK_WPS : MDX_WPS)) void tabulate_kernel(MdxTabArgs a) {
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
     static_assert(!PK || (USE_LDS && FAST), "the packed kernel is the fast LDS kernel (plain, with the fused rescaling, or with --min-basequal)");
-    static_assert(!ML || (PK && !RS), "epochs by library: the packed kernels (plain and --min-basequal)");
+    static_assert(!ML || (PK && !RS), "a library per pool: the packed kernels (plain and --min-basequal)");
     constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK);
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
@@ -1833,11 +1835,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // (record indices fit 32 bits: mdx_tabulate_device rejects batches of 2^30 records and more)
     // A tile holds a multiple of R records (63 at three per step): the fast run of a tile of complete
     // records ends on a full step.
-    // (ML: the records of the epoch's library, places [rec_lo, rec_lo + n_rec) of the bucketed columns; ml_lib = that library,
+    // (ML: the records of the pool's library, places [rec_lo, rec_lo + n_rec) of the bucketed columns; ml_lib = that library,
     // counted from the launch's first one)
     u32 n_rec = (u32)a.n_reads, rec_lo = 0u;
     int ml_lib = 0;
-    u32 ml_chunk0 = 0u;     // ML: chunks of tiles handed out by the epochs so far (the pools take them round-robin across epochs)
+    u32 ml_k = 0u, ml_m = 1u, ml_first = 0u;     // ML: the pool's place among the ml_m pools of its library, the first of which is pool ml_first
     const u32 T = FAST ? 64u - 64u % (u32)d.R : 64u;
     const u32 rounds = (n_rec / T) / nwaves;
     const u32 rem_lo = rounds * nwaves * T, rem = n_rec - rem_lo;
@@ -1856,11 +1858,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // l* = entries appended so far, h* = entries taken so far (entry k of a ring sits at k & (size - 1)).  Written with plain
     // stores and read back by the same wavefront past the vector L1 (ring_at: a line of a ring may sit there from the
     // turn before).
-    // (the rings' size is the launch's: MDX_LIST_RING for the kernels that work in rounds; the fused kernels, the epoch launches and
-    // the packed masked kernel — ROUNDS false: their registers do not take the loop of rounds around the tile loop, measured:
-    // config 5 -6 %, 8 libraries -4 %, --min-basequal -6 % (10 registers spilled) — keep one round and rings that hold what a
-    // wavefront's quota of tiles can append)
-    constexpr bool ROUNDS = !(RS || ML || (MASK && PK));
+    // (the rings' size is the launch's: MDX_LIST_RING for the kernels that work in rounds; the fused kernels and the packed
+    // masked kernel of a one-library launch — ROUNDS false: their registers do not take the loop of rounds around the tile
+    // loop, measured: config 5 -6 %, --min-basequal -6 % (10 registers spilled) — keep one round and rings that hold what a
+    // wavefront's quota of tiles can append.  A launch over several libraries works in rounds whatever else it is: its pools
+    // are as full as their libraries are large, and a quota would have to know the fullest)
+    constexpr bool ROUNDS = !(RS || (MASK && PK && !ML));
     constexpr u32 DM = MDX_DRING - 1;
     const u32 RM = (u32)a.ring_size - 1u;
     uint4 *const lists = a.lists + (i64)gwave * MDX_WAVE_SCRATCH(a.ring_size);
@@ -1919,7 +1922,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
         // the others are left to their own launch (a library id beyond the last one is an error in every launch)
         if (!ML && c_lib < a.nlib_total && (c_lib < a.lib_lo || c_lib >= a.lib_lo + d.nlib)) kept = false;
-        // (ML: the image holds the epoch's library alone — table offsets are library 0's, the fragment lengths beyond the
+        // (ML: the image holds the pool's library alone — table offsets are library 0's, the fragment lengths beyond the
         // LDS histogram go by lg_lib)
         const int lg_lib = ML ? ml_lib : c_lib - a.lib_lo;
         int w1 = 0, nq = 0, libid = 0, n0 = 0, ncols = 0, nI = 0, cig_n = 0;
@@ -2427,27 +2430,26 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 
     };   // general
 
-    // (ML: one epoch per library of the launch, see the template's comment; otherwise once through)
-#pragma unroll 1
-    for (int ep = 0; ep < (ML ? a.n_epochs : 1); ep++) {
+    // (ML: a pool counts ONE library of the launch — MdxTabArgs::ml_plan, made on the device from the libraries' sizes: pool p
+    // is the ml_k-th of the ml_m pools of library ml_lib, which share that library's tiles among themselves as the pools of a
+    // one-library launch share the batch's; see the template's comment)
+    {
     if (ML) {
         const MdxTabArgs *kp = ka;
         asm volatile("" : "+s"(kp));
         // (a kept record whose library the context does not know was given no place by the sort: reported here, like the
         // record the one-library kernel finds)
-        if (ep == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
             const u64 v = *kp->sort_bad;
             if (v != ~0ull) flag_error(kp->err, (i64)(v >> 8) + kp->record_base, (int)(v & 0xFFu));
         }
-        ml_lib = ep;
-        // (empty at the end of an epoch; said again so that nothing of them is live around the loop)
-#pragma unroll
-        for (int i = 0; i < 8; i++) { bsL[i] = 0u; bsH[i] = 0u; b2L[i] = 0u; b2H[i] = 0u; }
-        bs_steps = 0; qcount = 0;
-        // (the wavefront's lists are written anew: no line of them left in this CU's L1 from the epoch before)
-        if (ep > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        rec_lo = kp->lib_start[a.lib_lo + ep];
-        n_rec = kp->lib_start[a.lib_lo + ep + 1] - rec_lo;
+        const uint4 pl = kp->ml_plan[blockIdx.x % mdx_n_pools(gridDim.x)];
+        ml_lib = (int)__builtin_amdgcn_readfirstlane((int)pl.x);
+        ml_k = (u32)__builtin_amdgcn_readfirstlane((int)pl.y);
+        ml_m = (u32)__builtin_amdgcn_readfirstlane((int)pl.z);
+        ml_first = (u32)__builtin_amdgcn_readfirstlane((int)pl.w);
+        rec_lo = kp->lib_start[a.lib_lo + ml_lib];
+        n_rec = kp->lib_start[a.lib_lo + ml_lib + 1] - rec_lo;
     }
     if (!FAST) {
         for (u32 it = 0; it < n_it; it++) {
@@ -2485,22 +2487,22 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // (a pool's tiles: chunks of MDX_POOL_CHUNK consecutive tiles, the pools' chunks interleaved — the whole chip works
         // on one neighbourhood of a coordinate-sorted batch at a time and shares its reference lines in the L2s, as it did
         // when the tiles were dealt round-robin; a stretch of its own per pool cost such a batch 5 %)
-        static_assert(!(ML && MDX_PK_PREFETCH), "the prefetched columns know no epochs");
+        static_assert(!(ML && MDX_PK_PREFETCH), "the prefetched columns know no libraries");
         u32 grabs = 0;
-        // (STEAL — the packed kernels but the epoch launches, whose epochs are too short for it (8 libraries +2 %): a wavefront
-        // whose pool has run dry goes on with the tiles of other pools, see tile_of; pool_cur = the pool it asks at present.
-        // A stolen tile takes the place of the answer that found the pool empty: the quota counts it once)
-        constexpr bool STEAL = MDX_PK_STEAL && PK && !ML;
+        // (STEAL — the packed kernels: a wavefront whose pool has run dry goes on with the tiles of other pools — ML: of its
+        // library's —, see tile_of; pool_cur = the pool it asks at present.  A stolen tile takes the place of the answer
+        // that found the pool empty: the quota counts it once)
+        constexpr bool STEAL = MDX_PK_STEAL && PK;
         u32 pool_cur = pool;
+        // (the pools that share these tiles: all of them, or — ML — the ml_m pools of the library, from pool ml_first on)
+        const u32 pm = ML ? ml_m : n_pools, pf = ML ? ml_first : 0u;
         auto grab = [&]() -> u32 {
             // (lane 0 asks; the value is read — readfirstlane — where it is first needed)
             u32 v = 0xFFFFFFFFu;
-            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + ((ML ? (u32)ep * n_pools : 0u) + (STEAL ? pool_cur : pool)) * MDX_CTR_PAD, 1u); grabs++; }
+            if (grabs < (u32)a.tile_quota) { if (lane == 0) v = atomicAdd(a.tile_ctr + (STEAL ? pool_cur : pool) * MDX_CTR_PAD, 1u); grabs++; }
             return v;
         };
-        // (ML: the chunks of an epoch go on round-robin over the pools where the epoch before stopped — chunk c of the launch
-        // is pool c % n_pools's —, so that libraries of a few chunks each do not all begin with pool 0)
-        const u32 ch_first = ML ? (pool + n_pools - ml_chunk0 % n_pools) % n_pools : pool;
+        const u32 ch_first = pool - pf;
         auto tile_of = [&](const u32 raw) -> u32 {
             u32 v = (u32)__builtin_amdgcn_readfirstlane((int)raw);
             if (v == 0xFFFFFFFFu) return v;
@@ -2515,17 +2517,17 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 u32 tile = 0xFFFFFFFFu;
 #pragma unroll 1
                 for (int tries = 0;; tries++) {
-                    const u32 ch = v / MDX_POOL_CHUNK, t = (ch * n_pools + pool_cur) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
+                    const u32 ch = v / MDX_POOL_CHUNK, t = (ch * pm + (pool_cur - pf)) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
                     if (t < n_tiles) { tile = t; break; }
                     if (tries == MDX_PK_STEAL) break;
-                    pool_cur = (pool_cur + 37u) % n_pools;
+                    pool_cur = pf + (pool_cur - pf + 37u) % pm;
                     u32 r = 0u;
                     if (lane == 0) r = atomicAdd(a.tile_ctr + pool_cur * MDX_CTR_PAD, 1u);
                     v = (u32)__builtin_amdgcn_readfirstlane((int)r);
                 }
                 return tile;
             }
-            const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * n_pools + ch_first) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
+            const u32 ch = v / MDX_POOL_CHUNK, tile = (ch * pm + ch_first) * MDX_POOL_CHUNK + (v - ch * MDX_POOL_CHUNK);
             return tile < n_tiles ? tile : 0xFFFFFFFFu;
         };
         // (the fused kernel knows its next tile while it works on one — the bounds of that tile's quality copy are requested
@@ -2666,7 +2668,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 }
                 // ---------------------------------------------------- phase 1 of the single-match records
-                // (ML: place rec_lo + ... of the batch ordered by library; the record's library is the epoch's)
+                // (ML: place rec_lo + ... of the batch ordered by library; the record's library is the pool's)
                 const u32 ri = r_lo + lane + (ML ? rec_lo : 0u);
                 const bool valid = r_lo + lane < r_hi;
                 const u32 rj = valid ? ri : tbase + (ML ? rec_lo : 0u);
@@ -3137,8 +3139,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             if (threadIdx.x < 4) a.rs.subs_part[(size_t)blockIdx.x * rs_ncnt + threadIdx.x] = rs_cnt[threadIdx.x];
             __syncthreads();
         }
-        // (ML: the block's slot of the epoch's library, [library][block])
-        u32 *out = a.partials + ((i64)(ML ? ep : 0) * gridDim.x + blockIdx.x) * d.w_total;
+        u32 *out = a.partials + (i64)blockIdx.x * d.w_total;
         if (PK) {
             // The TC words of the slot in the layout every consumer knows (MdxDims: [strand][base][64 byte + lane], the counts
             // in the words of slot 0): word (strand, k, lane (side, m), byte jb) = window byte b = 8 m + jb of the left side /
@@ -3162,14 +3163,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         } else
         for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) out[i] = lds[i];
     }
-    if (ML) {
-        // the next epoch: an empty image, empty lists (the event queue and the bit-sliced counters are empty already)
-        __syncthreads();
-        for (i64 i = threadIdx.x; i < d.w_total; i += BLOCK) lds[i] = 0;
-        __syncthreads();
-        ml_chunk0 += ((n_rec + T - 1) / T + MDX_POOL_CHUNK - 1) / MDX_POOL_CHUNK;
     }
-    }   // epochs
 }
 
 template <bool MASK, bool FAST>
@@ -3261,10 +3255,10 @@ hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     return e;
 }
-// (a.n_epochs > 0: the libraries [lib_lo, lib_lo + n_epochs) in one launch over the bucketed columns, see ML)
+// (a.n_libs > 0: the libraries [lib_lo, lib_lo + n_libs) in one launch over the bucketed columns, a library per pool: see ML)
 void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    if (a.n_epochs > 0) hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    if (a.n_libs > 0) hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
     else
     hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
@@ -3313,11 +3307,11 @@ hipError_t mdx_k_prepare_packed(size_t lds_bytes) {
     return e;
 }
 
-// the packed kernel: 4-bit SEQ column and 4-bit reference; one library per launch, or (a.n_epochs > 0) the libraries
-// [lib_lo, lib_lo + n_epochs) one after the other over the bucketed columns
+// the packed kernel: 4-bit SEQ column and 4-bit reference; one library per launch, or (a.n_libs > 0) the libraries
+// [lib_lo, lib_lo + n_libs) side by side over the bucketed columns, a library per pool
 void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    if (a.n_epochs > 0) hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    if (a.n_libs > 0) hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
     else
     hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
 }
@@ -3357,31 +3351,84 @@ void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t l
 // (the last word, the number of kept reads, goes to *raw_tail: a launch may hold a group of the libraries only)
 // (tile_ctr: the pools' tile counters of the launch just reduced — 4096 words, fewer than any table — zeroed here for the
 // next launch: one memset node less in front of every launch)
-// (blockIdx.z: the library of an epoch launch — slots [library][block] of w_total = one library's words + 1, summed into
-// that library's stretch of raw, lib_stride words on)
+// (blockIdx.z: the library of a launch over several — a block's slot holds the image of its pool's library, `plan`; every
+// library is summed into its own stretch of raw, lib_stride words apart)
+// Which library a pool counts in a launch over several (tabulate_kernel<.., ML>): the pools are dealt to the libraries in
+// proportion to their tiles — every library that has a record gets one at least, and then a pool goes, one at a time, to the
+// library whose pools have the most tiles each — and a library's pools lie side by side.  plan[p] = {library, the pool's
+// place among the library's pools, their number, the first of them}.  One thread: a few thousand steps at most.
+__global__ void ml_plan_kernel(const u32 *__restrict__ lib_start, int lib_lo, int nlib, u32 T, int n_pools, uint4 *__restrict__ plan) {
+    // (one wavefront, lane l = library l: its tiles and the pools it has so far in registers)
+    const int l = (int)threadIdx.x;
+    if (blockIdx.x || l >= 64) return;
+    const u32 tiles = l < nlib ? (lib_start[lib_lo + l + 1] - lib_start[lib_lo + l] + T - 1u) / T : 0u;
+    // (its share of the pools rounded down, one at least; what is left over — fewer than there are libraries — one at a time to
+    // the library whose pools have the most tiles each; should the ones have made it too many, back from the library
+    // whose pools have the fewest)
+    auto wsum = [&](u32 v) -> u32 {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    const u32 total = wsum(tiles);
+    u32 m = tiles ? (u32)(((u64)tiles * (u32)n_pools) / (total ? total : 1u)) : 0u;
+    if (tiles && !m) m = 1u;
+    if (total == 0u && l == 0) m = (u32)n_pools;        // (no record at all: the pools are library 0's, which has no tile for them)
+    int given = (int)wsum(m);
+    while (given != n_pools) {
+        const bool more = given < n_pools;
+        // (more: the highest load, tiles per pool; fewer: the lowest load among the libraries that can spare a pool)
+        float load = more ? (m ? (float)tiles / (float)m : -1.0f) : (m > 1u ? -(float)tiles / (float)(m - 1u) : -3.0e38f);
+        int who = l;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const float lo_ = __shfl_xor(load, o);
+            const int wo = __shfl_xor(who, o);
+            if (lo_ > load || (lo_ == load && wo < who)) { load = lo_; who = wo; }
+        }
+        if (l == who) m += more ? 1u : 0xFFFFFFFFu;
+        given += more ? 1 : -1;
+    }
+    // the first pool of every library: the sum of the pools of the libraries in front
+    u32 first = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 v = __shfl_up(first, o);
+        if (l >= o) first += v;
+    }
+    first -= m;
+    for (u32 k = 0; k < m && (int)(first + k) < n_pools; k++) plan[first + k] = make_uint4((u32)l, k, m, first);
+}
+void mdx_k_ml_plan(const uint32_t *lib_start, int lib_lo, int nlib, int T, int grid, void *plan, hipStream_t s) {
+    hipLaunchKernelGGL(ml_plan_kernel, dim3(1), dim3(64), 0, s, lib_start, lib_lo, nlib, (u32)T, (int)mdx_n_pools((unsigned)grid), (uint4 *)plan);
+}
+
 __global__ void reduce_partials_kernel(const u32 *__restrict__ partials, u64 *__restrict__ raw, u64 *__restrict__ raw_tail,
-                                       i64 w_total, int grid, int parts, u32 *__restrict__ tile_ctr, i64 lib_stride) {
+                                       i64 w_total, int grid, int parts, u32 *__restrict__ tile_ctr, i64 lib_stride,
+                                       const uint4 *__restrict__ plan, int n_pools) {
     const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= w_total) return;
     const int part = blockIdx.y;
     const i64 z = blockIdx.z;
     if (tile_ctr && part == 0 && z == 0 && w < 4096) tile_ctr[w * MDX_CTR_PAD] = 0u;       // (the counters of up to 4 096 pools, a line apart)
     const int b0 = (int)((i64)grid * part / parts), b1 = (int)((i64)grid * (part + 1) / parts);
-    const u32 *const pz = partials + z * (i64)grid * w_total;
+    // (plan: a launch over several libraries — block b has counted the library of its pool, plan[b mod n_pools].x; grid z adds
+    // up the blocks of library z)
     u64 acc = 0;
-    for (int b = b0; b < b1; b++) acc += (u64)(i64)(int)pz[(i64)b * w_total + w];   // signed (soft-clip differences)
+    for (int b = b0; b < b1; b++)
+        if (!plan || (i64)plan[b % n_pools].x == z) acc += (u64)(i64)(int)partials[(i64)b * w_total + w];   // signed (soft-clip differences)
     if (acc) atomicAdd(w == w_total - 1 ? raw_tail : &raw[z * lib_stride + w], acc);
 }
 
 void mdx_k_reduce_partials(const uint32_t *partials, unsigned long long *raw, unsigned long long *raw_tail,
-                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr, int n_lib, int64_t lib_stride) {
+                           int64_t w_total, int grid, hipStream_t s, uint32_t *tile_ctr, int n_lib, int64_t lib_stride, const void *plan) {
     const int threads = 256;
     const int blocks = (int)((w_total + threads - 1) / threads);
     int parts = grid < 32 ? grid : 32;
     if (n_lib > 8 && parts > 8) parts = 8;
     if (parts < 1) parts = 1;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks, parts, n_lib), dim3(threads), 0, s, partials, raw, raw_tail,
-                       (i64)w_total, grid, parts, w_total >= 4096 ? tile_ctr : nullptr, (i64)lib_stride);
+                       (i64)w_total, grid, parts, w_total >= 4096 ? tile_ctr : nullptr, (i64)lib_stride, (const uint4 *)plan, (int)mdx_n_pools((unsigned)grid));
 }
 
 // raw (reference orientation) -> canonical tables (mapdamage_amd/layout.py):
