@@ -40,7 +40,7 @@ def run_engine(ref, batch, libraries, length, around, minqual=0, lgd_max=65536, 
             else:
                 eng.tabulate(part)
         # the packed kernel is what runs for a 4-bit column in a tabulation with the fast geometry (ONE launch per call whatever
-        # the number of libraries — an epoch each over the records bucketed by library; with --min-basequal its masked form),
+        # the number of libraries — a library per pool of blocks over the records bucketed by library; with --min-basequal its masked form),
         # and only then
         plain = eng.table_mode == "lds" and length + around <= 248
         want = splits if (DamageEngine.default_packed and plain and batch.n) else 0
@@ -196,7 +196,7 @@ def test_hip_library_groups_match_oracle(nlib, Q, mid_genome):
         eng.tabulate(batch)
         eng.tabulate(batch.slice(0, 1000))
         got = eng.finish()
-        # (a 4-bit column: one launch per call — an epoch per library over the records bucketed by library — not one per library)
+        # (a 4-bit column: one launch per call — a library per pool of blocks over the records bucketed by library — not one per library)
         assert eng.packed_launches() == (2 if DamageEngine.default_packed else 0)
     want2 = oracle_tableset(mid_genome, batch.slice(0, 1000), libs, 70, 10, Q, lgd_max=300)
     np.testing.assert_array_equal(got.mis, want.mis + want2.mis)
@@ -212,7 +212,7 @@ def test_hip_library_groups_match_oracle(nlib, Q, mid_genome):
 def test_hip_one_pass_over_the_libraries_of_a_resident_batch(nlib, mid_genome):
     """reader.py:47-50, statistics.py:12-20: the tables are keyed by library and a file interleaves the libraries.  A resident
     4-bit batch brings its columns bucketed by library (mdx_batch::libsort) and every call is one launch of the packed kernel
-    per twenty-odd libraries — an epoch per library over its own records —, libraries without a single record, filtered
+    per sixty-four libraries — a library per pool of blocks, over its own records —, libraries without a single record, filtered
     records and skewed library sizes included; accumulating calls, and the same batch through the in-launch sort."""
     from mapdamage_amd.engine import DamageEngine
     batch = synth.make_reads(mid_genome, 30_000, 8 + nlib, len_range=(30, 120), nlib=nlib, frac_softclip=0.1, frac_ins=0.05,
@@ -368,7 +368,7 @@ def test_hip_path_of_a_reference_of_4_gbases_and_more(mid_genome, monkeypatch, Q
         eng.set_reference(mid_genome)
         eng.tabulate(batch, packed=True)
         got = eng.finish()
-        assert eng.packed_launches() == 1          # (two libraries, one launch: an epoch each)
+        assert eng.packed_launches() == 1          # (two libraries, one launch: half of the pools each)
     assert_tables_equal(got, want)
 
 

@@ -1,6 +1,6 @@
 """Kernel time of the tabulation pass by number of libraries (config-3 records dealt to the libraries at random, as the
 read groups of a BAM file are; reader.py:47-50, statistics.py:12-20): the packed kernel over a resident 4-bit batch —
-ONE launch, an epoch per library over the records bucketed by library (mdx_batch::libsort, built at upload) —, the same
+ONE launch, a library per pool of blocks over the records bucketed by library (mdx_batch::libsort, built at upload) —, the same
 with the sort inside every launch (a batch that does not bring it), and the ASCII kernel (one launch per group of
 libraries that fits the LDS, each over all records).  MDX_NO_ML=1 in the environment: the packed kernel as it was
 before round 5, one launch per library over all records.  Run on the GPU box:
@@ -53,7 +53,7 @@ def main():
             row["ascii_launches_per_pass"], row["ascii_ms"] = timed(eng, lambda: eng.tabulate(da))
             da.free()
         if nlib == 2:
-            # (the epoch kernel itself: two libraries, every record in the first)
+            # (the several-library kernel itself: two libraries, every record in the first)
             b.lib[:] = 0
             with DamageEngine(libs, 70, 10, 0, lgd_max=4096) as eng:
                 eng.set_reference(ref)
