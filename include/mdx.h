@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 5   /* 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
+#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -147,6 +147,25 @@ int mdx_set_stream(mdx_ctx *ctx, void *hip_stream);
  * contig i = bases[contig_off[i] .. contig_off[i+1])) once and keeps them resident in HBM,
  * case-folded and symbol-classified by a device kernel.  Host pointers. */
 int mdx_set_reference(mdx_ctx *ctx, const uint8_t *bases, const int64_t *contig_off, int32_t n_contig);
+
+/* The same from the FASTA file itself: replaces pysam.FastaFile(options.ref) (main.py:115 — htslib's faidx, which reads
+ * `<fasta>.fai` and builds it when the file has none) and the fetches behind it (main.py:180, align.py:32-33).
+ * mdx_fasta_index: makes sure `<fasta_path>.fai` exists (name, length, offset, linebases, linewidth per sequence, htslib's
+ * format; lines of unequal length within a sequence are an error, as they are to faidx); err (may be NULL) receives the text.
+ * mdx_set_reference_fasta: the sequences `names[0 .. n_contig)` (the BAM header's, in tid order: chrom lookup is by name,
+ * main.py:175-180) become the resident reference.  The file's bytes go to HBM as they lie on disk, a piece at a time, and a
+ * kernel takes the line ends out by the index's arithmetic — no pass over the bases on the host; pieces of the file that
+ * hold none of the wanted sequences are not read.  lengths (may be NULL) receives the length of each; a name the index
+ * lacks is MDX_ERR_ARG, or with missing_ok an empty contig (a record mapped to it is MDX_ERR_BAD_READ when it is met: the
+ * reference fails in fetch at that read, not before).  Uncompressed FASTA only (a bgzip-ed one goes through
+ * mdx_set_reference).  Synchronous. */
+int mdx_fasta_index(const char *fasta_path, char *err, int32_t err_cap);
+int mdx_set_reference_fasta(mdx_ctx *ctx, const char *fasta_path, int32_t n_contig, const char *const *names, int32_t missing_ok,
+                            int64_t *lengths);
+/* Introspection for tests: bases [start, end) of contig tid of the resident reference as the kernels see them — the letter
+ * where ref.fetch(chrom, start, end).upper() (main.py:180) holds one of "ACGT", '-' for '-', 'N' for anything else.  Host
+ * buffer of end - start bytes; synchronous. */
+int mdx_reference_fetch(mdx_ctx *ctx, int32_t tid, int64_t start, int64_t end, uint8_t *out);
 
 /* Copies a host batch into device memory owned by the library (for resident/benchmark use).
  * `dev` receives device pointers; release with mdx_batch_free. */
@@ -396,6 +415,17 @@ int mdx_gbam_fixups(const mdx_gbam *g);
 int mdx_gbam_view_flags(mdx_gbam *g, uint16_t *flags, int64_t n);
 int mdx_gbam_view_set_flags(mdx_gbam *g, const uint16_t *flags, int64_t n);
 void mdx_gbam_close(mdx_gbam *g);
+/* The host beside the device.  mdx_host_threads: the threads this process inflates BGZF blocks on (the host's share of a slab,
+ * mdx_gbam_next; the pool starts with the first such slab and keeps its size) — half of the hardware threads, at most 128 and
+ * at most what the control group's cpu.max grants less two, divided by LOCAL_WORLD_SIZE (the ranks of this node, one per GPU,
+ * SURVEY 8e, inflate at the same time); MDX_GBAM_HOST_THREADS overrides, MDX_CPU_MAX_FILE names a stand-in for
+ * /sys/fs/cgroup/cpu.max.  mdx_host_pool_threads: starts the pool if need be and returns its size.
+ * mdx_warm: what a process pays once whichever file comes first — the device's context, the decode kernels' code object, the
+ * pool, a pinned buffer of pinned_bytes for the host's share — for a helper thread at the start of a run (the command line
+ * warms up beside its header and index reads).  The reference has no counterpart (pysam opens a file in microseconds). */
+int mdx_host_threads(void);
+int mdx_host_pool_threads(void);
+int mdx_warm(int32_t device, int64_t pinned_bytes);
 /* Introspection for tests: the device inflate and CRC32 stages of the decode path alone, on BGZF payloads the caller
  * supplies (host buffers).  blk holds four words per block — payload offset in comp, payload bytes, offset in out,
  * bytes out (ISIZE, at most 65536) — and want_crc the CRC32 of each block's inflated bytes (may be NULL: no check).

@@ -8,7 +8,7 @@ import subprocess
 HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmdx.so"
-SOURCES = ["mdx_kernels.hip", "mdx_capi.cpp", "mdx_bamio.cpp", "mdx_gbam.hip", "mdx_libsort.hip"]
+SOURCES = ["mdx_kernels.hip", "mdx_capi.cpp", "mdx_bamio.cpp", "mdx_gbam.hip", "mdx_libsort.hip", "mdx_fasta.hip"]
 HEADERS = [CSRC / "mdx_internal.h", CSRC / "mdx_inflate.h", CSRC / "mdx_crc32.h", HERE.parent / "include" / "mdx.h"]
 
 
@@ -28,15 +28,31 @@ def needs_build():
 
 
 def build_lib(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+    """Every source to an object of its own (side by side; an object newer than its source and the headers is kept), then
+    one link.  ``extra_flags`` (A/B builds: -D...) compile everything afresh into a directory of their own."""
+    if not force and not extra_flags and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-x", "hip", "-Wall", "-Wno-unused-function"]
-    cmd += list(extra_flags)
-    cmd += [str(CSRC / s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function"] + list(extra_flags)
+    objdir = HERE / "build" / ("obj" if not extra_flags else "obj_" + "_".join(f.strip("-").replace("=", "_") for f in extra_flags))
+    objdir.mkdir(parents=True, exist_ok=True)
+    newest_header = max(p.stat().st_mtime for p in HEADERS)
+
+    def compile_one(name):
+        src, obj = CSRC / name, objdir / (name + ".o")
+        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, newest_header):
+            return obj
+        cmd = [hipcc()] + flags + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
     # linked under another name and moved into place: a process that finds libmdx.so finds a complete one
     tmp = LIB.with_name("libmdx.so.%d.tmp" % os.getpid())
-    cmd += ["-lz", "-lpthread", "-ldl", "-o", str(tmp)]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [str(o) for o in objs] + ["-lz", "-lpthread", "-ldl", "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
     try:

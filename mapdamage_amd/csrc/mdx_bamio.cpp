@@ -925,33 +925,41 @@ void mdx_bam_close(mdx_bam_stream *s) {
 
 #ifndef MDX_HOST_ONLY
 namespace {
-// the process's pool of inflating threads (half of the hardware threads, 128 at most; MDX_GBAM_HOST_THREADS) and the buffer
-// they inflate into: both outlive a file — a hundred threads take milliseconds to start and to join, and a buffer of a
-// few hundred megabytes as long to fault in
+// Threads this process may keep busy inflating: half of the hardware threads, 128 at most — and not more than the CPU time
+// the control group grants (cpu.max: "quota period"; MDX_CPU_MAX_FILE names another file, for the tests): threads beyond the
+// quota use it up in a fraction of the period and then the whole process stands still for the rest of it (a pod with 256
+// hardware threads and 16 CPUs' worth of quota: slabs took 60 ms now and then instead of 5 with 128 threads) — divided by the
+// ranks of this node (LOCAL_WORLD_SIZE, as torchrun sets it; SURVEY 8e: one process per GPU, and all of them inflate at the
+// same time: eight ranks of 14 threads each on a quota of 16 CPUs are that stall again).  MDX_GBAM_HOST_THREADS overrides.
+int host_thread_budget() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    int want_threads = (int)(hc > 8 ? hc / 2 : (hc ? hc : 4));
+    if (want_threads > 128) want_threads = 128;
+    const char *cpu_max = std::getenv("MDX_CPU_MAX_FILE");
+    if (FILE *fh = std::fopen(cpu_max && *cpu_max ? cpu_max : "/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long period = 0;
+        if (std::fscanf(fh, "%63s %ld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+            const long cpus = std::atol(q) / period;
+            if (cpus >= 1 && want_threads > (int)cpus - 2) want_threads = (int)std::max<long>(1, cpus - 2);
+        }
+        std::fclose(fh);
+    }
+    if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int ranks = std::atoi(e);
+        if (ranks > 1) want_threads = std::max(1, want_threads / ranks);
+    }
+    if (const char *e = std::getenv("MDX_GBAM_HOST_THREADS")) want_threads = std::max(1, std::atoi(e));
+    return want_threads;
+}
+// the process's pool of inflating threads (host_thread_budget() of them, counted when the pool starts) and the buffer they
+// inflate into: both outlive a file — a hundred threads take milliseconds to start and to join, and a buffer of a few hundred
+// megabytes as long to fault in
 WorkerPool *host_pool() {
     static std::mutex mu;
     static std::unique_ptr<WorkerPool> pool;
     std::lock_guard<std::mutex> lk(mu);
-    if (!pool) {
-        // half of the hardware threads, 128 at most — and not more than the CPU time the control group grants (cpu.max:
-        // "quota period"): threads beyond the quota use it up in a fraction of the period and then the whole process
-        // stands still for the rest of it (a pod with 256 hardware threads and 16 CPUs' worth of quota: slabs took 60 ms
-        // now and then instead of 5 with 128 threads)
-        const unsigned hc = std::thread::hardware_concurrency();
-        int want_threads = (int)(hc > 8 ? hc / 2 : (hc ? hc : 4));
-        if (want_threads > 128) want_threads = 128;
-        if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[64] = {0};
-            long period = 0;
-            if (std::fscanf(fh, "%63s %ld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
-                const long cpus = std::atol(q) / period;
-                if (cpus >= 1 && want_threads > (int)cpus - 2) want_threads = (int)std::max<long>(1, cpus - 2);
-            }
-            std::fclose(fh);
-        }
-        if (const char *e = std::getenv("MDX_GBAM_HOST_THREADS")) want_threads = std::max(1, std::atoi(e));
-        pool.reset(new WorkerPool(want_threads));
-    }
+    if (!pool) pool.reset(new WorkerPool(host_thread_budget()));
     return pool.get();
 }
 // (pinned: a copy out of pageable memory has the runtime pin and unpin the pages it reads, under the address space's lock
@@ -1361,7 +1369,9 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
                 // (room for the largest share of a slab like this one, so that it need not grow again)
                 if (g->hbuf) (void)hipHostFree(g->hbuf);
                 g->hbuf = nullptr;
-                g->hbuf_cap = std::max(tail_bytes + 64, (size_t)((double)unc_bytes * 0.46) + ((size_t)1 << 20));
+                // (... of a slab like this one at a share that has grown by three quarters: the share moves by halves towards the balance
+                // of the two rates, and pinned memory costs a tenth of a second per 600 MB to map)
+                g->hbuf_cap = std::max(tail_bytes + 64, (size_t)((double)unc_bytes * std::min(0.46, std::max(0.2, 1.75 * g->host_share))) + ((size_t)1 << 20));
                 const auto t_p = std::chrono::steady_clock::now();
                 if (hipHostMalloc((void **)&g->hbuf, g->hbuf_cap, hipHostMallocDefault) != hipSuccess) { g->hbuf_cap = 0; g->error = "out of pinned host memory"; return MDX_ERR_HIP; }
                 if (timing) std::fprintf(stderr, "mdx_gbam_next pinned buffer of %.0f MB: %.1f ms\n", g->hbuf_cap / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p).count());
@@ -1828,6 +1838,35 @@ void mdx_gbam_close(mdx_gbam *g) {
     lap("file");
     delete g;
     lap("handle");
+}
+
+int mdx_host_threads(void) { return host_thread_budget(); }
+int mdx_host_pool_threads(void) { return (int)host_pool()->threads.size(); }
+
+int mdx_warm(int32_t device, int64_t pinned_bytes) {
+    // what a process pays once, whichever file comes first: the device's context, the decode kernels' code object, the
+    // inflating threads, and the pinned buffer the host's share of a slab is inflated into (a few hundred megabytes: tens of
+    // milliseconds to fault in and map) — on a thread of the caller's choice, beside whatever else the start of a run does
+    try {
+        if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) { (void)hipGetLastError(); return MDX_ERR_HIP; }
+        if (mdx_k_gbam_prepare() != hipSuccess) { (void)hipGetLastError(); return MDX_ERR_HIP; }
+        (void)host_pool();
+        if (pinned_bytes > 0) {
+            uint8_t *p = nullptr;
+            size_t cap = 0;
+            host_buffer_take(p, cap);
+            if (cap < (size_t)pinned_bytes) {
+                if (p) (void)hipHostFree(p);
+                p = nullptr; cap = 0;
+                if (hipHostMalloc((void **)&p, (size_t)pinned_bytes, hipHostMallocDefault) == hipSuccess) cap = (size_t)pinned_bytes;
+                else { (void)hipGetLastError(); p = nullptr; }
+            }
+            host_buffer_give(p, cap);
+        }
+        return MDX_OK;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
 }
 
 #endif  // MDX_HOST_ONLY

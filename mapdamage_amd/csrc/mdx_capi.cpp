@@ -353,38 +353,96 @@ int mdx_set_stream(mdx_ctx *c, void *hip_stream) {
     return MDX_OK;
 }
 
+// the resident reference of n bases: the old one released, the new one allocated with its guard bands (a guard band on both
+// sides keeps speculative flank addresses inside the allocation) and filled with the "other symbol" code
+static const size_t kRefPad = 256;
+static int ref_begin(mdx_ctx *c, int64_t n, int32_t n_contig) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_ref) { (void)hipFree(c->d_ref); c->d_ref = nullptr; }
+    if (c->d_ref4) { (void)hipFree(c->d_ref4); c->d_ref4 = nullptr; }
+    if (c->d_contig_off) { (void)hipFree(c->d_contig_off); c->d_contig_off = nullptr; }
+    c->n_contig = 0; c->ref_len = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_ref, (size_t)n + 2 * kRefPad + 1));
+    HIP_TRY(c, hipMalloc((void **)&c->d_contig_off, (size_t)(n_contig + 1) * 8));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref, 0x85, (size_t)n + 2 * kRefPad + 1, c->stream));
+    return MDX_OK;
+}
+// ... and, the bases in place: the contig offsets and the 4-bit form of the same bytes, guard bands included (an even number
+// of them: one more guard byte behind an odd genome)
+static int ref_finish(mdx_ctx *c, const int64_t *contig_off, int32_t n_contig, int64_t n) {
+    const size_t n4 = ((size_t)n + 2 * kRefPad + 1) / 2;
+    hipError_t e = hipMemcpyAsync(c->d_contig_off, contig_off, (size_t)(n_contig + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_ref4, n4 + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_ref4, 0, n4 + 64, c->stream);
+    if (e == hipSuccess) { mdx_k_encode_ref4(c->d_ref, c->d_ref4, (int64_t)(2 * n4), c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        // (a reference half in place is none: the launches ask for d_ref)
+        (void)hipFree(c->d_ref); c->d_ref = nullptr;
+        return fail(c, MDX_ERR_HIP, std::string("set_reference: ") + hipGetErrorString(e));
+    }
+    c->n_contig = n_contig;
+    c->ref_len = n;
+    return MDX_OK;
+}
+
 int mdx_set_reference(mdx_ctx *c, const uint8_t *bases, const int64_t *contig_off, int32_t n_contig) {
     if (!c || !contig_off || n_contig < 1) return fail(c, MDX_ERR_ARG, "set_reference: bad arguments");
     for (int i = 0; i < n_contig; i++)
         if (contig_off[i + 1] < contig_off[i]) return fail(c, MDX_ERR_ARG, "contig_off not monotone");
     const int64_t n = contig_off[n_contig];
     if (contig_off[0] != 0 || (n > 0 && !bases)) return fail(c, MDX_ERR_ARG, "set_reference: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->d_ref) { (void)hipFree(c->d_ref); c->d_ref = nullptr; }
-    if (c->d_ref4) { (void)hipFree(c->d_ref4); c->d_ref4 = nullptr; }
-    if (c->d_contig_off) { (void)hipFree(c->d_contig_off); c->d_contig_off = nullptr; }
-    // a guard band on both sides keeps speculative flank addresses inside the allocation
-    const size_t pad = 256;
+    int rc = ref_begin(c, n, n_contig);
+    if (rc != MDX_OK) return rc;
     uint8_t *tmp = nullptr;
     HIP_TRY(c, hipMalloc((void **)&tmp, (size_t)n + 1));
-    HIP_TRY(c, hipMalloc((void **)&c->d_ref, (size_t)n + 2 * pad + 1));
-    HIP_TRY(c, hipMalloc((void **)&c->d_contig_off, (size_t)(n_contig + 1) * 8));
-    HIP_TRY(c, hipMemsetAsync(c->d_ref, 0x85, (size_t)n + 2 * pad + 1, c->stream));
-    if (n > 0) HIP_TRY(c, hipMemcpyAsync(tmp, bases, (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_contig_off, contig_off, (size_t)(n_contig + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    mdx_k_encode_ref(tmp, c->d_ref + pad, n, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    // the 4-bit form of the same bytes, guard bands included (an even number of them: one more guard byte behind an odd genome)
-    const size_t n4 = ((size_t)n + 2 * pad + 1) / 2;
-    HIP_TRY(c, hipMalloc((void **)&c->d_ref4, n4 + 64));
-    HIP_TRY(c, hipMemsetAsync(c->d_ref4, 0, n4 + 64, c->stream));
-    mdx_k_encode_ref4(c->d_ref, c->d_ref4, (int64_t)(2 * n4), c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipError_t e = n > 0 ? hipMemcpyAsync(tmp, bases, (size_t)n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    if (e == hipSuccess) { mdx_k_encode_ref(tmp, c->d_ref + kRefPad, n, c->stream); e = hipGetLastError(); }
+    rc = e == hipSuccess ? ref_finish(c, contig_off, n_contig, n) : fail(c, MDX_ERR_HIP, std::string("set_reference: ") + hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
-    c->n_contig = n_contig;
-    c->ref_len = n;
+    return rc;
+}
+
+int mdx_set_reference_fasta(mdx_ctx *c, const char *fasta_path, int32_t n_contig, const char *const *names, int32_t missing_ok,
+                            int64_t *lengths) {
+    if (!c || !fasta_path || !names || n_contig < 1) return fail(c, MDX_ERR_ARG, "set_reference_fasta: bad arguments");
+    try {
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        struct Arg { mdx_ctx *c; int32_t n_contig; int rc; } arg{c, n_contig, MDX_OK};
+        std::vector<int64_t> contig_off;
+        std::string err;
+        const int rc = mdx_fasta_to_device(fasta_path, n_contig, names, missing_ok, lengths, contig_off, err, c->stream,
+            [](void *a_, int64_t n) -> uint8_t * {
+                Arg *a = (Arg *)a_;
+                a->rc = ref_begin(a->c, n, a->n_contig);
+                return a->rc == MDX_OK ? a->c->d_ref + kRefPad : nullptr;
+            }, &arg);
+        if (arg.rc != MDX_OK) return arg.rc;
+        if (rc != MDX_OK) {
+            // (a reference half in place is none)
+            if (c->d_ref) { (void)hipFree(c->d_ref); c->d_ref = nullptr; }
+            return fail(c, rc, "set_reference_fasta: " + err);
+        }
+        return ref_finish(c, contig_off.data(), n_contig, contig_off[(size_t)n_contig]);
+    } catch (const std::exception &e) {
+        return fail(c, MDX_ERR_ARG, std::string("set_reference_fasta: ") + e.what());
+    }
+}
+
+// Introspection for tests: bases [start, end) of contig `tid` of the resident reference as the kernels see them — 'A' 'C' 'G'
+// 'T' where ref.fetch(chrom, start, end).upper() (main.py:180) holds one of the four, '-' for '-', 'N' for anything else.
+int mdx_reference_fetch(mdx_ctx *c, int32_t tid, int64_t start, int64_t end, uint8_t *out) {
+    if (!c || !out) return MDX_ERR_ARG;
+    if (!c->d_ref) return fail(c, MDX_ERR_STATE, "mdx_set_reference has not been called");
+    if (tid < 0 || tid >= c->n_contig || start < 0 || end < start) return fail(c, MDX_ERR_ARG, "reference_fetch: bad range");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int64_t off[2];
+    HIP_TRY(c, hipMemcpy(off, c->d_contig_off + tid, 16, hipMemcpyDeviceToHost));
+    if (start + off[0] > off[1] || end + off[0] > off[1]) return fail(c, MDX_ERR_ARG, "reference_fetch: beyond the contig's end");
+    if (end > start) HIP_TRY(c, hipMemcpy(out, c->d_ref + kRefPad + off[0] + start, (size_t)(end - start), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < end - start; i++) if (out[i] & 0x80) out[i] = out[i] == 0x84 ? '-' : 'N';
     return MDX_OK;
 }
 
@@ -540,7 +598,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     a.n_reads = b->n_reads;
     a.flag = b->flag; a.lib = b->lib; a.tid = b->tid; a.pos = b->pos; a.tlen = b->tlen;
     a.cigar_off = b->cigar_off; a.cigar = b->cigar; a.seq_off = b->seq_off; a.seq = b->seq; a.qual = b->qual;
-    a.ref = c->d_ref + 256;
+    a.ref = c->d_ref + 256;   // (kRefPad)
     a.contig_off = c->d_contig_off;
     a.n_contig = c->n_contig;
     a.minqual = c->cfg.minqual;

@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+#include <vector>
+
 // Raw (reference-orientation) accumulator layout, in words, per library (order: TC, MIS, CMP, LGD):
 //   MIS [strand 2][side 2][L][25]   rare events: substitutions, indels, soft clips; base columns
 //                                    0..3 (A,C,T,G order = (ascii >> 1) & 3) count the matching
@@ -405,3 +408,10 @@ void mdx_k_gbam_scan(const uint8_t *unc, const uint4 *blk, const int *status, in
 // pre[b] = (records, CIGAR operations, bases in front of segment b, first record of its chain); cnt[b].x = its records
 void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *pre, const uint4 *cnt, int n_blocks, uint32_t n_rec, uint32_t n_cig,
                        uint32_t n_seq, uint32_t *rec_off, const MdxGbamCols &c, hipStream_t s);
+
+// ---- FASTA file -> resident reference (mdx_fasta.hip; the context's side: mdx_set_reference_fasta in mdx_capi.cpp).  The
+// wanted sequences' lengths and offsets (contig_off: n_contig + 1 sums), then alloc_out(alloc_arg, total bases) = the device
+// buffer base 0 of sequence 0 goes to, then the file's pieces through two staging buffers and the strip kernel on `stream`.
+int mdx_fasta_to_device(const char *fasta_path, int32_t n_contig, const char *const *names, int missing_ok, int64_t *lengths,
+                        std::vector<int64_t> &contig_off, std::string &err, hipStream_t stream,
+                        uint8_t *(*alloc_out)(void *, int64_t), void *alloc_arg);

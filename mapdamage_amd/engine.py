@@ -37,6 +37,7 @@ EXPORTS = (
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
+    "mdx_fasta_index", "mdx_set_reference_fasta", "mdx_reference_fetch", "mdx_host_threads", "mdx_host_pool_threads", "mdx_warm",
 )
 
 SEQ_ASCII, SEQ_4BIT, SEQ_4BITQ = 0, 1, 2      # include/mdx.h MDX_SEQ_*
@@ -149,6 +150,11 @@ def load_library(path=None):
     lib.mdx_gbam_missing_qualities.argtypes = [ctypes.c_void_p]
     lib.mdx_gbam_close.restype = None
     lib.mdx_gbam_close.argtypes = [ctypes.c_void_p]
+    lib.mdx_fasta_index.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
+    lib.mdx_set_reference_fasta.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                            ctypes.c_void_p]
+    lib.mdx_reference_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    lib.mdx_warm.argtypes = [ctypes.c_int32, ctypes.c_int64]
     if path is None:
         _lib = lib
     return lib
@@ -274,10 +280,29 @@ class DamageEngine:
         self._check(self._lib.mdx_set_stream(self._ctx, ctypes.c_void_p(hip_stream or 0)))
 
     # ------------------------------------------------------------------ inputs
-    def set_reference(self, ref: Reference):
+    def set_reference(self, ref):
+        """``ref``: a ``Reference`` (contigs in host memory) or a ``fasta.FastaOnDisk`` — the FASTA file itself, which the
+        library sends to HBM as it lies on disk and strips of its line ends there (``mdx_set_reference_fasta``)."""
+        path = getattr(ref, "path", None)
+        if path is not None:
+            names = [n.encode() for n in ref.names]
+            arr = (ctypes.c_char_p * max(1, len(names)))(*names)
+            lengths = np.zeros(max(1, len(names)), np.int64)
+            self._check(self._lib.mdx_set_reference_fasta(self._ctx, str(path).encode(), ctypes.c_int32(len(names)), arr,
+                                                          ctypes.c_int32(1 if ref.missing_ok else 0), _ptr(lengths)))
+            ref.lengths = [int(x) for x in lengths[:len(names)]]
+            return
         bases, offs = ref.concat()
         self._check(self._lib.mdx_set_reference(self._ctx, _ptr(bases), _ptr(offs),
                                                 ctypes.c_int32(len(ref.names))))
+
+    def reference_fetch(self, tid, start, end):
+        """``ref.fetch(chrom, start, end).upper()`` (main.py:180) as the kernels see it: the four bases, '-', and 'N' for
+        every other symbol (tests)."""
+        out = np.zeros(max(0, end - start), np.uint8)
+        self._check(self._lib.mdx_reference_fetch(self._ctx, ctypes.c_int32(tid), ctypes.c_int64(start), ctypes.c_int64(end),
+                                                  _ptr(out)))
+        return out.tobytes()
 
     def upload(self, batch: ReadBatch, packed=None) -> DeviceBatch:
         """Resident copy of a host batch; ``packed``: with the SEQ column in its 4-bit form (``pack_seq``), which the

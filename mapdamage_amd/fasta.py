@@ -26,6 +26,9 @@ def read_fasta(path):
 
 
 def write_fasta(path, ref: Reference, width=60):
+    """FASTA + .fai (samtools faidx layout) of ``ref``; the line ends are put in by a reshape, not a loop over the lines
+    (a genome of human size is fifty million of them)."""
+    import numpy as np
     with open(path, "wb") as handle, open(str(path) + ".fai", "wt") as fai:
         offset = 0
         for name, seq in zip(ref.names, ref.seqs):
@@ -33,9 +36,38 @@ def write_fasta(path, ref: Reference, width=60):
             handle.write(header)
             offset += len(header)
             fai.write("%s\t%d\t%d\t%d\t%d\n" % (name, len(seq), offset, width, width + 1))
-            for i in range(0, len(seq), width):
-                handle.write(seq[i:i + width] + b"\n")
+            whole = len(seq) // width * width
+            if whole:
+                lines = np.empty((whole // width, width + 1), np.uint8)
+                lines[:, :width] = np.frombuffer(seq, np.uint8, whole).reshape(-1, width)
+                lines[:, width] = 10
+                handle.write(lines.data)
+            if len(seq) > whole:
+                handle.write(bytes(seq[whole:]) + b"\n")
             offset += len(seq) + (len(seq) + width - 1) // width
+
+
+class FastaOnDisk:
+    """The sequences of a BAM header (``tid`` order) as they lie in an indexed FASTA file: what ``pysam.FastaFile``
+    (main.py:115) is to the reference's loop.  Nothing is read here: ``DamageEngine.set_reference`` hands the path to the
+    library, which sends the file's bytes to HBM and strips the line ends there (include/mdx.h
+    ``mdx_set_reference_fasta``); ``lengths`` are the index's until then, the loaded ones afterwards."""
+
+    def __init__(self, path, names, lengths, missing_ok=False):
+        self.path, self.names, self.lengths, self.missing_ok = str(path), list(names), list(lengths), bool(missing_ok)
+
+
+def ensure_fasta_index(path):
+    """``<path>.fai`` exists afterwards (htslib builds it when ``pysam.FastaFile`` opens a file without one, main.py:115);
+    raises ValueError with the library's message when the file cannot be indexed."""
+    import ctypes
+    import os
+    if os.path.exists(str(path) + ".fai"):
+        return
+    from .engine import load_library
+    err = ctypes.create_string_buffer(512)
+    if load_library().mdx_fasta_index(str(path).encode(), err, 512) != 0:
+        raise ValueError("cannot index %r: %s" % (str(path), err.value.decode(errors="replace")))
 
 
 class _FaiError(ValueError):
@@ -109,7 +141,23 @@ def compare_sequence_dicts(fasta_dict, bam_dict):
 def reference_for_bam(fasta_path, bam_names, missing_ok=False):
     """Contigs of the FASTA reordered to BAM ``tid`` order (chrom lookup is by name,
     main.py:175-180).  ``missing_ok``: a sequence the FASTA lacks becomes an empty contig — a record that maps to it
-    is then a bad record when it is met (the reference fails in ``fetch`` at that read, not before)."""
+    is then a bad record when it is met (the reference fails in ``fetch`` at that read, not before).
+    An uncompressed FASTA stays on disk (``FastaOnDisk``: the library loads it, no pass over the bases here); a
+    gzip-compressed one is read here."""
+    if not str(fasta_path).endswith(".gz"):
+        ensure_fasta_index(fasta_path)
+        have = dict(_fai_records(str(fasta_path) + ".fai"))
+        if not missing_ok:
+            for n in bam_names:
+                if n not in have:
+                    raise KeyError(n)
+        return FastaOnDisk(fasta_path, bam_names, [have.get(n, 0) for n in bam_names], missing_ok)
+    return reference_in_memory(fasta_path, bam_names, missing_ok)
+
+
+def reference_in_memory(fasta_path, bam_names, missing_ok=False):
+    """The same contigs read into host memory by ``read_fasta`` (gzip-compressed files; the tests' second opinion on
+    the library's loader)."""
     names, seqs = read_fasta(fasta_path)
     by_name = dict(zip(names, seqs))
     return Reference(list(bam_names), [by_name.get(n, b"") if missing_ok else by_name[n] for n in bam_names])

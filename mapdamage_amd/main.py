@@ -25,6 +25,36 @@ from .statistics import check_table_and_warn_if_dmg_freq_is_low
 _LOG_FORMAT = "%(asctime)s %(name)s %(levelname)s %(message)s"
 
 
+class _Stages:
+    """MDX_STAGE_LOG=<file>: the wall-clock time (``time.time()``) at which each stage of the run was reached, as one JSON
+    object — what bench.py's ``cli_wall`` splits a cold run of this command into.  Costs a dictionary entry per stage."""
+
+    def __init__(self):
+        import os
+        self.path = os.environ.get("MDX_STAGE_LOG")
+        self.marks = []
+
+    def mark(self, label):
+        if self.path:
+            self.marks.append((label, time.time()))
+
+    def write(self):
+        if self.path:
+            import json
+            with open(self.path, "w") as fh:
+                json.dump({"stages": self.marks}, fh)
+
+
+def _warm_up(device, pinned_bytes):
+    """On a helper thread beside the header and index reads: the device's context, the decode kernels' code object, the
+    inflating threads and the pinned buffer of the host's share (include/mdx.h ``mdx_warm``; ctypes drops the GIL)."""
+    from .engine import load_library
+    try:
+        load_library().mdx_warm(device, pinned_bytes)
+    except Exception:       # (a run that cannot warm up finds out why when it creates its engine)
+        pass
+
+
 def _ranged(cls, lo=float("-inf"), hi=float("inf")):
     def parse(value):
         value = cls(value)
@@ -311,7 +341,21 @@ def _device_path_applies(options, world=1):
         options.downsample is None or (options.downsample < 1 and world == 1))
 
 
-def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
+def _slab_bytes(options, world):
+    """Compressed bytes per slab of the device decode path.  (A slab of compressed bytes inflates to about four times its
+    size; at the default --chunk-mb a single rank takes slabs four times the size — the file in a few large, equal slabs: a
+    1.15 GB file 139 -> 151 M reads/s from 256 MiB to 1 GiB slabs —, several ranks keep the smaller unit they deal out among
+    themselves.)"""
+    import os
+    slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
+    if world == 1 and options.chunk_mb == 1024:
+        slab = 1 << 30
+    if os.environ.get("MDX_GBAM_SLAB_BYTES"):      # (tests: several slabs out of a small file whatever --chunk-mb says)
+        slab = max(1 << 16, int(os.environ["MDX_GBAM_SLAB_BYTES"]))
+    return slab
+
+
+def _tabulate_on_device(options, reader, ref, libraries, logger, ranks, stages):
     """--gpu-decode: the file inflated, unpacked and counted on the GPU.  Returns (tables, None), or (None, carry) when
     the path does not apply or has given up — the caller decodes on the host, which also words the errors the way the
     reference does: the whole file (carry None), or, when the device path failed on a slab it had not begun to count,
@@ -333,15 +377,11 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
         engine.set_reference(ref)
         warned_about_quals = False
         error = None
-        # (a slab of compressed bytes inflates to about four times its size; at the default --chunk-mb a single rank takes
-        # slabs four times the size — the file in a few large, equal slabs: a 1.15 GB file 139 -> 151 M reads/s from 256 MiB
-        # to 1 GiB slabs —, several ranks keep the smaller unit they deal out among themselves)
-        slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
-        if ranks.world == 1 and options.chunk_mb == 1024:
-            slab = 1 << 30
-        import os
-        if os.environ.get("MDX_GBAM_SLAB_BYTES"):      # (tests: several slabs out of a small file whatever --chunk-mb says)
-            slab = max(1 << 16, int(os.environ["MDX_GBAM_SLAB_BYTES"]))
+        slab = _slab_bytes(options, ranks.world)
+        warm = getattr(options, "warm_thread", None)
+        if warm is not None:
+            warm.join()         # (the pinned buffer it leaves behind is the one the first slab takes)
+        stages.mark("engine and reference")
         with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
                           chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
             # (several ranks: rank r decodes the slabs r, r + W, ... and steps over the others)
@@ -385,6 +425,7 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
                     engine.tabulate_view(view, record_base=n_reads)
                     n_reads += int(view.n_reads)
                 engine.sync()
+                stages.mark("decode and tabulate")
                 if stream.fixups():
                     logger.debug("device decode: %d BGZF blocks rescanned from the record their predecessor's chain ended on", stream.fixups())
             except (BadReadError, ValueError, MdxError) as exc:
@@ -421,6 +462,8 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks):
 
 def main(argv):
     start_time = time.time()
+    stages = _Stages()
+    stages.mark("main")
     logging.basicConfig(format=_LOG_FORMAT, datefmt="%H:%M:%S")
     logger = logging.getLogger(__name__)
     try:
@@ -450,6 +493,16 @@ def main(argv):
         return subprocess.call(cmd, env=env)
     ranks = _Ranks(options)
     first = ranks.rank == 0
+    if options.gpu_decode and not options.rescale_only and _device_path_applies(options, ranks.world):
+        # the device's context, the decode kernels and the pinned buffer of the host's share (about a fifth of a slab's
+        # inflated bytes, which are four to five times its compressed ones), beside the header, index and FASTA reads
+        import threading
+        try:
+            pinned = min(_slab_bytes(options, ranks.world), os.path.getsize(options.filename))
+        except OSError:
+            pinned = 0
+        options.warm_thread = threading.Thread(target=_warm_up, args=(ranks.device, pinned), daemon=True)
+        options.warm_thread.start()
     # (rank 0 keeps the log file and writes the tables; the other ranks speak up only when something is wrong)
     logging.getLogger().setLevel(options.log_level if first else "WARNING")
     handler = logging.FileHandler(options.folder / "Runtime_log.txt") if first else logging.NullHandler()
@@ -475,13 +528,14 @@ def main(argv):
             return 1
         ref = reference_for_bam(options.ref, reader.handle.header.references)
         libraries = reader.get_libraries()
+        stages.mark("headers and index")
 
         logger.info("Reading from '%s'", options.filename)
         if options.minqual != 0:
             logger.info("Filtering out bases with a Phred score < %d", options.minqual)
         logger.info("Writing results to '%s/'", options.folder)
 
-        tables, carry = _tabulate_on_device(options, reader, ref, libraries, logger, ranks) if options.gpu_decode else (None, None)
+        tables, carry = _tabulate_on_device(options, reader, ref, libraries, logger, ranks, stages) if options.gpu_decode else (None, None)
         if tables is None:
             tables = _tabulate_on_host(options, reader, ref, libraries, logger, ranks, carry)
         fallbacks = getattr(options, "gpu_decode_fallbacks", 0)
@@ -491,6 +545,7 @@ def main(argv):
         logger.debug("Done. %d filtered alignments processed", tables.n_kept)
         logger.debug("BAM read in %f seconds", time.time() - start_time)
 
+        stages.mark("tables")
         if not first:
             return 0
         tables.write(options.folder)
@@ -500,6 +555,7 @@ def main(argv):
         check_table_and_warn_if_dmg_freq_is_low(options.folder)
         logger.info("Successful run")
         logger.debug("Run completed in %f seconds", time.time() - start_time)
+        stages.mark("files written")
         return 0
     except BadReadError as error:
         # the reference dies with pysam's ValueError here (align.py:33)
@@ -512,6 +568,8 @@ def main(argv):
         logging.getLogger().removeHandler(handler)
         handler.close()
         ranks.close()
+        stages.mark("end")
+        stages.write()
 
 
 def entry_point():

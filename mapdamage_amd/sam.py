@@ -24,16 +24,25 @@ for _i, _c in enumerate(b"=ACMGRSVTWYHKDBN"):
 
 def usable_cpus():
     """CPUs this process may keep busy: its affinity mask, cut down to what the control group grants (``cpu.max``: a pod
-    with 256 hardware threads and 16 CPUs' worth of quota stalls for most of every period under 64 busy threads)."""
+    with 256 hardware threads and 16 CPUs' worth of quota stalls for most of every period under 64 busy threads;
+    ``MDX_CPU_MAX_FILE`` names a stand-in for the tests) and divided by the ranks of this node (``LOCAL_WORLD_SIZE``, as
+    torchrun sets it: one process per GPU, SURVEY 8e, and all of them decode at the same time).  The same rule as the
+    library's own pool (include/mdx.h ``mdx_host_threads``)."""
     import os
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        with open("/sys/fs/cgroup/cpu.max") as fh:
+        with open(os.environ.get("MDX_CPU_MAX_FILE") or "/sys/fs/cgroup/cpu.max") as fh:
             quota, period = fh.read().split()[:2]
         if quota != "max" and int(period) > 0:
             n = min(n, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
+    try:
+        ranks = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        ranks = 1
+    if ranks > 1:
+        n //= ranks
     return max(1, n)
 
 
@@ -684,14 +693,15 @@ _WB_JOB = None
 
 
 def _wb_slice(span):
-    """Worker of write_bam(workers=N): records [lo, hi) as finished BGZF blocks, each starting at a record."""
-    lo, hi = span
-    batch, rg_of_record = _WB_JOB
+    """Worker of write_bam(workers=N): records [lo, hi) of batch k as finished BGZF blocks, each starting at a record."""
+    k, lo, hi = span
+    batches, rg_of_record = _WB_JOB
+    batch = batches[k]
     out = io.BytesIO()
     room = 0xFF00
     piece = bytearray()
     for i in range(lo, hi):
-        record = _bam_record(batch, i, None if rg_of_record is None else rg_of_record[i])
+        record = _bam_record(batch, i, rg_of_record if rg_of_record is None or isinstance(rg_of_record, str) else rg_of_record[i])
         if piece and len(piece) + len(record) > room:
             out.write(_bgzf_block(bytes(piece)))
             piece = bytearray()
@@ -723,7 +733,7 @@ def _bam_record(batch, i, rg):
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of_record=None, htslib_blocks=True,
+def write_bam(path, batch, ref_names, ref_lengths, read_groups, rg_of_record=None, htslib_blocks=True,
               workers=1, block_bytes=0xFF00):
     """``htslib_blocks``: lay the BGZF blocks out as htslib does (the header flushed on its own, and a block closed
     early when the next record would not fit, ``bgzf_flush_try`` in ``bam_write1``), so that every block starts
@@ -731,9 +741,12 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
     record scan speculates on.  False: header and records as one stream cut into blocks of ``block_bytes`` anywhere — the
     header shares a block with records, records straddle blocks (htsjdk / Picard fill 65 498 bytes per block).
     ``workers`` > 1 (htslib layout only): the records are encoded and deflated by forked worker processes, a slice
-    each (call it before the process touches the GPU); a slice starts a block of its own, otherwise the same file."""
+    each (call it before the process touches the GPU); a slice starts a block of its own, otherwise the same file.
+    With workers, ``batch`` may be a list of batches (written one behind the other: a file of more than 4 G bases) and
+    ``rg_of_record`` one read-group id for every record."""
     text = header_text(ref_names, ref_lengths, read_groups).encode()
-    if htslib_blocks and workers > 1 and batch.n > 4 * workers:
+    batches = list(batch) if isinstance(batch, (list, tuple)) else [batch]
+    if htslib_blocks and workers > 1 and sum(b.n for b in batches) > 4 * workers:
         import multiprocessing as mp
         global _WB_JOB
         head = io.BytesIO()
@@ -743,8 +756,8 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
             head.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln))
         hv = head.getvalue()
         n_jobs = workers * 4
-        spans = [(batch.n * k // n_jobs, batch.n * (k + 1) // n_jobs) for k in range(n_jobs)]
-        _WB_JOB = (batch, rg_of_record)
+        spans = [(k, b.n * j // n_jobs, b.n * (j + 1) // n_jobs) for k, b in enumerate(batches) for j in range(n_jobs)]
+        _WB_JOB = (batches, rg_of_record)
         try:
             with mp.get_context("fork").Pool(workers) as pool, open(path, "wb") as out:
                 for lo in range(0, len(hv), 0xFF00):
@@ -755,6 +768,11 @@ def write_bam(path, batch: ReadBatch, ref_names, ref_lengths, read_groups, rg_of
         finally:
             _WB_JOB = None
         return
+    if len(batches) != 1:
+        raise ValueError("several batches are written by forked workers only (workers > 1, htslib layout)")
+    batch = batches[0]
+    if isinstance(rg_of_record, str):
+        rg_of_record = [rg_of_record] * batch.n
     raw = io.BytesIO()
     pieces = []                      # htslib layout: uncompressed payload of each block
     room = 0xFF00

@@ -33,10 +33,10 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.mdx_abi_version() == 5       # 5: mdx_batch::libsort
+    assert lib.mdx_abi_version() == 6       # 6: the FASTA loader, mdx_warm, mdx_host_threads
     import re
     hdr = (pathlib.Path(__file__).resolve().parent.parent / "include" / "mdx.h").read_text()
-    assert int(re.search(r"#define MDX_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    assert int(re.search(r"#define MDX_ABI_VERSION (\d+)", hdr).group(1)) == 6
     assert lib.mdx_strerror(0) == b"ok"
     assert b"contig" in lib.mdx_strerror(-6)
 

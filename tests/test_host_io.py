@@ -49,8 +49,14 @@ def test_fasta_roundtrip_and_index(files):
     assert fasta.compare_sequence_dicts(fai, dict(zip(ref.names, ref.lengths)))
     assert not fasta.compare_sequence_dicts(fai, {"c1": 3999})
     assert not fasta.compare_sequence_dicts(fai, {"other": 10})
-    reordered = fasta.reference_for_bam(d / "ref.fa", ref.names[::-1])
+    reordered = fasta.reference_in_memory(d / "ref.fa", ref.names[::-1])
     assert reordered.seqs == ref.seqs[::-1]
+    # (an uncompressed FASTA stays on disk: the library loads it — tests/test_gpu_parity.py holds that loader against this one)
+    on_disk = fasta.reference_for_bam(d / "ref.fa", ref.names[::-1])
+    assert on_disk.path == str(d / "ref.fa") and on_disk.names == ref.names[::-1] and on_disk.lengths == ref.lengths[::-1]
+    with pytest.raises(KeyError):
+        fasta.reference_for_bam(d / "ref.fa", ["nope"])
+    assert fasta.reference_for_bam(d / "ref.fa", ["nope", ref.names[0]], missing_ok=True).lengths == [0, ref.lengths[0]]
 
 
 def test_reader_libraries_filter_and_errors(files):
