@@ -998,7 +998,7 @@ void *rg_buffer_take(int device, size_t need, size_t &cap) {
     if (hipMalloc(&p, cap) != hipSuccess) { cap = 0; return nullptr; }
     return p;
 }
-// ... and the two buffers a handle sends the next slab's compressed bytes ahead into (mdx_gbam::pf_buf)
+// ... and the three buffers a handle sends the next slab's compressed bytes ahead into (mdx_gbam::pf_buf)
 std::vector<RgBuf> g_pfbufs;
 void pf_buffer_take(int device, size_t need, void *&p, size_t &cap) {
     std::lock_guard<std::mutex> lk(g_rgbuf_mu);
@@ -1012,7 +1012,24 @@ void pf_buffer_take(int device, size_t need, void *&p, size_t &cap) {
 void pf_buffer_give(int device, void *p, size_t cap) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_rgbuf_mu);
-    if (g_pfbufs.size() < 4) g_pfbufs.push_back(RgBuf{device, p, cap});
+    if (g_pfbufs.size() < 6) g_pfbufs.push_back(RgBuf{device, p, cap});
+    else (void)hipFree(p);
+}
+// ... and a handle's second arena (the first one stays with its context): the largest spare one of the device
+std::vector<RgBuf> g_arenas;
+void arena_take(int device, void *&p, size_t &cap) {
+    std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+    long best = -1;
+    for (size_t i = 0; i < g_arenas.size(); i++)
+        if (g_arenas[i].device == device && (best < 0 || g_arenas[i].cap > g_arenas[(size_t)best].cap)) best = (long)i;
+    if (best < 0) return;
+    p = g_arenas[(size_t)best].p; cap = g_arenas[(size_t)best].cap;
+    g_arenas.erase(g_arenas.begin() + best);
+}
+void arena_give(int device, void *p, size_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_rgbuf_mu);
+    if (g_arenas.size() < 2) g_arenas.push_back(RgBuf{device, p, cap});
     else (void)hipFree(p);
 }
 // ... and the 64 pinned bytes a handle's CRC verdict lands in
@@ -1081,15 +1098,25 @@ struct mdx_gbam {
     // device's inflate of the rest (whose compressed bytes alone are uploaded).  Adjusted slab by slab to whoever
     // finished first; MDX_GBAM_HOST_SHARE in the environment fixes it (0: the device inflates everything).
     double host_share = 0.12;
-    bool host_share_fixed = false, slabs_timed = false;
+    bool host_share_fixed = false;
     WorkerPool *pool = nullptr;          // (the process's: host_pool())
     uint8_t *hbuf = nullptr;             // pinned host memory (the process's: host_buffer_take / _give)
     size_t hbuf_cap = 0;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_infl = nullptr, ev_infl0 = nullptr;
+    // Round 6: the slabs in a pipeline of two.  A slab's life has two halves: A — its compressed bytes in HBM, the inflate
+    // launched on a stream of its own (infl_stream), the host's share inflated and copied beside it — and B — CRC, record
+    // scan, the chain walk on the host, unpack (the context's stream), the view handed out, the caller's tabulation.  A call
+    // does A of the slab behind the one it hands out before it does B of that one: the device goes from one slab's inflate
+    // straight into the next one's (they queue on infl_stream) while B and the tabulation of the slab in front run beside it
+    // on the context's stream, and the host's threads are never idle between two slabs.  Two arenas, used in turns: A of slab
+    // k + 2 writes where slab k lived — behind an event that says the caller's tabulation of slab k is done (ev_free).
+    // MDX_GBAM_NO_LOOKAHEAD=1: one slab at a time (A/B runs; MDX_BAM_TIMING and a handle that skips slabs — a run over several
+    // GPUs, mdx_gbam_skip — do the same).
+    hipStream_t infl_stream = nullptr;
+    hipEvent_t ev_free = nullptr;
+    bool no_ahead = false;
     // the CRC of the device-inflated blocks runs on the copy stream, under the scan, the chain walk and the unpack of the same
-    // slab: ev_crc = the inflate is done; pin_bad = where its verdict lands (pinned: an asynchronous copy)
-    hipEvent_t ev_crc = nullptr;
+    // slab; pin_bad = where its verdict lands (pinned: an asynchronous copy)
     int *pin_bad = nullptr;
     std::string error;
     bool want_qual = false, want_mate = false;
@@ -1105,18 +1132,33 @@ struct mdx_gbam {
     void *d_rg = nullptr;
     size_t d_rg_cap = 0;
     // The next slab's compressed bytes, uploaded under this slab's inflate (the device's part of them: the host's share
-    // reads the file itself) into one of two buffers of the handle's own — the arena moves from slab to slab; pf_cur = the
-    // buffer that holds bytes [pf_in0, pf_in0 + pf_bytes) of the file (-1: none), pf_used = the one the current slab's
-    // inflate reads (-1: the arena's).  MDX_GBAM_NO_PREFETCH=1: off (A/B runs).
-    void *pf_buf[2] = {nullptr, nullptr};
-    size_t pf_cap[2] = {0, 0};
-    int pf_cur = -1, pf_used = -1;
+    // reads the file itself) into one of three buffers of the handle's own — two slabs' inflates may be reading theirs while
+    // the third fills; pf_cur = the buffer that holds bytes [pf_in0, pf_in0 + pf_bytes) of the file (-1: none); a slab notes
+    // the one its inflate reads (Slab::pf_used; -1: its arena's).  MDX_GBAM_NO_PREFETCH=1: off (A/B runs).
+    void *pf_buf[3] = {nullptr, nullptr, nullptr};
+    size_t pf_cap[3] = {0, 0, 0};
+    int pf_cur = -1;
     size_t pf_in0 = 0, pf_bytes = 0;
     void *d_crc_tables = nullptr;        // mdx_crc32::Tables
-    // device buffers, grown on demand
-    struct Buf { void *p = nullptr; size_t cap = 0; } comp, blk, crc, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
-        cigar_off, cigar, seq_off, seq, qual, small, info, forced, arena;     // (all but `arena` point into it)
-    std::vector<Buf *> all() { return {&arena}; }
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    // one slab in flight: what half A leaves for half B, and its device buffers (all but `arena` point into it)
+    struct Slab {
+        bool ready = false;              // half A done for the slab that starts at block b0 with this chunk_bytes / ahead
+        int64_t chunk_bytes = 0;
+        size_t b0 = 0, b1 = 0, b2 = 0;   // the slab's blocks [b0, b1), inflated [b0, b2)
+        size_t slab_bytes = 0, unc_bytes = 0, out0 = 0, in0 = 0, nh = 0, ahead = 0;
+        size_t rec_cap = 0, cig_cap = 0, seq_cap = 0;
+        bool more_file = false;
+        std::vector<uint32_t> blk, crcs;
+        int pf_used = -1;
+        hipEvent_t ev_infl0 = nullptr, ev_infl = nullptr;   // around the device's inflate (timed: the host's share is set by them)
+        double t_host = 0, frac_host = 0;                    // the host's share of this slab: milliseconds, fraction of the bytes
+        bool timed = false;
+        Buf comp, blk_d, crc, status, unc, cnt, pre, rec_off, flag, lib, tid, pos, tlen, mtid, mpos,
+            cigar_off, cigar, seq_off, seq, qual, small, info, forced, arena;
+    } slab[2];
+    int cur = 0;                         // the slab the next call hands out
+    int view_slab = 0;                   // ... and the one the last call did (mdx_gbam_view_flags)
     bool reserve(Buf &b, size_t bytes) {
         if (bytes <= b.cap) return true;
         if (b.p) (void)hipFree(b.p);
@@ -1125,6 +1167,14 @@ struct mdx_gbam {
         if (hipMalloc(&b.p, want) != hipSuccess) { error = "out of device memory"; return false; }
         b.cap = want;
         return true;
+    }
+    // everything enqueued by this handle has run (the context's stream too)
+    bool drain() {
+        bool ok = true;
+        if (infl_stream) ok = hipStreamSynchronize(infl_stream) == hipSuccess && ok;
+        if (copy_stream) ok = hipStreamSynchronize(copy_stream) == hipSuccess && ok;
+        if (stream) ok = hipStreamSynchronize(stream) == hipSuccess && ok;
+        return ok;
     }
 };
 
@@ -1155,15 +1205,25 @@ int mdx_gbam_open(mdx_ctx *ctx, const char *path, mdx_gbam **out) {
             g->host_share = std::min(0.9, std::max(0.0, std::atof(e)));
             g->host_share_fixed = true;
         }
+        if (const char *e = std::getenv("MDX_GBAM_NO_LOOKAHEAD")) g->no_ahead = *e && *e != '0';
         if (hipSetDevice(g->device) != hipSuccess || mdx_k_gbam_prepare() != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
         {
             static mdx_crc32::Tables tables;
             static std::once_flag once;
             std::call_once(once, [] { mdx_crc32::make_tables(tables); });
-            // (what the previous file of this context left behind: its arena and the tables)
-            mdx_ctx_scratch_take(ctx, &g->arena.p, &g->arena.cap, &g->d_crc_tables, (void **)&g->copy_stream, (void **)&g->ev_infl);
+            // (what the previous file of this context left behind: its arena and the tables; the second arena from the process's
+            // spare buffers)
+            void *ev = nullptr;
+            mdx_ctx_scratch_take(ctx, &g->slab[0].arena.p, &g->slab[0].arena.cap, &g->d_crc_tables, (void **)&g->copy_stream, &ev);
+            if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+            arena_take(g->device, g->slab[1].arena.p, g->slab[1].arena.cap);
             if (!g->d_crc_tables && (hipMalloc(&g->d_crc_tables, sizeof(tables)) != hipSuccess ||
                 hipMemcpy(g->d_crc_tables, &tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess)) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+            if (hipStreamCreateWithFlags(&g->infl_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&g->ev_free, hipEventDisableTiming) != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
+            for (auto &s : g->slab)
+                if (hipEventCreate(&s.ev_infl0) != hipSuccess || hipEventCreate(&s.ev_infl) != hipSuccess) { g->error = "HIP set-up failed"; return MDX_ERR_HIP; }
         }
         return MDX_OK;
     } catch (const std::exception &e) {
@@ -1212,21 +1272,518 @@ int mdx_gbam_configure(mdx_gbam *g, int32_t n_rg, const char *const *rg_ids, con
     }
 }
 
-// Compressed bytes of the slab that starts at the handle's next block: the rest of the file in as many slabs as
-// `chunk_bytes` asks for, all of one size — a last slab of a few blocks pays the fixed times of a whole one, and the
-// compressed bytes sent ahead hide best behind an inflate of their own size (an 8 M-record file of 385 MB: two slabs of
-// 193 MB, 61 ms, against 256 + 129 MB, 63-66 ms).  A function of the file's size, the slab's first block and chunk_bytes
-// only: the ranks of a multi-GPU run, which step over each other's slabs (mdx_gbam_skip), agree on the borders.
-static size_t slab_want(const mdx_gbam *g, int64_t chunk_bytes) {
+// Compressed bytes of the slab that starts at block b0: the rest of the file in as many slabs as `chunk_bytes` asks for, all
+// of one size — a last slab of a few blocks pays the fixed times of a whole one, and the compressed bytes sent ahead hide
+// best behind an inflate of their own size (an 8 M-record file of 385 MB: two slabs of 193 MB, 61 ms, against 256 + 129 MB,
+// 63-66 ms).  A function of the file's size, the slab's first block and chunk_bytes only: the ranks of a multi-GPU run, which
+// step over each other's slabs (mdx_gbam_skip), agree on the borders.
+static size_t slab_want(const mdx_gbam *g, size_t b0, int64_t chunk_bytes) {
     size_t want = chunk_bytes < 65536 ? 65536 : (size_t)chunk_bytes;
     const size_t fsz = g->hs->file->size();
-    const size_t in0 = g->next_block < g->blocks.size() ? (size_t)g->blocks[g->next_block].in_off : g->scanned;
+    const size_t in0 = b0 < g->blocks.size() ? (size_t)g->blocks[b0].in_off : g->scanned;
     if (fsz > in0) {
         const size_t rem = fsz - in0, n = (rem + want - 1) / want;
         if (n > 1) want = (rem + n - 1) / n;
         if (want < 65536) want = 65536;
     }
     return want;
+}
+// ... and the block behind its last one
+static size_t slab_end_block(const mdx_gbam *g, size_t b0, size_t want, size_t *slab_bytes_out) {
+    size_t b1 = b0, slab_bytes = 0;
+    const size_t in0 = g->blocks[b0].in_off;
+    while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && slab_bytes + g->blocks[b1].out_size < 0xE0000000ull))) {
+        slab_bytes += g->blocks[b1].out_size;
+        b1++;
+    }
+    if (slab_bytes_out) *slab_bytes_out = slab_bytes;
+    return b1;
+}
+
+namespace {
+// MDX_BAM_TRACE=1: when this thread reached each point of a call, without waiting for anything it would not wait for
+// anyway — one line per call on stderr
+struct GbamTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    std::vector<std::pair<const char *, double>> marks;
+    GbamTrace() : on(std::getenv("MDX_BAM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) { if (on) marks.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+    ~GbamTrace() {
+        if (!on || marks.empty()) return;
+        std::string line = "mdx_gbam_next trace (ms):";
+        char buf[96];
+        for (auto &m : marks) { std::snprintf(buf, sizeof buf, " %s %.2f", m.first, m.second); line += buf; }
+        std::fprintf(stderr, "%s\n", line.c_str());
+    }
+};
+// MDX_BAM_TIMING=1: stage times on stderr (each lap waits for the device; no slab is prepared ahead then)
+struct GbamLaps {
+    mdx_gbam *g;
+    bool on;
+    std::chrono::steady_clock::time_point t_last;
+    explicit GbamLaps(mdx_gbam *g_) : g(g_), on(std::getenv("MDX_BAM_TIMING") != nullptr), t_last(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        (void)g->drain();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mdx_gbam_next %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    }
+};
+const size_t kHostMinBlocks = [] { const char *e = std::getenv("MDX_GBAM_HOST_MIN_BLOCKS"); return e ? (size_t)std::max(2, std::atoi(e)) : (size_t)512; }();
+const int kNoBad = 0x7FFFFFFF;
+}  // namespace
+
+// The next slab's block headers and the device's part of its compressed bytes, sent ahead: the walk over the headers touches a
+// page of the file per block, the copy out of the file's (pageable) mapping keeps this thread busy for as long as it takes —
+// both while the device and the host's threads inflate the slab in hand.
+static int gbam_send_ahead(mdx_gbam *g, const mdx_gbam::Slab &s, size_t want, GbamTrace &tr) {
+    const size_t b1 = s.b1;
+    const size_t in1 = g->blocks[s.b2 - 1].in_off + g->blocks[s.b2 - 1].in_size;
+    if (!g->scan_to(in1 + want + 65536)) return MDX_ERR_ARG;
+    tr.mark("headers");
+    static const bool no_prefetch = [] { const char *e = std::getenv("MDX_GBAM_NO_PREFETCH"); return e && *e && *e != '0'; }();
+    if (no_prefetch || b1 >= g->blocks.size()) return MDX_OK;
+    const size_t pwant = slab_want(g, b1, s.chunk_bytes);
+    size_t pbytes = 0;
+    const size_t p1 = slab_end_block(g, b1, pwant, &pbytes);
+    const size_t pin0 = g->blocks[b1].in_off;
+    // (all of the slab's own blocks but the host's share of the inflated bytes, as its half A will split them)
+    size_t upto = p1;
+    if (g->host_share > 0.0 && p1 - b1 >= kHostMinBlocks) {
+        const size_t target = (size_t)((double)pbytes * g->host_share);
+        size_t acc = 0;
+        while (upto > b1 + 1 && acc + g->blocks[upto - 1].out_size <= target) { acc += g->blocks[upto - 1].out_size; upto--; }
+    }
+    const size_t bytes = (upto < g->blocks.size() ? g->blocks[upto].in_off : g->blocks[upto - 1].in_off + g->blocks[upto - 1].in_size) - pin0;
+    // a buffer neither of the two slabs in flight reads
+    int k = 0;
+    while (k < 3 && (k == g->slab[0].pf_used || k == g->slab[1].pf_used)) k++;
+    if (k >= 3) return MDX_OK;
+    const size_t cap_want = pwant + ((size_t)16 << 20);
+    if (g->pf_cap[k] < cap_want) {
+        if (g->pf_buf[k]) (void)hipFree(g->pf_buf[k]);
+        g->pf_buf[k] = nullptr; g->pf_cap[k] = 0;
+        pf_buffer_take(g->device, cap_want, g->pf_buf[k], g->pf_cap[k]);
+        if (!g->pf_buf[k]) {
+            if (hipMalloc(&g->pf_buf[k], cap_want) == hipSuccess) g->pf_cap[k] = cap_want;
+            else (void)hipGetLastError();
+        }
+    }
+    g->pf_cur = -1;
+    if (g->pf_cap[k] >= bytes + 64 && bytes > 0 &&
+        hipMemcpyAsync(g->pf_buf[k], g->hs->file->p + pin0, bytes, hipMemcpyHostToDevice, g->copy_stream) == hipSuccess) {
+        g->pf_cur = k; g->pf_in0 = pin0; g->pf_bytes = bytes;
+    }
+    tr.mark("sent-ahead");
+    return MDX_OK;
+}
+
+// Half A of the slab that starts at block b0, into `s`: the slab's and the blocks behind it that its last record may reach
+// into (`ahead` inflated bytes of them), the device's part of the compressed bytes in HBM, its inflate launched on
+// infl_stream, the host's part inflated by the pool and copied into place on copy_stream.
+static int gbam_half_a(mdx_gbam *g, mdx_gbam::Slab &s, size_t b0, int64_t chunk_bytes, size_t ahead, GbamLaps &laps, GbamTrace &tr) {
+    s.ready = false;
+    s.pf_used = -1;
+    const size_t want = slab_want(g, b0, chunk_bytes);
+    if (!g->scan_to((size_t)g->blocks[b0].in_off + want + 65536)) return MDX_ERR_ARG;
+    const size_t b1 = slab_end_block(g, b0, want, &s.slab_bytes);
+    const size_t in0 = g->blocks[b0].in_off, out0 = g->blocks[b0].out_off;
+    size_t b2 = b1, unc_bytes = s.slab_bytes;
+    while (unc_bytes - s.slab_bytes < ahead && unc_bytes < 0xF0000000ull) {
+        if (b2 >= g->blocks.size()) {
+            if (g->whole_file_scanned()) break;
+            if (!g->scan_to(g->scanned + ((size_t)4 << 20))) return MDX_ERR_ARG;
+            continue;
+        }
+        unc_bytes += g->blocks[b2].out_size;
+        b2++;
+    }
+    s.chunk_bytes = chunk_bytes; s.b0 = b0; s.b1 = b1; s.b2 = b2; s.unc_bytes = unc_bytes; s.out0 = out0; s.in0 = in0; s.ahead = ahead;
+    s.more_file = b2 < g->blocks.size() || !g->whole_file_scanned();
+    const size_t nba = b2 - b0;               // blocks inflated: the slab's and those ahead
+    const size_t in1 = g->blocks[b2 - 1].in_off + g->blocks[b2 - 1].in_size;
+    const size_t comp_bytes = in1 - in0;
+    std::vector<uint32_t> &blk = s.blk;
+    blk.resize(4 * nba); s.crcs.resize(nba);
+    for (size_t i = 0; i < nba; i++) {
+        const Block &b = g->blocks[b0 + i];
+        s.crcs[i] = b.crc;
+        blk[4 * i] = (uint32_t)(b.in_off - in0); blk[4 * i + 1] = (uint32_t)b.in_size;
+        blk[4 * i + 2] = (uint32_t)(b.out_off - out0); blk[4 * i + 3] = (uint32_t)b.out_size;
+    }
+    // upper bounds of the columns from the inflated size: a record is at least 36 bytes, and holds its bases
+    // twice over (4 bits + a quality byte each): l_seq <= 2/3 of its size
+    s.rec_cap = unc_bytes / 36 + 2; s.cig_cap = unc_bytes / 4 + 2; s.seq_cap = unc_bytes + 64;
+    // the host's share: the blocks [nh, nba), the last `host_share` of the inflated bytes (slabs of a few hundred blocks
+    // are the device's alone; MDX_GBAM_HOST_MIN_BLOCKS: tests put small files through the host's share)
+    size_t nh = nba;
+    if (g->host_share > 0.0 && nba >= kHostMinBlocks) {
+        const size_t target = (size_t)((double)unc_bytes * g->host_share);
+        size_t acc = 0;
+        while (nh > 1 && acc + g->blocks[b0 + nh - 1].out_size <= target) { acc += g->blocks[b0 + nh - 1].out_size; nh--; }
+        if (nba - nh < std::min<size_t>(64, kHostMinBlocks / 2)) nh = nba;
+    }
+    s.nh = nh;
+    const size_t head_comp = nh == nba ? comp_bytes : (size_t)blk[4 * nh];        // compressed bytes the device needs
+    // the arena is written behind its last readers: the caller's tabulation of the slab that lived here (enqueued on the
+    // context's stream before this call)
+    hipStream_t si = g->infl_stream;
+    if (hipEventRecord(g->ev_free, g->stream) != hipSuccess || hipStreamWaitEvent(si, g->ev_free, 0) != hipSuccess ||
+        hipStreamWaitEvent(g->copy_stream, g->ev_free, 0) != hipSuccess) return MDX_ERR_HIP;
+    // one allocation for everything (twenty hipMalloc / hipFree pairs were a tenth of a small file's time)
+    {
+        struct Want { mdx_gbam::Buf *b; size_t bytes; };
+        const Want wants[] = {
+            {&s.comp, comp_bytes + 64}, {&s.blk_d, nba * 16}, {&s.crc, nba * 4}, {&s.status, nba * 4}, {&s.unc, unc_bytes + 64}, {&s.cnt, nba * 16},
+            {&s.pre, nba * 16}, {&s.info, nba * 16}, {&s.forced, nba * 4}, {&s.small, 64}, {&s.rec_off, s.rec_cap * 4}, {&s.flag, s.rec_cap * 2},
+            {&s.lib, s.rec_cap * 2}, {&s.tid, s.rec_cap * 4}, {&s.pos, s.rec_cap * 4}, {&s.tlen, s.rec_cap * 4}, {&s.cigar_off, s.rec_cap * 4},
+            {&s.seq_off, s.rec_cap * 4}, {&s.cigar, s.cig_cap * 4}, {&s.seq, s.seq_cap}, {&s.qual, g->want_qual ? s.seq_cap : 0},
+            {&s.mtid, g->want_mate ? s.rec_cap * 4 : 0}, {&s.mpos, g->want_mate ? s.rec_cap * 4 : 0}};
+        size_t total_bytes = 0;
+        for (const Want &w : wants) total_bytes += (w.bytes + 255) & ~(size_t)255;
+        // (an arena that must grow is released first: everything that reads it must have run)
+        if (total_bytes > s.arena.cap && !g->drain()) return MDX_ERR_HIP;
+        if (!g->reserve(s.arena, total_bytes)) return MDX_ERR_HIP;
+        size_t at = 0;
+        for (const Want &w : wants) { w.b->p = w.bytes ? (char *)s.arena.p + at : nullptr; w.b->cap = 0; at += (w.bytes + 255) & ~(size_t)255; }
+    }
+    laps.lap("allocate");
+    tr.mark("arena");
+    (void)hipEventRecord(s.ev_infl0, si);
+    // (the bytes an earlier call sent ahead, if they are these: what is missing of them is sent behind)
+    const uint8_t *comp_dev = (const uint8_t *)s.comp.p;
+    if (g->pf_cur >= 0 && g->pf_in0 == in0 && g->pf_bytes > 0 && g->pf_cap[g->pf_cur] >= head_comp + 64) {
+        const int k = g->pf_cur;
+        if (hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+        if (g->pf_bytes < head_comp &&
+            hipMemcpyAsync((char *)g->pf_buf[k] + g->pf_bytes, g->hs->file->p + in0 + g->pf_bytes, head_comp - g->pf_bytes, hipMemcpyHostToDevice, si) != hipSuccess) {
+            g->error = "upload failed"; return MDX_ERR_HIP;
+        }
+        comp_dev = (const uint8_t *)g->pf_buf[k];
+        s.pf_used = k;
+    }
+    g->pf_cur = -1;
+    if ((s.pf_used < 0 && hipMemcpyAsync(s.comp.p, g->hs->file->p + in0, head_comp, hipMemcpyHostToDevice, si) != hipSuccess) ||
+        hipMemcpyAsync(s.blk_d.p, blk.data(), nba * 16, hipMemcpyHostToDevice, si) != hipSuccess ||
+        hipMemcpyAsync(s.crc.p, s.crcs.data(), nba * 4, hipMemcpyHostToDevice, si) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
+    int *d_bad_crc = (int *)((char *)s.small.p + 40);
+    (void)hipMemcpyAsync(d_bad_crc, &kNoBad, 4, hipMemcpyHostToDevice, si);
+    (void)hipMemsetAsync(s.forced.p, 0xFF, nba * 4, si);
+    // (a slab whose compressed bytes were not sent ahead — a file's first: the host's threads are about to read the file, and
+    // the runtime, copying from pageable memory, works on the same address space: one after the other)
+    if (nh < nba && s.pf_used < 0 && !std::getenv("MDX_GBAM_NO_UPLOAD_SYNC") && hipStreamSynchronize(si) != hipSuccess) return MDX_ERR_HIP;
+    laps.lap("upload");
+    tr.mark("uploaded");
+    mdx_k_gbam_inflate(comp_dev, (const uint4 *)s.blk_d.p, (int)nh, (uint8_t *)s.unc.p, (int *)s.status.p, si);
+    (void)hipEventRecord(s.ev_infl, si);
+    s.timed = false;
+    if (nh < nba) {
+        // ---- the host's blocks: inflated (and CRC-checked) by the pool into hbuf, piece by piece; this thread copies
+        // every finished piece to its place in `unc` on the copy stream, under the device's inflate
+        if (!g->pool) g->pool = host_pool();
+        if (!g->hbuf) host_buffer_take(g->hbuf, g->hbuf_cap);
+        const size_t nt = nba - nh, tail0 = blk[4 * nh + 2], tail_bytes = unc_bytes - tail0;
+        if (g->hbuf_cap < tail_bytes + 64) {
+            // (room for the largest share of a slab like this one at a share that has grown by three quarters: the share
+            // moves by halves towards the balance of the two rates, and pinned memory costs a tenth of a second per 600 MB to
+            // map; the copies out of the old buffer must have run)
+            if (hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+            if (g->hbuf) (void)hipHostFree(g->hbuf);
+            g->hbuf = nullptr;
+            g->hbuf_cap = std::max(tail_bytes + 64, (size_t)((double)unc_bytes * std::min(0.46, std::max(0.2, 1.75 * g->host_share))) + ((size_t)1 << 20));
+            const auto t_p = std::chrono::steady_clock::now();
+            if (hipHostMalloc((void **)&g->hbuf, g->hbuf_cap, hipHostMallocDefault) != hipSuccess) { g->hbuf_cap = 0; g->error = "out of pinned host memory"; return MDX_ERR_HIP; }
+            if (laps.on || tr.on) std::fprintf(stderr, "mdx_gbam_next pinned buffer of %.0f MB: %.1f ms\n", g->hbuf_cap / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p).count());
+        }
+        // pieces of about 8 MiB of inflated bytes; done[j] counts the finished blocks of piece j
+        std::vector<size_t> piece_lo;          // first block (relative to nh) of every piece, and the end
+        {
+            size_t acc = 0;
+            piece_lo.push_back(0);
+            for (size_t i = 0; i < nt; i++) {
+                acc += blk[4 * (nh + i) + 3];
+                if (acc >= ((size_t)8 << 20) && i + 1 < nt) { piece_lo.push_back(i + 1); acc = 0; }
+            }
+            piece_lo.push_back(nt);
+        }
+        const size_t np = piece_lo.size() - 1;
+        std::vector<uint32_t> piece_of(nt);
+        for (size_t j = 0; j < np; j++) for (size_t i = piece_lo[j]; i < piece_lo[j + 1]; i++) piece_of[i] = (uint32_t)j;
+        std::unique_ptr<std::atomic<uint32_t>[]> done(new std::atomic<uint32_t>[np]);
+        for (size_t j = 0; j < np; j++) done[j] = 0;
+        std::atomic<int> bad_block{-1};
+        std::vector<int32_t> host_status(nt);
+        const MappedFile &file = *g->hs->file;
+        const Block *const bl = &g->blocks[b0 + nh];
+        uint8_t *const hb = g->hbuf;
+        // (the pinned buffer is the previous slab's too: its copies must have left it)
+        if (hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+        const auto t_h0 = std::chrono::steady_clock::now();
+        g->pool->run(nt, 4, [&, bl, hb, tail0, out0](size_t i) {
+            const Block &k = bl[i];
+            const size_t off = (size_t)(k.out_off - out0) - tail0;
+            // (the block's compressed bytes through pread() into a buffer of the thread's own: a hundred threads faulting
+            // pages of the file's mapping in — under the address space's lock, next to whatever else maps and unmaps —
+            // stalled for tens of milliseconds now and then)
+            thread_local std::vector<uint8_t> mine;
+            const uint8_t *src = &file[k.in_off];
+            if (file.fd >= 0 && k.in_size) {
+                if (mine.size() < k.in_size) mine.resize(std::max<size_t>(k.in_size, 80 << 10));
+                size_t got = 0;
+                while (got < k.in_size) {
+                    const ssize_t r = pread(file.fd, mine.data() + got, k.in_size - got, (off_t)(k.in_off + got));
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                if (got == k.in_size) src = mine.data();
+            }
+            const bool ok = k.out_size == 0 || inflate_block(src, k.in_size, hb + off, k.out_size, k.crc);
+            host_status[i] = ok ? (int32_t)k.out_size : -1;
+            if (!ok) { int expect = -1; bad_block.compare_exchange_strong(expect, (int)i); }
+            done[piece_of[i]].fetch_add(1, std::memory_order_release);
+        });
+        // (this thread has nothing to copy for a while: the next slab's headers and compressed bytes meanwhile)
+        int rc_ahead = MDX_OK;
+        if (!laps.on) rc_ahead = gbam_send_ahead(g, s, want, tr);
+        bool copy_failed = false;
+        double t_waited = 0, t_copied = 0;
+        for (size_t j = 0; j < np; j++) {
+            const auto t_a = std::chrono::steady_clock::now();
+            const uint32_t need = (uint32_t)(piece_lo[j + 1] - piece_lo[j]);
+            while (done[j].load(std::memory_order_acquire) < need) std::this_thread::sleep_for(std::chrono::microseconds(30));
+            const auto t_b = std::chrono::steady_clock::now();
+            const size_t lo = (size_t)blk[4 * (nh + piece_lo[j]) + 2] - tail0;
+            const size_t hi = piece_lo[j + 1] < nt ? (size_t)blk[4 * (nh + piece_lo[j + 1]) + 2] - tail0 : tail_bytes;
+            if (hi > lo && hipMemcpyAsync((char *)s.unc.p + tail0 + lo, hb + lo, hi - lo, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess)
+                copy_failed = true;
+            const auto t_c = std::chrono::steady_clock::now();
+            t_waited += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+            t_copied += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+        }
+        g->pool->wait();
+        tr.mark("host-share");
+        s.t_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+        s.frac_host = (double)tail_bytes / (double)unc_bytes;
+        s.timed = true;
+        if (laps.on)
+            std::fprintf(stderr, "mdx_gbam_next host share  %.2f: %zu of %zu blocks, %.1f MB inflated on %zu threads; waited for them %.2f ms, copies %.2f ms, all %.2f ms; device %s\n",
+                         g->host_share, nt, nba, tail_bytes / 1e6, g->pool->threads.size(), t_waited, t_copied, s.t_host,
+                         hipEventQuery(s.ev_infl) == hipSuccess ? "done" : "still inflating");
+        if (copy_failed || hipMemcpyAsync((int32_t *)s.status.p + nh, host_status.data(), nt * 4, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess ||
+            hipStreamSynchronize(g->copy_stream) != hipSuccess) { g->error = "upload of the host-inflated blocks failed"; return MDX_ERR_HIP; }
+        tr.mark("host-copied");
+        if (bad_block.load() >= 0) {
+            g->error = "corrupt BGZF block " + std::to_string(b0 + nh + (size_t)bad_block.load()) + " (DEFLATE stream, ISIZE or CRC32)";
+            return MDX_ERR_ARG;
+        }
+        if (rc_ahead != MDX_OK) return rc_ahead;
+    } else if (!laps.on) {
+        const int rc_ahead = gbam_send_ahead(g, s, want, tr);
+        if (rc_ahead != MDX_OK) return rc_ahead;
+    }
+    laps.lap("inflate");
+    s.ready = true;
+    return MDX_OK;
+}
+
+// The share that would have let both sides finish together, from the two rates of a slab whose device inflate has run — the
+// device's inflate of its blocks, the host's inflate and copies of the others — approached by halves.
+static void gbam_adapt_share(mdx_gbam *g, mdx_gbam::Slab &s) {
+    if (g->host_share_fixed || !s.timed) return;
+    s.timed = false;
+    float t_dev = 0.f;
+    if (hipEventQuery(s.ev_infl) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventElapsedTime(&t_dev, s.ev_infl0, s.ev_infl) != hipSuccess || t_dev <= 0.1f || s.t_host <= 0.1) { (void)hipGetLastError(); return; }
+    const double f = s.frac_host;
+    const double r_host = f / s.t_host, r_dev = (1.0 - f) / (double)t_dev;
+    const double balanced = r_host / (r_host + r_dev);
+    // (aiming a little below the balance: a host that finishes early costs nothing, one that finishes late costs its lateness)
+    g->host_share = std::min(0.45, std::max(0.04, 0.5 * g->host_share + 0.5 * 0.85 * balanced));
+    g_host_share.store(g->host_share);
+}
+
+// Half B of a slab whose half A is done: CRC (beside, on the copy stream), the record chains of its segments and their check on
+// the host, unpack into the columns; the view.  *grow: the slab's last record reaches further than the blocks inflated behind
+// it (half A again, with more of them).
+static int gbam_half_b(mdx_gbam *g, mdx_gbam::Slab &s, mdx_batch *view, const int32_t **d_mtid, const int32_t **d_mpos, bool *grow_out,
+                       GbamLaps &laps, GbamTrace &tr) {
+    *grow_out = false;
+    hipStream_t st = g->stream;
+    const size_t b0 = s.b0, b1 = s.b1, nb = s.b1 - s.b0, nba = s.b2 - s.b0, nh = s.nh, unc_bytes = s.unc_bytes, slab_bytes = s.slab_bytes;
+    const std::vector<uint32_t> &blk = s.blk;
+    const bool more_file = s.more_file;
+    int *d_bad_crc = (int *)((char *)s.small.p + 40);
+    // the context's stream and the copy stream go on behind the device's inflate
+    if (hipStreamWaitEvent(st, s.ev_infl, 0) != hipSuccess) return MDX_ERR_HIP;
+    // (the CRC beside what follows, on the copy stream; its verdict is looked at before the slab is handed out.
+    // MDX_BAM_TIMING: in line, so that its lap is its own)
+    bool crc_aside = !laps.on;
+    if (crc_aside) {
+        if (!g->pin_bad) g->pin_bad = pin_take();
+        if (!g->pin_bad) crc_aside = false;
+    }
+    if (crc_aside) {
+        *g->pin_bad = kNoBad;
+        if (hipStreamWaitEvent(g->copy_stream, s.ev_infl, 0) != hipSuccess) return MDX_ERR_HIP;
+        mdx_k_gbam_crc((const uint8_t *)s.unc.p, (const uint4 *)s.blk_d.p, (const uint32_t *)s.crc.p, g->d_crc_tables, (int)nh, d_bad_crc, g->copy_stream);
+        if (hipMemcpyAsync(g->pin_bad, d_bad_crc, 4, hipMemcpyDeviceToHost, g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+    } else
+    mdx_k_gbam_crc((const uint8_t *)s.unc.p, (const uint4 *)s.blk_d.p, (const uint32_t *)s.crc.p, g->d_crc_tables, (int)nh, d_bad_crc, st);
+    laps.lap("crc32");
+    // the chains of the segments (every block inflated is one: those ahead of the slab say whether the next slab's
+    // first record can be found without this one), then their check on the host
+    const int n_ref = (int)g->hs->head.ref_names.size();
+    const uint32_t start0 = g->phase_known ? (uint32_t)g->phase : 0xFFFFFFFFu;
+    mdx_k_gbam_scan((const uint8_t *)s.unc.p, (const uint4 *)s.blk_d.p, (const int *)s.status.p, (int)nba, 0, nullptr, start0,
+                    (uint32_t)unc_bytes, n_ref, (uint4 *)s.info.p, (uint4 *)s.cnt.p, st);
+    laps.lap("scan");
+    std::vector<uint32_t> info(4 * nba), cnt(4 * nba);
+    int bad_crc = kNoBad;
+    if (hipMemcpyAsync(info.data(), s.info.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(cnt.data(), s.cnt.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (!crc_aside && hipMemcpyAsync(&bad_crc, d_bad_crc, 4, hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess) {
+        g->error = std::string("GPU decode failed: ") + hipGetErrorString(hipGetLastError());
+        return MDX_ERR_HIP;
+    }
+    tr.mark("scanned");
+    gbam_adapt_share(g, s);
+    for (size_t i = 0; i < nba; i++)
+        if ((int32_t)info[4 * i + 2] == -2) {
+            int stv = 0;
+            (void)hipMemcpy(&stv, (const int *)s.status.p + i, 4, hipMemcpyDeviceToHost);
+            g->error = "corrupt BGZF block " + std::to_string(b0 + i) + " (inflate code " + std::to_string(stv) + ")";
+            return MDX_ERR_ARG;
+        }
+    if (bad_crc != kNoBad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
+    // (crc_aside: the same check behind the unpack's launch, below)
+    auto crc_verdict = [&]() -> bool {
+        if (!crc_aside) return true;
+        if (hipStreamSynchronize(g->copy_stream) != hipSuccess) { g->error = "GPU decode failed (CRC32 pass)"; return false; }
+        if (*g->pin_bad != kNoBad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)*g->pin_bad) + " (CRC32)"; return false; }
+        return true;
+    };
+    // The walk: `at` = where the next record starts, known exactly; the segment that holds it must have begun its chain
+    // there — if its guess was another offset it is scanned again from the right one — and says where the chain lands.
+    const size_t slab_end = slab_bytes;
+    std::vector<uint8_t> used(nba, 0);
+    size_t at = 0, seg = 0;
+    bool have = g->phase_known;
+    if (have) at = g->phase;
+    else {
+        // behind a skipped slab: the first guess of this slab stands (its neighbour checks it: next_verified)
+        for (size_t i = 0; i < nb && !have; i++)
+            if (info[4 * i + 2] != 1u) { have = true; at = info[4 * i]; }
+        if (!have) at = slab_end;              // no record starts in this slab
+    }
+    bool grow = false;
+    while (at < slab_end) {
+        while (seg < nba && (size_t)blk[4 * seg + 2] + blk[4 * seg + 3] <= at) seg++;
+        if (seg >= nb) break;
+        if (info[4 * seg] != (uint32_t)at || info[4 * seg + 2] == 1u) {
+            // (rare: a guess that was not the record's start, or a segment whose first record begins behind a long one)
+            const int32_t f = (int32_t)at;
+            if (hipMemcpyAsync((int32_t *)s.forced.p + seg, &f, 4, hipMemcpyHostToDevice, st) != hipSuccess) return MDX_ERR_HIP;
+            mdx_k_gbam_scan((const uint8_t *)s.unc.p, (const uint4 *)s.blk_d.p, (const int *)s.status.p, (int)seg + 1, (int)seg,
+                            (const int *)s.forced.p, start0, (uint32_t)unc_bytes, n_ref, (uint4 *)s.info.p, (uint4 *)s.cnt.p, st);
+            if (hipMemcpyAsync(&info[4 * seg], (const uint4 *)s.info.p + seg, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&cnt[4 * seg], (const uint4 *)s.cnt.p + seg, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
+            g->fixups++;
+        }
+        const int32_t stv = (int32_t)info[4 * seg + 2];
+        if (stv == -1) { g->error = "corrupt BAM record in BGZF block " + std::to_string(b0 + seg); return MDX_ERR_ARG; }
+        if (stv == 3) { g->error = "a record that keeps its CIGAR in a CG tag (more than 65 535 operations): the host decoder's"; return MDX_ERR_UNSUPPORTED; }
+        if (stv == 2 && cnt[4 * seg] == 0 && info[4 * seg + 1] == (uint32_t)at && !more_file) {
+            g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG;
+        }
+        used[seg] = 1;
+        const size_t land = info[4 * seg + 1];
+        if (stv == 2 && land < slab_end) {
+            // the chain stopped at a record that starts in the slab and is not complete in what was inflated
+            if (!more_file) { g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG; }
+            grow = true;
+            break;
+        }
+        if (land <= at) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
+        at = land;
+    }
+    if (grow) {
+        // (the CRC pass of this attempt reads the bytes the next one writes)
+        if (crc_aside && hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
+        if (s.ahead >= ((size_t)1 << 30)) { g->error = "a BAM record of more than a gigabyte"; return MDX_ERR_UNSUPPORTED; }
+        *grow_out = true;
+        return MDX_OK;
+    }
+    // where the next slab's first record starts — and whether a process that has not seen this slab would find it: the
+    // segment ahead that holds it must have guessed exactly that offset (mdx_gbam_skip refuses to go on otherwise)
+    const size_t next_phase = at > slab_end ? at - slab_end : 0;
+    {
+        size_t sg = nb;
+        while (sg < nba && (size_t)blk[4 * sg + 2] + blk[4 * sg + 3] <= at) sg++;
+        if (b1 >= g->blocks.size() && g->whole_file_scanned()) g->next_verified = true;      // nothing follows
+        else {
+            // (the rank behind takes the first segment of its slab that has any guess: a segment in front of the right one —
+            // inside a record that straddles whole blocks — must not have produced one)
+            bool clean = true;
+            for (size_t i = nb; i < sg && i < nba; i++) clean = clean && info[4 * i + 2] == 1u;
+            g->next_verified = clean && sg < nba && info[4 * sg + 2] != 1u && info[4 * sg] == (uint32_t)at;
+        }
+    }
+    // prefix sums over the segments that hold the chain
+    std::vector<uint32_t> pre(4 * nb);
+    unsigned long long tot[3] = {0, 0, 0};
+    for (size_t i = 0; i < nb; i++) {
+        if (!used[i]) { cnt[4 * i] = cnt[4 * i + 1] = cnt[4 * i + 2] = 0; }
+        pre[4 * i] = (uint32_t)tot[0]; pre[4 * i + 1] = (uint32_t)tot[1]; pre[4 * i + 2] = (uint32_t)tot[2]; pre[4 * i + 3] = info[4 * i];
+        tot[0] += cnt[4 * i]; tot[1] += cnt[4 * i + 1]; tot[2] += cnt[4 * i + 2];
+    }
+    if (tot[0] > s.rec_cap - 2 || tot[1] > s.cig_cap - 2 || tot[2] > s.seq_cap - 64 || tot[2] > 0xFFFFFFFFull) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
+    if (hipMemcpyAsync(s.pre.p, pre.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(s.cnt.p, cnt.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess) return MDX_ERR_HIP;
+    laps.lap("chains");
+    MdxGbamCols c{};
+    c.flag = (uint16_t *)s.flag.p; c.lib = (uint16_t *)s.lib.p; c.tid = (int32_t *)s.tid.p; c.pos = (int32_t *)s.pos.p;
+    c.tlen = (int32_t *)s.tlen.p; c.mtid = g->want_mate ? (int32_t *)s.mtid.p : nullptr; c.mpos = g->want_mate ? (int32_t *)s.mpos.p : nullptr;
+    c.cigar_off = (uint32_t *)s.cigar_off.p; c.cigar = (uint32_t *)s.cigar.p; c.seq_off = (uint32_t *)s.seq_off.p;
+    c.seq = (uint8_t *)s.seq.p; c.qual = g->want_qual ? (uint8_t *)s.qual.p : nullptr;
+    c.rg_names = (const uint8_t *)g->d_rg_names; c.rg_off = (const uint32_t *)g->d_rg_off; c.lib_of_rg = (const int32_t *)g->d_lib_of_rg;
+    c.n_rg = (int)g->lib_of_rg.size(); c.lib_default = g->lib_default;
+    uint32_t *d_counters = (uint32_t *)((char *)s.small.p + 48);
+    c.minqual = g->want_qual ? g->minqual : 0; c.counters = d_counters;
+    if (c.minqual > 0 && hipMemsetAsync(d_counters, 0, 8, st) != hipSuccess) return MDX_ERR_HIP;
+    c.seq_packed = g->seq_format == MDX_SEQ_4BIT ? 1 : 0;
+    // (the unpack kernel ORs the nibbles of a record into the column: zeroed first, with the dword behind the last base)
+    if (c.seq_packed && hipMemsetAsync(c.seq, 0, (size_t)(tot[2] + 1) / 2 + 8, st) != hipSuccess) return MDX_ERR_HIP;
+    // (--min-basequal: the mask goes into the nibbles — MDX_SEQ_4BITQ, the packed masked kernel's input)
+    c.fold = (c.minqual > 0 && c.seq_packed) ? 1 : 0;
+    mdx_k_gbam_unpack((const uint8_t *)s.unc.p, (const uint4 *)s.pre.p, (const uint4 *)s.cnt.p, (int)nb,
+                      (uint32_t)tot[0], (uint32_t)tot[1], (uint32_t)tot[2], (uint32_t *)s.rec_off.p, c, st);
+    if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
+    tr.mark("unpack-enq");
+    if (!crc_verdict()) return g->error.find("corrupt") != std::string::npos ? MDX_ERR_ARG : MDX_ERR_HIP;
+    laps.lap("unpack");
+    view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
+    view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
+    view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
+    view->seq_format = c.fold ? MDX_SEQ_4BITQ : g->seq_format; view->reserved = 0; view->lowq = nullptr; view->libsort = nullptr;
+    if (c.minqual > 0) {
+        uint32_t counters[2] = {0, 0};
+        if (hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
+        if (counters[0]) g->no_qual_seen = true;
+        // nothing in this slab can be masked: the unmasked kernel (no nibble of the column is a complement)
+        if (counters[1] == 0) { view->qual = nullptr; view->seq_format = g->seq_format; }
+    }
+    if (d_mtid) *d_mtid = c.mtid;
+    if (d_mpos) *d_mpos = c.mpos;
+    g->next_block = b1;
+    g->phase = next_phase;
+    g->phase_known = have;
+    g->slabs_done++;
+    g->view_reads = view->n_reads;
+    s.ready = false;
+    return MDX_OK;
 }
 
 int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32_t **d_mtid, const int32_t **d_mpos) {
@@ -1235,9 +1792,8 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         std::memset(view, 0, sizeof(*view));
         if (d_mtid) *d_mtid = nullptr;
         if (d_mpos) *d_mpos = nullptr;
-        const size_t want = slab_want(g, chunk_bytes);
-        // (the block headers of this slab, unless the previous call has already walked them)
-        if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + want + 65536)) return MDX_ERR_ARG;
+        // (the block headers of this slab, unless an earlier call has already walked them)
+        if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + slab_want(g, g->next_block, chunk_bytes) + 65536)) return MDX_ERR_ARG;
         if (g->next_block >= g->blocks.size()) {                          // end of file: an empty view
             if (g->phase_known && g->phase != 0) { g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG; }
             return MDX_OK;
@@ -1247,426 +1803,40 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *view, const int32
         if (const char *fail = std::getenv("MDX_GBAM_FAIL_AT")) {
             if (g->slabs_done == std::atoi(fail)) { g->error = "MDX_GBAM_FAIL_AT"; return MDX_ERR_UNSUPPORTED; }
         }
-        // MDX_BAM_TIMING=1: stage times on stderr (each lap waits for the stream)
-        const bool timing = std::getenv("MDX_BAM_TIMING") != nullptr;
-        auto t_last = std::chrono::steady_clock::now();
-        auto lap = [&](const char *what) {
-            if (!timing) return;
-            (void)hipStreamSynchronize(g->stream);
-            const auto now = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "mdx_gbam_next %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-            t_last = now;
-        };
-        // the slab: blocks [b0, b1), about `want` compressed bytes, less than 4 GiB inflated
-        const size_t b0 = g->next_block;
-        size_t b1 = b0, slab_bytes = 0;
-        const size_t in0 = g->blocks[b0].in_off;
-        while (b1 < g->blocks.size() && (b1 == b0 || (g->blocks[b1].in_off - in0 < want && slab_bytes + g->blocks[b1].out_size < 0xE0000000ull))) {
-            slab_bytes += g->blocks[b1].out_size;
-            b1++;
-        }
-        const size_t nb = b1 - b0;
-        const size_t out0 = g->blocks[b0].out_off;
-        hipStream_t st = g->stream;
-        // ... and the blocks behind it that the slab's last record may reach into: `ahead` inflated bytes of them, more if
-        // the record turns out to be longer (a second pass of the whole slab: reads of a quarter of a megabyte are rare)
+        GbamLaps laps(g);
+        GbamTrace tr;
+        mdx_gbam::Slab &s = g->slab[g->cur], &n = g->slab[g->cur ^ 1];
+        // ... `ahead` inflated bytes of the blocks behind the slab, more if its last record turns out to be longer (half A of the
+        // whole slab again: reads of a quarter of a megabyte are rare)
         size_t ahead = (size_t)256 << 10;
         for (;;) {
-        size_t b2 = b1, unc_bytes = slab_bytes;
-        while (unc_bytes - slab_bytes < ahead && unc_bytes < 0xF0000000ull) {
-            if (b2 >= g->blocks.size()) {
-                if (g->whole_file_scanned()) break;
-                if (!g->scan_to(g->scanned + ((size_t)4 << 20))) return MDX_ERR_ARG;
-                continue;
+            if (!(s.ready && s.b0 == g->next_block && s.chunk_bytes == chunk_bytes && s.ahead == ahead)) {
+                const int rc = gbam_half_a(g, s, g->next_block, chunk_bytes, ahead, laps, tr);
+                if (rc != MDX_OK) { (void)g->drain(); return rc; }
             }
-            unc_bytes += g->blocks[b2].out_size;
-            b2++;
-        }
-        const bool more_file = b2 < g->blocks.size() || !g->whole_file_scanned();
-        const size_t nba = b2 - b0;               // blocks inflated: the slab's and those ahead
-        const size_t in1 = g->blocks[b2 - 1].in_off + g->blocks[b2 - 1].in_size;
-        const size_t comp_bytes = in1 - in0;
-        std::vector<uint32_t> blk(4 * nba), crcs(nba);
-        for (size_t i = 0; i < nba; i++) {
-            const Block &b = g->blocks[b0 + i];
-            crcs[i] = b.crc;
-            blk[4 * i] = (uint32_t)(b.in_off - in0); blk[4 * i + 1] = (uint32_t)b.in_size;
-            blk[4 * i + 2] = (uint32_t)(b.out_off - out0); blk[4 * i + 3] = (uint32_t)b.out_size;
-        }
-        // upper bounds of the columns from the inflated size: a record is at least 36 bytes, and holds its bases
-        // twice over (4 bits + a quality byte each): l_seq <= 2/3 of its size
-        const size_t rec_cap = unc_bytes / 36 + 2, cig_cap = unc_bytes / 4 + 2, seq_cap = unc_bytes + 64;
-        // one allocation for everything (twenty hipMalloc / hipFree pairs were a tenth of a small file's time)
-        {
-            struct Want { mdx_gbam::Buf *b; size_t bytes; };
-            const Want wants[] = {
-                {&g->comp, comp_bytes + 64}, {&g->blk, nba * 16}, {&g->crc, nba * 4}, {&g->status, nba * 4}, {&g->unc, unc_bytes + 64}, {&g->cnt, nba * 16},
-                {&g->pre, nba * 16}, {&g->info, nba * 16}, {&g->forced, nba * 4}, {&g->small, 64}, {&g->rec_off, rec_cap * 4}, {&g->flag, rec_cap * 2},
-                {&g->lib, rec_cap * 2}, {&g->tid, rec_cap * 4}, {&g->pos, rec_cap * 4}, {&g->tlen, rec_cap * 4}, {&g->cigar_off, rec_cap * 4},
-                {&g->seq_off, rec_cap * 4}, {&g->cigar, cig_cap * 4}, {&g->seq, seq_cap}, {&g->qual, g->want_qual ? seq_cap : 0},
-                {&g->mtid, g->want_mate ? rec_cap * 4 : 0}, {&g->mpos, g->want_mate ? rec_cap * 4 : 0}};
-            size_t total_bytes = 0;
-            for (const Want &w : wants) total_bytes += (w.bytes + 255) & ~(size_t)255;
-            // (the previous slab's columns may still be read by the tabulation kernel: wait before the arena moves)
-            if (total_bytes > g->arena.cap && hipStreamSynchronize(g->stream) != hipSuccess) return MDX_ERR_HIP;
-            if (!g->reserve(g->arena, total_bytes)) return MDX_ERR_HIP;
-            size_t at = 0;
-            for (const Want &w : wants) { w.b->p = w.bytes ? (char *)g->arena.p + at : nullptr; w.b->cap = 0; at += (w.bytes + 255) & ~(size_t)255; }
-        }
-        lap("allocate");
-        // the previous slab's columns may still be read by the tabulation kernel
-        if (hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
-        // the host's share: the blocks [nh, nba), the last `host_share` of the inflated bytes (slabs of a few hundred blocks
-        // are the device's alone)
-        size_t nh = nba;
-        // (MDX_GBAM_HOST_MIN_BLOCKS: tests put small files through the host's share)
-        static const size_t host_min_blocks = [] { const char *e = std::getenv("MDX_GBAM_HOST_MIN_BLOCKS"); return e ? (size_t)std::max(2, std::atoi(e)) : (size_t)512; }();
-        if (g->host_share > 0.0 && nba >= host_min_blocks) {
-            const size_t target = (size_t)((double)unc_bytes * g->host_share);
-            size_t acc = 0;
-            while (nh > 1 && acc + g->blocks[b0 + nh - 1].out_size <= target) { acc += g->blocks[b0 + nh - 1].out_size; nh--; }
-            if (nba - nh < std::min<size_t>(64, host_min_blocks / 2)) nh = nba;
-        }
-        const size_t head_comp = nh == nba ? comp_bytes : (size_t)blk[4 * nh];        // compressed bytes the device needs
-        if (nh < nba && g->ev_infl0) (void)hipEventRecord(g->ev_infl0, st);
-        // (the bytes the previous call sent ahead, if they are these: what is missing of them is sent behind)
-        const uint8_t *comp_dev = (const uint8_t *)g->comp.p;
-        g->pf_used = -1;
-        if (g->pf_cur >= 0 && g->pf_in0 == in0 && g->pf_bytes > 0 && g->pf_cap[g->pf_cur] >= head_comp + 64) {
-            const int k = g->pf_cur;
-            if (g->copy_stream && hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
-            if (g->pf_bytes < head_comp &&
-                hipMemcpyAsync((char *)g->pf_buf[k] + g->pf_bytes, g->hs->file->p + in0 + g->pf_bytes, head_comp - g->pf_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
-                g->error = "upload failed"; return MDX_ERR_HIP;
-            }
-            comp_dev = (const uint8_t *)g->pf_buf[k];
-            g->pf_used = k;
-        }
-        g->pf_cur = -1;
-        if ((g->pf_used < 0 && hipMemcpyAsync(g->comp.p, g->hs->file->p + in0, head_comp, hipMemcpyHostToDevice, st) != hipSuccess) ||
-            hipMemcpyAsync(g->blk.p, blk.data(), nba * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(g->crc.p, crcs.data(), nba * 4, hipMemcpyHostToDevice, st) != hipSuccess) { g->error = "upload failed"; return MDX_ERR_HIP; }
-        int *d_bad_crc = (int *)((char *)g->small.p + 40);
-        const int no_bad = 0x7FFFFFFF;
-        (void)hipMemcpyAsync(d_bad_crc, &no_bad, 4, hipMemcpyHostToDevice, st);
-        (void)hipMemsetAsync(g->forced.p, 0xFF, nba * 4, st);
-        // (the host's threads are about to fault in the pages of the file they read; the runtime, copying from pageable memory,
-        // works on the same address space: one after the other)
-        if (nh < nba && !std::getenv("MDX_GBAM_NO_UPLOAD_SYNC") && hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
-        lap("upload");
-        mdx_k_gbam_inflate(comp_dev, (const uint4 *)g->blk.p, (int)nh, (uint8_t *)g->unc.p, (int *)g->status.p, st);
-        if (nh < nba) {
-            // ---- the host's blocks: inflated (and CRC-checked) by the pool into hbuf, piece by piece; this thread copies
-            // every finished piece to its place in `unc` on the copy stream, under the device's inflate
-            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) return MDX_ERR_HIP;
-            if (!g->ev_infl && hipEventCreate(&g->ev_infl) != hipSuccess) return MDX_ERR_HIP;
-            if (!g->ev_infl0 && hipEventCreate(&g->ev_infl0) != hipSuccess) return MDX_ERR_HIP;
-            (void)hipEventRecord(g->ev_infl, st);
-            if (!g->pool) g->pool = host_pool();
-            if (!g->hbuf) host_buffer_take(g->hbuf, g->hbuf_cap);
-            const size_t nt = nba - nh, tail0 = blk[4 * nh + 2], tail_bytes = unc_bytes - tail0;
-            if (g->hbuf_cap < tail_bytes + 64) {
-                // (room for the largest share of a slab like this one, so that it need not grow again)
-                if (g->hbuf) (void)hipHostFree(g->hbuf);
-                g->hbuf = nullptr;
-                // (... of a slab like this one at a share that has grown by three quarters: the share moves by halves towards the balance
-                // of the two rates, and pinned memory costs a tenth of a second per 600 MB to map)
-                g->hbuf_cap = std::max(tail_bytes + 64, (size_t)((double)unc_bytes * std::min(0.46, std::max(0.2, 1.75 * g->host_share))) + ((size_t)1 << 20));
-                const auto t_p = std::chrono::steady_clock::now();
-                if (hipHostMalloc((void **)&g->hbuf, g->hbuf_cap, hipHostMallocDefault) != hipSuccess) { g->hbuf_cap = 0; g->error = "out of pinned host memory"; return MDX_ERR_HIP; }
-                if (timing) std::fprintf(stderr, "mdx_gbam_next pinned buffer of %.0f MB: %.1f ms\n", g->hbuf_cap / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p).count());
-            }
-            // pieces of about 8 MiB of inflated bytes; done[j] counts the finished blocks of piece j
-            std::vector<size_t> piece_lo;          // first block (relative to nh) of every piece, and the end
-            {
-                size_t acc = 0;
-                piece_lo.push_back(0);
-                for (size_t i = 0; i < nt; i++) {
-                    acc += blk[4 * (nh + i) + 3];
-                    if (acc >= ((size_t)8 << 20) && i + 1 < nt) { piece_lo.push_back(i + 1); acc = 0; }
+            tr.mark("A");
+            // the slab behind it, ahead of time: its inflate queues behind this one's, the host's threads go on with its share
+            if (!g->no_ahead && !laps.on && s.b1 < g->blocks.size() && !(n.ready && n.b0 == s.b1 && n.chunk_bytes == chunk_bytes)) {
+                const std::string keep = g->error;
+                if (gbam_half_a(g, n, s.b1, chunk_bytes, (size_t)256 << 10, laps, tr) != MDX_OK) {
+                    // (whatever is wrong with that slab is reported by the call that hands it out)
+                    (void)g->drain();
+                    n.ready = false; g->pf_cur = -1; g->error = keep;
                 }
-                piece_lo.push_back(nt);
+                tr.mark("A-next");
             }
-            const size_t np = piece_lo.size() - 1;
-            std::vector<uint32_t> piece_of(nt);
-            for (size_t j = 0; j < np; j++) for (size_t i = piece_lo[j]; i < piece_lo[j + 1]; i++) piece_of[i] = (uint32_t)j;
-            std::unique_ptr<std::atomic<uint32_t>[]> done(new std::atomic<uint32_t>[np]);
-            for (size_t j = 0; j < np; j++) done[j] = 0;
-            std::atomic<int> bad_block{-1};
-            std::vector<int32_t> host_status(nt);
-            const MappedFile &file = *g->hs->file;
-            const Block *const bl = &g->blocks[b0 + nh];
-            uint8_t *const hb = g->hbuf;
-            g->pool->run(nt, 4, [&, bl, hb, tail0](size_t i) {
-                const Block &k = bl[i];
-                const size_t off = (size_t)(k.out_off - out0) - tail0;
-                // (the block's compressed bytes through pread() into a buffer of the thread's own: a hundred threads faulting
-                // pages of the file's mapping in — under the address space's lock, next to whatever else maps and unmaps —
-                // stalled for tens of milliseconds now and then)
-                thread_local std::vector<uint8_t> mine;
-                const uint8_t *src = &file[k.in_off];
-                if (file.fd >= 0 && k.in_size) {
-                    if (mine.size() < k.in_size) mine.resize(std::max<size_t>(k.in_size, 80 << 10));
-                    size_t got = 0;
-                    while (got < k.in_size) {
-                        const ssize_t r = pread(file.fd, mine.data() + got, k.in_size - got, (off_t)(k.in_off + got));
-                        if (r <= 0) break;
-                        got += (size_t)r;
-                    }
-                    if (got == k.in_size) src = mine.data();
-                }
-                const bool ok = k.out_size == 0 || inflate_block(src, k.in_size, hb + off, k.out_size, k.crc);
-                host_status[i] = ok ? (int32_t)k.out_size : -1;
-                if (!ok) { int expect = -1; bad_block.compare_exchange_strong(expect, (int)i); }
-                done[piece_of[i]].fetch_add(1, std::memory_order_release);
-            });
-            bool copy_failed = false;
-            const auto t_h0 = std::chrono::steady_clock::now();
-            double t_waited = 0, t_copied = 0;
-            for (size_t j = 0; j < np; j++) {
-                const auto t_a = std::chrono::steady_clock::now();
-                const uint32_t need = (uint32_t)(piece_lo[j + 1] - piece_lo[j]);
-                while (done[j].load(std::memory_order_acquire) < need) std::this_thread::sleep_for(std::chrono::microseconds(30));
-                const auto t_b = std::chrono::steady_clock::now();
-                const size_t lo = (size_t)blk[4 * (nh + piece_lo[j]) + 2] - tail0;
-                const size_t hi = piece_lo[j + 1] < nt ? (size_t)blk[4 * (nh + piece_lo[j + 1]) + 2] - tail0 : tail_bytes;
-                if (hi > lo && hipMemcpyAsync((char *)g->unc.p + tail0 + lo, hb + lo, hi - lo, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess)
-                    copy_failed = true;
-                const auto t_c = std::chrono::steady_clock::now();
-                t_waited += std::chrono::duration<double, std::milli>(t_b - t_a).count();
-                t_copied += std::chrono::duration<double, std::milli>(t_c - t_b).count();
-            }
-            g->pool->wait();
-            if (timing)
-                std::fprintf(stderr, "mdx_gbam_next host share  %.2f: %zu of %zu blocks, %.1f MB inflated on %zu threads; waited for them %.2f ms, copies %.2f ms, all %.2f ms; device %s\n",
-                             g->host_share, nt, nba, tail_bytes / 1e6, g->pool->threads.size(), t_waited, t_copied,
-                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count(),
-                             hipEventQuery(g->ev_infl) == hipSuccess ? "done" : "still inflating");
-            // (the share that would have let both sides finish together, from the two rates of this slab — the device's
-            // upload and inflate of its blocks, the host's inflate and copies of the others — approached by halves)
-            const double t_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
-            float t_dev = 0.f;
-            if (!g->host_share_fixed && g->slabs_timed && hipEventSynchronize(g->ev_infl) == hipSuccess &&
-                hipEventElapsedTime(&t_dev, g->ev_infl0, g->ev_infl) == hipSuccess && t_dev > 0.1f && t_host > 0.1) {
-                const double f = (double)tail_bytes / (double)unc_bytes;
-                const double r_host = f / t_host, r_dev = (1.0 - f) / (double)t_dev;
-                const double balanced = r_host / (r_host + r_dev);
-                // (aiming a little below the balance: a host that finishes early costs nothing, one that finishes late costs its lateness)
-                g->host_share = std::min(0.45, std::max(0.04, 0.5 * g->host_share + 0.5 * 0.85 * balanced));
-                g_host_share.store(g->host_share);
-            }
-            g->slabs_timed = true;      // (the first slab of a handle has no start event of its own yet)
-            if (copy_failed || hipMemcpyAsync((int32_t *)g->status.p + nh, host_status.data(), nt * 4, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess ||
-                hipStreamSynchronize(g->copy_stream) != hipSuccess) { g->error = "upload of the host-inflated blocks failed"; return MDX_ERR_HIP; }
-            if (bad_block.load() >= 0) {
-                g->error = "corrupt BGZF block " + std::to_string(b0 + nh + (size_t)bad_block.load()) + " (DEFLATE stream, ISIZE or CRC32)";
-                return MDX_ERR_ARG;
-            }
-        }
-        // (the next slab's block headers, while the device inflates this one)
-        if (!timing && !g->scan_to(in1 + want + 65536)) return MDX_ERR_ARG;
-        // ... and the device's part of its compressed bytes, sent ahead: the copy out of the file's (pageable) mapping keeps
-        // this thread busy for as long as it takes, which is time the device spends on this slab's inflate
-        static const bool no_prefetch = [] { const char *e = std::getenv("MDX_GBAM_NO_PREFETCH"); return e && *e && *e != '0'; }();
-        if (!timing && !no_prefetch && b1 < g->blocks.size()) {
-            size_t p1 = b1, pbytes = 0;
-            const size_t pin0 = g->blocks[b1].in_off;
-            while (p1 < g->blocks.size() && (p1 == b1 || (g->blocks[p1].in_off - pin0 < want && pbytes + g->blocks[p1].out_size < 0xE0000000ull))) {
-                pbytes += g->blocks[p1].out_size;
-                p1++;
-            }
-            // (all of the slab's own blocks but the host's share of the inflated bytes, as the next call will split them)
-            size_t upto = p1;
-            if (g->host_share > 0.0 && p1 - b1 >= host_min_blocks) {
-                const size_t target = (size_t)((double)pbytes * g->host_share);
-                size_t acc = 0;
-                while (upto > b1 + 1 && acc + g->blocks[upto - 1].out_size <= target) { acc += g->blocks[upto - 1].out_size; upto--; }
-            }
-            const size_t bytes = (upto < g->blocks.size() ? g->blocks[upto].in_off : g->blocks[upto - 1].in_off + g->blocks[upto - 1].in_size) - pin0;
-            const int k = g->pf_used == 0 ? 1 : 0;
-            const size_t cap_want = (size_t)want + ((size_t)16 << 20);
-            if (g->pf_cap[k] < cap_want) {
-                if (g->pf_buf[k]) (void)hipFree(g->pf_buf[k]);
-                g->pf_buf[k] = nullptr; g->pf_cap[k] = 0;
-                pf_buffer_take(g->device, cap_want, g->pf_buf[k], g->pf_cap[k]);
-                if (!g->pf_buf[k]) {
-                    if (hipMalloc(&g->pf_buf[k], cap_want) == hipSuccess) g->pf_cap[k] = cap_want;
-                    else (void)hipGetLastError();
-                }
-            }
-            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) return MDX_ERR_HIP;
-            if (g->pf_cap[k] >= bytes + 64 && bytes > 0 &&
-                hipMemcpyAsync(g->pf_buf[k], g->hs->file->p + pin0, bytes, hipMemcpyHostToDevice, g->copy_stream) == hipSuccess) {
-                g->pf_cur = k; g->pf_in0 = pin0; g->pf_bytes = bytes;
-            }
-        }
-        lap("inflate");
-        // (the CRC beside what follows, on the copy stream; its verdict is looked at before the slab is handed out.
-        // MDX_BAM_TIMING: in line, so that its lap is its own)
-        bool crc_aside = !timing;
-        if (crc_aside) {
-            if (!g->copy_stream && hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) return MDX_ERR_HIP;
-            if (!g->ev_crc && hipEventCreateWithFlags(&g->ev_crc, hipEventDisableTiming) != hipSuccess) return MDX_ERR_HIP;
-            if (!g->pin_bad) g->pin_bad = pin_take();
-            if (!g->pin_bad) crc_aside = false;
-        }
-        if (crc_aside) {
-            *g->pin_bad = no_bad;
-            if (hipEventRecord(g->ev_crc, st) != hipSuccess || hipStreamWaitEvent(g->copy_stream, g->ev_crc, 0) != hipSuccess) return MDX_ERR_HIP;
-            mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nh, d_bad_crc, g->copy_stream);
-            if (hipMemcpyAsync(g->pin_bad, d_bad_crc, 4, hipMemcpyDeviceToHost, g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
-        } else
-        mdx_k_gbam_crc((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const uint32_t *)g->crc.p, g->d_crc_tables, (int)nh, d_bad_crc, st);
-        lap("crc32");
-        // the chains of the segments (every block inflated is one: those ahead of the slab say whether the next slab's
-        // first record can be found without this one), then their check on the host
-        const int n_ref = (int)g->hs->head.ref_names.size();
-        const uint32_t start0 = g->phase_known ? (uint32_t)g->phase : 0xFFFFFFFFu;
-        mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)nba, 0, nullptr, start0,
-                        (uint32_t)unc_bytes, n_ref, (uint4 *)g->info.p, (uint4 *)g->cnt.p, st);
-        lap("scan");
-        std::vector<uint32_t> info(4 * nba), cnt(4 * nba);
-        int bad_crc = no_bad;
-        if (hipMemcpyAsync(info.data(), g->info.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(cnt.data(), g->cnt.p, nba * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            (!crc_aside && hipMemcpyAsync(&bad_crc, d_bad_crc, 4, hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess) {
-            g->error = std::string("GPU decode failed: ") + hipGetErrorString(hipGetLastError());
-            return MDX_ERR_HIP;
-        }
-        for (size_t i = 0; i < nba; i++)
-            if ((int32_t)info[4 * i + 2] == -2) {
-                int stv = 0;
-                (void)hipMemcpy(&stv, (const int *)g->status.p + i, 4, hipMemcpyDeviceToHost);
-                g->error = "corrupt BGZF block " + std::to_string(b0 + i) + " (inflate code " + std::to_string(stv) + ")";
-                return MDX_ERR_ARG;
-            }
-        if (bad_crc != no_bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)bad_crc) + " (CRC32)"; return MDX_ERR_ARG; }
-        // (crc_aside: the same check behind the unpack's launch, below)
-        auto crc_verdict = [&]() -> bool {
-            if (!crc_aside) return true;
-            if (hipStreamSynchronize(g->copy_stream) != hipSuccess) { g->error = "GPU decode failed (CRC32 pass)"; return false; }
-            if (*g->pin_bad != no_bad) { g->error = "corrupt BGZF block " + std::to_string(b0 + (size_t)*g->pin_bad) + " (CRC32)"; return false; }
-            return true;
-        };
-        // The walk: `at` = where the next record starts, known exactly; the segment that holds it must have begun its chain
-        // there — if its guess was another offset it is scanned again from the right one — and says where the chain lands.
-        const size_t slab_end = slab_bytes;
-        std::vector<uint8_t> used(nba, 0);
-        size_t at = 0, seg = 0;
-        bool have = g->phase_known;
-        if (have) at = g->phase;
-        else {
-            // behind a skipped slab: the first guess of this slab stands (its neighbour checks it: next_verified)
-            for (size_t i = 0; i < nb && !have; i++)
-                if (info[4 * i + 2] != 1u) { have = true; at = info[4 * i]; }
-            if (!have) at = slab_end;              // no record starts in this slab
-        }
-        bool grow = false;
-        while (at < slab_end) {
-            while (seg < nba && (size_t)blk[4 * seg + 2] + blk[4 * seg + 3] <= at) seg++;
-            if (seg >= nb) break;
-            if (info[4 * seg] != (uint32_t)at || info[4 * seg + 2] == 1u) {
-                // (rare: a guess that was not the record's start, or a segment whose first record begins behind a long one)
-                const int32_t f = (int32_t)at;
-                if (hipMemcpyAsync((int32_t *)g->forced.p + seg, &f, 4, hipMemcpyHostToDevice, st) != hipSuccess) return MDX_ERR_HIP;
-                mdx_k_gbam_scan((const uint8_t *)g->unc.p, (const uint4 *)g->blk.p, (const int *)g->status.p, (int)seg + 1, (int)seg,
-                                (const int *)g->forced.p, start0, (uint32_t)unc_bytes, n_ref, (uint4 *)g->info.p, (uint4 *)g->cnt.p, st);
-                if (hipMemcpyAsync(&info[4 * seg], (const uint4 *)g->info.p + seg, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipMemcpyAsync(&cnt[4 * seg], (const uint4 *)g->cnt.p + seg, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
-                g->fixups++;
-            }
-            const int32_t stv = (int32_t)info[4 * seg + 2];
-            if (stv == -1) { g->error = "corrupt BAM record in BGZF block " + std::to_string(b0 + seg); return MDX_ERR_ARG; }
-            if (stv == 3) { g->error = "a record that keeps its CIGAR in a CG tag (more than 65 535 operations): the host decoder's"; return MDX_ERR_UNSUPPORTED; }
-            if (stv == 2 && cnt[4 * seg] == 0 && info[4 * seg + 1] == (uint32_t)at && !more_file) {
-                g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG;
-            }
-            used[seg] = 1;
-            const size_t land = info[4 * seg + 1];
-            if (stv == 2 && land < slab_end) {
-                // the chain stopped at a record that starts in the slab and is not complete in what was inflated
-                if (!more_file) { g->error = "truncated BAM file: the last record is incomplete"; return MDX_ERR_ARG; }
-                grow = true;
-                break;
-            }
-            if (land <= at) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
-            at = land;
-        }
-        if (grow) {
-            // (the CRC pass of this attempt reads the bytes the next one writes)
-            if (crc_aside && hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;
-            if (ahead >= ((size_t)1 << 30)) { g->error = "a BAM record of more than a gigabyte"; return MDX_ERR_UNSUPPORTED; }
+            bool grow = false;
+            const int rc = gbam_half_b(g, s, view, d_mtid, d_mpos, &grow, laps, tr);
+            if (rc != MDX_OK) { (void)g->drain(); s.ready = n.ready = false; return rc; }
+            if (!grow) break;
+            if (!g->drain()) return MDX_ERR_HIP;
+            s.ready = false;
             ahead *= 8;
-            continue;
         }
-        // where the next slab's first record starts — and whether a process that has not seen this slab would find it: the
-        // segment ahead that holds it must have guessed exactly that offset (mdx_gbam_skip refuses to go on otherwise)
-        const size_t next_phase = at > slab_end ? at - slab_end : 0;
-        {
-            size_t sg = nb;
-            while (sg < nba && (size_t)blk[4 * sg + 2] + blk[4 * sg + 3] <= at) sg++;
-            if (b1 >= g->blocks.size() && g->whole_file_scanned()) g->next_verified = true;      // nothing follows
-            else {
-                // (the rank behind takes the first segment of its slab that has any guess: a segment in front of the right one —
-                // inside a record that straddles whole blocks — must not have produced one)
-                bool clean = true;
-                for (size_t i = nb; i < sg && i < nba; i++) clean = clean && info[4 * i + 2] == 1u;
-                g->next_verified = clean && sg < nba && info[4 * sg + 2] != 1u && info[4 * sg] == (uint32_t)at;
-            }
-        }
-        // prefix sums over the segments that hold the chain
-        std::vector<uint32_t> pre(4 * nb);
-        unsigned long long tot[3] = {0, 0, 0};
-        for (size_t i = 0; i < nb; i++) {
-            if (!used[i]) { cnt[4 * i] = cnt[4 * i + 1] = cnt[4 * i + 2] = 0; }
-            pre[4 * i] = (uint32_t)tot[0]; pre[4 * i + 1] = (uint32_t)tot[1]; pre[4 * i + 2] = (uint32_t)tot[2]; pre[4 * i + 3] = info[4 * i];
-            tot[0] += cnt[4 * i]; tot[1] += cnt[4 * i + 1]; tot[2] += cnt[4 * i + 2];
-        }
-        if (tot[0] > rec_cap - 2 || tot[1] > cig_cap - 2 || tot[2] > seq_cap - 64 || tot[2] > 0xFFFFFFFFull) { g->error = "corrupt BAM records"; return MDX_ERR_ARG; }
-        if (hipMemcpyAsync(g->pre.p, pre.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(g->cnt.p, cnt.data(), nb * 16, hipMemcpyHostToDevice, st) != hipSuccess) return MDX_ERR_HIP;
-        lap("chains");
-        MdxGbamCols c{};
-        c.flag = (uint16_t *)g->flag.p; c.lib = (uint16_t *)g->lib.p; c.tid = (int32_t *)g->tid.p; c.pos = (int32_t *)g->pos.p;
-        c.tlen = (int32_t *)g->tlen.p; c.mtid = g->want_mate ? (int32_t *)g->mtid.p : nullptr; c.mpos = g->want_mate ? (int32_t *)g->mpos.p : nullptr;
-        c.cigar_off = (uint32_t *)g->cigar_off.p; c.cigar = (uint32_t *)g->cigar.p; c.seq_off = (uint32_t *)g->seq_off.p;
-        c.seq = (uint8_t *)g->seq.p; c.qual = g->want_qual ? (uint8_t *)g->qual.p : nullptr;
-        c.rg_names = (const uint8_t *)g->d_rg_names; c.rg_off = (const uint32_t *)g->d_rg_off; c.lib_of_rg = (const int32_t *)g->d_lib_of_rg;
-        c.n_rg = (int)g->lib_of_rg.size(); c.lib_default = g->lib_default;
-        uint32_t *d_counters = (uint32_t *)((char *)g->small.p + 48);
-        c.minqual = g->want_qual ? g->minqual : 0; c.counters = d_counters;
-        if (c.minqual > 0 && hipMemsetAsync(d_counters, 0, 8, st) != hipSuccess) return MDX_ERR_HIP;
-        c.seq_packed = g->seq_format == MDX_SEQ_4BIT ? 1 : 0;
-        // (the unpack kernel ORs the nibbles of a record into the column: zeroed first, with the dword behind the last base)
-        if (c.seq_packed && hipMemsetAsync(c.seq, 0, (size_t)(tot[2] + 1) / 2 + 8, st) != hipSuccess) return MDX_ERR_HIP;
-        // (--min-basequal: the mask goes into the nibbles — MDX_SEQ_4BITQ, the packed masked kernel's input)
-        c.fold = (c.minqual > 0 && c.seq_packed) ? 1 : 0;
-        mdx_k_gbam_unpack((const uint8_t *)g->unc.p, (const uint4 *)g->pre.p, (const uint4 *)g->cnt.p, (int)nb,
-                          (uint32_t)tot[0], (uint32_t)tot[1], (uint32_t)tot[2], (uint32_t *)g->rec_off.p, c, st);
-        if (hipGetLastError() != hipSuccess) { g->error = "GPU unpack launch failed"; return MDX_ERR_HIP; }
-        if (!crc_verdict()) return g->error.find("corrupt") != std::string::npos ? MDX_ERR_ARG : MDX_ERR_HIP;
-        lap("unpack");
-        view->n_reads = (int64_t)tot[0]; view->n_cigar = (int64_t)tot[1]; view->n_bases = (int64_t)tot[2];
-        view->flag = c.flag; view->lib = c.lib; view->tid = c.tid; view->pos = c.pos; view->tlen = c.tlen;
-        view->cigar_off = c.cigar_off; view->cigar = c.cigar; view->seq_off = c.seq_off; view->seq = c.seq; view->qual = c.qual;
-        view->seq_format = c.fold ? MDX_SEQ_4BITQ : g->seq_format; view->reserved = 0; view->lowq = nullptr; view->libsort = nullptr;
-        if (c.minqual > 0) {
-            uint32_t counters[2] = {0, 0};
-            if (hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return MDX_ERR_HIP;
-            if (counters[0]) g->no_qual_seen = true;
-            // nothing in this slab can be masked: the unmasked kernel (no nibble of the column is a complement)
-            if (counters[1] == 0) { view->qual = nullptr; view->seq_format = g->seq_format; }
-        }
-        if (d_mtid) *d_mtid = c.mtid;
-        if (d_mpos) *d_mpos = c.mpos;
-        g->next_block = b1;
-        g->phase = next_phase;
-        g->phase_known = have;
-        g->slabs_done++;
-        g->view_reads = view->n_reads;
+        g->view_slab = g->cur;
+        g->cur ^= 1;
+        tr.mark("end");
         return MDX_OK;
-        }
     } catch (const std::exception &e) {
         if (g) g->error = std::string("mdx_gbam_next: ") + e.what();
         return MDX_ERR_ARG;
@@ -1742,7 +1912,17 @@ int mdx_gbam_skip(mdx_gbam *g, int64_t chunk_bytes) {
     // says so here, before anybody counts a record twice or not at all.
     try {
         if (!g) return MDX_ERR_ARG;
-        const size_t want = slab_want(g, chunk_bytes);
+        // (a handle that steps over slabs prepares none ahead of time: the slab behind the one in hand is another rank's; what
+        // the first call has prepared is dropped)
+        if (!g->no_ahead) {
+            g->no_ahead = true;
+            if (g->slab[0].ready || g->slab[1].ready) {
+                (void)hipSetDevice(g->device);
+                if (!g->drain()) return MDX_ERR_HIP;
+                g->slab[0].ready = g->slab[1].ready = false;
+            }
+        }
+        const size_t want = slab_want(g, g->next_block, chunk_bytes);
         if (!g->scan_to((g->next_block < g->blocks.size() ? g->blocks[g->next_block].in_off : g->scanned) + want + 65536)) return MDX_ERR_ARG;
         if (g->next_block >= g->blocks.size()) return MDX_OK;
         if (g->phase_known && !g->next_verified) {
@@ -1770,7 +1950,7 @@ int mdx_gbam_view_flags(mdx_gbam *g, uint16_t *flags, int64_t n) {
     if (!g || n < 0 || n != g->view_reads || (n > 0 && !flags)) return MDX_ERR_ARG;
     if (n == 0) return MDX_OK;
     if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
-    if (hipMemcpyAsync(flags, g->flag.p, (size_t)n * 2, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+    if (hipMemcpyAsync(flags, g->slab[g->view_slab].flag.p, (size_t)n * 2, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
         hipStreamSynchronize(g->stream) != hipSuccess) { g->error = "copy of the flag column failed"; return MDX_ERR_HIP; }
     return MDX_OK;
 }
@@ -1780,7 +1960,7 @@ int mdx_gbam_view_set_flags(mdx_gbam *g, const uint16_t *flags, int64_t n) {
     if (n == 0) return MDX_OK;
     if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
     // (synchronous: the caller's buffer is free again when the call returns)
-    if (hipMemcpyAsync(g->flag.p, flags, (size_t)n * 2, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+    if (hipMemcpyAsync(g->slab[g->view_slab].flag.p, flags, (size_t)n * 2, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
         hipStreamSynchronize(g->stream) != hipSuccess) { g->error = "copy of the flag column failed"; return MDX_ERR_HIP; }
     return MDX_OK;
 }
@@ -1817,20 +1997,27 @@ void mdx_gbam_close(mdx_gbam *g) {
         t_last = now;
     };
     (void)hipSetDevice(g->device);
-    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    (void)g->drain();
     lap("sync");
-    // (arena, CRC tables, copy stream and the host's buffer stay with the context / the process for the next file: the
+    // (arenas, CRC tables, copy stream and the host's buffer stay with the context / the process for the next file: the
     // context must still be alive — it owns the stream this handle works on)
     host_buffer_give(g->hbuf, g->hbuf_cap);
-    if (g->ev_infl0) (void)hipEventDestroy(g->ev_infl0);
-    if (g->ev_crc) (void)hipEventDestroy(g->ev_crc);
+    for (auto &sl : g->slab) {
+        if (sl.ev_infl0) (void)hipEventDestroy(sl.ev_infl0);
+        if (sl.ev_infl) (void)hipEventDestroy(sl.ev_infl);
+    }
+    if (g->ev_free) (void)hipEventDestroy(g->ev_free);
+    if (g->infl_stream) (void)hipStreamDestroy(g->infl_stream);
     pin_give(g->pin_bad);
-    // (drained before it is given away: a context that already holds a copy stream — two handles on one context — destroys this one)
-    if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
-    mdx_ctx_scratch_give(g->ctx, g->arena.p, g->arena.cap, g->d_crc_tables, g->copy_stream, g->ev_infl);
+    // (the larger arena to the context, the other one to the process's spare buffers)
+    {
+        const int big = g->slab[1].arena.cap > g->slab[0].arena.cap ? 1 : 0;
+        mdx_ctx_scratch_give(g->ctx, g->slab[big].arena.p, g->slab[big].arena.cap, g->d_crc_tables, g->copy_stream, nullptr);
+        arena_give(g->device, g->slab[big ^ 1].arena.p, g->slab[big ^ 1].arena.cap);
+    }
     g->copy_stream = nullptr;
     rg_buffer_give(g->device, g->d_rg, g->d_rg_cap);
-    for (int k = 0; k < 2; k++) pf_buffer_give(g->device, g->pf_buf[k], g->pf_cap[k]);
+    for (int k = 0; k < 3; k++) pf_buffer_give(g->device, g->pf_buf[k], g->pf_cap[k]);
     lap("device");
     // (unmapping the file — a few hundred thousand touched pages — is 3-4 ms of an 8 M-record file's 63; done behind the
     // caller's back it holds the address space's lock against the next file's mmap and page faults, which then wait as long)
@@ -1848,9 +2035,21 @@ int mdx_warm(int32_t device, int64_t pinned_bytes) {
     // inflating threads, and the pinned buffer the host's share of a slab is inflated into (a few hundred megabytes: tens of
     // milliseconds to fault in and map) — on a thread of the caller's choice, beside whatever else the start of a run does
     try {
+        // (MDX_INIT_TRACE=1: what each step took, on stderr)
+        const bool trace = std::getenv("MDX_INIT_TRACE") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "mdx_warm %-16s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) { (void)hipGetLastError(); return MDX_ERR_HIP; }
+        lap("context");
         if (mdx_k_gbam_prepare() != hipSuccess) { (void)hipGetLastError(); return MDX_ERR_HIP; }
+        lap("decode kernels");
         (void)host_pool();
+        lap("pool");
         if (pinned_bytes > 0) {
             uint8_t *p = nullptr;
             size_t cap = 0;
@@ -1863,6 +2062,7 @@ int mdx_warm(int32_t device, int64_t pinned_bytes) {
             }
             host_buffer_give(p, cap);
         }
+        lap("pinned buffer");
         return MDX_OK;
     } catch (...) {
         return MDX_ERR_ARG;

@@ -5,6 +5,8 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -254,6 +256,15 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
     mdx_ctx *c = new (std::nothrow) mdx_ctx();
     if (!c) return MDX_ERR_ARG;
     c->cfg = *cfg;
+    // (MDX_INIT_TRACE=1: what each step took, on stderr)
+    const bool trace = getenv("MDX_INIT_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mdx_create %-14s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
         delete c;
@@ -266,6 +277,7 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    lap("context, stream");
 
     int lgd_lds = cfg->lgd_max < kLgdLds ? cfg->lgd_max : kLgdLds;
     // two blocks per CU need half of the LDS each: the short-fragment histogram gives way first (lengths beyond it
@@ -291,6 +303,7 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
         HIP_TRY(c, mdx_k_prepare(c->lds_bytes));
         // (the packed kernel counts one library per launch)
         HIP_TRY(c, mdx_k_prepare_packed(mdx_k_pk_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds))));
+        lap("kernels");
         HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * gdims.w_total * 4));
     } else {
         c->mode = MDX_MODE_GLOBAL;  // tables do not fit the LDS: global-atomic fallback
@@ -304,6 +317,7 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
     int rc = zero_accumulators(c);
     if (rc != MDX_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    lap("accumulators");
     return MDX_OK;
 }
 

@@ -342,14 +342,12 @@ def _device_path_applies(options, world=1):
 
 
 def _slab_bytes(options, world):
-    """Compressed bytes per slab of the device decode path.  (A slab of compressed bytes inflates to about four times its
-    size; at the default --chunk-mb a single rank takes slabs four times the size — the file in a few large, equal slabs: a
-    1.15 GB file 139 -> 151 M reads/s from 256 MiB to 1 GiB slabs —, several ranks keep the smaller unit they deal out among
-    themselves.)"""
+    """Compressed bytes per slab of the device decode path: a quarter of --chunk-mb (a slab of compressed bytes inflates to
+    about four times its size) — 256 MiB at the default.  (Rounds 4-5 gave a single rank slabs of 1 GiB, for their fixed
+    costs; since the slabs run as a pipeline of two — the device goes from one slab's inflate straight into the next one's —
+    more, smaller slabs fill it better, and the pinned buffer of the host's share is a quarter of the size.)"""
     import os
     slab = max(1 << 20, int(options.chunk_mb * (1 << 20)) // 4) if options.chunk_mb else 256 << 20
-    if world == 1 and options.chunk_mb == 1024:
-        slab = 1 << 30
     if os.environ.get("MDX_GBAM_SLAB_BYTES"):      # (tests: several slabs out of a small file whatever --chunk-mb says)
         slab = max(1 << 16, int(os.environ["MDX_GBAM_SLAB_BYTES"]))
     return slab
@@ -372,16 +370,18 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks, stages):
         readgroups = [(rg, libraries.index(lib)) for rg, lib in reader._readgroups.items()]
         lib_default = None
     engine = DamageEngine(libraries, options.length, options.around, options.minqual, device=ranks.device)
+    stages.mark("engine")
     carry = None
     try:
         engine.set_reference(ref)
+        stages.mark("reference resident")
         warned_about_quals = False
         error = None
         slab = _slab_bytes(options, ranks.world)
         warm = getattr(options, "warm_thread", None)
         if warm is not None:
             warm.join()         # (the pinned buffer it leaves behind is the one the first slab takes)
-        stages.mark("engine and reference")
+        stages.mark("warm-up joined")
         with GpuBamStream(engine, options.filename, readgroups=readgroups, lib_default=lib_default,
                           chunk_bytes=slab, want_qual=options.minqual != 0, min_basequal=options.minqual) as stream:
             # (several ranks: rank r decodes the slabs r, r + W, ... and steps over the others)
@@ -573,7 +573,17 @@ def main(argv):
 
 
 def entry_point():
-    return main(sys.argv[1:])
+    """The command's exit: the tables are on disk and the log is closed when ``main`` returns, and what is left — the
+    interpreter's and the HIP runtime's teardown, unpinning and unmapping a few gigabytes — is a fifth of a second the
+    operating system does faster for a process that simply leaves (MDX_NO_FAST_EXIT=1: the ordinary way out)."""
+    import os
+    rc = main(sys.argv[1:])
+    if os.environ.get("MDX_NO_FAST_EXIT"):
+        return rc
+    logging.shutdown()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(int(rc or 0))
 
 
 if __name__ == "__main__":
