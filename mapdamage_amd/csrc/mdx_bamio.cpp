@@ -1516,7 +1516,9 @@ static int gbam_half_a(mdx_gbam *g, mdx_gbam::Slab &s, size_t b0, int64_t chunk_
         std::atomic<int> bad_block{-1};
         std::vector<int32_t> host_status(nt);
         const MappedFile &file = *g->hs->file;
-        const Block *const bl = &g->blocks[b0 + nh];
+        // (a copy: the walk over the next slab's headers, below, appends to g->blocks while the pool reads these)
+        const std::vector<Block> host_blocks(g->blocks.begin() + (long)(b0 + nh), g->blocks.begin() + (long)(b0 + nba));
+        const Block *const bl = host_blocks.data();
         uint8_t *const hb = g->hbuf;
         // (the pinned buffer is the previous slab's too: its copies must have left it)
         if (hipStreamSynchronize(g->copy_stream) != hipSuccess) return MDX_ERR_HIP;

@@ -493,7 +493,7 @@ def main(argv):
         return subprocess.call(cmd, env=env)
     ranks = _Ranks(options)
     first = ranks.rank == 0
-    if options.gpu_decode and not options.rescale_only and _device_path_applies(options, ranks.world):
+    if options.gpu_decode and not options.rescale_only and _device_path_applies(options, ranks.world) and not os.environ.get("MDX_NO_WARM"):
         # the device's context, the decode kernels and the pinned buffer of the host's share (about a fifth of a slab's
         # inflated bytes, which are four to five times its compressed ones), beside the header, index and FASTA reads
         import threading
