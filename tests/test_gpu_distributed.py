@@ -76,12 +76,24 @@ def test_bench_line_with_rccl_initialised(tmp_path):
     assert line["n_gpus"] == 1 and line["parity"].startswith("bit-exact")
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     sec = line["secondary"]
-    assert set(sec) == {"config2", "config4", "config5", "minqual", "nlib8", "file_to_tables", "config3_genome3g"}
+    assert set(sec) == {"config2", "config4", "config5", "minqual", "nlib8", "file_to_tables", "config3_genome3g", "file_to_tables_50m",
+                        "cli_wall"}
     assert sec["minqual"]["q20_kernel_ms"] > 0 and sec["minqual"]["q0_kernel_ms"] > 0
     # (eight libraries: one launch of the packed kernel per call, the resident batch brings its copy ordered by library)
     assert sec["nlib8"]["packed_launches_per_call"] == 1 and sec["nlib8"]["sorts_inside_the_launches"] == 0
-    flat = [v for k, v in sec.items() if k != "config3_genome3g"] + list(sec["config3_genome3g"].values())
+    flat = [v for k, v in sec.items() if k not in ("config3_genome3g", "cli_wall")] + list(sec["config3_genome3g"].values())
     assert all(v["parity"].startswith("bit-exact") for v in flat)
+    # the command line as a cold process, over the run's own records as a BAM file and over the tiled genome as a FASTA file:
+    # the device decode path, the three text files byte-identical to the oracle's tables
+    assert set(sec["cli_wall"]) == {"genome10mb_50m", "genome3g_8m"}
+    for entry in sec["cli_wall"].values():
+        assert entry["wall_s"] > 0 and len(entry["runs"]) == 2
+        for run in entry["runs"]:
+            assert run["rc"] == 0 and run["decode_path"] == "device" and run["parity"].startswith("misincorporation.txt, dnacomp.txt")
+            assert run["stages_s"] and "FASTA file -> resident reference" in run["stages_s"]
+    # ... and the line's last key says all of it in a few hundred bytes
+    assert list(line)[-1] == "summary" and line["summary"]["parity"] == "bit-exact everywhere"
+    assert len(json.dumps(line["summary"])) < 1500 and line["summary"]["cli_wall_s"]["genome10mb_50m"] == sec["cli_wall"]["genome10mb_50m"]["wall_s"]
     assert sec["file_to_tables"]["device_decode"]["reads_per_s"] > 0 and sec["file_to_tables"]["host_decode"]["reads_per_s"] > 0
 
 
