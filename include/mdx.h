@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
+#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -44,9 +44,16 @@ extern "C" {
  * kernel then skips the record's quality window loads.  The caller vouches for it (mdx_bam_qmin gives the lowest
  * quality of each record; mapdamage_amd.batch.mark_unmaskable sets the bit); without the bit nothing changes.
  * SAM defines FLAG bits 0..11 only, but a file may carry anything in its 16 bits: the decoders of this library
- * (mdx_bam_*, mdx_gbam_*, the SAM text parser) clear bit 15 of what they read, and a caller that packs its own flag
+ * (mdx_bam_*, mdx_gbam_*, the SAM text parser) clear bits 14 and 15 (see MDX_FLAG_HAS_QUAL) of what they read, and a caller that packs its own flag
  * column must do the same unless it vouches for the record. */
 #define MDX_FLAG_QUAL_ABOVE_MIN 0x8000
+/* A second hint, bit 14 (round 6): the record HAS base qualities — it holds at least one base and the first byte of its
+ * quality string is not 0xFF (what `not read.qual` tests at main.py:185 and rescale.py:306).  The rescaling kernels then do
+ * not fetch that byte to route the record (a scattered load per record: a tenth of the fused launch's time when no second
+ * quality column is written, mdx_tabulate_rescale_patches_device); without the bit they look.  Set by the library where it
+ * sees the qualities anyway: mdx_batch_upload (a batch with a quality column) and the device decoder; the decoders clear
+ * bits 14 and 15 of what a file carries, and a caller that packs its own flag column does the same unless it vouches. */
+#define MDX_FLAG_HAS_QUAL 0x4000
 
 #define MDX_N_MIS_COLS 25         /* mapdamage/seq.py:6-30 without the derived "Total" */
 
@@ -286,6 +293,25 @@ int mdx_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *
                        uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
 int mdx_tabulate_rescale_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
                                 uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status);
+/* The same two calls with the rescaled qualities as a LIST instead of a second column (round 6): _rescale_qual_read changes a
+ * few quality bytes of a read — the C>T / G>A columns near its ends (rescale.py:228-246) — and a caller that writes the
+ * records back (rescale.py:266-273, 344) needs those bytes, not a copy of the hundred it leaves alone.  One entry per quality
+ * byte whose value changes: index of the byte in the batch's quality column | new Phred << 32, in no particular order.  The
+ * list comes in n_parts parts (a power of two; 256 and more for a launch of millions of records: thousands of wavefronts
+ * appending to one list queue at one address): part p = d_patch[p * patch_cap ..], d_n_patch[p] (device; zeroed by the call)
+ * its number of entries — which may pass patch_cap: the entries beyond are lost and the caller repeats the call with longer
+ * parts (n_reads x (len5p + len3p) entries in all always suffice; the parts fill evenly).  Nothing else is written: of a
+ * record that is written back unchanged no quality byte is read but its first (rescale.py:306).  mr_raw, status, the
+ * summary, errors: as above.  mdx_rescale_expand_device: d_qual_out = the batch's quality column with a list applied (for
+ * callers that want the column after all, and the tests; d_qual_out may be the column itself). */
+int mdx_rescale_patches_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
+                               uint64_t *d_patch, int64_t patch_cap, int32_t n_parts, uint64_t *d_n_patch, double *d_mr_raw,
+                               uint8_t *d_status);
+int mdx_tabulate_rescale_patches_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const int32_t *d_mtid, const int32_t *d_mpos,
+                                        uint64_t *d_patch, int64_t patch_cap, int32_t n_parts, uint64_t *d_n_patch, double *d_mr_raw,
+                                        uint8_t *d_status);
+int mdx_rescale_expand_device(mdx_ctx *ctx, const mdx_batch *dev_batch, const uint64_t *d_patch, int64_t patch_cap, int32_t n_parts,
+                              const uint64_t *d_n_patch, uint8_t *d_qual_out);
 int mdx_rescale_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms);
 /* Calls of mdx_tabulate_rescale_device so far that ran as the fused launch (the others: two kernels). */
 int64_t mdx_fused_launches(const mdx_ctx *ctx);

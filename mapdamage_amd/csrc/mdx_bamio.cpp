@@ -561,7 +561,7 @@ int unpack_records(mdx_bam *b, const uint8_t *data, size_t off, size_t total, in
         const size_t bs = (size_t)rdi32(r - 4);
         const uint32_t l_name = r[8], n_cig = rd16(r + 12);
         const int32_t l_seq = rdi32(r + 16);
-        b->tid[i] = rdi32(r); b->pos[i] = rdi32(r + 4); b->flag[i] = (uint16_t)(rd16(r + 14) & 0x7FFFu);   // bit 15: MDX_FLAG_QUAL_ABOVE_MIN, a hint, never the file's
+        b->tid[i] = rdi32(r); b->pos[i] = rdi32(r + 4); b->flag[i] = (uint16_t)(rd16(r + 14) & 0x3FFFu);   // bits 14, 15: MDX_FLAG_HAS_QUAL / _QUAL_ABOVE_MIN, hints, never the file's
         b->mtid[i] = rdi32(r + 20); b->mpos[i] = rdi32(r + 24); b->tlen[i] = rdi32(r + 28);
         const uint8_t *p = r + 32;
         if (l_name) std::memcpy(&b->qnames[noff[i]], p, l_name - 1);

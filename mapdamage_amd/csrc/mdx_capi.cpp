@@ -533,6 +533,12 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
         *col.dst = p;
         HIP_TRY(c, hipMemcpyAsync(p, col.src, col.bytes, hipMemcpyHostToDevice, c->stream));
     }
+    // a batch with qualities: the records that have them say so in their flags (MDX_FLAG_HAS_QUAL: the rescaling kernels then
+    // route a record without a look at its first quality byte)
+    if (dv->qual && n > 0) {
+        mdx_k_mark_has_qual(const_cast<uint16_t *>(dv->flag), dv->seq_off, dv->qual, n, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     // --min-basequal and a 4-bit SEQ column: the mask goes into the resident column itself (MDX_SEQ_4BITQ, include/mdx.h) —
     // the packed masked kernel then reads no quality, and nothing is folded in front of the launches
     // (MDX_NO_BATCH_LOWQ=1 in the environment: not — every launch folds into a scratch column, for A/B runs)
@@ -1223,8 +1229,13 @@ int mdx_rescale_summary(mdx_ctx *c, uint64_t *words) {
     return MDX_OK;
 }
 
-int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos, uint8_t *d_qual_out,
-                       double *d_mr_raw, uint8_t *d_status) {
+// where the rescaled bytes go: a second quality column (qual_out), or — patch mode — a list of the bytes that change
+struct RsOut { uint8_t *qual_out; uint64_t *patch; int64_t patch_cap; int32_t parts; uint64_t *n_patch; };
+static bool parts_ok(int32_t n) { return n >= 1 && n <= 65535 && (n & (n - 1)) == 0; }
+
+static int rescale_device_impl(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos, const RsOut &o,
+                               double *d_mr_raw, uint8_t *d_status, bool zero_count) {
+    uint8_t *const d_qual_out = o.qual_out;
     int rc = check_batch(c, b_in);
     if (rc != MDX_OK) return rc;
     // (the rescale kernels read ASCII)
@@ -1233,7 +1244,8 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid,
     if (rc != MDX_OK) return rc;
     const mdx_batch *b = &b_ascii;
     if (!c->d_ref || !c->d_lut) return fail(c, MDX_ERR_STATE, "set_reference and rescale_set_model first");
-    if (!b->qual || !d_mtid || !d_mpos || !d_qual_out || !d_mr_raw || !d_status) return fail(c, MDX_ERR_ARG, "null column");
+    if (!b->qual || !d_mtid || !d_mpos || !d_mr_raw || !d_status) return fail(c, MDX_ERR_ARG, "null column");
+    if (o.patch ? (!o.n_patch || o.patch_cap < 0 || !parts_ok(o.parts) || d_qual_out) : !d_qual_out) return fail(c, MDX_ERR_ARG, "null column");
     // (the kernels read the old qualities of a record after they have stored its new ones; offsets up to a few hundred
     //  bytes past the column are formed in 32 bits)
     if (d_qual_out == b->qual) return fail(c, MDX_ERR_ARG, "qual_out must not be the batch's own quality column");
@@ -1246,6 +1258,8 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid,
     a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
     a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p; a.key0_plain = c->key0_plain ? 1 : 0;
     a.qual_out = d_qual_out; a.mr_raw = d_mr_raw; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
+    a.patch = (unsigned long long *)o.patch; a.n_patch = (unsigned long long *)o.n_patch; a.patch_cap = o.patch_cap; a.patch_parts = o.parts;
+    if (o.patch && zero_count) HIP_TRY(c, hipMemsetAsync(o.n_patch, 0, (size_t)o.parts * 8, c->stream));
     HIP_TRY(c, c->rs_part.reserve(mdx_k_rescale_part_bytes(c->len5p, c->len3p, c->n_cu)));
     a.subs_part = (uint32_t *)c->rs_part.p;
     int64_t list_waves = 0, list_cap = 0;
@@ -1264,6 +1278,29 @@ int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid,
         (void)hipEventRecord(e1, c->stream);
         c->rs_events.emplace_back(e0, e1);
     }
+    HIP_TRY(c, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos, uint8_t *d_qual_out,
+                       double *d_mr_raw, uint8_t *d_status) {
+    if (!d_qual_out) return fail(c, MDX_ERR_ARG, "null column");
+    return rescale_device_impl(c, b_in, d_mtid, d_mpos, RsOut{d_qual_out, nullptr, 0, 0, nullptr}, d_mr_raw, d_status, true);
+}
+
+int mdx_rescale_patches_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos, uint64_t *d_patch,
+                               int64_t patch_cap, int32_t n_parts, uint64_t *d_n_patch, double *d_mr_raw, uint8_t *d_status) {
+    if (!d_patch || !d_n_patch || patch_cap < 0 || !parts_ok(n_parts)) return fail(c, MDX_ERR_ARG, "patch list: null, or n_parts not a power of two");
+    return rescale_device_impl(c, b_in, d_mtid, d_mpos, RsOut{nullptr, d_patch, patch_cap, n_parts, d_n_patch}, d_mr_raw, d_status, true);
+}
+
+int mdx_rescale_expand_device(mdx_ctx *c, const mdx_batch *b, const uint64_t *d_patch, int64_t patch_cap, int32_t n_parts,
+                              const uint64_t *d_n_patch, uint8_t *d_qual_out) {
+    int rc = check_batch(c, b);
+    if (rc != MDX_OK) return rc;
+    if (!b->qual || !d_patch || !d_n_patch || !d_qual_out || patch_cap < 0 || !parts_ok(n_parts)) return fail(c, MDX_ERR_ARG, "null column");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    mdx_k_rescale_expand(b->qual, d_qual_out, b->n_bases, (const unsigned long long *)d_patch, (const unsigned long long *)d_n_patch, patch_cap, n_parts, c->stream);
     HIP_TRY(c, hipGetLastError());
     return MDX_OK;
 }
@@ -1293,15 +1330,18 @@ static bool fuse_applies(const mdx_ctx *c, const mdx_batch *b, bool packed_form 
     return b->n_reads > 0 && b->n_bases <= 0xFFFF0000LL;
 }
 
-int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos,
-                                uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status) {
+static int tabulate_rescale_impl(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos,
+                                 const RsOut &o, double *d_mr_raw, uint8_t *d_status) {
+    uint8_t *const d_qual_out = o.qual_out;
     // one pass over one resident batch: the tables and, from the same columns in HBM, the rescaled qualities
     int rc = check_batch(c, b_in);
     if (rc != MDX_OK) return rc;
     // (the fused kernel copies the quality column in 16-byte units: both columns at the same 16-byte phase — true of any two
-    // device allocations)
-    const bool args_ok = c->d_ref && c->d_lut && b_in->qual && d_mtid && d_mpos && d_qual_out && d_mr_raw && d_status &&
-                         d_qual_out != b_in->qual && (((uintptr_t)d_qual_out ^ (uintptr_t)b_in->qual) & 15) == 0;
+    // device allocations; patch mode: no second column)
+    const bool args_ok = c->d_ref && c->d_lut && b_in->qual && d_mtid && d_mpos && d_mr_raw && d_status &&
+                         (o.patch ? (o.n_patch != nullptr && !d_qual_out && parts_ok(o.parts))
+                                  : (d_qual_out && d_qual_out != b_in->qual && (((uintptr_t)d_qual_out ^ (uintptr_t)b_in->qual) & 15) == 0));
+    if (o.patch && o.n_patch && parts_ok(o.parts)) HIP_TRY(c, hipMemsetAsync(o.n_patch, 0, (size_t)o.parts * 8, c->stream));
     // A 4-bit SEQ column goes through the packed fused kernel as it is (one library); the records that kernel lists for the
     // rescale kernels, which read ASCII, get their stretches of an ASCII scratch column written behind it (mdx_k_unpack_listed)
     const bool pkf = args_ok && b_in->seq_format == MDX_SEQ_4BIT && b_in->n_bases > 0 && fuse_applies(c, b_in, true);
@@ -1319,7 +1359,7 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     if (!pkf && (!args_ok || !fuse_applies(c, b))) {
         rc = mdx_tabulate_device(c, b_in);
         if (rc != MDX_OK) return rc;
-        return mdx_rescale_device(c, b, d_mtid, d_mpos, d_qual_out, d_mr_raw, d_status);
+        return rescale_device_impl(c, b, d_mtid, d_mpos, o, d_mr_raw, d_status, false);
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // The tabulation kernel rescales the records of its own tile loop as it counts them ([S] M [S] of at most 2 L
@@ -1329,6 +1369,7 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     const int npos = 1 + c->len5p + c->len3p, n_cnt = 752 + 2 * npos * 94;
     MdxFuse f{};
     f.mtid = d_mtid; f.mpos = d_mpos; f.qual_out = d_qual_out; f.mr_raw = d_mr_raw; f.status = d_status;
+    f.patch = (unsigned long long *)o.patch; f.n_patch = (unsigned long long *)o.n_patch; f.patch_cap = o.patch_cap; f.patch_parts = o.parts;
     f.lut = c->d_lut; f.term = c->d_term; f.len5p = c->len5p; f.len3p = c->len3p;
     HIP_TRY(c, c->rs_part.reserve(mdx_k_rescale_part_bytes(c->len5p, c->len3p, c->n_cu) + (size_t)c->n_cu * n_cnt * 4));
     f.subs_part = (uint32_t *)c->rs_part.p;
@@ -1341,6 +1382,7 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     a.ref = c->d_ref + 256; a.contig_off = c->d_contig_off; a.n_contig = c->n_contig;
     a.lut = c->d_lut; a.term = c->d_term; a.len5p = c->len5p; a.len3p = c->len3p; a.key0_plain = 1;
     a.qual_out = d_qual_out; a.mr_raw = d_mr_raw; a.status = d_status; a.err = c->d_err; a.subs = c->d_subs;
+    a.patch = (unsigned long long *)o.patch; a.n_patch = (unsigned long long *)o.n_patch; a.patch_cap = o.patch_cap; a.patch_parts = o.parts;
     a.subs_part = (uint32_t *)c->rs_part.p;
     const int64_t n_in = (int64_t)fgrid * (mdx_k_fuse_block_threads() / 64);
     a.in_count = (const uint32_t *)c->rs_in.p;
@@ -1367,6 +1409,17 @@ int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t
     }
     HIP_TRY(c, hipGetLastError());
     return MDX_OK;
+}
+
+int mdx_tabulate_rescale_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos,
+                                uint8_t *d_qual_out, double *d_mr_raw, uint8_t *d_status) {
+    return tabulate_rescale_impl(c, b_in, d_mtid, d_mpos, RsOut{d_qual_out, nullptr, 0, 0, nullptr}, d_mr_raw, d_status);
+}
+
+int mdx_tabulate_rescale_patches_device(mdx_ctx *c, const mdx_batch *b_in, const int32_t *d_mtid, const int32_t *d_mpos, uint64_t *d_patch,
+                                        int64_t patch_cap, int32_t n_parts, uint64_t *d_n_patch, double *d_mr_raw, uint8_t *d_status) {
+    if (!d_patch || !d_n_patch || patch_cap < 0 || !parts_ok(n_parts)) return fail(c, MDX_ERR_ARG, "patch list: null, or n_parts not a power of two");
+    return tabulate_rescale_impl(c, b_in, d_mtid, d_mpos, RsOut{nullptr, d_patch, patch_cap, n_parts, d_n_patch}, d_mr_raw, d_status);
 }
 
 int mdx_rescale_host(mdx_ctx *c, const mdx_batch *h, const int32_t *mtid, const int32_t *mpos, uint8_t *qual_out,

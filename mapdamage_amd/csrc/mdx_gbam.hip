@@ -181,7 +181,7 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
     const u32 bs = g32(p - 4);
     const u32 l_name = p[8], n_cig = g16(p + 12), l_seq = g32(p + 16);
     if (j == 0) {
-        c.flag[r] = (uint16_t)(g16(p + 14) & 0x7FFFu);     // bit 15 is the hint MDX_FLAG_QUAL_ABOVE_MIN, never the file's
+        c.flag[r] = (uint16_t)(g16(p + 14) & 0x3FFFu);     // bits 14 and 15 are the hints MDX_FLAG_HAS_QUAL / _QUAL_ABOVE_MIN, never the file's
         c.tid[r] = (int32_t)g32(p); c.pos[r] = (int32_t)g32(p + 4);
         c.tlen[r] = (int32_t)g32(p + 28);
         if (c.mtid) { c.mtid[r] = (int32_t)g32(p + 20); c.mpos[r] = (int32_t)g32(p + 24); }
@@ -268,11 +268,14 @@ __global__ void gbam_unpack_kernel(const u8 *__restrict__ unc, const u32 *__rest
             for (int o = 1; o < 8; o <<= 1) { const u32 other = (u32)__shfl_xor((int)qmin, o); qmin = other < qmin ? other : qmin; }
     }
     if (j != 0) return;
+    // (MDX_FLAG_HAS_QUAL: the rescaling kernels need not look at the record's first quality to route it, rescale.py:306)
+    const u32 hasq = (c.qual && l_seq > 0u && q[0] != 0xFFu) ? 0x4000u : 0u;
+    if (hasq) c.flag[r] = (uint16_t)((g16(p + 14) & 0x3FFFu) | hasq);
     if (c.qual && c.minqual > 0) {
         // --min-basequal: a record none of whose qualities is below the threshold cannot be masked (flag bit
         // MDX_FLAG_QUAL_ABOVE_MIN: the tabulation kernel skips its quality windows); a counted record without
         // qualities is what main.py:185-192 warns about
-        const u32 fl = g16(p + 14) & 0x7FFFu;
+        const u32 fl = (g16(p + 14) & 0x3FFFu) | hasq;
         if (qmin >= (u32)c.minqual) c.flag[r] = (uint16_t)(fl | 0x8000u);
         // (only whether there is one matters: a store where the word is still clear — eight million atomics on one address
         // were 10 ms of the 11.6 ms this kernel took on a file with qualities)

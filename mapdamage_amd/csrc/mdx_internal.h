@@ -147,6 +147,15 @@ struct MdxFuse {
     int len5p, len3p;
     uint32_t *subs_part;        // [grid][752 + 2 npos 94]: the block's own summary row (zeroed by the block itself)
     uint32_t *gen_list, *gen_count;
+    // patch mode (patch not null; qual_out is then null): the quality bytes that change are appended to a list instead of
+    // being stored into a copy of the column — entry = index of the byte in the quality column | new Phred << 32 — and
+    // *n_patch counts them (it may pass patch_cap: the entries beyond are dropped, the caller sees the count)
+    // The list comes in patch_parts parts (a power of two), patch_cap entries and a counter each — a thousand wavefronts
+    // appending to ONE list queue at one address of the L2 (2.7 M appends of a 25 M-record launch: 3 ms): a block appends
+    // to part blockIdx & (patch_parts - 1).
+    unsigned long long *patch, *n_patch;
+    long long patch_cap;
+    int patch_parts;
     int qcap;                   // events of a wavefront's queue (mdx_k_fuse_qcap)
     int tcb_off;                // word offset in the LDS of the second TC table (the fused records' own), then 4 words of
                                 // reference-base counts, the lookup table and the terms (mdx_k_fuse_lds_bytes)
@@ -269,6 +278,8 @@ void mdx_k_encode_ref(const uint8_t *d_ascii, uint8_t *d_codes, int64_t n, hipSt
 void mdx_k_encode_ref4(const uint8_t *d_codes, uint8_t *d_ref4, int64_t n, hipStream_t s);
 // SEQ columns between the two forms of mdx_batch::seq (n bases; the packed column holds (n + 1) / 2 bytes)
 void mdx_k_pack_seq(const uint8_t *d_ascii, uint8_t *d_packed, int64_t n, hipStream_t s);
+// MDX_FLAG_HAS_QUAL set on the records of a resident batch whose first quality byte is not 0xFF
+void mdx_k_mark_has_qual(uint16_t *d_flag, const uint32_t *d_seq_off, const uint8_t *d_qual, int64_t n, hipStream_t s);
 void mdx_k_unpack_seq(const uint8_t *d_packed, uint8_t *d_ascii, int64_t n, hipStream_t s);
 // the packed kernel's own block size and LDS image (queue offset, bytes; the staging offset is mdx_k_stage_off)
 int mdx_k_pk_block_threads();
@@ -340,6 +351,9 @@ struct MdxRescaleArgs {
     int lds_tables;          // set by mdx_k_rescale: lut, term and the summary counters live in the LDS
     uint8_t *qual_out;       // becomes a copy of qual (by rescale_kernel, tile by tile, or by a device copy in front of the walk
                              // kernel when that runs alone); the kernels then store the rescaled bytes only
+    unsigned long long *patch, *n_patch;   // patch mode, as in MdxFuse (qual_out null: nothing is copied, nothing stored)
+    long long patch_cap;
+    int patch_parts;
     double *mr_raw;
     uint8_t *status;
     unsigned long long *err;
@@ -363,6 +377,9 @@ struct MdxRescaleArgs {
     int copy_qual;              // set by mdx_k_rescale: rescale_kernel copies qual to qual_out tile by tile
 };
 void mdx_k_rescale(const MdxRescaleArgs &a, int n_cu, hipStream_t s);
+// qual_out = qual with the n_patch entries of a patch list applied (qual_out may be qual: in place)
+void mdx_k_rescale_expand(const uint8_t *qual, uint8_t *qual_out, int64_t n_bases, const unsigned long long *patch,
+                          const unsigned long long *n_patch, long long patch_cap, int patch_parts, hipStream_t s);
 // behind the fused kernel: rescale_kernel over a.in_list, the walk kernel over what that leaves, and the reduction of the
 // summary rows of all three kernels (the fused kernel's `fused_rows` rows come first in subs_part)
 void mdx_k_rescale_lists_pass(const MdxRescaleArgs &a, int fused_rows, int n_cu, hipStream_t s);

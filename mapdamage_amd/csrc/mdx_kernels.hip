@@ -341,6 +341,26 @@ __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_rea
 __device__ __forceinline__ int mbcnt64(u64 m, int base) {
     return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, (u32)base));
 }
+// Rescaling in patch mode (MdxFuse::patch / MdxRescaleArgs::patch): a quality byte that changes (rescale.py:228-246) becomes
+// an entry of the launch's list — index of the byte in the column | new Phred << 32 — instead of a store into a copy of the
+// column.  The lanes that have one at the same time append together: one atomic for all of them (called under divergence it
+// covers the active lanes — the ballot's).
+__device__ __forceinline__ void patch_put(unsigned long long *__restrict__ patch0, unsigned long long *__restrict__ n_patch0, long long cap,
+                                          int parts, bool on, u32 idx, u32 newq) {
+    const u64 m = __ballot(on);
+    if (m == 0) return;
+    // (the block's part of the list: a counter per part — one list for the whole launch is one address all wavefronts queue at)
+    const u32 part = blockIdx.x & (u32)(parts - 1);
+    unsigned long long *__restrict__ patch = patch0 + (size_t)part * (size_t)cap, *__restrict__ n_patch = n_patch0 + part;
+    const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+    u64 base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(n_patch, (unsigned long long)__popcll(m));
+    const u64 b = (u64)(u32)rl((int)(u32)base, leader) | ((u64)(u32)rl((int)(u32)(base >> 32), leader) << 32);
+    if (on) {
+        const u64 at = b + (u64)mbcnt64(m, 0);
+        if ((long long)at < cap) patch[at] = (u64)idx | ((u64)newq << 32);
+    }
+}
 
 // bytes [lo, hi) of a 64-bit word, the range clamped to [0, 8)
 __device__ __forceinline__ u64 byte_range(int lo, int hi) {
@@ -568,6 +588,21 @@ __global__ void pack_seq_kernel(const u8 *__restrict__ in, u8 *__restrict__ out,
         const u32 lo = code4_of_read(in[2 * i]), hi = 2 * i + 1 < n ? code4_of_read(in[2 * i + 1]) : 0u;
         out[i] = (u8)(lo | (hi << 4));
     }
+}
+// MDX_FLAG_HAS_QUAL (include/mdx.h) on the records of a resident batch that have qualities: at least one base, and a first
+// quality byte that is not 0xFF (main.py:185, rescale.py:306)
+__global__ void mark_has_qual_kernel(u16 *__restrict__ flag, const u32 *__restrict__ seq_off, const u8 *__restrict__ qual, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const u32 so = seq_off[i];
+        if (seq_off[i + 1] != so && qual[so] != 0xFF) flag[i] = (u16)(flag[i] | 0x4000u);
+    }
+}
+void mdx_k_mark_has_qual(uint16_t *d_flag, const uint32_t *d_seq_off, const uint8_t *d_qual, int64_t n, hipStream_t s) {
+    if (n <= 0 || !d_qual) return;
+    const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(mark_has_qual_kernel, dim3(grid), dim3(256), 0, s, (u16 *)d_flag, d_seq_off, d_qual, (i64)n);
 }
 void mdx_k_pack_seq(const u8 *d_ascii, u8 *d_packed, int64_t n, hipStream_t s) {
     if (n <= 0) return;
@@ -873,7 +908,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #endif
         if (t.y & 0x8000u) {
             const u32 newq = l_lut[idx - 752u + q];
-            if (newq != q) kp->rs.qual_out[t.x] = (u8)newq;
+            if (kp->rs.patch) patch_put(kp->rs.patch, kp->rs.n_patch, kp->rs.patch_cap, kp->rs.patch_parts, newq != q, t.x, newq);
+            else if (newq != q) kp->rs.qual_out[t.x] = (u8)newq;
         }
     };
     // the listed transitions, three per lane and round trip
@@ -2649,6 +2685,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // stores behind them: one round trip for both.
                     MDX_PH(15);
                     cp_b0 = nb0; cp_b1 = nb1;
+                    // (patch mode: there is no second column — nothing to copy)
+                    if (p.rs.patch) cp_b0 = cp_b1;
                     // (units at the same 16-byte phase as the source column: both columns are 16-byte aligned in any
                     // allocation this library is handed)
                     const u32 head = (0u - (cp_b0 + (u32)((size_t)p.qual & 15))) & 15u;
@@ -2714,7 +2752,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (cp_b0 + (u32)lane < cp_a0) { const u8 b = qin[cp_b0 + (u32)lane]; qout[cp_b0 + (u32)lane] = b; hi |= b; }
                     const u32 t0 = cp_a0 + 16u * cp_nu + (u32)lane;
                     if (t0 < cp_b1) { const u8 b = qin[t0]; qout[t0] = b; hi |= b; }
+                    // (patch mode: no pass over the tile's qualities has been made — every record looks at its first one)
+#ifdef MDX_RSABL_NOQF
                     rs_anyhi = __ballot((hi & 0x80808080u) != 0u) != 0ull;
+#else
+                    rs_anyhi = p.rs.patch != nullptr || __ballot((hi & 0x80808080u) != 0u) != 0ull;
+#endif
                     MDX_PH(1);
                 }
                 bool kept = (fl & 0xF04u) == 0;  // reader.py:121-132
@@ -2741,8 +2784,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (RS) {
                     // (the copy has seen every quality byte of the tile: without a byte above 127 among them every record
                     // has qualities, and the 63 scattered loads are not needed)
+                    // (... nor for a record that brings MDX_FLAG_HAS_QUAL)
                     rs_qf = 0u;
-                    if (rs_anyhi && valid && c_so1 != c_so0) rs_qf = p.qual[c_so0];
+                    if (rs_anyhi && valid && c_so1 != c_so0 && !(fl & 0x4000u)) rs_qf = p.qual[c_so0];
                 }
                 const bool m0 = ((0x181u >> (g0 & 0xFu)) & 1u) != 0, m1 = ((0x181u >> (g1 & 0xFu)) & 1u) != 0;
                 const bool s0 = (g0 & 0xFu) == 4u, s1 = (g1 & 0xFu) == 4u, s2 = (g2 & 0xFu) == 4u;
@@ -3662,7 +3706,7 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
             const u32 co = a.cigar_off[ri];
             const int cn = (int)(a.cigar_off[ri + 1] - co);
             const int c_tid = a.tid[ri], c_pos = a.pos[ri], c_mtid = a.mtid[ri], c_mpos = a.mpos[ri];
-            const u32 q_first = lseq > 0 ? (u32)a.qual[so] : 0xFFu;
+            const u32 q_first = lseq > 0 ? ((fl & 0x4000u) ? 0u : (u32)a.qual[so]) : 0xFFu;      // (MDX_FLAG_HAS_QUAL)
             const u32 c0 = cn > 0 ? a.cigar[co] : 0u, c1 = cn > 1 ? a.cigar[co + 1] : 0u, c2 = cn > 2 ? a.cigar[co + 2] : 0u;
             const u32 c3 = cn > 3 ? a.cigar[co + 3] : 0u, c4 = cn > 4 ? a.cigar[co + 4] : 0u;
             const bool tid_ok = c_tid >= 0 && c_tid < a.n_contig;
@@ -3797,7 +3841,8 @@ __global__ __launch_bounds__(RS_BLOCK, RS_WPS) void rescale_kernel(MdxRescaleArg
                         const u32 q = (u32)(q8 >> sh) & 0xFFu;
                         if (q <= 93) {
                             const u32 newq = l_lut[ti * 94 + q];
-                            if (newq != q) a.qual_out[(u32)(sb + (rev ? nq - 1 - oq : oq))] = (u8)newq;
+                            if (a.patch) patch_put(a.patch, a.n_patch, a.patch_cap, a.patch_parts, newq != q, (u32)(sb + (rev ? nq - 1 - oq : oq)), newq);
+                            else if (newq != q) a.qual_out[(u32)(sb + (rev ? nq - 1 - oq : oq))] = (u8)newq;
                         }
                     }
                 }
@@ -3976,7 +4021,9 @@ __global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a
         const u32 co = a.cigar_off[ri];
         const int cn = (int)(a.cigar_off[ri + 1] - co);
         const u8 *__restrict__ qin = a.qual + so;
-        u8 *__restrict__ qout = a.qual_out + so;
+        // (patch mode: no second column — what is written back unchanged is not written at all)
+        const bool to_list = a.patch != nullptr;
+        u8 *__restrict__ qout = to_list ? nullptr : a.qual_out + so;
         const int rev = (fl >> 4) & 1, mate_rev = (fl >> 5) & 1;
         // record routing, rescale.py:300-342
         int st, forward_only = 0;
@@ -3990,7 +4037,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a
         } else st = 2;
         if (lane == 0) { a.status[ri] = (u8)st; a.mr_raw[ri] = __builtin_nan(""); }
         if (st < 2 || st == 4) {
-            for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
+            if (!to_list) for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
             return;
         }
         // CIGAR: one op per lane; scan by lane 0's view via readlane
@@ -4034,12 +4081,14 @@ __global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a
         }
         if (bad) {
             if (lane == 0) flag_error(a.err, ri, ERR_BAD_READ);
-            for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
+            if (!to_list) for (int b = lane; b < lseq; b += 64) qout[b] = qin[b];
             return;
         }
         // soft-clipped qualities are kept
-        for (int b = lane; b < qs; b += 64) qout[b] = qin[b];
-        for (int b = qs + nq + lane; b < lseq; b += 64) qout[b] = qin[b];
+        if (!to_list) {
+            for (int b = lane; b < qs; b += 64) qout[b] = qin[b];
+            for (int b = qs + nq + lane; b < lseq; b += 64) qout[b] = qin[b];
+        }
 
         const i8 *__restrict__ rp = (const i8 *)a.ref + rbase;
         const u8 *__restrict__ sp = a.seq + so + qs;
@@ -4103,7 +4152,8 @@ __global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a
                     term = a.term[sub * npos + key];
                     if (q <= 93) newq = a.lut[(sub * npos + key) * 94 + q];
                 }
-                qout[qs + qi] = (u8)newq;
+                if (to_list) patch_put(a.patch, a.n_patch, a.patch_cap, a.patch_parts, newq != q, so + (u32)(qs + qi), newq);
+                else qout[qs + qi] = (u8)newq;
                 if (a.subs) {
                     // _record_subs (rescale.py:108-143): transitions by old/new quality, reference bases
                     count_ref(rch);
@@ -4295,7 +4345,8 @@ __global__ __launch_bounds__(RS_BLOCK) void rescale_walk_kernel(MdxRescaleArgs a
                                 mr += t_term[ti];                                // (x + 0.0 == x: a zero term changes nothing)
                                 if (qv <= 93) {
                                     const u32 newq = t_lut[ti * 94 + qv];
-                                    if (newq != qv) a.qual_out[sb + (u32)qi] = (u8)newq;
+                                    if (a.patch) patch_put(a.patch, a.n_patch, a.patch_cap, a.patch_parts, newq != qv, sb + (u32)qi, newq);
+                                    else if (newq != qv) a.qual_out[sb + (u32)qi] = (u8)newq;
                                     if (a.subs) sub_bump(756 + ti * 94 + qv);
                                 }
                             } else if (qv <= 93 && a.subs) {
@@ -4392,7 +4443,7 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     const int grid = (int)(want < (int64_t)n_cu * RS_BPC ? want : (int64_t)n_cu * RS_BPC);
     const int n_cnt = 752 + 2 * npos * 94;
     if (a.lds_tables) {
-        a.copy_qual = a.qual_out != a.qual ? 1 : 0;      // the fast kernel copies the quality column as it goes
+        a.copy_qual = (a.qual_out != a.qual && !a.patch) ? 1 : 0;      // the fast kernel copies the quality column as it goes
         if (need > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)rescale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
         hipLaunchKernelGGL(rescale_kernel, dim3(grid), dim3(RS_BLOCK), need, s, a);
@@ -4404,7 +4455,7 @@ void mdx_k_rescale(const MdxRescaleArgs &a0, int n_cu, hipStream_t s) {
     } else {
         // no fast path: every record by the walk; summary counters in the LDS when those alone fit
         const size_t walk_lds = rs_lds_bytes(npos, false);
-        if (a.qual_out != a.qual)
+        if (a.qual_out != a.qual && !a.patch)
             (void)hipMemcpyAsync(a.qual_out, a.qual, (size_t)a.n_bases, hipMemcpyDeviceToDevice, s);
         a.gen_list = nullptr;
         a.row_base = 0;
@@ -4448,6 +4499,25 @@ void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *c
     const int64_t nw = grid * (RS_BLOCK / 64), ntiles = (n_reads + 63) / 64;
     *n_waves = nw > 0 ? nw : 1;
     *cap = ((ntiles + *n_waves - 1) / *n_waves) * 64;
+}
+
+// a patch list applied: qual_out (a copy of the quality column, or the column itself) takes the new Phred of every entry;
+// blockIdx.y = the part of the list
+__global__ void rescale_expand_kernel(u8 *__restrict__ qual_out, const u64 *__restrict__ patch, const u64 *__restrict__ n_patch, long long cap,
+                                      i64 n_bases) {
+    const u64 n = n_patch[blockIdx.y] < (u64)cap ? n_patch[blockIdx.y] : (u64)cap;
+    const u64 *__restrict__ mine = patch + (size_t)blockIdx.y * (size_t)cap;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 e = mine[i];
+        const u32 idx = (u32)e;
+        if ((i64)idx < n_bases) qual_out[idx] = (u8)(e >> 32);
+    }
+}
+void mdx_k_rescale_expand(const uint8_t *qual, uint8_t *qual_out, int64_t n_bases, const unsigned long long *patch,
+                          const unsigned long long *n_patch, long long patch_cap, int patch_parts, hipStream_t s) {
+    if (n_bases <= 0 || patch_parts <= 0) return;
+    if (qual_out != qual) (void)hipMemcpyAsync(qual_out, qual, (size_t)n_bases, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(rescale_expand_kernel, dim3(16, patch_parts), dim3(256), 0, s, qual_out, (const u64 *)patch, (const u64 *)n_patch, patch_cap, (i64)n_bases);
 }
 
 size_t mdx_k_rescale_part_bytes(int len5p, int len3p, int n_cu) {

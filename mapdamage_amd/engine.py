@@ -37,6 +37,7 @@ EXPORTS = (
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
+    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device",
     "mdx_fasta_index", "mdx_set_reference_fasta", "mdx_reference_fetch", "mdx_host_threads", "mdx_host_pool_threads", "mdx_warm",
 )
 
@@ -83,7 +84,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = pathlib.Path(path) if path else _LIBPATH
+    # (MDX_LIBPATH: another build of the library — the A/B variants of tools/mkvariant.sh)
+    p = pathlib.Path(path) if path else pathlib.Path(os.environ.get("MDX_LIBPATH") or _LIBPATH)
     if not p.exists():
         raise RuntimeError("%s is missing: build it with `python -m mapdamage_amd.build` "
                            "(hipcc, gfx950); there is no CPU fallback" % p)
@@ -475,6 +477,25 @@ class DamageEngine:
         self._set_record_base(0)
         self._check(fn(self._ctx, ctypes.byref(dbatch.dev), ctypes.c_void_p(d_mtid), ctypes.c_void_p(d_mpos),
                        ctypes.c_void_p(d_qual_out), ctypes.c_void_p(d_mr), ctypes.c_void_p(d_status)))
+
+    def rescale_patches(self, dbatch, d_mtid, d_mpos, d_patch, patch_cap, n_parts, d_n_patch, d_mr, d_status, with_tables=False):
+        """``rescale_device`` with the rescaled bytes as a list (include/mdx.h ``mdx_*_patches_device``) in ``n_parts`` parts
+        (a power of two): ``d_patch`` a device buffer of ``n_parts * patch_cap`` uint64 entries (byte index | new Phred <<
+        32), ``d_n_patch`` ``n_parts`` device uint64 that receive the entries of each part."""
+        fn = self._lib.mdx_tabulate_rescale_patches_device if with_tables else self._lib.mdx_rescale_patches_device
+        fn.restype = ctypes.c_int
+        dev = dbatch.dev if isinstance(dbatch, DeviceBatch) else dbatch
+        self._set_record_base(0)
+        self._check(fn(self._ctx, ctypes.byref(dev), ctypes.c_void_p(d_mtid), ctypes.c_void_p(d_mpos), ctypes.c_void_p(d_patch),
+                       ctypes.c_int64(patch_cap), ctypes.c_int32(n_parts), ctypes.c_void_p(d_n_patch), ctypes.c_void_p(d_mr),
+                       ctypes.c_void_p(d_status)))
+
+    def rescale_expand(self, dbatch, d_patch, patch_cap, n_parts, d_n_patch, d_qual_out):
+        """The batch's quality column with a patch list applied, into ``d_qual_out`` (device pointers)."""
+        dev = dbatch.dev if isinstance(dbatch, DeviceBatch) else dbatch
+        self._lib.mdx_rescale_expand_device.restype = ctypes.c_int
+        self._check(self._lib.mdx_rescale_expand_device(self._ctx, ctypes.byref(dev), ctypes.c_void_p(d_patch), ctypes.c_int64(patch_cap),
+                                                        ctypes.c_int32(n_parts), ctypes.c_void_p(d_n_patch), ctypes.c_void_p(d_qual_out)))
 
     def fused_launches(self):
         """Calls of rescale_device(with_tables=True) so far that ran as one fused launch."""

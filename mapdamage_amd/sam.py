@@ -134,7 +134,7 @@ def read_sam(path_or_handle):
         if len(f) < 11:
             continue
         qnames.append(f[0])
-        flags.append(int(f[1]) & 0x7FFF)       # bit 15 is the kernel's hint bit (mdx.h MDX_FLAG_QUAL_ABOVE_MIN), never the file's
+        flags.append(int(f[1]) & 0x3FFF)       # bits 14 and 15 are the kernels' hint bits (mdx.h MDX_FLAG_HAS_QUAL / _QUAL_ABOVE_MIN), never the file's
         tids.append(tid_of.get(f[2], -1))
         poss.append(int(f[3]) - 1)
         tlens.append(int(f[8]))
@@ -241,7 +241,7 @@ def read_bam(path, keep_raw=False):
                 q += 5 + cnt * {b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}[sub]
             else:
                 break
-        flags.append(flag & 0x7FFF); tids.append(tid); poss.append(pos); tlens.append(tlen)
+        flags.append(flag & 0x3FFF); tids.append(tid); poss.append(pos); tlens.append(tlen)
         cigs.extend(int(c) for c in cig)
         cig_counts.append(n_cigar)
         rgs.append(rg)

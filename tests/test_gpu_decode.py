@@ -73,6 +73,13 @@ def test_device_columns_equal_host_decoder(tmp_path, chunk, layout):
                 got["seq"].append(_d2h(v.seq, int(v.n_bases), np.uint8)); got["qual"].append(_d2h(v.qual, int(v.n_bases), np.uint8))
     cat = {k: np.concatenate(v) for k, v in got.items()}
     assert n == hb.n
+    # (the device decoder's flag column carries the hint MDX_FLAG_HAS_QUAL, 0x4000, on the records that have qualities — at least
+    # one base and a first quality byte that is not 0xFF, main.py:185 / rescale.py:306 — on top of the file's bits)
+    lens = np.diff(hb.seq_off.astype(np.int64))
+    first = hb.qual[np.minimum(hb.seq_off[:-1].astype(np.int64), max(0, hb.qual.shape[0] - 1))] if hb.qual.shape[0] else np.zeros(hb.n, np.uint8)
+    has_qual = (lens > 0) & (first != 0xFF)
+    np.testing.assert_array_equal((cat["flag"] & 0x4000) != 0, has_qual)
+    cat["flag"] = cat["flag"] & np.uint16(0x3FFF)
     for name in ("flag", "tid", "pos", "tlen", "cigar", "seq", "qual"):
         np.testing.assert_array_equal(cat[name], getattr(hb, name), err_msg=name)
     np.testing.assert_array_equal(cat["mtid"], hb.mtid); np.testing.assert_array_equal(cat["mpos"], hb.mpos)
@@ -606,7 +613,8 @@ def test_flag_bit_15_of_a_file_is_not_the_kernels_hint(tmp_path):
     ref, b, rg, _ = _write(tmp_path, n=8_000, seed=21)
     b.qual[:] = np.random.default_rng(1).integers(2, 20, size=b.qual.shape[0]).astype(np.uint8)   # everything maskable
     clean = b.flag.copy()
-    b.flag = (b.flag | np.uint16(0x8000)).astype(np.uint16)
+    # (... and 0x4000, MDX_FLAG_HAS_QUAL, the second hint)
+    b.flag = (b.flag | np.uint16(0xC000)).astype(np.uint16)
     path = tmp_path / "bit15.bam"
     sam.write_bam(str(path), b, ref.names, ref.lengths, RGS, rg_of_record=rg)
     assert (sam.read_bam(str(path)).batch.flag == clean).all()

@@ -440,9 +440,11 @@ def test_hip_rescale_of_a_batch_whose_seq_column_carries_the_min_basequal_mask(t
     np.testing.assert_array_equal(got_mr[~np.isnan(got_mr)], want_mr[~np.isnan(want_mr)])
 
 
-def one_pass(eng, b, packed=False):
+def one_pass(eng, b, packed=False, patches=False, with_tables=True):
     """mdx_tabulate_rescale_device on the uploaded batch (``packed``: its SEQ column in the 4-bit form) -> (qualities, MR,
-    status) as host arrays; the tables stay in the engine."""
+    status) as host arrays; the tables stay in the engine.  ``patches``: through mdx_tabulate_rescale_patches_device — the
+    rescaled bytes as a list, which must name every byte once, only bytes that change, and applied to the quality column
+    (mdx_rescale_expand_device) give the same column; a list too short for them loses the entries beyond it and nothing else."""
     import torch
     dev = torch.device("cuda", 0)
     db = eng.upload(b, packed=packed)
@@ -451,25 +453,65 @@ def one_pass(eng, b, packed=False):
     mr = torch.zeros(b.n, dtype=torch.float64, device=dev)
     st = torch.zeros(b.n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    eng.rescale_device(db, mtid.data_ptr(), mpos.data_ptr(), qout.data_ptr(), mr.data_ptr(), st.data_ptr(), with_tables=True)
-    eng.sync()
+    if not patches:
+        eng.rescale_device(db, mtid.data_ptr(), mpos.data_ptr(), qout.data_ptr(), mr.data_ptr(), st.data_ptr(), with_tables=with_tables)
+        eng.sync()
+    else:
+        parts, cap = 16, b.n * 26 // 16
+        hole = np.uint64(0xFFFFFFFFFFFFFFFF)
+        plist = torch.full((parts * cap,), -1, dtype=torch.int64, device=dev)
+        count = torch.full((parts,), 12345, dtype=torch.int64, device=dev)
+        eng.rescale_patches(db, mtid.data_ptr(), mpos.data_ptr(), plist.data_ptr(), cap, parts, count.data_ptr(), mr.data_ptr(), st.data_ptr(),
+                            with_tables=with_tables)
+        eng.rescale_expand(db, plist.data_ptr(), cap, parts, count.data_ptr(), qout.data_ptr())
+        eng.sync()
+        counts = count.cpu().numpy()
+        n = int(counts.sum())
+        assert n > 0 and int(counts.max()) <= cap
+        entries = plist.cpu().numpy().view(np.uint64).reshape(parts, cap)
+        for p_ in range(parts):
+            assert (entries[p_, int(counts[p_]):] == hole).all()        # nothing behind the entries a part counts
+        listed = np.concatenate([entries[p_, :int(counts[p_])] for p_ in range(parts)])
+        idx, newq = (listed & np.uint64(0xFFFFFFFF)).astype(np.int64), (listed >> np.uint64(32)).astype(np.int64)
+        assert len(np.unique(idx)) == n and idx.max() < b.seq.shape[0]      # every byte once
+        assert (newq != b.qual[idx]).all() and newq.max() <= 93             # ... and only bytes that change
+        if with_tables:
+            # the same launch with parts of half the room of the fullest (the engine's tables would hold the batch twice: reset)
+            eng.reset()
+            small = int(counts.max()) // 2
+            plist.fill_(-1)
+            eng.rescale_patches(db, mtid.data_ptr(), mpos.data_ptr(), plist.data_ptr(), small, parts, count.data_ptr(), mr.data_ptr(),
+                                st.data_ptr(), with_tables=True)
+            eng.sync()
+            # (which block takes which tile is settled while the launch runs: the parts fill differently, their sum is the same)
+            counts2 = count.cpu().numpy()
+            assert int(counts2.sum()) == n and int(counts2.max()) > small
+            again = plist.cpu().numpy().view(np.uint64)
+            assert (again[parts * small:] == hole).all()
+            again = again[:parts * small].reshape(parts, small)
+            for p_ in range(parts):
+                k_ = min(small, int(counts2[p_]))
+                assert (again[p_, :k_] != hole).all() and (again[p_, k_:] == hole).all()
     out = qout.cpu().numpy()[:b.seq.shape[0]], mr.cpu().numpy(), st.cpu().numpy()
     db.free()
     return out
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("out_form", ["column", "patches"])
 @pytest.mark.parametrize("seq_form", ["ascii", "4bit"])
 @pytest.mark.parametrize("length,l5,l3,lens", [(70, 12, 12, (25, 160)), (25, 12, 12, (20, 120)), (70, 20, 3, (15, 90)),
                                                (12, 0, 30, (15, 60))])
-def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, monkeypatch, length, l5, l3, lens, seq_form):
+def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, monkeypatch, length, l5, l3, lens, seq_form, out_form):
     """The fused launch (the tabulation kernel rescales the records of its own tile loop and lists the others for the
     rescale kernels): tables, qualities, MR, routing and every summary word — against the oracle, and the summary
     word for word against the two-kernel path on the same batch.  Record lengths on both sides of --length and of
     2 x --length (longer records are listed), records the tabulation drops but the rescaling takes, models with
     uneven windows.  Both forms of the SEQ column: an ASCII one runs the fused ASCII kernel, a 4-bit one the packed fused
-    kernel (the records it lists are unpacked for the rescale kernels behind it)."""
+    kernel (the records it lists are unpacked for the rescale kernels behind it).  Both forms of the result: a second
+    quality column, and the list of the bytes that change (``one_pass``)."""
     packed = seq_form == "4bit"
+    patches = out_form == "patches"
     from mapdamage_amd.engine import DamageEngine
     from mapdamage_amd.rescale import RescaleModel
     from oracle import oracle
@@ -499,10 +541,14 @@ def test_hip_fused_pass_against_the_oracle_and_the_two_kernel_path(tmp_path, mon
         with DamageEngine(libs, length, 10, 0) as eng:
             eng.set_reference(ref)
             eng.set_rescale_model(model)
-            q, mr, st = one_pass(eng, b, packed)
-            assert eng.fused_launches() == (1 if fuse else 0)
-            assert eng.packed_launches() == (1 if packed else 0)
+            q, mr, st = one_pass(eng, b, packed, patches)
+            # (patches: the pass ran twice — the second time into a list too short — behind a reset of the tables)
+            assert eng.fused_launches() == ((2 if patches else 1) if fuse else 0)
+            assert eng.packed_launches() == ((2 if patches else 1) if packed else 0)
             words = eng.rescale_summary()
+            if patches:
+                assert (words % 2 == 0).all()
+                words = words // 2
             tables = eng.finish()
         assert_tables_equal(tables, want_tables)
         np.testing.assert_array_equal(q, want_q)
