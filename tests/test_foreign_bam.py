@@ -127,8 +127,15 @@ def test_device_decoder_against_construction_time_truth():
                                   want_qual=True, want_mate=True, packed=packed) as g:
                 view = g.next_view()
                 assert int(view.n_reads) == n and g.next_view() is None
-                for k, dt in (("flag", np.uint16), ("tid", np.int32), ("pos", np.int32), ("tlen", np.int32)):
+                for k, dt in (("tid", np.int32), ("pos", np.int32), ("tlen", np.int32)):
                     np.testing.assert_array_equal(_d2h(getattr(view, k), n, dt), t[k], err_msg=k)
+                # the file's flag bits, and on top the hint MDX_FLAG_HAS_QUAL (0x4000) where the record has qualities: a base
+                # at least, and a first quality byte that is not 0xFF (main.py:185, rescale.py:306)
+                flag = _d2h(view.flag, n, np.uint16)
+                np.testing.assert_array_equal(flag & np.uint16(0x3FFF), t["flag"], err_msg="flag")
+                lens = np.diff(t["seq_off"].astype(np.int64))
+                first = t["qual"][np.minimum(t["seq_off"][:-1].astype(np.int64), len(t["qual"]) - 1)]
+                np.testing.assert_array_equal((flag & 0x4000) != 0, (lens > 0) & (first != 0xFF))
                 np.testing.assert_array_equal(_d2h(view.cigar_off, n + 1, np.uint32), t["cigar_off"])
                 np.testing.assert_array_equal(_d2h(view.seq_off, n + 1, np.uint32), t["seq_off"])
                 np.testing.assert_array_equal(_d2h(view.cigar, int(view.n_cigar), np.uint32), t["cigar"])
