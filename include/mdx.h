@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
+#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -375,6 +375,10 @@ void mdx_bam_close(mdx_bam_stream *stream);
  * mdx_bam_patch_rescaled writes the chunk's records to `out` (capacity out_cap bytes: raw size + 7 per rescaled
  * record suffices), those with rescaled[i] != 0 with their QUAL replaced by qual_out[seq_off[i] ...] and an `MR:f`
  * tag (mr[i]) appended, every other byte unchanged. */
+/* mdx_mr_round: float("%.5f" % x) of rescale.py:275-276 for n MR sums (mr_raw of the rescale calls) on `threads` host threads —
+ * the value printed with five decimals, read back, and narrowed to the 32 bits of an MR:f tag; NaN (a record written back
+ * unchanged) gives 0. */
+int mdx_mr_round(const double *mr_raw, int64_t n, float *out, int32_t threads);
 int mdx_bam_stream_keep_raw(mdx_bam_stream *stream, int on);
 int mdx_bam_raw(const mdx_bam *bam, const uint8_t **data, const uint64_t **rec_off);
 int mdx_bam_patch_rescaled(const mdx_bam *bam, const uint8_t *qual_out, const float *mr, const uint8_t *rescaled,

@@ -916,6 +916,32 @@ int mdx_bam_patch_rescaled(const mdx_bam *b, const uint8_t *qual_out, const floa
     return MDX_OK;
 }
 
+// float("%.5f" % x) of rescale.py:275-276, element by element: the MR sum printed with five decimals and read back, then the
+// 32-bit value an MR:f tag holds.  (Python formats with correctly rounded decimal conversion in both directions; so does
+// glibc.)  n values on `threads` threads; NaN (a record written back unchanged) -> 0.
+int mdx_mr_round(const double *mr_raw, int64_t n, float *out, int32_t threads) {
+    if (n < 0 || (n > 0 && (!mr_raw || !out))) return MDX_ERR_ARG;
+    try {
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : 1, n / 4096 + 1));
+        auto work = [&](int64_t lo, int64_t hi) {
+            char buf[512];
+            for (int64_t i = lo; i < hi; i++) {
+                const double x = mr_raw[i];
+                if (x != x) { out[i] = 0.f; continue; }
+                std::snprintf(buf, sizeof buf, "%.5f", x);
+                out[i] = (float)std::strtod(buf, nullptr);
+            }
+        };
+        if (nt == 1) { work(0, n); return MDX_OK; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto &th : pool) th.join();
+        return MDX_OK;
+    } catch (...) {
+        return MDX_ERR_ARG;
+    }
+}
+
 void mdx_bam_close(mdx_bam_stream *s) {
     if (!s) return;
     delete s->file;

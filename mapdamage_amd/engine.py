@@ -37,7 +37,7 @@ EXPORTS = (
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
-    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device",
+    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device", "mdx_mr_round",
     "mdx_fasta_index", "mdx_set_reference_fasta", "mdx_reference_fetch", "mdx_host_threads", "mdx_host_pool_threads", "mdx_warm",
 )
 

@@ -148,32 +148,67 @@ def finalize_mr(raw_sum):
     return float("%.5f" % raw_sum)
 
 
-def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20):
+def round_mr(mr_raw):
+    """``float("%.5f" % x)`` (rescale.py:275-276) element by element, as the float32 of an ``MR:f`` tag; NaN (a record written
+    back unchanged) gives 0.  In the library, on the host's threads (include/mdx.h ``mdx_mr_round``)."""
+    import ctypes
+    from .engine import load_library
+    from .sam import usable_cpus
+    mr_raw = np.ascontiguousarray(mr_raw, np.float64)
+    out = np.zeros(mr_raw.shape[0], np.float32)
+    lib = load_library()
+    lib.mdx_mr_round.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32]
+    if lib.mdx_mr_round(mr_raw.ctypes.data, mr_raw.shape[0], out.ctypes.data, min(32, usable_cpus())) != 0:
+        raise ValueError("mdx_mr_round failed")
+    return out
+
+
+def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20, timings=None):
     """File-level mirror of ``_rescale_qual_core`` (rescale.py:285-365): every record of the BAM is
     written back, rescaled records get their new qualities and an ``MR:f`` tag, everything else in
     the record (name, MAPQ, mate fields, other tags) is preserved byte for byte.
     The file goes through in chunks: native decode (the encoded records kept), one rescale launch per chunk, the
     records patched natively, BGZF blocks deflated on a thread pool — host memory is bounded by the chunk and no
-    per-record Python work is done.  Returns (substitution summary, per-status record counts)."""
+    per-record Python work is done.  Returns (substitution summary, per-status record counts).  ``timings`` (a dict): receives
+    the seconds spent decoding (BGZF inflate + unpack on the host's threads), in the rescaling call (columns to HBM, the
+    kernels, qualities / MR / status back), formatting MR, patching the records and deflating + writing the output."""
+    import time
     from .sam import BamStream, BgzfWriter, bam_header_bytes
     engine.set_reference(ref)
     engine.set_rescale_model(model)
     counts = np.zeros(5, np.int64)
+    spent = {"decode": 0.0, "rescale": 0.0, "mr_format": 0.0, "patch": 0.0, "deflate_write": 0.0}
+    clock = time.perf_counter
     with BamStream(in_path, chunk_bytes=chunk_bytes, keep_raw=True) as stream, BgzfWriter(out_path) as out:
         out.write(bam_header_bytes(stream.header))
-        for chunk in stream:
+        while True:
+            t0 = clock()
+            chunk = stream.next_chunk()
+            t1 = clock()
+            spent["decode"] += t1 - t0
+            if chunk is None:
+                break
             batch = chunk.batch
             qual_out, mr_raw, status = engine.rescale(batch)
+            t2 = clock()
+            spent["rescale"] += t2 - t1
             rescaled = (status == STATUS_BOTH) | (status == STATUS_FORWARD)
             clash = rescaled & (np.asarray(chunk.has_mr) != 0)
             if clash.any():      # rescale.py:277-278
                 raise SystemExit("Read: %s already has a MR tag, can't rescale" % chunk.qname_at(int(np.nonzero(clash)[0][0])))
-            # float("%.5f" % x), element by element in C (rescale.py:275)
-            mr = np.zeros(batch.n, np.float32)
-            if rescaled.any():
-                mr[rescaled] = np.char.mod("%.5f", mr_raw[rescaled]).astype(np.float64).astype(np.float32)
-            out.write(stream.patch_rescaled(chunk, qual_out, mr, rescaled))
+            mr = round_mr(mr_raw)
+            t3 = clock()
+            spent["mr_format"] += t3 - t2
+            patched = stream.patch_rescaled(chunk, qual_out, mr, rescaled)
+            t4 = clock()
+            spent["patch"] += t4 - t3
+            out.write(patched)
+            spent["deflate_write"] += clock() - t4
             counts += np.bincount(status, minlength=5)[:5]
+        t5 = clock()
+    spent["deflate_write"] += clock() - t5          # (the writer's last blocks and its close)
+    if timings is not None:
+        timings.update(spent)
     summary = RescaleSummary(engine.rescale_summary(), model)
     return summary, {name: int(counts[code]) for name, code in
             (("unmapped", STATUS_UNMAPPED), ("without_qualities", STATUS_NO_QUAL), ("single_end", STATUS_BOTH),

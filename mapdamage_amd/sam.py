@@ -267,29 +267,45 @@ def write_bam_raw(path, raw_header, records):
 
 
 class BgzfWriter:
-    """BGZF output stream: 0xFF00-byte blocks deflated on a pool of threads (zlib drops the GIL), written in order."""
+    """BGZF output stream: 0xFF00-byte blocks deflated on a pool of threads (zlib drops the GIL), written in order.  ``write``
+    hands its blocks to the pool and returns: they are deflated while the caller prepares the next piece (the rescaling pass:
+    the next chunk's decode, kernels and patching run under the deflate of this one's output, which is what bounds it), at most
+    ``max_pending`` blocks — 256 MiB of input — wait at a time."""
 
-    def __init__(self, path, threads=None):
-        import os
+    def __init__(self, path, threads=None, max_pending=4096):
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         self._out = open(path, "wb")
         self._pool = ThreadPoolExecutor(threads or min(32, usable_cpus()))
         self._tail = b""
+        self._pending = deque()
+        self._max_pending = max_pending
+
+    def _drain(self, keep):
+        """Write the finished blocks at the head of the queue; wait for the oldest ones while more than ``keep`` are queued."""
+        while self._pending and (len(self._pending) > keep or self._pending[0].done()):
+            self._out.write(self._pending.popleft().result())
 
     def write(self, data):
-        """Append bytes (anything with the buffer protocol)."""
+        """Append bytes (anything with the buffer protocol; the object must not change until the stream is closed or flushed)."""
         view = memoryview(data).cast("B")
         if self._tail:
             view = memoryview(self._tail + view.tobytes())
         whole = len(view) // 0xFF00 * 0xFF00
-        blocks = [view[lo:lo + 0xFF00] for lo in range(0, whole, 0xFF00)]
         self._tail = view[whole:].tobytes()
-        for encoded in self._pool.map(_bgzf_block, blocks):
-            self._out.write(encoded)
+        for lo in range(0, whole, 0xFF00):
+            self._pending.append(self._pool.submit(_bgzf_block, view[lo:lo + 0xFF00]))
+            if len(self._pending) > self._max_pending:
+                self._drain(self._max_pending // 2)
+        self._drain(self._max_pending)
+
+    def flush(self):
+        self._drain(0)
 
     def close(self):
         if self._out is None:
             return
+        self._drain(0)
         if self._tail:
             self._out.write(_bgzf_block(self._tail))
         self._out.write(_bgzf_block(b""))
@@ -590,6 +606,18 @@ class BamStream:
         chunk = _native_alignments(self._lib, handle, _NativeBam(self._lib, handle), self.header)
         chunk.native = handle          # (kept alive by the chunk's owner object) for patch_rescaled()
         return chunk
+
+    def raw_bodies(self, chunk, count=None):
+        """The encoded bodies (without their block_size field) of the first ``count`` records of ``chunk`` (decoded with
+        ``keep_raw``), as bytes objects."""
+        import ctypes
+        n = chunk.batch.n if count is None else min(int(count), chunk.batch.n)
+        data, rec_off = ctypes.c_void_p(), ctypes.c_void_p()
+        if self._lib.mdx_bam_raw(chunk.native, ctypes.byref(data), ctypes.byref(rec_off)) != 0:
+            raise ValueError("the stream was not opened with keep_raw")
+        off = np.ctypeslib.as_array(ctypes.cast(rec_off, ctypes.POINTER(ctypes.c_uint64)), (chunk.batch.n + 1,))
+        blob = ctypes.string_at(data.value, int(off[n]))
+        return [blob[int(off[i]) + 4:int(off[i + 1])] for i in range(n)]
 
     def patch_rescaled(self, chunk, qual_out, mr, rescaled):
         """The encoded records of ``chunk`` (decoded with ``keep_raw``) with the QUAL of the records flagged in

@@ -52,6 +52,17 @@ def check(qual_out, mr_raw, want_qual, want_mr):
     np.testing.assert_array_equal(got[~np.isnan(got)], want_mr[~np.isnan(want_mr)])
 
 
+def test_mr_rounding_in_the_library_is_pythons():
+    """``float("%.5f" % x)`` (rescale.py:275-276) for every MR sum of a chunk at once (include/mdx.h mdx_mr_round) against the
+    expression itself, ties and tiny values included."""
+    from mapdamage_amd.rescale import finalize_mr, round_mr
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.random(50_000) * 3, rng.random(1000) * 1e-5, np.arange(0, 2000) * 5e-6 + 5e-6,
+                        [np.nan, 0.0, 0.000005, 0.000015, 0.123455, 2.5e-6, 1e10 / 3, 1e-300]])
+    want = np.array([0.0 if v != v else np.float32(finalize_mr(v)) for v in x], np.float32)
+    np.testing.assert_array_equal(round_mr(x), want)
+
+
 def test_lookup_table_matches_survey_probe():
     """SURVEY Appendix D rescale probe: q = 40, corr 0 / 0.01 / 0.1 / 0.25 / 0.5 / 0.9."""
     cp = {("C", "T", 1): 0.5, ("C", "T", 2): 0.25, ("C", "T", 3): 0.1, ("C", "T", 4): 0.01, ("G", "A", -1): 0.9}
