@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
+#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round, mdx_batch_fold; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -178,6 +178,13 @@ int mdx_reference_fetch(mdx_ctx *ctx, int32_t tid, int64_t start, int64_t end, u
  * `dev` receives device pointers; release with mdx_batch_free. */
 int mdx_batch_upload(mdx_ctx *ctx, const mdx_batch *host, mdx_batch *dev);
 int mdx_batch_free(mdx_ctx *ctx, mdx_batch *dev);
+/* A caller's own device batch under --min-basequal (align.py:53-73): a MDX_SEQ_4BIT column with qualities (or the bitmap
+ * `lowq`) is folded into a scratch column in front of EVERY launch that counts it — a pass over column and qualities each
+ * time (2.2 x the unmasked launch against 1.3 x).  mdx_batch_fold does it ONCE, in place: the batch's seq column takes the
+ * mask into its nibbles and *dev_batch becomes MDX_SEQ_4BITQ — from then on it belongs to this context's threshold (another
+ * context with another threshold must not be handed it: check_batch cannot tell).  Enqueued on the context's stream.  The
+ * library's own batches (mdx_batch_upload, the device decoder) are folded when they are made. */
+int mdx_batch_fold(mdx_ctx *ctx, mdx_batch *dev_batch);
 
 /* Replaces the loop body main.py:165-217 for every record of the batch: flag filter
  * (reader.py:121-132), coordinates/flanks (align.py:14-35), CIGAR gapping with optional
@@ -316,7 +323,8 @@ int mdx_rescale_timing_read(mdx_ctx *ctx, int64_t *n_launches, double *total_ms)
 /* Calls of mdx_tabulate_rescale_device so far that ran as the fused launch (the others: two kernels). */
 int64_t mdx_fused_launches(const mdx_ctx *ctx);
 /* Kernel launches so far that ran as the packed kernel (a MDX_SEQ_4BIT batch in a plain tabulation or with --min-basequal:
- * one per call whatever the number of libraries — up to some twenty libraries per launch). */
+ * one per call whatever the number of libraries — up to 64 libraries per launch, MDX_ML_MAX_LIBS, and as many as the
+ * launch has pools of two blocks). */
 int64_t mdx_packed_launches(const mdx_ctx *ctx);
 /* Calls so far that bucketed their batch by library themselves (several libraries, a batch without mdx_batch::libsort). */
 int64_t mdx_libsorts(const mdx_ctx *ctx);
@@ -418,7 +426,8 @@ int mdx_gbam_next(mdx_gbam *g, int64_t chunk_bytes, mdx_batch *dev_view, const i
  * MDX_FLAG_QUAL_ABOVE_MIN in the flag column, a 4-bit SEQ column takes the mask into its nibbles (the views are
  * MDX_SEQ_4BITQ), a slab without a single maskable record is handed over without its quality column (the unmasked
  * kernel), and mdx_gbam_missing_qualities says whether a record the kernel counts has come by without qualities so far
- * (what main.py:185-192 warns about). */
+ * (what main.py:185-192 warns about).  minqual must be the threshold of the context the file was opened on (or 0): the
+ * views carry it in their nibbles (MDX_ERR_ARG otherwise). */
 int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual);
 /* MDX_SEQ_4BIT: the unpack kernel keeps BAM's nibbles (recoded, low nibble first) instead of expanding them to ASCII;
  * the views of mdx_gbam_next then carry seq_format = MDX_SEQ_4BIT.  Default MDX_SEQ_ASCII. */

@@ -1929,6 +1929,13 @@ int mdx_gbam_inflate_blocks(mdx_ctx *ctx, const uint8_t *comp, int64_t comp_byte
 
 int mdx_gbam_set_min_basequal(mdx_gbam *g, int32_t minqual) {
     if (!g || minqual < 0 || minqual > 93) return MDX_ERR_ARG;
+    // (the views carry the threshold in their nibbles — MDX_SEQ_4BITQ — and the packed masked kernel reads nothing else: a
+    // decoder at one threshold in front of a context at another would be counted with the wrong mask, and nothing would notice)
+    if (minqual != 0 && minqual != mdx_ctx_minqual(g->ctx)) {
+        g->error = "mdx_gbam_set_min_basequal: " + std::to_string(minqual) + " is not the --min-basequal of the context the file was opened on (" +
+                   std::to_string(mdx_ctx_minqual(g->ctx)) + ")";
+        return MDX_ERR_ARG;
+    }
     g->minqual = minqual;
     return MDX_OK;
 }

@@ -149,6 +149,7 @@ struct mdx_ctx {
     DevBuf lowq;           // --min-basequal, packed kernel: the scratch column a MDX_SEQ_4BIT batch's mask is folded into (MDX_SEQ_4BITQ)
     DevBuf libsort;        // several libraries, packed kernel: the batch's columns bucketed by library (a batch that does not bring them)
     DevBuf libsort_scratch;
+    const void *libsort_checked = nullptr;   // the batch's own blob (mdx_batch::libsort) whose signature was read back last
     DevBuf ml_partials;    // ... and the plan of a launch over several libraries: which library a pool of blocks counts (MdxTabArgs::ml_plan)
     int64_t n_libsorts = 0;        // sorts done inside a launch so far (a resident batch brings its own: mdx_batch::libsort)
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
@@ -493,11 +494,21 @@ static int ascii_view(mdx_ctx *c, const mdx_batch *b, mdx_batch *out) {
     return MDX_OK;
 }
 
+// What a blob of mdx_k_libsort was laid out for, in the spare word of its header: the layout is a function of the batch's
+// sizes and of the libraries of the context that built it — a resident batch handed to a context of another nlib, or a
+// sub-view of it, would be read through the wrong offsets.
+static uint64_t libsort_signature(int64_t n, int64_t n_cigar, int64_t n_bases, int nlib) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (uint64_t v : {(uint64_t)n, (uint64_t)n_cigar, (uint64_t)n_bases, (uint64_t)nlib}) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xBF58476D1CE4E5B9ull; }
+    return h | 1ull;
+}
 // A device batch with a 4-bit SEQ column (either form), ordered by library, into `blob` (mdx_k_libsort_bytes; enqueued on
 // the stream)
 static int build_libsort(mdx_ctx *c, const mdx_batch *b, void *blob) {
     MdxLibSort ls;
     mdx_k_libsort_layout(blob, b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib, &ls);
+    const uint64_t sig = libsort_signature(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib);
+    HIP_TRY(c, hipMemcpyAsync((char *)blob + 8, &sig, 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, c->libsort_scratch.reserve(mdx_k_libsort_scratch_bytes(b->n_reads, c->cfg.nlib)));
     mdx_k_libsort(b->n_reads, b->n_cigar, b->n_bases, b->flag, b->lib, b->tid, b->pos, b->tlen, b->cigar_off, b->cigar, b->seq_off, b->seq,
                   c->cfg.nlib, c->libsort_scratch.p, ls, c->stream);
@@ -564,9 +575,27 @@ int mdx_batch_upload(mdx_ctx *c, const mdx_batch *h, mdx_batch *dv) {
     return MDX_OK;
 }
 
+int mdx_batch_fold(mdx_ctx *c, mdx_batch *b) {
+    int rc = check_batch(c, b);
+    if (rc != MDX_OK) return rc;
+    if (c->cfg.minqual <= 0) return fail(c, MDX_ERR_STATE, "mdx_batch_fold: the context has no --min-basequal");
+    if (b->seq_format == MDX_SEQ_4BITQ) return MDX_OK;
+    if (b->seq_format != MDX_SEQ_4BIT) return fail(c, MDX_ERR_ARG, "mdx_batch_fold: the seq column is not MDX_SEQ_4BIT");
+    if (!b->qual && !b->lowq) return fail(c, MDX_ERR_ARG, "mdx_batch_fold: neither qualities nor a bitmap of the low ones");
+    // (a copy of the batch ordered by library was made from the unmasked column)
+    if (b->libsort) return fail(c, MDX_ERR_ARG, "mdx_batch_fold: the batch brings mdx_batch::libsort, built from the column as it was");
+    if (b->n_bases == 0) { b->seq_format = MDX_SEQ_4BITQ; return MDX_OK; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    mdx_k_fold_mask(b->seq, const_cast<uint8_t *>(b->seq), b->qual, b->lowq, b->n_bases, c->cfg.minqual, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    b->seq_format = MDX_SEQ_4BITQ;
+    return MDX_OK;
+}
+
 int mdx_batch_free(mdx_ctx *c, mdx_batch *dv) {
     if (!c || !dv) return MDX_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (dv->libsort && dv->libsort == c->libsort_checked) c->libsort_checked = nullptr;
     const void *ptrs[] = {dv->flag, dv->lib, dv->tid, dv->pos, dv->tlen, dv->cigar_off,
                           dv->cigar, dv->seq_off, dv->seq, dv->qual, dv->lowq, dv->libsort};
     for (const void *p : ptrs) if (p) (void)hipFree(const_cast<void *>(p));
@@ -654,9 +683,13 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     int group = packed ? 1 : (c->mode == MDX_MODE_LDS ? c->lib_group : c->cfg.nlib);
     const MdxDims dims1 = mdx_make_dims(c->cfg.length, c->cfg.around, 1, c->cfg.lgd_max, c->dims.lgd_lds);
     if (ml) {
-        // (a pool of blocks counts one library: as many libraries per launch as a launch of the fewest blocks has pools — and
-        // as the plan's arrays hold)
+        // (a pool of blocks counts one library: as many libraries per launch as the largest launch has pools of two blocks —
+        // every library of a launch must get one, ml_plan_kernel — and as the plan's arrays hold)
         group = c->cfg.nlib < MDX_ML_MAX_LIBS ? c->cfg.nlib : MDX_ML_MAX_LIBS;
+        int per_cu = (int)(kLdsLimit / mdx_k_pk_lds_bytes(dims1));
+        if (per_cu > mdx_k_pk_blocks_per_cu()) per_cu = mdx_k_pk_blocks_per_cu();
+        const int pools = (c->n_cu * per_cu) / 2;
+        if (group > pools) group = pools > 0 ? pools : 1;
     }
     for (int lo = 0; lo < c->cfg.nlib; lo += group) {
         const int gn = c->cfg.nlib - lo < group ? c->cfg.nlib - lo : group;
@@ -680,7 +713,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         int grid = (int)(want < max_grid ? want : max_grid);
         // (several libraries: a pool — two blocks — for every library at least)
         if (ml && grid < 2 * gn) grid = 2 * gn < max_grid ? 2 * gn : max_grid;
-        if (ml && (grid & 1)) grid++;
+        // (an even number of blocks — pools of two —, never more than the launch's partial slots were sized for)
+        if (ml && (grid & 1)) grid += grid + 1 <= max_grid ? 1 : -1;
         int wpb_l = wpb;
         if (fuse) {
             // one 1024-thread block per CU (mdx_k_fuse_*): the whole batch in one launch, all libraries
@@ -771,6 +805,16 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         if (ml) {
             // the batch ordered by library: its own copy (a resident batch's), or sorted now (once for all launches of the call)
             const void *blob = b->libsort;
+            if (blob && blob != c->libsort_checked) {
+                // (a batch's own copy: laid out for these sizes and this many libraries?  Read back once per blob.)
+                uint64_t sig = 0;
+                HIP_TRY(c, hipMemcpyAsync(&sig, (const char *)blob + 8, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (sig != libsort_signature(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib))
+                    return fail(c, MDX_ERR_ARG, "mdx_batch::libsort was built for another batch or a context with another number of libraries: "
+                                                "upload the batch with the context that tabulates it, whole");
+                c->libsort_checked = blob;
+            }
             if (!blob) {
                 if (lo == 0) {
                     HIP_TRY(c, c->libsort.reserve(mdx_k_libsort_bytes(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib)));
@@ -1158,6 +1202,8 @@ void mdx_ctx_scratch_take(mdx_ctx *c, void **arena, size_t *cap, void **tables, 
     *arena = c->gbam_arena; *cap = c->gbam_arena_cap; *tables = c->gbam_tables; *stream = c->gbam_stream; *event = c->gbam_event;
     c->gbam_arena = nullptr; c->gbam_arena_cap = 0; c->gbam_tables = nullptr; c->gbam_stream = nullptr; c->gbam_event = nullptr;
 }
+
+int mdx_ctx_minqual(const mdx_ctx *c) { return c ? c->cfg.minqual : -1; }
 
 int mdx_ctx_stream(mdx_ctx *c, void **stream, int *device) {
     if (!c) return MDX_ERR_ARG;

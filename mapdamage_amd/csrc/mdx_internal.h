@@ -388,6 +388,7 @@ void mdx_k_rescale_lists(int64_t n_reads, int n_cu, int64_t *n_waves, int64_t *c
 
 // (mdx_capi.cpp) the device decode's arena and CRC tables, kept by the context between files
 struct mdx_ctx;
+extern "C" int mdx_ctx_minqual(const mdx_ctx *c);        // the context's --min-basequal (-1: no context)
 extern "C" void mdx_ctx_scratch_give(mdx_ctx *c, void *arena, size_t cap, void *tables, void *stream, void *event);
 extern "C" void mdx_ctx_scratch_take(mdx_ctx *c, void **arena, size_t *cap, void **tables, void **stream, void **event);
 

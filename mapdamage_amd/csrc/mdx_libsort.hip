@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void libsort_blockscan_kernel(const u32 *__res
 #define LS_COPY_WAVES 4
 __global__ __launch_bounds__(64 * LS_COPY_WAVES) void libsort_copy_kernel(const u32 *__restrict__ kept_p, const u32 *__restrict__ src_co,
                                                                           const u32 *__restrict__ src_so, const u32 *__restrict__ cigar,
-                                                                          const u32 *__restrict__ seq32, u32 ph, MdxLibSort out) {
+                                                                          const u32 *__restrict__ seq32, u32 ph, u32 seq_words, MdxLibSort out) {
     __shared__ u32 s_off[LS_COPY_WAVES][72], s_src[LS_COPY_WAVES][72];
     const i64 kept = *kept_p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -328,7 +328,9 @@ __global__ __launch_bounds__(64 * LS_COPY_WAVES) void libsort_copy_kernel(const 
                 if (e <= x) break;                          // behind the last kept base
                 const u32 take = (u32)((e < w_hi ? e : w_hi) - x);
                 const u64 sn = src_at(i) + ph + (x - off_at(i));
-                const u32 w0 = seq32[sn >> 3], w1 = seq32[(sn >> 3) + 1];
+                // (the second word only where the column still has one: a caller's own column ends with its last base)
+                const u32 wi = (u32)(sn >> 3);
+                const u32 w0 = seq32[wi], w1 = wi + 1u < seq_words ? seq32[wi + 1u] : 0u;
                 u32 bits = __builtin_amdgcn_alignbit(w1, w0, 4u * (u32)(sn & 7));
                 if (take < 8u) bits &= (1u << (4u * take)) - 1u;
                 v |= bits << (4u * (u32)(x - w_lo));
@@ -368,5 +370,7 @@ void mdx_k_libsort(int64_t n, int64_t n_cigar, int64_t n_bases, const uint16_t *
     const u32 *const seq32 = (const u32 *)(seq4 - ((size_t)seq4 & 3));
     const i64 tiles = (n + 64 * LS_COPY_WAVES - 1) / (64 * LS_COPY_WAVES);
     const unsigned cgrid = (unsigned)(tiles < 8192 ? (tiles > 0 ? tiles : 1) : 8192);
-    hipLaunchKernelGGL(libsort_copy_kernel, dim3(cgrid), dim3(64 * LS_COPY_WAVES), 0, s, kept_p, sc.src_co, sc.src_so, cigar, seq32, ph, out);
+    // (dwords of the column counted from that base: no byte behind its last one is read)
+    const u32 seq_words = (u32)((((size_t)seq4 & 3) + ((size_t)n_bases + 1) / 2 + 3) / 4);
+    hipLaunchKernelGGL(libsort_copy_kernel, dim3(cgrid), dim3(64 * LS_COPY_WAVES), 0, s, kept_p, sc.src_co, sc.src_so, cigar, seq32, ph, seq_words, out);
 }

@@ -37,7 +37,7 @@ EXPORTS = (
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
-    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device", "mdx_mr_round",
+    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device", "mdx_mr_round", "mdx_batch_fold",
     "mdx_fasta_index", "mdx_set_reference_fasta", "mdx_reference_fetch", "mdx_host_threads", "mdx_host_pool_threads", "mdx_warm",
 )
 
@@ -314,6 +314,13 @@ class DamageEngine:
         dev = MdxBatch()
         self._check(self._lib.mdx_batch_upload(self._ctx, ctypes.byref(hb), ctypes.byref(dev)))
         return DeviceBatch(self, dev, batch.n, int(batch.seq.shape[0]), int(batch.cigar.shape[0]))
+
+    def fold(self, dbatch):
+        """--min-basequal folded into a device batch's own 4-bit SEQ column, once and in place (include/mdx.h
+        ``mdx_batch_fold``): a ``DeviceBatch`` or an ``MdxBatch`` of device pointers; it is ``MDX_SEQ_4BITQ`` afterwards."""
+        dev = dbatch.dev if isinstance(dbatch, DeviceBatch) else dbatch
+        self._lib.mdx_batch_fold.restype = ctypes.c_int
+        self._check(self._lib.mdx_batch_fold(self._ctx, ctypes.byref(dev)))
 
     def _set_record_base(self, base):
         # (context state: every entry point that launches sets it, so that a base given to one call does not shift the

@@ -410,18 +410,22 @@ def _tabulate_on_device(options, reader, ref, libraries, logger, ranks, stages):
                         raise
                     if view is None:
                         break
-                    if options.minqual and not warned_about_quals and stream.missing_qualities():
-                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
-                        warned_about_quals = True
                     if options.downsample is not None:
                         # reader.py:134-146: one draw per record the flag filter keeps, in file order, from the run's one
                         # generator; the records that leave get a bit the kernel's flag filter drops
-                        # (several ranks: every rank draws for the slabs of the others too — the stream of draws is the file's)
                         flags = stream.view_flags(view)
                         kept = np.nonzero((flags & FLAG_FILTER) == 0)[0]
-                        gone = kept[draw_uniform(downsample_rand, len(kept)) >= options.downsample]
-                        flags[gone] |= 0x200
+                        stay = draw_uniform(downsample_rand, len(kept)) < options.downsample
+                        flags[kept[~stay]] |= 0x200
                         stream.set_view_flags(view, flags)
+                        # (main.py:185-192 warns about a read without qualities that the loop MEETS — one that survived the draws:
+                        # the decoder marks the records that have qualities, include/mdx.h MDX_FLAG_HAS_QUAL)
+                        if options.minqual and not warned_about_quals and bool(((flags[kept[stay]] & 0x4000) == 0).any()):
+                            logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                            warned_about_quals = True
+                    elif options.minqual and not warned_about_quals and stream.missing_qualities():
+                        logger.warning("Reads without PHRED scores found; cannot filter by --min-basequal")
+                        warned_about_quals = True
                     engine.tabulate_view(view, record_base=n_reads)
                     n_reads += int(view.n_reads)
                 engine.sync()

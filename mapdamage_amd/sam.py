@@ -450,7 +450,8 @@ class GpuBamStream:
             raise ValueError("%r: %s" % (str(path), self._error()))
         if min_basequal:
             # --min-basequal: unmaskable records are flagged on the device, see ``missing_qualities``
-            self._lib.mdx_gbam_set_min_basequal(self._g, int(min_basequal))
+            if self._lib.mdx_gbam_set_min_basequal(self._g, int(min_basequal)) != 0:
+                raise ValueError("%r: %s" % (str(path), self._error()))
         # the SEQ column of the views: BAM's nibbles kept as nibbles (MDX_SEQ_4BIT: the packed kernel — with --min-basequal
         # its masked form — reads them) unless the launches behind it read ASCII anyway (the rescale kernels of
         # --rescale-only want the qualities without a threshold); ``packed`` overrides the choice

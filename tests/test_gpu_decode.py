@@ -540,6 +540,9 @@ def test_the_device_decoder_folds_the_mask_into_the_seq_column(tmp_path):
                 slabs += 1
             got = eng.finish()
             assert slabs > 2 and eng.packed_launches() == slabs
+        # (a decoder at another threshold than its context's would hand out columns masked for the wrong one: refused)
+        with pytest.raises(ValueError, match="not the --min-basequal of the context"):
+            sam.GpuBamStream(eng, str(path), readgroups=list(lib_of.items()), chunk_bytes=1 << 19, want_qual=True, min_basequal=Q + 1)
     assert_tables_equal(got, want)
 
 

@@ -430,6 +430,20 @@ def test_hip_min_basequal_mask_in_the_column_or_folded_per_launch(mid_genome):
             with pytest.raises(MdxError, match="MDX_SEQ_4BITQ"):
                 eng0.tabulate_view(view)
             db.free()
+            # a caller's own batch folded ONCE (mdx_batch_fold): in place, MDX_SEQ_4BITQ from then on — every launch behind it is
+            # the resident batch's launch
+            view = MdxBatch()
+            ctypes.memmove(ctypes.byref(view), ctypes.byref(plain.dev), ctypes.sizeof(MdxBatch))
+            with pytest.raises(MdxError, match="no --min-basequal"):
+                eng0.fold(view)
+            eng.fold(view)
+            assert view.seq_format == 2
+            eng.fold(view)                          # (again: nothing to do)
+            want = oracle_tableset(mid_genome, batch, libs, 70, 10, 20)
+            for _ in range(2):
+                eng.reset()
+                eng.tabulate_view(view)
+                assert_tables_equal(eng.finish(), want)
         plain.free()
 
 
@@ -730,3 +744,38 @@ def test_hip_host_batches_in_flight_and_record_base():
         with pytest.raises(BadReadError) as err:
             eng.tabulate(broken.slice(16_000, 16_500))
         assert err.value.read_index == bad_at - 16_000
+
+
+@pytest.mark.gpu
+def test_hip_a_batch_ordered_by_library_belongs_to_the_layout_it_was_built_for(mid_genome):
+    """mdx_batch::libsort (the resident batch's copy ordered by library, statistics.py:12-20) is laid out for the batch's sizes
+    and the libraries of the context that uploaded it: a context with another number of libraries, or a view of a part of the
+    batch, refuses it instead of reading it through the wrong offsets."""
+    import ctypes
+
+    from mapdamage_amd.engine import DamageEngine, MdxBatch, MdxError
+    batch = synth.make_reads(mid_genome, 20_000, 23, len_range=(30, 120), nlib=2, paired=True, frac_softclip=0.1, frac_ins=0.04,
+                             frac_del=0.04)
+    libs2, libs3 = [("s", "a"), ("s", "b")], [("s", "a"), ("s", "b"), ("s", "c")]
+    with DamageEngine(libs2, 70, 10, 0) as eng2, DamageEngine(libs3, 70, 10, 0) as eng3:
+        eng2.set_reference(mid_genome)
+        eng3.set_reference(mid_genome)
+        db = eng2.upload(batch, packed=True)
+        assert db.dev.libsort
+        eng2.tabulate(db)
+        assert_tables_equal(eng2.finish(), oracle_tableset(mid_genome, batch, libs2, 70, 10, 0))
+        view = MdxBatch()
+        ctypes.memmove(ctypes.byref(view), ctypes.byref(db.dev), ctypes.sizeof(MdxBatch))
+        with pytest.raises(MdxError, match="mdx_batch::libsort was built for another batch"):
+            eng3.tabulate_view(view)
+        view.n_reads = batch.n // 2
+        view.n_cigar = int(batch.cigar_off[batch.n // 2])
+        view.n_bases = int(batch.seq_off[batch.n // 2])
+        with pytest.raises(MdxError, match="mdx_batch::libsort was built for another batch"):
+            eng2.tabulate_view(view)
+        # (without the copy the same views are sorted inside the launch and counted)
+        view.libsort = None
+        eng2.reset()
+        eng2.tabulate_view(view)
+        assert_tables_equal(eng2.finish(), oracle_tableset(mid_genome, batch.slice(0, batch.n // 2), libs2, 70, 10, 0))
+        db.free()
