@@ -138,6 +138,18 @@ typedef long long i64;
 #ifndef MDX_PKM_PD
 #define MDX_PKM_PD 3                    // ... and with --min-basequal
 #endif
+#ifndef MDX_PK_PD_ML
+#define MDX_PK_PD_ML 3                  // ... and of the launches over several libraries (a pool's library, its records' place
+#endif                                  // in the batch ordered by library and the pools that share its tiles want registers too)
+#ifndef MDX_PKM_PD_ML
+#define MDX_PKM_PD_ML 1                 // ... with --min-basequal (rounds and a second set of planes: 32 registers spilled at best)
+#endif
+#ifndef MDX_PD_P_ML
+#define MDX_PD_P_ML 2                   // ... their runs of partial entries (three: 4 registers spilled; two: none)
+#endif
+#ifndef MDX_PD_G_ML
+#define MDX_PD_G_ML 1                   // ... and of single-indel entries
+#endif
 #ifndef MDX_PREFIX
 #define MDX_PREFIX 1                    // plain prefixes of gapped records through the fast step
 #endif
@@ -1657,7 +1669,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 };
                 // (--min-basequal: three — the second set of planes and the bitmap words want the registers of the fourth)
-                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? MDX_PD_G : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : MDX_PD_P) : (MASK ? MDX_PKM_PD : MDX_PK_PD));
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? (ML ? MDX_PD_G_ML : MDX_PD_G) : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : (ML ? MDX_PD_P_ML : MDX_PD_P)) : (MASK ? (ML ? MDX_PKM_PD_ML : MDX_PKM_PD) : (ML ? MDX_PK_PD_ML : MDX_PK_PD)));
                 static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
                 St16 st[PD4];
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),

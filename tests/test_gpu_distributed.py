@@ -76,7 +76,7 @@ def test_bench_line_with_rccl_initialised(tmp_path):
     assert line["n_gpus"] == 1 and line["parity"].startswith("bit-exact")
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     sec = line["secondary"]
-    assert set(sec) == {"config2", "config4", "config5", "minqual", "nlib8", "file_to_tables", "config3_genome3g", "file_to_tables_50m",
+    assert set(sec) == {"config2", "config4", "config5", "minqual", "nlib8", "nlib8_q20", "rescale_file", "file_to_tables", "config3_genome3g", "file_to_tables_50m",
                         "cli_wall"}
     assert sec["minqual"]["q20_kernel_ms"] > 0 and sec["minqual"]["q0_kernel_ms"] > 0
     # (eight libraries: one launch of the packed kernel per call, the resident batch brings its copy ordered by library)
