@@ -150,6 +150,7 @@ struct mdx_ctx {
     DevBuf libsort;        // several libraries, packed kernel: the batch's columns bucketed by library (a batch that does not bring them)
     DevBuf libsort_scratch;
     const void *libsort_checked = nullptr;   // the batch's own blob (mdx_batch::libsort) whose signature was read back last
+    uint64_t libsort_checked_sig = 0;        // ... and that signature
     DevBuf ml_partials;    // ... and the plan of a launch over several libraries: which library a pool of blocks counts (MdxTabArgs::ml_plan)
     int64_t n_libsorts = 0;        // sorts done inside a launch so far (a resident batch brings its own: mdx_batch::libsort)
     int64_t n_fused = 0;           // fused launches so far (mdx_fused_launches)
@@ -805,15 +806,18 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         if (ml) {
             // the batch ordered by library: its own copy (a resident batch's), or sorted now (once for all launches of the call)
             const void *blob = b->libsort;
-            if (blob && blob != c->libsort_checked) {
-                // (a batch's own copy: laid out for these sizes and this many libraries?  Read back once per blob.)
-                uint64_t sig = 0;
-                HIP_TRY(c, hipMemcpyAsync(&sig, (const char *)blob + 8, 8, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                if (sig != libsort_signature(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib))
+            if (blob) {
+                // (a batch's own copy: laid out for these sizes and this many libraries?  Its signature is read back once per blob.)
+                if (blob != c->libsort_checked) {
+                    uint64_t sig = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&sig, (const char *)blob + 8, 8, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    c->libsort_checked = blob;
+                    c->libsort_checked_sig = sig;
+                }
+                if (c->libsort_checked_sig != libsort_signature(b->n_reads, b->n_cigar, b->n_bases, c->cfg.nlib))
                     return fail(c, MDX_ERR_ARG, "mdx_batch::libsort was built for another batch or a context with another number of libraries: "
                                                 "upload the batch with the context that tabulates it, whole");
-                c->libsort_checked = blob;
             }
             if (!blob) {
                 if (lo == 0) {
