@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round, mdx_batch_fold; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
+#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round, mdx_batch_fold, mdx_bgzf_deflate; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -383,6 +383,17 @@ void mdx_bam_close(mdx_bam_stream *stream);
  * mdx_bam_patch_rescaled writes the chunk's records to `out` (capacity out_cap bytes: raw size + 7 per rescaled
  * record suffices), those with rescaled[i] != 0 with their QUAL replaced by qual_out[seq_off[i] ...] and an `MR:f`
  * tag (mr[i]) appended, every other byte unchanged. */
+/* The BGZF writer on the device (round 6): replaces zlib's deflate behind pysam's AlignmentFile(..., "wb") for the output of the
+ * rescaling pass (rescale.py:290-291, :344 — every record is written back; on sixteen host threads the output's blocks were
+ * 2.1 of the pass's 3.5 seconds).  `data` (host, n bytes of encoded BAM: header or records, any cut) is cut into blocks of
+ * 0xFF00 bytes, every block becomes one BGZF member — in four pieces, a lane per piece: LZ77 with one hash candidate that may
+ * reach back into the piece in front, a dynamic Huffman code of the piece's own counts, a stored block where that is not
+ * smaller, the pieces joined the way zlib's Z_SYNC_FLUSH joins blocks (csrc/mdx_deflate.h, held against zlib's inflate by
+ * tests/test_inflate_core.py) —, and the members are written side by side to `out` (host; n + (n / 0xFF00 + 1) * 64 bytes
+ * always suffice), *out_len their bytes.  No end-of-file marker.  Any inflater reads the result; it is not zlib's output bit
+ * for bit (3 % larger than its level 6 on BAM records with qualities, smaller than its level 1).  2.9 GB/s of records in, host
+ * buffer to host buffer (sixteen host threads at level 6: 0.63 GB/s).  Synchronous, on the context's stream. */
+int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out, int64_t out_cap, int64_t *out_len);
 /* mdx_mr_round: float("%.5f" % x) of rescale.py:275-276 for n MR sums (mr_raw of the rescale calls) on `threads` host threads —
  * the value printed with five decimals, read back, and narrowed to the 32 bits of an MR:f tag; NaN (a record written back
  * unchanged) gives 0. */

@@ -9,7 +9,7 @@ HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmdx.so"
 SOURCES = ["mdx_kernels.hip", "mdx_capi.cpp", "mdx_bamio.cpp", "mdx_gbam.hip", "mdx_libsort.hip", "mdx_fasta.hip"]
-HEADERS = [CSRC / "mdx_internal.h", CSRC / "mdx_inflate.h", CSRC / "mdx_crc32.h", HERE.parent / "include" / "mdx.h"]
+HEADERS = [CSRC / "mdx_internal.h", CSRC / "mdx_inflate.h", CSRC / "mdx_deflate.h", CSRC / "mdx_crc32.h", HERE.parent / "include" / "mdx.h"]
 
 
 def hipcc():

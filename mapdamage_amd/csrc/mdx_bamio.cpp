@@ -2062,6 +2062,88 @@ void mdx_gbam_close(mdx_gbam *g) {
     lap("handle");
 }
 
+// The BGZF writer on the device (include/mdx.h mdx_bgzf_deflate): `data` cut into members of 0xFF00 bytes, every member in
+// pieces, a lane per piece (mdx_gbam.hip), at most kBgzfBatch members per launch (their working memory: 300 KB each); the
+// members are put together on the device — header, pieces, CRC32, ISIZE — side by side and copied back.  The buffers stay with
+// the process (a few gigabytes of HBM: allocating them was a sixth of a call).
+namespace {
+struct BgzfBuffers {
+    int device = -1, cap_members = 0;
+    uint8_t *d_in = nullptr, *d_slots = nullptr, *d_out = nullptr;
+    uint32_t *d_sizes = nullptr;
+    unsigned long long *d_off = nullptr;
+    void *d_scratch = nullptr, *d_tab = nullptr;
+    void release() {
+        for (void *p : {(void *)d_in, (void *)d_slots, (void *)d_out, (void *)d_sizes, (void *)d_off, d_scratch, d_tab}) if (p) (void)hipFree(p);
+        d_in = d_slots = d_out = nullptr; d_sizes = nullptr; d_off = nullptr; d_scratch = d_tab = nullptr; cap_members = 0; device = -1;
+    }
+};
+std::mutex g_bgzf_mu;
+BgzfBuffers g_bgzf;
+}  // namespace
+
+int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out, int64_t out_cap, int64_t *out_len) {
+    if (!ctx || n < 0 || (n > 0 && !data) || !out || !out_len) return MDX_ERR_ARG;
+    *out_len = 0;
+    if (n == 0) return MDX_OK;
+    void *st_ = nullptr;
+    int device = 0;
+    if (mdx_ctx_stream(ctx, &st_, &device) != MDX_OK) return MDX_ERR_ARG;
+    hipStream_t st = (hipStream_t)st_;
+    if (hipSetDevice(device) != hipSuccess) return MDX_ERR_HIP;
+    static mdx_crc32::Tables tables;
+    static std::once_flag once;
+    std::call_once(once, [] { mdx_crc32::make_tables(tables); });
+    const int64_t total_members = (n + 0xFF00 - 1) / 0xFF00;
+    const int kBgzfBatch = 8192;
+    const int batch = (int)std::min<int64_t>(total_members, kBgzfBatch);
+    const int pieces = mdx_k_bgzf_pieces();
+    int rc = MDX_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess) { rc = MDX_ERR_HIP; (void)hipGetLastError(); } return e == hipSuccess; };
+    std::lock_guard<std::mutex> lk(g_bgzf_mu);
+    BgzfBuffers &B = g_bgzf;
+    try {
+        if (B.device != device || B.cap_members < batch) {
+            B.release();
+            if (ok(hipMalloc((void **)&B.d_in, (size_t)batch * 0xFF00 + 64)) && ok(hipMalloc((void **)&B.d_slots, (size_t)batch * pieces * mdx_k_bgzf_slot_bytes())) &&
+                ok(hipMalloc((void **)&B.d_out, (size_t)batch * 65536)) && ok(hipMalloc((void **)&B.d_sizes, (size_t)batch * pieces * 4)) &&
+                ok(hipMalloc((void **)&B.d_off, (size_t)batch * 8)) && ok(hipMalloc(&B.d_scratch, mdx_k_bgzf_scratch_bytes(batch))) &&
+                ok(hipMalloc(&B.d_tab, sizeof(tables))) && ok(hipMemcpy(B.d_tab, &tables, sizeof(tables), hipMemcpyHostToDevice))) {
+                B.device = device; B.cap_members = batch;
+            } else { B.release(); return MDX_ERR_HIP; }
+        }
+        std::vector<uint32_t> sizes((size_t)batch * (size_t)pieces);
+        std::vector<unsigned long long> offs((size_t)batch);
+        int64_t written = 0;
+        for (int64_t b0 = 0; b0 < total_members && rc == MDX_OK; b0 += batch) {
+            const int nb = (int)std::min<int64_t>(batch, total_members - b0);
+            const int64_t lo = b0 * 0xFF00, bytes = std::min<int64_t>(n - lo, (int64_t)nb * 0xFF00);
+            if (!ok(hipMemcpyAsync(B.d_in, data + lo, (size_t)bytes, hipMemcpyHostToDevice, st))) break;
+            mdx_k_bgzf_deflate(B.d_in, bytes, nb, B.d_slots, B.d_sizes, B.d_scratch, st);
+            if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(sizes.data(), B.d_sizes, (size_t)nb * pieces * 4, hipMemcpyDeviceToHost, st)) ||
+                !ok(hipStreamSynchronize(st))) break;
+            unsigned long long at = 0;
+            for (int b = 0; b < nb; b++) {
+                unsigned long long body = 0;
+                for (int q = 0; q < pieces; q++) body += sizes[(size_t)b * pieces + q];
+                if (body == 0 || body + 26 > 65536u) { rc = MDX_ERR_ARG; break; }
+                offs[(size_t)b] = at; at += body + 26;
+            }
+            if (rc != MDX_OK) break;
+            if (written + (int64_t)at > out_cap) { rc = MDX_ERR_ARG; break; }
+            if (!ok(hipMemcpyAsync(B.d_off, offs.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st))) break;
+            mdx_k_bgzf_gather(B.d_in, bytes, B.d_slots, B.d_sizes, B.d_off, nb, B.d_tab, B.d_out, st);
+            if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(out + written, B.d_out, (size_t)at, hipMemcpyDeviceToHost, st)) ||
+                !ok(hipStreamSynchronize(st))) break;
+            written += (int64_t)at;
+        }
+        if (rc == MDX_OK) *out_len = written;
+    } catch (...) {
+        rc = MDX_ERR_ARG;
+    }
+    return rc;
+}
+
 int mdx_host_threads(void) { return host_thread_budget(); }
 int mdx_host_pool_threads(void) { return (int)host_pool()->threads.size(); }
 

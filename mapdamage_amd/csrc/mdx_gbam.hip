@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "mdx_crc32.h"
+#include "mdx_deflate.h"
 #include "mdx_inflate.h"
 #include "mdx_internal.h"
 
@@ -355,4 +356,79 @@ void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *pre, const uint4 *cnt, i
                        c.cigar_off, c.seq_off, n_rec, n_cig, n_seq);
     if (n_rec > 0)
         hipLaunchKernelGGL(gbam_unpack_kernel, dim3((n_rec + 31) / 32), dim3(256), 0, s, unc, rec_off, n_rec, c);
+}
+
+// ---- the way back: BGZF members out of a stream of encoded records (the rescaling pass writes every record back,
+// rescale.py:290-291, :344).  A member = 0xFF00 bytes of the stream in PIECES pieces, a LANE per piece — a gigabyte of records is
+// sixty thousand independent pieces, and a lane's encoder (mdx_deflate.h: LZ77 with one hash candidate, reaching back into the
+// piece in front, a dynamic Huffman code of the piece's own counts) is serial from end to end —, its working memory (a
+// PieceScratch, 75 KB) and its output slot in HBM.  sizes[t] = the piece's bytes (0 for a piece behind the member's end).
+namespace {
+enum { BGZF_PIECE_SLOT = mdx_deflate::PIECE + 64 };
+__global__ void __launch_bounds__(64) bgzf_deflate_kernel(const uint8_t *__restrict__ in, long long n, int n_pieces, uint8_t *__restrict__ slots,
+                                                           uint32_t *__restrict__ sizes, mdx_deflate::PieceScratch *__restrict__ scratch) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n_pieces) return;
+    const int b = t / mdx_deflate::PIECES, q = t % mdx_deflate::PIECES;
+    const long long m0 = (long long)b * mdx_deflate::MAX_IN;
+    const uint32_t mlen = (uint32_t)(n - m0 < (long long)mdx_deflate::MAX_IN ? n - m0 : (long long)mdx_deflate::MAX_IN);
+    const uint32_t lo = (uint32_t)q * mdx_deflate::PIECE;
+    if (lo >= mlen && !(lo == 0 && mlen == 0)) { sizes[t] = 0; return; }
+    const uint32_t hi = lo + mdx_deflate::PIECE < mlen ? lo + mdx_deflate::PIECE : mlen;
+    sizes[t] = mdx_deflate::deflate_piece(in + m0, lo, hi, lo >= (uint32_t)mdx_deflate::PIECE ? lo - mdx_deflate::PIECE : 0u, hi == mlen,
+                                          slots + (size_t)t * BGZF_PIECE_SLOT, (uint32_t)BGZF_PIECE_SLOT, scratch[t]);
+}
+// A wavefront per member: the gzip header with the BC subfield, the member's pieces side by side, CRC32 (1 KiB per lane, the
+// partial values joined by the "append n zero bytes" matrices, as gbam_crc_kernel does it) and ISIZE — at offsets[b] of out.
+__global__ void __launch_bounds__(64) bgzf_gather_kernel(const uint8_t *__restrict__ in, long long n, const uint8_t *__restrict__ slots,
+                                                          const uint32_t *__restrict__ sizes, const unsigned long long *__restrict__ offsets,
+                                                          const mdx_crc32::Tables *__restrict__ tb, uint8_t *__restrict__ out) {
+    __shared__ u32 tab[1024];
+    const int lane = threadIdx.x, b = (int)blockIdx.x;
+    for (int i = lane; i < 1024; i += 64) tab[i] = (&tb->tab[0][0])[i];
+    __syncthreads();
+    const long long m0 = (long long)b * mdx_deflate::MAX_IN;
+    const u32 mlen = (u32)(n - m0 < (long long)mdx_deflate::MAX_IN ? n - m0 : (long long)mdx_deflate::MAX_IN);
+    const u32 lo = 1024u * (u32)lane;
+    const u32 m = lo < mlen ? (mlen - lo < 1024u ? mlen - lo : 1024u) : 0u;
+    const u32 mine = mdx_crc32::crc_bytes(tab, in + m0 + lo, m);
+    u32 crc = (u32)__builtin_amdgcn_readlane((int)mine, 0);
+    for (int i = 1; i < 64; i++) {
+        const u32 li = 1024u * (u32)i;
+        if (li >= mlen) break;
+        const u32 mi = mlen - li < 1024u ? mlen - li : 1024u;
+        crc = mdx_crc32::shift(tb->mat, crc, mi) ^ (u32)__builtin_amdgcn_readlane((int)mine, i);
+    }
+    uint8_t *dst = out + offsets[b];
+    u32 body = 0;
+    for (int q = 0; q < mdx_deflate::PIECES; q++) {
+        const u32 sz = sizes[b * mdx_deflate::PIECES + q];
+        const uint8_t *src = slots + (size_t)(b * mdx_deflate::PIECES + q) * BGZF_PIECE_SLOT;
+        for (u32 i = (u32)lane; i < sz; i += 64) dst[18 + body + i] = src[i];
+        body += sz;
+    }
+    if (lane == 0) {
+        const u32 total = body + 26;
+        const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        for (int i = 0; i < 16; i++) dst[i] = head[i];
+        dst[16] = (uint8_t)(total - 1); dst[17] = (uint8_t)((total - 1) >> 8);
+        uint8_t *t = dst + 18 + body;
+        t[0] = (uint8_t)crc; t[1] = (uint8_t)(crc >> 8); t[2] = (uint8_t)(crc >> 16); t[3] = (uint8_t)(crc >> 24);
+        t[4] = (uint8_t)mlen; t[5] = (uint8_t)(mlen >> 8); t[6] = (uint8_t)(mlen >> 16); t[7] = (uint8_t)(mlen >> 24);
+    }
+}
+}  // namespace
+int mdx_k_bgzf_pieces() { return mdx_deflate::PIECES; }
+size_t mdx_k_bgzf_slot_bytes() { return BGZF_PIECE_SLOT; }
+size_t mdx_k_bgzf_scratch_bytes(int n_members) { return (size_t)n_members * mdx_deflate::PIECES * sizeof(mdx_deflate::PieceScratch); }
+void mdx_k_bgzf_deflate(const uint8_t *d_in, long long n, int n_members, uint8_t *d_slots, uint32_t *d_sizes, void *d_scratch, hipStream_t s) {
+    if (n_members <= 0) return;
+    const int n_pieces = n_members * mdx_deflate::PIECES;
+    hipLaunchKernelGGL(bgzf_deflate_kernel, dim3((n_pieces + 63) / 64), dim3(64), 0, s, d_in, n, n_pieces, d_slots, d_sizes,
+                       (mdx_deflate::PieceScratch *)d_scratch);
+}
+void mdx_k_bgzf_gather(const uint8_t *d_in, long long n, const uint8_t *d_slots, const uint32_t *d_sizes, const unsigned long long *d_offsets,
+                       int n_members, const void *tables, uint8_t *d_out, hipStream_t s) {
+    if (n_members <= 0) return;
+    hipLaunchKernelGGL(bgzf_gather_kernel, dim3(n_members), dim3(64), 0, s, d_in, n, d_slots, d_sizes, d_offsets, (const mdx_crc32::Tables *)tables, d_out);
 }

@@ -433,3 +433,13 @@ void mdx_k_gbam_unpack(const uint8_t *unc, const uint4 *pre, const uint4 *cnt, i
 int mdx_fasta_to_device(const char *fasta_path, int32_t n_contig, const char *const *names, int missing_ok, int64_t *lengths,
                         std::vector<int64_t> &contig_off, std::string &err, hipStream_t stream,
                         uint8_t *(*alloc_out)(void *, int64_t), void *alloc_arg);
+
+// ---- BGZF members on the device (mdx_gbam.hip; host side: mdx_bgzf_deflate in mdx_bamio.cpp): member b of the input = bytes
+// [b * 0xFF00, ...) in mdx_k_bgzf_pieces() pieces, a lane and a slot (mdx_k_bgzf_slot_bytes()) each, sizes[piece] its bytes;
+// then header, pieces, CRC32 and ISIZE of every member at offsets[b] of the output
+int mdx_k_bgzf_pieces();
+size_t mdx_k_bgzf_slot_bytes();
+size_t mdx_k_bgzf_scratch_bytes(int n_members);
+void mdx_k_bgzf_deflate(const uint8_t *d_in, long long n, int n_members, uint8_t *d_slots, uint32_t *d_sizes, void *d_scratch, hipStream_t s);
+void mdx_k_bgzf_gather(const uint8_t *d_in, long long n, const uint8_t *d_slots, const uint32_t *d_sizes, const unsigned long long *d_offsets,
+                       int n_members, const void *tables, uint8_t *d_out, hipStream_t s);

@@ -37,7 +37,7 @@ EXPORTS = (
     "mdx_gbam_inflate_blocks", "mdx_set_record_base", "mdx_pack_seq", "mdx_gbam_set_seq_format", "mdx_packed_launches",
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
-    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device", "mdx_mr_round", "mdx_batch_fold",
+    "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device", "mdx_mr_round", "mdx_batch_fold", "mdx_bgzf_deflate",
     "mdx_fasta_index", "mdx_set_reference_fasta", "mdx_reference_fetch", "mdx_host_threads", "mdx_host_pool_threads", "mdx_warm",
 )
 
@@ -314,6 +314,19 @@ class DamageEngine:
         dev = MdxBatch()
         self._check(self._lib.mdx_batch_upload(self._ctx, ctypes.byref(hb), ctypes.byref(dev)))
         return DeviceBatch(self, dev, batch.n, int(batch.seq.shape[0]), int(batch.cigar.shape[0]))
+
+    def bgzf_deflate(self, data):
+        """``data`` (bytes-like, host) as BGZF members of 0xFF00 input bytes each, deflated on the device (include/mdx.h
+        ``mdx_bgzf_deflate``) -> uint8 array; no end-of-file marker."""
+        view = np.frombuffer(memoryview(data).cast("B"), np.uint8)
+        n = int(view.shape[0])
+        out = np.empty(n + (n // 0xFF00 + 1) * 64, np.uint8)      # (a member of stored pieces: 26 + 5 per piece more than its bytes)
+        out_len = ctypes.c_int64(0)
+        fn = self._lib.mdx_bgzf_deflate
+        fn.restype = ctypes.c_int
+        self._check(fn(self._ctx, ctypes.c_void_p(view.ctypes.data), ctypes.c_int64(n), ctypes.c_void_p(out.ctypes.data),
+                       ctypes.c_int64(out.shape[0]), ctypes.byref(out_len)))
+        return out[:out_len.value]
 
     def fold(self, dbatch):
         """--min-basequal folded into a device batch's own 4-bit SEQ column, once and in place (include/mdx.h

@@ -127,6 +127,10 @@ def build_parser():
                         "number of reads are decoded on the host)")
     g.add_argument("--host-decode", dest="gpu_decode", action="store_false",
                    help="decode on the host (multi-threaded BGZF/BAM decoder) even where the GPU path applies")
+    g.add_argument("--host-deflate", action="store_true",
+                   help="--rescale-only: deflate the output's BGZF blocks with zlib (level 6) on the host's threads, as htslib does "
+                        "behind the reference, instead of on the device (the default: four times as fast, the file 3 %% larger; the "
+                        "records are the same)")
     g.add_argument("--chunk-mb", type=_ranged(float, 0), default=1024,
                    help="decode a BAM file in chunks of this many MiB of uncompressed records, overlapped with "
                         "the tabulation of the previous chunk (0: decode the whole file first)")
@@ -196,7 +200,8 @@ def rescale_qual(options):
                 logger.warning("FASTA sequence %r is %s; the BAM header says %i bp — records mapped to it may fail",
                                name, "missing" if not have else "%i bp" % have, length)
         with DamageEngine([("*", "*")], options.length, options.around, 0, device=options.device) as engine:
-            summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model)
+            summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model,
+                                          device_deflate=not options.host_deflate)
     except RescaleError as error:
         logger.error("%s", error)
         return 1

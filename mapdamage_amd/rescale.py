@@ -163,15 +163,18 @@ def round_mr(mr_raw):
     return out
 
 
-def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20, timings=None):
+def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20, timings=None, device_deflate=True):
     """File-level mirror of ``_rescale_qual_core`` (rescale.py:285-365): every record of the BAM is
     written back, rescaled records get their new qualities and an ``MR:f`` tag, everything else in
     the record (name, MAPQ, mate fields, other tags) is preserved byte for byte.
     The file goes through in chunks: native decode (the encoded records kept), one rescale launch per chunk, the
     records patched natively, BGZF blocks deflated on a thread pool — host memory is bounded by the chunk and no
     per-record Python work is done.  Returns (substitution summary, per-status record counts).  ``timings`` (a dict): receives
-    the seconds spent decoding (BGZF inflate + unpack on the host's threads), in the rescaling call (columns to HBM, the
-    kernels, qualities / MR / status back), formatting MR, patching the records and deflating + writing the output."""
+    the seconds spent waiting for the decoder (BGZF inflate + unpack on the host's threads — the next chunk is decoded on a
+    helper thread under this one's work), in the rescaling call (columns to HBM, the kernels, qualities / MR / status back),
+    formatting MR, patching the records and deflating + writing the output.  ``device_deflate``: the output's BGZF members are
+    made on the device (``mdx_bgzf_deflate``; False: zlib level 6 on the host's threads, as htslib behind the reference does
+    — the output's records are the same either way, its compressed bytes are not)."""
     import time
     from .sam import BamStream, BgzfWriter, bam_header_bytes
     engine.set_reference(ref)
@@ -179,11 +182,16 @@ def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20, ti
     counts = np.zeros(5, np.int64)
     spent = {"decode": 0.0, "rescale": 0.0, "mr_format": 0.0, "patch": 0.0, "deflate_write": 0.0}
     clock = time.perf_counter
-    with BamStream(in_path, chunk_bytes=chunk_bytes, keep_raw=True) as stream, BgzfWriter(out_path) as out:
+    from concurrent.futures import ThreadPoolExecutor
+    with BamStream(in_path, chunk_bytes=chunk_bytes, keep_raw=True) as stream, \
+            BgzfWriter(out_path, engine=engine if device_deflate else None) as out, ThreadPoolExecutor(1) as ahead:
         out.write(bam_header_bytes(stream.header))
+        coming = ahead.submit(stream.next_chunk)
         while True:
             t0 = clock()
-            chunk = stream.next_chunk()
+            chunk = coming.result()
+            if chunk is not None:
+                coming = ahead.submit(stream.next_chunk)        # (decoded while this chunk is rescaled, patched and written)
             t1 = clock()
             spent["decode"] += t1 - t0
             if chunk is None:

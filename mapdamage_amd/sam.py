@@ -272,11 +272,15 @@ class BgzfWriter:
     the next chunk's decode, kernels and patching run under the deflate of this one's output, which is what bounds it), at most
     ``max_pending`` blocks — 256 MiB of input — wait at a time."""
 
-    def __init__(self, path, threads=None, max_pending=4096):
+    def __init__(self, path, threads=None, max_pending=4096, engine=None):
+        """``engine`` (a ``DamageEngine``): the members are made on its device instead (include/mdx.h ``mdx_bgzf_deflate``: a lane
+        per quarter of a member, 2.9 GB/s against 0.6 on sixteen threads; 3 % larger than zlib's level 6) — every ``write`` is
+        then compressed on its own, its last member as short as it comes."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         self._out = open(path, "wb")
-        self._pool = ThreadPoolExecutor(threads or min(32, usable_cpus()))
+        self._engine = engine
+        self._pool = None if engine is not None else ThreadPoolExecutor(threads or min(32, usable_cpus()))
         self._tail = b""
         self._pending = deque()
         self._max_pending = max_pending
@@ -289,6 +293,10 @@ class BgzfWriter:
     def write(self, data):
         """Append bytes (anything with the buffer protocol; the object must not change until the stream is closed or flushed)."""
         view = memoryview(data).cast("B")
+        if self._engine is not None:
+            if len(view):
+                self._out.write(self._engine.bgzf_deflate(view).data)
+            return
         if self._tail:
             view = memoryview(self._tail + view.tobytes())
         whole = len(view) // 0xFF00 * 0xFF00
@@ -311,7 +319,8 @@ class BgzfWriter:
         self._out.write(_bgzf_block(b""))
         self._out.close()
         self._out = None
-        self._pool.shutdown()
+        if self._pool is not None:
+            self._pool.shutdown()
 
     def __enter__(self):
         return self

@@ -762,3 +762,46 @@ def test_device_inflate_against_zlib_every_block_type_and_damage():
             bad.append((i, kind, status, len(ref), crc_ok))
     assert not bad, bad[:10]
     assert sum(1 for k, _ in expect if k == "refused") > 300 and sum(1 for k, _ in expect if k == "ok") > 20
+
+
+def test_device_bgzf_writer_is_read_by_every_decoder(tmp_path):
+    """mdx_bgzf_deflate (the rescaling pass's writer, rescale.py:290-291, :344): a stream of encoded records cut into blocks of
+    0xFF00 bytes, a lane per block on the device — the members must inflate (Python's gzip: header, CRC32, ISIZE checked) to the
+    bytes that went in, keep BGZF's BSIZE field, and, written as a BAM file, read back record for record through the host
+    decoder and the device decoder of this library."""
+    import gzip
+    import struct
+
+    from mapdamage_amd.engine import DamageEngine
+    ref, b, rg, _ = _write(tmp_path, n=30_000, seed=31)
+    plain = tmp_path / "plain.bam"
+    sam.write_bam(str(plain), b, ref.names, ref.lengths, RGS, rg_of_record=rg)
+    stream = gzip.decompress(plain.read_bytes())              # header + records, as htslib would hand them to bgzf_write
+    rnd = np.random.default_rng(3)
+    with DamageEngine([("s", "lib1"), ("s", "lib2")]) as eng:
+        for data in (stream, b"", b"x", stream[:0xFF00], stream[:0xFF00 + 1], rnd.integers(0, 256, 200_000, dtype=np.uint8).tobytes(),
+                     b"\x00" * 300_000):
+            members = bytes(eng.bgzf_deflate(data))
+            assert gzip.decompress(members) == data if data else members == b""
+            at, n_members = 0, 0
+            while at < len(members):
+                assert members[at:at + 4] == b"\x1f\x8b\x08\x04" and members[at + 12:at + 16] == b"BC\x02\x00"
+                at += struct.unpack_from("<H", members, at + 16)[0] + 1
+                n_members += 1
+            assert at == len(members) and n_members == (len(data) + 0xFF00 - 1) // 0xFF00
+        out = tmp_path / "device.bam"
+        out.write_bytes(bytes(eng.bgzf_deflate(stream)) + sam._bgzf_block(b""))
+        assert out.stat().st_size < 1.1 * plain.stat().st_size            # (zlib level 6 wrote the other one)
+        back = sam.read_bam_native(str(out))
+        for k in ("flag", "tid", "pos", "tlen", "cigar", "seq", "qual"):
+            np.testing.assert_array_equal(getattr(back.batch, k), getattr(b, k), err_msg=k)
+        eng.set_reference(ref)
+        lib_of = {"rgA": 0, "rg_b2": 1, "x": 0}
+        with sam.GpuBamStream(eng, str(out), readgroups=list(lib_of.items()), chunk_bytes=1 << 20) as g:
+            n = 0
+            while True:
+                v = g.next_view()
+                if v is None:
+                    break
+                n += int(v.n_reads)
+        assert n == b.n

@@ -59,3 +59,57 @@ def test_crc32_pieces_join_to_zlibs_value(tmp_path):
                            "-lz", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, timeout=60)
     assert out.returncode == 0 and out.stdout.decode().strip().endswith("0 bad"), out.stdout.decode()
+
+
+def test_deflate_core_is_read_by_zlib(tmp_path):
+    """The DEFLATE encoder of the device BGZF writer (mapdamage_amd/csrc/mdx_deflate.h: one block per lane on the GPU,
+    tests/test_gpu_decode.py) compiled for the host: every block it writes — BGZF member around it — must inflate under zlib
+    (which checks the gzip header, CRC32 and ISIZE itself) to the bytes that went in.  Empty and tiny blocks, incompressible
+    ones (a stored block), runs, repeats at every distance, alphabets skewed enough to need the length limit of 15 bits,
+    BAM-like records."""
+    exe = tmp_path / "deflate_check"
+    subprocess.check_call(["g++", "-O2", "-I", str(ROOT / "mapdamage_amd" / "csrc"), str(ROOT / "tests" / "native" / "deflate_check.cpp"),
+                           "-lz", "-o", str(exe)])
+    rnd = random.Random(1)
+    full = 0xFF00
+    datas = [b"", b"a", b"ab", b"abc", b"abcd", b"aaaa", b"abc" * 1000, bytes(rnd.getrandbits(8) for _ in range(60000)),
+             bytes(rnd.choice(b"ACGT") for _ in range(full)), b"\x00" * full, os.urandom(100), os.urandom(full),
+             bytes(rnd.choice(b"ACGTN!#$%&'()*+,-./0123456789") for _ in range(30000)),
+             b"ACGT" * 3000 + os.urandom(30000) + b"TTTTGGGG" * 2000, bytes([i % 251 for i in range(65000)]),
+             bytes(rnd.choice(b"ab") for _ in range(full)), b"x" * 258 + b"y" + b"x" * 259 + b"z" + b"x" * 40000]
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    skew = bytearray()
+    for i, f in enumerate(fib[:24]):
+        skew += bytes([i]) * min(f, 20000)
+    skew = list(skew)
+    rnd.shuffle(skew)
+    datas.append(bytes(skew[:full]))
+    for _ in range(120):
+        n = rnd.randint(0, full)
+        kind = rnd.randint(0, 3)
+        if kind == 0:
+            d = os.urandom(n)
+        elif kind == 1:
+            d = bytes(rnd.choice(b"ACGT") for _ in range(n))
+        elif kind == 2:
+            w = os.urandom(rnd.randint(1, 300))
+            d = (w * (n // len(w) + 1))[:n]
+        else:
+            d = bytearray()
+            while len(d) < n:
+                if d and rnd.random() < 0.5:
+                    st = rnd.randint(0, len(d) - 1)
+                    d += d[st:st + rnd.randint(1, 400)]
+                else:
+                    d += os.urandom(rnd.randint(1, 50))
+            d = bytes(d[:n])
+        datas.append(d)
+    blob = bytearray()
+    for d in datas:
+        blob += struct.pack("<I", len(d)) + d
+    path = tmp_path / "cases.bin"
+    path.write_bytes(blob)
+    out = subprocess.run([str(exe), str(path)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok %d cases" % len(datas)), out.stdout + out.stderr
