@@ -280,13 +280,18 @@ class BgzfWriter:
         from concurrent.futures import ThreadPoolExecutor
         self._out = open(path, "wb")
         self._engine = engine
-        self._pool = None if engine is not None else ThreadPoolExecutor(threads or min(32, usable_cpus()))
+        # (engine: one thread writes the finished members to the file, in order, while the next piece is compressed)
+        self._pool = ThreadPoolExecutor(1) if engine is not None else ThreadPoolExecutor(threads or min(32, usable_cpus()))
         self._tail = b""
         self._pending = deque()
         self._max_pending = max_pending
 
     def _drain(self, keep):
         """Write the finished blocks at the head of the queue; wait for the oldest ones while more than ``keep`` are queued."""
+        if self._engine is not None:
+            while len(self._pending) > keep:
+                self._pending.popleft().result()
+            return
         while self._pending and (len(self._pending) > keep or self._pending[0].done()):
             self._out.write(self._pending.popleft().result())
 
@@ -295,7 +300,10 @@ class BgzfWriter:
         view = memoryview(data).cast("B")
         if self._engine is not None:
             if len(view):
-                self._out.write(self._engine.bgzf_deflate(view).data)
+                members = self._engine.bgzf_deflate(view)
+                self._pending.append(self._pool.submit(self._out.write, members.data))
+                while len(self._pending) > 2:           # (two pieces' members waiting for the disk at most)
+                    self._pending.popleft().result()
             return
         if self._tail:
             view = memoryview(self._tail + view.tobytes())
@@ -319,8 +327,7 @@ class BgzfWriter:
         self._out.write(_bgzf_block(b""))
         self._out.close()
         self._out = None
-        if self._pool is not None:
-            self._pool.shutdown()
+        self._pool.shutdown()
 
     def __enter__(self):
         return self
