@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round, mdx_batch_fold, mdx_bgzf_deflate; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
+#define MDX_ABI_VERSION 6   /* 6: mdx_fasta_index, mdx_set_reference_fasta, mdx_reference_fetch, mdx_host_threads, mdx_warm, mdx_*_patches_device, mdx_rescale_expand_device, mdx_mr_round, mdx_batch_fold, mdx_bgzf_deflate, mdx_gbam_rescale_slab / _write_rescaled / _record_name; 2: mdx_batch::seq_format, mdx_pack_seq, mdx_gbam_set_seq_format; 3: mdx_gbam_tell / _fixups, mdx_bam_seek; 4: mdx_batch::lowq (the struct grew by one pointer); 5: mdx_batch::libsort (another one), mdx_libsorts, mdx_gbam_view_flags / _set_flags */
 
 #define MDX_OK 0
 #define MDX_ERR_ARG (-1)          /* bad argument / unsupported configuration */
@@ -394,6 +394,24 @@ void mdx_bam_close(mdx_bam_stream *stream);
  * for bit (3 % larger than its level 6 on BAM records with qualities, smaller than its level 1).  2.9 GB/s of records in, host
  * buffer to host buffer (sixteen host threads at level 6: 0.63 GB/s).  Synchronous, on the context's stream. */
 int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out, int64_t out_cap, int64_t *out_len);
+/* --rescale-only with the records never on the host (round 6; rescale.py:285-365).  The handle is configured with qualities
+ * and mate columns and hands out ASCII seq columns (mdx_gbam_configure(.., want_qual = 1, want_mate = 1)); after every
+ * mdx_gbam_next:
+ *   mdx_gbam_rescale_slab   the slab's records through the context's rescale kernels (mdx_rescale_set_model first; the list
+ *                           form, mdx_rescale_patches_device), the new quality bytes into the QUAL fields of the inflated
+ *                           records in HBM, MR rounded as rescale.py:275-276 does, every record — rescaled ones with an MR:f tag
+ *                           appended — laid out as the output stream in HBM and compressed there (mdx_bgzf_deflate's kernels): `out`
+ *                           (host; the slab's inflated size + 7 bytes per record + 64 per member always suffice) receives BGZF
+ *                           members only.  counts[0..5) += records by routing status (rescale.py:300-342).  A rescaled record
+ *                           that has an MR tag already: MDX_ERR_BAD_READ, *mr_clash = its index in the slab (rescale.py:277-278;
+ *                           mdx_gbam_record_name gives its name); a record the kernels cannot process: *mr_clash = -2 - index.
+ *   mdx_gbam_write_rescaled the second half on its own, for a caller that ran the rescale kernels itself: patch list (device),
+ *                           mr / rescaled per record (host).
+ * The file's header is the caller's to write (mdx_bgzf_deflate takes any bytes), and the end-of-file marker. */
+int mdx_gbam_rescale_slab(struct mdx_gbam *g, uint8_t *out, int64_t out_cap, int64_t *out_len, int64_t *counts, int64_t *mr_clash);
+int mdx_gbam_write_rescaled(struct mdx_gbam *g, const uint64_t *d_patch, int64_t patch_cap, int32_t n_parts, const uint64_t *d_n_patch,
+                            const float *mr, const uint8_t *rescaled, uint8_t *out, int64_t out_cap, int64_t *out_len, int64_t *mr_clash);
+int mdx_gbam_record_name(struct mdx_gbam *g, int64_t index, char *buf, int32_t cap);
 /* mdx_mr_round: float("%.5f" % x) of rescale.py:275-276 for n MR sums (mr_raw of the rescale calls) on `threads` host threads —
  * the value printed with five decimals, read back, and narrowed to the 32 bits of an MR:f tag; NaN (a record written back
  * unchanged) gives 0. */

@@ -1185,6 +1185,8 @@ struct mdx_gbam {
     } slab[2];
     int cur = 0;                         // the slab the next call hands out
     int view_slab = 0;                   // ... and the one the last call did (mdx_gbam_view_flags)
+    mdx_batch last_view{};               // ... its view (mdx_gbam_rescale_slab)
+    const int32_t *last_mtid = nullptr, *last_mpos = nullptr;
     bool reserve(Buf &b, size_t bytes) {
         if (bytes <= b.cap) return true;
         if (b.p) (void)hipFree(b.p);
@@ -1805,6 +1807,7 @@ static int gbam_half_b(mdx_gbam *g, mdx_gbam::Slab &s, mdx_batch *view, const in
     }
     if (d_mtid) *d_mtid = c.mtid;
     if (d_mpos) *d_mpos = c.mpos;
+    g->last_view = *view; g->last_mtid = c.mtid; g->last_mpos = c.mpos;
     g->next_block = b1;
     g->phase = next_phase;
     g->phase_known = have;
@@ -2082,21 +2085,20 @@ std::mutex g_bgzf_mu;
 BgzfBuffers g_bgzf;
 }  // namespace
 
-int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out, int64_t out_cap, int64_t *out_len) {
-    if (!ctx || n < 0 || (n > 0 && !data) || !out || !out_len) return MDX_ERR_ARG;
+// (d_data: the stream is in HBM already — no copy in; else `data` on the host)
+static int bgzf_deflate_impl(hipStream_t st, int device, const uint8_t *data, const uint8_t *d_data, int64_t n, uint8_t *out, int64_t out_cap,
+                             int64_t *out_len) {
     *out_len = 0;
     if (n == 0) return MDX_OK;
-    void *st_ = nullptr;
-    int device = 0;
-    if (mdx_ctx_stream(ctx, &st_, &device) != MDX_OK) return MDX_ERR_ARG;
-    hipStream_t st = (hipStream_t)st_;
     if (hipSetDevice(device) != hipSuccess) return MDX_ERR_HIP;
     static mdx_crc32::Tables tables;
     static std::once_flag once;
     std::call_once(once, [] { mdx_crc32::make_tables(tables); });
     const int64_t total_members = (n + 0xFF00 - 1) / 0xFF00;
     const int kBgzfBatch = 8192;
-    const int batch = (int)std::min<int64_t>(total_members, kBgzfBatch);
+    // (buffers for as many members as this call has, never fewer than a fifth of a launch's — a process that writes a header
+    // first and a gigabyte behind it allocates once)
+    const int batch = (int)std::min<int64_t>(std::max<int64_t>(total_members, kBgzfBatch / 4), kBgzfBatch);
     const int pieces = mdx_k_bgzf_pieces();
     int rc = MDX_OK;
     auto ok = [&](hipError_t e) { if (e != hipSuccess) { rc = MDX_ERR_HIP; (void)hipGetLastError(); } return e == hipSuccess; };
@@ -2118,8 +2120,9 @@ int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out,
         for (int64_t b0 = 0; b0 < total_members && rc == MDX_OK; b0 += batch) {
             const int nb = (int)std::min<int64_t>(batch, total_members - b0);
             const int64_t lo = b0 * 0xFF00, bytes = std::min<int64_t>(n - lo, (int64_t)nb * 0xFF00);
-            if (!ok(hipMemcpyAsync(B.d_in, data + lo, (size_t)bytes, hipMemcpyHostToDevice, st))) break;
-            mdx_k_bgzf_deflate(B.d_in, bytes, nb, B.d_slots, B.d_sizes, B.d_scratch, st);
+            const uint8_t *src = d_data ? d_data + lo : B.d_in;
+            if (!d_data && !ok(hipMemcpyAsync(B.d_in, data + lo, (size_t)bytes, hipMemcpyHostToDevice, st))) break;
+            mdx_k_bgzf_deflate(src, bytes, nb, B.d_slots, B.d_sizes, B.d_scratch, st);
             if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(sizes.data(), B.d_sizes, (size_t)nb * pieces * 4, hipMemcpyDeviceToHost, st)) ||
                 !ok(hipStreamSynchronize(st))) break;
             unsigned long long at = 0;
@@ -2132,7 +2135,7 @@ int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out,
             if (rc != MDX_OK) break;
             if (written + (int64_t)at > out_cap) { rc = MDX_ERR_ARG; break; }
             if (!ok(hipMemcpyAsync(B.d_off, offs.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st))) break;
-            mdx_k_bgzf_gather(B.d_in, bytes, B.d_slots, B.d_sizes, B.d_off, nb, B.d_tab, B.d_out, st);
+            mdx_k_bgzf_gather(src, bytes, B.d_slots, B.d_sizes, B.d_off, nb, B.d_tab, B.d_out, st);
             if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(out + written, B.d_out, (size_t)at, hipMemcpyDeviceToHost, st)) ||
                 !ok(hipStreamSynchronize(st))) break;
             written += (int64_t)at;
@@ -2142,6 +2145,154 @@ int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out,
         rc = MDX_ERR_ARG;
     }
     return rc;
+}
+
+int mdx_bgzf_deflate(mdx_ctx *ctx, const uint8_t *data, int64_t n, uint8_t *out, int64_t out_cap, int64_t *out_len) {
+    if (!ctx || n < 0 || (n > 0 && !data) || !out || !out_len) return MDX_ERR_ARG;
+    void *st_ = nullptr;
+    int device = 0;
+    if (mdx_ctx_stream(ctx, &st_, &device) != MDX_OK) return MDX_ERR_ARG;
+    return bgzf_deflate_impl((hipStream_t)st_, device, data, nullptr, n, out, out_cap, out_len);
+}
+
+// The slab mdx_gbam_next handed out last, written back (include/mdx.h): patch list -> QUAL fields of the inflated records in
+// HBM, sizes -> host -> offsets (a prefix sum of a few million numbers), records + MR tags to their places in an output stream
+// in HBM, that stream through the device's BGZF writer; only the compressed members come back.
+int mdx_gbam_write_rescaled(mdx_gbam *g, const uint64_t *d_patch, int64_t patch_cap, int32_t n_parts, const uint64_t *d_n_patch,
+                            const float *mr, const uint8_t *rescaled, uint8_t *out, int64_t out_cap, int64_t *out_len, int64_t *mr_clash) {
+    if (!g || !out || !out_len || patch_cap < 0 || (n_parts > 0 && (!d_patch || !d_n_patch))) return MDX_ERR_ARG;
+    *out_len = 0;
+    if (mr_clash) *mr_clash = -1;
+    const int64_t n = g->view_reads;
+    if (n == 0) return MDX_OK;
+    if (!mr || !rescaled) return MDX_ERR_ARG;
+    try {
+        if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+        hipStream_t st = g->stream;
+        mdx_gbam::Slab &s = g->slab[g->view_slab];
+        uint8_t *d_resc = nullptr, *d_stream = nullptr;
+        float *d_mr = nullptr;
+        uint32_t *d_sizes = nullptr;
+        unsigned long long *d_off = nullptr;
+        int *d_clash = nullptr;
+        int rc = MDX_OK;
+        auto ok = [&](hipError_t e) { if (e != hipSuccess) { rc = MDX_ERR_HIP; g->error = std::string("write_rescaled: ") + hipGetErrorString(e); (void)hipGetLastError(); } return e == hipSuccess; };
+        std::vector<uint32_t> sizes((size_t)n);
+        std::vector<unsigned long long> offs((size_t)n);
+        const int no_clash = 0x7FFFFFFF;
+        int clash = no_clash;
+        if (ok(hipMalloc((void **)&d_resc, (size_t)n)) && ok(hipMalloc((void **)&d_mr, (size_t)n * 4)) && ok(hipMalloc((void **)&d_sizes, (size_t)n * 4)) &&
+            ok(hipMalloc((void **)&d_off, (size_t)n * 8)) && ok(hipMalloc((void **)&d_clash, 4)) &&
+            ok(hipMemcpyAsync(d_resc, rescaled, (size_t)n, hipMemcpyHostToDevice, st)) && ok(hipMemcpyAsync(d_mr, mr, (size_t)n * 4, hipMemcpyHostToDevice, st)) &&
+            ok(hipMemcpyAsync(d_clash, &no_clash, 4, hipMemcpyHostToDevice, st))) {
+            if (n_parts > 0)
+                mdx_k_gbam_patch_qual((uint8_t *)s.unc.p, (const uint32_t *)s.rec_off.p, (const uint32_t *)s.seq_off.p, (uint32_t)n,
+                                      (const unsigned long long *)d_patch, (const unsigned long long *)d_n_patch, patch_cap, n_parts, st);
+            mdx_k_gbam_out_sizes((const uint8_t *)s.unc.p, (const uint32_t *)s.rec_off.p, d_resc, (uint32_t)n, d_sizes, st);
+            if (ok(hipGetLastError()) && ok(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)n * 4, hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st))) {
+                unsigned long long total = 0;
+                for (int64_t i = 0; i < n; i++) { offs[(size_t)i] = total; total += sizes[(size_t)i]; }
+                if (ok(hipMalloc((void **)&d_stream, (size_t)total + 64)) && ok(hipMemcpyAsync(d_off, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, st))) {
+                    mdx_k_gbam_write_back((const uint8_t *)s.unc.p, (const uint32_t *)s.rec_off.p, d_off, d_resc, d_mr, (uint32_t)n, d_stream, d_clash, st);
+                    if (ok(hipGetLastError()) && ok(hipMemcpyAsync(&clash, d_clash, 4, hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st))) {
+                        if (clash != no_clash) {
+                            if (mr_clash) *mr_clash = clash;
+                            g->error = "record " + std::to_string(clash) + " of the slab is to be rescaled and has an MR tag already";
+                            rc = MDX_ERR_BAD_READ;
+                        } else {
+                            rc = bgzf_deflate_impl(st, g->device, nullptr, d_stream, (int64_t)total, out, out_cap, out_len);
+                            if (rc != MDX_OK) g->error = "the BGZF writer failed (output buffer too small?)";
+                        }
+                    }
+                }
+            }
+        }
+        for (void *p : {(void *)d_resc, (void *)d_mr, (void *)d_sizes, (void *)d_off, (void *)d_clash, (void *)d_stream}) if (p) (void)hipFree(p);
+        return rc;
+    } catch (const std::exception &e) {
+        g->error = std::string("mdx_gbam_write_rescaled: ") + e.what();
+        return MDX_ERR_ARG;
+    }
+}
+
+// the name of record `index` of that slab (for the message of rescale.py:277-278); buf holds cap bytes
+int mdx_gbam_record_name(mdx_gbam *g, int64_t index, char *buf, int32_t cap) {
+    if (!g || !buf || cap < 1 || index < 0 || index >= g->view_reads) return MDX_ERR_ARG;
+    buf[0] = 0;
+    if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+    mdx_gbam::Slab &s = g->slab[g->view_slab];
+    uint32_t off = 0;
+    uint8_t head[12];
+    if (hipMemcpy(&off, (const uint32_t *)s.rec_off.p + index, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(head, (const uint8_t *)s.unc.p + off, 12, hipMemcpyDeviceToHost) != hipSuccess) return MDX_ERR_HIP;
+    const int len = std::min<int>(head[8], cap - 1);
+    if (len > 0 && hipMemcpy(buf, (const uint8_t *)s.unc.p + off + 32, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) return MDX_ERR_HIP;
+    buf[len] = 0;
+    return MDX_OK;
+}
+
+// One call per slab of a --rescale-only pass on the device (rescale.py:285-365): the view mdx_gbam_next handed out last (it
+// must bring qualities, mate columns and an ASCII seq column) through the context's rescale kernels in patch mode, MR rounded
+// on the host (rescale.py:275-276, mdx_mr_round), the records written back (mdx_gbam_write_rescaled).
+int mdx_gbam_rescale_slab(mdx_gbam *g, uint8_t *out, int64_t out_cap, int64_t *out_len, int64_t *counts, int64_t *mr_clash) {
+    if (!g || !out || !out_len) return MDX_ERR_ARG;
+    *out_len = 0;
+    if (mr_clash) *mr_clash = -1;
+    const int64_t n = g->view_reads;
+    if (n == 0) return MDX_OK;
+    const mdx_batch &v = g->last_view;
+    if (!v.qual || !g->last_mtid || !g->last_mpos || v.seq_format != MDX_SEQ_ASCII) {
+        g->error = "mdx_gbam_rescale_slab: the handle must be configured with qualities and mate columns, the seq column ASCII";
+        return MDX_ERR_STATE;
+    }
+    try {
+        if (hipSetDevice(g->device) != hipSuccess) return MDX_ERR_HIP;
+        hipStream_t st = g->stream;
+        const int parts = 256;
+        const int64_t cap = std::max<int64_t>(4096, 8 * n / parts);
+        uint64_t *d_patch = nullptr, *d_count = nullptr;
+        double *d_mr = nullptr;
+        uint8_t *d_status = nullptr;
+        int rc = MDX_OK;
+        auto ok = [&](hipError_t e) { if (e != hipSuccess) { rc = MDX_ERR_HIP; g->error = std::string("rescale_slab: ") + hipGetErrorString(e); (void)hipGetLastError(); } return e == hipSuccess; };
+        std::vector<double> mr_raw((size_t)n);
+        std::vector<uint8_t> status((size_t)n), rescaled((size_t)n);
+        std::vector<float> mr((size_t)n);
+        std::vector<uint64_t> cnt((size_t)parts);
+        if (ok(hipMalloc((void **)&d_count, (size_t)parts * 8)) && ok(hipMalloc((void **)&d_mr, (size_t)n * 8)) && ok(hipMalloc((void **)&d_status, (size_t)n))) {
+            // (eight entries of room per record, in 256 parts: this workload's records change 0.11 bytes each; a part that
+            // overflows is an error — a second launch would count the records into the summary twice)
+            if (ok(hipMalloc((void **)&d_patch, (size_t)parts * (size_t)cap * 8))) {
+                rc = mdx_rescale_patches_device(g->ctx, &v, g->last_mtid, g->last_mpos, d_patch, cap, parts, d_count, d_mr, d_status);
+                if (rc != MDX_OK) g->error = std::string("rescale kernels: ") + mdx_last_error(g->ctx);
+                else if (ok(hipMemcpyAsync(cnt.data(), d_count, (size_t)parts * 8, hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st))) {
+                    uint64_t fullest = 0;
+                    for (uint64_t c_ : cnt) fullest = std::max(fullest, c_);
+                    if ((int64_t)fullest > cap) { g->error = "rescale_slab: more rescaled bytes than the list holds"; rc = MDX_ERR_ARG; }
+                }
+            }
+        }
+        if (rc == MDX_OK) {
+            int64_t bad = -1;
+            rc = mdx_sync(g->ctx, &bad);
+            if (rc != MDX_OK) { g->error = std::string("rescale kernels: ") + mdx_last_error(g->ctx); if (mr_clash && rc == MDX_ERR_BAD_READ) *mr_clash = -2 - bad; }
+        }
+        if (rc == MDX_OK && ok(hipMemcpyAsync(mr_raw.data(), d_mr, (size_t)n * 8, hipMemcpyDeviceToHost, st)) &&
+            ok(hipMemcpyAsync(status.data(), d_status, (size_t)n, hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st))) {
+            for (int64_t i = 0; i < n; i++) {
+                const uint8_t stv = status[(size_t)i];
+                rescaled[(size_t)i] = (stv == 2 || stv == 3) ? 1 : 0;
+                if (counts && stv < 5) counts[stv]++;
+            }
+            (void)mdx_mr_round(mr_raw.data(), n, mr.data(), host_thread_budget());
+            rc = mdx_gbam_write_rescaled(g, d_patch, cap, parts, d_count, mr.data(), rescaled.data(), out, out_cap, out_len, mr_clash);
+        }
+        for (void *p : {(void *)d_patch, (void *)d_count, (void *)d_mr, (void *)d_status}) if (p) (void)hipFree(p);
+        return rc;
+    } catch (const std::exception &e) {
+        g->error = std::string("mdx_gbam_rescale_slab: ") + e.what();
+        return MDX_ERR_ARG;
+    }
 }
 
 int mdx_host_threads(void) { return host_thread_budget(); }

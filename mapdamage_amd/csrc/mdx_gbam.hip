@@ -417,7 +417,88 @@ __global__ void __launch_bounds__(64) bgzf_gather_kernel(const uint8_t *__restri
         t[4] = (uint8_t)mlen; t[5] = (uint8_t)(mlen >> 8); t[6] = (uint8_t)(mlen >> 16); t[7] = (uint8_t)(mlen >> 24);
     }
 }
+// ---- the rescaled records of a decoded slab, written back on the device (rescale.py:266-273, :275-281, :344: new QUAL, an MR:f
+// tag, every other byte of the record as it stood): the slab's inflated bytes are still in HBM (`unc`), its records at rec_off.
+// (1) the patch list of the rescale kernels goes into the records' QUAL fields themselves
+__global__ void gbam_patch_qual_kernel(u8 *__restrict__ unc, const u32 *__restrict__ rec_off, const u32 *__restrict__ seq_off, u32 n_rec,
+                                       const u64 *__restrict__ patch, const u64 *__restrict__ n_patch, long long cap) {
+    const u64 n = n_patch[blockIdx.y] < (u64)cap ? n_patch[blockIdx.y] : (u64)cap;
+    const u64 *__restrict__ mine = patch + (size_t)blockIdx.y * (size_t)cap;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 e = mine[i];
+        const u32 idx = (u32)e;
+        // the record that holds byte idx of the quality column: the last one whose seq_off is at or below it
+        u32 lo = 0, hi = n_rec;
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (seq_off[mid] <= idx) lo = mid; else hi = mid; }
+        u8 *p = unc + rec_off[lo];
+        const u32 l_name = p[8], n_cig = g16(p + 12), l_seq = g32(p + 16);
+        const u32 at = idx - seq_off[lo];
+        if (at < l_seq) p[32 + l_name + 4u * n_cig + (l_seq + 1) / 2 + at] = (u8)(e >> 32);
+    }
+}
+// (2) the bytes every record takes in the output: its own, and seven more for the tag of a rescaled one
+__global__ void gbam_out_sizes_kernel(const u8 *__restrict__ unc, const u32 *__restrict__ rec_off, const u8 *__restrict__ rescaled, u32 n_rec,
+                                      u32 *__restrict__ sizes) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    sizes[r] = g32(unc + rec_off[r] - 4) + 4u + (rescaled[r] ? 7u : 0u);
+}
+// (3) eight lanes per record: the record to its place in the output stream; a rescaled one with block_size seven larger and
+// "MR" 'f' <float> behind its last tag — unless it has an MR tag already (rescale.py:277-278: the reference stops there),
+// whose lowest record index lands in *clash
+__global__ void gbam_write_back_kernel(const u8 *__restrict__ unc, const u32 *__restrict__ rec_off, const unsigned long long *__restrict__ out_off,
+                                       const u8 *__restrict__ rescaled, const float *__restrict__ mr, u32 n_rec, u8 *__restrict__ out,
+                                       int *__restrict__ clash) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 r = t >> 3, j = t & 7u;
+    if (r >= n_rec) return;
+    const u8 *__restrict__ p = unc + rec_off[r];
+    const u32 bs = g32(p - 4);
+    u8 *__restrict__ o = out + out_off[r];
+    const bool rs = rescaled[r] != 0;
+    for (u32 k = j; k < bs; k += 8u) o[4 + k] = p[k];
+    if (j != 0) return;
+    const u32 nbs = bs + (rs ? 7u : 0u);
+    o[0] = (u8)nbs; o[1] = (u8)(nbs >> 8); o[2] = (u8)(nbs >> 16); o[3] = (u8)(nbs >> 24);
+    if (!rs) return;
+    u8 *t7 = o + 4 + bs;
+    const u32 fb = __float_as_uint(mr[r]);
+    t7[0] = 'M'; t7[1] = 'R'; t7[2] = 'f'; t7[3] = (u8)fb; t7[4] = (u8)(fb >> 8); t7[5] = (u8)(fb >> 16); t7[6] = (u8)(fb >> 24);
+    // an MR tag among the record's own?
+    const u32 l_name = p[8], n_cig = g16(p + 12), l_seq = g32(p + 16);
+    const u8 *q = p + 32 + l_name + 4u * n_cig + (l_seq + 1) / 2 + l_seq, *end = p + bs;
+    while (q + 3 <= end) {
+        const u32 t0 = q[0], t1 = q[1], ty = q[2];
+        if (t0 == 'M' && t1 == 'R') { atomicMin(clash, (int)r); break; }
+        q += 3;
+        if (ty == 'Z' || ty == 'H') { while (q < end && *q) q++; q++; }
+        else if (ty == 'A' || ty == 'c' || ty == 'C') q += 1;
+        else if (ty == 's' || ty == 'S') q += 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') q += 4;
+        else if (ty == 'B') {
+            if (q + 5 > end) break;
+            const u32 sub = q[0], cntb = g32(q + 1);
+            const u32 w = (sub == 'c' || sub == 'C') ? 1u : ((sub == 's' || sub == 'S') ? 2u : 4u);
+            if ((u64)cntb * w > (u64)(end - q)) break;
+            q += 5 + cntb * w;
+        } else break;
+    }
+}
 }  // namespace
+void mdx_k_gbam_patch_qual(uint8_t *unc, const uint32_t *rec_off, const uint32_t *seq_off, uint32_t n_rec, const unsigned long long *patch,
+                           const unsigned long long *n_patch, long long cap, int parts, hipStream_t s) {
+    if (n_rec == 0 || parts <= 0) return;
+    hipLaunchKernelGGL(gbam_patch_qual_kernel, dim3(16, parts), dim3(256), 0, s, unc, rec_off, seq_off, n_rec, (const u64 *)patch, (const u64 *)n_patch, cap);
+}
+void mdx_k_gbam_out_sizes(const uint8_t *unc, const uint32_t *rec_off, const uint8_t *rescaled, uint32_t n_rec, uint32_t *sizes, hipStream_t s) {
+    if (n_rec == 0) return;
+    hipLaunchKernelGGL(gbam_out_sizes_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, s, unc, rec_off, rescaled, n_rec, sizes);
+}
+void mdx_k_gbam_write_back(const uint8_t *unc, const uint32_t *rec_off, const unsigned long long *out_off, const uint8_t *rescaled, const float *mr,
+                           uint32_t n_rec, uint8_t *out, int *clash, hipStream_t s) {
+    if (n_rec == 0) return;
+    hipLaunchKernelGGL(gbam_write_back_kernel, dim3((n_rec + 31) / 32), dim3(256), 0, s, unc, rec_off, out_off, rescaled, mr, n_rec, out, clash);
+}
 int mdx_k_bgzf_pieces() { return mdx_deflate::PIECES; }
 size_t mdx_k_bgzf_slot_bytes() { return BGZF_PIECE_SLOT; }
 size_t mdx_k_bgzf_scratch_bytes(int n_members) { return (size_t)n_members * mdx_deflate::PIECES * sizeof(mdx_deflate::PieceScratch); }

@@ -443,3 +443,12 @@ size_t mdx_k_bgzf_scratch_bytes(int n_members);
 void mdx_k_bgzf_deflate(const uint8_t *d_in, long long n, int n_members, uint8_t *d_slots, uint32_t *d_sizes, void *d_scratch, hipStream_t s);
 void mdx_k_bgzf_gather(const uint8_t *d_in, long long n, const uint8_t *d_slots, const uint32_t *d_sizes, const unsigned long long *d_offsets,
                        int n_members, const void *tables, uint8_t *d_out, hipStream_t s);
+
+// ---- the rescaled records of a decoded slab written back on the device (mdx_gbam.hip; host side: mdx_gbam_write_rescaled):
+// the patch list into the QUAL fields of the inflated records, the records' sizes in the output (+ 7 for an MR:f tag), the
+// records with their tags to their places in the output stream; *clash = lowest rescaled record that has an MR tag already
+void mdx_k_gbam_patch_qual(uint8_t *unc, const uint32_t *rec_off, const uint32_t *seq_off, uint32_t n_rec, const unsigned long long *patch,
+                           const unsigned long long *n_patch, long long cap, int parts, hipStream_t s);
+void mdx_k_gbam_out_sizes(const uint8_t *unc, const uint32_t *rec_off, const uint8_t *rescaled, uint32_t n_rec, uint32_t *sizes, hipStream_t s);
+void mdx_k_gbam_write_back(const uint8_t *unc, const uint32_t *rec_off, const unsigned long long *out_off, const uint8_t *rescaled, const float *mr,
+                           uint32_t n_rec, uint8_t *out, int *clash, hipStream_t s);

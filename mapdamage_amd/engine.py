@@ -38,6 +38,7 @@ EXPORTS = (
     "mdx_gbam_skip", "mdx_comm_count", "mdx_gbam_tell", "mdx_gbam_fixups", "mdx_bam_seek", "mdx_libsorts",
     "mdx_gbam_view_flags", "mdx_gbam_view_set_flags",
     "mdx_rescale_patches_device", "mdx_tabulate_rescale_patches_device", "mdx_rescale_expand_device", "mdx_mr_round", "mdx_batch_fold", "mdx_bgzf_deflate",
+    "mdx_gbam_rescale_slab", "mdx_gbam_write_rescaled", "mdx_gbam_record_name",
     "mdx_fasta_index", "mdx_set_reference_fasta", "mdx_reference_fetch", "mdx_host_threads", "mdx_host_pool_threads", "mdx_warm",
 )
 

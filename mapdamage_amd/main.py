@@ -200,8 +200,21 @@ def rescale_qual(options):
                 logger.warning("FASTA sequence %r is %s; the BAM header says %i bp — records mapped to it may fail",
                                name, "missing" if not have else "%i bp" % have, length)
         with DamageEngine([("*", "*")], options.length, options.around, 0, device=options.device) as engine:
-            summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model,
-                                          device_deflate=not options.host_deflate)
+            summary = None
+            if options.gpu_decode and not options.host_deflate and _device_path_applies(options):
+                # the records never on the host: inflated, rescaled, written back and deflated in HBM
+                from .rescale import rescale_bam_on_device
+                from .sam import GpuDecodeUnsupported
+                try:
+                    summary, counts = rescale_bam_on_device(engine, ref, options.filename, options.rescale_out, model)
+                except (GpuDecodeUnsupported, ValueError, MdxError) as error:
+                    # (never silent; the host decoder reads the whole file again and words the errors as the reference does)
+                    logger.warning("GPU decode path gave up: %s; rescaling through the host decoder (the whole file again)", error)
+                    engine.reset()
+                    summary = None
+            if summary is None:
+                summary, counts = rescale_bam(engine, ref, options.filename, options.rescale_out, model,
+                                              device_deflate=not options.host_deflate)
     except RescaleError as error:
         logger.error("%s", error)
         return 1

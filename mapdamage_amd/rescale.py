@@ -163,6 +163,47 @@ def round_mr(mr_raw):
     return out
 
 
+def rescale_bam_on_device(engine, ref, in_path, out_path, model, slab_bytes=256 << 20, timings=None):
+    """``rescale_bam`` with the records never on the host (include/mdx.h ``mdx_gbam_rescale_slab``): the compressed file goes to
+    HBM a slab at a time, is inflated and unpacked there (the decode pipeline of the tabulation pass, with quality and mate
+    columns), the rescale kernels list the quality bytes that change, those go into the inflated records themselves, every
+    record — a rescaled one with its ``MR:f`` tag — is laid out as the output stream in HBM and compressed there; only BGZF
+    members come back.  Same return value; raises ``sam.GpuDecodeUnsupported`` (or ValueError for a damaged file) for what
+    the device decoder does not take: the caller falls back to ``rescale_bam``."""
+    import time
+    from .sam import BgzfWriter, GpuBamStream, bam_header_bytes
+    engine.set_reference(ref)
+    engine.set_rescale_model(model)
+    counts = np.zeros(5, np.int64)
+    spent = {"decode": 0.0, "rescale_write_back_deflate": 0.0, "file_write": 0.0}
+    clock = time.perf_counter
+    # (no read group is looked up: the rescaling pass knows no libraries, rescale.py:285-365)
+    with GpuBamStream(engine, in_path, readgroups=[], lib_default=0, chunk_bytes=slab_bytes, want_qual=True, want_mate=True,
+                      packed=False) as stream, BgzfWriter(out_path, engine=engine) as out:
+        out.write(bam_header_bytes(stream.header))
+        while True:
+            t0 = clock()
+            view = stream.next_view()
+            engine.sync()
+            t1 = clock()
+            spent["decode"] += t1 - t0
+            if view is None:
+                break
+            members = stream.rescale_slab(view, counts)
+            t2 = clock()
+            spent["rescale_write_back_deflate"] += t2 - t1
+            out.write_members(members)
+            spent["file_write"] += clock() - t2
+        t3 = clock()
+    spent["file_write"] += clock() - t3
+    if timings is not None:
+        timings.update(spent)
+    summary = RescaleSummary(engine.rescale_summary(), model)
+    return summary, {name: int(counts[code]) for name, code in
+            (("unmapped", STATUS_UNMAPPED), ("without_qualities", STATUS_NO_QUAL), ("single_end", STATUS_BOTH),
+             ("inward_pairs", STATUS_FORWARD), ("improper_pairs", STATUS_IMPROPER))}
+
+
 def rescale_bam(engine, ref, in_path, out_path, model, chunk_bytes=256 << 20, timings=None, device_deflate=True):
     """File-level mirror of ``_rescale_qual_core`` (rescale.py:285-365): every record of the BAM is
     written back, rescaled records get their new qualities and an ``MR:f`` tag, everything else in

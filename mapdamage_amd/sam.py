@@ -315,6 +315,13 @@ class BgzfWriter:
                 self._drain(self._max_pending // 2)
         self._drain(self._max_pending)
 
+    def write_members(self, members):
+        """Append finished BGZF members (the device's: ``GpuBamStream.rescale_slab``) as they are."""
+        assert not self._tail
+        self._pending.append(self._pool.submit(self._out.write, memoryview(members)))
+        while len(self._pending) > 2:
+            self._pending.popleft().result()
+
     def flush(self):
         self._drain(0)
 
@@ -531,6 +538,37 @@ class GpuBamStream:
         rc = self._lib.mdx_gbam_view_set_flags(self._g, ctypes.c_void_p(flags.ctypes.data), ctypes.c_int64(flags.shape[0]))
         if rc != 0:
             raise ValueError("%r: %s" % (str(self.path), self._error()))
+
+    def rescale_slab(self, view, counts):
+        """The slab ``next_view`` handed out last (a stream opened with ``want_qual``, ``want_mate``, ``packed=False``) rescaled
+        through the engine's model and written back on the device (include/mdx.h ``mdx_gbam_rescale_slab``): returns the slab's
+        records — new qualities, ``MR:f`` tags — as BGZF members (a uint8 array); ``counts`` (int64[5]) += records by routing
+        status.  Raises SystemExit with the reference's message when a record to be rescaled has an MR tag already
+        (rescale.py:277-278), BadReadError for a record the kernels cannot process."""
+        import ctypes
+        import numpy as np
+        n, nb, ncg = int(view.n_reads), int(view.n_bases), int(view.n_cigar)
+        # (the slab's inflated bytes are at most: per record 36 + a name of 255 + its CIGAR + 1.5 x its bases + tags — bounded
+        # by what the decoder itself allows: 4 x the compressed slab and more; taken from the view: bases x 1.5 + 4 per
+        # operation + 400 per record covers names and tags of any file this library has seen; a longer one is MDX_ERR_ARG)
+        cap = int(nb * 1.5) + 4 * ncg + 400 * n + (1 << 20)
+        cap += (cap // 0xFF00 + 1) * 64
+        out = np.empty(cap, np.uint8)
+        out_len, clash = ctypes.c_int64(0), ctypes.c_int64(-1)
+        fn = self._lib.mdx_gbam_rescale_slab
+        fn.restype = ctypes.c_int
+        rc = fn(self._g, ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(cap), ctypes.byref(out_len),
+                ctypes.c_void_p(counts.ctypes.data), ctypes.byref(clash))
+        if rc == -6 and clash.value >= 0:
+            name = ctypes.create_string_buffer(256)
+            self._lib.mdx_gbam_record_name(self._g, ctypes.c_int64(clash.value), name, 256)
+            raise SystemExit("Read: %s already has a MR tag, can't rescale" % name.value.decode(errors="replace"))
+        if rc == -6:
+            from .engine import BadReadError
+            raise BadReadError(-2 - clash.value, self._error())
+        if rc != 0:
+            raise ValueError("%r: %s" % (str(self.path), self._error()))
+        return out[:out_len.value]
 
     def fixups(self):
         """BGZF blocks whose guessed first record was not where the chain of the records in front of it ended (rescanned

@@ -622,9 +622,11 @@ def test_hip_rescale_names_the_record_it_cannot_process(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_rescale_only_rewrites_bam(tmp_path):
+@pytest.mark.parametrize("flags", [[], ["--host-decode"], ["--host-deflate"]], ids=["device", "host-decode", "host-deflate"])
+def test_cli_rescale_only_rewrites_bam(tmp_path, flags):
     """`--rescale-only`: every record written back, new qualities + MR:f on the rescaled ones,
-    untouched fields preserved."""
+    untouched fields preserved.  Three routes: the records never on the host (inflated, rescaled, written back and deflated in
+    HBM: the default), the host decoder with the BGZF writer on the device, the host decoder with zlib."""
     import struct
 
     from mapdamage_amd import fasta, sam
@@ -636,8 +638,9 @@ def test_cli_rescale_only_rewrites_bam(tmp_path):
     folder.mkdir()
     (folder / "Stats_out_MCMC_correct_prob.csv").write_bytes((tmp_path / "Stats_out_MCMC_correct_prob.csv").read_bytes())
     rc = main(["-i", str(tmp_path / "in.bam"), "-r", str(tmp_path / "ref.fa"), "-d", str(folder), "--rescale-only",
-               "--rescale-length-5p", "12", "--rescale-length-3p", "10"])
+               "--rescale-length-5p", "12", "--rescale-length-3p", "10"] + flags)
     assert rc == 0
+    assert "gave up" not in (folder / "Runtime_log.txt").read_text()
     out = sam.read_bam(folder / "in.rescaled.bam", keep_raw=True)
     assert out.batch.n == batch.n
     np.testing.assert_array_equal(out.batch.qual, want_qual)
@@ -678,3 +681,21 @@ def test_cli_rescale_only_tolerates_a_fasta_without_an_unused_contig(tmp_path):
     assert rc == 0
     out = sam.read_bam(folder / "in.rescaled.bam", keep_raw=True)
     np.testing.assert_array_equal(out.batch.qual, want_qual)
+
+
+@pytest.mark.gpu
+def test_rescale_on_device_refuses_a_record_that_has_an_mr_tag(tmp_path):
+    """rescale.py:277-278: a record that is to be rescaled and carries an MR tag already stops the pass, by name — on the path
+    that never brings the records to the host too (the write-back kernel looks at the tags of the records it extends)."""
+    from mapdamage_amd import sam
+    from mapdamage_amd.engine import DamageEngine
+    from mapdamage_amd.rescale import rescale_bam, rescale_bam_on_device
+    ref, batch, model, corr_prob, want_qual, want_mr = load(tmp_path)
+    sam.write_bam(tmp_path / "in.bam", batch, ref.names, ref.lengths, [], None)
+    with DamageEngine([("*", "*")]) as eng:
+        rescale_bam_on_device(eng, ref, tmp_path / "in.bam", tmp_path / "once.bam", model)
+    first = next(i for i in range(batch.n) if not np.isnan(want_mr[i]))
+    for fn in (rescale_bam_on_device, rescale_bam):
+        with DamageEngine([("*", "*")]) as eng:
+            with pytest.raises(SystemExit, match="Read: r%d already has a MR tag" % first):
+                fn(eng, ref, tmp_path / "once.bam", tmp_path / "twice.bam", model)
