@@ -188,3 +188,62 @@ def test_cli_tables_of_the_foreign_files(tmp_path, name, tag, extra):
         assert texts[decode] == [want.misincorporation_text(), want.dnacomp_text(), want.lgdistribution_text()], decode
     log = (tmp_path / "gpu-decode" / "Runtime_log.txt").read_text()
     assert ("GPU decode path gave up" in log) == (tag == "full")
+
+
+@pytest.mark.gpu
+def test_rescaling_a_foreign_file_on_the_device_writes_what_the_host_route_writes(tmp_path):
+    """--rescale-only over records this repository's writer did not produce (aux fields of every type in front of and behind RG,
+    B arrays, records straddling unevenly cut BGZF blocks, 0xFF qualities, an unmapped record, a record without SEQ): the route
+    that never brings the records to the host (mdx_gbam_rescale_slab: the new qualities patched into the inflated records, the
+    tags walked for an MR, MR:f appended, the stream compressed on the device) must write the records the host route writes —
+    every encoded byte of every record — and both must hold the oracle's qualities.  The file is foreign_nocg.bam less the
+    records the reference's rescaling cannot take (the oracle says which: rescale.py raises on them), their encoded bytes
+    carried over as they stand."""
+    from mapdamage_amd.engine import BadReadError, DamageEngine
+    from mapdamage_amd.rescale import RescaleModel, rescale_bam, rescale_bam_on_device
+    from oracle import oracle
+    t, z = truth("nocg")
+    ref = reference(z)
+    rng = np.random.default_rng(5)
+    corr_prob = {}
+    for p in list(range(1, 13)) + list(range(-12, 0)):
+        corr_prob[("C", "T", p)] = float(rng.random() * 0.8)
+        corr_prob[("G", "A", p)] = float(rng.random() * 0.8)
+    model = RescaleModel(corr_prob, 12, 12)
+    corr = np.zeros((2, model.npos))
+    for (r_, _s, p_), v in corr_prob.items():
+        corr[0 if r_ == "C" else 1, p_ if p_ > 0 else model.len5p - p_] = v
+    al = sam.read_bam(GOLDEN / "foreign_nocg.bam", keep_raw=True)
+    whole = al.batch
+    keep = list(range(whole.n))
+    while True:
+        b = whole.take(np.asarray(keep))
+        try:
+            wq, wmr, wst = oracle.rescale(ref, b, corr, 12, 12)
+            break
+        except oracle.OracleError as error:
+            keep.pop(int(error.read_index))
+    assert 0 < len(keep) < whole.n                       # (some records of the file are not the rescaling's to take, most are)
+    src = tmp_path / "foreign_rescalable.bam"
+    sam.write_bam_raw(src, al.raw_header, [bytes(al.raw[i]) for i in keep])
+    # (the whole file stops every route at the same record)
+    for fn in (rescale_bam_on_device, rescale_bam):
+        with DamageEngine([("*", "*")]) as eng:
+            with pytest.raises(BadReadError):
+                fn(eng, ref, GOLDEN / "foreign_nocg.bam", tmp_path / "never.bam", model)
+    outs = {}
+    for name, fn, kw in (("device", rescale_bam_on_device, dict(slab_bytes=1 << 16)), ("host", rescale_bam, dict(chunk_bytes=3000, device_deflate=False)),
+                         ("host_device_deflate", rescale_bam, dict(chunk_bytes=1 << 20))):
+        with DamageEngine([("*", "*")]) as eng:
+            _, counts = fn(eng, ref, src, tmp_path / (name + ".bam"), model, **kw)
+        outs[name] = (counts, sam.read_bam(tmp_path / (name + ".bam"), keep_raw=True))
+    counts, back = outs["device"]
+    assert back.batch.n == len(keep) and sum(counts.values()) == back.batch.n
+    for other in ("host", "host_device_deflate"):
+        assert outs[other][0] == counts
+        assert [bytes(x) for x in outs[other][1].raw] == [bytes(x) for x in back.raw]
+    # ... and the qualities are the oracle's, the tag where it rescaled
+    np.testing.assert_array_equal(back.batch.qual, wq)
+    np.testing.assert_array_equal(np.asarray(back.has_mr), ~np.isnan(wmr))
+    for k in ("flag", "tid", "pos", "tlen", "cigar", "seq", "mtid", "mpos"):
+        np.testing.assert_array_equal(getattr(back.batch, k), getattr(b, k), err_msg=k)
