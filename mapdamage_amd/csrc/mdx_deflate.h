@@ -17,6 +17,10 @@
 #define MDX_DF_HD
 #endif
 
+#ifndef MDX_DEFLATE_PIECES
+#define MDX_DEFLATE_PIECES 4
+#endif
+
 namespace mdx_deflate {
 
 enum { MAX_IN = 0xFF00, HASH_BITS = 12, HASH_SIZE = 1 << HASH_BITS, MIN_MATCH = 4, MAX_MATCH = 258, WINDOW = 32768,
@@ -25,7 +29,7 @@ enum { MAX_IN = 0xFF00, HASH_BITS = 12, HASH_SIZE = 1 << HASH_BITS, MIN_MATCH = 
        // may reach back into the piece in front (the lane hashes that one's positions first), every piece but the last closed
        // with an empty stored block — zlib's Z_SYNC_FLUSH — so that the next one starts on a byte.  Four lanes per member
        // instead of one: 0.6 % more bytes.
-       PIECES = 4, PIECE = MAX_IN / PIECES };
+       PIECES = MDX_DEFLATE_PIECES, PIECE = MAX_IN / PIECES };
 static_assert(PIECE * PIECES == MAX_IN, "the pieces tile a member");
 
 // Per-block working memory (the caller's: on the device a slot per lane in HBM).  A token: a literal byte, or
@@ -64,15 +68,17 @@ struct BitWriter {
 };
 
 MDX_DF_HD inline uint32_t reverse_bits(uint32_t code, int len) {
+#if defined(__clang__)
+    return len ? __builtin_bitreverse32(code) >> (32 - len) : 0u;
+#else
     uint32_t r = 0;
     for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1u); code >>= 1; }
     return r;
+#endif
 }
 
-MDX_DF_HD inline int floor_log2(uint32_t v) {
-    int n = 0;
-    while (v >>= 1) n++;
-    return n;
+MDX_DF_HD inline int floor_log2(uint32_t v) {       // (v > 0)
+    return 31 - __builtin_clz(v);
 }
 
 // length 3..258 -> (code 257..285, number of extra bits, their value); RFC 1951 section 3.2.5

@@ -539,6 +539,11 @@ def main(argv):
         if ranks.world > 1:
             logger.info("Rank 0 of %d: one process per GPU, records sharded by slab of the file, tables summed over %s",
                         ranks.world, "RCCL" if ranks.backend == "nccl" else "gloo (host)")
+        # (the host is the node's: every rank takes its share of the threads cpu.max grants, include/mdx.h mdx_host_threads)
+        from .engine import load_library
+        from .sam import usable_cpus
+        logger.debug("Host threads of this rank: %d inflating beside the device, %d for the host decoder (LOCAL_WORLD_SIZE %s)",
+                     load_library().mdx_host_threads(), usable_cpus(), os.environ.get("LOCAL_WORLD_SIZE", "1"))
         reader = BAMReader(options.filename, merge_libraries=options.merge_libraries,
                            downsample_to=options.downsample, downsample_seed=options.downsample_seed,
                            chunk_bytes=int(options.chunk_mb * (1 << 20)))

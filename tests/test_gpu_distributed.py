@@ -158,6 +158,15 @@ def test_cli_on_two_ranks_shards_the_slabs_of_a_file(tmp_path, layout):
     for f in ("misincorporation.txt", "dnacomp.txt", "lgdistribution.txt"):
         assert (one / f).read_bytes() == (two / f).read_bytes(), f
     assert "fallbacks from the device path: 0" in (two / "Runtime_log.txt").read_text()
+    # the two ranks share the host: each takes half of the threads the one rank had (mdx_host_threads, sam.usable_cpus)
+    import re
+    threads = {}
+    for name, folder in (("one", one), ("two", two)):
+        m = re.search(r"Host threads of this rank: (\d+) inflating beside the device, (\d+) for the host decoder \(LOCAL_WORLD_SIZE (\d+)\)",
+                      (folder / "Runtime_log.txt").read_text())
+        threads[name] = tuple(int(x) for x in m.groups())
+    assert threads["one"][2] == 1 and threads["two"][2] == 2
+    assert threads["two"][0] == max(1, threads["one"][0] // 2) and threads["two"][1] == max(1, threads["one"][1] // 2)
     # ... and both are the oracle's
     from mapdamage_amd.tables import TableSet
     w = oracle.tabulate(ref, b, 1, 70, 10)
