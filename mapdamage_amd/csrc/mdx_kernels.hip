@@ -122,6 +122,9 @@ typedef long long i64;
 #ifndef MDX_PK_PREFETCH
 #define MDX_PK_PREFETCH 0               // the packed kernel requests a tile's phase-1 loads a tile ahead (measured: no gain; 26 registers)
 #endif
+#ifndef MDX_PK_FASTIDX
+#define MDX_PK_FASTIDX 1                // the packed kernels' complete steps: the staging entry's LDS address as add + min (a slot past its strand's
+#endif                                  // last entry reads that last entry and is masked out), the event's place from two shift-adds
 #ifndef MDX_PK_PD
 #define MDX_PK_PD 4                     // ... and of the packed kernel's complete runs
 #endif
@@ -830,6 +833,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // step's loads only.
     uint4 *const qQ = (uint4 *)(lds + a.queue_off + (PK ? wave * (MDX_PK_EVQ_BYTES / 4) : 0));
     u32 *const qE = (u32 *)(qQ + MDX_PK_QCAP);
+    // (their LDS addresses: the dynamic LDS starts at address 0)
+    typedef __attribute__((address_space(3))) u32x4 lds_u4;
+    typedef __attribute__((address_space(3))) u32 lds_u1;
+    const u32 qQ_a = (u32)(size_t)(lds_u4 *)qQ, qE_a = qQ_a + 16u * MDX_PK_QCAP;
     static_assert(MDX_PK_QCAP >= 64 && MDX_PK_QCAP % 4 == 0, "a step's events fit an empty queue");
     const u32x2 *const emtab = (const u32x2 *)(ltab + 17);
     const u16 *const pktab = (const u16 *)(ltab + 17 + 64);
@@ -1396,6 +1403,15 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (bs_steps + nsteps4 > 255) bs_flush();
                 bs_steps += nsteps4;
                 const int base_l = e0 + (p_strand ? nP_ : 0) + c_slot, lim_l = (p_strand ? nM_ : nP_) - c_slot;
+                // (FASTIDX — complete steps outside the fused kernels, which want nothing of an entry but its first three words: the
+                // entry's LDS address is min(first + 16 H k, last entry of the lane's strand) — the dynamic LDS starts at address 0.
+                // A slot past its strand's last entry reads that entry, or the run's first when the strand has none, and is
+                // masked out by the step (actm))
+                constexpr bool FIDX = MDX_PK_FASTIDX && KIND == STEP_C && !RS;
+                const u32 stg_a = (u32)(size_t)(lds_u4 *)stg;
+                const int last_l = e0 + (p_strand ? nP_ : 0) + (p_strand ? nM_ : nP_) - 1;
+                const u32 ent_a0 = stg_a + 16u * (u32)base_l, ent_cap = stg_a + 16u * (u32)(last_l > e0 ? last_l : e0);
+                const int H16 = 16 * H;
                 // (one <3 x i32> load per operand: a struct of three words is taken apart and put together again as the
                 // vectorizer likes — two overlapping dwordx2 loads at times)
                 struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
@@ -1420,13 +1436,19 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     const int k = st.valid ? kf : nsteps4 - 1;
                     // (the slot holds a record iff H k + slot < the entries of its strand)
                     bool act = true;
-                    const int idx = ent_index(kf, act);
+                    int idx = 0;
+                    if (!FIDX || MDX_PK_ENT_AHEAD) idx = ent_index(kf, act);
                     kf++;
                     st.k = k;
 #if MDX_PK_ENT_AHEAD
                     const uint4 ent = ent_next;
 #else
-                    const uint4 ent = stg[idx];
+                    uint4 ent;
+                    if constexpr (FIDX) {
+                        const u32 ad = ent_a0 + (u32)(H16 * k);
+                        const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
+                        ent = make_uint4(e_.x, e_.y, e_.z, e_.w);
+                    } else ent = stg[idx];
 #endif
                     const u32 t = ent.z & c_cm;
                     u32 ro = ent.x + c_ro + t;
@@ -1613,9 +1635,19 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             return;
                         }
                         if (ev) {
+#if MDX_PK_FASTIDX
+                            // (the event's place among this step's events, the queue's fill in the scalar part of both addresses)
+                            const u32 slot = (u32)mbcnt64(mm, 0);
+                            // (kept apart: the sum of slot and fill would be a vector add)
+                            const u32 qa_s = (u32)__builtin_amdgcn_readfirstlane((int)(qQ_a + 16u * (u32)qcount)),
+                                      ea_s = (u32)__builtin_amdgcn_readfirstlane((int)(qE_a + 4u * (u32)qcount));
+                            *(lds_u4 *)((slot << 4) + qa_s) = u32x4{s_lo, s_hi, r_lo, r_hi};
+                            *(lds_u1 *)((slot << 2) + ea_s) = evw;
+#else
                             const int slot = mbcnt64(mm, qcount);
                             qQ[slot] = make_uint4(s_lo, s_hi, r_lo, r_hi);
                             qE[slot] = evw;
+#endif
                         }
                         qcount += n;
                     }
@@ -2535,7 +2567,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // (a pool's tiles: chunks of MDX_POOL_CHUNK consecutive tiles, the pools' chunks interleaved — the whole chip works
         // on one neighbourhood of a coordinate-sorted batch at a time and shares its reference lines in the L2s, as it did
         // when the tiles were dealt round-robin; a stretch of its own per pool cost such a batch 5 %)
-        static_assert(!(ML && MDX_PK_PREFETCH), "the prefetched columns know no libraries");
         u32 grabs = 0;
         // (STEAL — the packed kernels: a wavefront whose pool has run dry goes on with the tiles of other pools — ML: of its
         // library's —, see tile_of; pool_cur = the pool it asks at present.  A stolen tile takes the place of the answer
@@ -2582,7 +2613,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // a tile ahead — and asks for the one after; the others ask for the next one: a wavefront that finds its pool
         // empty has one tile less left to do)
         u32 cur = tile_of(grab());
-        constexpr bool PF = PK && MDX_PK_PREFETCH;
+        constexpr bool PF = PK && !ML && !RS && !MASK && MDX_PK_PREFETCH;     // (the prefetched columns know no libraries)
         u32 nxt = (RS || PF) && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
         // PK: the loads of a tile's phase 1 — its nine column values, then the operations and contig bounds they lead to —
         // are requested a tile ahead, the first round trip in front of the current tile's phase 1 and the second in front of
@@ -2619,7 +2650,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         };
         Cols Cc = {}, Cn = {};
         Rt2 Gc = {}, Gn = {};
-        if (PF && cur != 0xFFFFFFFFu) { Cc = p_cols(cur); Gc = p_rt2(Cc); }
+        constexpr bool PF2 = PF && MDX_PK_PREFETCH == 1;        // (2: the columns only — the second round trip stays in phase 1)
+        if (PF && cur != 0xFFFFFFFFu) { Cc = p_cols(cur); if (PF2) Gc = p_rt2(Cc); }
         if (RS && cur != 0xFFFFFFFFu) {
             const u32 tb0 = cur * T, rh0 = tb0 + T < n_rec ? tb0 + T : n_rec;
             nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
@@ -2783,7 +2815,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (32-bit reference coordinates: the fast path runs on references shorter than 4 GiB, MdxTabArgs::ref32)
                 u32 c0 = 0, clen = 0;
                 u32 q0 = 0xFFu;
-                if (PF) { g0 = Gc.g0; g1 = Gc.g1; g2 = Gc.g2; c0 = Gc.c0; clen = Gc.clen; }
+                if (PF2) { g0 = Gc.g0; g1 = Gc.g1; g2 = Gc.g2; c0 = Gc.c0; clen = Gc.clen; }
                 else if (cand) {
                     g0 = a.cigar[c_co0];
                     if (cn >= 2u) g1 = a.cigar[c_co0 + 1];
@@ -3012,7 +3044,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // in flight and their waits are counted; PK: the next tile's second round trip goes out behind that wait and
                 // lands under the run)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
-                if (PF && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
+                if (PF2 && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) {
                     MDX_PH(2);
                     if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp);
@@ -3098,7 +3130,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             if (!past) {
                 if (RS || PF) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
                 else cur = tile_of(nxt2_raw);
-                if (PF) { Cc = Cn; Gc = Gn; }
+                if (PF) { Cc = Cn; if (PF2) Gc = Gn; }
             }
         }
         // ---------------------------------------------------- the lists, at the end of a round: whole passes (63 entries:
