@@ -144,6 +144,7 @@ struct mdx_ctx {
     uint32_t *d_tile_ctr = nullptr; // tile counters of the fast kernels' pools (MdxTabArgs::tile_ctr)
     size_t fuse_prepared = 0;      // LDS bytes the fused kernel has been prepared for
     size_t pkf_prepared = 0;       // ... and the packed fused kernel
+    MdxPkConfig pk = {512, 0};     // the packed kernels' block and whether they prefetch a tile's columns into the LDS (mdx_k_pk_config)
     bool tile_ctr_clean = false;   // d_tile_ctr is all zero (the reduction behind a launch leaves it so)
     bool pkm_prepared = false;     // the packed kernel's masked form
     DevBuf lowq;           // --min-basequal, packed kernel: the scratch column a MDX_SEQ_4BIT batch's mask is folded into (MDX_SEQ_4BITQ)
@@ -304,7 +305,14 @@ int mdx_create(const mdx_config *cfg, mdx_ctx **out) {
         c->max_grid = c->n_cu * (2048 / mdx_k_block_threads());
         HIP_TRY(c, mdx_k_prepare(c->lds_bytes));
         // (the packed kernel counts one library per launch)
-        HIP_TRY(c, mdx_k_prepare_packed(mdx_k_pk_lds_bytes(mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds))));
+        {
+            const MdxDims d1 = mdx_make_dims(cfg->length, cfg->around, 1, cfg->lgd_max, lgd_lds);
+            c->pk = mdx_k_pk_config(d1, kLdsLimit);
+            HIP_TRY(c, mdx_k_prepare_packed(mdx_k_pk_lds_bytes(d1, c->pk)));
+            if (const char *e = getenv("MDX_DEBUG_PK")) if (*e && *e != '0')
+                fprintf(stderr, "[mdx] packed kernels: blocks of %d threads, %zu bytes of LDS, columns %s\n", c->pk.threads, mdx_k_pk_lds_bytes(d1, c->pk),
+                        c->pk.pfl ? "prefetched into the LDS" : "by plain loads");
+        }
         lap("kernels");
         HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)c->max_grid * gdims.w_total * 4));
     } else {
@@ -673,7 +681,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     a.n_bases = b->n_bases;
     a.ref32 = ref32 ? 1 : 0;
     const bool mask = c->cfg.minqual > 0 && b->qual != nullptr;
-    const int wpb = (packed ? mdx_k_pk_block_threads() : mdx_k_block_threads()) / 64;
+    const int wpb = (packed ? c->pk.threads : mdx_k_block_threads()) / 64;
     const int64_t ntiles = (b->n_reads + 63) / 64;
     const int64_t want = (ntiles + wpb - 1) / wpb;
     if (b->n_reads >= (int64_t)1 << 30) return fail(c, MDX_ERR_ARG, "batch of 2^30 records or more; split it");
@@ -687,8 +695,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
         // (a pool of blocks counts one library: as many libraries per launch as the largest launch has pools of two blocks —
         // every library of a launch must get one, ml_plan_kernel — and as the plan's arrays hold)
         group = c->cfg.nlib < MDX_ML_MAX_LIBS ? c->cfg.nlib : MDX_ML_MAX_LIBS;
-        int per_cu = (int)(kLdsLimit / mdx_k_pk_lds_bytes(dims1));
-        if (per_cu > mdx_k_pk_blocks_per_cu()) per_cu = mdx_k_pk_blocks_per_cu();
+        int per_cu = (int)(kLdsLimit / mdx_k_pk_lds_bytes(dims1, c->pk));
+        if (per_cu > mdx_k_pk_blocks_per_cu(c->pk.threads)) per_cu = mdx_k_pk_blocks_per_cu(c->pk.threads);
         const int pools = (c->n_cu * per_cu) / 2;
         if (group > pools) group = pools > 0 ? pools : 1;
     }
@@ -702,15 +710,17 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             a.dims = ml ? dims1 : (gn == c->cfg.nlib ? c->dims : mdx_make_dims(c->cfg.length, c->cfg.around, gn, c->cfg.lgd_max, c->dims.lgd_lds));
             a.raw = c->d_raw + (size_t)lo * c->dims.w_lib;
             a.lgd_dense = c->d_lgd_dense + (size_t)lo * 4 * c->cfg.lgd_max;
-            lds = packed ? mdx_k_pk_lds_bytes(a.dims) : mdx_k_lds_bytes(a.dims);
+            lds = packed ? mdx_k_pk_lds_bytes(a.dims, c->pk) : mdx_k_lds_bytes(a.dims);
             int per_cu = (int)(kLdsLimit / lds);
             // (the packed kernel: two blocks per CU at most — its registers)
-            const int by_threads = packed ? mdx_k_pk_blocks_per_cu() : 2048 / mdx_k_block_threads();
+            const int by_threads = packed ? mdx_k_pk_blocks_per_cu(c->pk.threads) : 2048 / mdx_k_block_threads();
             if (per_cu > by_threads) per_cu = by_threads;
             max_grid = c->n_cu * per_cu;
         }
         a.stage_off = mdx_k_stage_off(a.dims);
-        a.queue_off = packed ? mdx_k_pk_queue_off(a.dims) : mdx_k_queue_off(a.dims);
+        a.queue_off = packed ? mdx_k_pk_queue_off(a.dims, c->pk.threads) : mdx_k_queue_off(a.dims);
+        // (the fused kernels have an image of their own: no prefetch areas)
+        a.pfl_off = packed && !fuse && c->pk.pfl ? mdx_k_pk_pfl_off(a.dims, c->pk.threads) : 0;
         int grid = (int)(want < max_grid ? want : max_grid);
         // (several libraries: a pool — two blocks — for every library at least)
         if (ml && grid < 2 * gn) grid = 2 * gn < max_grid ? 2 * gn : max_grid;
@@ -744,7 +754,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             // Tiles are handed out on demand within pools of two blocks (mdx_kernels.hip): a wavefront takes at most twice
             // its even share of its pool's tiles, and its lists hold the records of that many
             const int64_t nwaves = (int64_t)grid * wpb_l;
-            const int64_t T = a.dims.R > 0 ? 64 - 64 % a.dims.R : 64;
+            const int64_t T = mdx_tile_records(a.dims, a.pfl_off != 0);
             const int64_t n_tiles = (b->n_reads + T - 1) / T;
             const int64_t n_pools = mdx_n_pools((unsigned)grid);
             // (a pool takes chunks of MDX_POOL_CHUNK tiles, the pools' chunks interleaved: at most one chunk more than its share)
@@ -800,7 +810,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             bs = &b_fold;
         }
         if (pmask && !c->pkm_prepared) {
-            HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(dims1)));
+            HIP_TRY(c, mdx_k_prepare_packed_masked(mdx_k_pk_lds_bytes(dims1, c->pk)));
             c->pkm_prepared = true;
         }
         if (ml) {
@@ -836,7 +846,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             // the pools dealt to the libraries by their sizes (on the device: nothing of the sort comes back to the host)
             HIP_TRY(c, c->ml_partials.reserve((size_t)mdx_n_pools((unsigned)grid) * 16));
             a.ml_plan = (const uint4 *)c->ml_partials.p;
-            mdx_k_ml_plan(ls.lib_start, lo, gn, (int)(a.dims.R > 0 ? 64 - 64 % a.dims.R : 64), grid, c->ml_partials.p, c->stream);
+            mdx_k_ml_plan(ls.lib_start, lo, gn, mdx_tile_records(a.dims, a.pfl_off != 0), grid, c->ml_partials.p, c->stream);
         }
         // (the pools' tile counters: zeroed by the reduction behind the previous launch, as a rule; else here, inside the timed region)
         // (a counter per 128-byte line; the reduction behind a launch zeroes those of the first 4 096 pools)
@@ -856,8 +866,8 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
             c->fuse_list_cap = a.list_cap;
             if (fused_grid) *fused_grid = grid;
         } else if (packed) {
-            if (pmask) mdx_k_tabulate_packed_masked(a, grid, lds, c->stream);
-            else mdx_k_tabulate_packed(a, grid, lds, c->stream);
+            if (pmask) mdx_k_tabulate_packed_masked(a, grid, c->pk.threads, lds, c->stream);
+            else mdx_k_tabulate_packed(a, grid, c->pk.threads, lds, c->stream);
             c->n_packed++;
         } else {
             mdx_k_tabulate(a, c->mode, mask, grid, lds, c->stream);

@@ -203,6 +203,8 @@ struct MdxTabArgs {
     long long record_base;           // index of the batch's first record in the caller's numbering (mdx_set_record_base)
     int stage_off;                   // word offset of the per-wave record staging areas in the LDS
     int queue_off;                   // word offset of the per-wave rare-event queues in the LDS
+    int pfl_off;                     // the packed kernels: word offset of the per-wave areas the next tile's phase-1 columns are
+                                     // prefetched into (MDX_PFL_WAVE_BYTES each; 0: none — the columns come by plain loads)
     int ref32;                       // reference (with guard bands) shorter than 4 GiB: 32-bit window offsets
     int64_t n_bases;                 // bytes in seq (and qual): bounds the speculative 8-byte loads
     int lib_lo, nlib_total;          // this launch counts libraries [lib_lo, lib_lo + dims.nlib) of nlib_total
@@ -281,20 +283,35 @@ void mdx_k_pack_seq(const uint8_t *d_ascii, uint8_t *d_packed, int64_t n, hipStr
 // MDX_FLAG_HAS_QUAL set on the records of a resident batch whose first quality byte is not 0xFF
 void mdx_k_mark_has_qual(uint16_t *d_flag, const uint32_t *d_seq_off, const uint8_t *d_qual, int64_t n, hipStream_t s);
 void mdx_k_unpack_seq(const uint8_t *d_packed, uint8_t *d_ascii, int64_t n, hipStream_t s);
-// the packed kernel's own block size and LDS image (queue offset, bytes; the staging offset is mdx_k_stage_off)
-int mdx_k_pk_block_threads();
-int mdx_k_pk_blocks_per_cu();     // by its registers
-int mdx_k_pk_queue_off(const MdxDims &d);
-size_t mdx_k_pk_lds_bytes(const MdxDims &d);
+// The packed kernels' block and LDS image (the staging offset is mdx_k_stage_off).  Their registers allow four wavefronts per
+// SIMD, and the launch puts them into ONE block of 1024 threads per CU (rounds 4-5: two of 512): one image of the tables
+// instead of two, and what that frees of the LDS gives every wavefront an area (MDX_PFL_WAVE_BYTES) into which the phase-1
+// columns of its NEXT tile are prefetched with LDS-DMA loads (global_load_lds_*: no registers) under the current tile's work.
+// Where the tables of a long --length leave less room the block is 512 or 256 threads (MdxPkConfig, mdx_k_pk_config); the
+// fused kernel (tabulate + rescale) has an image of its own and no such areas (MdxTabArgs::pfl_off = 0).
+#define MDX_PFL_COLS 12                          // flag, library, tid, pos, tlen, cigar_off, seq_off; three operations, two contig bounds
+#define MDX_PFL_WAVE_BYTES (MDX_PFL_COLS * 256)  // a dword per lane and column
+struct MdxPkConfig { int threads; int pfl; };
+MdxPkConfig mdx_k_pk_config(const MdxDims &d, size_t lds_limit);
+int mdx_k_pk_blocks_per_cu(int threads);     // by its registers
+int mdx_k_pk_queue_off(const MdxDims &d, int threads);
+int mdx_k_pk_pfl_off(const MdxDims &d, int threads);
+size_t mdx_k_pk_lds_bytes(const MdxDims &d, const MdxPkConfig &k);
+// records of a tile of the fast kernels: a multiple of R (the ASCII kernels' steps); at most 63 where the columns are
+// prefetched (a record's end offsets are its neighbour's start offsets: lane 63 brings the last one)
+static inline __host__ __device__ int mdx_tile_records(const MdxDims &d, bool pfl) {
+    const int t = d.R > 0 ? 64 - 64 % d.R : 64;
+    return pfl && t > 63 ? 63 : t;
+}
 hipError_t mdx_k_prepare_packed(size_t lds_bytes);
 // ... with --min-basequal (a MDX_SEQ_4BITQ column: the mask is in the nibbles)
 hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes);
-void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
+void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, int threads, size_t lds_bytes, hipStream_t s);
 // MDX_SEQ_4BIT -> MDX_SEQ_4BITQ: the bases whose quality is below minqual (qual, or the bitmap lowq if not null) complemented;
 // seq4_out may be seq4_in
 void mdx_k_fold_mask(const uint8_t *seq4_in, uint8_t *seq4_out, const uint8_t *qual, const uint8_t *lowq, int64_t n_bases, int minqual,
                      hipStream_t s);
-void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
+void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, int threads, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate(const MdxTabArgs &a, int mode, bool mask, int grid, size_t lds_bytes, hipStream_t s);
 void mdx_k_tabulate_fused(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s);
 // (tile_ctr, if not null and w_total >= 4096: 4096 words zeroed on the way — the next launch's tile counters)

@@ -219,7 +219,7 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 // sixteen-base lanes need half the instructions per record and half the wavefronts to keep the units busy, and its bit-sliced
 // counters want the registers (at 80 the hot loop spills)
 #ifndef MDX_PK_BLOCK
-#define MDX_PK_BLOCK 512
+#define MDX_PK_BLOCK 1024               // the largest block of the packed kernels (their launch bound): see MdxPkConfig
 #endif
 #ifndef MDX_PK_DEFER
 #define MDX_PK_DEFER 1                  // the plain packed kernel adds its groups of four steps in pairs (tabulate_kernel: HS)
@@ -233,10 +233,28 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 #ifndef MDX_PK_WPS
 #define MDX_PK_WPS 4
 #endif
-int mdx_k_pk_block_threads() { return MDX_PK_BLOCK; }
-int mdx_k_pk_blocks_per_cu() { return MDX_PK_WPS * 256 / MDX_PK_BLOCK; }
-int mdx_k_pk_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_PK_BLOCK / 64) * mdx_stage_entries(d) * 4; }
-size_t mdx_k_pk_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_pk_queue_off(d) * 4 + (size_t)(MDX_PK_BLOCK / 64) * MDX_PK_EVQ_BYTES + LT_BYTES + MDX_PK_TAB_BYTES; }
+int mdx_k_pk_blocks_per_cu(int threads) { return MDX_PK_WPS * 256 / threads; }
+int mdx_k_pk_queue_off(const MdxDims &d, int threads) { return mdx_k_stage_off(d) + (threads / 64) * mdx_stage_entries(d) * 4; }
+// (behind the queues and the two tables, 16-byte aligned)
+int mdx_k_pk_pfl_off(const MdxDims &d, int threads) {
+    return (int)((((size_t)mdx_k_pk_queue_off(d, threads) * 4 + (size_t)(threads / 64) * MDX_PK_EVQ_BYTES + LT_BYTES + MDX_PK_TAB_BYTES + 15) & ~(size_t)15) / 4);
+}
+size_t mdx_k_pk_lds_bytes(const MdxDims &d, const MdxPkConfig &k) {
+    if (k.pfl) return (size_t)mdx_k_pk_pfl_off(d, k.threads) * 4 + (size_t)(k.threads / 64) * MDX_PFL_WAVE_BYTES;
+    return (size_t)mdx_k_pk_queue_off(d, k.threads) * 4 + (size_t)(k.threads / 64) * MDX_PK_EVQ_BYTES + LT_BYTES + MDX_PK_TAB_BYTES;
+}
+// The largest block whose image fits the LDS: 1024 threads at the defaults (--length 70: 153 KB), 512 or 256 where the tables
+// of a long --length leave less room (a block of 256 — 25 KB beside the tables — fits wherever the ASCII kernel's image does).
+// (MDX_PK_THREADS=256|512|1024: A/B runs and the tests of the smaller blocks)
+MdxPkConfig mdx_k_pk_config(const MdxDims &d, size_t lds_limit) {
+    static const int force_threads = [] { const char *e = getenv("MDX_PK_THREADS"); return e && *e ? atoi(e) : 0; }();
+    MdxPkConfig k;
+    k.threads = MDX_PK_BLOCK; k.pfl = 1;
+    if (force_threads == 256 || force_threads == 512 || force_threads == 1024) k.threads = force_threads;
+    if (k.threads > MDX_PK_BLOCK) k.threads = MDX_PK_BLOCK;
+    while (k.threads > 256 && mdx_k_pk_lds_bytes(d, k) > lds_limit) k.threads /= 2;
+    return k;
+}
 int mdx_k_fuse_queue_off(const MdxDims &d) { return mdx_k_stage_off(d) + (MDX_FUSE_BLOCK / 64) * mdx_stage_entries(d) * 4; }
 int mdx_k_fuse_tcb_off(const MdxDims &d, int qcap) {
     const size_t end = (size_t)mdx_k_fuse_queue_off(d) * 4 + (size_t)(MDX_FUSE_BLOCK / 64) * (size_t)qcap * 20 + LT_BYTES;
@@ -360,6 +378,62 @@ __device__ __forceinline__ int mbcnt64(u64 m, int base) {
 // an entry of the launch's list — index of the byte in the column | new Phred << 32 — instead of a store into a copy of the
 // column.  The lanes that have one at the same time append together: one atomic for all of them (called under divergence it
 // covers the active lanes — the ballot's).
+// the kernel arguments where they lie — in the constant address space: what is read through such a pointer comes by a scalar
+// load at the point of use (through a generic pointer it would be a vector load and a round trip)
+typedef const __attribute__((address_space(4))) MdxTabArgs *karg_p;
+
+// LDS-DMA (global_load_lds_*, gfx950): lane i's element lands in the LDS at the wave-uniform byte address in M0 + 4 i — a
+// ushort zero-extended to a dword — and takes no register on the way (tools/experiments/glds_test.hip holds the semantics
+// against the hardware).  The packed kernels prefetch the phase-1 columns of a wavefront's NEXT tile this way.  Written as asm
+// statements: beside the builtin the compiler waits for vmcnt(0) at the next use of any ordinary load — in the middle of the
+// pipelined runs.  What follows from that: the loads are absent from the compiler's count of outstanding loads (its counted
+// waits can only wait longer for them, never too short: loads return in order), and their data is waited for by hand — an asm
+// s_waitcnt vmcnt(0) with a memory clobber in front of the first read of the area.  M0 is the compiler's: saved and restored.
+// (offsets: bytes from the column's base, 32 bits; the bases: kernel arguments — scalar registers never written by the VALU)
+template <bool LIB>
+__device__ __forceinline__ void pfl_dma_cols(const u32 dst, const u32 off2, const u32 off4, const u32 offo, const u16 *flag, const u16 *lib,
+                                             const int32_t *tid, const int32_t *pos, const int32_t *tlen, const u32 *co, const u32 *so) {
+    u32 keep;
+    if (LIB)
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %6\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %7\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %8\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %9\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %10\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %11\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off2), "v"(off4), "v"(offo), "s"(dst), "s"(flag), "s"(lib), "s"(tid), "s"(pos), "s"(tlen), "s"(co), "s"(so)
+                     : "memory", "scc");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x200\n\ts_nop 0\n\tglobal_load_lds_dword %2, %6\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %7\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %8\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %9\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %10\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off2), "v"(off4), "v"(offo), "s"(dst), "s"(flag), "s"(tid), "s"(pos), "s"(tlen), "s"(co), "s"(so)
+                     : "memory", "scc");
+}
+// ... and the second round trip of a tile: up to three operations of the record's CIGAR and the bounds of its contig (the low
+// words of contig_off[tid] and [tid + 1]), by the lanes that want them
+__device__ __forceinline__ void pfl_dma_rt2(const u32 dst, const u32 o0, const u32 o1, const u32 o2, const u32 oc, const u32 oc1,
+                                            const u32 *cigar, const int64_t *contig_off) {
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %7\n\t"
+                 "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %7\n\t"
+                 "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %7\n\t"
+                 "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %4, %8\n\t"
+                 "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %5, %8\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "v"(o1), "v"(o2), "v"(oc), "v"(oc1), "s"(dst), "s"(cigar), "s"(contig_off)
+                 : "memory", "scc");
+}
+
 __device__ __forceinline__ void patch_put(unsigned long long *__restrict__ patch0, unsigned long long *__restrict__ n_patch0, long long cap,
                                           int parts, bool on, u32 idx, u32 newq) {
     const u64 m = __ballot(on);
@@ -660,7 +734,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     static_assert(!RS || (USE_LDS && FAST && !MASK), "the fused kernel is the unmasked fast LDS kernel");
     static_assert(!PK || (USE_LDS && FAST), "the packed kernel is the fast LDS kernel (plain, with the fused rescaling, or with --min-basequal)");
     static_assert(!ML || (PK && !RS), "a library per pool: the packed kernels (plain and --min-basequal)");
-    constexpr int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOCK);
+    // (the packed kernels: the launch's own block, 512 or 1024 threads — MdxPkConfig)
+    const int BLOCK = RS ? MDX_FUSE_BLOCK : (PK ? (int)blockDim.x : MDX_BLOCK);
+    // pfl: the phase-1 columns of a tile come out of the wavefront's prefetch area in the LDS (see the tile loop) — the packed
+    // kernels but the fused one (its image has no room for the areas)
+    constexpr bool PFLC = PK && !RS;
+    constexpr bool pfl = PFLC;
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const MdxDims d = a.dims;
     const int L = d.L, A = d.A;
@@ -837,6 +916,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     typedef __attribute__((address_space(3))) u32x4 lds_u4;
     typedef __attribute__((address_space(3))) u32 lds_u1;
     const u32 qQ_a = (u32)(size_t)(lds_u4 *)qQ, qE_a = qQ_a + 16u * MDX_PK_QCAP;
+    // the wavefront's prefetch area (MdxTabArgs::pfl_off): [column][lane] dwords
+    const u32 pfl_a = PFLC ? (u32)__builtin_amdgcn_readfirstlane((int)((u32)(size_t)(lds_u1 *)(lds + a.pfl_off) + (u32)wave * (u32)MDX_PFL_WAVE_BYTES)) : 0u;
     static_assert(MDX_PK_QCAP >= 64 && MDX_PK_QCAP % 4 == 0, "a step's events fit an empty queue");
     const u32x2 *const emtab = (const u32x2 *)(ltab + 17);
     const u16 *const pktab = (const u16 *)(ltab + 17 + 64);
@@ -1920,13 +2001,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     u32 n_rec = (u32)a.n_reads, rec_lo = 0u;
     int ml_lib = 0;
     u32 ml_k = 0u, ml_m = 1u, ml_first = 0u;     // ML: the pool's place among the ml_m pools of its library, the first of which is pool ml_first
-    const u32 T = FAST ? 64u - 64u % (u32)d.R : 64u;
+    const u32 T = FAST ? (u32)mdx_tile_records(d, pfl) : 64u;
     const u32 rounds = (n_rec / T) / nwaves;
     const u32 rem_lo = rounds * nwaves * T, rem = n_rec - rem_lo;
     const u32 t_lo = rem_lo + (u32)((u64)rem * gwave / nwaves), t_hi = rem_lo + (u32)((u64)rem * (gwave + 1) / nwaves);
     const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
     // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
-    const MdxTabArgs *const ka = (const MdxTabArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
     // The wavefront's part of MdxTabArgs::lists (MDX_WAVE_SCRATCH(ring_size) 16-byte entries): rings.
     //   ringP / ringI / ringD / ringC   MDX_LIST_RING entries each: partial records, single insertions, single deletions, the
     //                                   complete records the general pass finds.  A list is emptied at the end of a round
@@ -1994,9 +2075,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // the arguments phase 1 needs are read from the kernel-argument segment when they are used (scalar loads through
         // the constant cache) instead of living in SGPRs across the whole kernel: the kernel wants far more scalar
         // registers than there are, and every spilled one costs a v_readlane per use
-        const MdxTabArgs *kp = ka;
+        karg_p kp = ka;
         asm volatile("" : "+s"(kp));
-        const MdxTabArgs &p = *kp;
+        const __attribute__((address_space(4))) MdxTabArgs &p = *kp;
         // ------------------------------------------------------------ phase 1: lane per record
         bool kept = valid && (fl & 0xF04u) == 0;  // reader.py:121-132
         // a launch counts the libraries [lib_lo, lib_lo + d.nlib) (mdx_capi.cpp: as many as fit the LDS); records of
@@ -2515,7 +2596,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // one-library launch share the batch's; see the template's comment)
     {
     if (ML) {
-        const MdxTabArgs *kp = ka;
+        karg_p kp = ka;
         asm volatile("" : "+s"(kp));
         // (a kept record whose library the context does not know was given no place by the sort: reported here, like the
         // record the one-library kernel finds)
@@ -2614,7 +2695,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // empty has one tile less left to do)
         u32 cur = tile_of(grab());
         constexpr bool PF = PK && !ML && !RS && !MASK && MDX_PK_PREFETCH;     // (the prefetched columns know no libraries)
-        u32 nxt = (RS || PF) && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
+        u32 nxt = (RS || PF || pfl) && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
         // PK: the loads of a tile's phase 1 — its nine column values, then the operations and contig bounds they lead to —
         // are requested a tile ahead, the first round trip in front of the current tile's phase 1 and the second in front of
         // its run: with sixteen-base lanes the units have the slack, and what bounds a wavefront is the chain of round trips
@@ -2650,6 +2731,43 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         };
         Cols Cc = {}, Cn = {};
         Rt2 Gc = {}, Gn = {};
+        // pfl — the same without registers: the columns of the NEXT tile are requested into the wavefront's prefetch area by
+        // LDS-DMA loads (pfl_dma_cols) at the head of a tile, as soon as the current tile's have been read out of it; its
+        // second round trip (pfl_dma_rt2) goes out in front of the current tile's run, once those columns have landed, and
+        // lands under the run.  A tile's phase 1 then starts with everything it needs in the LDS: no round trip but the one of
+        // the run's own first loads.  Area: [flag | library | tid | pos | tlen | cigar_off | seq_off | op 0 | op 1 | op 2 |
+        // contig start | contig end][lane]; a record's end offsets are its right neighbour's start offsets (a tile has 63
+        // records at most: lane 63 brings the last end).
+        // (the columns' bases through the kernel arguments' own address space: scalar loads at the point of use — the asm
+        // statements want them in scalar registers, and nothing keeps them there across a tile)
+        auto pfl_cols = [&](const u32 tile) {
+            karg_p kp = ka;
+            asm volatile("" : "+s"(kp));
+            const u32 i_ = tile * T + (u32)lane;
+            // (lanes past the batch's end: its last record, and the offsets' last entry — their records are not valid)
+            const u32 i1 = (i_ < n_rec - 1u ? i_ : n_rec - 1u) + (ML ? rec_lo : 0u), i2 = (i_ < n_rec ? i_ : n_rec) + (ML ? rec_lo : 0u);
+            pfl_dma_cols<!ML>(pfl_a, i1 * 2u, i1 * 4u, i2 * 4u, kp->flag, kp->lib, kp->tid, kp->pos, kp->tlen, kp->cigar_off, kp->seq_off);
+        };
+        auto pfl_rt2 = [&](const u32 tile) {
+            karg_p kp = ka;
+            asm volatile("" : "+s"(kp));
+            const u32 tb = tile * T, rh = tb + T < n_rec ? tb + T : n_rec;
+            const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
+            const u32 fl_ = tb + (u32)lane < rh ? C[0] : 0x4u;
+            const int lib_ = ML ? a.lib_lo + ml_lib : (int)C[64], tid_ = (int)C[128];
+            const u32 co0_ = C[320], co1_ = C[321];
+            bool kept_ = (fl_ & 0xF04u) == 0;
+            if (!ML && lib_ < a.nlib_total && (lib_ < a.lib_lo || lib_ >= a.lib_lo + d.nlib)) kept_ = false;
+            const u32 cn_ = co1_ - co0_;
+            const bool cand_ = kept_ && cn_ - 1u < 3u && tid_ >= 0 && tid_ < a.n_contig && lib_ < a.nlib_total;
+            if (cand_) pfl_dma_rt2(pfl_a + 7u * 256u, co0_ * 4u, (co0_ + (cn_ >= 2u ? 1u : 0u)) * 4u, (co0_ + (cn_ >= 3u ? 2u : 0u)) * 4u,
+                                   (u32)tid_ * 8u, (u32)tid_ * 8u + 8u, kp->cigar, kp->contig_off);
+        };
+        if (pfl && cur != 0xFFFFFFFFu) {
+            pfl_cols(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pfl_rt2(cur);
+        }
         constexpr bool PF2 = PF && MDX_PK_PREFETCH == 1;        // (2: the columns only — the second round trip stays in phase 1)
         if (PF && cur != 0xFFFFFFFFu) { Cc = p_cols(cur); if (PF2) Gc = p_rt2(Cc); }
         if (RS && cur != 0xFFFFFFFFu) {
@@ -2709,11 +2827,27 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             if (!past) {
                 MDX_PH(1);
                 tiles_left--;
-                if (!(RS || PF) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
+                // pfl: the tile's columns and second round trip out of the prefetch area (requested a tile ago: landed), then the
+                // next tile's columns into it
+                u32 P_fl = 0u, P_lib = 0u, P_tid = 0u, P_pos = 0u, P_tlen = 0u, P_co0 = 0u, P_co1 = 0u, P_so0 = 0u, P_so1 = 0u;
+                u32 P_g0 = 0u, P_g1 = 0u, P_g2 = 0u, P_c0 = 0u, P_c1 = 0u;
+                if (pfl) {
+                    MDX_PH(11);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
+                    P_fl = C[0]; if (!ML) P_lib = C[64];
+                    P_tid = C[128]; P_pos = C[192]; P_tlen = C[256]; P_co0 = C[320]; P_co1 = C[321]; P_so0 = C[384]; P_so1 = C[385];
+                    P_g0 = C[448]; P_g1 = C[512]; P_g2 = C[576]; P_c0 = C[640]; P_c1 = C[704];
+                    // (read before the next tile's columns may land on them)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    MDX_PH(1);
+                }
+                if (!(RS || PF || pfl) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
+                if (pfl && nxt != 0xFFFFFFFFu) pfl_cols(nxt);
                 if (PF && nxt != 0xFFFFFFFFu) Cn = p_cols(nxt);
-                const MdxTabArgs *kp = ka;
+                karg_p kp = ka;
                 asm volatile("" : "+s"(kp));
-                const MdxTabArgs &p = *kp;
+                const __attribute__((address_space(4))) MdxTabArgs &p = *kp;
                 const u32 tbase = cur * T;
                 const u32 r_lo = tbase;
                 const u32 r_hi = tbase + T < n_rec ? tbase + T : n_rec;
@@ -2754,11 +2888,21 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const u32 ri = r_lo + lane + (ML ? rec_lo : 0u);
                 const bool valid = r_lo + lane < r_hi;
                 const u32 rj = valid ? ri : tbase + (ML ? rec_lo : 0u);
-                const u32 fl = PF ? Cc.fl : (valid ? (u32)ld32(a.flag, rj) : 0x4u);
-                const int c_lib = PF ? Cc.lib : (ML ? a.lib_lo + ml_lib : ld32(a.lib, rj)), c_tid = PF ? Cc.tid : ld32(a.tid, rj), c_pos = PF ? Cc.pos : ld32(a.pos, rj),
-                          c_tlen = PF ? Cc.tlen : ld32(a.tlen, rj);
-                const u32 c_co0 = PF ? Cc.co0 : ld32(a.cigar_off, rj), c_co1 = PF ? Cc.co1 : ld32(a.cigar_off, rj + 1),
-                          c_so0 = PF ? Cc.so0 : ld32(a.seq_off, rj), c_so1 = PF ? Cc.so1 : ld32(a.seq_off, rj + 1);
+                u32 fl;
+                int c_lib, c_tid, c_pos, c_tlen;
+                u32 c_co0, c_co1, c_so0, c_so1;
+                if (PF) {
+                    fl = Cc.fl; c_lib = Cc.lib; c_tid = Cc.tid; c_pos = Cc.pos; c_tlen = Cc.tlen;
+                    c_co0 = Cc.co0; c_co1 = Cc.co1; c_so0 = Cc.so0; c_so1 = Cc.so1;
+                } else if (pfl) {
+                    fl = valid ? P_fl : 0x4u;
+                    c_lib = ML ? a.lib_lo + ml_lib : (int)P_lib; c_tid = (int)P_tid; c_pos = (int)P_pos; c_tlen = (int)P_tlen;
+                    c_co0 = P_co0; c_co1 = P_co1; c_so0 = P_so0; c_so1 = P_so1;
+                } else {
+                    fl = valid ? (u32)ld32(a.flag, rj) : 0x4u;
+                    c_lib = ML ? a.lib_lo + ml_lib : ld32(a.lib, rj); c_tid = ld32(a.tid, rj); c_pos = ld32(a.pos, rj); c_tlen = ld32(a.tlen, rj);
+                    c_co0 = ld32(a.cigar_off, rj); c_co1 = ld32(a.cigar_off, rj + 1); c_so0 = ld32(a.seq_off, rj); c_so1 = ld32(a.seq_off, rj + 1);
+                }
                 int c_mtid = 0, c_mpos = 0;
                 bool rs_anyhi = false;       // RS: some quality byte of the tile has bit 7 set (0xFF: a record without qualities)
                 if (RS) {
@@ -2816,6 +2960,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 u32 c0 = 0, clen = 0;
                 u32 q0 = 0xFFu;
                 if (PF2) { g0 = Gc.g0; g1 = Gc.g1; g2 = Gc.g2; c0 = Gc.c0; clen = Gc.clen; }
+                else if (pfl) {
+                    // (the lanes that asked: pfl_rt2 made the same test on the same columns)
+                    if (cand) { g0 = P_g0; c0 = P_c0; clen = P_c1 - P_c0; }
+                    if (cand && cn >= 2u) g1 = P_g1;
+                    if (cand && cn >= 3u) g2 = P_g2;
+                }
                 else if (cand) {
                     g0 = a.cigar[c_co0];
                     if (cn >= 2u) g1 = a.cigar[c_co0 + 1];
@@ -3043,6 +3193,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (the stores of this phase 1 retired — they have had the phase —, so that the run's loops see nothing but loads
                 // in flight and their waits are counted; PK: the next tile's second round trip goes out behind that wait and
                 // lands under the run)
+                if (pfl) {
+                    // (... and the next tile's columns landed: its second round trip goes out here and lands under the run)
+                    MDX_PH(15);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (nxt != 0xFFFFFFFFu) pfl_rt2(nxt);
+                } else
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (PF2 && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) {
@@ -3128,7 +3284,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             }
             if (over ? dDone >= nDef : past) break;
             if (!past) {
-                if (RS || PF) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
+                if (RS || PF || pfl) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
                 else cur = tile_of(nxt2_raw);
                 if (PF) { Cc = Cn; if (PF2) Gc = Gn; }
             }
@@ -3344,11 +3500,11 @@ hipError_t mdx_k_prepare_packed_masked(size_t lds_bytes) {
     return e;
 }
 // (a.n_libs > 0: the libraries [lib_lo, lib_lo + n_libs) in one launch over the bucketed columns, a library per pool: see ML)
-void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+void mdx_k_tabulate_packed_masked(const MdxTabArgs &a, int grid, int threads, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    if (a.n_libs > 0) hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    if (a.n_libs > 0) hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true, true>), dim3(grid), dim3(threads), lds_bytes, s, a);
     else
-    hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((tabulate_kernel<true, true, true, false, true>), dim3(grid), dim3(threads), lds_bytes, s, a);
 }
 // --min-basequal for the packed kernels: the mask folded into the 4-bit SEQ column (MDX_SEQ_4BIT -> MDX_SEQ_4BITQ,
 // include/mdx.h) — a symbol whose quality is below the threshold (align.py:65-71; 0xFF, no qualities, is not) becomes the
@@ -3397,11 +3553,11 @@ hipError_t mdx_k_prepare_packed(size_t lds_bytes) {
 
 // the packed kernel: 4-bit SEQ column and 4-bit reference; one library per launch, or (a.n_libs > 0) the libraries
 // [lib_lo, lib_lo + n_libs) side by side over the bucketed columns, a library per pool
-void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+void mdx_k_tabulate_packed(const MdxTabArgs &a, int grid, int threads, size_t lds_bytes, hipStream_t s) {
     if (a.n_reads <= 0) return;
-    if (a.n_libs > 0) hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    if (a.n_libs > 0) hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true, true>), dim3(grid), dim3(threads), lds_bytes, s, a);
     else
-    hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(MDX_PK_BLOCK), lds_bytes, s, a);
+    hipLaunchKernelGGL((tabulate_kernel<true, false, true, false, true>), dim3(grid), dim3(threads), lds_bytes, s, a);
 }
 
 hipError_t mdx_k_prepare(size_t lds_bytes) {

@@ -14,7 +14,7 @@ if os.environ.get('MDX_LIB'):
     engine._lib = engine.load_library(os.environ['MDX_LIB'])
 NAMES = ["other (tile hand-out, rounds)", "phase 1 of a tile", "complete runs of the tile", "partial runs of the tile", "drain (events)",
          "planes -> LDS", "general pass", "lists: complete / partial", "lists: insertion runs", "lists: deletion runs",
-         "final drain + fold", "(end)", "general: walks (phase 2b)", "general: compositions behind deletions", "lists: the runs themselves (of the three list rows)", "-"]
+         "final drain + fold", "prefetch area: wait + read (tile head)", "general: walks (phase 2b)", "general: compositions behind deletions", "lists: the runs themselves (of the three list rows)", "wait for the next tile's columns, its second round trip out"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 which = (sys.argv[2] if len(sys.argv) > 2 else "config 3").split("|")
 ref = synth.make_genome()
