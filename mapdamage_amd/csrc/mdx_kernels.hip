@@ -395,7 +395,7 @@ __device__ __forceinline__ void pfl_dma_cols(const u32 dst, const u32 off2, cons
                                              const int32_t *tid, const int32_t *pos, const int32_t *tlen, const u32 *co, const u32 *so) {
     u32 keep;
     if (LIB)
-        asm volatile("s_mov_b32 %0, m0\n\t"
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t"
                      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %5\n\t"
                      "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %6\n\t"
                      "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %7\n\t"
@@ -407,7 +407,7 @@ __device__ __forceinline__ void pfl_dma_cols(const u32 dst, const u32 off2, cons
                      : "=&s"(keep) : "v"(off2), "v"(off4), "v"(offo), "s"(dst), "s"(flag), "s"(lib), "s"(tid), "s"(pos), "s"(tlen), "s"(co), "s"(so)
                      : "memory", "scc");
     else
-        asm volatile("s_mov_b32 %0, m0\n\t"
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t"
                      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_ushort %1, %5\n\t"
                      "s_add_u32 m0, m0, 0x200\n\ts_nop 0\n\tglobal_load_lds_dword %2, %6\n\t"
                      "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %7\n\t"
@@ -423,7 +423,7 @@ __device__ __forceinline__ void pfl_dma_cols(const u32 dst, const u32 off2, cons
 __device__ __forceinline__ void pfl_dma_rt2(const u32 dst, const u32 o0, const u32 o1, const u32 o2, const u32 oc, const u32 oc1,
                                             const u32 *cigar, const int64_t *contig_off) {
     u32 keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %7\n\t"
                  "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, %7\n\t"
                  "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %7\n\t"
@@ -432,6 +432,17 @@ __device__ __forceinline__ void pfl_dma_rt2(const u32 dst, const u32 o0, const u
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(o0), "v"(o1), "v"(o2), "v"(oc), "v"(oc1), "s"(dst), "s"(cigar), "s"(contig_off)
                  : "memory", "scc");
+}
+
+// stores the compiler does not count either (the records a tile's phase 1 leaves to the general pass): base a wave-uniform
+// pointer, off a byte offset.  (s_nop 4 opening every statement that hands a scalar register pair to a memory instruction:
+// the pair may come fresh from a v_readlane — a spilled scalar — and a vector memory instruction reads it five states late;
+// the compiler pads its own instructions, not an asm statement's)
+__device__ __forceinline__ void pfl_store_b32(const void *base, const u32 off, const u32 v) {
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void pfl_store_b128(const void *base, const u32 off, const u32x4 v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(off), "v"(v), "s"(base) : "memory");
 }
 
 __device__ __forceinline__ void patch_put(unsigned long long *__restrict__ patch0, unsigned long long *__restrict__ n_patch0, long long cap,
@@ -1257,6 +1268,45 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // One step of the fast path: R records, one per slot of G lanes (see MdxDims).  Stage = the loaded bytes
     // of a step and its record words.
     struct Stage { u32x3 s12, r12, q12; u32 ro, so, pk, aux; int lim, k; bool valid; };
+    // (declared here, in front of the runs: the prefetch of the next tile's second round trip is issued from inside a run)
+    // (ML: the records of the pool's library, places [rec_lo, rec_lo + n_rec) of the bucketed columns; ml_lib = that library,
+    // counted from the launch's first one — set where the pool's plan is read)
+    u32 n_rec = (u32)a.n_reads, rec_lo = 0u;
+    int ml_lib = 0;
+    const u32 T = FAST ? (u32)mdx_tile_records(d, pfl) : 64u;
+    const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    // pfl — the phase-1 columns of the wavefront's NEXT tile are requested into its prefetch area by LDS-DMA loads
+    // (pfl_dma_cols) at the head of a tile, as soon as the current tile's have been read out of it; the next tile's second
+    // round trip (pfl_dma_rt2: it needs those columns) goes out from inside the current tile's first run, behind that run's
+    // first loads — by then the columns have landed — and lands under the run.  A tile's phase 1 then starts with everything
+    // it needs in the LDS, and the one round trip a wavefront waits for per tile is that of its run's first loads.
+    // Area: [flag | library | tid | pos | tlen | cigar_off | seq_off | op 0 | op 1 | op 2 | contig start | contig end][lane]; a
+    // record's end offsets are its right neighbour's start offsets (a tile has 63 records at most: lane 63 brings the last end).
+    auto pfl_cols = [&](const u32 tile) {
+        karg_p kp = ka;
+        asm volatile("" : "+s"(kp));
+        const u32 i_ = tile * T + (u32)lane;
+        // (lanes past the batch's end: its last record, and the offsets' last entry — their records are not valid)
+        const u32 i1 = (i_ < n_rec - 1u ? i_ : n_rec - 1u) + (ML ? rec_lo : 0u), i2 = (i_ < n_rec ? i_ : n_rec) + (ML ? rec_lo : 0u);
+        pfl_dma_cols<!ML>(pfl_a, i1 * 2u, i1 * 4u, i2 * 4u, kp->flag, kp->lib, kp->tid, kp->pos, kp->tlen, kp->cigar_off, kp->seq_off);
+    };
+    auto pfl_rt2 = [&](const u32 tile) {
+        karg_p kp = ka;
+        asm volatile("" : "+s"(kp));
+        const u32 tb = tile * T, rh = tb + T < n_rec ? tb + T : n_rec;
+        const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
+        const u32 fl_ = tb + (u32)lane < rh ? C[0] : 0x4u;
+        const int lib_ = ML ? a.lib_lo + ml_lib : (int)C[64], tid_ = (int)C[128];
+        const u32 co0_ = C[320], co1_ = C[321];
+        bool kept_ = (fl_ & 0xF04u) == 0;
+        if (!ML && lib_ < a.nlib_total && (lib_ < a.lib_lo || lib_ >= a.lib_lo + d.nlib)) kept_ = false;
+        const u32 cn_ = co1_ - co0_;
+        const bool cand_ = kept_ && cn_ - 1u < 3u && tid_ >= 0 && tid_ < a.n_contig && lib_ < a.nlib_total;
+        if (cand_) pfl_dma_rt2(pfl_a + 7u * 256u, co0_ * 4u, (co0_ + (cn_ >= 2u ? 1u : 0u)) * 4u, (co0_ + (cn_ >= 3u ? 2u : 0u)) * 4u,
+                               (u32)tid_ * 8u, (u32)tid_ * 8u + 8u, kp->cigar, kp->contig_off);
+    };
+    // (pfl_due: the tile whose second round trip the next run is to request behind its first loads — 0xFFFFFFFE: nothing due)
+    u32 pfl_due = 0xFFFFFFFEu;
     // Three kinds of steps (one instantiation each):
     //   STEP_C  complete records: every task present, static byte masks;
     //   STEP_P  a column range per side: short records and contig edges ([-flank, min(nq, L))), gapped records whose
@@ -1841,6 +1891,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
 #endif
 #pragma unroll
                     for (int dd = 0; dd < PD4; dd++) fill16(st[dd]);
+                    if (pfl && pfl_due != 0xFFFFFFFEu) {
+                        // the next tile's columns — older than the 2 PD4 loads just issued, and loads return in order — have landed:
+                        // its second round trip out, behind this run's first loads (stores still on their way only make
+                        // the count wait longer)
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * PD4) : "memory");
+                        if (pfl_due != 0xFFFFFFFFu) pfl_rt2(pfl_due);
+                        pfl_due = 0xFFFFFFFEu;
+                    }
                     int k = kstart + PD4;
                     using P0 = std::integral_constant<int, 0>;
                     if (HS && PD4 == 4) {
@@ -1998,16 +2056,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
     // records ends on a full step.
     // (ML: the records of the pool's library, places [rec_lo, rec_lo + n_rec) of the bucketed columns; ml_lib = that library,
     // counted from the launch's first one)
-    u32 n_rec = (u32)a.n_reads, rec_lo = 0u;
-    int ml_lib = 0;
     u32 ml_k = 0u, ml_m = 1u, ml_first = 0u;     // ML: the pool's place among the ml_m pools of its library, the first of which is pool ml_first
-    const u32 T = FAST ? (u32)mdx_tile_records(d, pfl) : 64u;
     const u32 rounds = (n_rec / T) / nwaves;
     const u32 rem_lo = rounds * nwaves * T, rem = n_rec - rem_lo;
     const u32 t_lo = rem_lo + (u32)((u64)rem * gwave / nwaves), t_hi = rem_lo + (u32)((u64)rem * (gwave + 1) / nwaves);
     const u32 n_it = rounds + (t_hi - t_lo + T - 1) / T;
     // the wavefront's lists of staged entries that are not complete records (MdxTabArgs::lists)
-    const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
     // The wavefront's part of MdxTabArgs::lists (MDX_WAVE_SCRATCH(ring_size) 16-byte entries): rings.
     //   ringP / ringI / ringD / ringC   MDX_LIST_RING entries each: partial records, single insertions, single deletions, the
     //                                   complete records the general pass finds.  A list is emptied at the end of a round
@@ -2731,38 +2785,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         };
         Cols Cc = {}, Cn = {};
         Rt2 Gc = {}, Gn = {};
-        // pfl — the same without registers: the columns of the NEXT tile are requested into the wavefront's prefetch area by
-        // LDS-DMA loads (pfl_dma_cols) at the head of a tile, as soon as the current tile's have been read out of it; its
-        // second round trip (pfl_dma_rt2) goes out in front of the current tile's run, once those columns have landed, and
-        // lands under the run.  A tile's phase 1 then starts with everything it needs in the LDS: no round trip but the one of
-        // the run's own first loads.  Area: [flag | library | tid | pos | tlen | cigar_off | seq_off | op 0 | op 1 | op 2 |
-        // contig start | contig end][lane]; a record's end offsets are its right neighbour's start offsets (a tile has 63
-        // records at most: lane 63 brings the last end).
-        // (the columns' bases through the kernel arguments' own address space: scalar loads at the point of use — the asm
-        // statements want them in scalar registers, and nothing keeps them there across a tile)
-        auto pfl_cols = [&](const u32 tile) {
-            karg_p kp = ka;
-            asm volatile("" : "+s"(kp));
-            const u32 i_ = tile * T + (u32)lane;
-            // (lanes past the batch's end: its last record, and the offsets' last entry — their records are not valid)
-            const u32 i1 = (i_ < n_rec - 1u ? i_ : n_rec - 1u) + (ML ? rec_lo : 0u), i2 = (i_ < n_rec ? i_ : n_rec) + (ML ? rec_lo : 0u);
-            pfl_dma_cols<!ML>(pfl_a, i1 * 2u, i1 * 4u, i2 * 4u, kp->flag, kp->lib, kp->tid, kp->pos, kp->tlen, kp->cigar_off, kp->seq_off);
-        };
-        auto pfl_rt2 = [&](const u32 tile) {
-            karg_p kp = ka;
-            asm volatile("" : "+s"(kp));
-            const u32 tb = tile * T, rh = tb + T < n_rec ? tb + T : n_rec;
-            const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
-            const u32 fl_ = tb + (u32)lane < rh ? C[0] : 0x4u;
-            const int lib_ = ML ? a.lib_lo + ml_lib : (int)C[64], tid_ = (int)C[128];
-            const u32 co0_ = C[320], co1_ = C[321];
-            bool kept_ = (fl_ & 0xF04u) == 0;
-            if (!ML && lib_ < a.nlib_total && (lib_ < a.lib_lo || lib_ >= a.lib_lo + d.nlib)) kept_ = false;
-            const u32 cn_ = co1_ - co0_;
-            const bool cand_ = kept_ && cn_ - 1u < 3u && tid_ >= 0 && tid_ < a.n_contig && lib_ < a.nlib_total;
-            if (cand_) pfl_dma_rt2(pfl_a + 7u * 256u, co0_ * 4u, (co0_ + (cn_ >= 2u ? 1u : 0u)) * 4u, (co0_ + (cn_ >= 3u ? 2u : 0u)) * 4u,
-                                   (u32)tid_ * 8u, (u32)tid_ * 8u + 8u, kp->cigar, kp->contig_off);
-        };
         if (pfl && cur != 0xFFFFFFFFu) {
             pfl_cols(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2834,6 +2856,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (pfl) {
                     MDX_PH(11);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // (... said again for the compiler, which does not read asm statements: nothing is on its way from here, and
+                    // the runs of this tile count their waits)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
                     const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
                     P_fl = C[0]; if (!ML) P_lib = C[64];
                     P_tid = C[128]; P_pos = C[192]; P_tlen = C[256]; P_co0 = C[320]; P_co1 = C[321]; P_so0 = C[384]; P_so1 = C[385];
@@ -3023,9 +3048,17 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         uint4 c0_, c1_;
                         c0_.x = fl | ((u32)c_lib << 16); c0_.y = (u32)c_tid; c0_.z = (u32)c_pos; c0_.w = (u32)c_tlen;
                         c1_.x = c_co0; c1_.y = c_co1; c1_.z = c_so0; c1_.w = c_so1;
+                        if (pfl) {
+                            // (stores the compiler does not know of: it would wait for them — vmcnt(0) — at the head of the runs'
+                            // pipelined loops; they are waited for in front of the general pass that reads them back)
+                            pfl_store_b32(dlist, ((u32)at & DM) * 4u, ri | (rs_def << 30));
+                            pfl_store_b128(dcols, ((u32)at & DM) * 32u, u32x4{c0_.x, c0_.y, c0_.z, c0_.w});
+                            pfl_store_b128(dcols, ((u32)at & DM) * 32u + 16u, u32x4{c1_.x, c1_.y, c1_.z, c1_.w});
+                        } else {
                         dlist[(u32)at & DM] = ri | (rs_def << 30);
                         dcols[2 * ((u32)at & DM)] = c0_;
                         dcols[2 * ((u32)at & DM) + 1] = c1_;
+                        }
                     }
                     nDef += __popcll(mDef);
                 }
@@ -3193,12 +3226,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (the stores of this phase 1 retired — they have had the phase —, so that the run's loops see nothing but loads
                 // in flight and their waits are counted; PK: the next tile's second round trip goes out behind that wait and
                 // lands under the run)
-                if (pfl) {
-                    // (... and the next tile's columns landed: its second round trip goes out here and lands under the run)
-                    MDX_PH(15);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (nxt != 0xFFFFFFFFu) pfl_rt2(nxt);
-                } else
+                // (pfl: no wait — this phase 1 has stored nothing the compiler knows of (pfl_store_*), and the next tile's second
+                // round trip goes out from inside the tile's first run; a tile without a run: here)
+                if (pfl) pfl_due = nxt;
+                else
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 if (PF2 && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) {
@@ -3206,6 +3237,12 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp);
                     MDX_PH(3);
                     if (PTILE && nPt) run(nF, nPt, std::integral_constant<int, STEP_P>{}, std::true_type{}, nPtp);
+                    if (pfl && pfl_due != 0xFFFFFFFEu) {
+                        MDX_PH(15);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (pfl_due != 0xFFFFFFFFu) pfl_rt2(pfl_due);
+                        pfl_due = 0xFFFFFFFEu;
+                    }
                     MDX_PH(0);
                 }
                 else {
@@ -3272,6 +3309,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (PK) bs_flush();
 #endif
                 // (the wavefront's own stores: complete before they are read back)
+                if (pfl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const u32 at = (u32)(dDone + (lane < m ? lane : 0)) & DM;
