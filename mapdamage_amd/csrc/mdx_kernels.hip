@@ -142,10 +142,11 @@ typedef long long i64;
 #define MDX_PKM_PD 3                    // ... and with --min-basequal
 #endif
 #ifndef MDX_PK_PD_ML
-#define MDX_PK_PD_ML 3                  // ... and of the launches over several libraries (a pool's library, its records' place
+#define MDX_PK_PD_ML 4                  // ... and of the launches over several libraries (a pool's library, its records' place
 #endif                                  // in the batch ordered by library and the pools that share its tiles want registers too)
 #ifndef MDX_PKM_PD_ML
-#define MDX_PKM_PD_ML 1                 // ... with --min-basequal (rounds and a second set of planes: 32 registers spilled at best)
+#define MDX_PKM_PD_ML 3                 // ... with --min-basequal (rounds and a second set of planes; 16 M records over 8 libraries at -Q 20, x the
+                                        // one-library masked launch: one step in flight 1.20, two 1.07, three — 2 registers spilled — 1.02)
 #endif
 #ifndef MDX_PD_P_ML
 #define MDX_PD_P_ML 2                   // ... their runs of partial entries (three: 4 registers spilled; two: none)
@@ -228,7 +229,7 @@ int mdx_k_fuse_block_threads() { return MDX_FUSE_BLOCK; }
 #define MDX_PK_STEAL 2                    // pools a wavefront of the packed kernels asks for tiles once its own is empty (0: none)
 #endif
 #ifndef MDX_PK_DEFER_ML
-#define MDX_PK_DEFER_ML 0               // ... the kernel of the launches over several libraries does not: 128 registers (with them: no faster)
+#define MDX_PK_DEFER_ML 1               // ... the kernel of the launches over several libraries too (round 6: it has the registers)
 #endif
 #ifndef MDX_PK_WPS
 #define MDX_PK_WPS 4
@@ -1832,7 +1833,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                 };
                 // (--min-basequal: three — the second set of planes and the bitmap words want the registers of the fourth)
-                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? (ML ? MDX_PD_G_ML : MDX_PD_G) : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : (ML ? MDX_PD_P_ML : MDX_PD_P)) : (MASK ? (ML ? MDX_PKM_PD_ML : MDX_PKM_PD) : (ML ? MDX_PK_PD_ML : MDX_PK_PD)));
+                // (ML without MASK: the depths of the one-library kernel since round 6 — its arguments come by scalar loads and
+                // it has that kernel's registers; ML with MASK — rounds and a second set of planes — keeps depths of its own)
+                constexpr bool MLM = ML && MASK;
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? (MLM ? MDX_PD_G_ML : MDX_PD_G) : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : (MLM ? MDX_PD_P_ML : MDX_PD_P)) : (MASK ? (ML ? MDX_PKM_PD_ML : MDX_PKM_PD) : (ML ? MDX_PK_PD_ML : MDX_PK_PD)));
                 static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
                 St16 st[PD4];
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
