@@ -114,6 +114,7 @@ struct mdx_ctx {
     // reference
     uint8_t *d_ref = nullptr;
     uint8_t *d_ref4 = nullptr;     // the same bases as 4-bit codes, guard bands included (the packed kernel's)
+    bool ref2 = false;             // ... twice, the second copy 2 GiB + 64 bytes behind the first (MdxTabArgs::ref2)
     int64_t *d_contig_off = nullptr;
     int n_contig = 0;
     int64_t ref_len = 0;
@@ -396,10 +397,23 @@ static int ref_begin(mdx_ctx *c, int64_t n, int32_t n_contig) {
 // of them: one more guard byte behind an odd genome)
 static int ref_finish(mdx_ctx *c, const int64_t *contig_off, int32_t n_contig, int64_t n) {
     const size_t n4 = ((size_t)n + 2 * kRefPad + 1) / 2;
+    // (MdxTabArgs::ref2 — a genome whose 4-bit form is past what the caches hold, 64 MB and more: a second copy 2 GiB + 64 bytes
+    // behind the first, for the packed kernels to pick from per record; both within the 4 GiB a 32-bit byte offset reaches.
+    // MDX_NO_REF2=1: one copy, for A/B runs)
+    static const bool no_ref2 = [] { const char *e = getenv("MDX_NO_REF2"); return e && *e && *e != '0'; }();
+    const size_t kCopyB = ((size_t)1 << 31) + 64;
+    // (MDX_REF2_MIN=bytes: the size of the 4-bit form from which there are two — the tests' way to the second copy on a small genome)
+    static const size_t ref2_min = [] { const char *e = getenv("MDX_REF2_MIN"); return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t)64 << 20; }();
+    c->ref2 = n4 >= ref2_min && n4 + 128 <= ((size_t)1 << 31) - 64 && !no_ref2;
     hipError_t e = hipMemcpyAsync(c->d_contig_off, contig_off, (size_t)(n_contig + 1) * 8, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_ref4, n4 + 64);
+    if (e == hipSuccess) {
+        e = hipMalloc((void **)&c->d_ref4, (c->ref2 ? kCopyB : 0) + n4 + 64);
+        // (no room for the gap: one copy)
+        if (e != hipSuccess && c->ref2) { (void)hipGetLastError(); c->ref2 = false; e = hipMalloc((void **)&c->d_ref4, n4 + 64); }
+    }
     if (e == hipSuccess) e = hipMemsetAsync(c->d_ref4, 0, n4 + 64, c->stream);
     if (e == hipSuccess) { mdx_k_encode_ref4(c->d_ref, c->d_ref4, (int64_t)(2 * n4), c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess && c->ref2) e = hipMemcpyAsync(c->d_ref4 + kCopyB, c->d_ref4, n4 + 64, hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         // (a reference half in place is none: the launches ask for d_ref)
@@ -652,6 +666,7 @@ static int tabulate_impl(mdx_ctx *c, const mdx_batch *b_in, const MdxFuse *fuse,
     }
     MdxTabArgs a{};
     a.ref4 = c->d_ref4;
+    a.ref2 = c->ref2 ? 1 : 0;
     a.seq_packed = packed ? 1 : 0;
     a.n_reads = b->n_reads;
     a.flag = b->flag; a.lib = b->lib; a.tid = b->tid; a.pos = b->pos; a.tlen = b->tlen;

@@ -187,6 +187,12 @@ struct MdxTabArgs {
     // ... and its 4-bit form (MDX_SEQ_4BIT codes, two bases per byte, the 256-base guard bands included: nibble i is
     // genome coordinate i - 256), read by the packed kernel (tabulate_kernel<.., PK>) together with a 4-bit SEQ column
     const uint8_t *ref4;
+    // ref2 (a large genome): a SECOND copy of the 4-bit reference at ref4 + 2 GiB + 64 bytes — half a 128-byte line out of
+    // phase.  What a random access to the reference costs the memory system is the lines it touches, not the bytes (55 G lines/s
+    // chip-wide whatever a window's width, tools/experiments/randwin.hip); the window of a 100-base record — 68 bytes — straddles
+    // two lines 47 % of the time in one copy and 3 % of the time in the better of the two.  Phase 1 of the packed kernels picks
+    // the copy per record (bit 31 of a complete record's staging word w: a byte offset of 2 GiB, or'ed to the lane's).
+    int ref2;
     int seq_packed;                  // the batch's seq column holds MDX_SEQ_4BIT codes (include/mdx.h)
     const int64_t *contig_off;
     int n_contig;

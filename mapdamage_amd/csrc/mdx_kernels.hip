@@ -1569,6 +1569,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // (the slot holds a record iff H k + slot < the entries of its strand)
                     bool act = true;
                     int idx = 0;
+                    u32 ref_copy = 0u;
                     if (!FIDX || MDX_PK_ENT_AHEAD) idx = ent_index(kf, act);
                     kf++;
                     st.k = k;
@@ -1580,6 +1581,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const u32 ad = ent_a0 + (u32)(H16 * k);
                         const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
                         ent = make_uint4(e_.x, e_.y, e_.z, e_.w);
+                        // (w of a complete record's entry: the byte offset of the copy of the reference its window is read from —
+                        // 0, or 2 GiB: MdxTabArgs::ref2)
+                        ref_copy = e_.w;
                     } else ent = stg[idx];
 #endif
                     const u32 t = ent.z & c_cm;
@@ -1644,7 +1648,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     }
                     // sixteen nibbles from bit 4 (offset & 7) of the aligned dword triple
                     st.ra = ro << 2; st.sa = so << 2;
-                    st.r = *(const u32v3_u *)(refW + ((ro >> 1) & ~3u));
+                    st.r = *(const u32v3_u *)(refW + (((ro >> 1) & 0x7FFFFFFCu) | ref_copy));
                     st.s = *(const u32v3_u *)(seqW + ((so >> 1) & ~3u));
                     st.pk = KIND == STEP_C ? 0u : ent.w;
 #if MDX_PK_ENT_AHEAD
@@ -2815,7 +2819,11 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const u64 mR = __ballot(mine && rv_), mW = __ballot(mine && !rv_);
                 n_fwd = __popcll(mW);
                 sidx = rv_ ? n_fwd + mbcnt64(mR, 0) : mbcnt64(mW, 0);
-                if (mine) stg[sidx] = ent;
+                // (a complete record's w is the copy of the reference its window is read from, see phase 1: the first one for
+                // the few such records the general pass finds)
+                uint4 e2 = ent;
+                if (!RS && decltype(kind_tag)::value == STEP_C) e2.w = 0u;
+                if (mine) stg[sidx] = e2;
             } else {
                 if (lane < m) stg[lane] = ent;
                 if (lane < d.R - 1) stg[m + lane] = ent;    // (lanes 0 .. R-2 hold real entries: m > 0)
@@ -3182,7 +3190,33 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const u64 mFm = PK ? __ballot(isF && rev) : 0ull;
                 nFp = PK ? nF - __popcll(mFm) : 0;
                 if (mF) {
-                    if (PK) { if (isF) stg[rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0)] = ent; }
+                    if (PK) {
+                        uint4 entC = ent;
+                        if (!RS) {
+                            // MdxTabArgs::ref2 — a complete record's window is read from the copy of the reference in which it
+                            // lies in ONE 128-byte line, where there is such a one: [lo, hi] = the bytes its lanes load (a dword-
+                            // aligned triple each, the last lane's sixteen nibbles ending with the right flank); w = that copy's
+                            // byte offset
+                            entC.w = 0u;
+                            // (a tile of a coordinate-sorted batch — its first and last complete record within 64 KB of one
+                            // another — reads the first copy only: its records share their lines with their neighbours, and two
+                            // copies are twice the lines; 25 M sorted records over 3 Gb: 1.09 ms with one copy, 1.16 with both)
+                            bool scattered = false;
+                            if (a.ref2) {
+                                const u32 xa = (u32)rl((int)ent.x, __ffsll((long long)mF) - 1), xb = (u32)rl((int)ent.x, 63 - __clzll((long long)mF));
+                                scattered = (xa > xb ? xa - xb : xb - xa) >= (1u << 17);
+                            }
+                            if (scattered) {
+                                const u32 last = ent.x + (u32)nq + (u32)(2 * A) - 16u;
+                                const u32 lo = (ent.x >> 3) << 2, hi = ((last >> 3) << 2) + 11u;
+                                const bool two_a = (lo >> 7) != (hi >> 7), two_b = ((lo + 64u) >> 7) != ((hi + 64u) >> 7);
+                                // (the second copy lies 2 GiB + 64 bytes behind the first: the 2 GiB in w, the 64 bytes — 128
+                                // nibbles — in the window's offset, and out of the SEQ column's, which is relative to it)
+                                if (two_a && !two_b) { entC.w = 0x80000000u; entC.x += 128u; entC.y -= 128u; }
+                            }
+                        }
+                        if (isF) stg[rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0)] = entC;
+                    }
                     else if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
                     // the slots past the last record of a step shadow a real record (and are masked out); a run of the
                     // clean records in front (MASK) reads its own last slots from the maskable records' entries
