@@ -122,6 +122,9 @@ typedef long long i64;
 #ifndef MDX_PK_PREFETCH
 #define MDX_PK_PREFETCH 0               // the packed kernel requests a tile's phase-1 loads a tile ahead (measured: no gain; 26 registers)
 #endif
+#ifndef MDX_PK_SIP
+#define MDX_PK_SIP 1                    // the packed kernels' phase 1 makes the entries of single-indel records itself (see SIP)
+#endif
 #ifndef MDX_PK_FASTIDX
 #define MDX_PK_FASTIDX 1                // the packed kernels' complete steps: the staging entry's LDS address as add + min (a slot past its strand's
 #endif                                  // last entry reads that last entry and is masked out), the event's place from two shift-adds
@@ -2414,12 +2417,13 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 mS = __ballot(isS);
                 mSI = __ballot(isS && dnq < 0);      // insertions first, then deletions (one kind of step each)
                 isD = isS && dnq > 0;
-                if (__ballot(isS && dnq > 0)) {
+                if (!PK && __ballot(isS && dnq > 0)) {
                     MDX_PH_IN(13);
                     // A single deletion of g bases: the lanes of its entry work in column space and reach query index
                     // min(n0, L) - g - 1 at most; the read bases of the (up to g) composition positions above that,
                     // per side, are counted here (statistics.py:75-83).
-                    if (isS && dnq > 0) {
+                    // (PK, round 6: by the pass of the list that counts the entry — above_deletion in list_pass —, whoever made the entry)
+                    if (!PK && isS && dnq > 0) {
                         const int g = dnq, u = vlr & 0xFF, v = vlr >> 8, Lq = nq < L ? nq : L;
                         const int b_cmp = libid * d.w_lib + d.off_cmp() + rev * 2 * L * 4;
                         const int qa = u > L - g ? u : L - g, ia = v > L - g ? v : L - g;
@@ -2811,6 +2815,39 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const int m = avail < (u32)TL ? (int)avail : TL;
             const u32 at = (head + (u32)(lane < m ? lane : 0)) & RM;
             const uint4 ent = ring_at(ring + at);
+            if (PK && decltype(kind_tag)::value == STEP_GD) {
+                // A single deletion of g bases: the lanes of its entry work in column space and reach query index min(n0, L) - g - 1
+                // at most; the read bases of the (up to g) composition positions above that, per side, are counted here
+                // (statistics.py:75-83), from the entry alone — whoever made it, the general pass or a tile's phase 1.  At most
+                // seven bases per side, adjacent in the read: one unaligned load of sixteen nibbles each, both in flight together.
+                MDX_PH_IN(13);
+                const int g = (int)(i8)(ent.w & 0xFFu), nq_ = (int)(ent.z & 0x7FFFu), u = (int)((ent.z >> 16) & 0xFFu), v = (int)(ent.z >> 24);
+                const int Lq = nq_ < L ? nq_ : L;
+                const int qa = u > L - g ? u : L - g, ia = v > L - g ? v : L - g;
+                const bool any = lane < m && g > 0 && (qa < Lq || ia < Lq);
+                if (__ballot(any)) {
+                    if (any) {
+                        const int b_cmp = __mul24((int)((ent.w >> 24) & 0x3Fu), d.w_lib) + d.off_cmp() + (int)(ent.w >> 31) * 2 * L * 4;
+                        const u32 sq_ = ent.y + ent.x - pk_dso;
+                        const u32 fl_ = sq_ + (u32)qa, fr_ = sq_ + (u32)(nq_ - Lq);
+                        const u64 wl = *(const u64_u *)(a.seq + (fl_ >> 1)), wr = *(const u64_u *)(a.seq + (fr_ >> 1));
+                        auto nib_cls = [&](const u64 w, const u32 k) -> int {
+                            u32 nib = (u32)(w >> (4u * k)) & 15u;
+                            if (MASK) { bool mk; nib = unmask4(nib, mk); }
+                            return cls4(nib);
+                        };
+                        for (int q = qa; q < Lq; q++) {
+                            const int sc = nib_cls(wl, (fl_ & 1u) + (u32)(q - qa));
+                            if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + q * 4 + sc);
+                        }
+                        for (int i = ia; i < Lq; i++) {
+                            const int sc = nib_cls(wr, (fr_ & 1u) + (u32)(Lq - 1 - i));
+                            if (sc < 4) bump<USE_LDS>(lds, raw, b_cmp + (L + i) * 4 + sc);
+                        }
+                    }
+                }
+                MDX_PH_OUT();
+            }
             int n_fwd = -1;
             int sidx = 0;       // (PK: where this lane's entry is staged)
             if (PK) {
@@ -3052,9 +3089,29 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 }
                 // (PK: a record of the general pass that is to be rescaled says so there — see general())
                 const u32 rs_def = (RS && PK && want) ? (u32)(1 + rs_fwd) : 0u;
-                const u64 mDef = __ballot(kept && !triv);
+                // SIP (the packed kernels but the fused one, round 6): a record with ONE indel of up to seven bases between two
+                // match runs and no clip — M a, I | D g, M b: its three operations are here — is given its single-indel entry by
+                // this phase instead of the general pass (which took 260 wave-cycles per record it saw, a plain record's whole
+                // cost): the conditions are the general pass's for such an entry (complete flanks, the window loads inside the
+                // SEQ column with the sixteen nibbles of slack of a gapped step, a CIGAR that agrees with SEQ), the entry is the
+                // one it would have made, and anything it would have refused or reported is left to it.
+                constexpr bool SIP = PK && !RS && MDX_PK_SIP;
+                bool sone = false, s_del = false;
+                u32 s_nq = 0u, s_n0 = 0u, s_vlr = 0u;
+                // (a tile without such a record — any tile of ungapped data — skips all of it)
+                if (SIP && __ballot(cand && cn == 3u && ((6u >> (g1 & 0xFu)) & 1u) != 0u)) {
+                    const u32 op1 = g1 & 0xFu, s_a = g0 >> 4, s_g = g1 >> 4, s_b = g2 >> 4;
+                    const bool m2 = ((0x181u >> (g2 & 0xFu)) & 1u) != 0;
+                    s_del = op1 == 2u;
+                    s_nq = s_a + s_b + (s_del ? 0u : s_g); s_n0 = s_a + s_b + (s_del ? s_g : 0u);
+                    s_vlr = (s_a < (u32)L ? s_a : (u32)L) | ((s_b < (u32)L ? s_b : (u32)L) << 8);
+                    sone = cand && cn == 3u && m0 && m2 && (op1 == 1u || op1 == 2u) && s_g - 1u < 7u && s_a - 1u < 32767u && s_b - 1u < 32767u &&
+                           s_nq == lseq && s_nq < 32768u && c_pos >= A && (u32)c_pos + s_n0 + (u32)A <= clen &&
+                           c_so0 >= pad8 + 16u && s_nq + pad8 + 16u <= nb32 && c_so0 <= nb32 - s_nq - pad8 - 16u;
+                }
+                const u64 mDef = __ballot(kept && !triv && !sone);
                 if (mDef) {
-                    if (kept && !triv) {
+                    if (kept && !triv && !sone) {
                         // the record's index and the columns just read (36 bytes): the general pass does not gather them again
                         const int at = nDef + mbcnt64(mDef, 0);
                         uint4 c0_, c1_;
@@ -3122,8 +3179,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 int lkey = -1;
                 {
                     const u32 paired = fl & 1u;
-                    const bool counts = triv && (!paired || (fl & 0x42u) == 0x42u);
-                    const u32 flen = paired ? (c_tlen < 0 ? 0u - (u32)c_tlen : (u32)c_tlen) : len;
+                    const bool counts = (triv || sone) && (!paired || (fl & 0x42u) == 0x42u);
+                    const u32 flen = paired ? (c_tlen < 0 ? 0u - (u32)c_tlen : (u32)c_tlen) : (sone ? s_n0 : len);
                     const int krow = (paired ? 0 : 2) + rev;                 // kind * 2 + strand
                     if (counts && flen < (u32)d.lgd_lds) lkey = lbase + d.off_lgd() + __mul24(krow, d.lgd_lds) + (int)flen;
                     if (__ballot(counts && flen >= (u32)d.lgd_lds)) {          // (a tile in five at the survey's insert sizes)
@@ -3163,6 +3220,24 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 }
                 const u64 mT = __ballot(triv);
                 n_kept_lite += (u32)__popcll(mT);        // (added to the table once, behind the loop)
+                if (SIP) {
+                    const u64 mS1 = __ballot(sone);
+                    if (mS1) {
+                        n_kept_lite += (u32)__popcll(mS1);
+                        // (the general pass's entry of such a record: see its gpre / isS)
+                        uint4 es;
+                        es.x = c0 + (u32)c_pos - (u32)A + 256u;
+                        es.y = c_so0 - es.x + pk_dso;
+                        es.z = s_nq | 0x8000u | (s_vlr << 16);
+                        const u32 dnq = s_n0 - s_nq;
+                        es.w = ((u32)(lbase + d.off_tc() + rev * 4 * 512) << 2) | ((u32)libid << 24) | (MASK ? 0x40000000u : 0u) | ((u32)rev << 31) |
+                               (dnq & 0xFFu) | (((dnq >> 8) & 7u) << 21) | PK_ONE;
+                        const u64 mD1 = __ballot(sone && s_del), mI1 = mS1 & ~mD1;
+                        if (sone && !s_del) pfl_store_b128(ringI, ((lI + (u32)mbcnt64(mI1, 0)) & RM) * 16u, u32x4{es.x, es.y, es.z, es.w});
+                        if (sone && s_del) pfl_store_b128(ringD, ((lD + (u32)mbcnt64(mD1, 0)) & RM) * 16u, u32x4{es.x, es.y, es.z, es.w});
+                        lI += (u32)__popcll(mI1); lD += (u32)__popcll(mD1);
+                    }
+                }
                 // staging entry (as in the general pass)
                 uint4 ent;
                 ent.x = c0 + (u32)c_pos - (u32)A + 256u;
@@ -3373,6 +3448,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             const u32 need = (!ROUNDS || cur == 0xFFFFFFFFu) ? 1u : (u32)TL;
             if (lC - hC >= need || lP - hP >= need || lI - hI >= need || lD - hD >= need) {
                 // the entries this wavefront appended (its own stores: complete before they are read back)
+                if (pfl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (phase 1's single-indel entries: stores the compiler does not count)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 MDX_PH(7);
