@@ -154,6 +154,9 @@ typedef long long i64;
 #ifndef MDX_PD_P_ML
 #define MDX_PD_P_ML 2                   // ... their runs of partial entries (three: 4 registers spilled; two: none)
 #endif
+#ifndef MDX_PD_G_M
+#define MDX_PD_G_M 2                    // ... of the masked one-library kernel and the fused one (their registers)
+#endif
 #ifndef MDX_PD_G_ML
 #define MDX_PD_G_ML 1                   // ... and of single-indel entries
 #endif
@@ -1843,7 +1846,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (ML without MASK: the depths of the one-library kernel since round 6 — its arguments come by scalar loads and
                 // it has that kernel's registers; ML with MASK — rounds and a second set of planes — keeps depths of its own)
                 constexpr bool MLM = ML && MASK;
-                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? (MLM ? MDX_PD_G_ML : MDX_PD_G) : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : (MLM ? MDX_PD_P_ML : MDX_PD_P)) : (MASK ? (ML ? MDX_PKM_PD_ML : MDX_PKM_PD) : (ML ? MDX_PK_PD_ML : MDX_PK_PD)));
+                constexpr int PD4 = (KIND == STEP_GI || KIND == STEP_GD) ? (MLM ? MDX_PD_G_ML : ((MASK || RS) ? MDX_PD_G_M : MDX_PD_G)) : (KIND == STEP_P ? (HS ? MDX_PK_PD_P : (MLM ? MDX_PD_P_ML : MDX_PD_P)) : (MASK ? (ML ? MDX_PKM_PD_ML : MDX_PKM_PD) : (ML ? MDX_PK_PD_ML : MDX_PK_PD)));
                 static_assert(PD4 >= 1 && PD4 <= 8, "steps in flight");
                 St16 st[PD4];
                 // a group of PD4 steps: their words through carry-save adders into the planes (bs_add_group: four at a time),
