@@ -19,11 +19,13 @@ ref = synth.make_genome()
 b = synth.parallel_batch(dict(dict(read_len=100, paired=True, contigs=[0, 1]), **kw), ref, n, 3, workers=64)
 with engine.DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
     eng.set_reference(ref)
-    db = eng.upload(b)
+    db = eng.upload(b, packed=True)
     for _ in range(3):
         eng.tabulate(db)
     eng.sync()
-    nw = 512 * 12
+    # (round 6: the packed kernels run as 256 blocks of 16 wavefronts; NB / WPB in the environment for other launches)
+    NB, WPB = int(os.environ.get("NB", 256)), int(os.environ.get("WPB", 16))
+    nw = NB * WPB
     out = np.zeros(nw * 3, np.uint64)
     lib = engine._lib
     rc = lib.mdx_dbg_clk_read(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(nw))
@@ -33,10 +35,10 @@ with engine.DamageEngine([("s", "l")], 70, 10, 0, lgd_max=4096) as eng:
     print("rc", rc, "waves", nw)
     for name, v in (("start", s), ("end of tile loop", m), ("end", e), ("tile loop duration", m - s), ("lists duration", e - m), ("total duration", e - s)):
         print("%-20s min %8.1f  p50 %8.1f  p90 %8.1f  p99 %8.1f  max %8.1f  mean %8.1f us" % (name, v.min(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(), v.mean()))
-    eb = e.reshape(512, 12).max(axis=1)
+    eb = e.reshape(NB, WPB).max(axis=1)
     print("block end           min %8.1f  p50 %8.1f  max %8.1f" % (eb.min(), np.percentile(eb, 50), eb.max()))
     db.free()
-    d = (e - s).reshape(512, 12)
+    d = (e - s).reshape(NB, WPB)
     bm = d.mean(axis=1)
     print("by XCD (block % 8):", " ".join("%.0f" % bm[x::8].mean() for x in range(8)))
     print("by XCD spread (std of block means within XCD):", " ".join("%.0f" % bm[x::8].std() for x in range(8)))
