@@ -122,6 +122,9 @@ typedef long long i64;
 #ifndef MDX_PK_PREFETCH
 #define MDX_PK_PREFETCH 0               // the packed kernel requests a tile's phase-1 loads a tile ahead (measured: no gain; 26 registers)
 #endif
+#ifndef MDX_PK_FASTP
+#define MDX_PK_FASTP 1                  // the partial steps of the plain packed kernels: see FIDP
+#endif
 #ifndef MDX_PK_SIP
 #define MDX_PK_SIP 1                    // the packed kernels' phase 1 makes the entries of single-indel records itself (see SIP)
 #endif
@@ -1526,7 +1529,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // A run = the steps of the nrec staged records from entry e0 on, all of one kind (count())
         // (n_plus >= 0 — PK, complete runs of the tile loop: the entries are sorted by strand, the first n_plus of them forward)
         auto run = [&](const int e0, const int nrec, auto kind_tag, auto qm_tag, const int n_plus = -1) {
-            constexpr int KIND = decltype(kind_tag)::value;
+            // (kind | 8: the partial records of a tile — ungapped: no n0 - nq in their entries)
+            constexpr int KIND = decltype(kind_tag)::value & 7;
+            constexpr bool TILE_P = (decltype(kind_tag)::value & 8) != 0;
             constexpr bool QM = MASK && decltype(qm_tag)::value;
             const int nsteps = (nrec + R - 1) / R;
             int kf = 0;
@@ -1546,13 +1551,19 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // A slot past its strand's last entry reads that entry, or the run's first when the strand has none, and is
                 // masked out by the step (actm))
                 constexpr bool FIDX = MDX_PK_FASTIDX && KIND == STEP_C && !RS;
+                // (FIDP — the partial steps of the kernels with the registers for it: the same addressing, the slot's being
+                // past its strand's last entry from one compare of the address; and the lane's nibble mask, a table lookup by a
+                // value of the entry, requested by the fill — four steps ahead of the step that wants it — instead of by the step,
+                // which waited for it)
+                constexpr bool FIDP = MDX_PK_FASTIDX && MDX_PK_FASTP && KIND == STEP_P && !RS && !MASK;
                 const u32 stg_a = (u32)(size_t)(lds_u4 *)stg;
                 const int last_l = e0 + (p_strand ? nP_ : 0) + (p_strand ? nM_ : nP_) - 1;
                 const u32 ent_a0 = stg_a + 16u * (u32)base_l, ent_cap = stg_a + 16u * (u32)(last_l > e0 ? last_l : e0);
                 const int H16 = 16 * H;
+                const u32 ent_capr = stg_a + 16u * (u32)last_l;        // (unclamped: below the lane's first address when its strand has no entry)
                 // (one <3 x i32> load per operand: a struct of three words is taken apart and put together again as the
                 // vectorizer likes — two overlapping dwordx2 loads at times)
-                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; };
+                struct St16 { u32v3 s, r; u32 sa, ra, pk, aux, aux2; int k; bool valid; u64 mk; };
                 // (MDX_PK_ENT_AHEAD: the staging entry of a step is read from the LDS one fill ahead — LDS operations return in
                 // order, so a fill that reads its own entry waits, in front of its window loads, for that read and for the
                 // event writes of the step just counted)
@@ -1576,13 +1587,19 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     bool act = true;
                     int idx = 0;
                     u32 ref_copy = 0u;
-                    if (!FIDX || MDX_PK_ENT_AHEAD) idx = ent_index(kf, act);
+                    if (!(FIDX || FIDP) || MDX_PK_ENT_AHEAD) idx = ent_index(kf, act);
                     kf++;
                     st.k = k;
 #if MDX_PK_ENT_AHEAD
                     const uint4 ent = ent_next;
 #else
                     uint4 ent;
+                    if constexpr (FIDP) {
+                        const u32 ad = ent_a0 + (u32)(H16 * k);
+                        act = ad <= ent_capr;
+                        const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
+                        ent = make_uint4(e_.x, e_.y, e_.z, e_.w);
+                    } else
                     if constexpr (FIDX) {
                         const u32 ad = ent_a0 + (u32)(H16 * k);
                         const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
@@ -1607,8 +1624,10 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         st.aux = fz ? (((u32)t << 3) | ((u32)idx << 21) | (1u << 28)) : (c_side ? 128u : 0u);
                     }
                     if (KIND != STEP_C) {
+                        if (!TILE_P) {
                         const int dd11 = (int)(((ent.w >> 13) & 0x700u) | (ent.w & 0xFFu));
                         ro += c_cm != 0u ? (u32)((dd11 << 21) >> 21) : 0u;
+                        }
                         const u32 z = ent.z;
                         const int nq_ = (int)(z & 0x7FFFu);
                         const int t8 = (int)((z >> (16 + 8 * c_side)) & 0xFFu);      // task nibbles / run length of this side
@@ -1619,6 +1638,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             // the lane's tasks: its nibbles [0, t8 - m16) on the left side, [16 - (t8 - m16), 16) on the right
                             const int dm = t8 - c_m8;
                             st.aux = act ? c16(c_side ? 16 - dm : dm) : (c_side ? 128u : 0u);
+                            if constexpr (FIDP) st.mk = *(const u64 *)((const u8 *)ltab + (st.aux & 0xFFu));
                             if (RS) {
                                 // (a fused partial record, see the complete ones above: a record shorter than --length has all its
                                 // columns in its left window; [15:8] the offset of the nibble-mask table's entry, [27:21], bit 28)
@@ -1706,7 +1726,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         const u64 vm64 = (u64)c_vm_lo | ((u64)c_vm_hi << 32);
                         u64 s64 = (u64)s_lo | ((u64)s_hi << 32), r64 = (u64)r_lo | ((u64)r_hi << 32), X64;
                         if (KIND == STEP_P) {
-                            const u64 Mk = *(const u64 *)((const u8 *)ltab + (aux & 0xFFu));
+                            u64 Mk;
+                            if constexpr (FIDP) Mk = st.mk; else Mk = *(const u64 *)((const u8 *)ltab + (aux & 0xFFu));
                             const u64 dyn = (Mk ^ sm) & vm64;
                             s64 &= dyn; r64 &= dyn;
                             X64 = r64;
@@ -3352,7 +3373,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     MDX_PH(2);
                     if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp);
                     MDX_PH(3);
-                    if (PTILE && nPt) run(nF, nPt, std::integral_constant<int, STEP_P>{}, std::true_type{}, nPtp);
+                    if (PTILE && nPt) run(nF, nPt, std::integral_constant<int, STEP_P | (RS ? 0 : 8)>{}, std::true_type{}, nPtp);
                     if (pfl && pfl_due != 0xFFFFFFFEu) {
                         MDX_PH(15);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
