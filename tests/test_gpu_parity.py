@@ -657,6 +657,43 @@ def test_hip_long_reads_and_long_cigars(L, A, mid_genome):
     assert_tables_equal(got, want)
 
 
+@pytest.mark.parametrize("L,A", [(70, 10), (25, 4)])
+def test_hip_single_indel_entries_of_phase_1_at_their_limits(L, A, mid_genome):
+    """Records `M a, I|D g, M b` around the conditions under which the tile loop's phase 1 makes their single-indel entry itself
+    (csrc/mdx_kernels.hip: SIP) instead of leaving them to the general pass: gaps of 7 and 8 bases, runs of one base, `=` / `X`
+    as the match operations, flanks complete by one base and short by one at both ends of a contig, the first and the last
+    records of the batch (the window loads' slack in the SEQ column), between plain records of both strands."""
+    lens = [len(s) for s in mid_genome.seqs]
+    specs = []
+    for g in (1, 2, 7, 8):
+        for a, b in ((1, 60), (60, 1), (1, 1), (5, 69), (69, 5), (70, 70), (71, 30), (30, 71), (120, 3)):
+            for op in (1, 2):
+                for flag in (0, 16):
+                    for m_op in (0, 7, 8):
+                        pos = 5000 + 37 * len(specs)
+                        specs.append((0, pos, flag, [(m_op, a), (op, g), (m_op if m_op != 8 else 0, b)]))
+    # flanks: complete by exactly A, short by one; at the contig's end the same
+    for op in (1, 2):
+        n0 = lambda a_, g_, b_: a_ + b_ + (g_ if op == 2 else 0)
+        for tid in (0, 1):
+            specs += [(tid, A, 0, [(0, 40), (op, 3), (0, 40)]), (tid, max(A - 1, 0), 16, [(0, 40), (op, 3), (0, 40)]),
+                      (tid, lens[tid] - A - n0(40, 3, 40), 0, [(0, 40), (op, 3), (0, 40)]),
+                      (tid, lens[tid] - A - n0(40, 3, 40) + 1, 16, [(0, 40), (op, 3), (0, 40)])]
+    rng = np.random.default_rng(9)
+    plain = [(int(rng.integers(0, 2)), int(rng.integers(300, 90000)), int(rng.choice([0, 16])), [(0, int(rng.integers(20, 150)))])
+             for _ in range(400)]
+    order = rng.permutation(len(specs) + len(plain))
+    mixed = [(specs + plain)[i] for i in order]
+    # (a single-indel record first and last in the batch: no slack in front of / behind its SEQ)
+    mixed = [(0, 700, 0, [(0, 30), (1, 2), (0, 30)])] + mixed + [(1, 900, 16, [(0, 30), (2, 2), (0, 30)])]
+    batch = batch_from_records(_cigar_records(mid_genome, mixed, 123))
+    libs = [("s", "l")]
+    want = oracle_tableset(mid_genome, batch, libs, L, A, 0)
+    for resident in (True, False):
+        got = run_engine(mid_genome, batch, libs, L, A, 0, resident=resident)
+        assert_tables_equal(got, want)
+
+
 @pytest.mark.parametrize("L,A", [(70, 10), (8, 3), (150, 30), (100, 12)])
 def test_hip_single_indel_shapes_with_min_basequal(L, A, mid_genome):
     """The same shapes under --min-basequal 20: masked columns in the near and far entries, inserted columns that are
