@@ -22,6 +22,13 @@
 //     tables;
 //   * at block end the LDS image is stored to a per-block slot and a second kernel sums the
 //     slots into the u64 accumulators (no global atomics on the hot path).
+//   * tabulate_kernel<.., PK> — the packed kernels, what the benchmark and the command line run: the SEQ column and the
+//     reference as 4-bit one-hot codes, sixteen bases per lane, plain matches in bit-sliced register counters (see the
+//     template's comments).  Round 6: ONE block of 1024 threads per CU (MdxPkConfig); the phase-1 columns and the second
+//     round trip of a wavefront's NEXT tile prefetched into an area of the LDS by LDS-DMA loads (pfl_*: asm statements the
+//     compiler does not count — and what follows from that for the waits); kernel arguments through the constant address
+//     space (karg_p); phase 1 makes the entries of single-indel records itself (SIP); a large genome's reference twice, half
+//     a 128-byte line out of phase (MdxTabArgs::ref2);
 //   * tabulate_kernel<.., RS> is the same kernel with the quality rescaling of mapdamage/rescale.py fused in for the
 //     records of its own tile loop (mdx_tabulate_rescale_device, BASELINE configs[4]): routing and the quality copy in
 //     phase 1, the rescaled columns — they are mismatches, hence events — through drain_all, one 1024-thread block per
