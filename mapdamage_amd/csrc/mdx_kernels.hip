@@ -126,9 +126,6 @@ typedef long long i64;
 #ifndef MDX_QPREFETCH
 #define MDX_QPREFETCH 1                 // MASK: the quality windows requested with the other two, PIPE_DEPTH steps ahead
 #endif
-#ifndef MDX_PK_PREFETCH
-#define MDX_PK_PREFETCH 0               // the packed kernel requests a tile's phase-1 loads a tile ahead (measured: no gain; 26 registers)
-#endif
 #ifndef MDX_PK_FASTP
 #define MDX_PK_FASTP 1                  // the partial steps of the plain packed kernels: see FIDP
 #endif
@@ -2791,50 +2788,14 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         // a tile ahead — and asks for the one after; the others ask for the next one: a wavefront that finds its pool
         // empty has one tile less left to do)
         u32 cur = tile_of(grab());
-        constexpr bool PF = PK && !ML && !RS && !MASK && MDX_PK_PREFETCH;     // (the prefetched columns know no libraries)
-        u32 nxt = (RS || PF || pfl) && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
-        // PK: the loads of a tile's phase 1 — its nine column values, then the operations and contig bounds they lead to —
-        // are requested a tile ahead, the first round trip in front of the current tile's phase 1 and the second in front of
-        // its run: with sixteen-base lanes the units have the slack, and what bounds a wavefront is the chain of round trips
-        // per tile (phase 1 alone was half of the kernel's time)
-        struct Cols { u32 fl; int lib, tid, pos, tlen; u32 co0, co1, so0, so1; };
-        struct Rt2 { u32 g0, g1, g2, c0, clen; };
-        auto p_cols = [&](const u32 tile) -> Cols {
-            const u32 tb = tile * T, rh = tb + T < n_rec ? tb + T : n_rec;
-            const u32 ri_ = tb + lane;
-            const bool v_ = ri_ < rh;
-            const u32 rj_ = v_ ? ri_ : tb;
-            Cols c;
-            c.fl = v_ ? (u32)ld32(a.flag, rj_) : 0x4u;
-            c.lib = ld32(a.lib, rj_); c.tid = ld32(a.tid, rj_); c.pos = ld32(a.pos, rj_); c.tlen = ld32(a.tlen, rj_);
-            c.co0 = ld32(a.cigar_off, rj_); c.co1 = ld32(a.cigar_off, rj_ + 1); c.so0 = ld32(a.seq_off, rj_); c.so1 = ld32(a.seq_off, rj_ + 1);
-            return c;
-        };
-        auto p_rt2 = [&](const Cols &c) -> Rt2 {
-            bool kept_ = (c.fl & 0xF04u) == 0;
-            if (c.lib < a.nlib_total && (c.lib < a.lib_lo || c.lib >= a.lib_lo + d.nlib)) kept_ = false;
-            const u32 cn_ = c.co1 - c.co0;
-            const bool cand_ = kept_ && cn_ - 1u < 3u && c.tid >= 0 && c.tid < a.n_contig && c.lib < a.nlib_total;
-            Rt2 g;
-            g.g0 = g.g1 = g.g2 = 0xFu; g.c0 = 0u; g.clen = 0u;
-            if (cand_) {
-                g.g0 = a.cigar[c.co0];
-                if (cn_ >= 2u) g.g1 = a.cigar[c.co0 + 1];
-                if (cn_ >= 3u) g.g2 = a.cigar[c.co0 + 2];
-                g.c0 = (u32)a.contig_off[c.tid];
-                g.clen = (u32)a.contig_off[c.tid + 1] - g.c0;
-            }
-            return g;
-        };
-        Cols Cc = {}, Cn = {};
-        Rt2 Gc = {}, Gn = {};
+        u32 nxt = (RS || pfl) && cur != 0xFFFFFFFFu ? tile_of(grab()) : 0xFFFFFFFFu;
+        // (pfl: the first tile's columns and second round trip, one after the other — every later tile's come under the tile
+        // in front of it.  Rounds 4-6 had the same prefetch into registers behind MDX_PK_PREFETCH: 26 of them, spilled — DESIGN 4)
         if (pfl && cur != 0xFFFFFFFFu) {
             pfl_cols(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pfl_rt2(cur);
         }
-        constexpr bool PF2 = PF && MDX_PK_PREFETCH == 1;        // (2: the columns only — the second round trip stays in phase 1)
-        if (PF && cur != 0xFFFFFFFFu) { Cc = p_cols(cur); if (PF2) Gc = p_rt2(Cc); }
         if (RS && cur != 0xFFFFFFFFu) {
             const u32 tb0 = cur * T, rh0 = tb0 + T < n_rec ? tb0 + T : n_rec;
             nb0 = ld32(a.seq_off, tb0); nb1 = ld32(a.seq_off, rh0);
@@ -2947,9 +2908,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     MDX_PH(1);
                 }
-                if (!(RS || PF || pfl) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
+                if (!(RS || pfl) || nxt != 0xFFFFFFFFu) nxt2_raw = grab();
                 if (pfl && nxt != 0xFFFFFFFFu) pfl_cols(nxt);
-                if (PF && nxt != 0xFFFFFFFFu) Cn = p_cols(nxt);
                 karg_p kp = ka;
                 asm volatile("" : "+s"(kp));
                 const __attribute__((address_space(4))) MdxTabArgs &p = *kp;
@@ -2996,10 +2956,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 u32 fl;
                 int c_lib, c_tid, c_pos, c_tlen;
                 u32 c_co0, c_co1, c_so0, c_so1;
-                if (PF) {
-                    fl = Cc.fl; c_lib = Cc.lib; c_tid = Cc.tid; c_pos = Cc.pos; c_tlen = Cc.tlen;
-                    c_co0 = Cc.co0; c_co1 = Cc.co1; c_so0 = Cc.so0; c_so1 = Cc.so1;
-                } else if (pfl) {
+                if (pfl) {
                     fl = valid ? P_fl : 0x4u;
                     c_lib = ML ? a.lib_lo + ml_lib : (int)P_lib; c_tid = (int)P_tid; c_pos = (int)P_pos; c_tlen = (int)P_tlen;
                     c_co0 = P_co0; c_co1 = P_co1; c_so0 = P_so0; c_so1 = P_so1;
@@ -3064,8 +3021,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // (32-bit reference coordinates: the fast path runs on references shorter than 4 GiB, MdxTabArgs::ref32)
                 u32 c0 = 0, clen = 0;
                 u32 q0 = 0xFFu;
-                if (PF2) { g0 = Gc.g0; g1 = Gc.g1; g2 = Gc.g2; c0 = Gc.c0; clen = Gc.clen; }
-                else if (pfl) {
+                if (pfl) {
                     // (the lanes that asked: pfl_rt2 made the same test on the same columns)
                     if (cand) { g0 = P_g0; c0 = P_c0; clen = P_c1 - P_c0; }
                     if (cand && cn >= 2u) g1 = P_g1;
@@ -3375,7 +3331,6 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 if (pfl) pfl_due = nxt;
                 else
                 __builtin_amdgcn_s_waitcnt(0x0F70);
-                if (PF2 && nxt != 0xFFFFFFFFu) Gn = p_rt2(Cn);
                 if (PK) {
                     MDX_PH(2);
                     if (nF) run(0, nF, std::integral_constant<int, STEP_C>{}, std::true_type{}, nFp);
@@ -3466,9 +3421,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
             }
             if (over ? dDone >= nDef : past) break;
             if (!past) {
-                if (RS || PF || pfl) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
+                if (RS || pfl) { cur = nxt; nxt = nxt != 0xFFFFFFFFu ? tile_of(nxt2_raw) : 0xFFFFFFFFu; }
                 else cur = tile_of(nxt2_raw);
-                if (PF) { Cc = Cn; if (PF2) Gc = Gn; }
             }
         }
         // ---------------------------------------------------- the lists, at the end of a round: whole passes (63 entries:
