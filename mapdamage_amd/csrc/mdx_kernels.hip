@@ -1603,6 +1603,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                         act = ad <= ent_capr;
                         const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
                         ent = make_uint4(e_.x, e_.y, e_.z, e_.w);
+                        // (a tile's own partial entry: bit 31 of w = the copy of the reference, bits 1 and 0 are zero — the
+                        // lane's byte offset takes all three through the bit-field insert that was an and)
+                        if (TILE_P) ref_copy = e_.w & 0x80000003u;
                     } else
                     if constexpr (FIDX) {
                         const u32 ad = ent_a0 + (u32)(H16 * k);
@@ -3251,32 +3254,33 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 // holds the border count into one set of planes
                 const u64 mFm = PK ? __ballot(isF && rev) : 0ull;
                 nFp = PK ? nF - __popcll(mFm) : 0;
+                // MdxTabArgs::ref2 — a record's windows are read from the copy of the reference in which they lie in ONE 128-byte
+                // line, where there is such a one: [lo, hi] = the bytes its lanes load (a dword-aligned triple each: the left
+                // side's lanes from the window's first nibble on, the right side's up to the right flank's last).  The second
+                // copy lies 2 GiB + 64 bytes behind the first: the 64 bytes — 128 nibbles — go into the window's offset (and out
+                // of the SEQ column's, which is relative to it), the 2 GiB into bit 31 of the entry's word w, which the fill
+                // of a complete step, and of a tile's own partial step, or's to the lane's byte offset (for both the bit is
+                // free: the strand of such an entry is its place in the staging area).
+                // (a tile of a coordinate-sorted batch — its first and last record within 64 KB of one another — reads the
+                // first copy only: its records share their lines with their neighbours, and two copies are twice the lines;
+                // 25 M sorted records over 3 Gb: 1.09 ms with one copy, 1.16 with both)
+                constexpr bool REF2P = PK && !RS && !MASK && MDX_PK_FASTIDX && MDX_PK_FASTP;     // (... the partial steps that look at w: FIDP)
+                bool copy_b = false;
+                if (PK && !RS && a.ref2 && mT) {
+                    const u32 xa = (u32)rl((int)ent.x, __ffsll((long long)mT) - 1), xb = (u32)rl((int)ent.x, 63 - __clzll((long long)mT));
+                    if ((xa > xb ? xa - xb : xb - xa) >= (1u << 17)) {
+                        const u32 Wn = (u32)(16 * d.nl16), span = (u32)nq + (u32)(2 * A);
+                        const u32 first = span < Wn ? ent.x + span - Wn : ent.x, last = (span < Wn ? ent.x + Wn : ent.x + span) - 16u;
+                        const u32 lo = (first >> 3) << 2, hi = ((last >> 3) << 2) + 11u;
+                        const bool two_a = (lo >> 7) != (hi >> 7), two_b = ((lo + 64u) >> 7) != ((hi + 64u) >> 7);
+                        copy_b = triv && (isF || REF2P) && two_a && !two_b;
+                        if (copy_b) { ent.x += 128u; ent.y -= 128u; }
+                    }
+                }
                 if (mF) {
                     if (PK) {
                         uint4 entC = ent;
-                        if (!RS) {
-                            // MdxTabArgs::ref2 — a complete record's window is read from the copy of the reference in which it
-                            // lies in ONE 128-byte line, where there is such a one: [lo, hi] = the bytes its lanes load (a dword-
-                            // aligned triple each, the last lane's sixteen nibbles ending with the right flank); w = that copy's
-                            // byte offset
-                            entC.w = 0u;
-                            // (a tile of a coordinate-sorted batch — its first and last complete record within 64 KB of one
-                            // another — reads the first copy only: its records share their lines with their neighbours, and two
-                            // copies are twice the lines; 25 M sorted records over 3 Gb: 1.09 ms with one copy, 1.16 with both)
-                            bool scattered = false;
-                            if (a.ref2) {
-                                const u32 xa = (u32)rl((int)ent.x, __ffsll((long long)mF) - 1), xb = (u32)rl((int)ent.x, 63 - __clzll((long long)mF));
-                                scattered = (xa > xb ? xa - xb : xb - xa) >= (1u << 17);
-                            }
-                            if (scattered) {
-                                const u32 last = ent.x + (u32)nq + (u32)(2 * A) - 16u;
-                                const u32 lo = (ent.x >> 3) << 2, hi = ((last >> 3) << 2) + 11u;
-                                const bool two_a = (lo >> 7) != (hi >> 7), two_b = ((lo + 64u) >> 7) != ((hi + 64u) >> 7);
-                                // (the second copy lies 2 GiB + 64 bytes behind the first: the 2 GiB in w, the 64 bytes — 128
-                                // nibbles — in the window's offset, and out of the SEQ column's, which is relative to it)
-                                if (two_a && !two_b) { entC.w = 0x80000000u; entC.x += 128u; entC.y -= 128u; }
-                            }
-                        }
+                        if (!RS) entC.w = copy_b ? 0x80000000u : 0u;
                         if (isF) stg[rev ? nFp + mbcnt64(mFm, 0) : mbcnt64(mF & ~mFm, 0)] = entC;
                     }
                     else if (isF) stg[MASK ? ((ent.w & 0x40000000u) ? nF0 + mbcnt64(mF & ~mF0, 0) : mbcnt64(mF0, 0)) : mbcnt64(mF, 0)] = ent;
@@ -3298,7 +3302,9 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                 const u64 mPm = PTILE ? __ballot(triv && !isF && rev) : 0ull;
                 if (PTILE && mP) {
                     nPt = __popcll(mP); nPtp = nPt - __popcll(mPm);
-                    if (triv && !isF) stg[nF + (rev ? nPtp + mbcnt64(mPm, 0) : mbcnt64(mP & ~mPm, 0))] = ent;
+                    uint4 entP = ent;
+                    if (REF2P) entP.w = (ent.w & 0x7FFFFFFFu) | (copy_b ? 0x80000000u : 0u);
+                    if (triv && !isF) stg[nF + (rev ? nPtp + mbcnt64(mPm, 0) : mbcnt64(mP & ~mPm, 0))] = entP;
                 }
                 if (!PTILE && mP) {
                     // short records and contig edges: tasks [-flank, min(nq, L)) per side (the list of partial records; DMP)
