@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
         karg_p kp = ka;
         asm volatile("" : "+s"(kp));
         const u32 tb = tile * T, rh = tb + T < n_rec ? tb + T : n_rec;
-        const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
+        const lds_u1 *const C = (const lds_u1 *)(size_t)(pfl_a + 4u * (u32)lane);
         const u32 fl_ = tb + (u32)lane < rh ? C[0] : 0x4u;
         const int lib_ = ML ? a.lib_lo + ml_lib : (int)C[64], tid_ = (int)C[128];
         const u32 co0_ = C[320], co1_ = C[321];
@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     if constexpr (FIDP) {
                         const u32 ad = ent_a0 + (u32)(H16 * k);
                         act = ad <= ent_capr;
-                        const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
+                        const u32x4 e_ = *(const lds_u4 *)(size_t)(ad < ent_cap ? ad : ent_cap);
                         ent = make_uint4(e_.x, e_.y, e_.z, e_.w);
                         // (a tile's own partial entry: bit 31 of w = the copy of the reference, bits 1 and 0 are zero — the
                         // lane's byte offset takes all three through the bit-field insert that was an and)
@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     } else
                     if constexpr (FIDX) {
                         const u32 ad = ent_a0 + (u32)(H16 * k);
-                        const u32x4 e_ = *(const lds_u4 *)(ad < ent_cap ? ad : ent_cap);
+                        const u32x4 e_ = *(const lds_u4 *)(size_t)(ad < ent_cap ? ad : ent_cap);
                         ent = make_uint4(e_.x, e_.y, e_.z, e_.w);
                         // (w of a complete record's entry: the byte offset of the copy of the reference its window is read from —
                         // 0, or 2 GiB: MdxTabArgs::ref2)
@@ -1811,8 +1811,8 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                             // (kept apart: the sum of slot and fill would be a vector add)
                             const u32 qa_s = (u32)__builtin_amdgcn_readfirstlane((int)(qQ_a + 16u * (u32)qcount)),
                                       ea_s = (u32)__builtin_amdgcn_readfirstlane((int)(qE_a + 4u * (u32)qcount));
-                            *(lds_u4 *)((slot << 4) + qa_s) = u32x4{s_lo, s_hi, r_lo, r_hi};
-                            *(lds_u1 *)((slot << 2) + ea_s) = evw;
+                            *(lds_u4 *)(size_t)((slot << 4) + qa_s) = u32x4{s_lo, s_hi, r_lo, r_hi};
+                            *(lds_u1 *)(size_t)((slot << 2) + ea_s) = evw;
 #else
                             const int slot = mbcnt64(mm, qcount);
                             qQ[slot] = make_uint4(s_lo, s_hi, r_lo, r_hi);
@@ -2903,7 +2903,7 @@ __global__ __launch_bounds__(RS ? MDX_FUSE_BLOCK : (PK ? MDX_PK_BLOCK : MDX_BLOC
                     // (... said again for the compiler, which does not read asm statements: nothing is on its way from here, and
                     // the runs of this tile count their waits)
                     __builtin_amdgcn_s_waitcnt(0x0F70);
-                    const lds_u1 *const C = (const lds_u1 *)(pfl_a + 4u * (u32)lane);
+                    const lds_u1 *const C = (const lds_u1 *)(size_t)(pfl_a + 4u * (u32)lane);
                     P_fl = C[0]; if (!ML) P_lib = C[64];
                     P_tid = C[128]; P_pos = C[192]; P_tlen = C[256]; P_co0 = C[320]; P_co1 = C[321]; P_so0 = C[384]; P_so1 = C[385];
                     P_g0 = C[448]; P_g1 = C[512]; P_g2 = C[576]; P_c0 = C[640]; P_c1 = C[704];
