@@ -212,8 +212,12 @@ size_t mdx_k_lds_bytes(const MdxDims &d) { return (size_t)mdx_k_queue_off(d) * 4
 // The fused tabulate + rescale kernel (tabulate_kernel<.., RS>): one block of 1024 threads per CU — 16 wavefronts with
 // 128 registers each instead of 24 with 80 (measured with the plain kernel: +3 % on config 3) — because its image does
 // not fit twice: behind the plain image [second TC table, 256-byte aligned][4 words][lookup table][terms]
+#ifndef MDX_FUSE_BLOCK
 #define MDX_FUSE_BLOCK 1024
+#endif
+#ifndef MDX_FUSE_WPS
 #define MDX_FUSE_WPS 4
+#endif
 #ifndef MDX_FUSE_CPU
 #define MDX_FUSE_CPU 2                  // 16-byte units per lane of the first pass of a tile's quality copy (measured: 2 3.64 ms, 4 3.74, 7 4.18 — the registers)
 #endif
